@@ -1,0 +1,291 @@
+"""ctypes binding of the C ABI declared in ``include/pcd_engine.h``.
+
+The product binds ``libpcd_hip.so`` (prefix ``pcd_``).  The binding class is
+parameterised by (library, prefix) only so that the test oracle, which exports
+the same signatures under ``pcdo_``, can be driven by the same test code; the
+product never loads anything but the HIP library and raises if it is missing.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+# enums of include/pcd_engine.h
+BRM1, BRM2, RBRM1, RBRM2 = 1, 2, 3, 4
+MAT_AP, MAT_MP, MAT_KP, MAT_RP, MAT_A00, MAT_A01, MAT_A = range(7)
+KSP_AP, KSP_MP, KSP_RP, KSP_A00 = range(4)
+PREONLY, RICHARDSON, CHEBYSHEV, CG = range(4)
+PC_NONE, PC_JACOBI = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
+    INFO_NUM_PCD_APPLY, INFO_NUM_FS_APPLY, INFO_GMRES_ITS, \
+    INFO_GMRES_RNORM = range(10)
+INFO_NNZ_BASE = 16
+
+KSP_TYPES = {"preonly": PREONLY, "richardson": RICHARDSON,
+             "chebyshev": CHEBYSHEV, "cg": CG}
+PC_TYPES = {"none": PC_NONE, "jacobi": PC_JACOBI}
+VARIANTS = {"BRM1": BRM1, "BRM2": BRM2, "RBRM1": RBRM1, "RBRM2": RBRM2}
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+# name -> (argtypes after the handle, needs handle)
+_SIGNATURES = {
+    "destroy": [],
+    "set_csr": [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                C.c_void_p],
+    "update_values": [C.c_int, C.c_void_p, C.c_int],
+    "set_system": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+    "update_system": [C.c_void_p, C.c_void_p, C.c_int],
+    "set_bc": [C.c_int64, C.c_void_p, C.c_void_p],
+    "set_inner": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                  C.c_double],
+    "setup": [],
+    "apply": [C.c_void_p, C.c_void_p, C.c_int],
+    "fieldsplit_apply": [C.c_void_p, C.c_void_p, C.c_int],
+    "gmres_solve": [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                    C.c_int, C.c_int, C.POINTER(C.c_int), _f64p],
+    "spmv": [C.c_int, C.c_void_p, C.c_void_p, C.c_int],
+    "inner_solve": [C.c_int, C.c_void_p, C.c_void_p, C.c_int],
+    "apply_bc": [C.c_void_p, C.c_int],
+    "get_info": [C.c_int, _f64p],
+    "synchronize": [],
+}
+# entry points only the HIP library has
+_HIP_ONLY = {
+    "set_stream": [C.c_void_p],
+    "comm_init": [C.c_int, C.c_int, C.c_void_p],
+    "set_partition": [C.c_int64, C.c_int64, C.c_int64, C.c_int64],
+    "graph_enable": [C.c_int],
+}
+
+#: every symbol include/pcd_engine.h declares (checked by the CPU test-suite)
+DECLARED_SYMBOLS = (["pcd_create", "pcd_last_error", "pcd_comm_unique_id"]
+                    + ["pcd_" + k for k in _SIGNATURES]
+                    + ["pcd_" + k for k in _HIP_ONLY])
+
+
+class EngineError(RuntimeError):
+    """Raised for any nonzero status crossing the C ABI (SURVEY 8b Errors)."""
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):           # torch tensor
+        return a.data_ptr()
+    return int(a)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Library(object):
+    """A loaded shared object exporting ``<prefix>*`` per pcd_engine.h."""
+
+    def __init__(self, path, prefix="pcd_", hip=True):
+        if not os.path.exists(path):
+            raise EngineError(
+                "%s not found: build it first (python -c 'import "
+                "__graft_entry__ as g; g.build()')" % path)
+        self.path, self.prefix, self.hip = path, prefix, hip
+        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL if hip else C.DEFAULT_MODE)
+        self.fn = {}
+        sigs = dict(_SIGNATURES)
+        if hip:
+            sigs.update(_HIP_ONLY)
+        for name, args in sigs.items():
+            f = getattr(self.lib, prefix + name)
+            f.argtypes = [C.c_void_p] + args
+            f.restype = C.c_int
+            self.fn[name] = f
+        self.create = getattr(self.lib, prefix + "create")
+        self.create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        self.create.restype = C.c_int
+        self.last_error = getattr(self.lib, prefix + "last_error")
+        self.last_error.argtypes = []
+        self.last_error.restype = C.c_char_p
+        if hip:
+            self.comm_unique_id = getattr(self.lib, prefix + "comm_unique_id")
+            self.comm_unique_id.argtypes = [C.c_void_p]
+            self.comm_unique_id.restype = C.c_int
+
+    def error(self):
+        msg = self.last_error()
+        return msg.decode("utf-8", "replace") if msg else ""
+
+
+class Engine(object):
+    """One engine handle = one PCD context (+ its fieldsplit/GMRES shell)."""
+
+    def __init__(self, library, variant="BRM1", device=0):
+        self.L = library
+        self._h = C.c_void_p()
+        v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+        rc = library.create(C.byref(self._h), v, int(device))
+        if rc:
+            raise EngineError("create failed (%d): %s" % (rc, library.error()))
+        self.variant = v
+        self.shapes = {}
+
+    # -- plumbing -----------------------------------------------------------
+    def _call(self, name, *args):
+        if not self._h:
+            raise EngineError("engine handle already destroyed")
+        rc = self.L.fn[name](self._h, *args)
+        if rc:
+            raise EngineError("%s%s failed (%d): %s"
+                              % (self.L.prefix, name, rc, self.L.error()))
+
+    def destroy(self):
+        if self._h:
+            self.L.fn["destroy"](self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # -- operators ----------------------------------------------------------
+    def set_csr(self, which, A):
+        """``A``: scipy CSR (or anything with indptr/indices/data/shape)."""
+        ip, ix, dv = _i32(A.indptr), _i32(A.indices), _f64(A.data)
+        self.shapes[which] = A.shape
+        self._call("set_csr", which, A.shape[0], A.shape[1], _ptr(ip),
+                   _ptr(ix), _ptr(dv))
+
+    def update_values(self, which, vals, mem=MEM_HOST):
+        if mem == MEM_HOST:
+            vals = _f64(vals)
+        self._call("update_values", which, _ptr(vals), mem)
+
+    def set_system(self, A, is_u, is_p, P=None):
+        ip, ix, dv = _i32(A.indptr), _i32(A.indices), _f64(A.data)
+        pv = None
+        if P is not None:
+            assert P.nnz == A.nnz
+            pv = _f64(P.data)
+        iu, ipp = _i32(is_u), _i32(is_p)
+        self.n_u, self.n_p = iu.size, ipp.size
+        self._call("set_system", A.shape[0], _ptr(ip), _ptr(ix), _ptr(dv),
+                   _ptr(pv), iu.size, _ptr(iu), ipp.size, _ptr(ipp))
+
+    def update_system(self, vals, pvals=None, mem=MEM_HOST):
+        if mem == MEM_HOST:
+            vals = _f64(vals)
+            pvals = None if pvals is None else _f64(pvals)
+        self._call("update_system", _ptr(vals), _ptr(pvals), mem)
+
+    def set_bc(self, idx, vals):
+        idx, vals = _i32(idx), _f64(vals)
+        self._call("set_bc", idx.size, _ptr(idx), _ptr(vals))
+
+    def set_inner(self, slot, ksp_type, pc_type="jacobi", max_it=1,
+                  rtol=0.0, emin=0.5, emax=2.0):
+        k = KSP_TYPES[ksp_type] if isinstance(ksp_type, str) else ksp_type
+        p = PC_TYPES[pc_type] if isinstance(pc_type, str) else pc_type
+        self._call("set_inner", slot, k, p, int(max_it), float(rtol),
+                   float(emin), float(emax))
+
+    def setup(self):
+        self._call("setup")
+
+    # -- hot path -----------------------------------------------------------
+    def apply(self, x, y, mem=MEM_HOST):
+        self._call("apply", _ptr(x), _ptr(y), mem)
+
+    def fieldsplit_apply(self, x, y, mem=MEM_HOST):
+        self._call("fieldsplit_apply", _ptr(x), _ptr(y), mem)
+
+    def gmres_solve(self, b, x, mem=MEM_HOST, rtol=1e-6, atol=0.0,
+                    restart=150, max_it=10000):
+        its, rn = C.c_int(0), C.c_double(0.0)
+        self._call("gmres_solve", _ptr(b), _ptr(x), mem, float(rtol),
+                   float(atol), int(restart), int(max_it), C.byref(its),
+                   C.byref(rn))
+        return its.value, rn.value
+
+    def spmv(self, which, x, y, mem=MEM_HOST):
+        self._call("spmv", which, _ptr(x), _ptr(y), mem)
+
+    def inner_solve(self, slot, b, x, mem=MEM_HOST):
+        self._call("inner_solve", slot, _ptr(b), _ptr(x), mem)
+
+    def apply_bc(self, x, mem=MEM_HOST):
+        self._call("apply_bc", _ptr(x), mem)
+
+    def info(self, key):
+        out = C.c_double(0.0)
+        self._call("get_info", int(key), C.byref(out))
+        return out.value
+
+    def synchronize(self):
+        self._call("synchronize")
+
+    # -- HIP only -------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._call("set_stream", C.c_void_p(stream_ptr))
+
+    def graph_enable(self, on=True):
+        self._call("graph_enable", int(bool(on)))
+
+    def comm_init(self, rank, nranks, unique_id_bytes):
+        buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
+        self._call("comm_init", int(rank), int(nranks), buf)
+
+    # -- numpy conveniences used by tests ------------------------------------
+    def apply_np(self, x):
+        x = _f64(x)
+        y = np.empty_like(x)
+        self.apply(x, y)
+        return y
+
+    def fieldsplit_apply_np(self, x):
+        x = _f64(x)
+        y = np.empty_like(x)
+        self.fieldsplit_apply(x, y)
+        return y
+
+    def spmv_np(self, which, x, nrows):
+        x = _f64(x)
+        y = np.empty(nrows)
+        self.spmv(which, x, y)
+        return y
+
+    def inner_solve_np(self, slot, b):
+        b = _f64(b)
+        x = np.empty_like(b)
+        self.inner_solve(slot, b, x)
+        return x
+
+    def gmres_np(self, b, **kw):
+        b = _f64(b)
+        x = np.zeros_like(b)
+        its, rn = self.gmres_solve(b, x, **kw)
+        return x, its, rn
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIBRARY_PATH = os.path.join(_HERE, "lib", "libpcd_hip.so")
+_hip_library = None
+
+
+def hip_library():
+    """The product library.  Fails loudly when it has not been built."""
+    global _hip_library
+    if _hip_library is None:
+        _hip_library = Library(HIP_LIBRARY_PATH, "pcd_", hip=True)
+    return _hip_library

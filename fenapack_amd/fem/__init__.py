@@ -1,0 +1,4 @@
+"""Fixed-form P2/P1 finite-element input producer for the PCD engine."""
+from .mesh import Mesh, lshape_mesh, unit_square_mesh, cavity_mesh
+from .taylor_hood import TaylorHood, FixedPattern
+from .problems import FlowProblem, BackwardStep, Cavity

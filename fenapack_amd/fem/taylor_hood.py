@@ -1,0 +1,375 @@
+"""P2/P1 Taylor-Hood discretisation on triangles, vectorised with numpy.
+
+This is the *input producer* of the PCD engine: it stands in for the
+DOLFIN/FFC assembly the reference delegates to (``fenapack/assembling.py:
+151-180``) and assembles exactly the forms of the reference demos
+(``demo/navier-stokes-pcd/demo_navier-stokes-pcd.py:104-137``,
+``demo/unsteady-navier-stokes-pcd/demo_unsteady-navier-stokes-pcd.py:
+109-147``).  All matrices are fp64 CSR with int32 indices and a sparsity
+pattern that stays fixed between nonlinear iterations (only values change),
+which is what lets the engine keep its device-side layout and merely refresh
+values (``fenapack/field_split_backend.py:79-83, 285-291``).
+
+Numbering
+---------
+Nodes (vertices, then edge midpoints) are sorted lexicographically along the
+longest axis of the domain, so contiguous row blocks are geometric strips
+(at most two neighbours per strip: the row partition of SURVEY 8e).  The mixed
+space ``W = P2^2 x P1`` is numbered node-major: ``[ux, uy, p]`` on vertices,
+``[ux, uy]`` on edge midpoints - interleaved like DOLFIN's mixed dofmaps, so
+the fieldsplit index sets ``is_u`` / ``is_p`` are genuinely non-contiguous
+(``fenapack/field_split.py:71-73``).
+"""
+
+import numpy as np
+import scipy.sparse as sp
+
+# Dunavant 7-point rule, exact to degree 5 (enough for w(P2).grad u(P1) v(P2))
+_A1, _B1 = 0.059715871789770, 0.470142064105115
+_A2, _B2 = 0.797426985353087, 0.101286507323456
+_QP = np.array([[1 / 3., 1 / 3., 1 / 3.],
+                [_A1, _B1, _B1], [_B1, _A1, _B1], [_B1, _B1, _A1],
+                [_A2, _B2, _B2], [_B2, _A2, _B2], [_B2, _B2, _A2]])
+_QW = np.array([0.225] + [0.132394152788506] * 3 + [0.125939180544827] * 3)
+
+# 3-point Gauss rule on [0, 1] (degree 5) for boundary integrals
+_G3X = 0.5 + 0.5 * np.array([-np.sqrt(0.6), 0.0, np.sqrt(0.6)])
+_G3W = 0.5 * np.array([5 / 9., 8 / 9., 5 / 9.])
+
+
+def _p2_basis(lam):
+    """P2 basis at barycentric points ``lam`` (nq, 3).
+
+    Local dofs: vertices 0..2, then edge k (opposite vertex k) 3..5.
+    Returns (phi (nq, 6), dphi/dlam (nq, 6, 3)).
+    """
+    nq = lam.shape[0]
+    phi = np.empty((nq, 6))
+    dphi = np.zeros((nq, 6, 3))
+    for i in range(3):
+        phi[:, i] = lam[:, i] * (2 * lam[:, i] - 1)
+        dphi[:, i, i] = 4 * lam[:, i] - 1
+    for k, (i, j) in enumerate(((1, 2), (2, 0), (0, 1))):
+        phi[:, 3 + k] = 4 * lam[:, i] * lam[:, j]
+        dphi[:, 3 + k, i] = 4 * lam[:, j]
+        dphi[:, 3 + k, j] = 4 * lam[:, i]
+    return phi, dphi
+
+
+class FixedPattern(object):
+    """CSR sparsity pattern assembled once; values refreshed by ``bincount``."""
+
+    def __init__(self, rows, cols, shape):
+        rows = np.asarray(rows, dtype=np.int64).ravel()
+        cols = np.asarray(cols, dtype=np.int64).ravel()
+        key = rows * shape[1] + cols
+        ukey, inv = np.unique(key, return_inverse=True)
+        self.shape = shape
+        self.inv = inv
+        self.nnz = ukey.size
+        self.keys = ukey
+        urow = ukey // shape[1]
+        self.indices = (ukey % shape[1]).astype(np.int32)
+        self.indptr = np.zeros(shape[0] + 1, dtype=np.int32)
+        np.cumsum(np.bincount(urow, minlength=shape[0]), out=self.indptr[1:])
+        self.rows = urow.astype(np.int32)
+
+    def assemble(self, vals):
+        data = np.bincount(self.inv, weights=np.asarray(vals).ravel(),
+                           minlength=self.nnz)
+        return self.matrix(data)
+
+    def matrix(self, data):
+        """CSR on this pattern; explicit zeros are kept on purpose."""
+        return sp.csr_matrix((data, self.indices, self.indptr),
+                             shape=self.shape)
+
+    def locate(self, rows, cols):
+        """Positions (in CSR data order) of existing entries (rows, cols)."""
+        key = (np.asarray(rows, dtype=np.int64) * self.shape[1]
+               + np.asarray(cols, dtype=np.int64))
+        pos = np.searchsorted(self.keys, key)
+        assert np.all(self.keys[pos] == key), "entry outside the pattern"
+        return pos
+
+
+class TaylorHood(object):
+    """P2 velocity / P1 pressure spaces on a :class:`Mesh`."""
+
+    def __init__(self, mesh):
+        self.mesh = mesh
+        nv, ne = mesh.num_vertices, mesh.num_edges
+        self.nv, self.ne = nv, ne
+        self.nn = nn = nv + ne                       # scalar P2 dofs
+        coords = np.concatenate([mesh.vertices, mesh.edge_midpoints()])
+        ext = coords.max(axis=0) - coords.min(axis=0)
+        major = int(np.argmax(ext))
+        order = np.lexsort((coords[:, 1 - major], coords[:, major]))
+        rank = np.empty(nn, dtype=np.int64)
+        rank[order] = np.arange(nn)
+        self.node_coords = coords[order]             # by scalar P2 dof
+        is_vertex_sorted = order < nv
+        # P1 numbering: vertices in the same geometric order
+        pnum = np.empty(nv, dtype=np.int64)
+        pnum[order[is_vertex_sorted]] = np.arange(nv)
+        self.p_coords = mesh.vertices[order[is_vertex_sorted]]
+        self.p2_of_p1 = np.nonzero(is_vertex_sorted)[0]   # P2 dof of P1 dof
+        # cell dof tables
+        self.cell_dofs2 = np.concatenate(
+            [rank[mesh.cells], rank[nv + mesh.cell_edges]], axis=1)
+        self.cell_dofs1 = pnum[mesh.cells]
+        self._rank, self._pnum = rank, pnum
+        # sizes and fieldsplit index sets (mixed, node-major numbering)
+        self.n_u, self.n_p = 2 * nn, nv
+        self.ndof = self.n_u + self.n_p
+        width = np.where(is_vertex_sorted, 3, 2)
+        start = np.concatenate([[0], np.cumsum(width)[:-1]])
+        self.is_u = np.stack([start, start + 1], axis=1).ravel()
+        self.is_p = start[is_vertex_sorted] + 2
+        self._geometry()
+
+    # ------------------------------------------------------------------ geo
+    def _geometry(self):
+        m = self.mesh
+        p = m.vertices[m.cells]                       # (nc, 3, 2)
+        e1, e2 = p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]
+        det = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+        self.area = 0.5 * det
+        g = np.empty((m.num_cells, 3, 2))
+        # grad lambda_k = rot(edge opposite k) / det
+        g[:, 0, 0] = (p[:, 1, 1] - p[:, 2, 1]) / det
+        g[:, 0, 1] = (p[:, 2, 0] - p[:, 1, 0]) / det
+        g[:, 1, 0] = (p[:, 2, 1] - p[:, 0, 1]) / det
+        g[:, 1, 1] = (p[:, 0, 0] - p[:, 2, 0]) / det
+        g[:, 2, 0] = (p[:, 0, 1] - p[:, 1, 1]) / det
+        g[:, 2, 1] = (p[:, 1, 0] - p[:, 0, 0]) / det
+        self.gradlam = g
+        self.phi, dphi = _p2_basis(_QP)                        # (nq,6)
+        self.gphi = np.einsum('qak,ckd->cqad', dphi, g)         # (nc,nq,6,2)
+        self.psi = _QP                                          # (nq,3)
+        self.wq = _QW[None, :] * self.area[:, None]             # (nc,nq)
+        longest = np.maximum.reduce([
+            np.linalg.norm(p[:, 1] - p[:, 0], axis=1),
+            np.linalg.norm(p[:, 2] - p[:, 1], axis=1),
+            np.linalg.norm(p[:, 0] - p[:, 2], axis=1)])
+        # DOLFIN Cell::h() = 2 * circumradius for simplices
+        self.cell_h = (np.linalg.norm(p[:, 1] - p[:, 0], axis=1)
+                       * np.linalg.norm(p[:, 2] - p[:, 1], axis=1)
+                       * np.linalg.norm(p[:, 0] - p[:, 2], axis=1)
+                       / (2.0 * self.area))
+        self.cell_hmax = longest
+
+    # ------------------------------------------------------------- patterns
+    def _patterns(self, coupled):
+        """Fixed sparsity patterns in fieldsplit-local numbering."""
+        key = "_pat_%d" % int(coupled)
+        if hasattr(self, key):
+            return getattr(self, key)
+        d2, d1 = self.cell_dofs2, self.cell_dofs1
+        r2 = np.repeat(d2[:, :, None], 6, axis=2)     # (nc,6,6) row = a
+        c2 = np.repeat(d2[:, None, :], 6, axis=1)     # col = b
+        pat = {}
+        if coupled:
+            # rows (a,c) x cols (b,d), all four component pairs: (nc,6,6,2,2)
+            comp = np.arange(2)
+            rows = np.broadcast_to(2 * r2[..., None, None]
+                                   + comp[:, None], r2.shape + (2, 2))
+            cols = np.broadcast_to(2 * c2[..., None, None]
+                                   + comp[None, :], c2.shape + (2, 2))
+        else:
+            rows = 2 * r2[..., None] + np.arange(2)
+            cols = 2 * c2[..., None] + np.arange(2)
+        pat["A00"] = FixedPattern(rows, cols, (self.n_u, self.n_u))
+        # A01 rows (a,c) x cols j
+        r = 2 * np.repeat(d2[:, :, None], 3, axis=2)[..., None] + np.arange(2)
+        c = np.repeat(np.repeat(d1[:, None, :], 6, axis=1)[..., None], 2,
+                      axis=3)
+        pat["A01"] = FixedPattern(r, c, (self.n_u, self.n_p))
+        pat["A10"] = FixedPattern(c, r, (self.n_p, self.n_u))
+        r1 = np.repeat(d1[:, :, None], 3, axis=2)
+        c1 = np.repeat(d1[:, None, :], 3, axis=1)
+        pat["PP"] = FixedPattern(r1, c1, (self.n_p, self.n_p))
+        pat["SS"] = FixedPattern(r2, c2, (self.nn, self.nn))
+        setattr(self, key, pat)
+        return pat
+
+    # ----------------------------------------------------- scalar P2 pieces
+    def wind_at_qp(self, U):
+        """``U`` (nn, 2) nodal P2 velocity -> (nc, nq, 2) and its gradient
+        (nc, nq, 2[comp], 2[d])."""
+        Uc = U[self.cell_dofs2]                                 # (nc,6,2)
+        w = np.einsum('qa,cak->cqk', self.phi, Uc)
+        gw = np.einsum('cqad,cak->cqkd', self.gphi, Uc)
+        return w, gw
+
+    def p2_stiffness_cells(self):
+        return np.einsum('cq,cqad,cqbd->cab', self.wq, self.gphi, self.gphi)
+
+    def p2_mass_cells(self):
+        return np.einsum('cq,qa,qb->cab', self.wq, self.phi, self.phi)
+
+    def p2_convection_cells(self, w):
+        wg = np.einsum('cqd,cqbd->cqb', w, self.gphi)           # w.grad phi_b
+        return np.einsum('cq,qa,cqb->cab', self.wq, self.phi, wg)
+
+    def p2_supg_cells(self, w, delta):
+        """delta * (w.grad u, w.grad v): streamline diffusion added to the
+        preconditioner's 00-block (demo_navier-stokes-pcd.py:122-125)."""
+        wg = np.einsum('cqd,cqbd->cqb', w, self.gphi)
+        return np.einsum('c,cq,cqa,cqb->cab', delta, self.wq, wg, wg)
+
+    # ------------------------------------------------------------- velocity
+    def assemble_A00(self, nu, U=None, idt=0.0, newton=False, delta=None):
+        """Velocity block: nu*(grad u, grad v) + ((w.grad)u, v) [+ idt*(u,v)]
+        [+ Newton term ((u.grad)w, v)] [+ SUPG]."""
+        pat = self._patterns(newton)["A00"]
+        S = nu * self.p2_stiffness_cells()
+        if idt:
+            S = S + idt * self.p2_mass_cells()
+        if U is not None:
+            w, gw = self.wind_at_qp(U)
+            S = S + self.p2_convection_cells(w)
+            if delta is not None:
+                S = S + self.p2_supg_cells(w, delta)
+        if not newton:
+            vals = np.repeat(S[..., None], 2, axis=3)           # (nc,6,6,2)
+            return pat.assemble(vals)
+        vals = np.zeros(S.shape + (2, 2))
+        vals[..., 0, 0] = S
+        vals[..., 1, 1] = S
+        if U is not None:
+            # N[(a,c),(b,d)] = int phi_a phi_b d_d w_c
+            N = np.einsum('cq,qa,qb,cqkd->cabkd', self.wq, self.phi, self.phi,
+                          gw)
+            vals += N
+        return pat.assemble(vals)
+
+    def assemble_Mu(self, scale=1.0):
+        """Velocity mass matrix scale*(u, v) on the decoupled pattern."""
+        pat = self._patterns(False)["A00"]
+        M = scale * self.p2_mass_cells()
+        return pat.assemble(np.repeat(M[..., None], 2, axis=3))
+
+    def assemble_A01(self):
+        """Discrete gradient block from ``-p div v`` (rows velocity)."""
+        pat = self._patterns(False)["A01"]
+        # vals[c, a, j, comp] = -int psi_j d_comp phi_a
+        vals = -np.einsum('cq,qj,cqak->cajk', self.wq, self.psi, self.gphi)
+        return pat.assemble(vals)
+
+    def assemble_A10(self):
+        """Divergence block from ``-q div u`` (rows pressure) = A01^T."""
+        pat = self._patterns(False)["A10"]
+        vals = -np.einsum('cq,qj,cqak->cajk', self.wq, self.psi, self.gphi)
+        return pat.assemble(vals)
+
+    # ------------------------------------------------------------- pressure
+    def assemble_Mp(self, scale):
+        pat = self._patterns(False)["PP"]
+        return pat.assemble(scale * np.einsum('cq,qi,qj->cij', self.wq,
+                                              self.psi, self.psi))
+
+    def assemble_Ap(self):
+        pat = self._patterns(False)["PP"]
+        g = self.gradlam
+        return pat.assemble(self.area[:, None, None]
+                            * np.einsum('cid,cjd->cij', g, g))
+
+    def assemble_Kp(self, nu, U, idt=0.0, robin_edges=None):
+        """(1/nu) * (w.grad p, q) [+ (idt/nu) (p, q)]
+        [- (1/nu) int_{robin_edges} (w.n) p q ds]  (BRM2 boundary term,
+        demo_navier-stokes-pcd.py:131-135)."""
+        pat = self._patterns(False)["PP"]
+        w, _ = self.wind_at_qp(U)
+        wg = np.einsum('cqd,cjd->cqj', w, self.gradlam)         # w.grad psi_j
+        vals = np.einsum('cq,qi,cqj->cij', self.wq, self.psi, wg) / nu
+        if idt:
+            vals = vals + (idt / nu) * np.einsum('cq,qi,qj->cij', self.wq,
+                                                 self.psi, self.psi)
+        K = pat.assemble(vals)
+        if robin_edges is not None and len(robin_edges):
+            R = self._boundary_flux_mass(U, robin_edges)
+            K = pat.matrix(K.data - R.data / nu)
+        return K
+
+    def _boundary_flux_mass(self, U, edges):
+        """int_edges (w.n) p q ds as an n_p x n_p matrix on the PP pattern."""
+        m = self.mesh
+        pat = self._patterns(False)["PP"]
+        ev = m.edges[edges]                                     # (nb,2)
+        a, b = m.vertices[ev[:, 0]], m.vertices[ev[:, 1]]
+        t = b - a
+        length = np.linalg.norm(t, axis=1)
+        n = np.stack([t[:, 1], -t[:, 0]], axis=1) / length[:, None]
+        # orient outward: the single adjacent cell's opposite vertex is inside
+        cell_of = {}
+        flat = m.cell_edges.ravel()
+        pos = np.nonzero(np.isin(flat, edges))[0]
+        for q in pos:
+            cell_of[flat[q]] = (q // 3, q % 3)
+        opp = np.array([m.cells[cell_of[e][0], cell_of[e][1]] for e in edges])
+        inward = m.vertices[opp] - a
+        sgn = np.where((inward * n).sum(axis=1) > 0, -1.0, 1.0)
+        n = n * sgn[:, None]
+        # P2 wind along the edge: endpoints + midpoint dofs
+        r = self._rank
+        Ua, Ub = U[r[ev[:, 0]]], U[r[ev[:, 1]]]
+        Um = U[r[self.nv + np.asarray(edges)]]
+        s = _G3X
+        la, lb = 1 - s, s                                       # (3,)
+        wn = ((la * (2 * la - 1))[None, :] * (Ua * n).sum(1)[:, None]
+              + (lb * (2 * lb - 1))[None, :] * (Ub * n).sum(1)[:, None]
+              + (4 * la * lb)[None, :] * (Um * n).sum(1)[:, None])   # (nb,3)
+        psi = np.stack([la, lb], axis=1)                        # (3q, 2)
+        loc = np.einsum('q,eq,qi,qj->eij', _G3W, wn, psi, psi) \
+            * length[:, None, None]
+        pd = self._pnum[ev]                                     # (nb,2)
+        rows = np.repeat(pd[:, :, None], 2, axis=2).ravel()
+        cols = np.repeat(pd[:, None, :], 2, axis=1).ravel()
+        data = np.bincount(pat.locate(rows, cols), weights=loc.ravel(),
+                           minlength=pat.nnz)
+        return pat.matrix(data)
+
+    # ------------------------------------------------------- stabilisation
+    def supg_delta(self, U, nu, rho=1.0):
+        """Streamline-diffusion parameter per cell, formula of
+        ``fenapack/stabilization.py:66-67`` evaluated at the cell midpoint:
+        ``Pe = 0.5*|w|*h*rho/nu; delta = Pe>1 ? 0.5*h*(1-1/Pe)/|w| : 0``."""
+        lam = np.full((1, 3), 1 / 3.)
+        phi, _ = _p2_basis(lam)
+        wmid = np.einsum('a,cak->ck', phi[0], U[self.cell_dofs2])
+        wnorm = np.linalg.norm(wmid, axis=1)
+        h = self.cell_h
+        with np.errstate(divide='ignore', invalid='ignore'):
+            pe = 0.5 * wnorm * h * rho / nu
+            delta = np.where(pe > 1.0, 0.5 * h * (1.0 - 1.0 / pe) / wnorm, 0.0)
+        return np.nan_to_num(delta)
+
+    # ----------------------------------------------------------- utilities
+    def to_mixed(self, xu, xp):
+        x = np.empty(self.ndof)
+        x[self.is_u] = xu
+        x[self.is_p] = xp
+        return x
+
+    def monolithic(self, A00, A01, A10):
+        """Scatter the 2x2 blocks into the node-major mixed numbering on a
+        fixed pattern (explicit zero diagonal kept on the pressure rows, as
+        DOLFIN's ``keep_diagonal`` would)."""
+        key = "_mono_%d_%d_%d" % (A00.nnz, A01.nnz, A10.nnz)
+        iu, ip = self.is_u, self.is_p
+        if not hasattr(self, key):
+            def rc(M, ri, ci):
+                rows = np.repeat(np.arange(M.shape[0]), np.diff(M.indptr))
+                return ri[rows], ci[M.indices]
+            r0, c0 = rc(A00, iu, iu)
+            r1, c1 = rc(A01, iu, ip)
+            r2, c2 = rc(A10, ip, iu)
+            rows = np.concatenate([r0, r1, r2, ip])
+            cols = np.concatenate([c0, c1, c2, ip])
+            setattr(self, key, FixedPattern(rows, cols,
+                                            (self.ndof, self.ndof)))
+        pat = getattr(self, key)
+        vals = np.concatenate([A00.data, A01.data, A10.data,
+                               np.zeros(self.n_p)])
+        return pat.assemble(vals)

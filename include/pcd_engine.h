@@ -1,0 +1,184 @@
+/* pcd_engine.h - C ABI of the MI355X-native PCD preconditioner-apply engine.
+ *
+ * This is the drop-in boundary for fenapack's PCFieldSplit Schur path
+ * (SURVEY.md section 8b).  Every entry point names the reference interface it
+ * replaces (paths relative to the fenapack tree).  Calls that fenapack hands to
+ * PETSc through petsc4py are marked [ext PETSc]: their arithmetic lives in
+ * PETSc (version unpinned by the reference), restated in DESIGN.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a nonzero pcd_status otherwise; it
+ *    never throws and never aborts; the message of the last failure on the
+ *    calling thread is available from pcd_last_error().
+ *  - matrices are CSR, fp64 values, int32 indices, passed as HOST arrays and
+ *    copied at the call (the caller may free them afterwards).
+ *  - vectors are fp64; `mem` says where the pointers live (PCD_MEM_HOST: the
+ *    call copies in/out and synchronises; PCD_MEM_DEVICE: device pointers, work
+ *    is enqueued on the engine's stream and the call does not synchronise
+ *    unless stated).
+ *  - a handle is not re-entrant; with several ranks, collective calls must be
+ *    issued in the same order on every rank.
+ */
+#ifndef PCD_ENGINE_H
+#define PCD_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcd_engine_s* pcd_handle;
+
+enum pcd_status {
+  PCD_OK = 0,
+  PCD_ERR_ARG = 1,       /* bad argument / wrong call order                  */
+  PCD_ERR_HIP = 2,       /* HIP runtime failure (message has the HIP string) */
+  PCD_ERR_NOMEM = 3,
+  PCD_ERR_STATE = 4,     /* operator or solver missing at setup/apply        */
+  PCD_ERR_COMM = 5,      /* RCCL failure                                     */
+  PCD_ERR_BREAKDOWN = 6  /* numerical breakdown (zero pivot / NaN)           */
+};
+
+/* fenapack/preconditioners.py:89,139,211,256 - the four python contexts */
+enum pcd_variant {
+  PCD_BRM1 = 1,   /* y = -Mp^-1 (x + Kp Ap^-1 bc(x))            :124-135 */
+  PCD_BRM2 = 2,   /* y = -(I + Ap^-1 bc Kp) Mp^-1 x             :158-169 */
+  PCDR_BRM1 = 3,  /* BRM1 - Rp^-1 x                             :239-252 */
+  PCDR_BRM2 = 4   /* BRM2 - Rp^-1 x                             :285-298 */
+};
+
+/* operators owned by the context: preconditioners.py:29-30,79-82,197-207 and
+ * the blocks PETSc's PCFIELDSPLIT extracts (field_split.py:82,89-93) */
+enum pcd_mat {
+  PCD_MAT_AP = 0, PCD_MAT_MP = 1, PCD_MAT_KP = 2, PCD_MAT_RP = 3,
+  PCD_MAT_A00 = 4,  /* velocity block of the preconditioner matrix P       */
+  PCD_MAT_A01 = 5,  /* discrete gradient block                             */
+  PCD_MAT_A = 6,    /* whole operator in split ordering [u; p] (read only) */
+  PCD_MAT_COUNT = 7
+};
+
+/* inner KSPs: preconditioners.py:29-34 (Ap, Mp), :180-183 (Rp);
+ * field_split.py:93-98 (ksp0 = A00 solve) */
+enum pcd_slot { PCD_KSP_AP = 0, PCD_KSP_MP = 1, PCD_KSP_RP = 2,
+                PCD_KSP_A00 = 3, PCD_KSP_COUNT = 4 };
+
+/* [ext PETSc] KSP types honoured (-<prefix>ksp_type), SURVEY 5 "Config" */
+enum pcd_ksp_type { PCD_KSP_PREONLY = 0, PCD_KSP_RICHARDSON = 1,
+                    PCD_KSP_CHEBYSHEV = 2, PCD_KSP_CG = 3 };
+/* [ext PETSc] PC types honoured (-<prefix>pc_type) */
+enum pcd_pc_type { PCD_PC_NONE = 0, PCD_PC_JACOBI = 1 };
+
+enum pcd_mem { PCD_MEM_HOST = 0, PCD_MEM_DEVICE = 1 };
+
+/* keys of pcd_get_info */
+enum pcd_info {
+  PCD_INFO_N_U = 0, PCD_INFO_N_P = 1,
+  PCD_INFO_ITS_AP = 2, PCD_INFO_ITS_MP = 3, PCD_INFO_ITS_RP = 4,
+  PCD_INFO_ITS_A00 = 5,      /* iterations executed by the last inner solve */
+  PCD_INFO_NUM_PCD_APPLY = 6, PCD_INFO_NUM_FS_APPLY = 7,
+  PCD_INFO_GMRES_ITS = 8, PCD_INFO_GMRES_RNORM = 9,
+  PCD_INFO_NNZ_BASE = 16     /* + pcd_mat: stored nonzeros of that operator */
+};
+
+/* ---- lifetime ----------------------------------------------------------- */
+
+/* BasePCDPC.create (preconditioners.py:28-34).  `device` is the HIP device
+ * ordinal this rank drives (one process per GPU). */
+int pcd_create(pcd_handle* out, int variant, int device);
+/* idempotent; frees every device allocation of the handle */
+int pcd_destroy(pcd_handle h);
+const char* pcd_last_error(void);
+/* share the caller's HIP stream (e.g. torch's current stream); NULL = own */
+int pcd_set_stream(pcd_handle h, void* hip_stream);
+
+/* ---- operators ----------------------------------------------------------- */
+
+/* PCDInterface.setup_ksp_Ap/Mp/Rp, setup_mat_Kp (field_split_backend.py:
+ * 67-83,115-139): hand over an already extracted p-p (or u-u / u-p)
+ * submatrix.  First call for `which` fixes the sparsity pattern. */
+int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
+                const int32_t* rowptr, const int32_t* colidx,
+                const double* vals);
+/* non-constant forms are re-assembled into the existing submatrix every outer
+ * iteration (field_split_backend.py:82-83,285-291; assembling.py:103-104):
+ * same pattern, new values, Jacobi diagonals re-derived. */
+int pcd_update_values(pcd_handle h, int which, const double* vals, int mem);
+
+/* PCDKSP.init_pcd, field_split.py:71-82 + [ext PETSc] PCSetUp_FieldSplit:
+ * the monolithic operator A (caller's mixed numbering) and the two index sets
+ * (dofmap_dofs_is, _field_split_utils.py:39-50).  The engine extracts A00,
+ * A01 and the split-ordered operator itself.  `pvals` (may be NULL) are the
+ * values of the preconditioning matrix P on the SAME pattern (a_pc,
+ * assembling.py:143-148); NULL means P = A (nonlinear_solvers.py:75). */
+int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
+                   const int32_t* colidx, const double* vals,
+                   const double* pvals,
+                   int64_t n_u, const int32_t* is_u,
+                   int64_t n_p, const int32_t* is_p);
+/* in-place re-assembly of A (and P) between Newton steps, SURVEY 3.1 */
+int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
+                      int mem);
+
+/* SubfieldBC (SubfieldBC.h:48-53,92-160): subfield indices + values of the
+ * PCD Dirichlet condition in the contiguous pressure numbering. */
+int pcd_set_bc(pcd_handle h, int64_t n_bc, const int32_t* idx,
+               const double* vals);
+
+/* ---- inner solvers ([ext PETSc] options, demo_navier-stokes-pcd.py:151-165)
+ * rtol <= 0 means "run exactly max_it iterations" (-ksp_norm_type none). */
+int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type,
+                  int max_it, double rtol, double emin, double emax);
+
+/* BasePCDPC.setUp / BasePCDRPC.setUp (preconditioners.py:71-85,191-207) and
+ * ksp.setUp() of field_split_backend.py:254-263: checks every operator the
+ * variant needs is present, derives Jacobi diagonals, allocates work vectors
+ * (get_work_vecs, preconditioners.py:52-61). */
+int pcd_setup(pcd_handle h);
+
+/* ---- the hot path -------------------------------------------------------- */
+
+/* PCDPC_BRM1/BRM2/PCDRPC_BRM1/BRM2.apply(pc, x, y): x borrowed (n_p),
+ * y overwritten (n_p). */
+int pcd_apply(pcd_handle h, const double* x, double* y, int mem);
+
+/* [ext PETSc] PCApply_FieldSplit_Schur, factorisation UPPER (field_split.py:
+ * 54-57): y_p = pcd(x_p); y_u = A00^-1 (x_u - A01 y_p).  x, y have length
+ * n_u + n_p in the caller's mixed numbering. */
+int pcd_fieldsplit_apply(pcd_handle h, const double* x, double* y, int mem);
+
+/* [ext PETSc] KSPSolve of PCDKSP (field_split.py:46-57): restarted GMRES,
+ * right preconditioning by pcd_fieldsplit_apply, classical Gram-Schmidt,
+ * zero initial guess, stop when ||b - A x|| <= rtol*||b|| (or atol).
+ * Synchronises.  *its = iterations, *rnorm = final residual estimate. */
+int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
+                    double rtol, double atol, int restart, int max_it,
+                    int* its, double* rnorm);
+
+/* ---- building blocks, exported for parity tests and profiling ------------ */
+
+/* Mat.mult (preconditioners.py:131,164) on one stored operator */
+int pcd_spmv(pcd_handle h, int which, const double* x, double* y, int mem);
+/* KSP.solve (preconditioners.py:130,133,162,166,249,295) of one slot */
+int pcd_inner_solve(pcd_handle h, int slot, const double* b, double* x,
+                    int mem);
+/* SubfieldBC::apply (SubfieldBC.h:74-77,162-182) on a pressure vector */
+int pcd_apply_bc(pcd_handle h, double* x, int mem);
+
+int pcd_get_info(pcd_handle h, int key, double* out);
+int pcd_synchronize(pcd_handle h);
+
+/* ---- multi-GPU: contiguous row blocks per rank, RCCL over xGMI ----------- */
+
+/* SURVEY 8e.  `nccl_unique_id` is the 128-byte ncclUniqueId produced on rank 0
+ * (pcd_comm_unique_id) and broadcast by the host (torch.distributed store).
+ * After this call set_csr/set_system take GLOBAL matrices on every rank and
+ * keep only the owned row block [row_begin, row_end) of each field. */
+int pcd_comm_unique_id(void* out128);
+int pcd_comm_init(pcd_handle h, int rank, int nranks,
+                  const void* nccl_unique_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCD_ENGINE_H */

@@ -1,0 +1,44 @@
+"""CPU parity oracle for the PCD / fieldsplit apply path.
+
+TEST INFRASTRUCTURE ONLY: importable from ``tests/``, from
+``__graft_entry__.smoke()`` and from ``bench.py``'s ``cpu_baseline`` leg.  The
+product package ``fenapack_amd`` never imports this module.
+
+``oracle/pcd_oracle.c`` is a plain-C restatement (same C ABI as
+``include/pcd_engine.h`` under the prefix ``pcdo_``); ``oracle.reference_numpy``
+is an independent numpy/scipy restatement used to generate and to check the
+golden fixtures.  Parity status: the four ``apply`` bodies are pinned against
+the reference's own ``fenapack/preconditioners.py`` (tests/golden); everything
+that PETSc computes for the reference is "parity unpinned" (PETSc is absent
+and its version is not pinned by the reference) - see DESIGN.md.
+"""
+
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIBRARY_PATH = os.path.join(_HERE, "_build", "libpcd_oracle.so")
+_library = None
+
+
+def build(force=False):
+    """Compile pcd_oracle.c with gcc (seconds)."""
+    src = os.path.join(_HERE, "pcd_oracle.c")
+    if (force or not os.path.exists(ORACLE_LIBRARY_PATH)
+            or os.path.getmtime(ORACLE_LIBRARY_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return ORACLE_LIBRARY_PATH
+
+
+def library():
+    global _library
+    if _library is None:
+        from fenapack_amd._cabi import Library
+        _library = Library(build(), "pcdo_", hip=False)
+    return _library
+
+
+def Engine(variant="BRM1"):
+    """An oracle engine with the same Python surface as the HIP engine."""
+    from fenapack_amd._cabi import Engine as _Engine
+    return _Engine(library(), variant, 0)

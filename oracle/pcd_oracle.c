@@ -1,0 +1,617 @@
+/* pcd_oracle.c - CPU restatement of fenapack's PCD / fieldsplit apply path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product (fenapack_amd + libpcd_hip.so) never calls into it.
+ *
+ * What it restates (paths relative to the fenapack tree):
+ *   - the four PCPYTHON apply bodies, op for op:
+ *       fenapack/preconditioners.py:124-135 (PCDPC_BRM1), :158-169 (BRM2),
+ *       :239-252 (PCDRPC_BRM1), :285-298 (PCDRPC_BRM2);
+ *   - SubfieldBC::apply = VecSetValues(INSERT): fenapack/SubfieldBC.h:162-182;
+ *   - the algorithm PCDKSP selects and PETSc then runs (field_split.py:46-57):
+ *     right-preconditioned restarted GMRES over PCFIELDSPLIT/SCHUR/UPPER.
+ *
+ * Pinning: the apply bodies are pinned against goldens produced by running
+ * the reference's own preconditioners.py (tests/golden/make_goldens.py).  The
+ * Krylov/Chebyshev/fieldsplit arithmetic belongs to PETSc, which is NOT in
+ * /root/reference and whose version the reference does not pin:
+ * those parts restate PETSc's published algorithms (KSPCG with Jacobi and the
+ * natural norm, KSPCHEBYSHEV's three-term recurrence with user eigenvalue
+ * bounds, KSPRICHARDSON scale 1, KSPGMRES with classical Gram-Schmidt and
+ * right preconditioning, PCApply_FieldSplit_Schur UPPER) and are
+ * "parity unpinned" at the PETSc boundary; they are checked by algebraic
+ * properties instead (tests/test_oracle.py).
+ *
+ * Plain scalar C on purpose: one thread, sequential summation order.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { MAT_AP = 0, MAT_MP, MAT_KP, MAT_RP, MAT_A00, MAT_A01, MAT_A, MAT_COUNT };
+enum { SLOT_AP = 0, SLOT_MP, SLOT_RP, SLOT_A00, SLOT_COUNT };
+enum { KSP_PREONLY = 0, KSP_RICHARDSON, KSP_CHEBYSHEV, KSP_CG };
+enum { PC_NONE = 0, PC_JACOBI };
+enum { BRM1 = 1, BRM2, RBRM1, RBRM2 };
+
+typedef struct {
+  int64_t nrows, ncols, nnz;
+  int32_t *rowptr, *col;
+  double *val;
+  double *dinv;        /* reciprocal diagonal (square operators)   */
+  int64_t *src;        /* position in the caller's monolithic vals */
+  int set;
+} csr_t;
+
+typedef struct {
+  int ksp, pc, max_it;
+  double rtol, emin, emax;
+  int last_its;
+} inner_t;
+
+typedef struct pcdo_s {
+  int variant;
+  csr_t mat[MAT_COUNT];
+  inner_t inner[SLOT_COUNT];
+  int64_t n_bc;
+  int32_t *bc_idx;
+  double *bc_val;
+  int64_t n_u, n_p;
+  int32_t *perm;       /* split position -> caller's index */
+  int64_t sys_nnz;
+  int ready;
+  double *w[8];        /* pressure-sized work vectors */
+  double *wu[4];       /* velocity-sized work vectors */
+  double *ws[2];       /* system-sized work vectors   */
+  long num_pcd, num_fs;
+  int gmres_its;
+  double gmres_rnorm;
+} pcdo_t;
+
+static char g_err[512] = "";
+static int fail(int code, const char *msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+const char *pcdo_last_error(void) { return g_err; }
+
+/* ------------------------------------------------------------------ CSR */
+static void csr_free(csr_t *m) {
+  free(m->rowptr); free(m->col); free(m->val); free(m->dinv); free(m->src);
+  memset(m, 0, sizeof *m);
+}
+
+static void csr_diag(csr_t *m) {
+  if (m->nrows != m->ncols) return;
+  if (!m->dinv) m->dinv = (double *)malloc(sizeof(double) * m->nrows);
+  for (int64_t i = 0; i < m->nrows; ++i) {
+    double d = 0.0;
+    for (int32_t k = m->rowptr[i]; k < m->rowptr[i + 1]; ++k)
+      if (m->col[k] == i) d += m->val[k];
+    m->dinv[i] = (d != 0.0) ? 1.0 / d : 1.0;
+  }
+}
+
+/* Mat.mult: y = A x (preconditioners.py:131,164) */
+static void spmv(const csr_t *A, const double *x, double *y) {
+  for (int64_t i = 0; i < A->nrows; ++i) {
+    double s = 0.0;
+    for (int32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+      s += A->val[k] * x[A->col[k]];
+    y[i] = s;
+  }
+}
+
+static double dot(int64_t n, const double *a, const double *b) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+/* ----------------------------------------------------------- inner KSPs */
+static void pc_apply(const csr_t *A, int pc, const double *r, double *z) {
+  if (pc == PC_JACOBI)
+    for (int64_t i = 0; i < A->nrows; ++i) z[i] = A->dinv[i] * r[i];
+  else
+    memcpy(z, r, sizeof(double) * A->nrows);
+}
+
+/* [ext PETSc] KSPCG, PCJACOBI, zero initial guess, natural norm sqrt(r.z):
+ * stop at max_it, or when rtol > 0 and sqrt(r.z) <= rtol*sqrt(r0.z0). */
+static int solve_cg(const csr_t *A, inner_t *s, const double *b, double *x,
+                    double *r, double *z, double *p, double *q) {
+  int64_t n = A->nrows;
+  memset(x, 0, sizeof(double) * n);
+  memcpy(r, b, sizeof(double) * n);
+  pc_apply(A, s->pc, r, z);
+  double rz = dot(n, r, z), rz0 = rz, rz_old = 0.0;
+  int it = 0;
+  while (it < s->max_it) {
+    if (rz == 0.0) break;
+    if (s->rtol > 0.0 && sqrt(fabs(rz)) <= s->rtol * sqrt(fabs(rz0))) break;
+    if (it == 0)
+      memcpy(p, z, sizeof(double) * n);
+    else {
+      double beta = rz / rz_old;
+      for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+    }
+    spmv(A, p, q);
+    double pq = dot(n, p, q);
+    double alpha = rz / pq;
+    for (int64_t i = 0; i < n; ++i) x[i] += alpha * p[i];
+    for (int64_t i = 0; i < n; ++i) r[i] -= alpha * q[i];
+    pc_apply(A, s->pc, r, z);
+    rz_old = rz;
+    rz = dot(n, r, z);
+    ++it;
+  }
+  s->last_its = it;
+  return 0;
+}
+
+/* [ext PETSc] KSPCHEBYSHEV (cheby.c), eigenvalue bounds [emin, emax] of the
+ * preconditioned operator given by the user
+ * (-ksp_chebyshev_eigenvalues, demo_navier-stokes-pcd.py:163), zero initial
+ * guess, no norms: one initial preconditioner application, then max_it
+ * three-term updates
+ *   p_{k+1} = (1-omega) p_{k-1} + omega p_k + omega*scale * B (b - A p_k). */
+static int solve_cheb(const csr_t *A, inner_t *s, const double *b, double *x,
+                      double *pa, double *pb, double *pc_, double *r) {
+  int64_t n = A->nrows;
+  double scale = 2.0 / (s->emax + s->emin);
+  double alpha = 1.0 - scale * s->emin;
+  double mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
+  double c_km1 = 1.0, c_k = mu;
+  double *pkm1 = pa, *pk = pb, *pkp1 = pc_;
+  memset(pkm1, 0, sizeof(double) * n);
+  pc_apply(A, s->pc, b, pk);
+  for (int64_t i = 0; i < n; ++i) pk[i] = scale * pk[i] + pkm1[i];
+  for (int it = 0; it < s->max_it; ++it) {
+    double c_kp1 = 2.0 * mu * c_k - c_km1;
+    double omega = omegaprod * c_k / c_kp1;
+    spmv(A, pk, r);
+    for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
+    pc_apply(A, s->pc, r, pkp1);
+    for (int64_t i = 0; i < n; ++i)
+      pkp1[i] = (1.0 - omega) * pkm1[i] + omega * pk[i]
+                + omega * scale * pkp1[i];
+    double *t = pkm1; pkm1 = pk; pk = pkp1; pkp1 = t;
+    c_km1 = c_k; c_k = c_kp1;
+  }
+  memcpy(x, pk, sizeof(double) * n);
+  s->last_its = s->max_it;
+  return 0;
+}
+
+/* [ext PETSc] KSPRICHARDSON, scale 1, zero guess: x += B (b - A x) */
+static int solve_rich(const csr_t *A, inner_t *s, const double *b, double *x,
+                      double *r, double *z) {
+  int64_t n = A->nrows;
+  memset(x, 0, sizeof(double) * n);
+  for (int it = 0; it < s->max_it; ++it) {
+    if (it == 0)
+      memcpy(r, b, sizeof(double) * n);
+    else {
+      spmv(A, x, r);
+      for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
+    }
+    pc_apply(A, s->pc, r, z);
+    for (int64_t i = 0; i < n; ++i) x[i] += z[i];
+  }
+  s->last_its = s->max_it;
+  return 0;
+}
+
+static const int slot_mat[SLOT_COUNT] = {MAT_AP, MAT_MP, MAT_RP, MAT_A00};
+
+/* KSP.solve(b, x); b and x must not alias */
+static int inner_solve(pcdo_t *h, int slot, const double *b, double *x) {
+  csr_t *A = &h->mat[slot_mat[slot]];
+  inner_t *s = &h->inner[slot];
+  if (!A->set) return fail(4, "inner_solve: operator not set");
+  int64_t n = A->nrows;
+  double *t0 = (double *)malloc(sizeof(double) * n * 4);
+  double *t1 = t0 + n, *t2 = t1 + n, *t3 = t2 + n;
+  int rc = 0;
+  switch (s->ksp) {
+    case KSP_PREONLY: pc_apply(A, s->pc, b, x); s->last_its = 1; break;
+    case KSP_RICHARDSON: rc = solve_rich(A, s, b, x, t0, t1); break;
+    case KSP_CHEBYSHEV: rc = solve_cheb(A, s, b, x, t0, t1, t2, t3); break;
+    case KSP_CG: rc = solve_cg(A, s, b, x, t0, t1, t2, t3); break;
+    default: rc = fail(1, "unknown ksp type");
+  }
+  free(t0);
+  return rc;
+}
+
+/* --------------------------------------------------------------- public */
+int pcdo_create(pcdo_t **out, int variant, int device) {
+  (void)device;
+  if (variant < BRM1 || variant > RBRM2) return fail(1, "bad variant");
+  pcdo_t *h = (pcdo_t *)calloc(1, sizeof *h);
+  h->variant = variant;
+  for (int s = 0; s < SLOT_COUNT; ++s) {
+    /* reference default is an exact factorisation (preconditioners.py:42-49),
+     * which has no counterpart here: default to tightly converged PCG */
+    h->inner[s].ksp = KSP_CG; h->inner[s].pc = PC_JACOBI;
+    h->inner[s].max_it = 10000; h->inner[s].rtol = 1e-12;
+    h->inner[s].emin = 0.5; h->inner[s].emax = 2.0;
+  }
+  *out = h;
+  return 0;
+}
+
+int pcdo_destroy(pcdo_t *h) {
+  if (!h) return 0;
+  for (int m = 0; m < MAT_COUNT; ++m) csr_free(&h->mat[m]);
+  free(h->bc_idx); free(h->bc_val); free(h->perm);
+  for (int i = 0; i < 8; ++i) free(h->w[i]);
+  for (int i = 0; i < 4; ++i) free(h->wu[i]);
+  for (int i = 0; i < 2; ++i) free(h->ws[i]);
+  free(h);
+  return 0;
+}
+
+static int csr_store(csr_t *m, int64_t nrows, int64_t ncols,
+                     const int32_t *rowptr, const int32_t *col,
+                     const double *val) {
+  csr_free(m);
+  int64_t nnz = rowptr[nrows];
+  m->nrows = nrows; m->ncols = ncols; m->nnz = nnz;
+  m->rowptr = (int32_t *)malloc(sizeof(int32_t) * (nrows + 1));
+  m->col = (int32_t *)malloc(sizeof(int32_t) * (nnz ? nnz : 1));
+  m->val = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+  memcpy(m->rowptr, rowptr, sizeof(int32_t) * (nrows + 1));
+  memcpy(m->col, col, sizeof(int32_t) * nnz);
+  if (val) memcpy(m->val, val, sizeof(double) * nnz);
+  m->set = 1;
+  return 0;
+}
+
+int pcdo_set_csr(pcdo_t *h, int which, int64_t nrows, int64_t ncols,
+                 const int32_t *rowptr, const int32_t *col,
+                 const double *val) {
+  if (which < 0 || which >= MAT_A) return fail(1, "set_csr: bad operator");
+  csr_store(&h->mat[which], nrows, ncols, rowptr, col, val);
+  csr_diag(&h->mat[which]);
+  h->ready = 0;
+  return 0;
+}
+
+int pcdo_update_values(pcdo_t *h, int which, const double *val, int mem) {
+  (void)mem;
+  if (which < 0 || which >= MAT_A || !h->mat[which].set)
+    return fail(4, "update_values: operator not set");
+  memcpy(h->mat[which].val, val, sizeof(double) * h->mat[which].nnz);
+  csr_diag(&h->mat[which]);
+  return 0;
+}
+
+/* [ext PETSc] MatCreateSubMatrix on (is_r, is_c) plus value provenance */
+static void extract_block(csr_t *out, int64_t n, const int32_t *rowptr,
+                          const int32_t *col, const int32_t *rows,
+                          int64_t nr, const int32_t *colmap /* caller->local
+                          or -1 */, int64_t nc) {
+  csr_free(out);
+  out->nrows = nr; out->ncols = nc;
+  out->rowptr = (int32_t *)malloc(sizeof(int32_t) * (nr + 1));
+  int64_t nnz = 0;
+  for (int64_t i = 0; i < nr; ++i)
+    for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k)
+      if (colmap[col[k]] >= 0) ++nnz;
+  out->nnz = nnz;
+  out->col = (int32_t *)malloc(sizeof(int32_t) * (nnz ? nnz : 1));
+  out->val = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+  out->src = (int64_t *)malloc(sizeof(int64_t) * (nnz ? nnz : 1));
+  int64_t p = 0;
+  for (int64_t i = 0; i < nr; ++i) {
+    out->rowptr[i] = (int32_t)p;
+    int64_t start = p;
+    for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k) {
+      int32_t c = colmap[col[k]];
+      if (c < 0) continue;
+      /* insertion sort by local column keeps rows sorted */
+      int64_t q = p;
+      while (q > start && out->col[q - 1] > c) {
+        out->col[q] = out->col[q - 1]; out->src[q] = out->src[q - 1]; --q;
+      }
+      out->col[q] = c; out->src[q] = k; ++p;
+    }
+  }
+  out->rowptr[nr] = (int32_t)p;
+  out->set = 1;
+  (void)n;
+}
+
+static void block_values(csr_t *m, const double *vals) {
+  for (int64_t k = 0; k < m->nnz; ++k) m->val[k] = vals[m->src[k]];
+}
+
+int pcdo_update_system(pcdo_t *h, const double *vals, const double *pvals,
+                       int mem) {
+  (void)mem;
+  if (!h->mat[MAT_A].set) return fail(4, "update_system: no system set");
+  block_values(&h->mat[MAT_A], vals);
+  block_values(&h->mat[MAT_A00], pvals ? pvals : vals);
+  block_values(&h->mat[MAT_A01], pvals ? pvals : vals);
+  csr_diag(&h->mat[MAT_A00]);
+  return 0;
+}
+
+int pcdo_set_system(pcdo_t *h, int64_t n, const int32_t *rowptr,
+                    const int32_t *col, const double *vals,
+                    const double *pvals, int64_t n_u, const int32_t *is_u,
+                    int64_t n_p, const int32_t *is_p) {
+  if (n_u + n_p != n) return fail(1, "set_system: n_u + n_p != n");
+  h->n_u = n_u; h->n_p = n_p; h->sys_nnz = rowptr[n];
+  free(h->perm);
+  h->perm = (int32_t *)malloc(sizeof(int32_t) * n);
+  memcpy(h->perm, is_u, sizeof(int32_t) * n_u);
+  memcpy(h->perm + n_u, is_p, sizeof(int32_t) * n_p);
+  int32_t *mu = (int32_t *)malloc(sizeof(int32_t) * n);
+  int32_t *mp = (int32_t *)malloc(sizeof(int32_t) * n);
+  int32_t *ma = (int32_t *)malloc(sizeof(int32_t) * n);
+  for (int64_t i = 0; i < n; ++i) mu[i] = mp[i] = ma[i] = -1;
+  for (int64_t i = 0; i < n_u; ++i) { mu[is_u[i]] = (int32_t)i; }
+  for (int64_t i = 0; i < n_p; ++i) { mp[is_p[i]] = (int32_t)i; }
+  for (int64_t i = 0; i < n; ++i) ma[h->perm[i]] = (int32_t)i;
+  for (int64_t i = 0; i < n; ++i)
+    if (ma[i] < 0) { free(mu); free(mp); free(ma);
+      return fail(1, "set_system: index sets do not cover 0..n-1"); }
+  extract_block(&h->mat[MAT_A00], n, rowptr, col, is_u, n_u, mu, n_u);
+  extract_block(&h->mat[MAT_A01], n, rowptr, col, is_u, n_u, mp, n_p);
+  extract_block(&h->mat[MAT_A], n, rowptr, col, h->perm, n, ma, n);
+  free(mu); free(mp); free(ma);
+  h->ready = 0;
+  return pcdo_update_system(h, vals, pvals, 0);
+}
+
+int pcdo_set_bc(pcdo_t *h, int64_t n_bc, const int32_t *idx,
+                const double *vals) {
+  free(h->bc_idx); free(h->bc_val);
+  h->n_bc = n_bc;
+  h->bc_idx = (int32_t *)malloc(sizeof(int32_t) * (n_bc ? n_bc : 1));
+  h->bc_val = (double *)malloc(sizeof(double) * (n_bc ? n_bc : 1));
+  memcpy(h->bc_idx, idx, sizeof(int32_t) * n_bc);
+  memcpy(h->bc_val, vals, sizeof(double) * n_bc);
+  return 0;
+}
+
+int pcdo_set_inner(pcdo_t *h, int slot, int ksp, int pc, int max_it,
+                   double rtol, double emin, double emax) {
+  if (slot < 0 || slot >= SLOT_COUNT) return fail(1, "set_inner: bad slot");
+  if (ksp < KSP_PREONLY || ksp > KSP_CG) return fail(1, "set_inner: bad ksp");
+  if (pc != PC_NONE && pc != PC_JACOBI) return fail(1, "set_inner: bad pc");
+  if (ksp == KSP_CHEBYSHEV && !(emax > emin && emin > 0.0))
+    return fail(1, "set_inner: chebyshev needs 0 < emin < emax");
+  inner_t *s = &h->inner[slot];
+  s->ksp = ksp; s->pc = pc; s->max_it = max_it; s->rtol = rtol;
+  s->emin = emin; s->emax = emax;
+  return 0;
+}
+
+int pcdo_setup(pcdo_t *h) {
+  if (!h->mat[MAT_AP].set || !h->mat[MAT_MP].set || !h->mat[MAT_KP].set)
+    return fail(4, "setup: Ap, Mp and Kp are required");
+  if (h->variant >= RBRM1 && !h->mat[MAT_RP].set)
+    return fail(4, "setup: PCDR variants require Rp");
+  int64_t np = h->mat[MAT_AP].nrows;
+  if (h->n_p && h->n_p != np) return fail(1, "setup: n_p mismatch");
+  h->n_p = np;
+  for (int i = 0; i < 8; ++i) {
+    free(h->w[i]); h->w[i] = (double *)calloc(np ? np : 1, sizeof(double));
+  }
+  if (h->mat[MAT_A00].set) {
+    int64_t nu = h->mat[MAT_A00].nrows;
+    h->n_u = nu;
+    for (int i = 0; i < 4; ++i) {
+      free(h->wu[i]); h->wu[i] = (double *)calloc(nu ? nu : 1, sizeof(double));
+    }
+    for (int i = 0; i < 2; ++i) {
+      free(h->ws[i]);
+      h->ws[i] = (double *)calloc(nu + np ? nu + np : 1, sizeof(double));
+    }
+  }
+  h->ready = 1;
+  return 0;
+}
+
+/* SubfieldBC::apply_subfield_bc: VecSetValues(..., INSERT_VALUES) */
+static void apply_bc(const pcdo_t *h, double *x) {
+  for (int64_t i = 0; i < h->n_bc; ++i) x[h->bc_idx[i]] = h->bc_val[i];
+}
+
+int pcdo_apply_bc(pcdo_t *h, double *x, int mem) {
+  (void)mem; apply_bc(h, x); return 0;
+}
+
+/* The four apply bodies.  Comments quote the reference line being restated. */
+static int pcd_apply_core(pcdo_t *h, const double *x, double *y) {
+  int64_t n = h->n_p;
+  int rc = 0;
+  if (h->variant == BRM1 || h->variant == RBRM1) {
+    double *z = h->w[0];                            /* get_work_vecs(x, 1) */
+    memcpy(z, x, sizeof(double) * n);               /* x.copy(result=z)    */
+    apply_bc(h, z);                                 /* bcs_applier(z)      */
+    if ((rc = inner_solve(h, SLOT_AP, z, y))) return rc; /* y = Ap^-1 z   */
+    spmv(&h->mat[MAT_KP], y, z);                    /* z = Kp y            */
+    for (int64_t i = 0; i < n; ++i) z[i] += 1.0 * x[i]; /* z.axpy(1, x)   */
+    if ((rc = inner_solve(h, SLOT_MP, z, y))) return rc; /* y = Mp^-1 z   */
+    if (h->variant == RBRM1) {
+      if ((rc = inner_solve(h, SLOT_RP, x, z))) return rc; /* z = Rp^-1 x */
+      for (int64_t i = 0; i < n; ++i) y[i] += 1.0 * z[i];  /* y.axpy(1,z) */
+    }
+    for (int64_t i = 0; i < n; ++i) y[i] *= -1.0;   /* y.scale(-1)         */
+  } else {
+    double *z0 = h->w[0], *z1 = h->w[1];            /* get_work_vecs(x, 2) */
+    if ((rc = inner_solve(h, SLOT_MP, x, y))) return rc; /* y = Mp^-1 x   */
+    memcpy(z0, y, sizeof(double) * n);              /* y.copy(result=z0)   */
+    spmv(&h->mat[MAT_KP], z0, z1);                  /* z1 = Kp z0          */
+    apply_bc(h, z1);                                /* bcs_applier(z1)     */
+    if ((rc = inner_solve(h, SLOT_AP, z1, z0))) return rc; /* z0=Ap^-1 z1 */
+    for (int64_t i = 0; i < n; ++i) y[i] += 1.0 * z0[i]; /* y.axpy(1,z0)  */
+    if (h->variant == RBRM2) {
+      if ((rc = inner_solve(h, SLOT_RP, x, z0))) return rc; /* z0=Rp^-1 x */
+      for (int64_t i = 0; i < n; ++i) y[i] += 1.0 * z0[i];
+    }
+    for (int64_t i = 0; i < n; ++i) y[i] *= -1.0;   /* y.scale(-1)         */
+  }
+  ++h->num_pcd;
+  return 0;
+}
+
+int pcdo_apply(pcdo_t *h, const double *x, double *y, int mem) {
+  (void)mem;
+  if (!h->ready) return fail(4, "apply: call setup first");
+  return pcd_apply_core(h, x, y);
+}
+
+/* [ext PETSc] PCApply_FieldSplit_Schur, UPPER, on split-ordered vectors */
+static int fs_apply_split(pcdo_t *h, const double *x, double *y) {
+  int64_t nu = h->n_u, np = h->n_p;
+  const double *xu = x, *xp = x + nu;
+  double *yu = y, *yp = y + nu, *t = h->wu[0];
+  int rc;
+  if ((rc = pcd_apply_core(h, xp, yp))) return rc;      /* y_p = S^-1 x_p */
+  spmv(&h->mat[MAT_A01], yp, t);
+  for (int64_t i = 0; i < nu; ++i) t[i] = xu[i] - t[i]; /* x_u - A01 y_p  */
+  if ((rc = inner_solve(h, SLOT_A00, t, yu))) return rc; /* A00^-1 (...)  */
+  ++h->num_fs;
+  return 0;
+}
+
+int pcdo_fieldsplit_apply(pcdo_t *h, const double *x, double *y, int mem) {
+  (void)mem;
+  if (!h->ready || !h->mat[MAT_A00].set)
+    return fail(4, "fieldsplit_apply: system/setup missing");
+  int64_t n = h->n_u + h->n_p;
+  double *xs = h->ws[0], *ys = h->ws[1];
+  for (int64_t i = 0; i < n; ++i) xs[i] = x[h->perm[i]];
+  int rc = fs_apply_split(h, xs, ys);
+  if (rc) return rc;
+  for (int64_t i = 0; i < n; ++i) y[h->perm[i]] = ys[i];
+  return 0;
+}
+
+/* [ext PETSc] KSPGMRES: restart m, right preconditioning, classical
+ * Gram-Schmidt without refinement, zero initial guess, true-residual test
+ * ||r|| <= max(rtol*||b||, atol) on the recurrence estimate. */
+int pcdo_gmres_solve(pcdo_t *h, const double *b, double *x, int mem,
+                     double rtol, double atol, int m, int max_it, int *its,
+                     double *rnorm) {
+  (void)mem;
+  if (!h->ready || !h->mat[MAT_A].set)
+    return fail(4, "gmres_solve: system/setup missing");
+  int64_t n = h->n_u + h->n_p;
+  double *V = (double *)malloc(sizeof(double) * n * (m + 1));
+  double *H = (double *)calloc((size_t)(m + 1) * m, sizeof(double));
+  double *cs = (double *)calloc(m, sizeof(double));
+  double *sn = (double *)calloc(m, sizeof(double));
+  double *g = (double *)calloc(m + 1, sizeof(double));
+  double *yk = (double *)calloc(m, sizeof(double));
+  double *xs = (double *)calloc(n, sizeof(double));
+  double *bs = (double *)malloc(sizeof(double) * n);
+  double *z = (double *)malloc(sizeof(double) * n);
+  double *w = (double *)malloc(sizeof(double) * n);
+  for (int64_t i = 0; i < n; ++i) bs[i] = b[h->perm[i]];
+  double bnorm = sqrt(dot(n, bs, bs));
+  double tol = rtol * bnorm; if (atol > tol) tol = atol;
+  int it = 0, rc = 0; double res = bnorm;
+  memcpy(w, bs, sizeof(double) * n);               /* r0 = b (x0 = 0) */
+  while (it < max_it && res > tol) {
+    double beta = sqrt(dot(n, w, w));
+    res = beta;
+    if (beta <= tol) break;
+    for (int64_t i = 0; i < n; ++i) V[i] = w[i] / beta;
+    memset(g, 0, sizeof(double) * (m + 1)); g[0] = beta;
+    int k = 0;
+    for (; k < m && it < max_it; ++k) {
+      double *vk = V + (size_t)k * n, *vn = V + (size_t)(k + 1) * n;
+      if ((rc = fs_apply_split(h, vk, z))) goto done;  /* z = M^-1 v_k */
+      spmv(&h->mat[MAT_A], z, vn);                     /* w = A z      */
+      double *hc = H + (size_t)k * (m + 1);
+      for (int j = 0; j <= k; ++j) hc[j] = dot(n, V + (size_t)j * n, vn);
+      for (int j = 0; j <= k; ++j) {
+        const double *vj = V + (size_t)j * n; double hj = hc[j];
+        for (int64_t i = 0; i < n; ++i) vn[i] -= hj * vj[i];
+      }
+      double hn = sqrt(dot(n, vn, vn));
+      hc[k + 1] = hn;
+      if (hn != 0.0) for (int64_t i = 0; i < n; ++i) vn[i] /= hn;
+      for (int j = 0; j < k; ++j) {                    /* old rotations */
+        double t = cs[j] * hc[j] + sn[j] * hc[j + 1];
+        hc[j + 1] = -sn[j] * hc[j] + cs[j] * hc[j + 1]; hc[j] = t;
+      }
+      double d = hypot(hc[k], hc[k + 1]);
+      cs[k] = hc[k] / d; sn[k] = hc[k + 1] / d;
+      hc[k] = d; hc[k + 1] = 0.0;
+      g[k + 1] = -sn[k] * g[k]; g[k] = cs[k] * g[k];
+      res = fabs(g[k + 1]);
+      ++it;
+      if (res <= tol || hn == 0.0) { ++k; break; }
+    }
+    /* y = H^-1 g; x += M^-1 (V y)  (KSPGMRESBuildSoln + unwind right PC) */
+    for (int i = k - 1; i >= 0; --i) {
+      double s = g[i];
+      for (int j = i + 1; j < k; ++j) s -= H[(size_t)j * (m + 1) + i] * yk[j];
+      yk[i] = s / H[(size_t)i * (m + 1) + i];
+    }
+    memset(w, 0, sizeof(double) * n);
+    for (int j = 0; j < k; ++j) {
+      const double *vj = V + (size_t)j * n;
+      for (int64_t i = 0; i < n; ++i) w[i] += yk[j] * vj[i];
+    }
+    if ((rc = fs_apply_split(h, w, z))) goto done;
+    for (int64_t i = 0; i < n; ++i) xs[i] += z[i];
+    if (res <= tol || it >= max_it) break;
+    spmv(&h->mat[MAT_A], xs, z);                       /* restart: true r */
+    for (int64_t i = 0; i < n; ++i) w[i] = bs[i] - z[i];
+  }
+done:
+  for (int64_t i = 0; i < n; ++i) x[h->perm[i]] = xs[i];
+  h->gmres_its = it; h->gmres_rnorm = res;
+  if (its) *its = it;
+  if (rnorm) *rnorm = res;
+  free(V); free(H); free(cs); free(sn); free(g); free(yk); free(xs);
+  free(bs); free(z); free(w);
+  return rc;
+}
+
+int pcdo_spmv(pcdo_t *h, int which, const double *x, double *y, int mem) {
+  (void)mem;
+  if (which < 0 || which >= MAT_COUNT || !h->mat[which].set)
+    return fail(4, "spmv: operator not set");
+  spmv(&h->mat[which], x, y);
+  return 0;
+}
+
+int pcdo_inner_solve(pcdo_t *h, int slot, const double *b, double *x,
+                     int mem) {
+  (void)mem;
+  if (slot < 0 || slot >= SLOT_COUNT) return fail(1, "inner_solve: bad slot");
+  return inner_solve(h, slot, b, x);
+}
+
+int pcdo_get_info(pcdo_t *h, int key, double *out) {
+  switch (key) {
+    case 0: *out = (double)h->n_u; break;
+    case 1: *out = (double)h->n_p; break;
+    case 2: case 3: case 4: case 5:
+      *out = (double)h->inner[key - 2].last_its; break;
+    case 6: *out = (double)h->num_pcd; break;
+    case 7: *out = (double)h->num_fs; break;
+    case 8: *out = (double)h->gmres_its; break;
+    case 9: *out = h->gmres_rnorm; break;
+    default:
+      if (key >= 16 && key < 16 + MAT_COUNT) {
+        *out = (double)h->mat[key - 16].nnz; break;
+      }
+      return fail(1, "get_info: bad key");
+  }
+  return 0;
+}
+
+int pcdo_synchronize(pcdo_t *h) { (void)h; return 0; }
