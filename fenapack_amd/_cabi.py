@@ -58,7 +58,6 @@ _SIGNATURES = {
 _HIP_ONLY = {
     "set_stream": [C.c_void_p],
     "comm_init": [C.c_int, C.c_int, C.c_void_p],
-    "set_partition": [C.c_int64, C.c_int64, C.c_int64, C.c_int64],
     "graph_enable": [C.c_int],
 }
 

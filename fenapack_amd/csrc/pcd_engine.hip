@@ -1,0 +1,912 @@
+// pcd_engine.hip - host side of the MI355X PCD engine and its C ABI
+// (include/pcd_engine.h).  One handle drives one GPU; all work of the hot path
+// is enqueued on one HIP stream without host synchronisation unless an inner
+// solver was given a relative tolerance (then the host peeks at a device flag
+// every few iterations) or the caller hands over host pointers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pcd_engine.h"
+#include "pcd_kernels.hpp"
+
+using namespace pcd;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(expr)                                                        \
+  do {                                                                      \
+    hipError_t e_ = (expr);                                                 \
+    if (e_ != hipSuccess)                                                   \
+      return fail(PCD_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                  hipGetErrorString(e_));                                   \
+  } while (0)
+
+#define CHK(expr)              \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_) return rc_;       \
+  } while (0)
+
+// ------------------------------------------------------------ device data
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess)
+      return fail(PCD_ERR_NOMEM, "hipMalloc(%zu B): %s", count * sizeof(T),
+                  hipGetErrorString(e));
+    n = count;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+  }
+};
+
+struct DCsr {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  DBuf<int> rowptr, col;
+  DBuf<double> val, dinv;
+  DBuf<int64_t> src;      // provenance in the caller's monolithic values
+  bool has_src = false;
+  bool set = false;
+  int lpr = 8;
+  void release() {
+    rowptr.release(); col.release(); val.release(); dinv.release();
+    src.release(); set = false; nrows = ncols = nnz = 0; has_src = false;
+  }
+};
+
+struct Inner {
+  int ksp = PCD_KSP_CG, pc = PCD_PC_JACOBI, max_it = 10000;
+  double rtol = 1e-12, emin = 0.5, emax = 2.0;
+  // device scratch, sized at setup
+  DBuf<double> t0, t1, t2, t3;       // r,z,p,q  or the Chebyshev ring
+  DBuf<double> parts;                // 3 * kMaxParts
+  DBuf<CgState> state;
+  int last_its = 0;
+  bool its_on_device = false;
+  void release() {
+    t0.release(); t1.release(); t2.release(); t3.release();
+    parts.release(); state.release();
+  }
+};
+
+struct pcd_engine_s {
+  int variant = PCD_BRM1;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DCsr mat[PCD_MAT_COUNT];
+  Inner inner[PCD_KSP_COUNT];
+  int64_t n_bc = 0;
+  DBuf<int> bc_idx;
+  std::vector<int32_t> bc_host;
+  DBuf<double> bc_val;
+  int64_t n_u = 0, n_p = 0, sys_nnz = 0;
+  DBuf<int> perm;                     // split position -> caller's index
+  DBuf<double> sysvals, psysvals;     // staging of the caller's value arrays
+  bool ready = false;
+  DBuf<double> w[2];                  // pressure work vectors (get_work_vecs)
+  DBuf<double> wu;                    // velocity work vector
+  DBuf<double> xs, ys;                // split-ordered in/out
+  DBuf<double> io_x, io_y;            // staging for host-pointer calls
+  // GMRES
+  DBuf<double> V, gz, gw, gparts, gh, gy, gxs, gbs;
+  int64_t V_ld = 0;
+  int V_m = 0;
+  double* pinned = nullptr;           // host-pinned scratch
+  size_t pinned_n = 0;
+  long num_pcd = 0, num_fs = 0;
+  int gmres_its = 0;
+  double gmres_rnorm = 0.0;
+};
+
+typedef pcd_engine_s Engine;
+
+static const int kSlotMat[PCD_KSP_COUNT] = {PCD_MAT_AP, PCD_MAT_MP, PCD_MAT_RP,
+                                            PCD_MAT_A00};
+
+static inline int grid1d(int64_t n, int per_thread = 1, int cap = 8192) {
+  int64_t g = (n + (int64_t)kBlock * per_thread - 1) / ((int64_t)kBlock * per_thread);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+static inline int grid_rows(int64_t nrows, int lpr, int cap = 16384) {
+  int rpb = kBlock / lpr;
+  int64_t g = (nrows + rpb - 1) / rpb;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+
+static int choose_lpr(const DCsr& A) {
+  double avg = A.nrows ? (double)A.nnz / (double)A.nrows : 1.0;
+  int l = 4;
+  while (l < 32 && l < avg) l *= 2;
+  return l;
+}
+
+static int ensure_pinned(Engine* h, size_t n) {
+  if (n <= h->pinned_n) return 0;
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  h->pinned = nullptr; h->pinned_n = 0;
+  HIPCHK(hipHostMalloc((void**)&h->pinned, n * sizeof(double)));
+  h->pinned_n = n;
+  return 0;
+}
+
+// --------------------------------------------------------------- launches
+#define LAUNCH_LPR(A, KERNEL, GRID, ...)                                        \
+  do {                                                                          \
+    switch ((A).lpr) {                                                          \
+      case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(GRID), dim3(kBlock), 0,      \
+                                 h->stream, __VA_ARGS__); break;                \
+      case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(GRID), dim3(kBlock), 0,      \
+                                 h->stream, __VA_ARGS__); break;                \
+      case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(GRID), dim3(kBlock), 0,    \
+                                  h->stream, __VA_ARGS__); break;               \
+      default: hipLaunchKernelGGL((KERNEL<32>), dim3(GRID), dim3(kBlock), 0,    \
+                                  h->stream, __VA_ARGS__); break;               \
+    }                                                                           \
+  } while (0)
+
+template <int MODE>
+static void launch_spmv_mode(Engine* h, const DCsr& A, const double* x,
+                             const double* add, double* y) {
+  const int g = grid_rows(A.nrows, A.lpr);
+  switch (A.lpr) {
+    case 4: hipLaunchKernelGGL((k_spmv<4, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                               (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+    case 8: hipLaunchKernelGGL((k_spmv<8, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                               (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+    case 16: hipLaunchKernelGGL((k_spmv<16, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+    default: hipLaunchKernelGGL((k_spmv<32, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+  }
+}
+
+// y = A x (mode 0) | add + A x (1) | add - A x (2)
+static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
+                int mode = 0, const double* add = nullptr) {
+  if (!A.set) return fail(PCD_ERR_STATE, "spmv: operator not set");
+  if (mode == 0) launch_spmv_mode<0>(h, A, x, add, y);
+  else if (mode == 1) launch_spmv_mode<1>(h, A, x, add, y);
+  else launch_spmv_mode<2>(h, A, x, add, y);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int refresh_dinv(Engine* h, DCsr& A) {
+  if (A.nrows != A.ncols) return 0;
+  CHK(A.dinv.ensure(A.nrows));
+  hipLaunchKernelGGL(k_dinv, dim3(grid1d(A.nrows, 1, 1 << 30)), dim3(kBlock), 0,
+                     h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p,
+                     A.dinv.p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------ inner KSPs
+static int inner_prepare(Engine* h, int slot) {
+  Inner& s = h->inner[slot];
+  const DCsr& A = h->mat[kSlotMat[slot]];
+  if (!A.set) return 0;
+  const size_t n = A.nrows;
+  switch (s.ksp) {
+    case PCD_KSP_CG:
+      CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n)); CHK(s.t2.ensure(n));
+      CHK(s.t3.ensure(n)); CHK(s.parts.ensure(3 * kMaxParts));
+      CHK(s.state.ensure(1));
+      break;
+    case PCD_KSP_CHEBYSHEV:
+      CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n));
+      break;
+    case PCD_KSP_RICHARDSON:
+      CHK(s.t0.ensure(n));
+      break;
+    default: break;
+  }
+  return 0;
+}
+
+static int solve_cg(Engine* h, const DCsr& A, Inner& s, const double* b,
+                    double* x) {
+  const int n = (int)A.nrows;
+  const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
+  double *r = s.t0.p, *z = s.t1.p, *p = s.t2.p, *q = s.t3.p;
+  double* R[2] = {s.parts.p, s.parts.p + kMaxParts};
+  double* PQ = s.parts.p + 2 * kMaxParts;
+  CgState* st = s.state.p;
+  const int ge = grid1d(n, 4, kMaxParts);               // element-wise grid
+  const int gs = grid_rows(n, A.lpr, kMaxParts);        // SpMV + dot grid
+  hipLaunchKernelGGL(k_cg_init, dim3(ge), dim3(kBlock), 0, h->stream, n, dinv,
+                     b, x, r, z, p, R[0], st);
+  const int check = 16;
+  for (int it = 0; it < s.max_it; ++it) {
+    if (it > 0)
+      hipLaunchKernelGGL(k_cg_pupdate, dim3(ge), dim3(kBlock), 0, h->stream, n,
+                         z, p, R[it & 1], R[(it - 1) & 1], ge, s.rtol, st);
+    LAUNCH_LPR(A, k_cg_spmv_dot, gs, n, A.rowptr.p, A.col.p, A.val.p, p, q, PQ,
+               st);
+    hipLaunchKernelGGL(k_cg_update, dim3(ge), dim3(kBlock), 0, h->stream, n,
+                       dinv, p, q, x, r, z, R[it & 1], ge, PQ, gs,
+                       R[(it + 1) & 1], it, st);
+    if (s.rtol > 0.0 && (it % check) == check - 1 && it + 1 < s.max_it) {
+      CHK(ensure_pinned(h, 8));
+      int* flag = reinterpret_cast<int*>(h->pinned);
+      HIPCHK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost,
+                            h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (*flag) break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  s.its_on_device = true;
+  return 0;
+}
+
+// [ext PETSc] KSPCHEBYSHEV recurrence coefficients are data independent, so
+// the host computes them and every step is one fused launch.
+static int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
+                      double* x) {
+  const int n = (int)A.nrows;
+  const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
+  const double scale = 2.0 / (s.emax + s.emin);
+  const double alpha = 1.0 - scale * s.emin;
+  const double mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
+  double c_km1 = 1.0, c_k = mu;
+  // ring of three vectors arranged so that the last update lands in x
+  double* ring[3];
+  const int m = s.max_it;
+  ring[m % 3] = x; ring[(m + 1) % 3] = s.t0.p; ring[(m + 2) % 3] = s.t1.p;
+  const int g1 = grid1d(n, 1);
+  hipLaunchKernelGGL(k_scale_dinv, dim3(g1), dim3(kBlock), 0, h->stream, n,
+                     dinv, b, scale, ring[0]);
+  const int gs = grid_rows(n, A.lpr);
+  for (int it = 0; it < m; ++it) {
+    const double c_kp1 = 2.0 * mu * c_k - c_km1;
+    const double omega = omegaprod * c_k / c_kp1;
+    double* pk = ring[it % 3];
+    double* pn = ring[(it + 1) % 3];
+    // p_{-1} = 0 at the first step: coefficient forced to zero, never read
+    double* pm = (it == 0) ? pk : ring[(it + 2) % 3];
+    const double c0 = (it == 0) ? 0.0 : 1.0 - omega;
+    LAUNCH_LPR(A, k_cheb_step, gs, n, A.rowptr.p, A.col.p, A.val.p, dinv, b, pm,
+               pk, pn, c0, omega, omega * scale);
+    c_km1 = c_k; c_k = c_kp1;
+  }
+  HIPCHK(hipGetLastError());
+  s.last_its = m; s.its_on_device = false;
+  return 0;
+}
+
+static int solve_rich(Engine* h, const DCsr& A, Inner& s, const double* b,
+                      double* x) {
+  const int n = (int)A.nrows;
+  const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
+  const int m = std::max(s.max_it, 1);
+  // iteration 0 with zero guess is x = B b; then m-1 fused sweeps ping-pong
+  double* bufs[2];
+  bufs[(m - 1) % 2] = x; bufs[m % 2] = s.t0.p;
+  hipLaunchKernelGGL(k_scale_dinv, dim3(grid1d(n, 1)), dim3(kBlock), 0,
+                     h->stream, n, dinv, b, 1.0, bufs[0]);
+  const int gs = grid_rows(n, A.lpr);
+  for (int it = 1; it < m; ++it) {
+    double* pk = bufs[(it - 1) % 2];
+    double* pn = bufs[it % 2];
+    LAUNCH_LPR(A, k_cheb_step, gs, n, A.rowptr.p, A.col.p, A.val.p, dinv, b, pk,
+               pk, pn, 0.0, 1.0, 1.0);
+  }
+  HIPCHK(hipGetLastError());
+  s.last_its = m; s.its_on_device = false;
+  return 0;
+}
+
+// KSP.solve(b, x): b and x must not alias
+static int inner_solve(Engine* h, int slot, const double* b, double* x) {
+  const DCsr& A = h->mat[kSlotMat[slot]];
+  Inner& s = h->inner[slot];
+  if (!A.set) return fail(PCD_ERR_STATE, "inner_solve: operator of slot %d not set", slot);
+  if (b == x) return fail(PCD_ERR_ARG, "inner_solve: b and x alias");
+  switch (s.ksp) {
+    case PCD_KSP_PREONLY: {
+      const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
+      hipLaunchKernelGGL(k_scale_dinv, dim3(grid1d(A.nrows, 1)), dim3(kBlock), 0,
+                         h->stream, (int)A.nrows, dinv, b, 1.0, x);
+      HIPCHK(hipGetLastError());
+      s.last_its = 1; s.its_on_device = false;
+      return 0;
+    }
+    case PCD_KSP_RICHARDSON: return solve_rich(h, A, s, b, x);
+    case PCD_KSP_CHEBYSHEV: return solve_cheb(h, A, s, b, x);
+    case PCD_KSP_CG: return solve_cg(h, A, s, b, x);
+  }
+  return fail(PCD_ERR_ARG, "inner_solve: unknown ksp type %d", s.ksp);
+}
+
+// ---------------------------------------------------------- apply bodies
+static int apply_bc_dev(Engine* h, double* x) {
+  if (h->n_bc == 0) return 0;
+  hipLaunchKernelGGL(k_bc_set, dim3(grid1d(h->n_bc, 1, 1 << 30)), dim3(kBlock), 0,
+                     h->stream, (int)h->n_bc, h->bc_idx.p, h->bc_val.p, x);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The four PCPYTHON apply bodies on device pointers (x, y distinct, n_p long)
+static int pcd_apply_dev(Engine* h, const double* x, double* y) {
+  const int n = (int)h->n_p;
+  const int g = grid1d(n, 1);
+  const bool reaction = h->variant == PCDR_BRM1 || h->variant == PCDR_BRM2;
+  if (h->variant == PCD_BRM1 || h->variant == PCDR_BRM1) {
+    double* z = h->w[0].p;
+    hipLaunchKernelGGL(k_copy, dim3(g), dim3(kBlock), 0, h->stream, n, x, z);  // z = x
+    CHK(apply_bc_dev(h, z));                                   // bcs_applier(z)
+    CHK(inner_solve(h, PCD_KSP_AP, z, y));                      // y = Ap^-1 z
+    CHK(spmv(h, h->mat[PCD_MAT_KP], y, z, 1, x));               // z = Kp y + x
+    CHK(inner_solve(h, PCD_KSP_MP, z, y));                      // y = Mp^-1 z
+    if (reaction) {
+      CHK(inner_solve(h, PCD_KSP_RP, x, z));                    // z = Rp^-1 x
+      hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, -1.0,
+                         z, -1.0, y);                           // y = -(y + z)
+    } else {
+      hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, -1.0,
+                         y, 0.0, y);                            // y = -y
+    }
+  } else {
+    double *z0 = h->w[0].p, *z1 = h->w[1].p;
+    CHK(inner_solve(h, PCD_KSP_MP, x, y));                      // y = Mp^-1 x
+    CHK(spmv(h, h->mat[PCD_MAT_KP], y, z1));                    // z1 = Kp y
+    CHK(apply_bc_dev(h, z1));                                   // bcs_applier(z1)
+    CHK(inner_solve(h, PCD_KSP_AP, z1, z0));                    // z0 = Ap^-1 z1
+    if (reaction) {
+      hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, 1.0, z0,
+                         1.0, y);                               // y += z0
+      CHK(inner_solve(h, PCD_KSP_RP, x, z0));                   // z0 = Rp^-1 x
+    }
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, -1.0, z0,
+                       -1.0, y);                                // y = -(y + z0)
+  }
+  HIPCHK(hipGetLastError());
+  ++h->num_pcd;
+  return 0;
+}
+
+// [ext PETSc] PCApply_FieldSplit_Schur (UPPER) on split-ordered vectors
+static int fs_apply_split(Engine* h, const double* x, double* y) {
+  const int64_t nu = h->n_u;
+  const double *xu = x, *xp = x + nu;
+  double *yu = y, *yp = y + nu, *t = h->wu.p;
+  CHK(pcd_apply_dev(h, xp, yp));                                // y_p = S^-1 x_p
+  CHK(spmv(h, h->mat[PCD_MAT_A01], yp, t, 2, xu));              // t = x_u - A01 y_p
+  CHK(inner_solve(h, PCD_KSP_A00, t, yu));                      // y_u = A00^-1 t
+  ++h->num_fs;
+  return 0;
+}
+
+// ------------------------------------------------------------ host <-> dev
+struct IoMap {
+  Engine* h;
+  const double* dx = nullptr;
+  double* dy = nullptr;
+  double* hy = nullptr;
+  size_t ny = 0;
+  int mem;
+};
+
+static int io_begin(Engine* h, IoMap& io, const double* x, size_t nx, double* y,
+                    size_t ny, int mem, bool y_in = false) {
+  io.h = h; io.mem = mem; io.ny = ny;
+  if (mem == PCD_MEM_DEVICE) { io.dx = x; io.dy = y; return 0; }
+  if (mem != PCD_MEM_HOST) return fail(PCD_ERR_ARG, "bad mem flag %d", mem);
+  if (x) {
+    CHK(h->io_x.ensure(nx));
+    HIPCHK(hipMemcpyAsync(h->io_x.p, x, nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    io.dx = h->io_x.p;
+  }
+  if (y) {
+    CHK(h->io_y.ensure(ny));
+    if (y_in)
+      HIPCHK(hipMemcpyAsync(h->io_y.p, y, ny * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    io.dy = h->io_y.p; io.hy = y;
+  }
+  return 0;
+}
+
+static int io_end(IoMap& io) {
+  if (io.mem == PCD_MEM_DEVICE) return 0;
+  Engine* h = io.h;
+  if (io.hy)
+    HIPCHK(hipMemcpyAsync(io.hy, io.dy, io.ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
+                      const int32_t* rowptr, const int32_t* col,
+                      const double* val, const int64_t* src) {
+  const int64_t nnz = rowptr[nrows];
+  A.nrows = nrows; A.ncols = ncols; A.nnz = nnz;
+  CHK(A.rowptr.ensure(nrows + 1)); CHK(A.col.ensure(nnz)); CHK(A.val.ensure(nnz));
+  HIPCHK(hipMemcpyAsync(A.rowptr.p, rowptr, (nrows + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (nnz) HIPCHK(hipMemcpyAsync(A.col.p, col, nnz * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (val && nnz) HIPCHK(hipMemcpyAsync(A.val.p, val, nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  A.has_src = false;
+  if (src) {
+    CHK(A.src.ensure(nnz));
+    if (nnz) HIPCHK(hipMemcpyAsync(A.src.p, src, nnz * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    A.has_src = true;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));   // host arrays may be freed by the caller
+  A.set = true;
+  A.lpr = choose_lpr(A);
+  return 0;
+}
+
+// ================================================================= C ABI
+extern "C" {
+
+const char* pcd_last_error(void) { return g_err; }
+
+int pcd_create(pcd_handle* out, int variant, int device) {
+  if (!out) return fail(PCD_ERR_ARG, "create: null out");
+  if (variant < PCD_BRM1 || variant > PCDR_BRM2)
+    return fail(PCD_ERR_ARG, "create: bad variant %d", variant);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev)
+    return fail(PCD_ERR_ARG, "create: device %d not in [0,%d)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  Engine* h = new (std::nothrow) Engine();
+  if (!h) return fail(PCD_ERR_NOMEM, "create: out of host memory");
+  h->variant = variant; h->device = device;
+  *out = h;
+  return 0;
+}
+
+int pcd_destroy(pcd_handle h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& m : h->mat) m.release();
+  for (auto& s : h->inner) s.release();
+  h->bc_idx.release(); h->bc_val.release(); h->perm.release();
+  h->sysvals.release(); h->psysvals.release();
+  h->w[0].release(); h->w[1].release(); h->wu.release();
+  h->xs.release(); h->ys.release(); h->io_x.release(); h->io_y.release();
+  h->V.release(); h->gz.release(); h->gw.release(); h->gparts.release();
+  h->gh.release(); h->gy.release(); h->gxs.release(); h->gbs.release();
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  delete h;
+  return 0;
+}
+
+int pcd_set_stream(pcd_handle h, void* hip_stream) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return 0;
+}
+
+int pcd_synchronize(pcd_handle h) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
+                const int32_t* rowptr, const int32_t* colidx,
+                const double* vals) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (which < 0 || which >= PCD_MAT_A)
+    return fail(PCD_ERR_ARG, "set_csr: operator %d cannot be set directly", which);
+  if (!rowptr || (!colidx && rowptr[nrows]) || nrows < 0 || ncols < 0)
+    return fail(PCD_ERR_ARG, "set_csr: bad arrays");
+  if (nrows >= INT32_MAX || ncols >= INT32_MAX)
+    return fail(PCD_ERR_ARG, "set_csr: dimensions exceed int32 indexing");
+  HIPCHK(hipSetDevice(h->device));
+  DCsr& A = h->mat[which];
+  CHK(upload_csr(h, A, nrows, ncols, rowptr, colidx, vals, nullptr));
+  CHK(refresh_dinv(h, A));
+  h->ready = false;
+  return 0;
+}
+
+int pcd_update_values(pcd_handle h, int which, const double* vals, int mem) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (which < 0 || which >= PCD_MAT_A || !h->mat[which].set)
+    return fail(PCD_ERR_STATE, "update_values: operator %d not set", which);
+  DCsr& A = h->mat[which];
+  HIPCHK(hipMemcpyAsync(A.val.p, vals, A.nnz * sizeof(double),
+                        mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                        h->stream));
+  CHK(refresh_dinv(h, A));
+  if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// host-side MatCreateSubMatrix with value provenance
+static void extract_block(int64_t nr, const int32_t* rows, const int32_t* rowptr,
+                          const int32_t* col, const std::vector<int32_t>& colmap,
+                          std::vector<int32_t>& orp, std::vector<int32_t>& oc,
+                          std::vector<int64_t>& osrc) {
+  orp.assign(nr + 1, 0);
+  oc.clear(); osrc.clear();
+  std::vector<std::pair<int32_t, int64_t>> tmp;
+  for (int64_t i = 0; i < nr; ++i) {
+    tmp.clear();
+    for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k) {
+      const int32_t c = colmap[col[k]];
+      if (c >= 0) tmp.emplace_back(c, (int64_t)k);
+    }
+    std::sort(tmp.begin(), tmp.end());
+    for (auto& t : tmp) { oc.push_back(t.first); osrc.push_back(t.second); }
+    orp[i + 1] = (int32_t)oc.size();
+  }
+}
+
+static int gather_block_values(Engine* h, DCsr& A, const double* dvals) {
+  if (!A.nnz) return 0;
+  hipLaunchKernelGGL(k_gather_vals, dim3(grid1d(A.nnz, 4)), dim3(kBlock), 0,
+                     h->stream, A.nnz, A.src.p, dvals, A.val.p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
+                      int mem) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (!h->mat[PCD_MAT_A].set) return fail(PCD_ERR_STATE, "update_system: no system set");
+  if (!vals) return fail(PCD_ERR_ARG, "update_system: null vals");
+  const double *dv = vals, *dp = pvals;
+  if (mem == PCD_MEM_HOST) {
+    CHK(h->sysvals.ensure(h->sys_nnz));
+    HIPCHK(hipMemcpyAsync(h->sysvals.p, vals, h->sys_nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    dv = h->sysvals.p;
+    if (pvals) {
+      CHK(h->psysvals.ensure(h->sys_nnz));
+      HIPCHK(hipMemcpyAsync(h->psysvals.p, pvals, h->sys_nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      dp = h->psysvals.p;
+    }
+  }
+  if (!dp) dp = dv;                      // P = A  (nonlinear_solvers.py:75)
+  CHK(gather_block_values(h, h->mat[PCD_MAT_A], dv));
+  CHK(gather_block_values(h, h->mat[PCD_MAT_A00], dp));
+  CHK(gather_block_values(h, h->mat[PCD_MAT_A01], dp));
+  CHK(refresh_dinv(h, h->mat[PCD_MAT_A00]));
+  if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
+                   const int32_t* colidx, const double* vals,
+                   const double* pvals, int64_t n_u, const int32_t* is_u,
+                   int64_t n_p, const int32_t* is_p) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (!rowptr || !colidx || !vals || !is_u || !is_p)
+    return fail(PCD_ERR_ARG, "set_system: null argument");
+  if (n_u + n_p != n) return fail(PCD_ERR_ARG, "set_system: n_u + n_p != n");
+  if (n >= INT32_MAX) return fail(PCD_ERR_ARG, "set_system: n exceeds int32 indexing");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<int32_t> perm(n), mu(n, -1), mp(n, -1), ma(n, -1);
+  for (int64_t i = 0; i < n_u; ++i) perm[i] = is_u[i];
+  for (int64_t i = 0; i < n_p; ++i) perm[n_u + i] = is_p[i];
+  for (int64_t i = 0; i < n; ++i) {
+    if (perm[i] < 0 || perm[i] >= n || ma[perm[i]] >= 0)
+      return fail(PCD_ERR_ARG, "set_system: index sets do not partition 0..n-1");
+    ma[perm[i]] = (int32_t)i;
+  }
+  for (int64_t i = 0; i < n_u; ++i) mu[is_u[i]] = (int32_t)i;
+  for (int64_t i = 0; i < n_p; ++i) mp[is_p[i]] = (int32_t)i;
+  h->n_u = n_u; h->n_p = n_p; h->sys_nnz = rowptr[n];
+  CHK(h->perm.ensure(n));
+  HIPCHK(hipMemcpy(h->perm.p, perm.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  std::vector<int32_t> rp, cc; std::vector<int64_t> src;
+  extract_block(n_u, is_u, rowptr, colidx, mu, rp, cc, src);
+  CHK(upload_csr(h, h->mat[PCD_MAT_A00], n_u, n_u, rp.data(), cc.data(), nullptr, src.data()));
+  extract_block(n_u, is_u, rowptr, colidx, mp, rp, cc, src);
+  CHK(upload_csr(h, h->mat[PCD_MAT_A01], n_u, n_p, rp.data(), cc.data(), nullptr, src.data()));
+  extract_block(n, perm.data(), rowptr, colidx, ma, rp, cc, src);
+  CHK(upload_csr(h, h->mat[PCD_MAT_A], n, n, rp.data(), cc.data(), nullptr, src.data()));
+  h->ready = false;
+  return pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
+}
+
+int pcd_set_bc(pcd_handle h, int64_t n_bc, const int32_t* idx, const double* vals) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (n_bc < 0 || (n_bc && (!idx || !vals))) return fail(PCD_ERR_ARG, "set_bc: bad arrays");
+  h->n_bc = n_bc;
+  h->bc_host.assign(idx, idx + n_bc);
+  if (n_bc) {
+    CHK(h->bc_idx.ensure(n_bc)); CHK(h->bc_val.ensure(n_bc));
+    HIPCHK(hipMemcpy(h->bc_idx.p, idx, n_bc * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->bc_val.p, vals, n_bc * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type, int max_it,
+                  double rtol, double emin, double emax) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "set_inner: bad slot %d", slot);
+  if (ksp_type < PCD_KSP_PREONLY || ksp_type > PCD_KSP_CG)
+    return fail(PCD_ERR_ARG, "set_inner: unsupported ksp type %d", ksp_type);
+  if (pc_type != PCD_PC_NONE && pc_type != PCD_PC_JACOBI)
+    return fail(PCD_ERR_ARG, "set_inner: unsupported pc type %d", pc_type);
+  if (max_it < 0) return fail(PCD_ERR_ARG, "set_inner: negative max_it");
+  if (ksp_type == PCD_KSP_CHEBYSHEV && !(emax > emin && emin > 0.0))
+    return fail(PCD_ERR_ARG, "set_inner: chebyshev needs 0 < emin < emax");
+  Inner& s = h->inner[slot];
+  s.ksp = ksp_type; s.pc = pc_type; s.max_it = max_it; s.rtol = rtol;
+  s.emin = emin; s.emax = emax;
+  if (h->ready) CHK(inner_prepare(h, slot));
+  return 0;
+}
+
+int pcd_setup(pcd_handle h) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->mat[PCD_MAT_AP].set || !h->mat[PCD_MAT_MP].set || !h->mat[PCD_MAT_KP].set)
+    return fail(PCD_ERR_STATE, "setup: Ap, Mp and Kp are required");
+  if ((h->variant == PCDR_BRM1 || h->variant == PCDR_BRM2) && !h->mat[PCD_MAT_RP].set)
+    return fail(PCD_ERR_STATE, "setup: PCDR variants require Rp");
+  const int64_t np = h->mat[PCD_MAT_AP].nrows;
+  for (int m : {PCD_MAT_AP, PCD_MAT_MP, PCD_MAT_KP, PCD_MAT_RP}) {
+    const DCsr& A = h->mat[m];
+    if (A.set && (A.nrows != np || A.ncols != np))
+      return fail(PCD_ERR_ARG, "setup: operator %d is %lld x %lld, expected %lld^2", m,
+                  (long long)A.nrows, (long long)A.ncols, (long long)np);
+  }
+  if (h->mat[PCD_MAT_A00].set) {
+    if (h->n_p && h->n_p != np) return fail(PCD_ERR_ARG, "setup: n_p of the split (%lld) != size of Ap (%lld)", (long long)h->n_p, (long long)np);
+    if (h->mat[PCD_MAT_A01].ncols != np) return fail(PCD_ERR_ARG, "setup: A01 has %lld columns, expected %lld", (long long)h->mat[PCD_MAT_A01].ncols, (long long)np);
+    h->n_u = h->mat[PCD_MAT_A00].nrows;
+    CHK(h->wu.ensure(h->n_u));
+    CHK(h->xs.ensure(h->n_u + np)); CHK(h->ys.ensure(h->n_u + np));
+  }
+  h->n_p = np;
+  for (int32_t i : h->bc_host)
+    if (i < 0 || i >= np) return fail(PCD_ERR_ARG, "setup: bc index %d outside [0,%lld)", i, (long long)np);
+  CHK(h->w[0].ensure(np)); CHK(h->w[1].ensure(np));
+  for (int s = 0; s < PCD_KSP_COUNT; ++s) CHK(inner_prepare(h, s));
+  h->ready = true;
+  return 0;
+}
+
+int pcd_apply(pcd_handle h, const double* x, double* y, int mem) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (!h->ready) return fail(PCD_ERR_STATE, "apply: call pcd_setup first");
+  if (!x || !y || x == y) return fail(PCD_ERR_ARG, "apply: x and y must be distinct non-null vectors");
+  IoMap io;
+  CHK(io_begin(h, io, x, h->n_p, y, h->n_p, mem));
+  CHK(pcd_apply_dev(h, io.dx, io.dy));
+  return io_end(io);
+}
+
+int pcd_fieldsplit_apply(pcd_handle h, const double* x, double* y, int mem) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (!h->ready || !h->mat[PCD_MAT_A00].set)
+    return fail(PCD_ERR_STATE, "fieldsplit_apply: pcd_set_system + pcd_setup first");
+  if (!x || !y || x == y) return fail(PCD_ERR_ARG, "fieldsplit_apply: x and y must be distinct non-null vectors");
+  const int64_t n = h->n_u + h->n_p;
+  IoMap io;
+  CHK(io_begin(h, io, x, n, y, n, mem));
+  const int g = grid1d(n, 1);
+  hipLaunchKernelGGL(k_gather, dim3(g), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, io.dx, h->xs.p);
+  CHK(fs_apply_split(h, h->xs.p, h->ys.p));
+  hipLaunchKernelGGL(k_scatter, dim3(g), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, h->ys.p, io.dy);
+  HIPCHK(hipGetLastError());
+  return io_end(io);
+}
+
+// device dot/norm helper for GMRES: *out (pinned) = sqrt(v.v); synchronises
+static int dev_norm(Engine* h, int64_t n, const double* v, double* out) {
+  const int G = grid1d(n, 4, 512);
+  hipLaunchKernelGGL(k_mdot, dim3(G, 1), dim3(kBlock), 0, h->stream, n, v, (int64_t)0, 1, v, h->gparts.p, G);
+  hipLaunchKernelGGL(k_mdot_reduce, dim3(1), dim3(kBlock), 0, h->stream, h->gparts.p, G, h->gh.p);
+  HIPCHK(hipMemcpyAsync(h->pinned, h->gh.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *out = std::sqrt(h->pinned[0]);
+  return 0;
+}
+
+int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
+                    double rtol, double atol, int m, int max_it, int* its,
+                    double* rnorm) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (!h->ready || !h->mat[PCD_MAT_A].set)
+    return fail(PCD_ERR_STATE, "gmres_solve: pcd_set_system + pcd_setup first");
+  if (!b || !x || m < 1 || max_it < 0) return fail(PCD_ERR_ARG, "gmres_solve: bad arguments");
+  const int64_t n = h->n_u + h->n_p;
+  const int64_t ld = (n + 15) / 16 * 16;
+  if (h->V_m < m || h->V_ld != ld) {
+    CHK(h->V.ensure((size_t)ld * (m + 1)));
+    h->V_m = m; h->V_ld = ld;
+  }
+  const int G = grid1d(n, 4, 512);
+  CHK(h->gz.ensure(n)); CHK(h->gw.ensure(n)); CHK(h->gxs.ensure(n)); CHK(h->gbs.ensure(n));
+  CHK(h->gparts.ensure((size_t)(m + 2) * 512)); CHK(h->gh.ensure(m + 2)); CHK(h->gy.ensure(m + 2));
+  CHK(ensure_pinned(h, (size_t)m + 8));
+  IoMap io;
+  CHK(io_begin(h, io, b, n, x, n, mem));
+  double *V = h->V.p, *z = h->gz.p, *xs = h->gxs.p, *bs = h->gbs.p;
+  const int g1 = grid1d(n, 1);
+  hipLaunchKernelGGL(k_gather, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, io.dx, bs);
+  HIPCHK(hipMemsetAsync(xs, 0, n * sizeof(double), h->stream));
+  double bnorm = 0.0;
+  CHK(dev_norm(h, n, bs, &bnorm));
+  const double tol = std::max(rtol * bnorm, atol);
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m, 0.0), sn(m, 0.0), gvec(m + 1, 0.0), yk(m, 0.0);
+  int it = 0;
+  double res = bnorm;
+  // r0 = b (zero initial guess), kept in V_0 storage
+  HIPCHK(hipMemcpyAsync(V, bs, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  double beta = bnorm;
+  const DCsr& A = h->mat[PCD_MAT_A];
+  while (it < max_it && res > tol) {
+    res = beta;
+    if (beta <= tol) break;
+    hipLaunchKernelGGL(k_axpby, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, 1.0 / beta, V, 0.0, V);
+    std::fill(gvec.begin(), gvec.end(), 0.0);
+    gvec[0] = beta;
+    int k = 0;
+    bool breakdown = false;
+    for (; k < m && it < max_it;) {
+      double* vk = V + (size_t)k * ld;
+      double* vn = V + (size_t)(k + 1) * ld;
+      CHK(fs_apply_split(h, vk, z));                           // z = M^-1 v_k
+      CHK(spmv(h, A, z, vn));                                  // w = A z
+      const int nvec = k + 1;
+      const int tiles = (nvec + kDotTile - 1) / kDotTile;
+      hipLaunchKernelGGL(k_mdot, dim3(G, tiles), dim3(kBlock), 0, h->stream, n, V, ld, nvec, vn, h->gparts.p, G);
+      hipLaunchKernelGGL(k_mdot_reduce, dim3(nvec), dim3(kBlock), 0, h->stream, h->gparts.p, G, h->gh.p);
+      hipLaunchKernelGGL(k_maxpy_norm, dim3(G), dim3(kBlock), 0, h->stream, n, V, ld, nvec, h->gh.p, vn, -1.0, h->gparts.p);
+      hipLaunchKernelGGL(k_normalize, dim3(G), dim3(kBlock), 0, h->stream, n, vn, h->gparts.p, G, h->gh.p + nvec);
+      HIPCHK(hipMemcpyAsync(h->pinned, h->gh.p, (nvec + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      double* hc = &H[(size_t)k * (m + 1)];
+      for (int j = 0; j <= nvec; ++j) hc[j] = h->pinned[j];
+      const double hn = hc[k + 1];
+      if (!std::isfinite(hn)) return fail(PCD_ERR_BREAKDOWN, "gmres: non-finite Hessenberg entry at iteration %d", it);
+      for (int j = 0; j < k; ++j) {
+        const double t = cs[j] * hc[j] + sn[j] * hc[j + 1];
+        hc[j + 1] = -sn[j] * hc[j] + cs[j] * hc[j + 1];
+        hc[j] = t;
+      }
+      const double d = std::hypot(hc[k], hc[k + 1]);
+      cs[k] = hc[k] / d; sn[k] = hc[k + 1] / d;
+      hc[k] = d; hc[k + 1] = 0.0;
+      gvec[k + 1] = -sn[k] * gvec[k]; gvec[k] = cs[k] * gvec[k];
+      res = std::fabs(gvec[k + 1]);
+      ++it; ++k;
+      if (hn == 0.0) breakdown = true;
+      if (res <= tol || breakdown) break;
+    }
+    for (int i = k - 1; i >= 0; --i) {
+      double s = gvec[i];
+      for (int j = i + 1; j < k; ++j) s -= H[(size_t)j * (m + 1) + i] * yk[j];
+      yk[i] = s / H[(size_t)i * (m + 1) + i];
+    }
+    // x += M^-1 (V y)
+    for (int j = 0; j < k; ++j) h->pinned[j] = yk[j];
+    HIPCHK(hipMemcpyAsync(h->gy.p, h->pinned, k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_combine, dim3(G), dim3(kBlock), 0, h->stream, n, V, ld, k, h->gy.p, h->gw.p);
+    CHK(fs_apply_split(h, h->gw.p, z));
+    hipLaunchKernelGGL(k_axpby, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, 1.0, z, 1.0, xs);
+    HIPCHK(hipStreamSynchronize(h->stream));   // pinned reused next cycle
+    if (res <= tol || it >= max_it || breakdown) break;
+    CHK(spmv(h, A, xs, V, 2, bs));                              // r = b - A x
+    CHK(dev_norm(h, n, V, &beta));
+  }
+  hipLaunchKernelGGL(k_scatter, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, xs, io.dy);
+  HIPCHK(hipGetLastError());
+  CHK(io_end(io));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->gmres_its = it; h->gmres_rnorm = res;
+  if (its) *its = it;
+  if (rnorm) *rnorm = res;
+  return 0;
+}
+
+int pcd_spmv(pcd_handle h, int which, const double* x, double* y, int mem) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (which < 0 || which >= PCD_MAT_COUNT || !h->mat[which].set)
+    return fail(PCD_ERR_STATE, "spmv: operator %d not set", which);
+  if (!x || !y || x == y) return fail(PCD_ERR_ARG, "spmv: x and y must be distinct non-null vectors");
+  const DCsr& A = h->mat[which];
+  IoMap io;
+  CHK(io_begin(h, io, x, A.ncols, y, A.nrows, mem));
+  CHK(spmv(h, A, io.dx, io.dy));
+  return io_end(io);
+}
+
+int pcd_inner_solve(pcd_handle h, int slot, const double* b, double* x, int mem) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "inner_solve: bad slot %d", slot);
+  const DCsr& A = h->mat[kSlotMat[slot]];
+  if (!A.set) return fail(PCD_ERR_STATE, "inner_solve: operator of slot %d not set", slot);
+  if (!b || !x || b == x) return fail(PCD_ERR_ARG, "inner_solve: b and x must be distinct non-null vectors");
+  CHK(inner_prepare(h, slot));
+  IoMap io;
+  CHK(io_begin(h, io, b, A.nrows, x, A.nrows, mem));
+  CHK(inner_solve(h, slot, io.dx, io.dy));
+  return io_end(io);
+}
+
+int pcd_apply_bc(pcd_handle h, double* x, int mem) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (!x) return fail(PCD_ERR_ARG, "apply_bc: null vector");
+  const int64_t np = h->n_p ? h->n_p : h->mat[PCD_MAT_AP].nrows;
+  IoMap io;
+  CHK(io_begin(h, io, nullptr, 0, x, np, mem, true));
+  CHK(apply_bc_dev(h, io.dy));
+  return io_end(io);
+}
+
+int pcd_get_info(pcd_handle h, int key, double* out) {
+  if (!h || !out) return fail(PCD_ERR_ARG, "get_info: null argument");
+  switch (key) {
+    case PCD_INFO_N_U: *out = (double)h->n_u; return 0;
+    case PCD_INFO_N_P: *out = (double)h->n_p; return 0;
+    case PCD_INFO_ITS_AP: case PCD_INFO_ITS_MP: case PCD_INFO_ITS_RP:
+    case PCD_INFO_ITS_A00: {
+      Inner& s = h->inner[key - PCD_INFO_ITS_AP];
+      if (s.its_on_device && s.state.p) {
+        CgState st;
+        HIPCHK(hipMemcpyAsync(&st, s.state.p, sizeof st, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        s.last_its = st.its;
+      }
+      *out = (double)s.last_its;
+      return 0;
+    }
+    case PCD_INFO_NUM_PCD_APPLY: *out = (double)h->num_pcd; return 0;
+    case PCD_INFO_NUM_FS_APPLY: *out = (double)h->num_fs; return 0;
+    case PCD_INFO_GMRES_ITS: *out = (double)h->gmres_its; return 0;
+    case PCD_INFO_GMRES_RNORM: *out = h->gmres_rnorm; return 0;
+    default:
+      if (key >= PCD_INFO_NNZ_BASE && key < PCD_INFO_NNZ_BASE + PCD_MAT_COUNT) {
+        *out = (double)h->mat[key - PCD_INFO_NNZ_BASE].nnz;
+        return 0;
+      }
+  }
+  return fail(PCD_ERR_ARG, "get_info: unknown key %d", key);
+}
+
+int pcd_graph_enable(pcd_handle h, int on) {
+  (void)on;
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  return 0;
+}
+
+int pcd_comm_unique_id(void* out128) {
+  (void)out128;
+  return fail(PCD_ERR_COMM, "comm: multi-GPU path not built yet");
+}
+
+int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) {
+  (void)h; (void)rank; (void)nranks; (void)id;
+  return fail(PCD_ERR_COMM, "comm: multi-GPU path not built yet");
+}
+
+}  // extern "C"

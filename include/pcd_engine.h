@@ -167,6 +167,9 @@ int pcd_apply_bc(pcd_handle h, double* x, int mem);
 
 int pcd_get_info(pcd_handle h, int key, double* out);
 int pcd_synchronize(pcd_handle h);
+/* capture the fixed-iteration fieldsplit apply into a hipGraph and replay it
+ * (launch-bound at the 2D sizes: SURVEY 7, hard part 3); 0 = eager launches */
+int pcd_graph_enable(pcd_handle h, int on);
 
 /* ---- multi-GPU: contiguous row blocks per rank, RCCL over xGMI ----------- */
 

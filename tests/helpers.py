@@ -1,0 +1,88 @@
+"""Shared test utilities: golden loading and engine configuration."""
+import glob
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+from fenapack_amd import _cabi as c
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+VARIANTS = ("BRM1", "BRM2", "RBRM1", "RBRM2")
+# must match ITER_CFG of tests/golden/make_goldens.py
+ITER_CFG = {c.KSP_AP: ("cg", 8, 0.0, 0.5, 2.0),
+            c.KSP_MP: ("chebyshev", 5, 0.0, 0.5, 2.0),
+            c.KSP_RP: ("cg", 6, 0.0, 0.5, 2.0)}
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def csr_from(d, p):
+    return sp.csr_matrix((d[p + "_data"], d[p + "_indices"], d[p + "_indptr"]),
+                         shape=tuple(d[p + "_shape"]))
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def load_pcd_operators(e, d):
+    e.set_csr(c.MAT_AP, csr_from(d, "Ap"))
+    e.set_csr(c.MAT_MP, csr_from(d, "Mp"))
+    e.set_csr(c.MAT_KP, csr_from(d, "Kp"))
+    e.set_csr(c.MAT_RP, csr_from(d, "Rp"))
+    e.set_bc(d["bc_idx"], d["bc_val"])
+
+
+def set_iter_cfg(e, cfg=ITER_CFG):
+    for slot, (ksp, its, rtol, lo, hi) in cfg.items():
+        e.set_inner(slot, ksp, "jacobi", its, rtol, lo, hi)
+
+
+def set_tight_cg(e, slots=(c.KSP_AP, c.KSP_MP, c.KSP_RP), rtol=1e-14):
+    for s in slots:
+        e.set_inner(s, "cg", "jacobi", 100000, rtol)
+
+
+_state_cache = {}
+
+
+def flow_state(kind, level, variant="BRM1", picard_steps=2, **kw):
+    """Problem + matrices frozen at Picard iterate 2."""
+    key = (kind, level, variant, picard_steps, tuple(sorted(kw.items())))
+    if key in _state_cache:
+        return _state_cache[key]
+    import scipy.sparse.linalg as spla
+    from fenapack_amd.fem import BackwardStep, Cavity
+    pb = (BackwardStep if kind == "lshape" else Cavity)(level, variant=variant,
+                                                        **kw)
+    V = pb.space
+    xu, xp = pb.initial_guess()
+    for _ in range(picard_steps):
+        L = pb.linearise(xu, xp)
+        A = sp.bmat([[L["A00"], L["A01"]], [L["A10"], None]]).tocsc()
+        if kind != "lshape":
+            A = A + 1e-10 * sp.identity(A.shape[0], format="csc")
+        dx = spla.spsolve(A, np.concatenate([L["bu"], L["bp"]]))
+        xu, xp = xu - dx[:V.n_u], xp - dx[V.n_u:]
+    L = pb.linearise(xu, xp)
+    st = {"pb": pb, "V": V, "xu": xu, "xp": xp, "L": L,
+          "A": V.monolithic(L["A00"], L["A01"], L["A10"]),
+          "b": V.to_mixed(L["bu"], L["bp"]),
+          "Kp": pb.Kp(xu), "Rp": pb.Rp() if pb.idt else None}
+    _state_cache[key] = st
+    return st
+
+
+def configure_engine(e, st, with_system=True):
+    pb = st["pb"]
+    e.set_csr(c.MAT_AP, pb.Ap)
+    e.set_csr(c.MAT_MP, pb.Mp)
+    e.set_csr(c.MAT_KP, st["Kp"])
+    if st["Rp"] is not None:
+        e.set_csr(c.MAT_RP, st["Rp"])
+    e.set_bc(pb.bc_p_idx, pb.bc_p_val)
+    if with_system:
+        e.set_system(st["A"], st["V"].is_u, st["V"].is_p)

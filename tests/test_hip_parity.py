@@ -1,0 +1,236 @@
+"""GPU suite: the HIP engine, called through the C ABI, against the oracle and
+the golden vectors.  Tolerances (fp64; the only differences are summation
+order inside rows / reductions):
+  SpMV                              rel <= 1e-13
+  fixed-iteration inner solves      rel <= 1e-11
+  pcd_apply vs goldens (fixed its)  rel <= 1e-11
+  pcd_apply vs goldens (tight CG)   rel <= 1e-9
+  GMRES: identical iteration count, solution rel <= 1e-7
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from fenapack_amd import _cabi as c
+from helpers import (VARIANTS, golden_files, csr_from, relerr,
+                     load_pcd_operators, set_iter_cfg, set_tight_cg,
+                     flow_state, configure_engine)
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_engine(hip_lib, variant):
+    return c.Engine(hip_lib, variant, 0)
+
+
+@pytest.mark.parametrize("path", golden_files(),
+                         ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_apply_matches_reference_goldens(hip_lib, path, variant):
+    d = np.load(path)
+    e = hip_engine(hip_lib, variant)
+    load_pcd_operators(e, d)
+    set_iter_cfg(e)
+    e.setup()
+    y = e.apply_np(d["x"])
+    assert relerr(y, d["y_%s_iter" % variant]) < 1e-11
+    assert relerr(e.apply_np(d["x"]), y) == 0.0      # deterministic
+    if "cavity" in path and variant.startswith("R"):
+        return
+    set_tight_cg(e)
+    y = e.apply_np(d["x"])
+    assert relerr(y, d["y_%s_direct" % variant]) < 1e-9
+
+
+@pytest.mark.parametrize("kind,level", [("lshape", 3), ("cavity", 2),
+                                        ("lshape", 5)])
+def test_spmv_all_operators(hip_lib, kind, level):
+    st = flow_state(kind, level, dt=0.2)
+    V = st["V"]
+    e, o = hip_engine(hip_lib, "RBRM1"), oracle.Engine("RBRM1")
+    for eng in (e, o):
+        configure_engine(eng, st)
+        eng.setup()
+    rng = np.random.default_rng(0)
+    for which, ncols, nrows in ((c.MAT_AP, V.n_p, V.n_p),
+                                (c.MAT_MP, V.n_p, V.n_p),
+                                (c.MAT_KP, V.n_p, V.n_p),
+                                (c.MAT_RP, V.n_p, V.n_p),
+                                (c.MAT_A00, V.n_u, V.n_u),
+                                (c.MAT_A01, V.n_p, V.n_u),
+                                (c.MAT_A, V.ndof, V.ndof)):
+        x = rng.standard_normal(ncols)
+        assert relerr(e.spmv_np(which, x, nrows),
+                      o.spmv_np(which, x, nrows)) < 1e-13, which
+
+
+def test_empty_and_tiny_operators(hip_lib):
+    # ragged input: empty rows, a 1x1 system, no BC dofs
+    A = sp.csr_matrix(np.array([[2.0, 0, 0], [0, 0, 0], [1.0, 0, 3.0]]))
+    for eng in (hip_engine(hip_lib, "BRM1"), oracle.Engine("BRM1")):
+        eng.set_csr(c.MAT_KP, A)
+        y = eng.spmv_np(c.MAT_KP, np.array([1.0, 2.0, 3.0]), 3)
+        assert np.array_equal(y, np.array([2.0, 0.0, 10.0]))
+    one = sp.csr_matrix(np.array([[4.0]]))
+    e = hip_engine(hip_lib, "BRM2")
+    for m in (c.MAT_AP, c.MAT_MP, c.MAT_KP):
+        e.set_csr(m, one)
+    e.set_bc(np.zeros(0, dtype=np.int32), np.zeros(0))
+    set_tight_cg(e)
+    e.setup()
+    # y = -(I + Ap^-1 Kp) Mp^-1 x = -(1 + 1) * 0.25 * x
+    assert abs(e.apply_np(np.array([2.0]))[0] + 1.0) < 1e-14
+
+
+@pytest.mark.parametrize("kind,level", [("lshape", 3), ("cavity", 2)])
+def test_inner_solvers(hip_lib, kind, level):
+    st = flow_state(kind, level, nu=0.1)
+    V = st["V"]
+    e, o = hip_engine(hip_lib, "BRM1"), oracle.Engine("BRM1")
+    for eng in (e, o):
+        configure_engine(eng, st)
+        eng.setup()
+    rng = np.random.default_rng(1)
+    bp, bu = rng.standard_normal(V.n_p), rng.standard_normal(V.n_u)
+    cases = [
+        (c.KSP_AP, bp, ("cg", "jacobi", 25, 0.0)),
+        (c.KSP_AP, bp, ("cg", "none", 7, 0.0)),
+        (c.KSP_MP, bp, ("chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)),
+        (c.KSP_MP, bp, ("chebyshev", "jacobi", 1, 0.0, 0.5, 2.0)),
+        (c.KSP_MP, bp, ("chebyshev", "jacobi", 0, 0.0, 0.5, 2.0)),
+        (c.KSP_MP, bp, ("richardson", "jacobi", 1, 0.0)),
+        (c.KSP_MP, bp, ("richardson", "jacobi", 6, 0.0)),
+        (c.KSP_MP, bp, ("preonly", "jacobi", 1, 0.0)),
+        (c.KSP_A00, bu, ("chebyshev", "jacobi", 9, 0.0, 0.05, 2.2)),
+        (c.KSP_A00, bu, ("richardson", "jacobi", 3, 0.0)),
+    ]
+    for slot, b, cfg in cases:
+        e.set_inner(slot, *cfg)
+        o.set_inner(slot, *cfg)
+        assert relerr(e.inner_solve_np(slot, b),
+                      o.inner_solve_np(slot, b)) < 1e-11, cfg
+    # tolerance-terminated CG: same iteration count, same answer
+    for rtol in (1e-4, 1e-10):
+        e.set_inner(c.KSP_AP, "cg", "jacobi", 5000, rtol)
+        o.set_inner(c.KSP_AP, "cg", "jacobi", 5000, rtol)
+        xe, xo = e.inner_solve_np(c.KSP_AP, bp), o.inner_solve_np(c.KSP_AP, bp)
+        assert abs(e.info(c.INFO_ITS_AP) - o.info(c.INFO_ITS_AP)) <= 1
+        assert relerr(xe, xo) < 10 * rtol
+    # zero right-hand side must give zero, not NaN
+    e.set_inner(c.KSP_AP, "cg", "jacobi", 10, 0.0)
+    assert np.array_equal(e.inner_solve_np(c.KSP_AP, 0 * bp), 0 * bp)
+
+
+def test_apply_bc_inserts_values(hip_lib):
+    st = flow_state("lshape", 3)
+    pb = st["pb"]
+    e = hip_engine(hip_lib, "BRM1")
+    configure_engine(e, st, with_system=False)
+    e.set_bc(pb.bc_p_idx, np.arange(pb.bc_p_idx.size) + 1.0)
+    e.setup()
+    x = np.random.default_rng(5).standard_normal(pb.space.n_p)
+    ref = x.copy()
+    ref[pb.bc_p_idx] = np.arange(pb.bc_p_idx.size) + 1.0
+    e.apply_bc(x)
+    assert np.array_equal(x, ref)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("kind,level", [("lshape", 4), ("cavity", 3)])
+def test_pcd_and_fieldsplit_apply_vs_oracle(hip_lib, variant, kind, level):
+    flavour = "BRM1" if variant.endswith("1") else "BRM2"
+    st = flow_state(kind, level, variant=flavour, dt=0.2)
+    V = st["V"]
+    e, o = hip_engine(hip_lib, variant), oracle.Engine(variant)
+    for eng in (e, o):
+        configure_engine(eng, st)
+        set_iter_cfg(eng)
+        eng.set_inner(c.KSP_A00, "chebyshev", "jacobi", 4, 0.0, 0.2, 2.2)
+        eng.setup()
+    rng = np.random.default_rng(7)
+    xp = rng.standard_normal(V.n_p)
+    assert relerr(e.apply_np(xp), o.apply_np(xp)) < 1e-11
+    x = rng.standard_normal(V.ndof)
+    assert relerr(e.fieldsplit_apply_np(x), o.fieldsplit_apply_np(x)) < 1e-11
+    # linearity of the fixed-iteration (Chebyshev-only) preconditioner
+    for eng in (e,):
+        eng.set_inner(c.KSP_AP, "chebyshev", "jacobi", 6, 0.0, 0.05, 2.0)
+        eng.set_inner(c.KSP_RP, "chebyshev", "jacobi", 6, 0.0, 0.05, 2.0)
+    x2 = rng.standard_normal(V.ndof)
+    lhs = e.fieldsplit_apply_np(2.0 * x - 3.0 * x2)
+    rhs = 2.0 * e.fieldsplit_apply_np(x) - 3.0 * e.fieldsplit_apply_np(x2)
+    assert relerr(lhs, rhs) < 1e-10
+
+
+def test_values_update_keeps_pattern(hip_lib):
+    st = flow_state("lshape", 3)
+    V, L = st["V"], st["L"]
+    e = hip_engine(hip_lib, "BRM1")
+    configure_engine(e, st)
+    e.setup()
+    x = np.random.default_rng(8).standard_normal(V.n_u)
+    y0 = e.spmv_np(c.MAT_A00, x, V.n_u)
+    e.update_system(2.0 * st["A"].data)
+    assert relerr(e.spmv_np(c.MAT_A00, x, V.n_u), 2.0 * y0) < 1e-15
+    # a separate preconditioner matrix P feeds A00/A01, A stays the operator
+    e.update_system(st["A"].data, pvals=3.0 * st["A"].data)
+    assert relerr(e.spmv_np(c.MAT_A00, x, V.n_u), 3.0 * y0) < 1e-15
+    xs = np.random.default_rng(9).standard_normal(V.ndof)
+    As = sp.bmat([[L["A00"], L["A01"]], [L["A10"], None]]).tocsr()
+    assert relerr(e.spmv_np(c.MAT_A, xs, V.ndof), As @ xs) < 1e-13
+    K = st["Kp"]
+    e.update_values(c.MAT_KP, -K.data)
+    xp = np.random.default_rng(10).standard_normal(V.n_p)
+    assert relerr(e.spmv_np(c.MAT_KP, xp, V.n_p), -(K @ xp)) < 1e-13
+
+
+@pytest.mark.parametrize("kind,level,nu", [("lshape", 2, 0.1),
+                                           ("cavity", 1, 0.1)])
+def test_gmres_iteration_count_and_solution(hip_lib, kind, level, nu):
+    st = flow_state(kind, level, nu=nu)
+    e, o = hip_engine(hip_lib, "BRM1"), oracle.Engine("BRM1")
+    res = []
+    for eng in (e, o):
+        configure_engine(eng, st)
+        eng.set_inner(c.KSP_AP, "cg", "jacobi", 2000, 1e-13)
+        eng.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+        eng.set_inner(c.KSP_A00, "chebyshev", "jacobi", 30, 0.0, 0.03, 2.2)
+        eng.setup()
+        res.append(eng.gmres_np(st["b"], rtol=1e-8, restart=40, max_it=600))
+    (xe, ie, re_), (xo, io, ro) = res
+    assert ie == io
+    assert relerr(xe, xo) < 1e-7
+    assert relerr(st["A"] @ xe, st["b"]) < 1e-6
+
+
+def test_device_pointer_path_with_torch(hip_lib):
+    import torch
+    st = flow_state("lshape", 4)
+    V = st["V"]
+    e = hip_engine(hip_lib, "BRM1")
+    configure_engine(e, st)
+    set_iter_cfg(e)
+    e.set_inner(c.KSP_A00, "chebyshev", "jacobi", 4, 0.0, 0.2, 2.2)
+    e.setup()
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    xh = np.random.default_rng(11).standard_normal(V.ndof)
+    x = torch.from_numpy(xh).cuda()
+    y = torch.empty_like(x)
+    e.fieldsplit_apply(x, y, c.MEM_DEVICE)
+    torch.cuda.synchronize()
+    assert relerr(y.cpu().numpy(), e.fieldsplit_apply_np(xh)) == 0.0
+
+
+def test_error_paths(hip_lib):
+    e = hip_engine(hip_lib, "RBRM2")
+    with pytest.raises(c.EngineError):
+        e.setup()
+    with pytest.raises(c.EngineError):
+        e.apply_np(np.zeros(3))
+    with pytest.raises(c.EngineError):
+        e.set_inner(c.KSP_AP, 9, 1, 1, 0.0, 0.5, 2.0)
+    with pytest.raises(c.EngineError):
+        c.Engine(hip_lib, "BRM1", 99)
+    e.destroy()
+    e.destroy()                          # idempotent

@@ -1,0 +1,183 @@
+"""CPU suite, part 1: the C oracle against the goldens generated from the
+reference's own apply bodies, plus algebraic properties of the parts whose
+arithmetic is PETSc's (parity unpinned there: SURVEY 8c)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import oracle
+from oracle import reference_numpy as rn
+from fenapack_amd import _cabi as c
+from helpers import (VARIANTS, golden_files, csr_from, relerr,
+                     load_pcd_operators, set_iter_cfg, set_tight_cg,
+                     flow_state, configure_engine)
+
+
+@pytest.mark.parametrize("path", golden_files(),
+                         ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_apply_matches_reference_goldens(path, variant):
+    d = np.load(path)
+    e = oracle.Engine(variant)
+    load_pcd_operators(e, d)
+    set_iter_cfg(e)
+    e.setup()
+    y = e.apply_np(d["x"])
+    # fixed-iteration inner solves: same arithmetic, different summation code
+    assert relerr(y, d["y_%s_iter" % variant]) < 1e-13
+    # x is borrowed and a second apply reuses the work vectors
+    assert relerr(e.apply_np(d["x"]), y) == 0.0
+    if "cavity" in path and variant.startswith("R"):
+        return   # Rp of an enclosed flow is singular: no exact-solve golden
+    set_tight_cg(e)
+    y = e.apply_np(d["x"])
+    assert relerr(y, d["y_%s_direct" % variant]) < 1e-9
+
+
+def test_brm1_without_convection_is_minus_mass_solve():
+    d = np.load(golden_files()[0])
+    e = oracle.Engine("BRM1")
+    load_pcd_operators(e, d)
+    K = csr_from(d, "Kp")
+    e.update_values(c.MAT_KP, 0.0 * K.data)
+    set_tight_cg(e)
+    e.setup()
+    y = e.apply_np(d["x"])
+    ref = -spla.spsolve(csr_from(d, "Mp").tocsc(), d["x"])
+    assert relerr(y, ref) < 1e-10
+
+
+def test_inner_solvers_match_numpy_restatement():
+    st = flow_state("lshape", 2)
+    pb = st["pb"]
+    e = oracle.Engine("BRM1")
+    configure_engine(e, st)
+    e.setup()
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(pb.space.n_p)
+    e.set_inner(c.KSP_AP, "cg", "jacobi", 12, 0.0)
+    assert relerr(e.inner_solve_np(c.KSP_AP, b), rn.cg(pb.Ap, b, 12)[0]) < 1e-13
+    e.set_inner(c.KSP_AP, "cg", "jacobi", 1000, 1e-8)
+    x, its = rn.cg(pb.Ap, b, 1000, 1e-8)
+    assert relerr(e.inner_solve_np(c.KSP_AP, b), x) < 1e-12
+    assert e.info(c.INFO_ITS_AP) == its
+    e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+    assert relerr(e.inner_solve_np(c.KSP_MP, b),
+                  rn.chebyshev(pb.Mp, b, 5, 0.5, 2.0)[0]) < 1e-13
+    e.set_inner(c.KSP_MP, "richardson", "jacobi", 4, 0.0)
+    assert relerr(e.inner_solve_np(c.KSP_MP, b),
+                  rn.richardson(pb.Mp, b, 4)[0]) < 1e-13
+    e.set_inner(c.KSP_MP, "preonly", "jacobi", 1, 0.0)
+    assert relerr(e.inner_solve_np(c.KSP_MP, b), b / pb.Mp.diagonal()) < 1e-15
+
+
+def test_chebyshev_converges_on_p1_mass_matrix():
+    # eigenvalues of diag(Mp)^-1 Mp lie in [0.5, 2] for 2D P1
+    # (demo/navier-stokes-pcd/documentation.rst:143-147)
+    st = flow_state("lshape", 2)
+    pb = st["pb"]
+    e = oracle.Engine("BRM1")
+    configure_engine(e, st, with_system=False)
+    e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 40, 0.0, 0.5, 2.0)
+    e.setup()
+    b = np.random.default_rng(2).standard_normal(pb.space.n_p)
+    x = e.inner_solve_np(c.KSP_MP, b)
+    assert relerr(pb.Mp @ x, b) < 1e-10
+
+
+def test_split_extraction_and_fieldsplit_apply():
+    st = flow_state("lshape", 1)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    e = oracle.Engine("BRM1")
+    configure_engine(e, st)
+    set_tight_cg(e)
+    e.set_inner(c.KSP_A00, "richardson", "jacobi", 3, 0.0)
+    e.setup()
+    assert e.info(c.INFO_NNZ_BASE + c.MAT_A00) == L["A00"].nnz
+    assert e.info(c.INFO_NNZ_BASE + c.MAT_A01) == L["A01"].nnz
+    rng = np.random.default_rng(3)
+    xu, xp = rng.standard_normal(V.n_u), rng.standard_normal(V.n_p)
+    assert relerr(e.spmv_np(c.MAT_A00, xu, V.n_u), L["A00"] @ xu) < 1e-14
+    assert relerr(e.spmv_np(c.MAT_A01, xp, V.n_u), L["A01"] @ xp) < 1e-14
+    xs = np.concatenate([xu, xp])
+    As = sp.bmat([[L["A00"], L["A01"]], [L["A10"], None]]).tocsr()
+    assert relerr(e.spmv_np(c.MAT_A, xs, V.ndof), As @ xs) < 1e-14
+    # fieldsplit upper apply against the numpy restatement
+    x = V.to_mixed(xu, xp)
+    y = e.fieldsplit_apply_np(x)
+    sAp = rn.make_inner(pb.Ap, ("cg", 100000, 1e-14))
+    sMp = rn.make_inner(pb.Mp, ("cg", 100000, 1e-14))
+    pcd = lambda v: rn.pcd_apply("BRM1", v, pb.Ap, pb.Mp, st["Kp"],
+                                 pb.bc_p_idx, pb.bc_p_val, sAp, sMp)
+    yu, yp = rn.fieldsplit_upper(xu, xp, pcd, L["A01"],
+                                 rn.make_inner(L["A00"], ("richardson", 3)))
+    assert relerr(y, V.to_mixed(yu, yp)) < 1e-11
+
+
+def test_gmres_with_exact_schur_complement_takes_two_iterations():
+    # doc/source/math.rst:24-36: with the exact Schur complement GMRES
+    # converges in two iterations.  Feed S^-1 through the PCD slots:
+    # Kp = 0, Ap = I (unused), Mp = -S  =>  y = -Mp^-1 x = S^-1 x.
+    st = flow_state("lshape", 0)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    A00 = L["A00"].toarray()
+    S = -(L["A10"].toarray() @ np.linalg.solve(A00, L["A01"].toarray()))
+    e = oracle.Engine("BRM1")
+    e.set_csr(c.MAT_AP, sp.identity(V.n_p, format="csr"))
+    e.set_csr(c.MAT_MP, sp.csr_matrix(-S))
+    e.set_csr(c.MAT_KP, sp.csr_matrix((V.n_p, V.n_p)))
+    e.set_bc(np.zeros(0, dtype=np.int32), np.zeros(0))
+    e.set_system(st["A"], V.is_u, V.is_p)
+    # S is nonsymmetric: an "exact" Mp solve needs more than CG; use many
+    # Richardson sweeps on a diagonally dominant surrogate instead -> skip to
+    # the numpy route for the exact solves and check the C GMRES by parity
+    M = lambda v: np.concatenate([
+        np.linalg.solve(A00, v[:V.n_u] - L["A01"] @ np.linalg.solve(
+            S, v[V.n_u:])), np.linalg.solve(S, v[V.n_u:])])
+    As = sp.bmat([[L["A00"], L["A01"]], [L["A10"], None]]).tocsr()
+    b = np.concatenate([L["bu"], L["bp"]])
+    x, its, res, _ = rn.gmres_right(As, b, M, rtol=1e-10)
+    assert its <= 2
+    assert relerr(As @ x, b) < 1e-8
+
+
+def test_gmres_parity_c_vs_numpy_and_true_residual():
+    # nu = 0.1: on this coarse mesh the default nu = 0.02 is convection
+    # dominated (complex spectrum of D^-1 A00) and Chebyshev/Jacobi on A00
+    # diverges; fixed-iteration CG would make the preconditioner nonlinear,
+    # so Ap is solved tightly (hard part 1)
+    st = flow_state("lshape", 1, nu=0.1)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    e = oracle.Engine("BRM1")
+    configure_engine(e, st)
+    e.set_inner(c.KSP_AP, "cg", "jacobi", 1000, 1e-13)
+    e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+    e.set_inner(c.KSP_A00, "chebyshev", "jacobi", 30, 0.0, 0.05, 2.2)
+    e.setup()
+    x, its, rnorm = e.gmres_np(st["b"], rtol=1e-8, restart=30, max_it=400)
+    assert relerr(st["A"] @ x, st["b"]) < 1e-6
+    # numpy restatement with the same (linear, fixed-iteration) inner solves
+    As = sp.bmat([[L["A00"], L["A01"]], [L["A10"], None]]).tocsr()
+    bs = np.concatenate([L["bu"], L["bp"]])
+    sAp = rn.make_inner(pb.Ap, ("cg", 1000, 1e-13))
+    sMp = rn.make_inner(pb.Mp, ("chebyshev", 5, 0.5, 2.0))
+    sA00 = rn.make_inner(L["A00"], ("chebyshev", 30, 0.05, 2.2))
+    pcd = lambda v: rn.pcd_apply("BRM1", v, pb.Ap, pb.Mp, st["Kp"],
+                                 pb.bc_p_idx, pb.bc_p_val, sAp, sMp)
+    M = lambda v: np.concatenate(rn.fieldsplit_upper(
+        v[:V.n_u], v[V.n_u:], pcd, L["A01"], sA00))
+    x2, its2, res2, _ = rn.gmres_right(As, bs, M, rtol=1e-8, restart=30,
+                                       max_it=400)
+    assert its == its2
+    assert relerr(x, V.to_mixed(x2[:V.n_u], x2[V.n_u:])) < 1e-7
+
+
+def test_error_paths():
+    e = oracle.Engine("RBRM1")
+    with pytest.raises(c.EngineError):
+        e.setup()                       # operators missing
+    with pytest.raises(c.EngineError):
+        e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 2.0, 0.5)
+    with pytest.raises(c.EngineError):
+        e.apply_np(np.zeros(4))         # before setup
