@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Steady incompressible Navier-Stokes with PCD preconditioning on MI355X.
+
+Counterpart of the reference's ``demo/navier-stokes-pcd/
+demo_navier-stokes-pcd.py`` (same flags ``-l --nu --pcd --nls``), on the
+reference's L-shaped backward-facing step or on the lid-driven cavity that
+BASELINE.json names.  Inner solvers are the device-native ones (Jacobi-CG,
+Chebyshev-Jacobi); ``--ls direct`` of the reference has no counterpart."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from fenapack_amd.driver import default_inner_options, solve_steady  # noqa
+from fenapack_amd.fem import BackwardStep, Cavity                    # noqa
+
+p = argparse.ArgumentParser(description=__doc__)
+p.add_argument("-l", type=int, dest="level", default=4)
+p.add_argument("--nu", type=float, dest="viscosity", default=None)
+p.add_argument("--pcd", dest="pcd_variant", default="BRM1",
+               choices=["BRM1", "BRM2"])
+p.add_argument("--nls", default="picard", choices=["picard", "newton"])
+p.add_argument("--geometry", default="lshape", choices=["lshape", "cavity"])
+p.add_argument("--a00-its", type=int, default=60)
+p.add_argument("--a00-ratio", type=float, default=0.01)
+args = p.parse_args()
+
+if args.geometry == "lshape":
+    pb = BackwardStep(args.level, nu=args.viscosity or 0.02,
+                      variant=args.pcd_variant, nls=args.nls)
+    print("Reynolds number: Re = %g" % (2.0 / pb.nu))
+else:
+    pb = Cavity(args.level, nu=args.viscosity or 0.01,
+                variant=args.pcd_variant, nls=args.nls)
+    print("Reynolds number: Re = %g" % (1.0 / pb.nu))
+print("Dimension of the function space: %d" % pb.space.ndof)
+default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio)
+out = solve_steady(pb)
+print("Newton iterations: %d, converged: %s" % (out["newton_its"],
+                                                out["converged"]))
+print("GMRES iterations per Newton step:", out["krylov_per_step"])
+print("residuals:", ["%.3e" % r for r in out["residuals"]])
+print("solve time: %.2f s" % out["time"])

@@ -2,3 +2,4 @@
 from .mesh import Mesh, lshape_mesh, unit_square_mesh, cavity_mesh
 from .taylor_hood import TaylorHood, FixedPattern
 from .problems import FlowProblem, BackwardStep, Cavity
+from .forms import Function, DirichletBC, Form, navier_stokes_forms

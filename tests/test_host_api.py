@@ -1,0 +1,164 @@
+"""CPU suite, part 3: host logic of the API mirror (no engine calls)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from fenapack_amd import (PCDAssembler, PCDForm, PCDKSP, PCDKrylovSolver,
+                          PETScOptions)
+from fenapack_amd.utils import allow_only_one_call
+from fenapack_amd.petsc import IS, KSP, Mat, Options, Vec, estimate_emax
+from fenapack_amd.field_split_backend import PCDInterface, SubfieldBC
+from fenapack_amd.fem import BackwardStep
+from fenapack_amd.fem.forms import navier_stokes_forms, DirichletBC
+from helpers import golden_files, csr_from, relerr
+
+
+def test_allow_only_one_call():
+    # known answers restated from the reference's test/unit/test_utils.py:24-57
+    class C(object):
+        @allow_only_one_call
+        def foo(self, *args, **kwargs):
+            """Foo"""
+            return args, kwargs
+
+        @allow_only_one_call
+        def bar(self, *args, **kwargs):
+            """Bar"""
+            return args, kwargs
+
+        def baz(self, *args, **kwargs):
+            """Baz"""
+            return args, kwargs
+
+    o = C()
+    assert (o.foo.__doc__, o.bar.__doc__, o.baz.__doc__) == ("Foo", "Bar",
+                                                             "Baz")
+    for f in (o.foo, o.bar, o.baz):
+        assert f(1, 2, 3, four=5) == ((1, 2, 3), {"four": 5})
+    for f in (o.foo, o.bar):
+        with pytest.raises(RuntimeError):
+            f(1, 2, 3, four=5)
+    assert o.baz(1, 2, 3, four=5) == ((1, 2, 3), {"four": 5})
+    assert C().foo(7) == ((7,), {})       # per instance, not per class
+
+
+def test_subksp_prefixes_follow_an_early_prefix():
+    # test/unit/test_fieldsplit.py:84-96: a prefix set before the PC set-up
+    # propagates to foo_fieldsplit_u_/p_
+    ksp = PCDKSP()
+    ksp.setOptionsPrefix("foo_")
+    ksp.pc.setFieldSplitIS(["u", IS([0, 1])], ["p", IS([2])])
+    with pytest.raises(RuntimeError):
+        PCDKSP().pc.getFieldSplitSubKSP()       # before setUp (issue #160)
+    ksp.pc.setUp()
+    k0, k1 = ksp.pc.getFieldSplitSubKSP()
+    assert k0.getOptionsPrefix() == "foo_fieldsplit_u_"
+    assert k1.getOptionsPrefix() == "foo_fieldsplit_p_"
+
+
+def test_options_db_and_unsupported_solvers_are_rejected():
+    PETScOptions.clear()
+    PETScOptions.set("t_ksp_type", "chebyshev")
+    PETScOptions.set("t_ksp_max_it", 7)
+    PETScOptions.set("t_ksp_chebyshev_eigenvalues", "0.5, 2.0")
+    PETScOptions.set("t_pc_type", "jacobi")
+    k = KSP()
+    k.setOptionsPrefix("t_")
+    k.setFromOptions()
+    assert (k.type, k.max_it, k.cheb_eigs, k.pc.type) == \
+        ("chebyshev", 7, (0.5, 2.0), "jacobi")
+    assert Options("t_").getString("pc_python_type", "") == ""
+    PETScOptions.set("t_pc_type", "hypre")
+    with pytest.raises(ValueError):
+        k.setFromOptions()
+    PETScOptions.set("t_pc_type", "jacobi")
+    PETScOptions.set("t_ksp_type", "pipecr")
+    with pytest.raises(ValueError):
+        k.setFromOptions()
+    PETScOptions.clear()
+
+
+def test_pcd_form_defaults_and_missing_forms():
+    pb = BackwardStep(0)
+    w, forms = navier_stokes_forms(pb)
+    a = PCDAssembler(**forms)
+    # assembling.py:98-106
+    assert a.get_pcd_form("ap").is_constant()
+    assert a.get_pcd_form("mp").is_constant()
+    assert not a.get_pcd_form("kp").is_constant()
+    assert a.get_pcd_form("gp").is_phantom()
+    with pytest.raises(AttributeError):
+        a.get_pcd_form("fp")
+    with pytest.raises(AttributeError):
+        a.get_pcd_form("nonsense")
+    assert isinstance(a.get_pcd_form("kp"), PCDForm)
+    assert a.function_space() is pb.space
+
+
+def test_forms_assemble_on_the_mixed_space_and_split_back():
+    pb = BackwardStep(1)
+    V = pb.space
+    w, forms = navier_stokes_forms(pb)
+    a = PCDAssembler(**forms)
+    M = Mat()
+    a.mp(M)
+    assert M.getSize() == (V.ndof, V.ndof)
+    sub = M.createSubMatrix(IS(V.is_p))
+    assert abs(sub.A - pb.Mp).max() == 0.0
+    A = Mat()
+    a.system_matrix(A)
+    L = pb.linearise(*w.split())
+    assert abs(A.createSubMatrix(IS(V.is_u), IS(V.is_p)).A - L["A01"]).max() \
+        == 0.0
+    state = A.state
+    a.system_matrix(A)
+    assert A.state == state + 1            # re-assembly is noticed
+
+
+def test_subfield_bc_maps_mixed_dofs_to_subfield_indices():
+    pb = BackwardStep(2, variant="BRM1")
+    V = pb.space
+    bc = DirichletBC(V, V.is_p[pb.bc_p_idx], pb.bc_p_val + 3.0)
+    sbc = SubfieldBC(bc, IS(V.is_p))
+    assert np.array_equal(np.sort(sbc.indices), np.sort(pb.bc_p_idx))
+    assert np.all(sbc.values == 3.0) and not sbc.is_homogeneous()
+    # a velocity BC has no image in the pressure subfield
+    bcu = DirichletBC(V, V.is_u[pb.bc_u_idx], pb.bc_u_values(0.0))
+    assert SubfieldBC(bcu, IS(V.is_p)).indices.size == 0
+    # inlet of the L-shape at level l has 2^l + 1 vertices
+    assert pb.bc_p_idx.size == 2 ** 2 + 1
+
+
+@pytest.mark.parametrize("path", golden_files()[:3],
+                         ids=lambda p: p.split("/")[-1][:-4])
+def test_rp_builder_matches_the_reference_built_golden(path):
+    d = np.load(path)
+    A01 = csr_from(d, "A01")
+    Mu = sp.diags(d["Mu_diag"]).tocsr()
+    iface = object.__new__(PCDInterface)
+    R = iface._build_approx_Ap(Mat(Mu), Mat(A01)).A
+    assert relerr(R.toarray(), csr_from(d, "Rp").toarray()) < 1e-14
+
+
+def test_emax_estimate_is_a_tight_lower_bound():
+    pb = BackwardStep(2)
+    e = estimate_emax(pb.Mp, iters=40)
+    true = np.linalg.eigvals((sp.diags(1 / pb.Mp.diagonal()) @ pb.Mp)
+                             .toarray()).real.max()
+    assert 0.9 * true < e <= true * (1 + 1e-12)
+    assert true <= 2.0 + 1e-12             # the documented 2D P1 bound
+
+
+def test_krylov_solver_requires_the_hip_library(monkeypatch, tmp_path):
+    from fenapack_amd import _cabi
+    monkeypatch.setattr(_cabi, "_hip_library", None)
+    monkeypatch.setattr(_cabi, "HIP_LIBRARY_PATH", str(tmp_path / "x.so"))
+    pb = BackwardStep(0)
+    w, forms = navier_stokes_forms(pb)
+    a = PCDAssembler(**forms)
+    s = PCDKrylovSolver()
+    A = Mat()
+    a.system_matrix(A)
+    s.set_operators(A, A)
+    with pytest.raises(_cabi.EngineError):
+        s.init_pcd(a)                       # no silent CPU fallback
