@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fieldsplit PCApply calls/sec on the 2D lid-driven cavity
+Re=100, P2/P1 (BASELINE.json configs[1]: level 6, about 0.92 M DOF), plus the
+outer GMRES iterations per Newton step that the same settings give.
+
+A "step" is one fieldsplit PCApply (PCD Schur apply + A01 SpMV + A00 solve,
+SURVEY 8a rows a1/a13-a15) on vectors resident in HBM.  One JSON line is
+printed by rank 0; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--level", type=int, default=6)
+    p.add_argument("--geometry", default="cavity", choices=["cavity", "lshape"])
+    p.add_argument("--variant", default="BRM1", choices=["BRM1", "BRM2"])
+    p.add_argument("--a00-its", type=int, default=240)
+    p.add_argument("--a00-ratio", type=float, default=0.002)
+    p.add_argument("--ap-rtol", type=float, default=1e-8)
+    p.add_argument("--ap-its", type=int, default=10000)
+    p.add_argument("--mp-its", type=int, default=5)
+    p.add_argument("--picard-steps", type=int, default=2,
+                   help="nonlinear iterations before the matrices are frozen")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from fenapack_amd import PETScOptions
+    from fenapack_amd import _cabi as c
+    from fenapack_amd import roofline as rf
+    from fenapack_amd.driver import default_inner_options, make_solver
+    from fenapack_amd.fem import BackwardStep, Cavity
+    from fenapack_amd.petsc import Vec
+
+    t_setup = time.time()
+    if args.geometry == "cavity":
+        pb = Cavity(args.level, nu=0.01, variant=args.variant)   # Re = 100
+    else:
+        pb = BackwardStep(args.level, nu=0.02, variant=args.variant)
+    V = pb.space
+    PETScOptions.clear()
+    default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
+                          ap_rtol=args.ap_rtol, ap_its=args.ap_its,
+                          mp_its=args.mp_its)
+    w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150,
+                              newton_rtol=1e-5, max_newton=args.picard_steps,
+                              device=local)
+    nls.parameters["error_on_nonconvergence"] = False
+    # M2: real Picard steps from w = 0 on the GPU; the matrices of the last
+    # one (Picard iterate `picard_steps`) are the frozen microbench state
+    nls.solve(nlp, w.vector(), on_update=w.touch)
+    gmres_per_step = list(nls.krylov_history)
+    ksp = nls.linear_solver().ksp()
+    eng = ksp.engine
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    t_setup = time.time() - t_setup
+
+    n = V.ndof
+    rng = np.random.default_rng(0)
+    x = Vec(rng.standard_normal(n), device="cuda:%d" % local)
+    y = x.duplicate()
+
+    def step():
+        eng.fieldsplit_apply(x.t, y.t, c.MEM_DEVICE)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # executed inner iteration counts -> algorithmic bytes of one PCApply
+    k_a = int(eng.info(c.INFO_ITS_AP))
+    k_m = int(eng.info(c.INFO_ITS_MP))
+    k_f = int(eng.info(c.INFO_ITS_A00))
+    nnz = lambda m: int(eng.info(c.INFO_NNZ_BASE + m))
+    ksp0, ksp1 = ksp.pc.getFieldSplitSubKSP()
+    pcd = ksp1.pc.getPythonContext()
+    bytes_pcd = rf.b_pcd(V.n_p, nnz(c.MAT_AP), nnz(c.MAT_MP), nnz(c.MAT_KP),
+                         pb.bc_p_idx.size, k_a, k_m, pcd.ksp_Ap.type,
+                         pcd.ksp_Mp.type)
+    bytes_pc = rf.b_fieldsplit(V.n_u, V.n_p, nnz(c.MAT_A00), nnz(c.MAT_A01),
+                               bytes_pcd, k_f, ksp0.type)
+
+    # roofline of the dominant kernel (fused Chebyshev step on A00), timed
+    # live with events on the stream the engine launches on
+    def time_a00(m, reps=5):
+        eng.set_inner(c.KSP_A00, ksp0.type, "jacobi", m, 0.0,
+                      *ksp0._chebyshev_bounds())
+        bu = x.t[:V.n_u].clone()
+        xu = torch.empty_like(bu)
+        eng.inner_solve(c.KSP_A00, bu, xu, c.MEM_DEVICE)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for _ in range(reps):
+            eng.inner_solve(c.KSP_A00, bu, xu, c.MEM_DEVICE)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    m_hi, m_lo = 65, 1
+    t_kernel = (time_a00(m_hi) - time_a00(m_lo)) / (m_hi - m_lo)
+    ksp0.push_settings()                      # restore the bench settings
+    b_kernel = rf.b_cheb(V.n_u, nnz(c.MAT_A00))
+    achieved = b_kernel / t_kernel / 1e9
+
+    out = {
+        "metric": "fieldsplit PCApply calls/sec (2D cavity Re=100, P2/P1)",
+        "value": args.steps / dt,
+        "unit": "PCApply/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (own P2/P1 assembly; matrices frozen at Picard "
+                "iterate %d computed on the GPU)" % args.picard_steps,
+        "config": {
+            "workload": "%s level %d, Re=100, P2/P1, PCD %s"
+                        % (args.geometry, args.level, args.variant),
+            "ndof": int(n), "n_u": int(V.n_u), "n_p": int(V.n_p),
+            "inner": {"Ap": "cg+jacobi rtol %g (k_A=%d executed)"
+                            % (args.ap_rtol, k_a),
+                      "Mp": "chebyshev+jacobi its %d eig [0.5,2]" % k_m,
+                      "A00": "chebyshev+jacobi its %d eig ratio %g"
+                             % (k_f, args.a00_ratio)},
+            "gmres": "restart 150, rtol 1e-6, right PC",
+            "parallelism": "row partition x%d" % world,
+        },
+        "gmres_its_per_newton_step": gmres_per_step,
+        "algorithmic_bytes_per_pcapply": int(bytes_pc),
+        "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
+        "roofline": {
+            "bound": "hbm", "kernel": "k_cheb_step (A00)",
+            "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / rf.HBM_PEAK_GBS,
+            "bytes_per_launch": int(b_kernel),
+            "us_per_launch": 1e6 * t_kernel,
+            "traffic": None,
+        },
+        "setup_seconds": t_setup,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, pb, ksp, eng, c, x)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, pb, ksp, eng, c, x):
+    """The oracle (a scalar C port, 1 thread) on the same workload, bounded
+    to about ``--cpu-seconds`` of CPU work.  A reported baseline, not the
+    target; it is "CPU restatement, not PETSc" (BASELINE.md section 3)."""
+    import oracle
+    V = pb.space
+    o = oracle.Engine(pb.variant)
+    pcd = ksp.pc.getFieldSplitSubKSP()[1].pc.getPythonContext()
+    o.set_csr(c.MAT_AP, pcd.ksp_Ap.getOperators()[0].A)
+    o.set_csr(c.MAT_MP, pcd.ksp_Mp.getOperators()[0].A)
+    o.set_csr(c.MAT_KP, pcd.mat_Kp.A)
+    o.set_bc(pb.bc_p_idx, pb.bc_p_val)
+    A, P = ksp.getOperators()
+    o.set_system(A.A, V.is_u, V.is_p, None if P is A else P.A)
+    ksp0 = ksp.pc.getFieldSplitSubKSP()[0]
+    lo, hi = ksp0._chebyshev_bounds()
+    o.set_inner(c.KSP_A00, ksp0.type, "jacobi", ksp0.max_it, 0.0, lo, hi)
+    o.set_inner(c.KSP_AP, pcd.ksp_Ap.type, "jacobi", pcd.ksp_Ap.max_it,
+                pcd.ksp_Ap.rtol if pcd.ksp_Ap.type == "cg" else 0.0)
+    o.set_inner(c.KSP_MP, pcd.ksp_Mp.type, "jacobi", pcd.ksp_Mp.max_it, 0.0,
+                *(pcd.ksp_Mp.cheb_eigs or (0.5, 2.0)))
+    o.setup()
+    xh = x.getArray()
+    yh = np.empty_like(xh)
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        o.fieldsplit_apply(xh, yh)
+        n_done += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or n_done >= 50:
+            break
+    # parity of this very workload while we are at it
+    yg = np.empty_like(xh)
+    eng.fieldsplit_apply(xh, yg)
+    err = float(np.abs(yg - yh).max() / np.abs(yh).max())
+    return {"value": n_done / el, "unit": "PCApply/s", "cores": 1,
+            "kind": "port",
+            "sample": "%d fieldsplit PCApply of the same workload and inner "
+                      "settings (%.1f s), oracle/pcd_oracle.c single thread; "
+                      "CPU restatement, not PETSc" % (n_done, el),
+            "gpu_vs_oracle_rel_err": err,
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()
