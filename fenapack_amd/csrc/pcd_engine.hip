@@ -73,6 +73,7 @@ struct DCsr {
   bool has_src = false;
   bool set = false;
   int lpr = 8;
+  int rb = 0;             // rows per workgroup of the CSR-stream kernels (0: n/a)
   void release() {
     rowptr.release(); col.release(); val.release(); dinv.release();
     src.release(); set = false; nrows = ncols = nnz = 0; has_src = false;
@@ -83,13 +84,13 @@ struct Inner {
   int ksp = PCD_KSP_CG, pc = PCD_PC_JACOBI, max_it = 10000;
   double rtol = 1e-12, emin = 0.5, emax = 2.0;
   // device scratch, sized at setup
-  DBuf<double> t0, t1, t2, t3;       // r,z,p,q  or the Chebyshev ring
+  DBuf<double> t0, t1, t2, t3, t4;   // r,z,p,q,p'  or the Chebyshev ring
   DBuf<double> parts;                // 3 * kMaxParts
   DBuf<CgState> state;
   int last_its = 0;
   bool its_on_device = false;
   void release() {
-    t0.release(); t1.release(); t2.release(); t3.release();
+    t0.release(); t1.release(); t2.release(); t3.release(); t4.release();
     parts.release(); state.release();
   }
 };
@@ -145,6 +146,27 @@ static int choose_lpr(const DCsr& A) {
   return l;
 }
 
+// rows per workgroup for the CSR-stream kernels: the largest of 256/128/64
+// whose every row block fits the LDS tile; 0 = some row block is too long
+static int choose_rb(int64_t nrows, const int32_t* rowptr) {
+  for (int rb : {256, 128, 64}) {
+    bool ok = true;
+    for (int64_t r = 0; r < nrows && ok; r += rb) {
+      const int64_t r1 = std::min<int64_t>(r + rb, nrows);
+      if (rowptr[r1] - rowptr[r] > kTile) ok = false;
+    }
+    if (ok) return rb;
+  }
+  return 0;
+}
+// workgroups for a stream kernel: one per row block (capped), multiple of 8
+static inline int grid_stream(int64_t nrows, int rb, int cap = 1 << 20) {
+  int64_t nrb = (nrows + rb - 1) / rb;
+  int64_t g = std::min<int64_t>(std::max<int64_t>(nrb, 1), cap);
+  return (int)((g + 7) / 8 * 8);
+}
+static bool g_force_vector = false;   // PCD_FORCE_CSR_VECTOR=1: A/B switch
+
 static int ensure_pinned(Engine* h, size_t n) {
   if (n <= h->pinned_n) return 0;
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -169,6 +191,32 @@ static int ensure_pinned(Engine* h, size_t n) {
     }                                                                           \
   } while (0)
 
+#define LAUNCH_RB(A, KERNEL, GRID, ...)                                         \
+  do {                                                                          \
+    switch ((A).rb) {                                                           \
+      case 256: hipLaunchKernelGGL((KERNEL<256>), dim3(GRID), dim3(kBlock), 0,  \
+                                   h->stream, __VA_ARGS__); break;              \
+      case 128: hipLaunchKernelGGL((KERNEL<128>), dim3(GRID), dim3(kBlock), 0,  \
+                                   h->stream, __VA_ARGS__); break;              \
+      default: hipLaunchKernelGGL((KERNEL<64>), dim3(GRID), dim3(kBlock), 0,    \
+                                  h->stream, __VA_ARGS__); break;               \
+    }                                                                           \
+  } while (0)
+
+template <int MODE>
+static void launch_spmv_stream(Engine* h, const DCsr& A, const double* x,
+                               const double* add, double* y) {
+  const int g = grid_stream(A.nrows, A.rb);
+  switch (A.rb) {
+    case 256: hipLaunchKernelGGL((k_spmv_s<256, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+    case 128: hipLaunchKernelGGL((k_spmv_s<128, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+    default: hipLaunchKernelGGL((k_spmv_s<64, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+  }
+}
+
 template <int MODE>
 static void launch_spmv_mode(Engine* h, const DCsr& A, const double* x,
                              const double* add, double* y) {
@@ -189,7 +237,11 @@ static void launch_spmv_mode(Engine* h, const DCsr& A, const double* x,
 static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
                 int mode = 0, const double* add = nullptr) {
   if (!A.set) return fail(PCD_ERR_STATE, "spmv: operator not set");
-  if (mode == 0) launch_spmv_mode<0>(h, A, x, add, y);
+  if (A.rb) {
+    if (mode == 0) launch_spmv_stream<0>(h, A, x, add, y);
+    else if (mode == 1) launch_spmv_stream<1>(h, A, x, add, y);
+    else launch_spmv_stream<2>(h, A, x, add, y);
+  } else if (mode == 0) launch_spmv_mode<0>(h, A, x, add, y);
   else if (mode == 1) launch_spmv_mode<1>(h, A, x, add, y);
   else launch_spmv_mode<2>(h, A, x, add, y);
   HIPCHK(hipGetLastError());
@@ -215,7 +267,7 @@ static int inner_prepare(Engine* h, int slot) {
   switch (s.ksp) {
     case PCD_KSP_CG:
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n)); CHK(s.t2.ensure(n));
-      CHK(s.t3.ensure(n)); CHK(s.parts.ensure(3 * kMaxParts));
+      CHK(s.t3.ensure(n)); CHK(s.t4.ensure(n)); CHK(s.parts.ensure(3 * kMaxParts));
       CHK(s.state.ensure(1));
       break;
     case PCD_KSP_CHEBYSHEV:
@@ -229,8 +281,60 @@ static int inner_prepare(Engine* h, int slot) {
   return 0;
 }
 
+static void launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
+                             const double* b, const double* pm, const double* pk,
+                             double* pn, double c0, double c1, double c2) {
+  const int n = (int)A.nrows;
+  if (A.rb) {
+    LAUNCH_RB(A, k_cheb_step_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
+              A.val.p, dinv, b, pm, pk, pn, c0, c1, c2);
+  } else {
+    LAUNCH_LPR(A, k_cheb_step, grid_rows(n, A.lpr), n, A.rowptr.p, A.col.p,
+               A.val.p, dinv, b, pm, pk, pn, c0, c1, c2);
+  }
+}
+
+// CG with the direction update fused into the SpMV: two launches per
+// iteration (k_cg_spmv_s, k_cg_update); p ping-pongs between two buffers
+static int solve_cg_stream(Engine* h, const DCsr& A, Inner& s, const double* b,
+                           double* x) {
+  const int n = (int)A.nrows;
+  const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
+  double *r = s.t0.p, *z = s.t1.p, *q = s.t3.p;
+  double* P[2] = {s.t2.p, s.t4.p};
+  double* R[2] = {s.parts.p, s.parts.p + kMaxParts};
+  double* PQ = s.parts.p + 2 * kMaxParts;
+  CgState* st = s.state.p;
+  const int ge = grid1d(n, 2, kMaxParts);
+  const int gs = grid_stream(n, A.rb, kMaxParts);
+  hipLaunchKernelGGL(k_cg_init, dim3(ge), dim3(kBlock), 0, h->stream, n, dinv,
+                     b, x, r, z, P[1], R[0], st);
+  const int check = 32;
+  for (int it = 0; it < s.max_it; ++it) {
+    double* pn = P[it & 1];
+    const double* po = P[(it + 1) & 1];
+    LAUNCH_RB(A, k_cg_spmv_s, gs, n, A.rowptr.p, A.col.p, A.val.p, z, po, pn, q,
+              R[it & 1], R[(it + 1) & 1], ge, s.rtol, it == 0 ? 1 : 0, PQ, st);
+    hipLaunchKernelGGL(k_cg_update, dim3(ge), dim3(kBlock), 0, h->stream, n,
+                       dinv, pn, q, x, r, z, R[it & 1], ge, PQ, gs,
+                       R[(it + 1) & 1], it, st);
+    if (s.rtol > 0.0 && (it % check) == check - 1 && it + 1 < s.max_it) {
+      CHK(ensure_pinned(h, 8));
+      int* flag = reinterpret_cast<int*>(h->pinned);
+      HIPCHK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost,
+                            h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (*flag) break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  s.its_on_device = true;
+  return 0;
+}
+
 static int solve_cg(Engine* h, const DCsr& A, Inner& s, const double* b,
                     double* x) {
+  if (A.rb) return solve_cg_stream(h, A, s, b, x);
   const int n = (int)A.nrows;
   const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
   double *r = s.t0.p, *z = s.t1.p, *p = s.t2.p, *q = s.t3.p;
@@ -282,7 +386,6 @@ static int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
   const int g1 = grid1d(n, 1);
   hipLaunchKernelGGL(k_scale_dinv, dim3(g1), dim3(kBlock), 0, h->stream, n,
                      dinv, b, scale, ring[0]);
-  const int gs = grid_rows(n, A.lpr);
   for (int it = 0; it < m; ++it) {
     const double c_kp1 = 2.0 * mu * c_k - c_km1;
     const double omega = omegaprod * c_k / c_kp1;
@@ -291,8 +394,7 @@ static int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
     // p_{-1} = 0 at the first step: coefficient forced to zero, never read
     double* pm = (it == 0) ? pk : ring[(it + 2) % 3];
     const double c0 = (it == 0) ? 0.0 : 1.0 - omega;
-    LAUNCH_LPR(A, k_cheb_step, gs, n, A.rowptr.p, A.col.p, A.val.p, dinv, b, pm,
-               pk, pn, c0, omega, omega * scale);
+    launch_cheb_step(h, A, dinv, b, pm, pk, pn, c0, omega, omega * scale);
     c_km1 = c_k; c_k = c_kp1;
   }
   HIPCHK(hipGetLastError());
@@ -310,12 +412,10 @@ static int solve_rich(Engine* h, const DCsr& A, Inner& s, const double* b,
   bufs[(m - 1) % 2] = x; bufs[m % 2] = s.t0.p;
   hipLaunchKernelGGL(k_scale_dinv, dim3(grid1d(n, 1)), dim3(kBlock), 0,
                      h->stream, n, dinv, b, 1.0, bufs[0]);
-  const int gs = grid_rows(n, A.lpr);
   for (int it = 1; it < m; ++it) {
     double* pk = bufs[(it - 1) % 2];
     double* pn = bufs[it % 2];
-    LAUNCH_LPR(A, k_cheb_step, gs, n, A.rowptr.p, A.col.p, A.val.p, dinv, b, pk,
-               pk, pn, 0.0, 1.0, 1.0);
+    launch_cheb_step(h, A, dinv, b, pk, pk, pn, 0.0, 1.0, 1.0);
   }
   HIPCHK(hipGetLastError());
   s.last_its = m; s.its_on_device = false;
@@ -460,6 +560,7 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   HIPCHK(hipStreamSynchronize(h->stream));   // host arrays may be freed by the caller
   A.set = true;
   A.lpr = choose_lpr(A);
+  A.rb = g_force_vector ? 0 : choose_rb(nrows, rowptr);
   return 0;
 }
 
@@ -477,6 +578,7 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   if (device < 0 || device >= ndev)
     return fail(PCD_ERR_ARG, "create: device %d not in [0,%d)", device, ndev);
   HIPCHK(hipSetDevice(device));
+  { const char* e = getenv("PCD_FORCE_CSR_VECTOR"); g_force_vector = e && e[0] == '1'; }
   Engine* h = new (std::nothrow) Engine();
   if (!h) return fail(PCD_ERR_NOMEM, "create: out of host memory");
   h->variant = variant; h->device = device;

@@ -212,6 +212,166 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(
   }
 }
 
+// ==========================================================================
+// CSR-stream kernels (the fast path).  One workgroup owns RB consecutive rows.
+// Phase 1 streams that row block's val/col arrays with unit-stride lanes
+// (fully coalesced, several independent loads in flight per lane), multiplies
+// by the gathered vector entry and parks the products in LDS.  Phase 2: one
+// thread per row sums its LDS segment in index order (same order as a scalar
+// CPU loop).  Phase 3: the fused epilogue runs thread-per-row, so the vector
+// operands (b, p_k, p_{k-1}, diag) are read and written coalesced as well.
+// Workgroups are mapped to row blocks XCD-aware: workgroups b, b+8, b+16, ...
+// share an XCD (round-robin dispatch), so they are given CONTIGUOUS row-block
+// ranges - each XCD's private L2 then holds one slab of the gathered vector
+// instead of all of it.
+// ==========================================================================
+constexpr int kTile = 4096;       // LDS doubles per workgroup (32 KiB)
+
+struct XPlain {
+  const double* x;
+  __device__ __forceinline__ double operator()(int c) const { return x[c]; }
+};
+// p = z + beta * p_old formed on the fly (CG direction update fused in SpMV)
+struct XCg {
+  const double* z; const double* p; double beta; bool first;
+  __device__ __forceinline__ double operator()(int c) const {
+    return first ? z[c] : z[c] + beta * p[c];
+  }
+};
+
+// contiguous range of row blocks of this workgroup (gridDim.x multiple of 8)
+__device__ __forceinline__ void row_block_range(int nrb, int& begin, int& end) {
+  const int G = gridDim.x;
+  const int slot = (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
+  begin = (int)((long long)slot * nrb / G);
+  end = (int)((long long)(slot + 1) * nrb / G);
+}
+
+template <int RB, class XF>
+__device__ __forceinline__ double stream_row_block(
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const XF& xf, int r0, int nrows,
+    double* lds) {
+  const int r1 = min(r0 + RB, nrows);
+  const int k0 = rowptr[r0], k1 = rowptr[r1];
+  int k = k0 + threadIdx.x;
+  for (; k + 3 * kBlock < k1; k += 4 * kBlock) {
+    const int c0 = col[k], c1 = col[k + kBlock], c2 = col[k + 2 * kBlock],
+              c3 = col[k + 3 * kBlock];
+    const double v0 = val[k], v1 = val[k + kBlock], v2 = val[k + 2 * kBlock],
+                 v3 = val[k + 3 * kBlock];
+    const double x0 = xf(c0), x1 = xf(c1), x2 = xf(c2), x3 = xf(c3);
+    lds[k - k0] = v0 * x0;
+    lds[k - k0 + kBlock] = v1 * x1;
+    lds[k - k0 + 2 * kBlock] = v2 * x2;
+    lds[k - k0 + 3 * kBlock] = v3 * x3;
+  }
+  for (; k < k1; k += kBlock) lds[k - k0] = val[k] * xf(col[k]);
+  __syncthreads();
+  double s = 0.0;
+  const int row = r0 + threadIdx.x;
+  if (threadIdx.x < RB && row < r1) {
+    const int a = rowptr[row] - k0, b = rowptr[row + 1] - k0;
+    for (int j = a; j < b; ++j) s += lds[j];
+  }
+  return s;
+}
+
+template <int RB, int MODE>
+__global__ __launch_bounds__(kBlock) void k_spmv_s(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* x, const double* add,
+    double* y) {
+  __shared__ double lds[kTile];
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, rb0, rb1);
+  const XPlain xf{x};
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const int row = r0 + threadIdx.x;
+    if (threadIdx.x < RB && row < nrows) {
+      if (MODE == 0) y[row] = s;
+      if (MODE == 1) y[row] = add[row] + s;
+      if (MODE == 2) y[row] = add[row] - s;
+    }
+    __syncthreads();
+  }
+}
+
+template <int RB>
+__global__ __launch_bounds__(kBlock) void k_cheb_step_s(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* __restrict__ dinv,
+    const double* b, const double* pm, const double* pk, double* pn,
+    double c0, double c1, double c2) {
+  __shared__ double lds[kTile];
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, rb0, rb1);
+  const XPlain xf{pk};
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const int row = r0 + threadIdx.x;
+    if (threadIdx.x < RB && row < nrows) {
+      double z = b[row] - s;
+      if (dinv) z *= dinv[row];
+      double out = c1 * pk[row] + c2 * z;
+      if (c0 != 0.0) out += c0 * pm[row];
+      pn[row] = out;
+    }
+    __syncthreads();
+  }
+}
+
+// CG, first kernel of an iteration: direction update fused into the SpMV.
+//   beta = rz_new / rz_old (both re-reduced from workgroup partials);
+//   p_new = z + beta p_old;  q = A p_new;  parts_pq[wg] = sum p_new . q
+template <int RB>
+__global__ __launch_bounds__(kBlock) void k_cg_spmv_s(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* z, const double* p_old,
+    double* p_new, double* q, const double* parts_new, const double* parts_old,
+    int nparts, double rtol, int first, double* parts_pq, CgState* st) {
+  __shared__ double lds[kTile];
+  __shared__ double sm[4];
+  if (st->done) return;
+  double beta = 0.0;
+  if (!first) {
+    const double rz_new = reduce_parts(parts_new, nparts, sm);
+    const double rz_old = reduce_parts(parts_old, nparts, sm);
+    const double rz0 = st->rz0;
+    const bool conv = (rz_new == 0.0) ||
+        (rtol > 0.0 && sqrt(fabs(rz_new)) <= rtol * sqrt(fabs(rz0)));
+    if (conv) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) st->done = 1;
+      return;
+    }
+    beta = rz_new / rz_old;
+  }
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, rb0, rb1);
+  const XCg xf{z, p_old, beta, first != 0};
+  double acc = 0.0;
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const int row = r0 + threadIdx.x;
+    if (threadIdx.x < RB && row < nrows) {
+      const double pn = xf(row);
+      p_new[row] = pn;
+      q[row] = s;
+      acc += pn * s;
+    }
+    __syncthreads();
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) parts_pq[blockIdx.x] = acc;
+}
+
 // ---- BLAS-1 glue of the apply bodies --------------------------------------
 __global__ __launch_bounds__(kBlock) void k_copy(int n, const double* x,
                                                   double* y) {
