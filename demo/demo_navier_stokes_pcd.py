@@ -12,7 +12,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from fenapack_amd.driver import default_inner_options, solve_steady  # noqa
+from fenapack_amd.driver import (default_inner_options,               # noqa
+                                 multigrid_inner_options, solve_steady)
 from fenapack_amd.fem import BackwardStep, Cavity                    # noqa
 
 p = argparse.ArgumentParser(description=__doc__)
@@ -22,6 +23,10 @@ p.add_argument("--pcd", dest="pcd_variant", default="BRM1",
                choices=["BRM1", "BRM2"])
 p.add_argument("--nls", default="picard", choices=["picard", "newton"])
 p.add_argument("--geometry", default="lshape", choices=["lshape", "cavity"])
+p.add_argument("--ls", default="mg", choices=["mg", "jacobi"],
+               help="inner solvers: multigrid V-cycles (counterpart of the "
+                    "reference's 'iterative' AMG setting) or plain "
+                    "Jacobi-CG / Chebyshev-Jacobi")
 p.add_argument("--a00-its", type=int, default=60)
 p.add_argument("--a00-ratio", type=float, default=0.01)
 args = p.parse_args()
@@ -35,7 +40,10 @@ else:
                 variant=args.pcd_variant, nls=args.nls)
     print("Reynolds number: Re = %g" % (1.0 / pb.nu))
 print("Dimension of the function space: %d" % pb.space.ndof)
-default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio)
+if args.ls == "mg":
+    multigrid_inner_options()
+else:
+    default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio)
 out = solve_steady(pb)
 print("Newton iterations: %d, converged: %s" % (out["newton_its"],
                                                 out["converged"]))

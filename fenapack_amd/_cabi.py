@@ -16,7 +16,7 @@ BRM1, BRM2, RBRM1, RBRM2 = 1, 2, 3, 4
 MAT_AP, MAT_MP, MAT_KP, MAT_RP, MAT_A00, MAT_A01, MAT_A = range(7)
 KSP_AP, KSP_MP, KSP_RP, KSP_A00 = range(4)
 PREONLY, RICHARDSON, CHEBYSHEV, CG = range(4)
-PC_NONE, PC_JACOBI = 0, 1
+PC_NONE, PC_JACOBI, PC_MG = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
     INFO_NUM_PCD_APPLY, INFO_NUM_FS_APPLY, INFO_GMRES_ITS, \
@@ -25,7 +25,7 @@ INFO_NNZ_BASE = 16
 
 KSP_TYPES = {"preonly": PREONLY, "richardson": RICHARDSON,
              "chebyshev": CHEBYSHEV, "cg": CG}
-PC_TYPES = {"none": PC_NONE, "jacobi": PC_JACOBI}
+PC_TYPES = {"none": PC_NONE, "jacobi": PC_JACOBI, "mg": PC_MG}
 VARIANTS = {"BRM1": BRM1, "BRM2": BRM2, "RBRM1": RBRM1, "RBRM2": RBRM2}
 
 _i32p = C.POINTER(C.c_int32)
@@ -43,6 +43,12 @@ _SIGNATURES = {
     "set_bc": [C.c_int64, C.c_void_p, C.c_void_p],
     "set_inner": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                   C.c_double],
+    "mg_begin": [C.c_int, C.c_int, C.c_int, C.c_int],
+    "mg_set_level": [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                     C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                     C.c_void_p, C.c_double, C.c_double],
+    "mg_update_values": [C.c_int, C.c_int, C.c_void_p, C.c_double,
+                         C.c_double, C.c_int],
     "setup": [],
     "apply": [C.c_void_p, C.c_void_p, C.c_int],
     "fieldsplit_apply": [C.c_void_p, C.c_void_p, C.c_int],
@@ -201,6 +207,29 @@ class Engine(object):
 
     def setup(self):
         self._call("setup")
+
+    # -- multigrid ----------------------------------------------------------
+    def mg_begin(self, slot, nlevels, nu_pre=2, nu_post=2):
+        self._call("mg_begin", slot, int(nlevels), int(nu_pre), int(nu_post))
+
+    def mg_set_level(self, slot, level, A=None, P=None, emin=0.0, emax=0.0):
+        a = [0, None, None, None]
+        if A is not None:
+            ip, ix, dv = _i32(A.indptr), _i32(A.indices), _f64(A.data)
+            a = [A.shape[0], _ptr(ip), _ptr(ix), _ptr(dv)]
+        b = [0, 0, None, None, None]
+        if P is not None:
+            pp, px, pv = _i32(P.indptr), _i32(P.indices), _f64(P.data)
+            b = [P.shape[0], P.shape[1], _ptr(pp), _ptr(px), _ptr(pv)]
+        self._call("mg_set_level", slot, int(level), *(a + b),
+                   float(emin), float(emax))
+
+    def mg_update_values(self, slot, level, vals, emin=0.0, emax=0.0,
+                         mem=MEM_HOST):
+        if vals is not None and mem == MEM_HOST:
+            vals = _f64(vals)
+        self._call("mg_update_values", slot, int(level), _ptr(vals),
+                   float(emin), float(emax), mem)
 
     # -- hot path -----------------------------------------------------------
     def apply(self, x, y, mem=MEM_HOST):

@@ -80,9 +80,23 @@ struct DCsr {
   }
 };
 
+// one level of the geometric multigrid hierarchy (level 0 = coarsest)
+struct MgLevel {
+  DCsr A;                 // operator; level 0: explicit inverse; finest: unused
+  DCsr P, R;              // prolongation level-1 -> level and its transpose
+  double emin = 0.0, emax = 0.0;
+  DBuf<double> x, t0, t1, r, b;
+  void release() {
+    A.release(); P.release(); R.release();
+    x.release(); t0.release(); t1.release(); r.release(); b.release();
+  }
+};
+
 struct Inner {
   int ksp = PCD_KSP_CG, pc = PCD_PC_JACOBI, max_it = 10000;
   double rtol = 1e-12, emin = 0.5, emax = 2.0;
+  int nu_pre = 2, nu_post = 2;
+  std::vector<MgLevel> mg;
   // device scratch, sized at setup
   DBuf<double> t0, t1, t2, t3, t4;   // r,z,p,q,p'  or the Chebyshev ring
   DBuf<double> parts;                // 3 * kMaxParts
@@ -92,6 +106,8 @@ struct Inner {
   void release() {
     t0.release(); t1.release(); t2.release(); t3.release(); t4.release();
     parts.release(); state.release();
+    for (auto& l : mg) l.release();
+    mg.clear();
   }
 };
 
@@ -264,6 +280,18 @@ static int inner_prepare(Engine* h, int slot) {
   const DCsr& A = h->mat[kSlotMat[slot]];
   if (!A.set) return 0;
   const size_t n = A.nrows;
+  if (s.pc == PCD_PC_MG) {
+    CHK(s.t0.ensure(n));
+    for (size_t l = 0; l < s.mg.size(); ++l) {
+      MgLevel& M = s.mg[l];
+      const size_t nl = (l + 1 == s.mg.size()) ? n
+                        : (M.A.set ? (size_t)M.A.nrows : 0);
+      if (!nl) continue;
+      CHK(M.x.ensure(nl)); CHK(M.b.ensure(nl));
+      if (l > 0) { CHK(M.t0.ensure(nl)); CHK(M.t1.ensure(nl)); CHK(M.r.ensure(nl)); }
+    }
+    return 0;
+  }
   switch (s.ksp) {
     case PCD_KSP_CG:
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n)); CHK(s.t2.ensure(n));
@@ -422,12 +450,125 @@ static int solve_rich(Engine* h, const DCsr& A, Inner& s, const double* b,
   return 0;
 }
 
+// ---- [ext PETSc] PCMG: multiplicative V-cycle on the device -----------------
+// Chebyshev-Jacobi smoothing; every step is one fused k_cheb_step launch.
+// Iterates rotate through bufs[0..2]; with a nonzero guess the guess sits in
+// bufs[0].  *result points at the buffer holding the smoothed vector.
+static int mg_smooth(Engine* h, const DCsr& A, double emin, double emax, int nu,
+                     const double* b, double* bufs[3], bool zero_guess,
+                     double** result) {
+  const int n = (int)A.nrows;
+  if (nu == 0) {
+    if (zero_guess) HIPCHK(hipMemsetAsync(bufs[0], 0, n * sizeof(double), h->stream));
+    *result = bufs[0];
+    return 0;
+  }
+  const double* dinv = A.dinv.p;
+  const double scale = 2.0 / (emax + emin);
+  const double alpha = 1.0 - scale * emin;
+  const double mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
+  double c_km1 = 1.0, c_k = mu;
+  int cur;                       // index in bufs of the newest iterate
+  bool have_pm;                  // p_{k-1} is a real vector (not zero)
+  if (zero_guess) {
+    hipLaunchKernelGGL(k_scale_dinv, dim3(grid1d(n, 1)), dim3(kBlock), 0,
+                       h->stream, n, dinv, b, scale, bufs[0]);
+    cur = 0; have_pm = false;
+  } else {
+    launch_cheb_step(h, A, dinv, b, bufs[0], bufs[0], bufs[1], 0.0, 1.0, scale);
+    cur = 1; have_pm = true;
+  }
+  for (int it = 0; it < nu - 1; ++it) {
+    const double c_kp1 = 2.0 * mu * c_k - c_km1;
+    const double omega = omegaprod * c_k / c_kp1;
+    double* pk = bufs[cur % 3];
+    double* pn = bufs[(cur + 1) % 3];
+    double* pm = have_pm ? bufs[(cur + 2) % 3] : pk;
+    launch_cheb_step(h, A, dinv, b, pm, pk, pn, have_pm ? 1.0 - omega : 0.0,
+                     omega, omega * scale);
+    c_km1 = c_k; c_k = c_kp1;
+    ++cur; have_pm = true;
+  }
+  HIPCHK(hipGetLastError());
+  *result = bufs[cur % 3];
+  return 0;
+}
+
+// x_l = V-cycle(b) on level l; *out points at the level buffer with the result
+static int mg_vcycle(Engine* h, const DCsr& Afine, Inner& s, int l,
+                     const double* b, double** out) {
+  MgLevel& L = s.mg[l];
+  if (l == 0) {
+    CHK(spmv(h, L.A, b, L.x.p));              // explicit coarse inverse
+    *out = L.x.p;
+    return 0;
+  }
+  const DCsr& A = (l == (int)s.mg.size() - 1) ? Afine : L.A;
+  MgLevel& C = s.mg[l - 1];
+  double* bufs[3] = {L.x.p, L.t0.p, L.t1.p};
+  double* px = nullptr;
+  CHK(mg_smooth(h, A, L.emin, L.emax, s.nu_pre, b, bufs, true, &px));
+  const double* r = b;
+  if (s.nu_pre > 0) {
+    CHK(spmv(h, A, px, L.r.p, 2, b));        // r = b - A x
+    r = L.r.p;
+  }
+  CHK(spmv(h, L.R, r, C.b.p));                // restrict
+  double* pe = nullptr;
+  CHK(mg_vcycle(h, Afine, s, l - 1, C.b.p, &pe));
+  CHK(spmv(h, L.P, pe, px, 1, px));           // x += P e
+  double* post[3];
+  int j = 0;
+  post[0] = px;
+  for (double* q : bufs) if (q != px) post[++j] = q;
+  CHK(mg_smooth(h, A, L.emin, L.emax, s.nu_post, b, post, false, out));
+  return 0;
+}
+
+// KSPPREONLY (one cycle) / KSPRICHARDSON (max_it cycles) around the V-cycle
+static int solve_mg(Engine* h, const DCsr& A, Inner& s, const double* b,
+                    double* x) {
+  const int n = (int)A.nrows;
+  const int L = (int)s.mg.size();
+  if (L < 1) return fail(PCD_ERR_STATE, "pc mg: no hierarchy (pcd_mg_begin / pcd_mg_set_level)");
+  for (int l = 0; l < L; ++l) {
+    const MgLevel& M = s.mg[l];
+    if ((l < L - 1 && !M.A.set) || (l > 0 && !M.P.set))
+      return fail(PCD_ERR_STATE, "pc mg: level %d incomplete", l);
+  }
+  if (s.mg[L - 1].P.set && s.mg[L - 1].P.nrows != n)
+    return fail(PCD_ERR_ARG, "pc mg: finest prolongation has %lld rows, operator %d",
+                (long long)s.mg[L - 1].P.nrows, n);
+  const int its = (s.ksp == PCD_KSP_PREONLY) ? 1 : std::max(s.max_it, 1);
+  const int g = grid1d(n, 1);
+  for (int it = 0; it < its; ++it) {
+    const double* r = b;
+    if (it > 0) {
+      CHK(spmv(h, A, x, s.t0.p, 2, b));       // r = b - A x
+      r = s.t0.p;
+    }
+    double* z = nullptr;
+    if (L == 1) { CHK(spmv(h, s.mg[0].A, r, s.mg[0].x.p)); z = s.mg[0].x.p; }
+    else CHK(mg_vcycle(h, A, s, L - 1, r, &z));
+    if (it == 0) hipLaunchKernelGGL(k_copy, dim3(g), dim3(kBlock), 0, h->stream, n, z, x);
+    else hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, 1.0, z, 1.0, x);
+  }
+  HIPCHK(hipGetLastError());
+  s.last_its = its; s.its_on_device = false;
+  return 0;
+}
+
 // KSP.solve(b, x): b and x must not alias
 static int inner_solve(Engine* h, int slot, const double* b, double* x) {
   const DCsr& A = h->mat[kSlotMat[slot]];
   Inner& s = h->inner[slot];
   if (!A.set) return fail(PCD_ERR_STATE, "inner_solve: operator of slot %d not set", slot);
   if (b == x) return fail(PCD_ERR_ARG, "inner_solve: b and x alias");
+  if (s.pc == PCD_PC_MG) {
+    if (s.ksp != PCD_KSP_PREONLY && s.ksp != PCD_KSP_RICHARDSON)
+      return fail(PCD_ERR_ARG, "pc mg is supported under preonly / richardson only");
+    return solve_mg(h, A, s, b, x);
+  }
   switch (s.ksp) {
     case PCD_KSP_PREONLY: {
       const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
@@ -747,14 +888,96 @@ int pcd_set_bc(pcd_handle h, int64_t n_bc, const int32_t* idx, const double* val
   return 0;
 }
 
+// ---- multigrid hierarchy ------------------------------------------------
+int pcd_mg_begin(pcd_handle h, int slot, int nlevels, int nu_pre, int nu_post) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_begin: bad slot %d", slot);
+  if (nlevels < 1 || nlevels > 32 || nu_pre < 0 || nu_post < 0)
+    return fail(PCD_ERR_ARG, "mg_begin: bad level / smoothing counts");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  Inner& s = h->inner[slot];
+  for (auto& l : s.mg) l.release();
+  s.mg.clear();
+  s.mg.resize(nlevels);
+  s.nu_pre = nu_pre; s.nu_post = nu_post;
+  return 0;
+}
+
+int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
+                     const int32_t* rowptr, const int32_t* colidx,
+                     const double* vals, int64_t p_rows, int64_t p_cols,
+                     const int32_t* prowptr, const int32_t* pcolidx,
+                     const double* pvals, double emin, double emax) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_set_level: bad slot %d", slot);
+  Inner& s = h->inner[slot];
+  const int L = (int)s.mg.size();
+  if (level < 0 || level >= L) return fail(PCD_ERR_ARG, "mg_set_level: level %d outside [0,%d)", level, L);
+  if (level > 0 && !(emax > emin && emin > 0.0))
+    return fail(PCD_ERR_ARG, "mg_set_level: smoother needs 0 < emin < emax");
+  MgLevel& M = s.mg[level];
+  if (rowptr) {
+    if (!colidx || !vals) return fail(PCD_ERR_ARG, "mg_set_level: bad operator arrays");
+    CHK(upload_csr(h, M.A, n, n, rowptr, colidx, vals, nullptr));
+    CHK(refresh_dinv(h, M.A));
+  } else if (level != L - 1) {
+    return fail(PCD_ERR_ARG, "mg_set_level: coarse levels need an operator");
+  }
+  if (level > 0) {
+    if (!prowptr || !pcolidx || !pvals) return fail(PCD_ERR_ARG, "mg_set_level: prolongation missing");
+    CHK(upload_csr(h, M.P, p_rows, p_cols, prowptr, pcolidx, pvals, nullptr));
+    // restriction = transpose, built on the host (counting sort by column)
+    const int64_t nnz = prowptr[p_rows];
+    std::vector<int32_t> trp(p_cols + 1, 0), tc(nnz);
+    std::vector<double> tv(nnz);
+    for (int64_t k = 0; k < nnz; ++k) ++trp[pcolidx[k] + 1];
+    for (int64_t c = 0; c < p_cols; ++c) trp[c + 1] += trp[c];
+    std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
+    for (int64_t i = 0; i < p_rows; ++i)
+      for (int32_t k = prowptr[i]; k < prowptr[i + 1]; ++k) {
+        const int32_t q = fill[pcolidx[k]]++;
+        tc[q] = (int32_t)i; tv[q] = pvals[k];
+      }
+    CHK(upload_csr(h, M.R, p_cols, p_rows, trp.data(), tc.data(), tv.data(), nullptr));
+  }
+  M.emin = emin; M.emax = emax;
+  if (h->ready) CHK(inner_prepare(h, slot));
+  return 0;
+}
+
+int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
+                         double emin, double emax, int mem) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_update_values: bad slot %d", slot);
+  Inner& s = h->inner[slot];
+  if (level < 0 || level >= (int)s.mg.size()) return fail(PCD_ERR_STATE, "mg_update_values: level %d not set", level);
+  MgLevel& M = s.mg[level];
+  if (vals) {
+    if (!M.A.set) return fail(PCD_ERR_STATE, "mg_update_values: level %d has no operator", level);
+    HIPCHK(hipMemcpyAsync(M.A.val.p, vals, M.A.nnz * sizeof(double),
+                          mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          h->stream));
+    CHK(refresh_dinv(h, M.A));
+    if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  if (level > 0) {
+    if (!(emax > emin && emin > 0.0)) return fail(PCD_ERR_ARG, "mg_update_values: smoother needs 0 < emin < emax");
+    M.emin = emin; M.emax = emax;
+  }
+  return 0;
+}
+
 int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type, int max_it,
                   double rtol, double emin, double emax) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "set_inner: bad slot %d", slot);
   if (ksp_type < PCD_KSP_PREONLY || ksp_type > PCD_KSP_CG)
     return fail(PCD_ERR_ARG, "set_inner: unsupported ksp type %d", ksp_type);
-  if (pc_type != PCD_PC_NONE && pc_type != PCD_PC_JACOBI)
+  if (pc_type != PCD_PC_NONE && pc_type != PCD_PC_JACOBI && pc_type != PCD_PC_MG)
     return fail(PCD_ERR_ARG, "set_inner: unsupported pc type %d", pc_type);
+  if (pc_type == PCD_PC_MG && ksp_type != PCD_KSP_PREONLY && ksp_type != PCD_KSP_RICHARDSON)
+    return fail(PCD_ERR_ARG, "set_inner: pc mg is supported under preonly / richardson only");
   if (max_it < 0) return fail(PCD_ERR_ARG, "set_inner: negative max_it");
   if (ksp_type == PCD_KSP_CHEBYSHEV && !(emax > emin && emin > 0.0))
     return fail(PCD_ERR_ARG, "set_inner: chebyshev needs 0 < emin < emax");

@@ -11,6 +11,26 @@ from . import (PCDAssembler, PCDKrylovSolver, PCDNewtonSolver,
 from .fem.forms import navier_stokes_forms
 
 
+def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
+                            mp_its=5, pcdr=False):
+    """The reference's "iterative" configuration (demo_navier-stokes-pcd.py:
+    152-165: Richardson + one/two multigrid cycles for A00 and Ap, Chebyshev +
+    Jacobi for Mp) with hypre BoomerAMG replaced by the engine's geometric
+    multigrid (``pc_type mg``)."""
+    S = PETScOptions.set
+    for key, cycles in (("fieldsplit_u_", cycles_u),
+                        ("fieldsplit_p_PCD_Ap_", cycles_p)) \
+            + ((("fieldsplit_p_PCD_Rp_", cycles_p),) if pcdr else ()):
+        S(prefix + key + "ksp_type", "richardson")
+        S(prefix + key + "ksp_max_it", cycles)
+        S(prefix + key + "pc_type", "mg")
+        S(prefix + key + "mg_levels_ksp_max_it", smooth)
+    S(prefix + "fieldsplit_p_PCD_Mp_ksp_type", "chebyshev")
+    S(prefix + "fieldsplit_p_PCD_Mp_ksp_max_it", mp_its)
+    S(prefix + "fieldsplit_p_PCD_Mp_ksp_chebyshev_eigenvalues", "0.5, 2.0")
+    S(prefix + "fieldsplit_p_PCD_Mp_pc_type", "jacobi")
+
+
 def default_inner_options(prefix="", a00_its=60, a00_ratio=0.01, ap_rtol=1e-8,
                           ap_its=10000, mp_its=5, pcdr=False):
     """North-star inner solvers expressed with the reference's option names

@@ -126,5 +126,10 @@ def unit_square_mesh(n):
 
 
 def cavity_mesh(level):
-    """Unit-square cavity with N = 5 * 2**level cells per side."""
-    return unit_square_mesh(5 * 2 ** level)
+    """Unit-square cavity with N = 5 * 2**level cells per side:
+    the 5 x 5 base mesh refined ``level`` times (a uniformly refined
+    right-diagonal mesh is the right-diagonal mesh of twice the resolution)."""
+    mesh = unit_square_mesh(5)
+    for _ in range(level):
+        mesh = mesh.refine()
+    return mesh

@@ -1,0 +1,133 @@
+"""Nested mesh hierarchies and P2 / P1 prolongation operators.
+
+Input producer for the engine's geometric-multigrid inner solves (the
+device-native stand-in for the hypre BoomerAMG cycles of the reference's
+"iterative" configuration, ``demo/navier-stokes-pcd/demo_navier-stokes-pcd.py:
+153-160``).  Meshes are nested by uniform refinement, so a fine node lies in
+exactly one parent cell and the prolongation row is the parent's basis
+evaluated at that node (<= 6 entries for P2, <= 3 for P1).  Coarse operators
+are Galerkin products ``P^T A P`` (host side, scipy)."""
+
+import numpy as np
+import scipy.sparse as sp
+
+from .taylor_hood import TaylorHood, _p2_basis
+
+
+class MeshHierarchy(object):
+    """``meshes[0]`` (coarsest) ... ``meshes[-1]``; ``parents[l][f]`` = cell of
+    level ``l-1`` containing fine cell ``f`` of level ``l``."""
+
+    def __init__(self, base, levels):
+        self.meshes, self.parents = [base], [None]
+        for _ in range(levels):
+            m = self.meshes[-1]
+            fine = m.refine()          # children stacked in 4 blocks of nc
+            self.meshes.append(fine)
+            self.parents.append(np.arange(fine.num_cells) % m.num_cells)
+        self._spaces = {}
+
+    @property
+    def finest(self):
+        return self.meshes[-1]
+
+    def space(self, level, finest_space=None):
+        if level == len(self.meshes) - 1 and finest_space is not None:
+            return finest_space
+        if level not in self._spaces:
+            self._spaces[level] = TaylorHood(self.meshes[level])
+        return self._spaces[level]
+
+
+def _unique_entries(rows, cols, vals, shape):
+    key = rows.ravel().astype(np.int64) * shape[1] + cols.ravel()
+    u, idx = np.unique(key, return_index=True)
+    v = vals.ravel()[idx]
+    keep = np.abs(v) > 1e-14
+    P = sp.csr_matrix((v[keep], (u[keep] // shape[1], u[keep] % shape[1])),
+                      shape=shape)
+    P.sort_indices()
+    return P
+
+
+def prolongations(Vc, Vf, parent):
+    """(scalar P2, P1) prolongation matrices coarse -> fine."""
+    mc, mf = Vc.mesh, Vf.mesh
+    pc = mc.vertices[mc.cells[parent]]                 # parent triangles
+    pf = mf.vertices[mf.cells]
+    mids = np.stack([0.5 * (pf[:, 1] + pf[:, 2]), 0.5 * (pf[:, 2] + pf[:, 0]),
+                     0.5 * (pf[:, 0] + pf[:, 1])], axis=1)
+    pts = np.concatenate([pf, mids], axis=1)           # 6 P2 nodes per cell
+    e1, e2 = pc[:, 1] - pc[:, 0], pc[:, 2] - pc[:, 0]
+    det = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+    d = pts - pc[:, None, 0, :]
+    l1 = (d[..., 0] * e2[:, None, 1] - d[..., 1] * e2[:, None, 0]) \
+        / det[:, None]
+    l2 = (d[..., 1] * e1[:, None, 0] - d[..., 0] * e1[:, None, 1]) \
+        / det[:, None]
+    lam = np.stack([1.0 - l1 - l2, l1, l2], axis=2)    # (nf, 6, 3)
+    phi, _ = _p2_basis(lam.reshape(-1, 3))
+    phi = phi.reshape(lam.shape[0], 6, 6)
+    rows = np.repeat(Vf.cell_dofs2[:, :, None], 6, axis=2)
+    cols = np.repeat(Vc.cell_dofs2[parent][:, None, :], 6, axis=1)
+    P2 = _unique_entries(rows, cols, phi, (Vf.nn, Vc.nn))
+    rows1 = np.repeat(Vf.cell_dofs1[:, :, None], 3, axis=2)
+    cols1 = np.repeat(Vc.cell_dofs1[parent][:, None, :], 3, axis=1)
+    P1 = _unique_entries(rows1, cols1, lam[:, :3, :], (Vf.n_p, Vc.n_p))
+    return P2, P1
+
+
+def interleave2(P):
+    """Scalar P2 prolongation -> velocity prolongation (dofs 2*node+comp)."""
+    P = sp.kron(P, sp.identity(2, format="csr"), format="csr")
+    P.sort_indices()
+    return P
+
+
+class Interpolations(object):
+    """Prolongation chains of a problem: ``velocity[l]`` / ``pressure[l]`` map
+    level ``l-1`` to level ``l`` (index 0 is ``None``)."""
+
+    def __init__(self, hierarchy, finest_space):
+        self.velocity, self.pressure = [None], [None]
+        L = len(hierarchy.meshes) - 1
+        for l in range(1, L + 1):
+            Vc = hierarchy.space(l - 1)
+            Vf = hierarchy.space(l, finest_space)
+            P2, P1 = prolongations(Vc, Vf, hierarchy.parents[l])
+            self.velocity.append(interleave2(P2))
+            self.pressure.append(P1)
+
+    def chain(self, field, nlevels=None):
+        """Prolongations for ``nlevels`` levels ending at the finest one."""
+        full = self.velocity if field == "u" else self.pressure
+        if nlevels is None or nlevels >= len(full):
+            return list(full)
+        return [None] + full[len(full) - nlevels + 1:]
+
+
+def galerkin_chain(A, chain):
+    """Coarse operators ``A_{l-1} = P_l^T A_l P_l``; returns the list of
+    operators, coarsest first (``ops[-1] is A``)."""
+    ops = [None] * len(chain)
+    ops[-1] = sp.csr_matrix(A)
+    for l in range(len(chain) - 1, 0, -1):
+        P = chain[l]
+        C = (P.T @ ops[l] @ P).tocsr()
+        C.sort_indices()
+        ops[l - 1] = C
+    return ops
+
+
+def dense_csr(C):
+    """Dense matrix as CSR with the FULL pattern (explicit zeros kept), so a
+    refreshed coarse inverse always fits the pattern handed over first."""
+    C = np.ascontiguousarray(C, dtype=np.float64)
+    n, m = C.shape
+    return sp.csr_matrix((C.ravel(), np.tile(np.arange(m, dtype=np.int32), n),
+                          np.arange(n + 1, dtype=np.int32) * m), shape=(n, m))
+
+
+def coarse_inverse(A0):
+    """Explicit (pseudo-)inverse of the coarsest operator."""
+    return dense_csr(np.linalg.pinv(A0.toarray(), rcond=1e-12))

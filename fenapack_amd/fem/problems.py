@@ -17,7 +17,9 @@ symmetrically as ``SystemAssembler`` does (``fenapack/assembling.py:98-100,
 import numpy as np
 import scipy.sparse as sp
 
-from .mesh import lshape_mesh, cavity_mesh
+from .mesh import Mesh, unit_square_mesh
+from .mesh import _LSHAPE_VERTICES, _LSHAPE_CELLS
+from .multigrid import MeshHierarchy, Interpolations
 from .taylor_hood import TaylorHood
 
 
@@ -66,11 +68,12 @@ class _Dirichlet(object):
 class FlowProblem(object):
     """Common machinery; subclasses define geometry and boundary data."""
 
-    def __init__(self, mesh, nu, variant="BRM1", nls="picard", dt=None,
+    def __init__(self, hierarchy, nu, variant="BRM1", nls="picard", dt=None,
                  pcdr=False, stabilize=False):
         assert variant in ("BRM1", "BRM2")
         assert nls in ("picard", "newton")
-        self.space = V = TaylorHood(mesh)
+        self.hierarchy = hierarchy
+        self.space = V = TaylorHood(hierarchy.finest)
         self.nu = float(nu)
         self.variant = variant
         self.nls = nls
@@ -92,6 +95,13 @@ class FlowProblem(object):
         if self.idt:
             self._Mmass = V.assemble_Mu(1.0)
         self.u0 = np.zeros(V.n_u)
+        V.interpolations = self.interpolations     # for pc_type mg
+
+    def interpolations(self):
+        """Prolongation chains for the multigrid inner solves (lazy)."""
+        if not hasattr(self, "_interp"):
+            self._interp = Interpolations(self.hierarchy, self.space)
+        return self._interp
 
     # -- helpers -----------------------------------------------------------
     def _edge_dofs_u(self, edges):
@@ -173,7 +183,8 @@ class BackwardStep(FlowProblem):
 
     def __init__(self, level, nu=0.02, **kw):
         self.level = level
-        FlowProblem.__init__(self, lshape_mesh(level), nu, **kw)
+        base = Mesh(_LSHAPE_VERTICES.copy(), _LSHAPE_CELLS.copy())
+        FlowProblem.__init__(self, MeshHierarchy(base, level), nu, **kw)
 
     def _classify_boundary(self):
         V, m = self.space, self.space.mesh
@@ -216,10 +227,8 @@ class Cavity(FlowProblem):
 
     def __init__(self, level, nu=0.01, n=None, **kw):
         self.level = level
-        mesh = cavity_mesh(level) if n is None else \
-            __import__("fenapack_amd.fem.mesh", fromlist=["x"]) \
-            .unit_square_mesh(n)
-        FlowProblem.__init__(self, mesh, nu, **kw)
+        base = unit_square_mesh(5 if n is None else n)
+        FlowProblem.__init__(self, MeshHierarchy(base, level), nu, **kw)
 
     def _classify_boundary(self):
         V, m = self.space, self.space.mesh

@@ -104,7 +104,10 @@ class TaylorHood(object):
         coords = np.concatenate([mesh.vertices, mesh.edge_midpoints()])
         ext = coords.max(axis=0) - coords.min(axis=0)
         major = int(np.argmax(ext))
-        order = np.lexsort((coords[:, 1 - major], coords[:, major]))
+        # round so that nodes meant to share a coordinate compare equal
+        # whatever sequence of midpoint averages produced them
+        key = np.round(coords * 2.0 ** 30)
+        order = np.lexsort((key[:, 1 - major], key[:, major]))
         rank = np.empty(nn, dtype=np.int64)
         rank[order] = np.arange(nn)
         self.node_coords = coords[order]             # by scalar P2 dof

@@ -84,6 +84,8 @@ class PCDKSP(KSP):
         self._upload_system(A, P, is0, is1, first=True)
         ksp0.setOperators(Mat(self._A00_host(A, P, is0)))
         ksp0.bind(self.engine, c.KSP_A00)
+        if ksp0.pc.type == "mg" and ksp0.pc._mg_chain is None:
+            ksp0.pc.setMGInterpolations(V.interpolations().chain("u"))
         ksp0.setUp()
 
         ksp1.pc.setPythonContext(pcd_pc)
@@ -130,7 +132,8 @@ class PCDKSP(KSP):
             return
         self._upload_system(A, P)
         ksp0, ksp1 = self.pc.getFieldSplitSubKSP()
-        if ksp0.type == "chebyshev" and ksp0.cheb_eigs is None:
+        if (ksp0.type == "chebyshev" and ksp0.cheb_eigs is None) \
+                or ksp0.pc.type == "mg":
             ksp0.setOperators(Mat(self._A00_host(A, P, self._is[0])))
         ksp0.setUp()
         ksp1.pc.setUp()

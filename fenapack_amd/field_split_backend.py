@@ -121,6 +121,7 @@ class PCDInterface(object):
             mat.setOptionsPrefix(ksp.getOptionsPrefix())
             ksp.setOperators(mat, mat)
             ksp.bind(self.engine, c.KSP_RP)
+            self._give_interpolations(ksp)
             ksp.setUp()
 
     def _build_approx_Ap(self, Mu, Bt, mat=None):
@@ -134,6 +135,12 @@ class PCDInterface(object):
         Bt.copy(result=Ap)
         Ap.diagonalScale(L=diagMu)
         return Ap.transposeMatMult(Ap)
+
+    def _give_interpolations(self, ksp):
+        """pc_type mg on a pressure-space KSP: hand over the P1 chain."""
+        if ksp.pc.type == "mg" and ksp.pc._mg_chain is None:
+            V = self.assembler.function_space()
+            ksp.pc.setMGInterpolations(V.interpolations().chain("p"))
 
     def _cached(self, name, num, factory):
         items = self.__dict__.get(name)
@@ -167,6 +174,7 @@ class PCDInterface(object):
             mat.setOptionsPrefix(ksp.getOptionsPrefix())
             ksp.setOperators(mat, mat)
             ksp.bind(self.engine, slot)
+            self._give_interpolations(ksp)
             ksp.setUp()
         elif not const:
             work = Mat()

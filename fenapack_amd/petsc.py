@@ -246,12 +246,13 @@ class DeviceMat(Mat):
 # ------------------------------------------------------------------ KSP / PC
 _UNSUPPORTED_PC = ("lu", "cholesky", "hypre", "ilu", "icc", "gamg", "ml",
                    "bjacobi", "asm", "sor")
+_SUPPORTED_PC = ("none", "jacobi", "mg")
 
 
 class PC(object):
     class Type(object):
-        NONE, JACOBI, LU, CHOLESKY, FIELDSPLIT, PYTHON = \
-            "none", "jacobi", "lu", "cholesky", "fieldsplit", "python"
+        NONE, JACOBI, LU, CHOLESKY, FIELDSPLIT, PYTHON, MG = \
+            "none", "jacobi", "lu", "cholesky", "fieldsplit", "python", "mg"
 
     class Side(object):
         LEFT, RIGHT = "left", "right"
@@ -273,6 +274,17 @@ class PC(object):
         self._fs = {}
         self._is = None
         self._subksp = None
+        # [ext PETSc] PCMG: prolongation chain, levels, smoother settings
+        self._mg_chain = None
+        self.mg_levels = None
+        self.mg_smooth_its = 2
+        self.mg_esteig = (0.0, 0.1, 0.0, 1.1)
+        self._mg_pushed = None
+
+    def setMGInterpolations(self, chain):
+        """``chain[l]`` maps level l-1 to l, ``chain[0] is None``
+        (PCMGSetInterpolation)."""
+        self._mg_chain = list(chain)
 
     def setType(self, t):
         self.type = t
@@ -398,6 +410,13 @@ class KSP(object):
                     "(north star: Jacobi-CG / Chebyshev-Jacobi)"
                     % (self._prefix, p))
             self.pc.setType(p)
+        self.pc.mg_levels = o.getInt("pc_mg_levels", self.pc.mg_levels)
+        self.pc.mg_smooth_its = o.getInt("mg_levels_ksp_max_it",
+                                         self.pc.mg_smooth_its)
+        e = o.getString("mg_levels_ksp_chebyshev_esteig")
+        if e is not None:
+            self.pc.mg_esteig = tuple(float(v)
+                                      for v in e.replace(",", " ").split())
         self.max_it = o.getInt("ksp_max_it", self.max_it)
         self.rtol = o.getReal("ksp_rtol", self.rtol)
         self.atol = o.getReal("ksp_atol", self.atol)
@@ -424,12 +443,56 @@ class KSP(object):
         a, b, cc, d = self.cheb_esteig
         return (b * emax, d * emax)        # emin estimate taken as 0
 
+    def _push_multigrid(self):
+        """Galerkin coarse operators, smoother bounds and the explicit coarse
+        inverse, computed on the host and handed to ``pcd_mg_*``.  Patterns
+        are fixed, so later calls only refresh values."""
+        from .fem.multigrid import galerkin_chain, coarse_inverse
+        pc = self.pc
+        if pc._mg_chain is None:
+            raise RuntimeError("%spc_type mg needs interpolations "
+                               "(pc.setMGInterpolations)" % self._prefix)
+        chain = pc._mg_chain
+        if pc.mg_levels is not None and pc.mg_levels < len(chain):
+            chain = [None] + chain[len(chain) - pc.mg_levels + 1:]
+        ops = galerkin_chain(self._ops[1].A, chain)
+        a, b, cc, d = pc.mg_esteig
+        bounds = [None]
+        for l in range(1, len(ops)):
+            emax = estimate_emax(ops[l], iters=12)
+            bounds.append((b * emax, d * emax))
+        C = coarse_inverse(ops[0])
+        eng, slot, L = self.engine, self.slot, len(ops)
+        sig = (L, pc.mg_smooth_its, tuple(o.nnz for o in ops))
+        if pc._mg_pushed != sig:
+            eng.mg_begin(slot, L, pc.mg_smooth_its, pc.mg_smooth_its)
+            eng.mg_set_level(slot, 0, C)
+            for l in range(1, L):
+                eng.mg_set_level(slot, l, ops[l] if l < L - 1 else None,
+                                 chain[l], *bounds[l])
+            pc._mg_pushed = sig
+        else:
+            eng.mg_update_values(slot, 0, C.data)
+            for l in range(1, L):
+                eng.mg_update_values(slot, l,
+                                     ops[l].data if l < L - 1 else None,
+                                     *bounds[l])
+
     def push_settings(self):
         """Translate the PETSc-style description into ``pcd_set_inner``."""
-        pc = self.pc.type if self.pc.type in ("none", "jacobi") else None
+        pc = self.pc.type if self.pc.type in _SUPPORTED_PC else None
         if pc is None:
             raise ValueError("%spc_type %s is not supported by the HIP engine"
                              % (self._prefix, self.pc.type))
+        if pc == "mg":
+            if self.type not in ("preonly", "richardson"):
+                raise ValueError("%spc_type mg runs under ksp_type preonly or "
+                                 "richardson" % self._prefix)
+            self._push_multigrid()
+            self.engine.set_inner(self.slot, self.type, "mg",
+                                  1 if self.type == "preonly" else self.max_it,
+                                  0.0, 0.5, 2.0)
+            return
         lo, hi = 0.5, 2.0
         rtol = self.rtol
         if self.type == "chebyshev":

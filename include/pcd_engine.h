@@ -67,7 +67,7 @@ enum pcd_slot { PCD_KSP_AP = 0, PCD_KSP_MP = 1, PCD_KSP_RP = 2,
 enum pcd_ksp_type { PCD_KSP_PREONLY = 0, PCD_KSP_RICHARDSON = 1,
                     PCD_KSP_CHEBYSHEV = 2, PCD_KSP_CG = 3 };
 /* [ext PETSc] PC types honoured (-<prefix>pc_type) */
-enum pcd_pc_type { PCD_PC_NONE = 0, PCD_PC_JACOBI = 1 };
+enum pcd_pc_type { PCD_PC_NONE = 0, PCD_PC_JACOBI = 1, PCD_PC_MG = 2 };
 
 enum pcd_mem { PCD_MEM_HOST = 0, PCD_MEM_DEVICE = 1 };
 
@@ -129,6 +129,34 @@ int pcd_set_bc(pcd_handle h, int64_t n_bc, const int32_t* idx,
  * rtol <= 0 means "run exactly max_it iterations" (-ksp_norm_type none). */
 int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type,
                   int max_it, double rtol, double emin, double emax);
+
+/* ---- geometric multigrid as inner preconditioner (pc_type = PCD_PC_MG) ----
+ * The reference's "iterative" configuration runs hypre BoomerAMG V-cycles
+ * under Richardson for A00, Ap (and Rp): demo_navier-stokes-pcd.py:153-160,
+ * demo_unsteady-navier-stokes-pcdr.py:167-170.  hypre does not exist here;
+ * this is the device-native counterpart with the same role and call shape
+ * ([ext PETSc] PCMG: PCMGSetLevels / PCMGSetInterpolation / per-level
+ * operators): a multiplicative V(nu_pre, nu_post) cycle whose smoother is the
+ * fused Chebyshev-Jacobi kernel, restriction = transpose of the prolongation,
+ * level 0 solved by an explicit inverse handed over as a (dense) CSR matrix.
+ * Level nlevels-1 is the slot's own operator.  Supported under
+ * PCD_KSP_PREONLY (one cycle) and PCD_KSP_RICHARDSON (max_it cycles). */
+int pcd_mg_begin(pcd_handle h, int slot, int nlevels, int nu_pre, int nu_post);
+/* level 0: (n, rowptr, colidx, vals) = A_0^-1, no prolongation, no bounds.
+ * 0 < level < nlevels-1: A_level, prolongation level-1 -> level
+ *   (p_rows x p_cols = n_level x n_{level-1}) and the bounds [emin, emax] of
+ *   diag(A)^-1 A used by the smoother.
+ * level nlevels-1: rowptr == NULL (operator of the slot), prolongation and
+ *   bounds as above. */
+int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
+                     const int32_t* rowptr, const int32_t* colidx,
+                     const double* vals, int64_t p_rows, int64_t p_cols,
+                     const int32_t* prowptr, const int32_t* pcolidx,
+                     const double* pvals, double emin, double emax);
+/* re-assembled operator of one level (same pattern) and refreshed bounds;
+ * vals == NULL only refreshes the bounds (finest level) */
+int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
+                         double emin, double emax, int mem);
 
 /* BasePCDPC.setUp / BasePCDRPC.setUp (preconditioners.py:71-85,191-207) and
  * ksp.setUp() of field_split_backend.py:254-263: checks every operator the

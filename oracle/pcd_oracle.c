@@ -46,10 +46,19 @@ typedef struct {
   int set;
 } csr_t;
 
+enum { PC_MG = 2 };
+#define MG_MAX_LEVELS 16
+
 typedef struct {
   int ksp, pc, max_it;
   double rtol, emin, emax;
   int last_its;
+  /* [ext PETSc] PCMG: geometric V-cycle data, level 0 = coarsest */
+  int mg_levels, nu_pre, nu_post;
+  csr_t mgA[MG_MAX_LEVELS];   /* operator (level 0: explicit inverse);
+                                 finest level: unused, the slot's operator */
+  csr_t mgP[MG_MAX_LEVELS];   /* prolongation level-1 -> level */
+  double mg_emin[MG_MAX_LEVELS], mg_emax[MG_MAX_LEVELS];
 } inner_t;
 
 typedef struct pcdo_s {
@@ -205,6 +214,84 @@ static int solve_rich(const csr_t *A, inner_t *s, const double *b, double *x,
   return 0;
 }
 
+/* ---- [ext PETSc] PCMG: multiplicative V-cycle, Chebyshev/Jacobi smoothing,
+ * explicit coarse inverse.  Same recurrences as solve_cheb; a smoother call
+ * with a nonzero guess starts with p_1 = x + scale*B(b - A x). */
+static void spmv_t(const csr_t *P, const double *x, double *y) { /* y = P^T x */
+  memset(y, 0, sizeof(double) * P->ncols);
+  for (int64_t i = 0; i < P->nrows; ++i)
+    for (int32_t k = P->rowptr[i]; k < P->rowptr[i + 1]; ++k)
+      y[P->col[k]] += P->val[k] * x[i];
+}
+
+static void mg_smooth(const csr_t *A, double emin, double emax, int nu,
+                      const double *b, double *x, int zero_guess) {
+  int64_t n = A->nrows;
+  if (nu == 0) { if (zero_guess) memset(x, 0, sizeof(double) * n); return; }
+  double *base = (double *)malloc(sizeof(double) * n * 4);
+  double *pkm1 = base, *pk = pkm1 + n, *pkp1 = pk + n, *r = pkp1 + n;
+  double scale = 2.0 / (emax + emin), alpha = 1.0 - scale * emin;
+  double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, c_km1 = 1.0, c_k = mu;
+  if (zero_guess) {
+    memset(pkm1, 0, sizeof(double) * n);
+    for (int64_t i = 0; i < n; ++i) pk[i] = scale * (A->dinv[i] * b[i]);
+  } else {
+    memcpy(pkm1, x, sizeof(double) * n);
+    spmv(A, x, r);
+    for (int64_t i = 0; i < n; ++i)
+      pk[i] = x[i] + scale * (A->dinv[i] * (b[i] - r[i]));
+  }
+  for (int it = 0; it < nu - 1; ++it) {
+    double c_kp1 = 2.0 * mu * c_k - c_km1, omega = omegaprod * c_k / c_kp1;
+    spmv(A, pk, r);
+    for (int64_t i = 0; i < n; ++i)
+      pkp1[i] = (1.0 - omega) * pkm1[i] + omega * pk[i]
+                + omega * scale * (A->dinv[i] * (b[i] - r[i]));
+    double *t = pkm1; pkm1 = pk; pk = pkp1; pkp1 = t;
+    c_km1 = c_k; c_k = c_kp1;
+  }
+  memcpy(x, pk, sizeof(double) * n);
+  free(base);
+}
+
+static void mg_vcycle(const inner_t *s, const csr_t *Afine, int l,
+                      const double *b, double *x) {
+  if (l == 0) { spmv(&s->mgA[0], b, x); return; }
+  const csr_t *A = (l == s->mg_levels - 1) ? Afine : &s->mgA[l];
+  const csr_t *P = &s->mgP[l];
+  int64_t n = A->nrows, nc = P->ncols;
+  double *r = (double *)malloc(sizeof(double) * (n + 2 * nc));
+  double *bc = r + n, *ec = bc + nc;
+  mg_smooth(A, s->mg_emin[l], s->mg_emax[l], s->nu_pre, b, x, 1);
+  if (s->nu_pre) {
+    spmv(A, x, r);
+    for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
+  } else memcpy(r, b, sizeof(double) * n);
+  spmv_t(P, r, bc);
+  mg_vcycle(s, Afine, l - 1, bc, ec);
+  spmv(P, ec, r);
+  for (int64_t i = 0; i < n; ++i) x[i] += r[i];
+  mg_smooth(A, s->mg_emin[l], s->mg_emax[l], s->nu_post, b, x, 0);
+  free(r);
+}
+
+/* KSPRICHARDSON / KSPPREONLY around the V-cycle */
+static int solve_mg(const csr_t *A, inner_t *s, const double *b, double *x,
+                    double *r, double *z) {
+  int64_t n = A->nrows;
+  if (s->mg_levels < 1) return fail(4, "pc mg: no hierarchy set");
+  int its = (s->ksp == KSP_PREONLY) ? 1 : s->max_it;
+  memset(x, 0, sizeof(double) * n);
+  for (int it = 0; it < its; ++it) {
+    if (it == 0) memcpy(r, b, sizeof(double) * n);
+    else { spmv(A, x, r); for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i]; }
+    mg_vcycle(s, A, s->mg_levels - 1, r, z);
+    for (int64_t i = 0; i < n; ++i) x[i] += z[i];
+  }
+  s->last_its = its;
+  return 0;
+}
+
 static const int slot_mat[SLOT_COUNT] = {MAT_AP, MAT_MP, MAT_RP, MAT_A00};
 
 /* KSP.solve(b, x); b and x must not alias */
@@ -216,6 +303,13 @@ static int inner_solve(pcdo_t *h, int slot, const double *b, double *x) {
   double *t0 = (double *)malloc(sizeof(double) * n * 4);
   double *t1 = t0 + n, *t2 = t1 + n, *t3 = t2 + n;
   int rc = 0;
+  if (s->pc == PC_MG) {
+    if (s->ksp != KSP_PREONLY && s->ksp != KSP_RICHARDSON)
+      rc = fail(1, "pc mg is supported under preonly / richardson only");
+    else rc = solve_mg(A, s, b, x, t0, t1);
+    free(t0);
+    return rc;
+  }
   switch (s->ksp) {
     case KSP_PREONLY: pc_apply(A, s->pc, b, x); s->last_its = 1; break;
     case KSP_RICHARDSON: rc = solve_rich(A, s, b, x, t0, t1); break;
@@ -247,6 +341,10 @@ int pcdo_create(pcdo_t **out, int variant, int device) {
 int pcdo_destroy(pcdo_t *h) {
   if (!h) return 0;
   for (int m = 0; m < MAT_COUNT; ++m) csr_free(&h->mat[m]);
+  for (int s = 0; s < SLOT_COUNT; ++s)
+    for (int l = 0; l < MG_MAX_LEVELS; ++l) {
+      csr_free(&h->inner[s].mgA[l]); csr_free(&h->inner[s].mgP[l]);
+    }
   free(h->bc_idx); free(h->bc_val); free(h->perm);
   for (int i = 0; i < 8; ++i) free(h->w[i]);
   for (int i = 0; i < 4; ++i) free(h->wu[i]);
@@ -384,12 +482,66 @@ int pcdo_set_inner(pcdo_t *h, int slot, int ksp, int pc, int max_it,
                    double rtol, double emin, double emax) {
   if (slot < 0 || slot >= SLOT_COUNT) return fail(1, "set_inner: bad slot");
   if (ksp < KSP_PREONLY || ksp > KSP_CG) return fail(1, "set_inner: bad ksp");
-  if (pc != PC_NONE && pc != PC_JACOBI) return fail(1, "set_inner: bad pc");
+  if (pc != PC_NONE && pc != PC_JACOBI && pc != PC_MG)
+    return fail(1, "set_inner: bad pc");
   if (ksp == KSP_CHEBYSHEV && !(emax > emin && emin > 0.0))
     return fail(1, "set_inner: chebyshev needs 0 < emin < emax");
   inner_t *s = &h->inner[slot];
   s->ksp = ksp; s->pc = pc; s->max_it = max_it; s->rtol = rtol;
   s->emin = emin; s->emax = emax;
+  return 0;
+}
+
+/* [ext PETSc] PCMGSetLevels / PCMGSetInterpolation / per-level operators */
+int pcdo_mg_begin(pcdo_t *h, int slot, int nlevels, int nu_pre, int nu_post) {
+  if (slot < 0 || slot >= SLOT_COUNT) return fail(1, "mg_begin: bad slot");
+  if (nlevels < 1 || nlevels > MG_MAX_LEVELS || nu_pre < 0 || nu_post < 0)
+    return fail(1, "mg_begin: bad level / smoothing counts");
+  inner_t *s = &h->inner[slot];
+  for (int l = 0; l < MG_MAX_LEVELS; ++l) {
+    csr_free(&s->mgA[l]); csr_free(&s->mgP[l]);
+  }
+  s->mg_levels = nlevels; s->nu_pre = nu_pre; s->nu_post = nu_post;
+  return 0;
+}
+
+int pcdo_mg_set_level(pcdo_t *h, int slot, int level, int64_t n,
+                      const int32_t *rowptr, const int32_t *col,
+                      const double *val, int64_t p_rows, int64_t p_cols,
+                      const int32_t *prowptr, const int32_t *pcol,
+                      const double *pval, double emin, double emax) {
+  if (slot < 0 || slot >= SLOT_COUNT) return fail(1, "mg_set_level: bad slot");
+  inner_t *s = &h->inner[slot];
+  if (level < 0 || level >= s->mg_levels)
+    return fail(1, "mg_set_level: level out of range");
+  if (level > 0 && !(emax > emin && emin > 0.0))
+    return fail(1, "mg_set_level: smoother needs 0 < emin < emax");
+  if (rowptr) {
+    csr_store(&s->mgA[level], n, n, rowptr, col, val);
+    csr_diag(&s->mgA[level]);
+  } else if (level != s->mg_levels - 1)
+    return fail(1, "mg_set_level: coarse levels need an operator");
+  if (level > 0) {
+    if (!prowptr) return fail(1, "mg_set_level: prolongation missing");
+    csr_store(&s->mgP[level], p_rows, p_cols, prowptr, pcol, pval);
+  }
+  s->mg_emin[level] = emin; s->mg_emax[level] = emax;
+  return 0;
+}
+
+int pcdo_mg_update_values(pcdo_t *h, int slot, int level, const double *val,
+                          double emin, double emax, int mem) {
+  (void)mem;
+  if (slot < 0 || slot >= SLOT_COUNT) return fail(1, "mg_update: bad slot");
+  inner_t *s = &h->inner[slot];
+  if (level < 0 || level >= s->mg_levels)
+    return fail(4, "mg_update_values: level not set");
+  if (val) {
+    if (!s->mgA[level].set) return fail(4, "mg_update_values: level not set");
+    memcpy(s->mgA[level].val, val, sizeof(double) * s->mgA[level].nnz);
+    csr_diag(&s->mgA[level]);
+  }
+  if (level > 0) { s->mg_emin[level] = emin; s->mg_emax[level] = emax; }
   return 0;
 }
 

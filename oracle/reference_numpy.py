@@ -175,3 +175,64 @@ def gmres_right(A, b, M, rtol=1e-6, atol=0.0, restart=150, max_it=10000):
             break
         r = b - A @ x
     return x, it, res, hist
+
+
+# --------------------------------------------------------------- multigrid
+class Multigrid(object):
+    """[ext PETSc] PCMG-style geometric V-cycle, multiplicative, Chebyshev +
+    Jacobi smoothing with given eigenvalue bounds per level, explicit coarse
+    inverse on level 0.  ``ops``: operators coarsest..finest; ``chain[l]``:
+    prolongation level l-1 -> l (``chain[0] is None``); ``bounds[l]`` =
+    (emin, emax) of D^-1 A on level l >= 1."""
+
+    def __init__(self, ops, chain, bounds, nu_pre=2, nu_post=2,
+                 coarse_inverse=None):
+        self.ops, self.chain, self.bounds = ops, chain, bounds
+        self.nu_pre, self.nu_post = nu_pre, nu_post
+        self.dinv = [None if A is None else jacobi(A, "jacobi") for A in ops]
+        self.C = (np.linalg.inv(ops[0].toarray()) if coarse_inverse is None
+                  else coarse_inverse)
+
+    def smooth(self, l, b, x, nu):
+        if nu == 0:
+            return np.zeros_like(b) if x is None else x
+        A, dinv = self.ops[l], self.dinv[l]
+        emin, emax = self.bounds[l]
+        scale = 2.0 / (emax + emin)
+        alpha = 1.0 - scale * emin
+        mu, omegaprod = 1.0 / alpha, 2.0 / alpha
+        c_km1, c_k = 1.0, mu
+        if x is None:
+            pkm1 = np.zeros_like(b)
+            pk = scale * (dinv * b)
+        else:
+            pkm1 = x
+            pk = x + scale * (dinv * (b - A @ x))
+        for _ in range(nu - 1):
+            c_kp1 = 2.0 * mu * c_k - c_km1
+            omega = omegaprod * c_k / c_kp1
+            pkp1 = ((1.0 - omega) * pkm1 + omega * pk
+                    + omega * scale * (dinv * (b - A @ pk)))
+            pkm1, pk = pk, pkp1
+            c_km1, c_k = c_k, c_kp1
+        return pk
+
+    def vcycle(self, l, b):
+        if l == 0:
+            return self.C @ b
+        x = self.smooth(l, b, None, self.nu_pre)
+        r = b - self.ops[l] @ x if self.nu_pre else b
+        e = self.vcycle(l - 1, self.chain[l].T @ r)
+        x = x + self.chain[l] @ e
+        return self.smooth(l, b, x, self.nu_post)
+
+    def apply(self, b):
+        return self.vcycle(len(self.ops) - 1, b)
+
+    def richardson(self, b, its):
+        A = self.ops[-1]
+        x = np.zeros_like(b)
+        for it in range(its):
+            r = b if it == 0 else b - A @ x
+            x = x + self.apply(r)
+        return x

@@ -86,3 +86,24 @@ def configure_engine(e, st, with_system=True):
     e.set_bc(pb.bc_p_idx, pb.bc_p_val)
     if with_system:
         e.set_system(st["A"], st["V"].is_u, st["V"].is_p)
+
+
+def push_multigrid(e, slot, A, chain, nu=2, ratio=0.1, cycles=1):
+    """Galerkin hierarchy of ``A`` handed to an engine (HIP or oracle);
+    returns (ops, bounds, coarse_inverse) for the numpy restatement."""
+    from fenapack_amd.fem.multigrid import galerkin_chain, coarse_inverse
+    from fenapack_amd.petsc import estimate_emax
+    ops = galerkin_chain(A, chain)
+    bounds = [None]
+    for l in range(1, len(ops)):
+        emax = 1.1 * estimate_emax(ops[l], iters=12)
+        bounds.append((ratio * emax, emax))
+    Cs = coarse_inverse(ops[0])
+    C = Cs.toarray()
+    e.mg_begin(slot, len(ops), nu, nu)
+    e.mg_set_level(slot, 0, Cs)
+    for l in range(1, len(ops)):
+        e.mg_set_level(slot, l, ops[l] if l < len(ops) - 1 else None,
+                       chain[l], *bounds[l])
+    e.set_inner(slot, "richardson", "mg", cycles, 0.0)
+    return ops, bounds, C

@@ -125,3 +125,21 @@ def test_unsteady_pcd_and_pcdr_run():
         out = solve_unsteady(pb, dt=0.2, t_end=0.6, newton_rtol=1e-5)
         assert out["steps"] == 3
         assert out["krylov_its"] > 0
+
+
+def test_multigrid_options_same_counts_as_cpu_restatement(monkeypatch):
+    from fenapack_amd.driver import multigrid_inner_options
+
+    def run(lib):
+        if lib is not None:
+            monkeypatch.setattr(c, "hip_library", lambda: lib)
+        PETScOptions.clear()
+        multigrid_inner_options()
+        return solve_steady(Cavity(3, nu=0.01), newton_rtol=1e-5,
+                            gmres_rtol=1e-6)
+    gpu = run(None)
+    cpu = run(oracle.library())
+    assert gpu["converged"] and cpu["converged"]
+    assert gpu["krylov_per_step"] == cpu["krylov_per_step"]
+    assert relerr(gpu["w"].vector(), cpu["w"].vector()) < 1e-6
+    assert max(gpu["krylov_per_step"]) < 60

@@ -234,3 +234,42 @@ def test_error_paths(hip_lib):
         c.Engine(hip_lib, "BRM1", 99)
     e.destroy()
     e.destroy()                          # idempotent
+
+
+@pytest.mark.parametrize("kind,level", [("cavity", 3), ("lshape", 3)])
+def test_multigrid_vcycle_vs_oracle(hip_lib, kind, level):
+    from helpers import push_multigrid
+    st = flow_state(kind, level)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    I = pb.interpolations()
+    e, o = hip_engine(hip_lib, "BRM1"), oracle.Engine("BRM1")
+    for eng in (e, o):
+        configure_engine(eng, st)
+        push_multigrid(eng, c.KSP_AP, pb.Ap, I.chain("p"), cycles=2)
+        push_multigrid(eng, c.KSP_A00, L["A00"], I.chain("u"), cycles=1)
+        eng.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+        eng.setup()
+    rng = np.random.default_rng(12)
+    for slot, n in ((c.KSP_AP, V.n_p), (c.KSP_A00, V.n_u)):
+        b = rng.standard_normal(n)
+        assert relerr(e.inner_solve_np(slot, b),
+                      o.inner_solve_np(slot, b)) < 1e-11
+    # asymmetric smoothing and a truncated hierarchy
+    for eng in (e, o):
+        push_multigrid(eng, c.KSP_A00, L["A00"], I.chain("u", 2), nu=3)
+        eng.set_inner(c.KSP_A00, "preonly", "mg", 1, 0.0)
+    b = rng.standard_normal(V.n_u)
+    assert relerr(e.inner_solve_np(c.KSP_A00, b),
+                  o.inner_solve_np(c.KSP_A00, b)) < 1e-11
+    x = rng.standard_normal(V.ndof)
+    assert relerr(e.fieldsplit_apply_np(x), o.fieldsplit_apply_np(x)) < 1e-11
+    # refreshed operators between Newton steps: new values, same patterns
+    from fenapack_amd.fem.multigrid import galerkin_chain, coarse_inverse
+    ops = galerkin_chain(2.0 * L["A00"], I.chain("u", 2))
+    for eng in (e, o):
+        eng.update_system(2.0 * st["A"].data)
+        eng.mg_update_values(c.KSP_A00, 0, coarse_inverse(ops[0]).data)
+    assert relerr(e.inner_solve_np(c.KSP_A00, b),
+                  o.inner_solve_np(c.KSP_A00, b)) < 1e-11
+    assert relerr(2.0 * e.inner_solve_np(c.KSP_A00, b),
+                  o.inner_solve_np(c.KSP_A00, 2.0 * b)) < 1e-11

@@ -181,3 +181,52 @@ def test_error_paths():
         e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 2.0, 0.5)
     with pytest.raises(c.EngineError):
         e.apply_np(np.zeros(4))         # before setup
+
+
+def test_multigrid_c_vs_numpy_and_gmres_count_close_to_exact():
+    from helpers import push_multigrid
+    st = flow_state("cavity", 2)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    I = pb.interpolations()
+    e = oracle.Engine("BRM1")
+    configure_engine(e, st)
+    mgs = {}
+    for field, A, slot in (("p", pb.Ap, c.KSP_AP), ("u", L["A00"], c.KSP_A00)):
+        ops, bounds, C = push_multigrid(e, slot, A, I.chain(field), cycles=2)
+        mgs[field] = rn.Multigrid(ops, I.chain(field), bounds, 2, 2, C)
+    e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+    e.setup()
+    rng = np.random.default_rng(4)
+    for field, slot, n in (("p", c.KSP_AP, V.n_p), ("u", c.KSP_A00, V.n_u)):
+        b = rng.standard_normal(n)
+        assert relerr(e.inner_solve_np(slot, b),
+                      mgs[field].richardson(b, 2)) < 1e-13
+    # one V-cycle per inner solve: same outer count as exact inner solves +-3
+    for slot in (c.KSP_AP, c.KSP_A00):
+        e.set_inner(slot, "richardson", "mg", 1, 0.0)
+    x, its, _ = e.gmres_np(st["b"], rtol=1e-6, restart=150, max_it=300)
+    As = sp.bmat([[L["A00"], L["A01"]], [L["A10"], None]]).tocsr()
+    bs = np.concatenate([L["bu"], L["bp"]])
+    sAp, sA00 = rn.make_inner(pb.Ap, ("direct",)), \
+        rn.make_inner(L["A00"], ("direct",))
+    sMp = rn.make_inner(pb.Mp, ("chebyshev", 5, 0.5, 2.0))
+    pcd = lambda v: rn.pcd_apply("BRM1", v, pb.Ap, pb.Mp, st["Kp"],
+                                 pb.bc_p_idx, pb.bc_p_val, sAp, sMp)
+    M = lambda v: np.concatenate(rn.fieldsplit_upper(
+        v[:V.n_u], v[V.n_u:], pcd, L["A01"], sA00))
+    _, its_exact, _, _ = rn.gmres_right(As, bs, M, rtol=1e-6, restart=150)
+    assert abs(its - its_exact) <= 3, (its, its_exact)
+    assert relerr(st["A"] @ x, st["b"]) < 1e-4
+
+
+def test_prolongations_reproduce_polynomials():
+    from fenapack_amd.fem import BackwardStep
+    pb = BackwardStep(2)
+    I, V = pb.interpolations(), pb.space
+    Vc = pb.hierarchy.space(1)
+    f = lambda xy: xy[:, 0] ** 2 - 3 * xy[:, 0] * xy[:, 1] + 2
+    P2 = I.velocity[-1][0::2, 0::2]
+    assert abs(P2 @ f(Vc.node_coords) - f(V.node_coords)).max() < 1e-12
+    g = lambda xy: xy @ np.array([1.0, 2.0]) - 0.5
+    assert abs(I.pressure[-1] @ g(Vc.p_coords) - g(V.p_coords)).max() < 1e-12
+    assert len(I.chain("u", 2)) == 2 and I.chain("u", 2)[0] is None
