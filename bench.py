@@ -5,7 +5,14 @@ outer GMRES iterations per Newton step that the same settings give.
 
 A "step" is one fieldsplit PCApply (PCD Schur apply + A01 SpMV + A00 solve,
 SURVEY 8a rows a1/a13-a15) on vectors resident in HBM.  One JSON line is
-printed by rank 0; see DESIGN.md "Measurement" for every field.
+printed by rank 0; DESIGN.md "Measurement" explains every field.
+
+--inner mg      (default) the reference's "iterative" shape: Richardson + one
+                multigrid V(2,2) cycle for A00 and for Ap, Chebyshev(5)+Jacobi
+                for Mp (demo_navier-stokes-pcd.py:152-165), with the engine's
+                geometric multigrid in place of hypre BoomerAMG;
+--inner jacobi  north-star text taken literally: Jacobi-CG on Ap (rtol),
+                Chebyshev-Jacobi sweeps on A00.
 """
 import argparse
 import json
@@ -22,11 +29,15 @@ sys.path.insert(0, ROOT)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--level", type=int, default=6)
     p.add_argument("--geometry", default="cavity", choices=["cavity", "lshape"])
     p.add_argument("--variant", default="BRM1", choices=["BRM1", "BRM2"])
+    p.add_argument("--inner", default="mg", choices=["mg", "jacobi"])
+    p.add_argument("--cycles-u", type=int, default=1)
+    p.add_argument("--cycles-p", type=int, default=1)
+    p.add_argument("--smooth", type=int, default=2)
     p.add_argument("--a00-its", type=int, default=240)
     p.add_argument("--a00-ratio", type=float, default=0.002)
     p.add_argument("--ap-rtol", type=float, default=1e-8)
@@ -35,7 +46,7 @@ def parse():
     p.add_argument("--picard-steps", type=int, default=2,
                    help="nonlinear iterations before the matrices are frozen")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
 
 
@@ -56,7 +67,8 @@ def main():
     from fenapack_amd import PETScOptions
     from fenapack_amd import _cabi as c
     from fenapack_amd import roofline as rf
-    from fenapack_amd.driver import default_inner_options, make_solver
+    from fenapack_amd.driver import (default_inner_options, make_solver,
+                                     multigrid_inner_options)
     from fenapack_amd.fem import BackwardStep, Cavity
     from fenapack_amd.petsc import Vec
 
@@ -67,9 +79,13 @@ def main():
         pb = BackwardStep(args.level, nu=0.02, variant=args.variant)
     V = pb.space
     PETScOptions.clear()
-    default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
-                          ap_rtol=args.ap_rtol, ap_its=args.ap_its,
-                          mp_its=args.mp_its)
+    if args.inner == "mg":
+        multigrid_inner_options(cycles_u=args.cycles_u, cycles_p=args.cycles_p,
+                                smooth=args.smooth, mp_its=args.mp_its)
+    else:
+        default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
+                              ap_rtol=args.ap_rtol, ap_its=args.ap_its,
+                              mp_its=args.mp_its)
     w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150,
                               newton_rtol=1e-5, max_newton=args.picard_steps,
                               device=local)
@@ -117,17 +133,47 @@ def main():
     nnz = lambda m: int(eng.info(c.INFO_NNZ_BASE + m))
     ksp0, ksp1 = ksp.pc.getFieldSplitSubKSP()
     pcd = ksp1.pc.getPythonContext()
-    bytes_pcd = rf.b_pcd(V.n_p, nnz(c.MAT_AP), nnz(c.MAT_MP), nnz(c.MAT_KP),
-                         pb.bc_p_idx.size, k_a, k_m, pcd.ksp_Ap.type,
-                         pcd.ksp_Mp.type)
-    bytes_pc = rf.b_fieldsplit(V.n_u, V.n_p, nnz(c.MAT_A00), nnz(c.MAT_A01),
-                               bytes_pcd, k_f, ksp0.type)
+    if args.inner == "mg":
+        b_ap = k_a * rf.b_vcycle(pcd.ksp_Ap.pc.mg_data, V.n_p, nnz(c.MAT_AP)) \
+            + (k_a - 1) * (rf.b_spmv(V.n_p, V.n_p, nnz(c.MAT_AP)) + 32 * V.n_p)
+        b_a00 = k_f * rf.b_vcycle(ksp0.pc.mg_data, V.n_u, nnz(c.MAT_A00)) \
+            + (k_f - 1) * (rf.b_spmv(V.n_u, V.n_u, nnz(c.MAT_A00))
+                           + 32 * V.n_u)
+        bytes_pcd = (rf.b_copy(V.n_p) + rf.b_bc(pb.bc_p_idx.size) + b_ap
+                     + rf.b_spmv(V.n_p, V.n_p, nnz(c.MAT_KP)) + rf.b_axpy(V.n_p)
+                     + rf.b_inner("chebyshev", V.n_p, nnz(c.MAT_MP), k_m)
+                     + rf.b_copy(V.n_p))
+        bytes_pc = (bytes_pcd + rf.b_spmv(V.n_u, V.n_p, nnz(c.MAT_A01))
+                    + rf.b_axpy(V.n_u) + b_a00 + 16 * (V.n_u + V.n_p))
+        inner_desc = {
+            "Ap": "richardson x%d + mg V(%d,%d), %d levels"
+                  % (k_a, args.smooth, args.smooth,
+                     len(pcd.ksp_Ap.pc.mg_data["ops"])),
+            "Mp": "chebyshev+jacobi its %d eig [0.5,2]" % k_m,
+            "A00": "richardson x%d + mg V(%d,%d), %d levels"
+                   % (k_f, args.smooth, args.smooth,
+                      len(ksp0.pc.mg_data["ops"]))}
+    else:
+        bytes_pcd = rf.b_pcd(V.n_p, nnz(c.MAT_AP), nnz(c.MAT_MP),
+                             nnz(c.MAT_KP), pb.bc_p_idx.size, k_a, k_m,
+                             pcd.ksp_Ap.type, pcd.ksp_Mp.type)
+        bytes_pc = rf.b_fieldsplit(V.n_u, V.n_p, nnz(c.MAT_A00),
+                                   nnz(c.MAT_A01), bytes_pcd, k_f, ksp0.type)
+        inner_desc = {
+            "Ap": "cg+jacobi rtol %g (k_A=%d executed)" % (args.ap_rtol, k_a),
+            "Mp": "chebyshev+jacobi its %d eig [0.5,2]" % k_m,
+            "A00": "chebyshev+jacobi its %d eig ratio %g"
+                   % (k_f, args.a00_ratio)}
 
-    # roofline of the dominant kernel (fused Chebyshev step on A00), timed
-    # live with events on the stream the engine launches on
-    def time_a00(m, reps=5):
-        eng.set_inner(c.KSP_A00, ksp0.type, "jacobi", m, 0.0,
-                      *ksp0._chebyshev_bounds())
+    # roofline of the dominant kernel: the fused Chebyshev-Jacobi step on the
+    # finest A00 (the multigrid smoother / the Jacobi sweep), timed live with
+    # events on the stream the engine launches on; (t(65) - t(1)) / 64 launches
+    from fenapack_amd.petsc import estimate_emax
+    emax = 1.1 * estimate_emax(ksp0.getOperators()[1].A, iters=12)
+
+    def time_a00(m, reps=10):
+        eng.set_inner(c.KSP_A00, "chebyshev", "jacobi", m, 0.0, 0.1 * emax,
+                      emax)
         bu = x.t[:V.n_u].clone()
         xu = torch.empty_like(bu)
         eng.inner_solve(c.KSP_A00, bu, xu, c.MEM_DEVICE)
@@ -141,7 +187,10 @@ def main():
         return e0.elapsed_time(e1) * 1e-3 / reps
     m_hi, m_lo = 65, 1
     t_kernel = (time_a00(m_hi) - time_a00(m_lo)) / (m_hi - m_lo)
-    ksp0.push_settings()                      # restore the bench settings
+    if args.inner == "mg":                     # restore the bench settings
+        eng.set_inner(c.KSP_A00, "richardson", "mg", args.cycles_u, 0.0)
+    else:
+        ksp0.push_settings()
     b_kernel = rf.b_cheb(V.n_u, nnz(c.MAT_A00))
     achieved = b_kernel / t_kernel / 1e9
 
@@ -161,11 +210,7 @@ def main():
             "workload": "%s level %d, Re=100, P2/P1, PCD %s"
                         % (args.geometry, args.level, args.variant),
             "ndof": int(n), "n_u": int(V.n_u), "n_p": int(V.n_p),
-            "inner": {"Ap": "cg+jacobi rtol %g (k_A=%d executed)"
-                            % (args.ap_rtol, k_a),
-                      "Mp": "chebyshev+jacobi its %d eig [0.5,2]" % k_m,
-                      "A00": "chebyshev+jacobi its %d eig ratio %g"
-                             % (k_f, args.a00_ratio)},
+            "inner": inner_desc,
             "gmres": "restart 150, rtol 1e-6, right PC",
             "parallelism": "row partition x%d" % world,
         },
@@ -173,7 +218,7 @@ def main():
         "algorithmic_bytes_per_pcapply": int(bytes_pc),
         "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
         "roofline": {
-            "bound": "hbm", "kernel": "k_cheb_step (A00)",
+            "bound": "hbm", "kernel": "k_cheb_step_s (finest A00)",
             "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / rf.HBM_PEAK_GBS,
             "bytes_per_launch": int(b_kernel),
@@ -192,26 +237,36 @@ def main():
 
 
 def cpu_baseline(args, pb, ksp, eng, c, x):
-    """The oracle (a scalar C port, 1 thread) on the same workload, bounded
-    to about ``--cpu-seconds`` of CPU work.  A reported baseline, not the
-    target; it is "CPU restatement, not PETSc" (BASELINE.md section 3)."""
+    """The oracle (a scalar C port, 1 thread) on the same workload and inner
+    settings, bounded to about ``--cpu-seconds`` of CPU work.  A reported
+    baseline, not the target; "CPU restatement, not PETSc" (BASELINE.md 3)."""
     import oracle
     V = pb.space
     o = oracle.Engine(pb.variant)
-    pcd = ksp.pc.getFieldSplitSubKSP()[1].pc.getPythonContext()
+    ksp0, ksp1 = ksp.pc.getFieldSplitSubKSP()
+    pcd = ksp1.pc.getPythonContext()
     o.set_csr(c.MAT_AP, pcd.ksp_Ap.getOperators()[0].A)
     o.set_csr(c.MAT_MP, pcd.ksp_Mp.getOperators()[0].A)
     o.set_csr(c.MAT_KP, pcd.mat_Kp.A)
     o.set_bc(pb.bc_p_idx, pb.bc_p_val)
     A, P = ksp.getOperators()
     o.set_system(A.A, V.is_u, V.is_p, None if P is A else P.A)
-    ksp0 = ksp.pc.getFieldSplitSubKSP()[0]
-    lo, hi = ksp0._chebyshev_bounds()
-    o.set_inner(c.KSP_A00, ksp0.type, "jacobi", ksp0.max_it, 0.0, lo, hi)
-    o.set_inner(c.KSP_AP, pcd.ksp_Ap.type, "jacobi", pcd.ksp_Ap.max_it,
-                pcd.ksp_Ap.rtol if pcd.ksp_Ap.type == "cg" else 0.0)
-    o.set_inner(c.KSP_MP, pcd.ksp_Mp.type, "jacobi", pcd.ksp_Mp.max_it, 0.0,
-                *(pcd.ksp_Mp.cheb_eigs or (0.5, 2.0)))
+    for k, slot in ((ksp0, c.KSP_A00), (pcd.ksp_Ap, c.KSP_AP),
+                    (pcd.ksp_Mp, c.KSP_MP)):
+        if k.pc.type == "mg":
+            d = k.pc.mg_data
+            L = len(d["ops"])
+            o.mg_begin(slot, L, d["nu"], d["nu"])
+            o.mg_set_level(slot, 0, d["C"])
+            for l in range(1, L):
+                o.mg_set_level(slot, l, d["ops"][l] if l < L - 1 else None,
+                               d["chain"][l], *d["bounds"][l])
+            o.set_inner(slot, k.type, "mg", k.max_it, 0.0)
+        else:
+            lo, hi = (k._chebyshev_bounds() if k.type == "chebyshev"
+                      else (0.5, 2.0))
+            o.set_inner(slot, k.type, "jacobi", k.max_it,
+                        k.rtol if k.type == "cg" else 0.0, lo, hi)
     o.setup()
     xh = x.getArray()
     yh = np.empty_like(xh)
@@ -220,9 +275,9 @@ def cpu_baseline(args, pb, ksp, eng, c, x):
         o.fieldsplit_apply(xh, yh)
         n_done += 1
         el = time.perf_counter() - t0
-        if el > args.cpu_seconds or n_done >= 50:
+        if el > args.cpu_seconds or n_done >= 200:
             break
-    # parity of this very workload while we are at it
+    # parity of this very workload at full size while we are at it
     yg = np.empty_like(xh)
     eng.fieldsplit_apply(xh, yg)
     err = float(np.abs(yg - yh).max() / np.abs(yh).max())

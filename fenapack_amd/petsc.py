@@ -463,6 +463,9 @@ class KSP(object):
             bounds.append((b * emax, d * emax))
         C = coarse_inverse(ops[0])
         eng, slot, L = self.engine, self.slot, len(ops)
+        # kept for statistics (roofline bytes) and for the CPU baseline
+        pc.mg_data = {"ops": ops, "chain": chain, "bounds": bounds, "C": C,
+                      "nu": pc.mg_smooth_its}
         sig = (L, pc.mg_smooth_its, tuple(o.nnz for o in ops))
         if pc._mg_pushed != sig:
             eng.mg_begin(slot, L, pc.mg_smooth_its, pc.mg_smooth_its)

@@ -58,3 +58,22 @@ def b_fieldsplit(n_u, n_p, nnz_a00, nnz_a01, pcd_bytes, k_f,
                  ksp_f="chebyshev"):
     return (pcd_bytes + b_spmv(n_u, n_p, nnz_a01) + b_axpy(n_u)
             + b_inner(ksp_f, n_u, nnz_a00, k_f) + 16 * (n_u + n_p))
+
+
+def b_vcycle(mg_data, n_fine, nnz_fine):
+    """One V(nu, nu) cycle (pcd_engine.hip: mg_vcycle / mg_smooth): per level
+    l >= 1 a Jacobi start (24 n), nu-1 + nu fused Chebyshev steps, the
+    residual SpMV, restriction and prolongation-add SpMVs; level 0 is one
+    dense SpMV; one final copy on the finest level."""
+    ops, chain, nu = mg_data["ops"], mg_data["chain"], mg_data["nu"]
+    L = len(ops)
+    total = b_spmv(ops[0].shape[0], ops[0].shape[0], mg_data["C"].nnz)
+    for l in range(1, L):
+        n = n_fine if l == L - 1 else ops[l].shape[0]
+        nnz = nnz_fine if l == L - 1 else ops[l].nnz
+        P = chain[l]
+        total += 24 * n + (2 * nu - 1) * b_cheb(n, nnz)
+        total += b_spmv(n, n, nnz) + 8 * n
+        total += b_spmv(P.shape[1], P.shape[0], P.nnz)
+        total += b_spmv(P.shape[0], P.shape[1], P.nnz) + 8 * n
+    return total + b_copy(n_fine)
