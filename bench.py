@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--mp-its", type=int, default=5)
     p.add_argument("--picard-steps", type=int, default=2,
                    help="nonlinear iterations before the matrices are frozen")
+    p.add_argument("--no-graph", action="store_true",
+                   help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
@@ -97,6 +99,7 @@ def main():
     ksp = nls.linear_solver().ksp()
     eng = ksp.engine
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.graph_enable(not args.no_graph)
     t_setup = time.time() - t_setup
 
     n = V.ndof
@@ -212,6 +215,7 @@ def main():
             "ndof": int(n), "n_u": int(V.n_u), "n_p": int(V.n_p),
             "inner": inner_desc,
             "gmres": "restart 150, rtol 1e-6, right PC",
+            "launch": "eager" if args.no_graph else "hipGraph replay",
             "parallelism": "row partition x%d" % world,
         },
         "gmres_its_per_newton_step": gmres_per_step,

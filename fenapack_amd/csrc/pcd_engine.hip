@@ -136,6 +136,11 @@ struct pcd_engine_s {
   double* pinned = nullptr;           // host-pinned scratch
   size_t pinned_n = 0;
   long num_pcd = 0, num_fs = 0;
+  // hipGraph replay of the fixed-iteration fieldsplit apply
+  bool graph_on = false;
+  hipGraphExec_t gexec = nullptr;
+  hipStream_t cap_stream = nullptr;
+  uint64_t gen = 1, ggen = 0;        // configuration generation / captured one
   int gmres_its = 0;
   double gmres_rnorm = 0.0;
 };
@@ -634,14 +639,64 @@ static int pcd_apply_dev(Engine* h, const double* x, double* y) {
 }
 
 // [ext PETSc] PCApply_FieldSplit_Schur (UPPER) on split-ordered vectors
-static int fs_apply_split(Engine* h, const double* x, double* y) {
+static int fs_apply_eager(Engine* h, const double* x, double* y) {
   const int64_t nu = h->n_u;
   const double *xu = x, *xp = x + nu;
   double *yu = y, *yp = y + nu, *t = h->wu.p;
   CHK(pcd_apply_dev(h, xp, yp));                                // y_p = S^-1 x_p
   CHK(spmv(h, h->mat[PCD_MAT_A01], yp, t, 2, xu));              // t = x_u - A01 y_p
   CHK(inner_solve(h, PCD_KSP_A00, t, yu));                      // y_u = A00^-1 t
+  return 0;
+}
+
+// A PCApply whose inner solvers all run a fixed number of steps contains no
+// host decision: ~100 short launches.  It is captured once into a hipGraph on
+// the fixed staging vectors (xs -> ys) and replayed (hard part 3:
+// this path is launch-bound at the 2D sizes).
+static bool graph_capturable(const Engine* h) {
+  const bool reaction = h->variant == PCDR_BRM1 || h->variant == PCDR_BRM2;
+  for (int slot : {PCD_KSP_AP, PCD_KSP_MP, PCD_KSP_RP, PCD_KSP_A00}) {
+    if (slot == PCD_KSP_RP && !reaction) continue;
+    const Inner& s = h->inner[slot];
+    if (s.pc != PCD_PC_MG && s.ksp == PCD_KSP_CG && s.rtol > 0.0) return false;
+  }
+  return true;
+}
+
+static int fs_apply_split(Engine* h, const double* x, double* y) {
   ++h->num_fs;
+  if (!h->graph_on || !graph_capturable(h)) return fs_apply_eager(h, x, y);
+  const int n = (int)(h->n_u + h->n_p);
+  if (!h->gexec || h->ggen != h->gen) {
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    if (!h->cap_stream)
+      HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipStream_t saved = h->stream;
+    h->stream = h->cap_stream;
+    hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+      h->stream = saved;
+      return fail(PCD_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    }
+    const int rc = fs_apply_eager(h, h->xs.p, h->ys.p);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(h->cap_stream, &g);
+    h->stream = saved;
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail(PCD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { h->gexec = nullptr; return fail(PCD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    h->ggen = h->gen;
+  }
+  const int g1 = grid1d(n, 2);
+  if (x != h->xs.p)
+    hipLaunchKernelGGL(k_copy, dim3(g1), dim3(kBlock), 0, h->stream, n, x, h->xs.p);
+  HIPCHK(hipGraphLaunch(h->gexec, h->stream));
+  if (y != h->ys.p)
+    hipLaunchKernelGGL(k_copy, dim3(g1), dim3(kBlock), 0, h->stream, n, h->ys.p, y);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -740,6 +795,8 @@ int pcd_destroy(pcd_handle h) {
   h->V.release(); h->gz.release(); h->gw.release(); h->gparts.release();
   h->gh.release(); h->gy.release(); h->gxs.release(); h->gbs.release();
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   delete h;
   return 0;
 }
@@ -748,6 +805,7 @@ int pcd_set_stream(pcd_handle h, void* hip_stream) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   HIPCHK(hipStreamSynchronize(h->stream));
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  ++h->gen;
   return 0;
 }
 
@@ -771,7 +829,7 @@ int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
   DCsr& A = h->mat[which];
   CHK(upload_csr(h, A, nrows, ncols, rowptr, colidx, vals, nullptr));
   CHK(refresh_dinv(h, A));
-  h->ready = false;
+  h->ready = false; ++h->gen;
   return 0;
 }
 
@@ -871,14 +929,14 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   CHK(upload_csr(h, h->mat[PCD_MAT_A01], n_u, n_p, rp.data(), cc.data(), nullptr, src.data()));
   extract_block(n, perm.data(), rowptr, colidx, ma, rp, cc, src);
   CHK(upload_csr(h, h->mat[PCD_MAT_A], n, n, rp.data(), cc.data(), nullptr, src.data()));
-  h->ready = false;
+  h->ready = false; ++h->gen;
   return pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
 }
 
 int pcd_set_bc(pcd_handle h, int64_t n_bc, const int32_t* idx, const double* vals) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (n_bc < 0 || (n_bc && (!idx || !vals))) return fail(PCD_ERR_ARG, "set_bc: bad arrays");
-  h->n_bc = n_bc;
+  h->n_bc = n_bc; ++h->gen;
   h->bc_host.assign(idx, idx + n_bc);
   if (n_bc) {
     CHK(h->bc_idx.ensure(n_bc)); CHK(h->bc_val.ensure(n_bc));
@@ -901,6 +959,7 @@ int pcd_mg_begin(pcd_handle h, int slot, int nlevels, int nu_pre, int nu_post) {
   s.mg.clear();
   s.mg.resize(nlevels);
   s.nu_pre = nu_pre; s.nu_post = nu_post;
+  ++h->gen;
   return 0;
 }
 
@@ -942,6 +1001,7 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
     CHK(upload_csr(h, M.R, p_cols, p_rows, trp.data(), tc.data(), tv.data(), nullptr));
   }
   M.emin = emin; M.emax = emax;
+  ++h->gen;
   if (h->ready) CHK(inner_prepare(h, slot));
   return 0;
 }
@@ -964,6 +1024,7 @@ int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
   if (level > 0) {
     if (!(emax > emin && emin > 0.0)) return fail(PCD_ERR_ARG, "mg_update_values: smoother needs 0 < emin < emax");
     M.emin = emin; M.emax = emax;
+    ++h->gen;                        // Chebyshev coefficients are baked in
   }
   return 0;
 }
@@ -982,6 +1043,7 @@ int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type, int max_it,
   if (ksp_type == PCD_KSP_CHEBYSHEV && !(emax > emin && emin > 0.0))
     return fail(PCD_ERR_ARG, "set_inner: chebyshev needs 0 < emin < emax");
   Inner& s = h->inner[slot];
+  ++h->gen;
   s.ksp = ksp_type; s.pc = pc_type; s.max_it = max_it; s.rtol = rtol;
   s.emin = emin; s.emax = emax;
   if (h->ready) CHK(inner_prepare(h, slot));
@@ -1014,7 +1076,7 @@ int pcd_setup(pcd_handle h) {
     if (i < 0 || i >= np) return fail(PCD_ERR_ARG, "setup: bc index %d outside [0,%lld)", i, (long long)np);
   CHK(h->w[0].ensure(np)); CHK(h->w[1].ensure(np));
   for (int s = 0; s < PCD_KSP_COUNT; ++s) CHK(inner_prepare(h, s));
-  h->ready = true;
+  h->ready = true; ++h->gen;
   return 0;
 }
 
@@ -1219,8 +1281,8 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
 }
 
 int pcd_graph_enable(pcd_handle h, int on) {
-  (void)on;
   if (!h) return fail(PCD_ERR_ARG, "null handle");
+  h->graph_on = on != 0;
   return 0;
 }
 

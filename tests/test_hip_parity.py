@@ -273,3 +273,40 @@ def test_multigrid_vcycle_vs_oracle(hip_lib, kind, level):
                   o.inner_solve_np(c.KSP_A00, b)) < 1e-11
     assert relerr(2.0 * e.inner_solve_np(c.KSP_A00, b),
                   o.inner_solve_np(c.KSP_A00, 2.0 * b)) < 1e-11
+
+
+def test_graph_replay_is_bitwise_equal_to_eager_launches(hip_lib):
+    from helpers import push_multigrid
+    st = flow_state("cavity", 3)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    I = pb.interpolations()
+    e = hip_engine(hip_lib, "BRM1")
+    configure_engine(e, st)
+    push_multigrid(e, c.KSP_AP, pb.Ap, I.chain("p"))
+    push_multigrid(e, c.KSP_A00, L["A00"], I.chain("u"))
+    e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+    e.setup()
+    rng = np.random.default_rng(13)
+    x1, x2 = rng.standard_normal(V.ndof), rng.standard_normal(V.ndof)
+    y1, y2 = e.fieldsplit_apply_np(x1), e.fieldsplit_apply_np(x2)
+    e.graph_enable(True)
+    assert np.array_equal(e.fieldsplit_apply_np(x1), y1)     # capture
+    assert np.array_equal(e.fieldsplit_apply_np(x2), y2)     # replay
+    assert np.array_equal(e.fieldsplit_apply_np(x1), y1)
+    # a settings change re-captures; a tolerance-driven CG falls back to eager
+    e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 3, 0.0, 0.5, 2.0)
+    y3 = e.fieldsplit_apply_np(x1)
+    e.graph_enable(False)
+    assert np.array_equal(e.fieldsplit_apply_np(x1), y3)
+    assert not np.array_equal(y3, y1)
+    e.graph_enable(True)
+    e.set_inner(c.KSP_MP, "cg", "jacobi", 50, 1e-6)
+    y4 = e.fieldsplit_apply_np(x1)
+    e.graph_enable(False)
+    assert np.array_equal(e.fieldsplit_apply_np(x1), y4)
+    # GMRES drives the replayed PCApply through staging copies
+    e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+    xa, ia, _ = e.gmres_np(st["b"], rtol=1e-8, restart=60, max_it=200)
+    e.graph_enable(True)
+    xb, ib, _ = e.gmres_np(st["b"], rtol=1e-8, restart=60, max_it=200)
+    assert ia == ib and np.array_equal(xa, xb)
