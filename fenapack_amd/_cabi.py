@@ -20,7 +20,7 @@ PC_NONE, PC_JACOBI, PC_MG = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
     INFO_NUM_PCD_APPLY, INFO_NUM_FS_APPLY, INFO_GMRES_ITS, \
-    INFO_GMRES_RNORM = range(10)
+    INFO_GMRES_RNORM, INFO_N_U_LOCAL, INFO_N_P_LOCAL = range(12)
 INFO_NNZ_BASE = 16
 
 KSP_TYPES = {"preonly": PREONLY, "richardson": RICHARDSON,
@@ -64,6 +64,7 @@ _SIGNATURES = {
 _HIP_ONLY = {
     "set_stream": [C.c_void_p],
     "comm_init": [C.c_int, C.c_int, C.c_void_p],
+    "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "graph_enable": [C.c_int],
 }
 
@@ -274,6 +275,11 @@ class Engine(object):
         buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
         self._call("comm_init", int(rank), int(nranks), buf)
 
+    def comm_init_threads(self, rank, nranks, group):
+        """Test backend; ``group`` is a ``ctypes.c_void_p`` shared by all."""
+        self._call("comm_init_threads", int(rank), int(nranks),
+                   C.byref(group))
+
     # -- numpy conveniences used by tests ------------------------------------
     def apply_np(self, x):
         x = _f64(x)
@@ -304,6 +310,16 @@ class Engine(object):
         x = np.zeros_like(b)
         its, rn = self.gmres_solve(b, x, **kw)
         return x, its, rn
+
+
+def comm_unique_id():
+    """128-byte ncclUniqueId (rank 0 creates it, the host broadcasts it)."""
+    buf = C.create_string_buffer(128)
+    lib = hip_library()
+    rc = lib.comm_unique_id(buf)
+    if rc:
+        raise EngineError("comm_unique_id failed (%d): %s" % (rc, lib.error()))
+    return buf.raw
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -1,0 +1,330 @@
+// pcd_dist.hpp - row partition, matrix localisation and communication
+// backends of the multi-GPU path.
+//
+// One process drives one GPU.  DOF rows are split into contiguous blocks of a
+// locality-preserving ordering (geometric strips), each rank keeps the rows it
+// owns of every operator; a column it does not own becomes a *ghost* column
+// whose value arrives in a halo exchange before the SpMV (the MPIAIJ picture
+// PETSc gives the reference, restated for RCCL over xGMI).  Every rank is
+// handed the same global matrices at set-up and cuts its slice out itself, so
+// set-up needs no communication at all; the hot path needs two primitives:
+//   exchange()  - neighbour halo: grouped ncclSend/ncclRecv
+//   allreduce() - dot products / norms: ncclAllReduce(sum, fp64) in place
+// A second backend with the same two primitives runs R "ranks" as R threads of
+// one process on one GPU (device-to-device copies + a barrier); it exists so
+// that the partition / localisation / halo logic can be tested on a single-GPU
+// box, where RCCL refuses two ranks on one device.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace pcd {
+
+// ---- index spaces --------------------------------------------------------
+// A space is one field or the [u; p] system.  Field f occupies global indices
+// [goff[f], goff[f] + n[f]) and is cut at bounds[f][0..R]; the local layout of
+// a rank is its slice of field 0 followed by its slice of field 1.
+struct Space {
+  int nf = 0;
+  int64_t goff[2] = {0, 0};
+  std::vector<int64_t> bounds[2];
+
+  static std::vector<int64_t> cut(int64_t n, int R, bool even) {
+    std::vector<int64_t> b(R + 1);
+    for (int r = 0; r <= R; ++r) {
+      int64_t v = n * r / R;
+      if (even) v -= v % 2;
+      b[r] = v;
+    }
+    b[R] = n;
+    return b;
+  }
+  static Space field(int64_t n, int R, bool even) {
+    Space s; s.nf = 1; s.bounds[0] = cut(n, R, even); return s;
+  }
+  static Space system(const Space& u, const Space& p) {
+    Space s; s.nf = 2; s.bounds[0] = u.bounds[0]; s.bounds[1] = p.bounds[0];
+    s.goff[1] = u.bounds[0].back();
+    return s;
+  }
+  int64_t total() const {
+    int64_t t = 0;
+    for (int f = 0; f < nf; ++f) t += bounds[f].back();
+    return t;
+  }
+  int64_t nloc(int r) const {
+    int64_t t = 0;
+    for (int f = 0; f < nf; ++f) t += bounds[f][r + 1] - bounds[f][r];
+    return t;
+  }
+  int field_of(int64_t g) const { return (nf == 2 && g >= goff[1]) ? 1 : 0; }
+  int owner(int64_t g) const {
+    const int f = field_of(g);
+    const int64_t i = g - goff[f];
+    const auto& b = bounds[f];
+    return (int)(std::upper_bound(b.begin(), b.end(), i) - b.begin()) - 1;
+  }
+  // local index of an owned global index
+  int64_t local(int64_t g, int r) const {
+    const int f = field_of(g);
+    int64_t off = 0;
+    for (int k = 0; k < f; ++k) off += bounds[k][r + 1] - bounds[k][r];
+    return off + (g - goff[f]) - bounds[f][r];
+  }
+  // global index of local index i of rank r
+  int64_t global(int64_t i, int r) const {
+    for (int f = 0; f < nf; ++f) {
+      const int64_t len = bounds[f][r + 1] - bounds[f][r];
+      if (i < len) return goff[f] + bounds[f][r] + i;
+      i -= len;
+    }
+    return -1;
+  }
+};
+
+// ---- halo plan -------------------------------------------------------------
+struct HaloPlan {
+  int nghost = 0;
+  std::vector<int> peers_recv, recv_off;    // recv_off has peers+1 entries
+  std::vector<int> peers_send, send_off;
+  std::vector<int32_t> send_idx;            // local indices to pack, per peer
+};
+
+// Cut rank `me`'s rows out of a global CSR (rows in `rs`, columns in `cs`),
+// renumber columns (owned -> local, others -> nloc + ghost slot) and derive the
+// halo plan.  `src_in` (optional) carries value provenance through.
+inline void localize(const Space& rs, const Space& cs, int me, int R,
+                     const int32_t* rowptr, const int32_t* col,
+                     const double* val, const int64_t* src_in,
+                     std::vector<int32_t>& orp, std::vector<int32_t>& oc,
+                     std::vector<double>& ov, std::vector<int64_t>& osrc,
+                     HaloPlan& plan) {
+  const int64_t nrow_loc = rs.nloc(me), ncol_loc = cs.nloc(me);
+  // needed[q] = sorted unique global columns rank q needs from another owner
+  std::vector<std::vector<int64_t>> need_from_me(R);   // by requesting rank
+  std::vector<int64_t> my_ghosts;
+  const int64_t nrows = rs.total();
+  std::vector<int> row_owner(nrows);
+  for (int64_t g = 0; g < nrows; ++g) row_owner[g] = rs.owner(g);
+  for (int64_t g = 0; g < nrows; ++g) {
+    const int q = row_owner[g];
+    for (int32_t k = rowptr[g]; k < rowptr[g + 1]; ++k) {
+      const int o = cs.owner(col[k]);
+      if (o == q) continue;
+      if (q == me) my_ghosts.push_back(col[k]);
+      else if (o == me) need_from_me[q].push_back(col[k]);
+    }
+  }
+  auto uniq = [](std::vector<int64_t>& v) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  };
+  uniq(my_ghosts);
+  // ghosts ordered by (owner, global)
+  std::stable_sort(my_ghosts.begin(), my_ghosts.end(),
+                   [&](int64_t a, int64_t b) { return cs.owner(a) < cs.owner(b); });
+  plan = HaloPlan();
+  plan.nghost = (int)my_ghosts.size();
+  plan.recv_off.push_back(0);
+  for (size_t i = 0; i < my_ghosts.size();) {
+    const int o = cs.owner(my_ghosts[i]);
+    size_t j = i;
+    while (j < my_ghosts.size() && cs.owner(my_ghosts[j]) == o) ++j;
+    plan.peers_recv.push_back(o);
+    plan.recv_off.push_back((int)j);
+    i = j;
+  }
+  plan.send_off.push_back(0);
+  for (int q = 0; q < R; ++q) {
+    if (q == me || need_from_me[q].empty()) continue;
+    uniq(need_from_me[q]);
+    plan.peers_send.push_back(q);
+    for (int64_t g : need_from_me[q]) plan.send_idx.push_back((int32_t)cs.local(g, me));
+    plan.send_off.push_back((int)plan.send_idx.size());
+  }
+  // local matrix
+  orp.assign(nrow_loc + 1, 0);
+  oc.clear(); ov.clear(); osrc.clear();
+  std::vector<std::pair<int32_t, int64_t>> tmp;
+  for (int64_t i = 0; i < nrow_loc; ++i) {
+    const int64_t g = rs.global(i, me);
+    tmp.clear();
+    for (int32_t k = rowptr[g]; k < rowptr[g + 1]; ++k) {
+      const int64_t cg = col[k];
+      int32_t lc;
+      if (cs.owner(cg) == me) lc = (int32_t)cs.local(cg, me);
+      else {
+        // position among my ghosts (sorted by owner then global)
+        const int o = cs.owner(cg);
+        size_t pi = 0;
+        while (plan.peers_recv[pi] != o) ++pi;
+        auto b = my_ghosts.begin() + plan.recv_off[pi];
+        auto e = my_ghosts.begin() + plan.recv_off[pi + 1];
+        lc = (int32_t)(ncol_loc + (std::lower_bound(b, e, cg) - my_ghosts.begin()));
+      }
+      tmp.emplace_back(lc, (int64_t)k);
+    }
+    std::sort(tmp.begin(), tmp.end());
+    for (auto& t : tmp) {
+      oc.push_back(t.first);
+      if (val) ov.push_back(val[t.second]);
+      osrc.push_back(src_in ? src_in[t.second] : t.second);
+    }
+    orp[i + 1] = (int32_t)oc.size();
+  }
+}
+
+// ---- communication backends -----------------------------------------------
+struct Msg { int peer; double* ptr; size_t count; };
+
+struct CommBackend {
+  int rank = 0, nranks = 1;
+  std::string err;
+  virtual ~CommBackend() {}
+  // in-place sum over ranks of a device buffer, enqueued on `s`
+  virtual int allreduce(double* dbuf, size_t count, hipStream_t s) = 0;
+  // all sends and receives of one halo exchange, enqueued on `s`
+  virtual int exchange(const std::vector<Msg>& sends,
+                       const std::vector<Msg>& recvs, hipStream_t s) = 0;
+};
+
+// RCCL, bound at run time so that the library loads without it
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t,
+                            ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t,
+                       hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t,
+                       hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+
+  bool load(std::string& err) {
+    if (lib) return true;
+    // the copy torch already mapped wins (same SONAME), else the ROCm one
+    for (const char* name : {"librccl.so.1", "librccl.so",
+                             "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) { err = std::string("dlopen librccl: ") + dlerror(); return false; }
+#define PCD_SYM(field, name)                                            \
+    field = reinterpret_cast<decltype(field)>(dlsym(lib, name));        \
+    if (!field) { err = std::string("dlsym ") + name; return false; }
+    PCD_SYM(GetUniqueId, "ncclGetUniqueId")
+    PCD_SYM(CommInitRank, "ncclCommInitRank")
+    PCD_SYM(CommDestroy, "ncclCommDestroy")
+    PCD_SYM(AllReduce, "ncclAllReduce")
+    PCD_SYM(Send, "ncclSend")
+    PCD_SYM(Recv, "ncclRecv")
+    PCD_SYM(GroupStart, "ncclGroupStart")
+    PCD_SYM(GroupEnd, "ncclGroupEnd")
+    PCD_SYM(GetErrorString, "ncclGetErrorString")
+#undef PCD_SYM
+    return true;
+  }
+};
+
+inline RcclApi& rccl_api() { static RcclApi api; return api; }
+
+struct RcclBackend : CommBackend {
+  ncclComm_t comm = nullptr;
+  ~RcclBackend() override { if (comm) (void)rccl_api().CommDestroy(comm); }
+  int check(ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return 0;
+    err = std::string(what) + ": " + rccl_api().GetErrorString(r);
+    return 1;
+  }
+  int allreduce(double* dbuf, size_t count, hipStream_t s) override {
+    return check(rccl_api().AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, comm, s),
+                 "ncclAllReduce");
+  }
+  int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs,
+               hipStream_t s) override {
+    if (sends.empty() && recvs.empty()) return 0;
+    RcclApi& a = rccl_api();
+    if (check(a.GroupStart(), "ncclGroupStart")) return 1;
+    for (const Msg& m : recvs)
+      if (check(a.Recv(m.ptr, m.count, ncclDouble, m.peer, comm, s), "ncclRecv")) return 1;
+    for (const Msg& m : sends)
+      if (check(a.Send(m.ptr, m.count, ncclDouble, m.peer, comm, s), "ncclSend")) return 1;
+    return check(a.GroupEnd(), "ncclGroupEnd");
+  }
+};
+
+// In-process stand-in: R threads, one engine each, one GPU.  Correct but slow
+// (host barriers); used by the tests only.
+struct ThreadGroup {
+  int nranks;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t phase = 0;
+  std::vector<double*> ar_buf;                       // allreduce operands
+  std::vector<std::vector<Msg>> sends;               // posted sends per rank
+  std::vector<double> scratch;
+  explicit ThreadGroup(int n) : nranks(n), ar_buf(n, nullptr), sends(n) {}
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t ph = phase;
+    if (++arrived == nranks) { arrived = 0; ++phase; cv.notify_all(); }
+    else cv.wait(lk, [&] { return phase != ph; });
+  }
+};
+
+struct ThreadBackend : CommBackend {
+  ThreadGroup* g = nullptr;
+  int fail(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+  }
+  int allreduce(double* dbuf, size_t count, hipStream_t s) override {
+    if (fail(hipStreamSynchronize(s), "sync")) return 1;
+    g->ar_buf[rank] = dbuf;
+    g->barrier();
+    // every rank sums all operands in rank order: identical results
+    std::vector<double> acc(count, 0.0), tmp(count);
+    for (int r = 0; r < nranks; ++r) {
+      if (fail(hipMemcpy(tmp.data(), g->ar_buf[r], count * sizeof(double),
+                         hipMemcpyDeviceToHost), "memcpy")) return 1;
+      for (size_t i = 0; i < count; ++i) acc[i] += tmp[i];
+    }
+    g->barrier();                                    // all have read
+    if (fail(hipMemcpy(dbuf, acc.data(), count * sizeof(double),
+                       hipMemcpyHostToDevice), "memcpy")) return 1;
+    g->barrier();
+    return 0;
+  }
+  int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs,
+               hipStream_t s) override {
+    if (fail(hipStreamSynchronize(s), "sync")) return 1;
+    g->sends[rank] = sends;
+    g->barrier();
+    for (const Msg& m : recvs) {
+      const Msg* src = nullptr;
+      for (const Msg& q : g->sends[m.peer]) if (q.peer == rank) src = &q;
+      if (!src || src->count != m.count) { err = "halo mismatch"; return 1; }
+      if (fail(hipMemcpy(m.ptr, src->ptr, m.count * sizeof(double),
+                         hipMemcpyDeviceToDevice), "memcpy")) return 1;
+    }
+    g->barrier();
+    return 0;
+  }
+};
+
+}  // namespace pcd

@@ -15,6 +15,7 @@
 
 #include "../../include/pcd_engine.h"
 #include "pcd_kernels.hpp"
+#include "pcd_dist.hpp"
 
 using namespace pcd;
 
@@ -74,9 +75,17 @@ struct DCsr {
   bool set = false;
   int lpr = 8;
   int rb = 0;             // rows per workgroup of the CSR-stream kernels (0: n/a)
+  // multi-GPU: nrows / ncols are LOCAL counts (ncols = owned columns); ghost
+  // columns are numbered ncols .. ncols + nghost and live in `ghost`
+  HaloPlan plan;
+  int64_t gnnz = 0;       // nonzeros of the GLOBAL matrix (value updates)
+  DBuf<double> ghost, sendbuf;
+  DBuf<int> send_idx;
   void release() {
     rowptr.release(); col.release(); val.release(); dinv.release();
-    src.release(); set = false; nrows = ncols = nnz = 0; has_src = false;
+    src.release(); ghost.release(); sendbuf.release(); send_idx.release();
+    plan = HaloPlan();
+    set = false; nrows = ncols = nnz = 0; has_src = false;
   }
 };
 
@@ -100,12 +109,14 @@ struct Inner {
   // device scratch, sized at setup
   DBuf<double> t0, t1, t2, t3, t4;   // r,z,p,q,p'  or the Chebyshev ring
   DBuf<double> parts;                // 3 * kMaxParts
+  DBuf<double> slots;                // rank-reduced scalars (multi-GPU)
   DBuf<CgState> state;
+  std::vector<Space> mg_space;       // multi-GPU: row space of every level
   int last_its = 0;
   bool its_on_device = false;
   void release() {
     t0.release(); t1.release(); t2.release(); t3.release(); t4.release();
-    parts.release(); state.release();
+    parts.release(); slots.release(); state.release();
     for (auto& l : mg) l.release();
     mg.clear();
   }
@@ -121,8 +132,16 @@ struct pcd_engine_s {
   DBuf<int> bc_idx;
   std::vector<int32_t> bc_host;
   DBuf<double> bc_val;
-  int64_t n_u = 0, n_p = 0, sys_nnz = 0;
-  DBuf<int> perm;                     // split position -> caller's index
+  int64_t n_u = 0, n_p = 0, sys_nnz = 0;   // GLOBAL sizes
+  int64_t nu_loc = 0, np_loc = 0;         // rows of this rank (= global on 1 GPU)
+  // multi-GPU: contiguous row blocks per rank
+  CommBackend* comm = nullptr;
+  int rank = 0, nranks = 1;
+  Space sp_u, sp_p, sp_sys;
+  DBuf<int> l2g_u, l2g_p;             // local -> global index of each field
+  DBuf<double> loc_x, loc_y;          // local slices for host-pointer calls
+  std::vector<double> bc_val_host;
+  DBuf<int> perm;                     // LOCAL split position -> caller's index
   DBuf<double> sysvals, psysvals;     // staging of the caller's value arrays
   bool ready = false;
   DBuf<double> w[2];                  // pressure work vectors (get_work_vecs)
@@ -224,17 +243,58 @@ static int ensure_pinned(Engine* h, size_t n) {
     }                                                                           \
   } while (0)
 
+static inline XVec xvec(const DCsr& A, const double* x) {
+  return XVec{x, A.ghost.p, (int)A.ncols};
+}
+
+// Neighbour halo exchange of an SpMV input vector (multi-GPU): pack the owned
+// entries other ranks read, grouped send/recv into the ghost buffer.  Every
+// rank calls it for every SpMV (the threaded test backend synchronises there).
+static int halo_exchange(Engine* h, const DCsr& A, const double* x) {
+  if (!h->comm) return 0;
+  const HaloPlan& pl = A.plan;
+  const int ns = (int)pl.send_idx.size();
+  if (ns)
+    hipLaunchKernelGGL(k_pack, dim3(grid1d(ns, 1)), dim3(kBlock), 0, h->stream,
+                       ns, A.send_idx.p, x, A.sendbuf.p);
+  std::vector<Msg> sends, recvs;
+  for (size_t i = 0; i < pl.peers_send.size(); ++i)
+    sends.push_back(Msg{pl.peers_send[i], A.sendbuf.p + pl.send_off[i],
+                        (size_t)(pl.send_off[i + 1] - pl.send_off[i])});
+  for (size_t i = 0; i < pl.peers_recv.size(); ++i)
+    recvs.push_back(Msg{pl.peers_recv[i], A.ghost.p + pl.recv_off[i],
+                        (size_t)(pl.recv_off[i + 1] - pl.recv_off[i])});
+  if (h->comm->exchange(sends, recvs, h->stream))
+    return fail(PCD_ERR_COMM, "halo exchange: %s", h->comm->err.c_str());
+  return 0;
+}
+
+// rank-local partials -> (pointer, count) the consumer kernels reduce; with
+// several ranks the partials are summed into one slot and all-reduced first
+struct PartsRef { const double* p; int n; };
+static int reduce_global(Engine* h, double* parts, int nparts, double* slot,
+                         PartsRef* out) {
+  if (!h->comm) { out->p = parts; out->n = nparts; return 0; }
+  hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, h->stream, parts,
+                     nparts, 0, slot);
+  if (h->comm->allreduce(slot, 1, h->stream))
+    return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+  out->p = slot; out->n = 1;
+  return 0;
+}
+
 template <int MODE>
 static void launch_spmv_stream(Engine* h, const DCsr& A, const double* x,
                                const double* add, double* y) {
   const int g = grid_stream(A.nrows, A.rb);
+  const XVec xv = xvec(A, x);
   switch (A.rb) {
     case 256: hipLaunchKernelGGL((k_spmv_s<256, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
     case 128: hipLaunchKernelGGL((k_spmv_s<128, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
     default: hipLaunchKernelGGL((k_spmv_s<64, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
   }
 }
 
@@ -242,15 +302,16 @@ template <int MODE>
 static void launch_spmv_mode(Engine* h, const DCsr& A, const double* x,
                              const double* add, double* y) {
   const int g = grid_rows(A.nrows, A.lpr);
+  const XVec xv = xvec(A, x);
   switch (A.lpr) {
     case 4: hipLaunchKernelGGL((k_spmv<4, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                               (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+                               (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
     case 8: hipLaunchKernelGGL((k_spmv<8, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                               (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+                               (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
     case 16: hipLaunchKernelGGL((k_spmv<16, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
     default: hipLaunchKernelGGL((k_spmv<32, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, x, add, y); break;
+                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
   }
 }
 
@@ -258,6 +319,7 @@ static void launch_spmv_mode(Engine* h, const DCsr& A, const double* x,
 static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
                 int mode = 0, const double* add = nullptr) {
   if (!A.set) return fail(PCD_ERR_STATE, "spmv: operator not set");
+  CHK(halo_exchange(h, A, x));
   if (A.rb) {
     if (mode == 0) launch_spmv_stream<0>(h, A, x, add, y);
     else if (mode == 1) launch_spmv_stream<1>(h, A, x, add, y);
@@ -301,6 +363,7 @@ static int inner_prepare(Engine* h, int slot) {
     case PCD_KSP_CG:
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n)); CHK(s.t2.ensure(n));
       CHK(s.t3.ensure(n)); CHK(s.t4.ensure(n)); CHK(s.parts.ensure(3 * kMaxParts));
+      CHK(s.slots.ensure(4));
       CHK(s.state.ensure(1));
       break;
     case PCD_KSP_CHEBYSHEV:
@@ -314,17 +377,19 @@ static int inner_prepare(Engine* h, int slot) {
   return 0;
 }
 
-static void launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
-                             const double* b, const double* pm, const double* pk,
-                             double* pn, double c0, double c1, double c2) {
+static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
+                            const double* b, const double* pm, const double* pk,
+                            double* pn, double c0, double c1, double c2) {
   const int n = (int)A.nrows;
+  CHK(halo_exchange(h, A, pk));
   if (A.rb) {
     LAUNCH_RB(A, k_cheb_step_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
-              A.val.p, dinv, b, pm, pk, pn, c0, c1, c2);
+              A.val.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, (int)A.ncols);
   } else {
     LAUNCH_LPR(A, k_cheb_step, grid_rows(n, A.lpr), n, A.rowptr.p, A.col.p,
-               A.val.p, dinv, b, pm, pk, pn, c0, c1, c2);
+               A.val.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, (int)A.ncols);
   }
+  return 0;
 }
 
 // CG with the direction update fused into the SpMV: two launches per
@@ -367,27 +432,38 @@ static int solve_cg_stream(Engine* h, const DCsr& A, Inner& s, const double* b,
 
 static int solve_cg(Engine* h, const DCsr& A, Inner& s, const double* b,
                     double* x) {
-  if (A.rb) return solve_cg_stream(h, A, s, b, x);
+  // the fused two-launch form gathers z and p_old: single GPU only (the halo
+  // would have to carry both); with several ranks the direction update is its
+  // own launch, followed by the halo of p
+  if (A.rb && !h->comm) return solve_cg_stream(h, A, s, b, x);
   const int n = (int)A.nrows;
   const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
   double *r = s.t0.p, *z = s.t1.p, *p = s.t2.p, *q = s.t3.p;
   double* R[2] = {s.parts.p, s.parts.p + kMaxParts};
   double* PQ = s.parts.p + 2 * kMaxParts;
+  double* slot = s.slots.p;                             // [R0, R1, PQ]
   CgState* st = s.state.p;
   const int ge = grid1d(n, 4, kMaxParts);               // element-wise grid
   const int gs = grid_rows(n, A.lpr, kMaxParts);        // SpMV + dot grid
+  PartsRef rz[2], pq;
   hipLaunchKernelGGL(k_cg_init, dim3(ge), dim3(kBlock), 0, h->stream, n, dinv,
                      b, x, r, z, p, R[0], st);
+  CHK(reduce_global(h, R[0], ge, slot + 0, &rz[0]));
   const int check = 16;
   for (int it = 0; it < s.max_it; ++it) {
     if (it > 0)
       hipLaunchKernelGGL(k_cg_pupdate, dim3(ge), dim3(kBlock), 0, h->stream, n,
-                         z, p, R[it & 1], R[(it - 1) & 1], ge, s.rtol, st);
+                         z, p, rz[it & 1].p, rz[(it - 1) & 1].p, rz[it & 1].n,
+                         s.rtol, st);
+    CHK(halo_exchange(h, A, p));
     LAUNCH_LPR(A, k_cg_spmv_dot, gs, n, A.rowptr.p, A.col.p, A.val.p, p, q, PQ,
-               st);
+               st, A.ghost.p, (int)A.ncols);
+    CHK(reduce_global(h, PQ, gs, slot + 2, &pq));
     hipLaunchKernelGGL(k_cg_update, dim3(ge), dim3(kBlock), 0, h->stream, n,
-                       dinv, p, q, x, r, z, R[it & 1], ge, PQ, gs,
-                       R[(it + 1) & 1], it, st);
+                       dinv, p, q, x, r, z, rz[it & 1].p, rz[it & 1].n, pq.p,
+                       pq.n, R[(it + 1) & 1], it, st);
+    CHK(reduce_global(h, R[(it + 1) & 1], ge, slot + ((it + 1) & 1),
+                      &rz[(it + 1) & 1]));
     if (s.rtol > 0.0 && (it % check) == check - 1 && it + 1 < s.max_it) {
       CHK(ensure_pinned(h, 8));
       int* flag = reinterpret_cast<int*>(h->pinned);
@@ -427,7 +503,7 @@ static int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
     // p_{-1} = 0 at the first step: coefficient forced to zero, never read
     double* pm = (it == 0) ? pk : ring[(it + 2) % 3];
     const double c0 = (it == 0) ? 0.0 : 1.0 - omega;
-    launch_cheb_step(h, A, dinv, b, pm, pk, pn, c0, omega, omega * scale);
+    CHK(launch_cheb_step(h, A, dinv, b, pm, pk, pn, c0, omega, omega * scale));
     c_km1 = c_k; c_k = c_kp1;
   }
   HIPCHK(hipGetLastError());
@@ -448,7 +524,7 @@ static int solve_rich(Engine* h, const DCsr& A, Inner& s, const double* b,
   for (int it = 1; it < m; ++it) {
     double* pk = bufs[(it - 1) % 2];
     double* pn = bufs[it % 2];
-    launch_cheb_step(h, A, dinv, b, pk, pk, pn, 0.0, 1.0, 1.0);
+    CHK(launch_cheb_step(h, A, dinv, b, pk, pk, pn, 0.0, 1.0, 1.0));
   }
   HIPCHK(hipGetLastError());
   s.last_its = m; s.its_on_device = false;
@@ -480,7 +556,7 @@ static int mg_smooth(Engine* h, const DCsr& A, double emin, double emax, int nu,
                        h->stream, n, dinv, b, scale, bufs[0]);
     cur = 0; have_pm = false;
   } else {
-    launch_cheb_step(h, A, dinv, b, bufs[0], bufs[0], bufs[1], 0.0, 1.0, scale);
+    CHK(launch_cheb_step(h, A, dinv, b, bufs[0], bufs[0], bufs[1], 0.0, 1.0, scale));
     cur = 1; have_pm = true;
   }
   for (int it = 0; it < nu - 1; ++it) {
@@ -489,8 +565,8 @@ static int mg_smooth(Engine* h, const DCsr& A, double emin, double emax, int nu,
     double* pk = bufs[cur % 3];
     double* pn = bufs[(cur + 1) % 3];
     double* pm = have_pm ? bufs[(cur + 2) % 3] : pk;
-    launch_cheb_step(h, A, dinv, b, pm, pk, pn, have_pm ? 1.0 - omega : 0.0,
-                     omega, omega * scale);
+    CHK(launch_cheb_step(h, A, dinv, b, pm, pk, pn, have_pm ? 1.0 - omega : 0.0,
+                         omega, omega * scale));
     c_km1 = c_k; c_k = c_kp1;
     ++cur; have_pm = true;
   }
@@ -601,7 +677,7 @@ static int apply_bc_dev(Engine* h, double* x) {
 
 // The four PCPYTHON apply bodies on device pointers (x, y distinct, n_p long)
 static int pcd_apply_dev(Engine* h, const double* x, double* y) {
-  const int n = (int)h->n_p;
+  const int n = (int)h->np_loc;
   const int g = grid1d(n, 1);
   const bool reaction = h->variant == PCDR_BRM1 || h->variant == PCDR_BRM2;
   if (h->variant == PCD_BRM1 || h->variant == PCDR_BRM1) {
@@ -640,7 +716,7 @@ static int pcd_apply_dev(Engine* h, const double* x, double* y) {
 
 // [ext PETSc] PCApply_FieldSplit_Schur (UPPER) on split-ordered vectors
 static int fs_apply_eager(Engine* h, const double* x, double* y) {
-  const int64_t nu = h->n_u;
+  const int64_t nu = h->nu_loc;
   const double *xu = x, *xp = x + nu;
   double *yu = y, *yp = y + nu, *t = h->wu.p;
   CHK(pcd_apply_dev(h, xp, yp));                                // y_p = S^-1 x_p
@@ -665,8 +741,8 @@ static bool graph_capturable(const Engine* h) {
 
 static int fs_apply_split(Engine* h, const double* x, double* y) {
   ++h->num_fs;
-  if (!h->graph_on || !graph_capturable(h)) return fs_apply_eager(h, x, y);
-  const int n = (int)(h->n_u + h->n_p);
+  if (!h->graph_on || h->comm || !graph_capturable(h)) return fs_apply_eager(h, x, y);
+  const int n = (int)(h->nu_loc + h->np_loc);
   if (!h->gexec || h->ggen != h->gen) {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     if (!h->cap_stream)
@@ -760,6 +836,93 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   return 0;
 }
 
+// field spaces are fixed by the first operator that shows their size
+static int ensure_space(Engine* h, Space& sp, int64_t n, bool even, const char* what) {
+  if (!h->comm) return 0;
+  if (sp.nf == 0) { sp = Space::field(n, h->nranks, even); return 0; }
+  if (sp.total() != n)
+    return fail(PCD_ERR_ARG, "%s: size %lld does not match the partitioned space (%lld)",
+                what, (long long)n, (long long)sp.total());
+  return 0;
+}
+
+// Hand over a GLOBAL CSR.  One GPU: uploaded as is.  Several ranks: this
+// rank's row block with localised columns and the halo plan (pcd_dist.hpp);
+// the provenance array then maps local entries to the caller's value array.
+static int upload_global(Engine* h, DCsr& A, const Space* rs, const Space* cs,
+                         int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                         const int32_t* col, const double* val,
+                         const int64_t* src) {
+  A.gnnz = rowptr[nrows];
+  if (!h->comm) {
+    A.plan = HaloPlan();
+    return upload_csr(h, A, nrows, ncols, rowptr, col, val, src);
+  }
+  std::vector<int32_t> orp, oc;
+  std::vector<double> ov;
+  std::vector<int64_t> osrc;
+  HaloPlan plan;
+  localize(*rs, *cs, h->rank, h->nranks, rowptr, col, val, src, orp, oc, ov, osrc, plan);
+  CHK(upload_csr(h, A, rs->nloc(h->rank), cs->nloc(h->rank), orp.data(), oc.data(),
+                 val ? ov.data() : nullptr, osrc.data()));
+  A.plan = plan;
+  CHK(A.ghost.ensure(plan.nghost));
+  CHK(A.sendbuf.ensure(plan.send_idx.size()));
+  CHK(A.send_idx.ensure(plan.send_idx.size()));
+  if (!plan.send_idx.empty())
+    HIPCHK(hipMemcpy(A.send_idx.p, plan.send_idx.data(), plan.send_idx.size() * sizeof(int),
+                     hipMemcpyHostToDevice));
+  return 0;
+}
+
+// new values of a handed-over operator: one GPU copies, several ranks stage
+// the caller's global array and gather their entries
+static int refresh_values(Engine* h, DCsr& A, const double* vals, int mem) {
+  if (!h->comm) {
+    HIPCHK(hipMemcpyAsync(A.val.p, vals, A.nnz * sizeof(double),
+                          mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          h->stream));
+    return 0;
+  }
+  const double* dv = vals;
+  if (mem == PCD_MEM_HOST) {
+    CHK(h->sysvals.ensure(A.gnnz));
+    HIPCHK(hipMemcpyAsync(h->sysvals.p, vals, A.gnnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    dv = h->sysvals.p;
+  }
+  if (A.nnz)
+    hipLaunchKernelGGL(k_gather_vals, dim3(grid1d(A.nnz, 4)), dim3(kBlock), 0,
+                       h->stream, A.nnz, A.src.p, dv, A.val.p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// copy between a GLOBAL device vector of a space and this rank's local one
+static int slice_in(Engine* h, const Space& sp, const double* full, double* loc) {
+  int64_t off = 0;
+  for (int f = 0; f < sp.nf; ++f) {
+    const int64_t b0 = sp.bounds[f][h->rank], len = sp.bounds[f][h->rank + 1] - b0;
+    if (len) HIPCHK(hipMemcpyAsync(loc + off, full + sp.goff[f] + b0, len * sizeof(double),
+                                   hipMemcpyDeviceToDevice, h->stream));
+    off += len;
+  }
+  return 0;
+}
+static int slice_out(Engine* h, const Space& sp, const double* loc, double* full) {
+  const int64_t n = sp.total();
+  HIPCHK(hipMemsetAsync(full, 0, n * sizeof(double), h->stream));
+  int64_t off = 0;
+  for (int f = 0; f < sp.nf; ++f) {
+    const int64_t b0 = sp.bounds[f][h->rank], len = sp.bounds[f][h->rank + 1] - b0;
+    if (len) HIPCHK(hipMemcpyAsync(full + sp.goff[f] + b0, loc + off, len * sizeof(double),
+                                   hipMemcpyDeviceToDevice, h->stream));
+    off += len;
+  }
+  if (h->comm->allreduce(full, n, h->stream))
+    return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+  return 0;
+}
+
 // ================================================================= C ABI
 extern "C" {
 
@@ -794,6 +957,8 @@ int pcd_destroy(pcd_handle h) {
   h->xs.release(); h->ys.release(); h->io_x.release(); h->io_y.release();
   h->V.release(); h->gz.release(); h->gw.release(); h->gparts.release();
   h->gh.release(); h->gy.release(); h->gxs.release(); h->gbs.release();
+  h->loc_x.release(); h->loc_y.release(); h->l2g_u.release(); h->l2g_p.release();
+  delete h->comm;
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -827,7 +992,21 @@ int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
     return fail(PCD_ERR_ARG, "set_csr: dimensions exceed int32 indexing");
   HIPCHK(hipSetDevice(h->device));
   DCsr& A = h->mat[which];
-  CHK(upload_csr(h, A, nrows, ncols, rowptr, colidx, vals, nullptr));
+  const Space *rs = nullptr, *cs = nullptr;
+  if (h->comm) {
+    if (which == PCD_MAT_A00) {
+      CHK(ensure_space(h, h->sp_u, nrows, true, "set_csr"));
+      rs = cs = &h->sp_u;
+    } else if (which == PCD_MAT_A01) {
+      CHK(ensure_space(h, h->sp_u, nrows, true, "set_csr"));
+      CHK(ensure_space(h, h->sp_p, ncols, false, "set_csr"));
+      rs = &h->sp_u; cs = &h->sp_p;
+    } else {
+      CHK(ensure_space(h, h->sp_p, nrows, false, "set_csr"));
+      rs = cs = &h->sp_p;
+    }
+  }
+  CHK(upload_global(h, A, rs, cs, nrows, ncols, rowptr, colidx, vals, nullptr));
   CHK(refresh_dinv(h, A));
   h->ready = false; ++h->gen;
   return 0;
@@ -838,9 +1017,7 @@ int pcd_update_values(pcd_handle h, int which, const double* vals, int mem) {
   if (which < 0 || which >= PCD_MAT_A || !h->mat[which].set)
     return fail(PCD_ERR_STATE, "update_values: operator %d not set", which);
   DCsr& A = h->mat[which];
-  HIPCHK(hipMemcpyAsync(A.val.p, vals, A.nnz * sizeof(double),
-                        mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                        h->stream));
+  CHK(refresh_values(h, A, vals, mem));
   CHK(refresh_dinv(h, A));
   if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -920,15 +1097,24 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   for (int64_t i = 0; i < n_u; ++i) mu[is_u[i]] = (int32_t)i;
   for (int64_t i = 0; i < n_p; ++i) mp[is_p[i]] = (int32_t)i;
   h->n_u = n_u; h->n_p = n_p; h->sys_nnz = rowptr[n];
-  CHK(h->perm.ensure(n));
-  HIPCHK(hipMemcpy(h->perm.p, perm.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  CHK(ensure_space(h, h->sp_u, n_u, true, "set_system"));
+  CHK(ensure_space(h, h->sp_p, n_p, false, "set_system"));
+  if (h->comm) h->sp_sys = Space::system(h->sp_u, h->sp_p);
+  {  // local split position -> caller's index
+    const int64_t nloc = h->comm ? h->sp_sys.nloc(h->rank) : n;
+    std::vector<int32_t> pl(nloc);
+    for (int64_t i = 0; i < nloc; ++i)
+      pl[i] = perm[h->comm ? h->sp_sys.global(i, h->rank) : i];
+    CHK(h->perm.ensure(nloc));
+    if (nloc) HIPCHK(hipMemcpy(h->perm.p, pl.data(), nloc * sizeof(int), hipMemcpyHostToDevice));
+  }
   std::vector<int32_t> rp, cc; std::vector<int64_t> src;
   extract_block(n_u, is_u, rowptr, colidx, mu, rp, cc, src);
-  CHK(upload_csr(h, h->mat[PCD_MAT_A00], n_u, n_u, rp.data(), cc.data(), nullptr, src.data()));
+  CHK(upload_global(h, h->mat[PCD_MAT_A00], &h->sp_u, &h->sp_u, n_u, n_u, rp.data(), cc.data(), nullptr, src.data()));
   extract_block(n_u, is_u, rowptr, colidx, mp, rp, cc, src);
-  CHK(upload_csr(h, h->mat[PCD_MAT_A01], n_u, n_p, rp.data(), cc.data(), nullptr, src.data()));
+  CHK(upload_global(h, h->mat[PCD_MAT_A01], &h->sp_u, &h->sp_p, n_u, n_p, rp.data(), cc.data(), nullptr, src.data()));
   extract_block(n, perm.data(), rowptr, colidx, ma, rp, cc, src);
-  CHK(upload_csr(h, h->mat[PCD_MAT_A], n, n, rp.data(), cc.data(), nullptr, src.data()));
+  CHK(upload_global(h, h->mat[PCD_MAT_A], &h->sp_sys, &h->sp_sys, n, n, rp.data(), cc.data(), nullptr, src.data()));
   h->ready = false; ++h->gen;
   return pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
 }
@@ -936,13 +1122,9 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
 int pcd_set_bc(pcd_handle h, int64_t n_bc, const int32_t* idx, const double* vals) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (n_bc < 0 || (n_bc && (!idx || !vals))) return fail(PCD_ERR_ARG, "set_bc: bad arrays");
-  h->n_bc = n_bc; ++h->gen;
   h->bc_host.assign(idx, idx + n_bc);
-  if (n_bc) {
-    CHK(h->bc_idx.ensure(n_bc)); CHK(h->bc_val.ensure(n_bc));
-    HIPCHK(hipMemcpy(h->bc_idx.p, idx, n_bc * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->bc_val.p, vals, n_bc * sizeof(double), hipMemcpyHostToDevice));
-  }
+  h->bc_val_host.assign(vals, vals + n_bc);
+  h->ready = false; ++h->gen;             // filtered / uploaded by pcd_setup
   return 0;
 }
 
@@ -975,17 +1157,34 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
   if (level < 0 || level >= L) return fail(PCD_ERR_ARG, "mg_set_level: level %d outside [0,%d)", level, L);
   if (level > 0 && !(emax > emin && emin > 0.0))
     return fail(PCD_ERR_ARG, "mg_set_level: smoother needs 0 < emin < emax");
-  MgLevel& M = s.mg[level];
-  if (rowptr) {
-    if (!colidx || !vals) return fail(PCD_ERR_ARG, "mg_set_level: bad operator arrays");
-    CHK(upload_csr(h, M.A, n, n, rowptr, colidx, vals, nullptr));
-    CHK(refresh_dinv(h, M.A));
-  } else if (level != L - 1) {
+  if (level > 0 && (!prowptr || !pcolidx || !pvals))
+    return fail(PCD_ERR_ARG, "mg_set_level: prolongation missing");
+  if (!rowptr && level != L - 1)
     return fail(PCD_ERR_ARG, "mg_set_level: coarse levels need an operator");
+  if (rowptr && (!colidx || !vals)) return fail(PCD_ERR_ARG, "mg_set_level: bad operator arrays");
+  MgLevel& M = s.mg[level];
+  // multi-GPU: every level is cut into contiguous row blocks like the finest
+  // one (velocity levels keep the two components of a node together)
+  const bool even = slot == PCD_KSP_A00;
+  const Space *sl = nullptr, *sc = nullptr;
+  if (h->comm) {
+    s.mg_space.resize(L);
+    const int64_t nl = rowptr ? n : p_rows;
+    if (s.mg_space[level].nf == 0) s.mg_space[level] = Space::field(nl, h->nranks, even);
+    if (s.mg_space[level].total() != nl) return fail(PCD_ERR_ARG, "mg_set_level: level %d size mismatch", level);
+    sl = &s.mg_space[level];
+    if (level > 0) {
+      if (s.mg_space[level - 1].nf == 0) s.mg_space[level - 1] = Space::field(p_cols, h->nranks, even);
+      if (s.mg_space[level - 1].total() != p_cols) return fail(PCD_ERR_ARG, "mg_set_level: level %d prolongation width mismatch", level);
+      sc = &s.mg_space[level - 1];
+    }
+  }
+  if (rowptr) {
+    CHK(upload_global(h, M.A, sl, sl, n, n, rowptr, colidx, vals, nullptr));
+    CHK(refresh_dinv(h, M.A));
   }
   if (level > 0) {
-    if (!prowptr || !pcolidx || !pvals) return fail(PCD_ERR_ARG, "mg_set_level: prolongation missing");
-    CHK(upload_csr(h, M.P, p_rows, p_cols, prowptr, pcolidx, pvals, nullptr));
+    CHK(upload_global(h, M.P, sl, sc, p_rows, p_cols, prowptr, pcolidx, pvals, nullptr));
     // restriction = transpose, built on the host (counting sort by column)
     const int64_t nnz = prowptr[p_rows];
     std::vector<int32_t> trp(p_cols + 1, 0), tc(nnz);
@@ -998,7 +1197,7 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
         const int32_t q = fill[pcolidx[k]]++;
         tc[q] = (int32_t)i; tv[q] = pvals[k];
       }
-    CHK(upload_csr(h, M.R, p_cols, p_rows, trp.data(), tc.data(), tv.data(), nullptr));
+    CHK(upload_global(h, M.R, sc, sl, p_cols, p_rows, trp.data(), tc.data(), tv.data(), nullptr));
   }
   M.emin = emin; M.emax = emax;
   ++h->gen;
@@ -1015,9 +1214,7 @@ int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
   MgLevel& M = s.mg[level];
   if (vals) {
     if (!M.A.set) return fail(PCD_ERR_STATE, "mg_update_values: level %d has no operator", level);
-    HIPCHK(hipMemcpyAsync(M.A.val.p, vals, M.A.nnz * sizeof(double),
-                          mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                          h->stream));
+    CHK(refresh_values(h, M.A, vals, mem));
     CHK(refresh_dinv(h, M.A));
     if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
   }
@@ -1057,7 +1254,8 @@ int pcd_setup(pcd_handle h) {
     return fail(PCD_ERR_STATE, "setup: Ap, Mp and Kp are required");
   if ((h->variant == PCDR_BRM1 || h->variant == PCDR_BRM2) && !h->mat[PCD_MAT_RP].set)
     return fail(PCD_ERR_STATE, "setup: PCDR variants require Rp");
-  const int64_t np = h->mat[PCD_MAT_AP].nrows;
+  const int64_t np = h->mat[PCD_MAT_AP].nrows;            // rows of this rank
+  const int64_t np_glob = h->comm ? h->sp_p.total() : np;
   for (int m : {PCD_MAT_AP, PCD_MAT_MP, PCD_MAT_KP, PCD_MAT_RP}) {
     const DCsr& A = h->mat[m];
     if (A.set && (A.nrows != np || A.ncols != np))
@@ -1065,29 +1263,78 @@ int pcd_setup(pcd_handle h) {
                   (long long)A.nrows, (long long)A.ncols, (long long)np);
   }
   if (h->mat[PCD_MAT_A00].set) {
-    if (h->n_p && h->n_p != np) return fail(PCD_ERR_ARG, "setup: n_p of the split (%lld) != size of Ap (%lld)", (long long)h->n_p, (long long)np);
+    if (h->n_p && h->n_p != np_glob) return fail(PCD_ERR_ARG, "setup: n_p of the split (%lld) != size of Ap (%lld)", (long long)h->n_p, (long long)np_glob);
     if (h->mat[PCD_MAT_A01].ncols != np) return fail(PCD_ERR_ARG, "setup: A01 has %lld columns, expected %lld", (long long)h->mat[PCD_MAT_A01].ncols, (long long)np);
-    h->n_u = h->mat[PCD_MAT_A00].nrows;
-    CHK(h->wu.ensure(h->n_u));
-    CHK(h->xs.ensure(h->n_u + np)); CHK(h->ys.ensure(h->n_u + np));
+    h->nu_loc = h->mat[PCD_MAT_A00].nrows;
+    if (!h->comm) h->n_u = h->nu_loc;
+    CHK(h->wu.ensure(h->nu_loc));
+    CHK(h->xs.ensure(h->nu_loc + np)); CHK(h->ys.ensure(h->nu_loc + np));
   }
-  h->n_p = np;
-  for (int32_t i : h->bc_host)
-    if (i < 0 || i >= np) return fail(PCD_ERR_ARG, "setup: bc index %d outside [0,%lld)", i, (long long)np);
+  h->n_p = np_glob; h->np_loc = np;
+  // SubfieldBC::compute_subfield_bc keeps the owned indices and shifts them by
+  // the rank offset (SubfieldBC.h:138-155); here: global -> local
+  {
+    const int64_t p0 = h->comm ? h->sp_p.bounds[0][h->rank] : 0;
+    std::vector<int32_t> li; std::vector<double> lv;
+    for (size_t k = 0; k < h->bc_host.size(); ++k) {
+      const int64_t g = h->bc_host[k];
+      if (g < 0 || g >= np_glob) return fail(PCD_ERR_ARG, "setup: bc index %lld outside [0,%lld)", (long long)g, (long long)np_glob);
+      if (g >= p0 && g < p0 + np) { li.push_back((int32_t)(g - p0)); lv.push_back(h->bc_val_host[k]); }
+    }
+    h->n_bc = (int64_t)li.size();
+    if (h->n_bc) {
+      CHK(h->bc_idx.ensure(h->n_bc)); CHK(h->bc_val.ensure(h->n_bc));
+      HIPCHK(hipMemcpy(h->bc_idx.p, li.data(), h->n_bc * sizeof(int), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(h->bc_val.p, lv.data(), h->n_bc * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
   CHK(h->w[0].ensure(np)); CHK(h->w[1].ensure(np));
   for (int s = 0; s < PCD_KSP_COUNT; ++s) CHK(inner_prepare(h, s));
   h->ready = true; ++h->gen;
   return 0;
 }
 
+// Host-pointer calls always carry GLOBAL vectors; with several ranks each rank
+// works on its slice and the result is summed back into a full vector.
+// Device-pointer calls carry the rank's LOCAL slice (split ordering for
+// system vectors) when several ranks are active.
+struct FieldIo {
+  Engine* h; IoMap io; const Space* sp; int64_t nglob, nloc;
+  const double* lx = nullptr; double* ly = nullptr;
+};
+
+static int fio_begin(FieldIo& f, Engine* h, const Space* spx, int64_t nx_glob, int64_t nx_loc,
+                     const Space* spy, int64_t ny_glob, int64_t ny_loc,
+                     const double* x, double* y, int mem, bool y_in = false) {
+  f.h = h; f.sp = spy; f.nglob = ny_glob; f.nloc = ny_loc;
+  if (!h->comm || mem == PCD_MEM_DEVICE) {
+    CHK(io_begin(h, f.io, x, nx_glob, y, ny_glob, mem, y_in));
+    if (h->comm) { f.io.dx = x; f.io.dy = y; }
+    f.lx = f.io.dx; f.ly = f.io.dy;
+    return 0;
+  }
+  CHK(io_begin(h, f.io, x, nx_glob, y, ny_glob, mem, y_in));
+  CHK(h->loc_x.ensure(nx_loc)); CHK(h->loc_y.ensure(ny_loc));
+  if (x) CHK(slice_in(h, *spx, f.io.dx, h->loc_x.p));
+  if (y_in) CHK(slice_in(h, *spy, f.io.dy, h->loc_y.p));
+  f.lx = h->loc_x.p; f.ly = h->loc_y.p;
+  return 0;
+}
+
+static int fio_end(FieldIo& f) {
+  Engine* h = f.h;
+  if (h->comm && f.io.mem == PCD_MEM_HOST) CHK(slice_out(h, *f.sp, f.ly, f.io.dy));
+  return io_end(f.io);
+}
+
 int pcd_apply(pcd_handle h, const double* x, double* y, int mem) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!h->ready) return fail(PCD_ERR_STATE, "apply: call pcd_setup first");
   if (!x || !y || x == y) return fail(PCD_ERR_ARG, "apply: x and y must be distinct non-null vectors");
-  IoMap io;
-  CHK(io_begin(h, io, x, h->n_p, y, h->n_p, mem));
-  CHK(pcd_apply_dev(h, io.dx, io.dy));
-  return io_end(io);
+  FieldIo f;
+  CHK(fio_begin(f, h, &h->sp_p, h->n_p, h->np_loc, &h->sp_p, h->n_p, h->np_loc, x, y, mem));
+  CHK(pcd_apply_dev(h, f.lx, f.ly));
+  return fio_end(f);
 }
 
 int pcd_fieldsplit_apply(pcd_handle h, const double* x, double* y, int mem) {
@@ -1095,22 +1342,29 @@ int pcd_fieldsplit_apply(pcd_handle h, const double* x, double* y, int mem) {
   if (!h->ready || !h->mat[PCD_MAT_A00].set)
     return fail(PCD_ERR_STATE, "fieldsplit_apply: pcd_set_system + pcd_setup first");
   if (!x || !y || x == y) return fail(PCD_ERR_ARG, "fieldsplit_apply: x and y must be distinct non-null vectors");
-  const int64_t n = h->n_u + h->n_p;
+  const int64_t n = h->n_u + h->n_p, nloc = h->nu_loc + h->np_loc;
+  if (h->comm && mem == PCD_MEM_DEVICE)          // local split-ordered slices
+    return fs_apply_split(h, x, y);
   IoMap io;
   CHK(io_begin(h, io, x, n, y, n, mem));
-  const int g = grid1d(n, 1);
-  hipLaunchKernelGGL(k_gather, dim3(g), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, io.dx, h->xs.p);
+  const int g = grid1d(nloc, 1);
+  hipLaunchKernelGGL(k_gather, dim3(g), dim3(kBlock), 0, h->stream, (int)nloc, h->perm.p, io.dx, h->xs.p);
   CHK(fs_apply_split(h, h->xs.p, h->ys.p));
-  hipLaunchKernelGGL(k_scatter, dim3(g), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, h->ys.p, io.dy);
+  if (h->comm) HIPCHK(hipMemsetAsync(io.dy, 0, n * sizeof(double), h->stream));
+  hipLaunchKernelGGL(k_scatter, dim3(g), dim3(kBlock), 0, h->stream, (int)nloc, h->perm.p, h->ys.p, io.dy);
   HIPCHK(hipGetLastError());
+  if (h->comm && h->comm->allreduce(io.dy, n, h->stream))
+    return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
   return io_end(io);
 }
 
-// device dot/norm helper for GMRES: *out (pinned) = sqrt(v.v); synchronises
+// sqrt(v.v) over all ranks; synchronises
 static int dev_norm(Engine* h, int64_t n, const double* v, double* out) {
   const int G = grid1d(n, 4, 512);
   hipLaunchKernelGGL(k_mdot, dim3(G, 1), dim3(kBlock), 0, h->stream, n, v, (int64_t)0, 1, v, h->gparts.p, G);
   hipLaunchKernelGGL(k_mdot_reduce, dim3(1), dim3(kBlock), 0, h->stream, h->gparts.p, G, h->gh.p);
+  if (h->comm && h->comm->allreduce(h->gh.p, 1, h->stream))
+    return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
   HIPCHK(hipMemcpyAsync(h->pinned, h->gh.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   *out = std::sqrt(h->pinned[0]);
@@ -1124,7 +1378,9 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
   if (!h->ready || !h->mat[PCD_MAT_A].set)
     return fail(PCD_ERR_STATE, "gmres_solve: pcd_set_system + pcd_setup first");
   if (!b || !x || m < 1 || max_it < 0) return fail(PCD_ERR_ARG, "gmres_solve: bad arguments");
-  const int64_t n = h->n_u + h->n_p;
+  const int64_t nglob = h->n_u + h->n_p;
+  const int64_t n = h->nu_loc + h->np_loc;               // rows of this rank
+  const bool local_io = h->comm && mem == PCD_MEM_DEVICE;
   const int64_t ld = (n + 15) / 16 * 16;
   if (h->V_m < m || h->V_ld != ld) {
     CHK(h->V.ensure((size_t)ld * (m + 1)));
@@ -1135,10 +1391,12 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
   CHK(h->gparts.ensure((size_t)(m + 2) * 512)); CHK(h->gh.ensure(m + 2)); CHK(h->gy.ensure(m + 2));
   CHK(ensure_pinned(h, (size_t)m + 8));
   IoMap io;
-  CHK(io_begin(h, io, b, n, x, n, mem));
+  if (local_io) { io.h = h; io.mem = mem; io.dx = b; io.dy = x; }
+  else CHK(io_begin(h, io, b, nglob, x, nglob, mem));
   double *V = h->V.p, *z = h->gz.p, *xs = h->gxs.p, *bs = h->gbs.p;
   const int g1 = grid1d(n, 1);
-  hipLaunchKernelGGL(k_gather, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, io.dx, bs);
+  if (local_io) HIPCHK(hipMemcpyAsync(bs, io.dx, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  else hipLaunchKernelGGL(k_gather, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, io.dx, bs);
   HIPCHK(hipMemsetAsync(xs, 0, n * sizeof(double), h->stream));
   double bnorm = 0.0;
   CHK(dev_norm(h, n, bs, &bnorm));
@@ -1165,10 +1423,15 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
       CHK(spmv(h, A, z, vn));                                  // w = A z
       const int nvec = k + 1;
       const int tiles = (nvec + kDotTile - 1) / kDotTile;
+      // classical Gram-Schmidt: all k+1 dots in one batch, ONE all-reduce
       hipLaunchKernelGGL(k_mdot, dim3(G, tiles), dim3(kBlock), 0, h->stream, n, V, ld, nvec, vn, h->gparts.p, G);
       hipLaunchKernelGGL(k_mdot_reduce, dim3(nvec), dim3(kBlock), 0, h->stream, h->gparts.p, G, h->gh.p);
+      if (h->comm && h->comm->allreduce(h->gh.p, nvec, h->stream))
+        return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
       hipLaunchKernelGGL(k_maxpy_norm, dim3(G), dim3(kBlock), 0, h->stream, n, V, ld, nvec, h->gh.p, vn, -1.0, h->gparts.p);
-      hipLaunchKernelGGL(k_normalize, dim3(G), dim3(kBlock), 0, h->stream, n, vn, h->gparts.p, G, h->gh.p + nvec);
+      PartsRef nr;
+      CHK(reduce_global(h, h->gparts.p, G, h->gy.p + m + 1, &nr));
+      hipLaunchKernelGGL(k_normalize, dim3(G), dim3(kBlock), 0, h->stream, n, vn, nr.p, nr.n, h->gh.p + nvec);
       HIPCHK(hipMemcpyAsync(h->pinned, h->gh.p, (nvec + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       double* hc = &H[(size_t)k * (m + 1)];
@@ -1205,14 +1468,31 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
     CHK(spmv(h, A, xs, V, 2, bs));                              // r = b - A x
     CHK(dev_norm(h, n, V, &beta));
   }
-  hipLaunchKernelGGL(k_scatter, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, xs, io.dy);
-  HIPCHK(hipGetLastError());
-  CHK(io_end(io));
+  if (local_io) {
+    HIPCHK(hipMemcpyAsync(io.dy, xs, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    if (h->comm) HIPCHK(hipMemsetAsync(io.dy, 0, nglob * sizeof(double), h->stream));
+    hipLaunchKernelGGL(k_scatter, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, xs, io.dy);
+    HIPCHK(hipGetLastError());
+    if (h->comm && h->comm->allreduce(io.dy, nglob, h->stream))
+      return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+    CHK(io_end(io));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   h->gmres_its = it; h->gmres_rnorm = res;
   if (its) *its = it;
   if (rnorm) *rnorm = res;
   return 0;
+}
+
+// which -> (row space, column space) of a stored operator
+static void mat_spaces(Engine* h, int which, const Space** rs, const Space** cs) {
+  switch (which) {
+    case PCD_MAT_A00: *rs = *cs = &h->sp_u; break;
+    case PCD_MAT_A01: *rs = &h->sp_u; *cs = &h->sp_p; break;
+    case PCD_MAT_A: *rs = *cs = &h->sp_sys; break;
+    default: *rs = *cs = &h->sp_p; break;
+  }
 }
 
 int pcd_spmv(pcd_handle h, int which, const double* x, double* y, int mem) {
@@ -1221,10 +1501,13 @@ int pcd_spmv(pcd_handle h, int which, const double* x, double* y, int mem) {
     return fail(PCD_ERR_STATE, "spmv: operator %d not set", which);
   if (!x || !y || x == y) return fail(PCD_ERR_ARG, "spmv: x and y must be distinct non-null vectors");
   const DCsr& A = h->mat[which];
-  IoMap io;
-  CHK(io_begin(h, io, x, A.ncols, y, A.nrows, mem));
-  CHK(spmv(h, A, io.dx, io.dy));
-  return io_end(io);
+  const Space *rs, *cs;
+  mat_spaces(h, which, &rs, &cs);
+  FieldIo f;
+  CHK(fio_begin(f, h, cs, h->comm ? cs->total() : A.ncols, A.ncols,
+                rs, h->comm ? rs->total() : A.nrows, A.nrows, x, y, mem));
+  CHK(spmv(h, A, f.lx, f.ly));
+  return fio_end(f);
 }
 
 int pcd_inner_solve(pcd_handle h, int slot, const double* b, double* x, int mem) {
@@ -1234,20 +1517,23 @@ int pcd_inner_solve(pcd_handle h, int slot, const double* b, double* x, int mem)
   if (!A.set) return fail(PCD_ERR_STATE, "inner_solve: operator of slot %d not set", slot);
   if (!b || !x || b == x) return fail(PCD_ERR_ARG, "inner_solve: b and x must be distinct non-null vectors");
   CHK(inner_prepare(h, slot));
-  IoMap io;
-  CHK(io_begin(h, io, b, A.nrows, x, A.nrows, mem));
-  CHK(inner_solve(h, slot, io.dx, io.dy));
-  return io_end(io);
+  const Space *rs, *cs;
+  mat_spaces(h, kSlotMat[slot], &rs, &cs);
+  const int64_t ng = h->comm ? rs->total() : A.nrows;
+  FieldIo f;
+  CHK(fio_begin(f, h, rs, ng, A.nrows, rs, ng, A.nrows, b, x, mem));
+  CHK(inner_solve(h, slot, f.lx, f.ly));
+  return fio_end(f);
 }
 
 int pcd_apply_bc(pcd_handle h, double* x, int mem) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!x) return fail(PCD_ERR_ARG, "apply_bc: null vector");
-  const int64_t np = h->n_p ? h->n_p : h->mat[PCD_MAT_AP].nrows;
-  IoMap io;
-  CHK(io_begin(h, io, nullptr, 0, x, np, mem, true));
-  CHK(apply_bc_dev(h, io.dy));
-  return io_end(io);
+  if (!h->ready) return fail(PCD_ERR_STATE, "apply_bc: call pcd_setup first");
+  FieldIo f;
+  CHK(fio_begin(f, h, &h->sp_p, h->n_p, h->np_loc, &h->sp_p, h->n_p, h->np_loc, nullptr, x, mem, true));
+  CHK(apply_bc_dev(h, f.ly));
+  return fio_end(f);
 }
 
 int pcd_get_info(pcd_handle h, int key, double* out) {
@@ -1271,9 +1557,12 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_NUM_FS_APPLY: *out = (double)h->num_fs; return 0;
     case PCD_INFO_GMRES_ITS: *out = (double)h->gmres_its; return 0;
     case PCD_INFO_GMRES_RNORM: *out = h->gmres_rnorm; return 0;
+    case PCD_INFO_N_U_LOCAL: *out = (double)h->nu_loc; return 0;
+    case PCD_INFO_N_P_LOCAL: *out = (double)h->np_loc; return 0;
     default:
       if (key >= PCD_INFO_NNZ_BASE && key < PCD_INFO_NNZ_BASE + PCD_MAT_COUNT) {
-        *out = (double)h->mat[key - PCD_INFO_NNZ_BASE].nnz;
+        const DCsr& A = h->mat[key - PCD_INFO_NNZ_BASE];
+        *out = (double)(h->comm ? A.gnnz : A.nnz);
         return 0;
       }
   }
@@ -1286,14 +1575,53 @@ int pcd_graph_enable(pcd_handle h, int on) {
   return 0;
 }
 
+// ---- multi-GPU bootstrap ---------------------------------------------------
 int pcd_comm_unique_id(void* out128) {
-  (void)out128;
-  return fail(PCD_ERR_COMM, "comm: multi-GPU path not built yet");
+  if (!out128) return fail(PCD_ERR_ARG, "comm_unique_id: null buffer");
+  std::string err;
+  if (!rccl_api().load(err)) return fail(PCD_ERR_COMM, "%s", err.c_str());
+  ncclUniqueId id;
+  ncclResult_t r = rccl_api().GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(PCD_ERR_COMM, "ncclGetUniqueId: %s", rccl_api().GetErrorString(r));
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(out128, &id, sizeof id);
+  return 0;
+}
+
+static int comm_attach(Engine* h, CommBackend* c, int rank, int nranks) {
+  for (auto& m : h->mat) if (m.set) { delete c; return fail(PCD_ERR_STATE, "comm_init: call before any operator is handed over"); }
+  delete h->comm;
+  c->rank = rank; c->nranks = nranks;
+  h->comm = c; h->rank = rank; h->nranks = nranks;
+  h->sp_u = Space(); h->sp_p = Space(); h->sp_sys = Space();
+  ++h->gen;
+  return 0;
 }
 
 int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) {
-  (void)h; (void)rank; (void)nranks; (void)id;
-  return fail(PCD_ERR_COMM, "comm: multi-GPU path not built yet");
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(PCD_ERR_ARG, "comm_init: bad rank/size/id");
+  if (nranks == 1) return 0;                      // nothing to partition
+  HIPCHK(hipSetDevice(h->device));
+  std::string err;
+  if (!rccl_api().load(err)) return fail(PCD_ERR_COMM, "%s", err.c_str());
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  RcclBackend* b = new RcclBackend();
+  ncclResult_t r = rccl_api().CommInitRank(&b->comm, nranks, uid, rank);
+  if (r != ncclSuccess) { delete b; return fail(PCD_ERR_COMM, "ncclCommInitRank: %s", rccl_api().GetErrorString(r)); }
+  return comm_attach(h, b, rank, nranks);
+}
+
+// test-only backend: `nranks` engines of ONE process (one thread each) on one
+// GPU exchange through device copies; *group is created by the first caller
+int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group) {
+  if (!h || !group) return fail(PCD_ERR_ARG, "comm_init_threads: null argument");
+  if (nranks < 2 || rank < 0 || rank >= nranks) return fail(PCD_ERR_ARG, "comm_init_threads: bad rank/size");
+  if (!*group) *group = new ThreadGroup(nranks);
+  ThreadBackend* b = new ThreadBackend();
+  b->g = static_cast<ThreadGroup*>(*group);
+  return comm_attach(h, b, rank, nranks);
 }
 
 }  // extern "C"

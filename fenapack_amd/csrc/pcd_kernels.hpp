@@ -41,16 +41,25 @@ __device__ __forceinline__ double reduce_parts(const double* part, int n,
 }
 
 // ---- CSR row sum: LPR lanes cooperate on one row -------------------------
+// gathered vector: owned entries in x[0, nloc), ghost entries (filled by the
+// halo exchange) in ghost[0, nghost); single GPU: nloc = ncols, no ghosts
+struct XVec {
+  const double* x; const double* ghost; int nloc;
+  __device__ __forceinline__ double operator()(int c) const {
+    return c < nloc ? x[c] : ghost[c - nloc];
+  }
+};
+
 template <int LPR>
 __device__ __forceinline__ double row_dot(const int* __restrict__ rowptr,
                                           const int* __restrict__ col,
                                           const double* __restrict__ val,
-                                          const double* x, int row, int nrows,
+                                          const XVec x, int row, int nrows,
                                           int lane) {
   double s = 0.0;
   if (row < nrows) {
     const int b = rowptr[row], e = rowptr[row + 1];
-    for (int k = b + lane; k < e; k += LPR) s += val[k] * x[col[k]];
+    for (int k = b + lane; k < e; k += LPR) s += val[k] * x(col[k]);
   }
 #pragma unroll
   for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LPR);
@@ -61,7 +70,7 @@ __device__ __forceinline__ double row_dot(const int* __restrict__ rowptr,
 template <int LPR, int MODE>
 __global__ __launch_bounds__(kBlock) void k_spmv(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double* x, const double* add,
+    const double* __restrict__ val, const XVec x, const double* add,
     double* y) {
   constexpr int RPB = kBlock / LPR;
   const int lane = threadIdx.x % LPR;
@@ -84,13 +93,14 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* __restrict__ dinv,
     const double* b, const double* pm, const double* pk, double* pn,
-    double c0, double c1, double c2) {
+    double c0, double c1, double c2, const double* ghost, int nloc) {
   constexpr int RPB = kBlock / LPR;
   const int lane = threadIdx.x % LPR;
   const int nloop = (nrows + RPB - 1) / RPB * RPB;
+  const XVec xv{pk, ghost, nloc};
   for (int row = blockIdx.x * RPB + threadIdx.x / LPR; row < nloop;
        row += gridDim.x * RPB) {
-    double s = row_dot<LPR>(rowptr, col, val, pk, row, nrows, lane);
+    double s = row_dot<LPR>(rowptr, col, val, xv, row, nrows, lane);
     if (lane == 0 && row < nrows) {
       double z = b[row] - s;
       if (dinv) z *= dinv[row];
@@ -166,16 +176,17 @@ template <int LPR>
 __global__ __launch_bounds__(kBlock) void k_cg_spmv_dot(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* p, double* q,
-    double* parts_pq, const CgState* st) {
+    double* parts_pq, const CgState* st, const double* ghost, int nloc) {
   __shared__ double sm[4];
   if (st->done) return;
   constexpr int RPB = kBlock / LPR;
   const int lane = threadIdx.x % LPR;
   const int nloop = (nrows + RPB - 1) / RPB * RPB;
+  const XVec xv{p, ghost, nloc};
   double acc = 0.0;
   for (int row = blockIdx.x * RPB + threadIdx.x / LPR; row < nloop;
        row += gridDim.x * RPB) {
-    double s = row_dot<LPR>(rowptr, col, val, p, row, nrows, lane);
+    double s = row_dot<LPR>(rowptr, col, val, xv, row, nrows, lane);
     if (lane == 0 && row < nrows) { q[row] = s; acc += p[row] * s; }
   }
   acc = block_sum(acc, sm);
@@ -227,10 +238,6 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(
 // ==========================================================================
 constexpr int kTile = 4096;       // LDS doubles per workgroup (32 KiB)
 
-struct XPlain {
-  const double* x;
-  __device__ __forceinline__ double operator()(int c) const { return x[c]; }
-};
 // p = z + beta * p_old formed on the fly (CG direction update fused in SpMV)
 struct XCg {
   const double* z; const double* p; double beta; bool first;
@@ -280,13 +287,12 @@ __device__ __forceinline__ double stream_row_block(
 template <int RB, int MODE>
 __global__ __launch_bounds__(kBlock) void k_spmv_s(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double* x, const double* add,
+    const double* __restrict__ val, const XVec xf, const double* add,
     double* y) {
   __shared__ double lds[kTile];
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, rb0, rb1);
-  const XPlain xf{x};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
@@ -305,12 +311,12 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_s(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* __restrict__ dinv,
     const double* b, const double* pm, const double* pk, double* pn,
-    double c0, double c1, double c2) {
+    double c0, double c1, double c2, const double* ghost, int nloc) {
   __shared__ double lds[kTile];
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, rb0, rb1);
-  const XPlain xf{pk};
+  const XVec xf{pk, ghost, nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
@@ -387,6 +393,24 @@ __global__ __launch_bounds__(kBlock) void k_axpby(int n, double a,
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
        i += gridDim.x * kBlock)
     y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+}
+
+// halo pack: out[i] = x[idx[i]]
+__global__ __launch_bounds__(kBlock) void k_pack(
+    int n, const int* __restrict__ idx, const double* x, double* out) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += gridDim.x * kBlock)
+    out[i] = x[idx[i]];
+}
+
+// slot[j] = sum parts[j*stride .. j*stride + n)   (one workgroup per j): the
+// rank-local value that then goes through ncclAllReduce
+__global__ __launch_bounds__(kBlock) void k_sum_parts(const double* parts,
+                                                       int n, int stride,
+                                                       double* slot) {
+  __shared__ double sm[4];
+  const double s = reduce_parts(parts + (int64_t)blockIdx.x * stride, n, sm);
+  if (threadIdx.x == 0) slot[blockIdx.x] = s;
 }
 
 // SubfieldBC::apply: x[idx[i]] = val[i]  (VecSetValues INSERT)

@@ -78,6 +78,7 @@ enum pcd_info {
   PCD_INFO_ITS_A00 = 5,      /* iterations executed by the last inner solve */
   PCD_INFO_NUM_PCD_APPLY = 6, PCD_INFO_NUM_FS_APPLY = 7,
   PCD_INFO_GMRES_ITS = 8, PCD_INFO_GMRES_RNORM = 9,
+  PCD_INFO_N_U_LOCAL = 10, PCD_INFO_N_P_LOCAL = 11,  /* rows of this rank */
   PCD_INFO_NNZ_BASE = 16     /* + pcd_mat: stored nonzeros of that operator */
 };
 
@@ -208,6 +209,12 @@ int pcd_graph_enable(pcd_handle h, int on);
 int pcd_comm_unique_id(void* out128);
 int pcd_comm_init(pcd_handle h, int rank, int nranks,
                   const void* nccl_unique_id);
+/* TEST backend with the same two primitives (halo exchange, all-reduce):
+ * `nranks` handles driven by `nranks` threads of ONE process on one GPU.
+ * *group must be NULL for the first caller and is shared by the others.  It
+ * exists because RCCL refuses two ranks on one device, so that partitioning,
+ * column localisation and halo plans can be exercised on a single-GPU box. */
+int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group);
 
 #ifdef __cplusplus
 }

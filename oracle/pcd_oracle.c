@@ -757,6 +757,8 @@ int pcdo_get_info(pcdo_t *h, int key, double *out) {
     case 7: *out = (double)h->num_fs; break;
     case 8: *out = (double)h->gmres_its; break;
     case 9: *out = h->gmres_rnorm; break;
+    case 10: *out = (double)h->n_u; break;      /* one rank owns every row */
+    case 11: *out = (double)h->n_p; break;
     default:
       if (key >= 16 && key < 16 + MAT_COUNT) {
         *out = (double)h->mat[key - 16].nnz; break;

@@ -1,0 +1,110 @@
+"""GPU suite, part 3: the row-partitioned multi-rank path, exercised on ONE
+GPU through the in-process threaded comm backend (RCCL refuses two ranks on a
+single device).  R engine handles = R ranks, one thread each; host-pointer
+calls carry global vectors, so results compare directly with one engine."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from fenapack_amd import _cabi as c
+from helpers import (flow_state, configure_engine, relerr, set_iter_cfg,
+                     push_multigrid)
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(hip_lib, R, variant, work):
+    """``work(engine, rank)`` on R ranks in lockstep; returns the results."""
+    group = ctypes.c_void_p()
+    engines = []
+    for r in range(R):
+        e = c.Engine(hip_lib, variant, 0)
+        e.comm_init_threads(r, R, group)
+        engines.append(e)
+    out, errs = [None] * R, []
+
+    def body(r):
+        try:
+            out[r] = work(engines[r], r)
+        except Exception as ex:            # pragma: no cover
+            errs.append((r, ex))
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "ranks deadlocked"
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_spmv_and_apply_partitioned_vs_single(hip_lib, R):
+    st = flow_state("lshape", 3, dt=0.2)
+    V = st["V"]
+    rng = np.random.default_rng(20)
+    xp, xu, xs = (rng.standard_normal(V.n_p), rng.standard_normal(V.n_u),
+                  rng.standard_normal(V.ndof))
+
+    def work(e, rank):
+        configure_engine(e, st)
+        set_iter_cfg(e)
+        e.set_inner(c.KSP_A00, "chebyshev", "jacobi", 4, 0.0, 0.2, 2.2)
+        e.setup()
+        res = {"np_loc": e.info(c.INFO_N_P_LOCAL),
+               "nu_loc": e.info(c.INFO_N_U_LOCAL)}
+        res["Kp"] = e.spmv_np(c.MAT_KP, xp, V.n_p)
+        res["A00"] = e.spmv_np(c.MAT_A00, xu, V.n_u)
+        res["A01"] = e.spmv_np(c.MAT_A01, xp, V.n_u)
+        res["A"] = e.spmv_np(c.MAT_A, xs, V.ndof)
+        res["cg"] = e.inner_solve_np(c.KSP_AP, xp)
+        res["cheb"] = e.inner_solve_np(c.KSP_A00, xu)
+        res["pcd"] = e.apply_np(xp)
+        res["fs"] = e.fieldsplit_apply_np(xs)
+        e.set_inner(c.KSP_AP, "cg", "jacobi", 3000, 1e-10)
+        res["cg_tol"] = e.inner_solve_np(c.KSP_AP, xp)
+        res["cg_its"] = e.info(c.INFO_ITS_AP)
+        return res
+
+    outs = run_ranks(hip_lib, R, "RBRM1", work)
+    ref = work(oracle.Engine("RBRM1"), 0)
+    assert sum(o["np_loc"] for o in outs) == V.n_p
+    assert sum(o["nu_loc"] for o in outs) == V.n_u
+    assert all(o["nu_loc"] % 2 == 0 for o in outs)
+    for o in outs:                       # every rank returns the full vector
+        for key in ("Kp", "A00", "A01", "A"):
+            assert relerr(o[key], ref[key]) < 1e-13, key
+        for key in ("cg", "cheb", "pcd", "fs"):
+            assert relerr(o[key], ref[key]) < 1e-11, key
+        assert abs(o["cg_its"] - ref["cg_its"]) <= 1
+        assert relerr(o["cg_tol"], ref["cg_tol"]) < 1e-8
+
+
+def test_gmres_with_multigrid_partitioned(hip_lib):
+    st = flow_state("cavity", 3)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    I = pb.interpolations()
+
+    def work(e, rank):
+        configure_engine(e, st)
+        push_multigrid(e, c.KSP_AP, pb.Ap, I.chain("p"))
+        push_multigrid(e, c.KSP_A00, L["A00"], I.chain("u"))
+        e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+        e.setup()
+        x, its, rn = e.gmres_np(st["b"], rtol=1e-8, restart=60, max_it=200)
+        # values refreshed between Newton steps keep working
+        e.update_system(st["A"].data)
+        y = e.fieldsplit_apply_np(st["b"])
+        return x, its, y
+
+    outs = run_ranks(hip_lib, 2, "BRM1", work)
+    xr, ir, yr = work(oracle.Engine("BRM1"), 0)
+    for x, its, y in outs:
+        assert its == ir
+        assert relerr(x, xr) < 1e-7
+        assert relerr(y, yr) < 1e-11
+    assert relerr(st["A"] @ outs[0][0], st["b"]) < 1e-6
