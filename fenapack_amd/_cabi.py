@@ -69,7 +69,8 @@ _HIP_ONLY = {
 }
 
 #: every symbol include/pcd_engine.h declares (checked by the CPU test-suite)
-DECLARED_SYMBOLS = (["pcd_create", "pcd_last_error", "pcd_comm_unique_id"]
+DECLARED_SYMBOLS = (["pcd_create", "pcd_last_error", "pcd_comm_unique_id",
+                     "pcd_dist_probe"]
                     + ["pcd_" + k for k in _SIGNATURES]
                     + ["pcd_" + k for k in _HIP_ONLY])
 
@@ -310,6 +311,43 @@ class Engine(object):
         x = np.zeros_like(b)
         its, rn = self.gmres_solve(b, x, **kw)
         return x, its, rn
+
+
+def dist_probe(A, rank, nranks, even_rows=False, even_cols=False):
+    """Row block / halo plan of ``rank`` for the global CSR ``A`` (host only).
+    Returns dict(local=csr with ghost columns appended, row0, col0, nghost,
+    send={peer: local indices}, recv={peer: (ghost_begin, ghost_end)})."""
+    import scipy.sparse as sp
+    lib = hip_library()
+    f = lib.lib.pcd_dist_probe
+    f.restype = C.c_int
+    ip, ix, dv = _i32(A.indptr), _i32(A.indices), _f64(A.data)
+    nr, nc, nnz = A.shape[0], A.shape[1], A.nnz
+    counts = np.zeros(7, dtype=np.int64)
+    orp, oc, ov = (np.zeros(nr + 1, np.int32), np.zeros(max(nnz, 1), np.int32),
+                   np.zeros(max(nnz, 1)))
+    sp_, so, si = (np.zeros(nranks, np.int32), np.zeros(nranks + 1, np.int32),
+                   np.zeros(max(nc, 1), np.int32))
+    rp_, ro = np.zeros(nranks, np.int32), np.zeros(nranks + 1, np.int32)
+    args = [C.c_int64(nr), C.c_int64(nc)] + [C.c_void_p(_ptr(a))
+                                             for a in (ip, ix, dv)] \
+        + [C.c_int(rank), C.c_int(nranks), C.c_int(int(even_rows)),
+           C.c_int(int(even_cols))] \
+        + [C.c_void_p(_ptr(a)) for a in (counts, orp, oc, ov, sp_, so, si,
+                                         rp_, ro)]
+    rc = f(*args)
+    if rc:
+        raise EngineError("dist_probe failed (%d): %s" % (rc, lib.error()))
+    nl, ncl, ng, ns, nrv, row0, col0 = (int(v) for v in counts)
+    lnnz = int(orp[nl])
+    local = sp.csr_matrix((ov[:lnnz], oc[:lnnz], orp[:nl + 1]),
+                          shape=(nl, ncl + ng))
+    return {"local": local, "row0": row0, "col0": col0, "ncols_owned": ncl,
+            "nghost": ng,
+            "send": {int(sp_[i]): si[so[i]:so[i + 1]].copy()
+                     for i in range(ns)},
+            "recv": {int(rp_[i]): (int(ro[i]), int(ro[i + 1]))
+                     for i in range(nrv)}}
 
 
 def comm_unique_id():

@@ -1624,4 +1624,35 @@ int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group) {
   return comm_attach(h, b, rank, nranks);
 }
 
+// Host-only view of the partitioning (no device call): the row block, the
+// localised columns and the halo plan rank `rank` of `nranks` derives from a
+// global CSR.  Lets multi-process CPU tests drive the same C++ that the GPU
+// path uses.  Output arrays must hold nrows+1 / nnz / ncols / nranks+1 entries.
+int pcd_dist_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                   const int32_t* colidx, const double* vals, int rank,
+                   int nranks, int even_rows, int even_cols, int64_t* counts,
+                   int32_t* out_rowptr, int32_t* out_col, double* out_val,
+                   int32_t* send_peers, int32_t* send_off, int32_t* send_idx,
+                   int32_t* recv_peers, int32_t* recv_off) {
+  if (!rowptr || !colidx || !vals || !counts || nranks < 1 || rank < 0 || rank >= nranks)
+    return fail(PCD_ERR_ARG, "dist_probe: bad arguments");
+  const Space rs = Space::field(nrows, nranks, even_rows != 0);
+  const Space cs = Space::field(ncols, nranks, even_cols != 0);
+  std::vector<int32_t> orp, oc; std::vector<double> ov; std::vector<int64_t> osrc;
+  HaloPlan plan;
+  localize(rs, cs, rank, nranks, rowptr, colidx, vals, nullptr, orp, oc, ov, osrc, plan);
+  counts[0] = rs.nloc(rank); counts[1] = cs.nloc(rank); counts[2] = plan.nghost;
+  counts[3] = (int64_t)plan.peers_send.size(); counts[4] = (int64_t)plan.peers_recv.size();
+  counts[5] = rs.bounds[0][rank]; counts[6] = cs.bounds[0][rank];
+  std::copy(orp.begin(), orp.end(), out_rowptr);
+  std::copy(oc.begin(), oc.end(), out_col);
+  std::copy(ov.begin(), ov.end(), out_val);
+  std::copy(plan.peers_send.begin(), plan.peers_send.end(), send_peers);
+  std::copy(plan.send_off.begin(), plan.send_off.end(), send_off);
+  std::copy(plan.send_idx.begin(), plan.send_idx.end(), send_idx);
+  std::copy(plan.peers_recv.begin(), plan.peers_recv.end(), recv_peers);
+  std::copy(plan.recv_off.begin(), plan.recv_off.end(), recv_off);
+  return 0;
+}
+
 }  // extern "C"

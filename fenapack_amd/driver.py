@@ -57,12 +57,12 @@ def default_inner_options(prefix="", a00_its=60, a00_ratio=0.01, ap_rtol=1e-8,
 
 
 def make_solver(problem, prefix="", gmres_rtol=1e-6, restart=150,
-                newton_rtol=1e-5, max_newton=25, device=0):
+                newton_rtol=1e-5, max_newton=25, device=0, comm=None):
     """Wire up the solver stack for ``problem``; returns (w, nls, nlp)."""
     w, forms = navier_stokes_forms(problem)
     assembler = PCDAssembler(**forms)
     nlp = PCDNonlinearProblem(assembler)
-    linear_solver = PCDKrylovSolver(device=device)
+    linear_solver = PCDKrylovSolver(comm=comm, device=device)
     if prefix:
         linear_solver.set_options_prefix(prefix)
     linear_solver.parameters["relative_tolerance"] = gmres_rtol

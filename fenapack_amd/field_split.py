@@ -80,6 +80,11 @@ class PCDKSP(KSP):
 
         # the engine: one handle = PCD context + fieldsplit shell + GMRES
         self.engine = c.Engine(c.hip_library(), pcd_pc.variant, self.device)
+        if self.comm is not None and getattr(self.comm, "size", 1) > 1:
+            # one process per GPU: rows are partitioned inside the engine,
+            # RCCL carries the halos and the dot-product all-reduces
+            self.engine.comm_init(self.comm.rank, self.comm.size,
+                                  self.comm.unique_id())
         A, P = self.getOperators()
         self._upload_system(A, P, is0, is1, first=True)
         ksp0.setOperators(Mat(self._A00_host(A, P, is0)))

@@ -215,6 +215,16 @@ int pcd_comm_init(pcd_handle h, int rank, int nranks,
  * exists because RCCL refuses two ranks on one device, so that partitioning,
  * column localisation and halo plans can be exercised on a single-GPU box. */
 int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group);
+/* Host-only probe of the same partitioning code (no device call, no handle):
+ * row block, localised columns and halo plan of `rank`.  counts[7] = local
+ * rows, owned cols, ghosts, #send peers, #recv peers, first row, first col.
+ * Used by the world_size-2 gloo tests on CPU. */
+int pcd_dist_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                   const int32_t* colidx, const double* vals, int rank,
+                   int nranks, int even_rows, int even_cols, int64_t* counts,
+                   int32_t* out_rowptr, int32_t* out_col, double* out_val,
+                   int32_t* send_peers, int32_t* send_off, int32_t* send_idx,
+                   int32_t* recv_peers, int32_t* recv_off);
 
 #ifdef __cplusplus
 }
