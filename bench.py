@@ -238,7 +238,7 @@ def main():
             "frac": achieved / rf.HBM_PEAK_GBS,
             "bytes_per_launch": int(b_kernel),
             "us_per_launch": 1e6 * t_kernel,
-            "traffic": None,
+            "traffic": pmc_traffic(int(V.n_u), nnz_a00, world),
         },
         "setup_seconds": t_setup,
     }
@@ -249,6 +249,24 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(n_u, nnz_a00, world):
+    """HBM bytes per launch of the roofline kernel from the committed
+    rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, calibrated on
+    a kernel of known byte count: profiles/r01_pmc_cheb_step_level6.json).
+    PMC cannot be collected inside this process; null unless the committed
+    measurement is for exactly this operator."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_cheb_step_level6.json")
+    try:
+        d = json.load(open(path))
+        k = d["k_cheb_step_s<256>"]
+        if world == 1 and k["algorithmic_bytes_per_launch"] == \
+                12 * nnz_a00 + 92 * n_u + 4:
+            return k["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(args, pb, ksp, eng, c, x):
