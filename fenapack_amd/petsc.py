@@ -277,6 +277,7 @@ class PC(object):
         # [ext PETSc] PCMG: prolongation chain, levels, smoother settings
         self._mg_chain = None
         self.mg_levels = None
+        self.mg_coarse_eq_limit = 2000     # like -pc_gamg_coarse_eq_limit
         self.mg_smooth_its = 2
         self.mg_esteig = (0.0, 0.1, 0.0, 1.1)
         self._mg_pushed = None
@@ -411,6 +412,8 @@ class KSP(object):
                     % (self._prefix, p))
             self.pc.setType(p)
         self.pc.mg_levels = o.getInt("pc_mg_levels", self.pc.mg_levels)
+        self.pc.mg_coarse_eq_limit = o.getInt("pc_mg_coarse_eq_limit",
+                                              self.pc.mg_coarse_eq_limit)
         self.pc.mg_smooth_its = o.getInt("mg_levels_ksp_max_it",
                                          self.pc.mg_smooth_its)
         e = o.getString("mg_levels_ksp_chebyshev_esteig")
@@ -453,8 +456,17 @@ class KSP(object):
             raise RuntimeError("%spc_type mg needs interpolations "
                                "(pc.setMGInterpolations)" % self._prefix)
         chain = pc._mg_chain
-        if pc.mg_levels is not None and pc.mg_levels < len(chain):
-            chain = [None] + chain[len(chain) - pc.mg_levels + 1:]
+        nlev = pc.mg_levels
+        if nlev is None:
+            # the coarsest level is the LARGEST one whose explicit inverse
+            # stays small: a dense SpMV of a few MB costs less than the ~7
+            # short launches of one more level
+            nlev = len(chain)
+            while nlev > 1 and chain[len(chain) - nlev + 1].shape[0] \
+                    <= pc.mg_coarse_eq_limit:
+                nlev -= 1
+        if nlev < len(chain):
+            chain = [None] + chain[len(chain) - nlev + 1:]
         ops = galerkin_chain(self._ops[1].A, chain)
         a, b, cc, d = pc.mg_esteig
         bounds = [None]
