@@ -75,6 +75,7 @@ struct DCsr {
   bool set = false;
   int lpr = 8;
   int rb = 0;             // rows per workgroup of the CSR-stream kernels (0: n/a)
+  bool long_rows = false; // >= 256 nonzeros per row on average: workgroup per row
   // multi-GPU: nrows / ncols are LOCAL counts (ncols = owned columns); ghost
   // columns are numbered ncols .. ncols + nghost and live in `ghost`
   HaloPlan plan;
@@ -130,6 +131,7 @@ struct pcd_engine_s {
   Inner inner[PCD_KSP_COUNT];
   int64_t n_bc = 0;
   DBuf<int> bc_idx;
+  DBuf<int> bc_slot;                  // row -> position in bc_val, or -1
   std::vector<int32_t> bc_host;
   DBuf<double> bc_val;
   int64_t n_u = 0, n_p = 0, sys_nnz = 0;   // GLOBAL sizes
@@ -320,7 +322,13 @@ static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
                 int mode = 0, const double* add = nullptr) {
   if (!A.set) return fail(PCD_ERR_STATE, "spmv: operator not set");
   CHK(halo_exchange(h, A, x));
-  if (A.rb) {
+  if (A.long_rows) {
+    const int g = (int)std::min<int64_t>(A.nrows, 65535);
+    const XVec xv = xvec(A, x);
+    if (mode == 0) hipLaunchKernelGGL((k_spmv_long<0>), dim3(g), dim3(kBlock), 0, h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv_long<1>), dim3(g), dim3(kBlock), 0, h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
+    else hipLaunchKernelGGL((k_spmv_long<2>), dim3(g), dim3(kBlock), 0, h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
+  } else if (A.rb) {
     if (mode == 0) launch_spmv_stream<0>(h, A, x, add, y);
     else if (mode == 1) launch_spmv_stream<1>(h, A, x, add, y);
     else launch_spmv_stream<2>(h, A, x, add, y);
@@ -390,6 +398,19 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                A.val.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, (int)A.ncols);
   }
   return 0;
+}
+
+// zero-guess start fused with the first step (single GPU, stream kernels):
+// p0 = s D^-1 b (also written to `p0` unless null), pn = c1 p0 + c2 D^-1(b - A p0)
+static bool can_fuse_first(const Engine* h, const DCsr& A, const double* dinv) {
+  return A.rb && !h->comm && dinv != nullptr;
+}
+static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
+                              const double* b, double* p0, double* pn, double s,
+                              double c1, double c2) {
+  const int n = (int)A.nrows;
+  LAUNCH_RB(A, k_cheb_first_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
+            A.val.p, dinv, b, p0, pn, s, c1, c2);
 }
 
 // CG with the direction update fused into the SpMV: two launches per
@@ -481,7 +502,7 @@ static int solve_cg(Engine* h, const DCsr& A, Inner& s, const double* b,
 // [ext PETSc] KSPCHEBYSHEV recurrence coefficients are data independent, so
 // the host computes them and every step is one fused launch.
 static int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
-                      double* x) {
+                      double* x, double out_scale = 1.0) {
   const int n = (int)A.nrows;
   const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
   const double scale = 2.0 / (s.emax + s.emin);
@@ -493,17 +514,27 @@ static int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
   const int m = s.max_it;
   ring[m % 3] = x; ring[(m + 1) % 3] = s.t0.p; ring[(m + 2) % 3] = s.t1.p;
   const int g1 = grid1d(n, 1);
-  hipLaunchKernelGGL(k_scale_dinv, dim3(g1), dim3(kBlock), 0, h->stream, n,
-                     dinv, b, scale, ring[0]);
+  const bool fuse = m >= 1 && can_fuse_first(h, A, dinv);
+  if (!fuse)
+    hipLaunchKernelGGL(k_scale_dinv, dim3(g1), dim3(kBlock), 0, h->stream, n,
+                       dinv, b, m == 0 ? scale * out_scale : scale, ring[0]);
   for (int it = 0; it < m; ++it) {
     const double c_kp1 = 2.0 * mu * c_k - c_km1;
     const double omega = omegaprod * c_k / c_kp1;
+    const double f = (it == m - 1) ? out_scale : 1.0;   // sign folded in
     double* pk = ring[it % 3];
     double* pn = ring[(it + 1) % 3];
-    // p_{-1} = 0 at the first step: coefficient forced to zero, never read
-    double* pm = (it == 0) ? pk : ring[(it + 2) % 3];
-    const double c0 = (it == 0) ? 0.0 : 1.0 - omega;
-    CHK(launch_cheb_step(h, A, dinv, b, pm, pk, pn, c0, omega, omega * scale));
+    if (it == 0 && fuse) {
+      // p_{-1} = 0: p1 = omega p0 + omega scale D^-1 (b - A p0)
+      launch_cheb_first(h, A, dinv, b, m >= 2 ? pk : nullptr, pn, scale,
+                        f * omega, f * omega * scale);
+    } else {
+      // p_{-1} = 0 at the first step: coefficient forced to zero, never read
+      double* pm = (it == 0) ? pk : ring[(it + 2) % 3];
+      const double c0 = (it == 0) ? 0.0 : 1.0 - omega;
+      CHK(launch_cheb_step(h, A, dinv, b, pm, pk, pn, f * c0, f * omega,
+                           f * omega * scale));
+    }
     c_km1 = c_k; c_k = c_kp1;
   }
   HIPCHK(hipGetLastError());
@@ -551,7 +582,17 @@ static int mg_smooth(Engine* h, const DCsr& A, double emin, double emax, int nu,
   double c_km1 = 1.0, c_k = mu;
   int cur;                       // index in bufs of the newest iterate
   bool have_pm;                  // p_{k-1} is a real vector (not zero)
-  if (zero_guess) {
+  if (zero_guess && nu >= 2 && can_fuse_first(h, A, dinv)) {
+    // Jacobi start + first step in one launch; p0 kept only if a later step
+    // needs it as p_{k-1}
+    const double c_kp1 = 2.0 * mu * c_k - c_km1;
+    const double omega = omegaprod * c_k / c_kp1;
+    launch_cheb_first(h, A, dinv, b, nu >= 3 ? bufs[0] : nullptr, bufs[1],
+                      scale, omega, omega * scale);
+    c_km1 = c_k; c_k = c_kp1;
+    cur = 1; have_pm = true;
+    --nu;                                  // one step already done
+  } else if (zero_guess) {
     hipLaunchKernelGGL(k_scale_dinv, dim3(grid1d(n, 1)), dim3(kBlock), 0,
                        h->stream, n, dinv, b, scale, bufs[0]);
     cur = 0; have_pm = false;
@@ -577,7 +618,7 @@ static int mg_smooth(Engine* h, const DCsr& A, double emin, double emax, int nu,
 
 // x_l = V-cycle(b) on level l; *out points at the level buffer with the result
 static int mg_vcycle(Engine* h, const DCsr& Afine, Inner& s, int l,
-                     const double* b, double** out) {
+                     const double* b, double** out, double* target = nullptr) {
   MgLevel& L = s.mg[l];
   if (l == 0) {
     CHK(spmv(h, L.A, b, L.x.p));              // explicit coarse inverse
@@ -597,11 +638,22 @@ static int mg_vcycle(Engine* h, const DCsr& Afine, Inner& s, int l,
   CHK(spmv(h, L.R, r, C.b.p));                // restrict
   double* pe = nullptr;
   CHK(mg_vcycle(h, Afine, s, l - 1, C.b.p, &pe));
-  CHK(spmv(h, L.P, pe, px, 1, px));           // x += P e
   double* post[3];
-  int j = 0;
-  post[0] = px;
-  for (double* q : bufs) if (q != px) post[++j] = q;
+  if (target) {
+    // arrange the ring so that the last smoothing step writes the caller's
+    // vector: no copy at the end of the cycle
+    const int last = s.nu_post % 3;
+    double* spare[2] = {L.t0.p, L.t1.p};
+    if (px == spare[0] || px == spare[1]) spare[px == spare[0] ? 0 : 1] = L.x.p;
+    post[last] = target;
+    post[(last + 1) % 3] = spare[0];
+    post[(last + 2) % 3] = spare[1];
+  } else {
+    int j = 0;
+    post[0] = px;
+    for (double* q : bufs) if (q != px) post[++j] = q;
+  }
+  CHK(spmv(h, L.P, pe, post[0], 1, px));      // post[0] = x + P e
   CHK(mg_smooth(h, A, L.emin, L.emax, s.nu_post, b, post, false, out));
   return 0;
 }
@@ -629,22 +681,31 @@ static int solve_mg(Engine* h, const DCsr& A, Inner& s, const double* b,
       r = s.t0.p;
     }
     double* z = nullptr;
-    if (L == 1) { CHK(spmv(h, s.mg[0].A, r, s.mg[0].x.p)); z = s.mg[0].x.p; }
-    else CHK(mg_vcycle(h, A, s, L - 1, r, &z));
-    if (it == 0) hipLaunchKernelGGL(k_copy, dim3(g), dim3(kBlock), 0, h->stream, n, z, x);
-    else hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, 1.0, z, 1.0, x);
+    if (L == 1) { CHK(spmv(h, s.mg[0].A, r, it == 0 ? x : s.mg[0].x.p)); z = it == 0 ? x : s.mg[0].x.p; }
+    else CHK(mg_vcycle(h, A, s, L - 1, r, &z, it == 0 ? x : nullptr));
+    if (it == 0) {
+      if (z != x) hipLaunchKernelGGL(k_copy, dim3(g), dim3(kBlock), 0, h->stream, n, z, x);
+    } else hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, 1.0, z, 1.0, x);
   }
   HIPCHK(hipGetLastError());
   s.last_its = its; s.its_on_device = false;
   return 0;
 }
 
-// KSP.solve(b, x): b and x must not alias
-static int inner_solve(Engine* h, int slot, const double* b, double* x) {
+// KSP.solve(b, x): b and x must not alias.  `out_scale` asks for x scaled by
+// a constant; *scaled tells whether the solver folded it in (for free) or the
+// caller still has to apply it.
+static int inner_solve(Engine* h, int slot, const double* b, double* x,
+                       double out_scale = 1.0, bool* scaled = nullptr) {
   const DCsr& A = h->mat[kSlotMat[slot]];
   Inner& s = h->inner[slot];
   if (!A.set) return fail(PCD_ERR_STATE, "inner_solve: operator of slot %d not set", slot);
   if (b == x) return fail(PCD_ERR_ARG, "inner_solve: b and x alias");
+  if (scaled) *scaled = false;
+  if (s.pc != PCD_PC_MG && s.ksp == PCD_KSP_CHEBYSHEV) {
+    if (scaled) *scaled = true;
+    return solve_cheb(h, A, s, b, x, scaled ? out_scale : 1.0);
+  }
   if (s.pc == PCD_PC_MG) {
     if (s.ksp != PCD_KSP_PREONLY && s.ksp != PCD_KSP_RICHARDSON)
       return fail(PCD_ERR_ARG, "pc mg is supported under preonly / richardson only");
@@ -682,18 +743,23 @@ static int pcd_apply_dev(Engine* h, const double* x, double* y) {
   const bool reaction = h->variant == PCDR_BRM1 || h->variant == PCDR_BRM2;
   if (h->variant == PCD_BRM1 || h->variant == PCDR_BRM1) {
     double* z = h->w[0].p;
-    hipLaunchKernelGGL(k_copy, dim3(g), dim3(kBlock), 0, h->stream, n, x, z);  // z = x
-    CHK(apply_bc_dev(h, z));                                   // bcs_applier(z)
+    // z = x; bcs_applier(z): copy and VecSetValues(INSERT) in one launch
+    hipLaunchKernelGGL(k_copy_bc, dim3(g), dim3(kBlock), 0, h->stream, n, x,
+                       h->bc_slot.p, h->bc_val.p, z);
     CHK(inner_solve(h, PCD_KSP_AP, z, y));                      // y = Ap^-1 z
     CHK(spmv(h, h->mat[PCD_MAT_KP], y, z, 1, x));               // z = Kp y + x
-    CHK(inner_solve(h, PCD_KSP_MP, z, y));                      // y = Mp^-1 z
     if (reaction) {
+      CHK(inner_solve(h, PCD_KSP_MP, z, y));                    // y = Mp^-1 z
       CHK(inner_solve(h, PCD_KSP_RP, x, z));                    // z = Rp^-1 x
       hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, -1.0,
                          z, -1.0, y);                           // y = -(y + z)
     } else {
-      hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, -1.0,
-                         y, 0.0, y);                            // y = -y
+      // y = -(Mp^-1 z): the sign rides on the last Chebyshev step when it can
+      bool scaled = false;
+      CHK(inner_solve(h, PCD_KSP_MP, z, y, -1.0, &scaled));
+      if (!scaled)
+        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(kBlock), 0, h->stream, n, -1.0,
+                           y, 0.0, y);                          // y = -y
     }
   } else {
     double *z0 = h->w[0].p, *z1 = h->w[1].p;
@@ -833,6 +899,7 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.set = true;
   A.lpr = choose_lpr(A);
   A.rb = g_force_vector ? 0 : choose_rb(nrows, rowptr);
+  A.long_rows = A.rb == 0 && nrows > 0 && nnz / nrows >= 256;
   return 0;
 }
 
@@ -951,7 +1018,7 @@ int pcd_destroy(pcd_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto& m : h->mat) m.release();
   for (auto& s : h->inner) s.release();
-  h->bc_idx.release(); h->bc_val.release(); h->perm.release();
+  h->bc_idx.release(); h->bc_val.release(); h->bc_slot.release(); h->perm.release();
   h->sysvals.release(); h->psysvals.release();
   h->w[0].release(); h->w[1].release(); h->wu.release();
   h->xs.release(); h->ys.release(); h->io_x.release(); h->io_y.release();
@@ -1282,6 +1349,12 @@ int pcd_setup(pcd_handle h) {
       if (g >= p0 && g < p0 + np) { li.push_back((int32_t)(g - p0)); lv.push_back(h->bc_val_host[k]); }
     }
     h->n_bc = (int64_t)li.size();
+    {
+      std::vector<int32_t> slot(np, -1);
+      for (size_t k = 0; k < li.size(); ++k) slot[li[k]] = (int32_t)k;   // last one wins
+      CHK(h->bc_slot.ensure(np));
+      if (np) HIPCHK(hipMemcpy(h->bc_slot.p, slot.data(), np * sizeof(int), hipMemcpyHostToDevice));
+    }
     if (h->n_bc) {
       CHK(h->bc_idx.ensure(h->n_bc)); CHK(h->bc_val.ensure(h->n_bc));
       HIPCHK(hipMemcpy(h->bc_idx.p, li.data(), h->n_bc * sizeof(int), hipMemcpyHostToDevice));

@@ -332,6 +332,67 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_s(
   }
 }
 
+// First smoothing step from a ZERO guess, fused with the Jacobi start:
+//   p0 = s * dinv .* b  (formed on the fly for the gathered columns and
+//   written once for the owned rows);  pn = c1 p0 + c2 dinv .* (b - A p0)
+struct XScaled {
+  const double* b; const double* dinv; double s;
+  __device__ __forceinline__ double operator()(int c) const {
+    return s * dinv[c] * b[c];
+  }
+};
+
+template <int RB>
+__global__ __launch_bounds__(kBlock) void k_cheb_first_s(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* __restrict__ dinv,
+    const double* b, double* p0, double* pn, double s, double c1, double c2) {
+  __shared__ double lds[kTile];
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, rb0, rb1);
+  const XScaled xf{b, dinv, s};
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const double sum = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const int row = r0 + threadIdx.x;
+    if (threadIdx.x < RB && row < nrows) {
+      const double d = dinv[row], bi = b[row];
+      const double x0 = s * d * bi;
+      if (p0) p0[row] = x0;
+      pn[row] = c1 * x0 + c2 * d * (bi - sum);
+    }
+    __syncthreads();
+  }
+}
+
+// long rows (dense coarse inverse): one workgroup per row, 4 loads in flight
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_spmv_long(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const XVec x, const double* add,
+    double* y) {
+  __shared__ double sm[4];
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int b = rowptr[row], e = rowptr[row + 1];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = b + threadIdx.x;
+    for (; k + 3 * kBlock < e; k += 4 * kBlock) {
+      s0 += val[k] * x(col[k]);
+      s1 += val[k + kBlock] * x(col[k + kBlock]);
+      s2 += val[k + 2 * kBlock] * x(col[k + 2 * kBlock]);
+      s3 += val[k + 3 * kBlock] * x(col[k + 3 * kBlock]);
+    }
+    for (; k < e; k += kBlock) s0 += val[k] * x(col[k]);
+    const double s = block_sum((s0 + s1) + (s2 + s3), sm);
+    if (threadIdx.x == 0) {
+      if (MODE == 0) y[row] = s;
+      if (MODE == 1) y[row] = add[row] + s;
+      if (MODE == 2) y[row] = add[row] - s;
+    }
+  }
+}
+
 // CG, first kernel of an iteration: direction update fused into the SpMV.
 //   beta = rz_new / rz_old (both re-reduced from workgroup partials);
 //   p_new = z + beta p_old;  q = A p_new;  parts_pq[wg] = sum p_new . q
@@ -411,6 +472,18 @@ __global__ __launch_bounds__(kBlock) void k_sum_parts(const double* parts,
   __shared__ double sm[4];
   const double s = reduce_parts(parts + (int64_t)blockIdx.x * stride, n, sm);
   if (threadIdx.x == 0) slot[blockIdx.x] = s;
+}
+
+// z = x with the subfield BC values inserted (copy + VecSetValues fused):
+// slot[i] = position in val[] of row i's BC value, or -1
+__global__ __launch_bounds__(kBlock) void k_copy_bc(
+    int n, const double* x, const int* __restrict__ slot,
+    const double* __restrict__ val, double* z) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += gridDim.x * kBlock) {
+    const int m = slot[i];
+    z[i] = m >= 0 ? val[m] : x[i];
+  }
 }
 
 // SubfieldBC::apply: x[idx[i]] = val[i]  (VecSetValues INSERT)
