@@ -27,24 +27,30 @@ p.add_argument("--ls", default="mg", choices=["mg", "jacobi"],
                help="inner solvers: multigrid V-cycles (counterpart of the "
                     "reference's 'iterative' AMG setting) or plain "
                     "Jacobi-CG / Chebyshev-Jacobi")
+p.add_argument("--stabilize", action="store_true",
+               help="SUPG-stabilised 00-block in the preconditioner matrix "
+                    "(the reference's J_pc for --ls iterative)")
+p.add_argument("--cycles", type=int, default=1)
 p.add_argument("--a00-its", type=int, default=60)
 p.add_argument("--a00-ratio", type=float, default=0.01)
 args = p.parse_args()
 
 if args.geometry == "lshape":
     pb = BackwardStep(args.level, nu=args.viscosity or 0.02,
-                      variant=args.pcd_variant, nls=args.nls)
+                      variant=args.pcd_variant, nls=args.nls,
+                      stabilize=args.stabilize)
     print("Reynolds number: Re = %g" % (2.0 / pb.nu))
 else:
     pb = Cavity(args.level, nu=args.viscosity or 0.01,
-                variant=args.pcd_variant, nls=args.nls)
+                variant=args.pcd_variant, nls=args.nls,
+                stabilize=args.stabilize)
     print("Reynolds number: Re = %g" % (1.0 / pb.nu))
 print("Dimension of the function space: %d" % pb.space.ndof)
 if args.ls == "mg":
-    multigrid_inner_options()
+    multigrid_inner_options(cycles_u=args.cycles, cycles_p=args.cycles)
 else:
     default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio)
-out = solve_steady(pb)
+out = solve_steady(pb, max_newton=40)
 print("Newton iterations: %d, converged: %s" % (out["newton_its"],
                                                 out["converged"]))
 print("GMRES iterations per Newton step:", out["krylov_per_step"])

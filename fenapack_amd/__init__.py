@@ -16,8 +16,10 @@ from fenapack_amd.nonlinear_solvers import (PCDNewtonSolver,
                                             PCDNonlinearProblem)
 from fenapack_amd.preconditioners import (PCDPC_BRM1, PCDPC_BRM2,
                                           PCDRPC_BRM1, PCDRPC_BRM2)
+from fenapack_amd.stabilization import StabilizationParameterSD
 from fenapack_amd.petsc import PETScOptions
 
 __all__ = ["PCDKSP", "PCDKrylovSolver", "PCDAssembler", "PCDForm",
            "PCDNewtonSolver", "PCDNonlinearProblem", "PCDPC_BRM1",
-           "PCDPC_BRM2", "PCDRPC_BRM1", "PCDRPC_BRM2", "PETScOptions"]
+           "PCDPC_BRM2", "PCDRPC_BRM1", "PCDRPC_BRM2", "StabilizationParameterSD",
+           "PETScOptions"]

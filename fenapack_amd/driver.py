@@ -80,6 +80,7 @@ def make_solver(problem, prefix="", gmres_rtol=1e-6, restart=150,
 def solve_steady(problem, **kw):
     """Run the steady demo; returns a stats dict (M2 = GMRES its/Newton step)."""
     w, nls, nlp = make_solver(problem, **kw)
+    nls.parameters["error_on_nonconvergence"] = False
     t0 = time.time()
     its, converged = nls.solve(nlp, w.vector(), on_update=w.touch)
     return {"w": w, "newton_its": its, "converged": converged,
@@ -94,7 +95,7 @@ def solve_unsteady(problem, dt, t_end, **kw):
     w, nls, nlp = make_solver(problem, **kw)
     V = problem.space
     t, steps, krylov, newton = 0.0, 0, 0, 0
-    per_step = []
+    per_step, newton_per_step, residuals = [], [], []
     t0 = time.time()
     while t < t_end - 0.1 * dt:
         t += dt
@@ -105,8 +106,11 @@ def solve_unsteady(problem, dt, t_end, **kw):
         krylov += nls.krylov_iterations()
         newton += n_it
         per_step.append(nls.krylov_iterations())
+        newton_per_step.append(list(nls.krylov_history))
+        residuals.append(list(nls.residual_history))
         problem.u0 = w.split()[0].copy()        # w0.assign(w)
         w.touch()
     return {"w": w, "steps": steps, "krylov_its": krylov,
             "krylov_per_step": per_step, "newton_its": newton,
+            "krylov_per_newton": newton_per_step, "residuals": residuals,
             "time": time.time() - t0, "ndof": V.ndof}

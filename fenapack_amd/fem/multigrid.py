@@ -129,5 +129,17 @@ def dense_csr(C):
 
 
 def coarse_inverse(A0):
-    """Explicit (pseudo-)inverse of the coarsest operator."""
-    return dense_csr(np.linalg.pinv(A0.toarray(), rcond=1e-12))
+    """Explicit inverse of the coarsest operator (LU); a pseudo-inverse when
+    the operator is singular (enclosed-flow ``R_p``: constants in the
+    kernel)."""
+    D = A0.toarray()
+    try:
+        C = np.linalg.inv(D)
+        probe = np.ones(D.shape[0]) / np.sqrt(D.shape[0])
+        ok = np.all(np.isfinite(C)) and \
+            np.linalg.norm(D @ (C @ probe) - probe) < 1e-8
+    except np.linalg.LinAlgError:
+        ok = False
+    if not ok:
+        C = np.linalg.pinv(D, rcond=1e-12)
+    return dense_csr(C)

@@ -47,11 +47,13 @@ class _Dirichlet(object):
             self._cache[key] = (kill, diag)
         return self._cache[key]
 
-    def square(self, M):
-        """Zero bc rows and columns, unit diagonal (pattern preserved)."""
+    def square(self, M, diag_values=None):
+        """Zero bc rows and columns, unit diagonal (pattern preserved);
+        ``diag_values`` (per dof) replaces the unit diagonal."""
         kill, diag = self._masks(M, True, True, "sq")
         data = np.where(kill, 0.0, M.data)
-        data[diag] = 1.0
+        data[diag] = 1.0 if diag_values is None else \
+            diag_values[M.indices[diag]]
         return sp.csr_matrix((data, M.indices, M.indptr), shape=M.shape)
 
     def rows(self, M):
@@ -69,7 +71,7 @@ class FlowProblem(object):
     """Common machinery; subclasses define geometry and boundary data."""
 
     def __init__(self, hierarchy, nu, variant="BRM1", nls="picard", dt=None,
-                 pcdr=False, stabilize=False):
+                 pcdr=False, stabilize=False, dirichlet_diag="unit"):
         assert variant in ("BRM1", "BRM2")
         assert nls in ("picard", "newton")
         self.hierarchy = hierarchy
@@ -81,6 +83,15 @@ class FlowProblem(object):
         self.pcdr = pcdr
         self.stabilize = stabilize
         self.t = 0.0
+        # [ext DOLFIN] SystemAssembler writes 1 on the diagonal of a Dirichlet
+        # row once per cell tensor, so the assembled diagonal (and the
+        # right-hand side entry) of such a row is the number of cells sharing
+        # the dof.  "multiplicity" reproduces that scaling (it changes the
+        # residual norms the nonlinear stopping test sees, not the solution).
+        assert dirichlet_diag in ("unit", "multiplicity")
+        mult = np.bincount(V.cell_dofs2.ravel(), minlength=V.nn).astype(float)
+        self._bc_mult = np.repeat(mult, 2) if dirichlet_diag == "multiplicity" \
+            else np.ones(V.n_u)
         self._classify_boundary()
         self.bc_u = _Dirichlet(V.n_u, self.bc_u_idx)
         self.bc_p = _Dirichlet(V.n_p, self.bc_p_idx)
@@ -153,14 +164,14 @@ class FlowProblem(object):
         d[self.bc_u_idx] = xu[self.bc_u_idx] - g
         Fu = Fu - A00 @ d
         Fp = Fp - self._A10_raw @ d
-        Fu[self.bc_u_idx] = d[self.bc_u_idx]
-        out = {"A00": self.bc_u.square(A00), "A01": self.A01,
+        Fu[self.bc_u_idx] = self._bc_mult[self.bc_u_idx] * d[self.bc_u_idx]
+        out = {"A00": self.bc_u.square(A00, self._bc_mult), "A01": self.A01,
                "A10": self.A10, "bu": Fu, "bp": Fp}
         if self.stabilize:
             delta = V.supg_delta(U, self.nu)
             P00 = V.assemble_A00(self.nu, U, idt=self.idt,
                                  newton=(self.nls == "newton"), delta=delta)
-            out["P00"] = self.bc_u.square(P00)
+            out["P00"] = self.bc_u.square(P00, self._bc_mult)
         return out
 
     def initial_guess(self):

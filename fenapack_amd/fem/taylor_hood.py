@@ -370,9 +370,15 @@ class TaylorHood(object):
             r2, c2 = rc(A10, ip, iu)
             rows = np.concatenate([r0, r1, r2, ip])
             cols = np.concatenate([c0, c1, c2, ip])
-            setattr(self, key, FixedPattern(rows, cols,
-                                            (self.ndof, self.ndof)))
+            pat = FixedPattern(rows, cols, (self.ndof, self.ndof))
+            # every (row, col) of the blocks is unique: assembly is a pure
+            # permutation, so keep its inverse and gather instead of summing
+            assert pat.nnz == rows.size
+            order = np.empty(pat.nnz, dtype=np.int64)
+            order[pat.inv] = np.arange(pat.nnz)
+            pat.order = order
+            setattr(self, key, pat)
         pat = getattr(self, key)
         vals = np.concatenate([A00.data, A01.data, A10.data,
                                np.zeros(self.n_p)])
-        return pat.assemble(vals)
+        return pat.matrix(vals[pat.order])

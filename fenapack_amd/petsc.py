@@ -442,7 +442,10 @@ class KSP(object):
         if self.cheb_eigs is not None:
             return self.cheb_eigs
         A = self._ops[1].A
-        emax = estimate_emax(A, jacobi=(self.pc.type == "jacobi"))
+        if not hasattr(self, "_cheb_warm"):
+            self._cheb_warm = {}
+        emax = estimate_emax(A, jacobi=(self.pc.type == "jacobi"),
+                             warm=self._cheb_warm)
         a, b, cc, d = self.cheb_esteig
         return (b * emax, d * emax)        # emin estimate taken as 0
 
@@ -470,8 +473,11 @@ class KSP(object):
         ops = galerkin_chain(self._ops[1].A, chain)
         a, b, cc, d = pc.mg_esteig
         bounds = [None]
+        if not hasattr(pc, "_mg_warm"):
+            pc._mg_warm = {}
         for l in range(1, len(ops)):
-            emax = estimate_emax(ops[l], iters=12)
+            emax = estimate_emax(ops[l], iters=12,
+                                 warm=pc._mg_warm.setdefault(l, {}))
             bounds.append((b * emax, d * emax))
         C = coarse_inverse(ops[0])
         eng, slot, L = self.engine, self.slot, len(ops)
@@ -525,20 +531,28 @@ class KSP(object):
         self.engine.inner_solve(self.slot, b.t, x.t, c.MEM_DEVICE)
 
 
-def estimate_emax(A, jacobi=True, iters=20, seed=0):
+def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None):
     """Largest eigenvalue (modulus) of ``D^-1 A`` by power iteration on the
-    host - the stand-in for PETSc's ``-ksp_chebyshev_esteig`` [ext PETSc]."""
+    host - the stand-in for PETSc's ``-ksp_chebyshev_esteig`` [ext PETSc].
+    ``warm``: a dict that carries the iterate between calls (re-estimation
+    after a value refresh then needs only a few steps)."""
     A = sp.csr_matrix(A)
     d = A.diagonal().copy()
     d[d == 0.0] = 1.0
     dinv = 1.0 / d if jacobi else np.ones_like(d)
-    v = np.random.default_rng(seed).standard_normal(A.shape[0])
+    v = None if warm is None else warm.get("v")
+    if v is None or v.size != A.shape[0]:
+        v = np.random.default_rng(seed).standard_normal(A.shape[0])
+    else:
+        iters = max(3, iters // 4)
     lam = 1.0
     for _ in range(iters):
-        v /= np.linalg.norm(v)
+        v = v / np.linalg.norm(v)
         w = dinv * (A @ v)
         lam = np.linalg.norm(w)
         v = w
+    if warm is not None:
+        warm["v"] = v
     return float(lam)
 
 
