@@ -50,7 +50,7 @@ if args.ls == "mg":
     multigrid_inner_options(cycles_u=args.cycles, cycles_p=args.cycles)
 else:
     default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio)
-out = solve_steady(pb, max_newton=40)
+out = solve_steady(pb, max_newton=25)
 print("Newton iterations: %d, converged: %s" % (out["newton_its"],
                                                 out["converged"]))
 print("GMRES iterations per Newton step:", out["krylov_per_step"])

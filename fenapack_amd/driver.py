@@ -66,6 +66,7 @@ def make_solver(problem, prefix="", gmres_rtol=1e-6, restart=150,
     if prefix:
         linear_solver.set_options_prefix(prefix)
     linear_solver.parameters["relative_tolerance"] = gmres_rtol
+    linear_solver.parameters["maximum_iterations"] = 600
     PETScOptions.set(prefix + "ksp_gmres_restart", restart)
     cls = ("PCDRPC_" if problem.pcdr else "PCDPC_") + problem.variant
     PETScOptions.set(prefix + "fieldsplit_p_pc_python_type",
