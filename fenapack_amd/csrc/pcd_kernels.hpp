@@ -439,6 +439,149 @@ __global__ __launch_bounds__(kBlock) void k_cg_spmv_s(
   if (threadIdx.x == 0) parts_pq[blockIdx.x] = acc;
 }
 
+// ==========================================================================
+// Two-component (Kronecker) operators: A = F (x) I_2 on interleaved dofs
+// (2*node + component).  Picard velocity blocks, their Galerkin coarse levels
+// and the velocity prolongations have this structure: both components of a
+// node see the same scalar stencil.  The engine then streams F ONCE (half the
+// matrix bytes) and carries both components as double2: 16-byte gathers and
+// coalesced 16-byte vector traffic.  Same three phases as the stream kernels.
+// ==========================================================================
+constexpr int kTile2 = 2048;      // LDS double2 per workgroup (32 KiB)
+
+struct XVec2 {
+  const double2* x; const double2* ghost; int nloc;      // in node units
+  __device__ __forceinline__ double2 operator()(int c) const {
+    return c < nloc ? x[c] : ghost[c - nloc];
+  }
+};
+struct XScaled2 {
+  const double2* b; const double2* dinv; double s;
+  __device__ __forceinline__ double2 operator()(int c) const {
+    const double2 d = dinv[c], v = b[c];
+    return make_double2(s * d.x * v.x, s * d.y * v.y);
+  }
+};
+
+template <int RB, class XF>
+__device__ __forceinline__ double2 stream_row_block2(
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const XF& xf, int r0, int nrows,
+    double2* lds) {
+  const int r1 = min(r0 + RB, nrows);
+  const int k0 = rowptr[r0], k1 = rowptr[r1];
+  int k = k0 + threadIdx.x;
+  for (; k + 3 * kBlock < k1; k += 4 * kBlock) {
+    const int c0 = col[k], c1 = col[k + kBlock], c2 = col[k + 2 * kBlock],
+              c3 = col[k + 3 * kBlock];
+    const double v0 = val[k], v1 = val[k + kBlock], v2 = val[k + 2 * kBlock],
+                 v3 = val[k + 3 * kBlock];
+    const double2 x0 = xf(c0), x1 = xf(c1), x2 = xf(c2), x3 = xf(c3);
+    lds[k - k0] = make_double2(v0 * x0.x, v0 * x0.y);
+    lds[k - k0 + kBlock] = make_double2(v1 * x1.x, v1 * x1.y);
+    lds[k - k0 + 2 * kBlock] = make_double2(v2 * x2.x, v2 * x2.y);
+    lds[k - k0 + 3 * kBlock] = make_double2(v3 * x3.x, v3 * x3.y);
+  }
+  for (; k < k1; k += kBlock) {
+    const double v = val[k];
+    const double2 xv = xf(col[k]);
+    lds[k - k0] = make_double2(v * xv.x, v * xv.y);
+  }
+  __syncthreads();
+  double2 s = make_double2(0.0, 0.0);
+  const int row = r0 + threadIdx.x;
+  if (threadIdx.x < RB && row < r1) {
+    const int a = rowptr[row] - k0, b = rowptr[row + 1] - k0;
+    for (int j = a; j < b; ++j) { const double2 t = lds[j]; s.x += t.x; s.y += t.y; }
+  }
+  return s;
+}
+
+template <int RB, int MODE>
+__global__ __launch_bounds__(kBlock) void k_spmv_s2(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const XVec2 xf, const double2* add,
+    double2* y) {
+  __shared__ double2 lds[kTile2];
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, rb0, rb1);
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const double2 s = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const int row = r0 + threadIdx.x;
+    if (threadIdx.x < RB && row < nrows) {
+      if (MODE == 0) y[row] = s;
+      if (MODE == 1) { const double2 a = add[row]; y[row] = make_double2(a.x + s.x, a.y + s.y); }
+      if (MODE == 2) { const double2 a = add[row]; y[row] = make_double2(a.x - s.x, a.y - s.y); }
+    }
+    __syncthreads();
+  }
+}
+
+template <int RB>
+__global__ __launch_bounds__(kBlock) void k_cheb_step_s2(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double2* __restrict__ dinv,
+    const double2* b, const double2* pm, const double2* pk, double2* pn,
+    double c0, double c1, double c2, const double2* ghost, int nloc) {
+  __shared__ double2 lds[kTile2];
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, rb0, rb1);
+  const XVec2 xf{pk, ghost, nloc};
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const double2 s = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const int row = r0 + threadIdx.x;
+    if (threadIdx.x < RB && row < nrows) {
+      const double2 bi = b[row], d = dinv[row], xk = pk[row];
+      double2 out = make_double2(c1 * xk.x + c2 * d.x * (bi.x - s.x),
+                                 c1 * xk.y + c2 * d.y * (bi.y - s.y));
+      if (c0 != 0.0) { const double2 xm = pm[row]; out.x += c0 * xm.x; out.y += c0 * xm.y; }
+      pn[row] = out;
+    }
+    __syncthreads();
+  }
+}
+
+template <int RB>
+__global__ __launch_bounds__(kBlock) void k_cheb_first_s2(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double2* __restrict__ dinv,
+    const double2* b, double2* p0, double2* pn, double s, double c1, double c2) {
+  __shared__ double2 lds[kTile2];
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, rb0, rb1);
+  const XScaled2 xf{b, dinv, s};
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const double2 sum = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const int row = r0 + threadIdx.x;
+    if (threadIdx.x < RB && row < nrows) {
+      const double2 d = dinv[row], bi = b[row];
+      const double2 x0 = make_double2(s * d.x * bi.x, s * d.y * bi.y);
+      if (p0) p0[row] = x0;
+      pn[row] = make_double2(c1 * x0.x + c2 * d.x * (bi.x - sum.x),
+                             c1 * x0.y + c2 * d.y * (bi.y - sum.y));
+    }
+    __syncthreads();
+  }
+}
+
+// val2[k] = val[pos_even[k]]; *mismatch |= (val[pos_even[k]] != val[pos_odd[k]])
+__global__ __launch_bounds__(kBlock) void k_kron_gather(
+    int nnz2, const int* __restrict__ pos_even, const int* __restrict__ pos_odd,
+    const double* val, double* val2, int* mismatch) {
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < nnz2;
+       k += gridDim.x * kBlock) {
+    const double a = val[pos_even[k]], b = val[pos_odd[k]];
+    val2[k] = a;
+    if (a != b) *mismatch = 1;
+  }
+}
+
 // ---- BLAS-1 glue of the apply bodies --------------------------------------
 __global__ __launch_bounds__(kBlock) void k_copy(int n, const double* x,
                                                   double* y) {

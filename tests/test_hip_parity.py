@@ -310,3 +310,39 @@ def test_graph_replay_is_bitwise_equal_to_eager_launches(hip_lib):
     e.graph_enable(True)
     xb, ib, _ = e.gmres_np(st["b"], rtol=1e-8, restart=60, max_it=200)
     assert ia == ib and np.array_equal(xa, xb)
+
+
+def test_two_component_fast_path_and_its_fallback(hip_lib):
+    """A00 = F (x) I_2 (Picard) takes the double2 kernels; the same pattern
+    with component-dependent values, and a Newton (coupled) block, must take
+    the general kernels - all three against the oracle."""
+    from fenapack_amd.fem import BackwardStep
+    st = flow_state("lshape", 4)
+    V, A00 = st["V"], st["L"]["A00"]
+    rng = np.random.default_rng(14)
+    x = rng.standard_normal(V.n_u)
+    skew = A00.copy()
+    rows = np.repeat(np.arange(V.n_u), np.diff(A00.indptr))
+    skew.data = np.where(rows % 2 == 1, 2.0 * A00.data, A00.data)
+    pbn = BackwardStep(3, nls="newton")
+    xun = 0.1 * rng.standard_normal(pbn.space.n_u)
+    newton = pbn.linearise(xun, np.zeros(pbn.space.n_p))["A00"]
+    for M, xx in ((A00, x), (skew, x),
+                  (newton, rng.standard_normal(pbn.space.n_u))):
+        e, o = hip_engine(hip_lib, "BRM1"), oracle.Engine("BRM1")
+        for eng in (e, o):
+            eng.set_csr(c.MAT_A00, M)
+            eng.set_inner(c.KSP_A00, "chebyshev", "jacobi", 6, 0.0, 0.1, 2.2)
+        assert relerr(e.spmv_np(c.MAT_A00, xx, M.shape[0]),
+                      o.spmv_np(c.MAT_A00, xx, M.shape[0])) < 1e-13
+        assert relerr(e.inner_solve_np(c.KSP_A00, xx),
+                      o.inner_solve_np(c.KSP_A00, xx)) < 1e-11
+        # values that break the structure later must be noticed too
+        e.update_values(c.MAT_A00, np.where(
+            np.repeat(np.arange(M.shape[0]), np.diff(M.indptr)) % 2 == 1,
+            3.0 * M.data, M.data))
+        o.update_values(c.MAT_A00, np.where(
+            np.repeat(np.arange(M.shape[0]), np.diff(M.indptr)) % 2 == 1,
+            3.0 * M.data, M.data))
+        assert relerr(e.spmv_np(c.MAT_A00, xx, M.shape[0]),
+                      o.spmv_np(c.MAT_A00, xx, M.shape[0])) < 1e-13
