@@ -137,7 +137,9 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
     m_hi, m_lo = 65, 1
-    t_kernel = (time_a00(m_hi) - time_a00(m_lo)) / (m_hi - m_lo)
+    # best of three: a co-tenant hiccup must not pass for kernel time
+    t_kernel = min((time_a00(m_hi) - time_a00(m_lo)) / (m_hi - m_lo)
+                   for _ in range(3))
     if args.inner == "mg":                     # restore the bench settings
         eng.set_inner(c.KSP_A00, "richardson", "mg", args.cycles_u, 0.0)
     else:
@@ -233,7 +235,8 @@ def main():
         "algorithmic_bytes_per_pcapply": int(bytes_pc),
         "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
         "roofline": {
-            "bound": "hbm", "kernel": "k_cheb_step_s (finest A00)",
+            "bound": "hbm",
+            "kernel": "k_cheb_step_s2 / k_cheb_step_s (finest A00)",
             "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / rf.HBM_PEAK_GBS,
             "bytes_per_launch": int(b_kernel),
@@ -257,10 +260,12 @@ def pmc_traffic(n_u, nnz_a00, world):
     a kernel of known byte count: profiles/r01_pmc_cheb_step_level6.json).
     PMC cannot be collected inside this process; null unless the committed
     measurement is for exactly this operator."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_cheb_step_level6.json")
+    name = "r01_pmc_cheb_step_level6.json" \
+        if os.environ.get("PCD_NO_KRON2") == "1" \
+        else "r01_pmc_cheb_step_kron2_level6.json"
     try:
-        d = json.load(open(path))
-        k = d["k_cheb_step_s<256>"]
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        k = d.get("k_cheb_step_s<256>", d)
         if world == 1 and k["algorithmic_bytes_per_launch"] == \
                 12 * nnz_a00 + 92 * n_u + 4:
             return k["traffic_bytes_per_launch"]

@@ -295,12 +295,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv_s(
   row_block_range(nrb, rb0, rb1);
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
     const int row = r0 + threadIdx.x;
-    if (threadIdx.x < RB && row < nrows) {
+    const bool mine = threadIdx.x < RB && row < nrows;
+    double a = 0.0;
+    if (MODE != 0 && mine) a = add[row];          // early: hides under phase 1
+    const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    if (mine) {
       if (MODE == 0) y[row] = s;
-      if (MODE == 1) y[row] = add[row] + s;
-      if (MODE == 2) y[row] = add[row] - s;
+      if (MODE == 1) y[row] = a + s;
+      if (MODE == 2) y[row] = a - s;
     }
     __syncthreads();
   }
@@ -319,15 +322,17 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_s(
   const XVec xf{pk, ghost, nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
     const int row = r0 + threadIdx.x;
-    if (threadIdx.x < RB && row < nrows) {
-      double z = b[row] - s;
-      if (dinv) z *= dinv[row];
-      double out = c1 * pk[row] + c2 * z;
-      if (c0 != 0.0) out += c0 * pm[row];
-      pn[row] = out;
+    const bool mine = threadIdx.x < RB && row < nrows;
+    // epilogue operands first: their latency hides under the streaming phase
+    double bi = 0.0, d = 1.0, xk = 0.0, xm = 0.0;
+    if (mine) {
+      bi = b[row]; xk = pk[row];
+      if (dinv) d = dinv[row];
+      if (c0 != 0.0) xm = pm[row];
     }
+    const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    if (mine) pn[row] = c0 * xm + c1 * xk + c2 * (d * (bi - s));
     __syncthreads();
   }
 }
@@ -508,12 +513,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv_s2(
   row_block_range(nrb, rb0, rb1);
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const double2 s = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
     const int row = r0 + threadIdx.x;
-    if (threadIdx.x < RB && row < nrows) {
+    const bool mine = threadIdx.x < RB && row < nrows;
+    double2 a = make_double2(0.0, 0.0);
+    if (MODE != 0 && mine) a = add[row];          // early: hides under phase 1
+    const double2 s = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    if (mine) {
       if (MODE == 0) y[row] = s;
-      if (MODE == 1) { const double2 a = add[row]; y[row] = make_double2(a.x + s.x, a.y + s.y); }
-      if (MODE == 2) { const double2 a = add[row]; y[row] = make_double2(a.x - s.x, a.y - s.y); }
+      if (MODE == 1) y[row] = make_double2(a.x + s.x, a.y + s.y);
+      if (MODE == 2) y[row] = make_double2(a.x - s.x, a.y - s.y);
     }
     __syncthreads();
   }
@@ -532,15 +540,19 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_s2(
   const XVec2 xf{pk, ghost, nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const double2 s = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
     const int row = r0 + threadIdx.x;
-    if (threadIdx.x < RB && row < nrows) {
-      const double2 bi = b[row], d = dinv[row], xk = pk[row];
-      double2 out = make_double2(c1 * xk.x + c2 * d.x * (bi.x - s.x),
-                                 c1 * xk.y + c2 * d.y * (bi.y - s.y));
-      if (c0 != 0.0) { const double2 xm = pm[row]; out.x += c0 * xm.x; out.y += c0 * xm.y; }
-      pn[row] = out;
+    const bool mine = threadIdx.x < RB && row < nrows;
+    // the epilogue operands do not depend on the row sums: issue their loads
+    // first so that their latency hides under the streaming phase
+    double2 bi = make_double2(0.0, 0.0), d = bi, xk = bi, xm = bi;
+    if (mine) {
+      bi = b[row]; d = dinv[row]; xk = pk[row];
+      if (c0 != 0.0) xm = pm[row];
     }
+    const double2 s = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    if (mine)
+      pn[row] = make_double2(c0 * xm.x + c1 * xk.x + c2 * d.x * (bi.x - s.x),
+                             c0 * xm.y + c1 * xk.y + c2 * d.y * (bi.y - s.y));
     __syncthreads();
   }
 }
