@@ -1792,7 +1792,10 @@ static int comm_attach(Engine* h, CommBackend* c, int rank, int nranks) {
 int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(PCD_ERR_ARG, "comm_init: bad rank/size/id");
-  if (nranks == 1) return 0;                      // nothing to partition
+  // one rank: nothing to partition - unless PCD_FORCE_COMM=1 asks for the
+  // communicator anyway (single-rank RCCL smoke test of the multi-rank code)
+  { const char* e = getenv("PCD_FORCE_COMM");
+    if (nranks == 1 && !(e && e[0] == '1')) return 0; }
   HIPCHK(hipSetDevice(h->device));
   std::string err;
   if (!rccl_api().load(err)) return fail(PCD_ERR_COMM, "%s", err.c_str());

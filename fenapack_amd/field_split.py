@@ -80,7 +80,10 @@ class PCDKSP(KSP):
 
         # the engine: one handle = PCD context + fieldsplit shell + GMRES
         self.engine = c.Engine(c.hip_library(), pcd_pc.variant, self.device)
-        if self.comm is not None and getattr(self.comm, "size", 1) > 1:
+        import os
+        forced = os.environ.get("PCD_FORCE_COMM") == "1"   # 1-rank RCCL test
+        if self.comm is not None and (getattr(self.comm, "size", 1) > 1
+                                      or (forced and self.comm.unique_id())):
             # one process per GPU: rows are partitioned inside the engine,
             # RCCL carries the halos and the dot-product all-reduces
             self.engine.comm_init(self.comm.rank, self.comm.size,

@@ -25,6 +25,9 @@ class Comm(object):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) \
                 or dist.get_world_size() == 1:
+            if os.environ.get("PCD_FORCE_COMM") == "1":
+                from . import _cabi
+                return cls(0, 1, _cabi.comm_unique_id())
             return cls(0, 1, None)
         from . import _cabi
         rank, size = dist.get_rank(), dist.get_world_size()

@@ -108,3 +108,30 @@ def test_gmres_with_multigrid_partitioned(hip_lib):
         assert relerr(x, xr) < 1e-7
         assert relerr(y, yr) < 1e-11
     assert relerr(st["A"] @ outs[0][0], st["b"]) < 1e-6
+
+
+def test_rccl_backend_single_rank_smoke(hip_lib, monkeypatch):
+    """The RCCL backend itself (dlopen, unique id, ncclCommInitRank,
+    ncclAllReduce on the engine's stream) with a ONE-rank communicator: the
+    multi-rank code path (localised operators, slot reductions, global-vector
+    staging) must reproduce the plain single-GPU results."""
+    monkeypatch.setenv("PCD_FORCE_COMM", "1")
+    st = flow_state("cavity", 3)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    I = pb.interpolations()
+
+    def run(e):
+        configure_engine(e, st)
+        push_multigrid(e, c.KSP_A00, L["A00"], I.chain("u"))
+        e.set_inner(c.KSP_AP, "cg", "jacobi", 2000, 1e-10)
+        e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+        e.setup()
+        return e.gmres_np(st["b"], rtol=1e-8, restart=60, max_it=200)
+
+    e = c.Engine(hip_lib, "BRM1", 0)
+    e.comm_init(0, 1, c.comm_unique_id())
+    x1, its1, _ = run(e)
+    monkeypatch.delenv("PCD_FORCE_COMM")
+    x0, its0, _ = run(c.Engine(hip_lib, "BRM1", 0))
+    assert its1 == its0
+    assert relerr(x1, x0) < 1e-9
