@@ -137,9 +137,11 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
     m_hi, m_lo = 65, 1
-    # best of three: a co-tenant hiccup must not pass for kernel time
-    t_kernel = min((time_a00(m_hi) - time_a00(m_lo)) / (m_hi - m_lo)
-                   for _ in range(3))
+    # best of three for each loop length separately: a co-tenant hiccup must
+    # not pass for (or cancel) kernel time
+    t_hi = min(time_a00(m_hi) for _ in range(3))
+    t_lo = min(time_a00(m_lo) for _ in range(3))
+    t_kernel = (t_hi - t_lo) / (m_hi - m_lo)
     if args.inner == "mg":                     # restore the bench settings
         eng.set_inner(c.KSP_A00, "richardson", "mg", args.cycles_u, 0.0)
     else:
