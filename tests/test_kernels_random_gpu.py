@@ -1,0 +1,97 @@
+"""GPU suite, part 5: the SpMV / smoother / CG kernels on adversarial CSR
+shapes a caller could hand over - ragged and empty rows, sizes around the
+wave (64) and workgroup (256) widths, rows longer than the LDS tile, dense
+blocks, rectangular operators, two-component (F x I_2) structure and its
+near misses - always against scipy / the oracle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from fenapack_amd import _cabi as c
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_csr(rng, n, m, avg, long_rows=0, empty_frac=0.1):
+    rows, cols = [], []
+    for i in range(n):
+        if rng.random() < empty_frac:
+            continue
+        k = min(m, max(1, rng.poisson(avg)))
+        if long_rows and i % max(n // long_rows, 1) == 0:
+            k = min(m, 6000)
+        cc = rng.choice(m, size=k, replace=False)
+        rows += [i] * k
+        cols += list(cc)
+    A = sp.csr_matrix((rng.standard_normal(len(rows)), (rows, cols)),
+                      shape=(n, m))
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("n,m,avg,long_rows", [
+    (1, 1, 1, 0), (63, 63, 5, 0), (64, 65, 9, 0), (255, 257, 12, 0),
+    (1000, 777, 30, 0), (5000, 5000, 7, 0), (7001, 7001, 20, 3),
+    (300, 9000, 400, 0), (4097, 4097, 2, 0)])
+def test_spmv_random_shapes(hip_lib, n, m, avg, long_rows):
+    rng = np.random.default_rng(n * 7 + m)
+    A = _random_csr(rng, n, m, avg, long_rows)
+    e = c.Engine(hip_lib, "BRM1", 0)
+    # A01 is the only rectangular slot; square ones go through Kp as well
+    e.set_csr(c.MAT_A01, A)
+    x = rng.standard_normal(m)
+    ref = A @ x
+    assert relerr(e.spmv_np(c.MAT_A01, x, n), ref) < 1e-13
+    if n == m:
+        e.set_csr(c.MAT_KP, A)
+        assert relerr(e.spmv_np(c.MAT_KP, x, n), ref) < 1e-13
+
+
+@pytest.mark.parametrize("nodes,mnodes", [(1, 1), (33, 33), (500, 321),
+                                          (4000, 4000)])
+def test_two_component_operators_and_near_misses(hip_lib, nodes, mnodes):
+    rng = np.random.default_rng(nodes)
+    F = _random_csr(rng, nodes, mnodes, 9, empty_frac=0.0)
+    K = sp.kron(F, sp.identity(2), format="csr")
+    K.sort_indices()
+    x = rng.standard_normal(2 * mnodes)
+    variants = [K]
+    # near misses: one value differs / one entry removed / odd size
+    K2 = K.copy()
+    K2.data[K2.nnz // 2] *= 1.5
+    variants.append(K2)
+    K3 = K.tolil()
+    r = int(K.nonzero()[0][0])
+    cidx = int(K.nonzero()[1][0])
+    K3[r, cidx] = 0.0
+    K3 = K3.tocsr()
+    K3.eliminate_zeros()
+    K3.sort_indices()
+    variants.append(K3)
+    for M in variants:
+        e = c.Engine(hip_lib, "BRM1", 0)
+        e.set_csr(c.MAT_A01, M)
+        assert relerr(e.spmv_np(c.MAT_A01, x, M.shape[0]), M @ x) < 1e-13
+
+
+@pytest.mark.parametrize("n", [1, 64, 257, 3000])
+def test_smoother_and_cg_on_random_spd(hip_lib, n):
+    rng = np.random.default_rng(n)
+    B = _random_csr(rng, n, n, 6, empty_frac=0.0)
+    A = (B @ B.T + sp.identity(n) * (1.0 + abs(B).sum(axis=1).max())).tocsr()
+    A.sort_indices()
+    b = rng.standard_normal(n)
+    e, o = c.Engine(hip_lib, "BRM1", 0), oracle.Engine("BRM1")
+    for eng in (e, o):
+        eng.set_csr(c.MAT_AP, A)
+    for cfg in (("chebyshev", "jacobi", 7, 0.0, 0.3, 1.8),
+                ("chebyshev", "none", 4, 0.0, 0.5, 3.0),
+                ("richardson", "jacobi", 5, 0.0),
+                ("cg", "jacobi", 9, 0.0), ("cg", "none", 200, 1e-9)):
+        e.set_inner(c.KSP_AP, *cfg)
+        o.set_inner(c.KSP_AP, *cfg)
+        tol = 1e-7 if cfg[3] else 1e-10
+        assert relerr(e.inner_solve_np(c.KSP_AP, b),
+                      o.inner_solve_np(c.KSP_AP, b)) < tol, cfg
