@@ -86,6 +86,7 @@ struct DCsr {
   // multi-GPU: nrows / ncols are LOCAL counts (ncols = owned columns); ghost
   // columns are numbered ncols .. ncols + nghost and live in `ghost`
   HaloPlan plan;
+  bool replicated = false;   // multi-GPU: whole operator on every rank, no halo
   int64_t gnnz = 0;       // nonzeros of the GLOBAL matrix (value updates)
   DBuf<double> ghost, sendbuf;
   DBuf<int> send_idx;
@@ -94,7 +95,7 @@ struct DCsr {
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); pos_even.release(); pos_odd.release();
     val2.release(); kron_flag.release(); kron2 = false; rb2 = 0; nnz2 = 0;
-    plan = HaloPlan();
+    plan = HaloPlan(); replicated = false;
     set = false; nrows = ncols = nnz = 0; has_src = false;
   }
 };
@@ -104,6 +105,12 @@ struct MgLevel {
   DCsr A;                 // operator; level 0: explicit inverse; finest: unused
   DCsr P, R;              // prolongation level-1 -> level and its transpose
   double emin = 0.0, emax = 0.0;
+  // multi-GPU: small levels are computed redundantly by every rank
+  // (replicated); `transition` marks the finest replicated level's parent,
+  // whose restriction ends in one all-reduce and whose prolongation reads the
+  // full coarse vector - no halo on any coarse kernel
+  bool replicated = false, transition = false;
+  int64_t n_coarse = 0;
   DBuf<double> x, t0, t1, r, b;
   void release() {
     A.release(); P.release(); R.release();
@@ -262,7 +269,7 @@ static inline XVec xvec(const DCsr& A, const double* x) {
 // entries other ranks read, grouped send/recv into the ghost buffer.  Every
 // rank calls it for every SpMV (the threaded test backend synchronises there).
 static int halo_exchange(Engine* h, const DCsr& A, const double* x) {
-  if (!h->comm) return 0;
+  if (!h->comm || A.replicated) return 0;
   const HaloPlan& pl = A.plan;
   const int ns = (int)pl.send_idx.size();
   if (ns)
@@ -695,6 +702,8 @@ static int mg_vcycle(Engine* h, const DCsr& Afine, Inner& s, int l,
     r = L.r.p;
   }
   CHK(spmv(h, L.R, r, C.b.p));                // restrict
+  if (L.transition && h->comm->allreduce(C.b.p, (size_t)L.n_coarse, h->stream))
+    return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
   double* pe = nullptr;
   CHK(mg_vcycle(h, Afine, s, l - 1, C.b.p, &pe));
   double* post[3];
@@ -1062,7 +1071,7 @@ static int upload_global(Engine* h, DCsr& A, const Space* rs, const Space* cs,
 // new values of a handed-over operator: one GPU copies, several ranks stage
 // the caller's global array and gather their entries
 static int refresh_values(Engine* h, DCsr& A, const double* vals, int mem) {
-  if (!h->comm) {
+  if (!h->comm || A.replicated) {
     HIPCHK(hipMemcpyAsync(A.val.p, vals, A.nnz * sizeof(double),
                           mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           h->stream));
@@ -1348,41 +1357,74 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
     return fail(PCD_ERR_ARG, "mg_set_level: coarse levels need an operator");
   if (rowptr && (!colidx || !vals)) return fail(PCD_ERR_ARG, "mg_set_level: bad operator arrays");
   MgLevel& M = s.mg[level];
-  // multi-GPU: every level is cut into contiguous row blocks like the finest
-  // one (velocity levels keep the two components of a node together)
+  // multi-GPU: large levels are cut into contiguous row blocks like the finest
+  // one (velocity levels keep the two components of a node together); levels
+  // of at most PCD_REPLICATE_BELOW rows (default 60000) are replicated
   const bool even = slot == PCD_KSP_A00;
   const Space *sl = nullptr, *sc = nullptr;
+  const int64_t nl = rowptr ? n : p_rows;
+  bool rep_l = false, rep_c = false;
   if (h->comm) {
+    const char* lim_env = getenv("PCD_REPLICATE_BELOW");
+    const int64_t limit = lim_env ? atoll(lim_env) : 60000LL;
+    rep_l = level < L - 1 && nl <= limit;
+    rep_c = level > 0 && p_cols <= limit;
     s.mg_space.resize(L);
-    const int64_t nl = rowptr ? n : p_rows;
-    if (s.mg_space[level].nf == 0) s.mg_space[level] = Space::field(nl, h->nranks, even);
-    if (s.mg_space[level].total() != nl) return fail(PCD_ERR_ARG, "mg_set_level: level %d size mismatch", level);
-    sl = &s.mg_space[level];
-    if (level > 0) {
+    if (!rep_l) {
+      if (s.mg_space[level].nf == 0) s.mg_space[level] = Space::field(nl, h->nranks, even);
+      if (s.mg_space[level].total() != nl) return fail(PCD_ERR_ARG, "mg_set_level: level %d size mismatch", level);
+      sl = &s.mg_space[level];
+    }
+    if (level > 0 && !rep_c) {
       if (s.mg_space[level - 1].nf == 0) s.mg_space[level - 1] = Space::field(p_cols, h->nranks, even);
       if (s.mg_space[level - 1].total() != p_cols) return fail(PCD_ERR_ARG, "mg_set_level: level %d prolongation width mismatch", level);
       sc = &s.mg_space[level - 1];
     }
   }
+  M.replicated = rep_l; M.transition = h->comm && !rep_l && rep_c; M.n_coarse = p_cols;
   if (rowptr) {
-    CHK(upload_global(h, M.A, sl, sl, n, n, rowptr, colidx, vals, nullptr));
+    if (rep_l) { CHK(upload_csr(h, M.A, n, n, rowptr, colidx, vals, nullptr)); M.A.replicated = true; M.A.gnnz = rowptr[n]; }
+    else CHK(upload_global(h, M.A, sl, sl, n, n, rowptr, colidx, vals, nullptr));
     CHK(refresh_dinv(h, M.A));
   }
   if (level > 0) {
-    CHK(upload_global(h, M.P, sl, sc, p_rows, p_cols, prowptr, pcolidx, pvals, nullptr));
     // restriction = transpose, built on the host (counting sort by column)
-    const int64_t nnz = prowptr[p_rows];
-    std::vector<int32_t> trp(p_cols + 1, 0), tc(nnz);
-    std::vector<double> tv(nnz);
-    for (int64_t k = 0; k < nnz; ++k) ++trp[pcolidx[k] + 1];
-    for (int64_t c = 0; c < p_cols; ++c) trp[c + 1] += trp[c];
-    std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
-    for (int64_t i = 0; i < p_rows; ++i)
-      for (int32_t k = prowptr[i]; k < prowptr[i + 1]; ++k) {
-        const int32_t q = fill[pcolidx[k]]++;
-        tc[q] = (int32_t)i; tv[q] = pvals[k];
-      }
-    CHK(upload_global(h, M.R, sc, sl, p_cols, p_rows, trp.data(), tc.data(), tv.data(), nullptr));
+    auto transpose = [](int64_t nr, int64_t nc, const int32_t* rp, const int32_t* ci, const double* va,
+                        std::vector<int32_t>& trp, std::vector<int32_t>& tc, std::vector<double>& tv) {
+      const int64_t nnz = rp[nr];
+      trp.assign(nc + 1, 0); tc.resize(nnz); tv.resize(nnz);
+      for (int64_t k = 0; k < nnz; ++k) ++trp[ci[k] + 1];
+      for (int64_t c = 0; c < nc; ++c) trp[c + 1] += trp[c];
+      std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
+      for (int64_t i = 0; i < nr; ++i)
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+          const int32_t q = fill[ci[k]]++;
+          tc[q] = (int32_t)i; tv[q] = va[k];
+        }
+    };
+    std::vector<int32_t> trp, tc; std::vector<double> tv;
+    if (!h->comm || rep_l) {                       // both levels on every rank
+      CHK(upload_csr(h, M.P, p_rows, p_cols, prowptr, pcolidx, pvals, nullptr));
+      transpose(p_rows, p_cols, prowptr, pcolidx, pvals, trp, tc, tv);
+      CHK(upload_csr(h, M.R, p_cols, p_rows, trp.data(), tc.data(), tv.data(), nullptr));
+      M.P.replicated = M.R.replicated = h->comm != nullptr;
+    } else if (M.transition) {
+      // my fine rows x ALL coarse columns; its transpose sums my contribution
+      // to every coarse row, the all-reduce in the cycle completes it
+      const int64_t r0 = sl->bounds[0][h->rank], r1 = sl->bounds[0][h->rank + 1];
+      std::vector<int32_t> lrp(r1 - r0 + 1);
+      for (int64_t i = r0; i <= r1; ++i) lrp[i - r0] = prowptr[i] - prowptr[r0];
+      const int32_t* lc = pcolidx + prowptr[r0];
+      const double* lv = pvals + prowptr[r0];
+      CHK(upload_csr(h, M.P, r1 - r0, p_cols, lrp.data(), lc, lv, nullptr));
+      transpose(r1 - r0, p_cols, lrp.data(), lc, lv, trp, tc, tv);
+      CHK(upload_csr(h, M.R, p_cols, r1 - r0, trp.data(), tc.data(), tv.data(), nullptr));
+      M.P.replicated = M.R.replicated = true;     // no halo on either
+    } else {
+      CHK(upload_global(h, M.P, sl, sc, p_rows, p_cols, prowptr, pcolidx, pvals, nullptr));
+      transpose(p_rows, p_cols, prowptr, pcolidx, pvals, trp, tc, tv);
+      CHK(upload_global(h, M.R, sc, sl, p_cols, p_rows, trp.data(), tc.data(), tv.data(), nullptr));
+    }
   }
   M.emin = emin; M.emax = emax;
   ++h->gen;

@@ -254,6 +254,11 @@ __device__ __forceinline__ void row_block_range(int nrb, int& begin, int& end) {
   end = (int)((long long)(slot + 1) * nrb / G);
 }
 
+// Loads of one pass are all issued before any use: kUnroll independent
+// (col, val) pairs per lane, then kUnroll independent gathers - one dependent
+// chain rowptr -> col/val -> x per row block instead of one per loop trip.
+constexpr int kUnroll = 8;
+
 template <int RB, class XF>
 __device__ __forceinline__ double stream_row_block(
     const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -261,26 +266,33 @@ __device__ __forceinline__ double stream_row_block(
     double* lds) {
   const int r1 = min(r0 + RB, nrows);
   const int k0 = rowptr[r0], k1 = rowptr[r1];
-  int k = k0 + threadIdx.x;
-  for (; k + 3 * kBlock < k1; k += 4 * kBlock) {
-    const int c0 = col[k], c1 = col[k + kBlock], c2 = col[k + 2 * kBlock],
-              c3 = col[k + 3 * kBlock];
-    const double v0 = val[k], v1 = val[k + kBlock], v2 = val[k + 2 * kBlock],
-                 v3 = val[k + 3 * kBlock];
-    const double x0 = xf(c0), x1 = xf(c1), x2 = xf(c2), x3 = xf(c3);
-    lds[k - k0] = v0 * x0;
-    lds[k - k0 + kBlock] = v1 * x1;
-    lds[k - k0 + 2 * kBlock] = v2 * x2;
-    lds[k - k0 + 3 * kBlock] = v3 * x3;
+  const int row = r0 + threadIdx.x;
+  const bool mine = threadIdx.x < RB && row < r1;
+  // this lane's own row bounds, fetched up front (used after the barrier)
+  const int ra = mine ? rowptr[row] - k0 : 0;
+  const int rb = mine ? rowptr[row + 1] - k0 : 0;
+  for (int base = k0; base < k1; base += kUnroll * kBlock) {
+    int c[kUnroll];
+    double v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int k = base + u * kBlock + threadIdx.x;
+      const bool in = k < k1;
+      c[u] = in ? col[k] : -1;
+      v[u] = in ? val[k] : 0.0;
+    }
+    double xv[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int k = base + u * kBlock + threadIdx.x;
+      if (k < k1) lds[k - k0] = v[u] * xv[u];
+    }
   }
-  for (; k < k1; k += kBlock) lds[k - k0] = val[k] * xf(col[k]);
   __syncthreads();
   double s = 0.0;
-  const int row = r0 + threadIdx.x;
-  if (threadIdx.x < RB && row < r1) {
-    const int a = rowptr[row] - k0, b = rowptr[row + 1] - k0;
-    for (int j = a; j < b; ++j) s += lds[j];
-  }
+  for (int j = ra; j < rb; ++j) s += lds[j];
   return s;
 }
 
@@ -475,30 +487,33 @@ __device__ __forceinline__ double2 stream_row_block2(
     double2* lds) {
   const int r1 = min(r0 + RB, nrows);
   const int k0 = rowptr[r0], k1 = rowptr[r1];
-  int k = k0 + threadIdx.x;
-  for (; k + 3 * kBlock < k1; k += 4 * kBlock) {
-    const int c0 = col[k], c1 = col[k + kBlock], c2 = col[k + 2 * kBlock],
-              c3 = col[k + 3 * kBlock];
-    const double v0 = val[k], v1 = val[k + kBlock], v2 = val[k + 2 * kBlock],
-                 v3 = val[k + 3 * kBlock];
-    const double2 x0 = xf(c0), x1 = xf(c1), x2 = xf(c2), x3 = xf(c3);
-    lds[k - k0] = make_double2(v0 * x0.x, v0 * x0.y);
-    lds[k - k0 + kBlock] = make_double2(v1 * x1.x, v1 * x1.y);
-    lds[k - k0 + 2 * kBlock] = make_double2(v2 * x2.x, v2 * x2.y);
-    lds[k - k0 + 3 * kBlock] = make_double2(v3 * x3.x, v3 * x3.y);
-  }
-  for (; k < k1; k += kBlock) {
-    const double v = val[k];
-    const double2 xv = xf(col[k]);
-    lds[k - k0] = make_double2(v * xv.x, v * xv.y);
+  const int row = r0 + threadIdx.x;
+  const bool mine = threadIdx.x < RB && row < r1;
+  const int ra = mine ? rowptr[row] - k0 : 0;
+  const int rb = mine ? rowptr[row + 1] - k0 : 0;
+  for (int base = k0; base < k1; base += kUnroll * kBlock) {
+    int c[kUnroll];
+    double v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int k = base + u * kBlock + threadIdx.x;
+      const bool in = k < k1;
+      c[u] = in ? col[k] : -1;
+      v[u] = in ? val[k] : 0.0;
+    }
+    double2 xv[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u)
+      xv[u] = c[u] >= 0 ? xf(c[u]) : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int k = base + u * kBlock + threadIdx.x;
+      if (k < k1) lds[k - k0] = make_double2(v[u] * xv[u].x, v[u] * xv[u].y);
+    }
   }
   __syncthreads();
   double2 s = make_double2(0.0, 0.0);
-  const int row = r0 + threadIdx.x;
-  if (threadIdx.x < RB && row < r1) {
-    const int a = rowptr[row] - k0, b = rowptr[row + 1] - k0;
-    for (int j = a; j < b; ++j) { const double2 t = lds[j]; s.x += t.x; s.y += t.y; }
-  }
+  for (int j = ra; j < rb; ++j) { const double2 t = lds[j]; s.x += t.x; s.y += t.y; }
   return s;
 }
 

@@ -84,7 +84,12 @@ def test_spmv_and_apply_partitioned_vs_single(hip_lib, R):
         assert relerr(o["cg_tol"], ref["cg_tol"]) < 1e-8
 
 
-def test_gmres_with_multigrid_partitioned(hip_lib):
+@pytest.mark.parametrize("replicate_below", ["60000", "0", "700"])
+def test_gmres_with_multigrid_partitioned(hip_lib, monkeypatch,
+                                          replicate_below):
+    # coarse levels replicated on every rank (default), fully distributed
+    # (0), or mixed (700 rows: both kinds of level and the transition)
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", replicate_below)
     st = flow_state("cavity", 3)
     pb, V, L = st["pb"], st["V"], st["L"]
     I = pb.interpolations()
