@@ -31,10 +31,13 @@ def build(force=False):
 
 
 def library():
+    """PCD_ORACLE_LIB overrides the path (e.g. the -fsanitize build made by
+    ``make -C oracle asan``)."""
     global _library
     if _library is None:
         from fenapack_amd._cabi import Library
-        _library = Library(build(), "pcdo_", hip=False)
+        path = os.environ.get("PCD_ORACLE_LIB") or build()
+        _library = Library(path, "pcdo_", hip=False)
     return _library
 
 
@@ -42,3 +45,20 @@ def Engine(variant="BRM1"):
     """An oracle engine with the same Python surface as the HIP engine."""
     from fenapack_amd._cabi import Engine as _Engine
     return _Engine(library(), variant, 0)
+
+
+OMP_LIBRARY_PATH = os.path.join(_HERE, "_build", "libpcd_oracle_omp.so")
+
+
+def omp_engine(variant="BRM1", threads=None):
+    """Multi-core TIMING variant (OpenMP, reduction order not fixed): for
+    bench.py's cpu_baseline only, never for parity.  Returns (engine,
+    threads in effect)."""
+    import ctypes
+    from fenapack_amd._cabi import Engine as _Engine, Library
+    build()
+    lib = Library(OMP_LIBRARY_PATH, "pcdo_", hip=False)
+    f = lib.lib.pcdo_set_threads
+    f.argtypes, f.restype = [ctypes.c_int], ctypes.c_int
+    n = f(int(threads or 0))
+    return _Engine(lib, variant, 0), n

@@ -31,6 +31,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Optional OpenMP build (make omp): used ONLY as the multi-core timing
+ * baseline of bench.py; parity tests use the serial build (sequential
+ * summation order). */
+#ifdef _OPENMP
+#include <omp.h>
+#define OMP_FOR _Pragma("omp parallel for schedule(static)")
+#define OMP_SUM _Pragma("omp parallel for schedule(static) reduction(+ : s)")
+#else
+#define OMP_FOR
+#define OMP_SUM
+#endif
+
 enum { MAT_AP = 0, MAT_MP, MAT_KP, MAT_RP, MAT_A00, MAT_A01, MAT_A, MAT_COUNT };
 enum { SLOT_AP = 0, SLOT_MP, SLOT_RP, SLOT_A00, SLOT_COUNT };
 enum { KSP_PREONLY = 0, KSP_RICHARDSON, KSP_CHEBYSHEV, KSP_CG };
@@ -58,6 +70,7 @@ typedef struct {
   csr_t mgA[MG_MAX_LEVELS];   /* operator (level 0: explicit inverse);
                                  finest level: unused, the slot's operator */
   csr_t mgP[MG_MAX_LEVELS];   /* prolongation level-1 -> level */
+  csr_t mgR[MG_MAX_LEVELS];   /* its transpose (restriction), explicit */
   double mg_emin[MG_MAX_LEVELS], mg_emax[MG_MAX_LEVELS];
 } inner_t;
 
@@ -106,6 +119,7 @@ static void csr_diag(csr_t *m) {
 
 /* Mat.mult: y = A x (preconditioners.py:131,164) */
 static void spmv(const csr_t *A, const double *x, double *y) {
+  OMP_FOR
   for (int64_t i = 0; i < A->nrows; ++i) {
     double s = 0.0;
     for (int32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
@@ -116,6 +130,7 @@ static void spmv(const csr_t *A, const double *x, double *y) {
 
 static double dot(int64_t n, const double *a, const double *b) {
   double s = 0.0;
+  OMP_SUM
   for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
 }
@@ -123,6 +138,7 @@ static double dot(int64_t n, const double *a, const double *b) {
 /* ----------------------------------------------------------- inner KSPs */
 static void pc_apply(const csr_t *A, int pc, const double *r, double *z) {
   if (pc == PC_JACOBI)
+    OMP_FOR
     for (int64_t i = 0; i < A->nrows; ++i) z[i] = A->dinv[i] * r[i];
   else
     memcpy(z, r, sizeof(double) * A->nrows);
@@ -145,12 +161,15 @@ static int solve_cg(const csr_t *A, inner_t *s, const double *b, double *x,
       memcpy(p, z, sizeof(double) * n);
     else {
       double beta = rz / rz_old;
+      OMP_FOR
       for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
     }
     spmv(A, p, q);
     double pq = dot(n, p, q);
     double alpha = rz / pq;
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) x[i] += alpha * p[i];
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) r[i] -= alpha * q[i];
     pc_apply(A, s->pc, r, z);
     rz_old = rz;
@@ -177,13 +196,16 @@ static int solve_cheb(const csr_t *A, inner_t *s, const double *b, double *x,
   double *pkm1 = pa, *pk = pb, *pkp1 = pc_;
   memset(pkm1, 0, sizeof(double) * n);
   pc_apply(A, s->pc, b, pk);
+  OMP_FOR
   for (int64_t i = 0; i < n; ++i) pk[i] = scale * pk[i] + pkm1[i];
   for (int it = 0; it < s->max_it; ++it) {
     double c_kp1 = 2.0 * mu * c_k - c_km1;
     double omega = omegaprod * c_k / c_kp1;
     spmv(A, pk, r);
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
     pc_apply(A, s->pc, r, pkp1);
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i)
       pkp1[i] = (1.0 - omega) * pkm1[i] + omega * pk[i]
                 + omega * scale * pkp1[i];
@@ -205,9 +227,11 @@ static int solve_rich(const csr_t *A, inner_t *s, const double *b, double *x,
       memcpy(r, b, sizeof(double) * n);
     else {
       spmv(A, x, r);
+      OMP_FOR
       for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
     }
     pc_apply(A, s->pc, r, z);
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) x[i] += z[i];
   }
   s->last_its = s->max_it;
@@ -217,11 +241,23 @@ static int solve_rich(const csr_t *A, inner_t *s, const double *b, double *x,
 /* ---- [ext PETSc] PCMG: multiplicative V-cycle, Chebyshev/Jacobi smoothing,
  * explicit coarse inverse.  Same recurrences as solve_cheb; a smoother call
  * with a nonzero guess starts with p_1 = x + scale*B(b - A x). */
-static void spmv_t(const csr_t *P, const double *x, double *y) { /* y = P^T x */
-  memset(y, 0, sizeof(double) * P->ncols);
-  for (int64_t i = 0; i < P->nrows; ++i)
-    for (int32_t k = P->rowptr[i]; k < P->rowptr[i + 1]; ++k)
-      y[P->col[k]] += P->val[k] * x[i];
+static void csr_transpose(csr_t *T, const csr_t *P) {
+  csr_free(T);
+  T->nrows = P->ncols; T->ncols = P->nrows; T->nnz = P->nnz;
+  T->rowptr = (int32_t *)calloc(T->nrows + 1, sizeof(int32_t));
+  T->col = (int32_t *)malloc(sizeof(int32_t) * (T->nnz ? T->nnz : 1));
+  T->val = (double *)malloc(sizeof(double) * (T->nnz ? T->nnz : 1));
+  for (int64_t k = 0; k < P->nnz; ++k) ++T->rowptr[P->col[k] + 1];
+  for (int64_t c = 0; c < T->nrows; ++c) T->rowptr[c + 1] += T->rowptr[c];
+  int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (T->nrows ? T->nrows : 1));
+  memcpy(fill, T->rowptr, sizeof(int32_t) * T->nrows);
+  for (int64_t i = 0; i < P->nrows; ++i)      /* rows ascending: each row of */
+    for (int32_t k = P->rowptr[i]; k < P->rowptr[i + 1]; ++k) { /* T sorted */
+      int32_t q = fill[P->col[k]]++;
+      T->col[q] = (int32_t)i; T->val[q] = P->val[k];
+    }
+  free(fill);
+  T->set = 1;
 }
 
 static void mg_smooth(const csr_t *A, double emin, double emax, int nu,
@@ -234,16 +270,19 @@ static void mg_smooth(const csr_t *A, double emin, double emax, int nu,
   double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, c_km1 = 1.0, c_k = mu;
   if (zero_guess) {
     memset(pkm1, 0, sizeof(double) * n);
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) pk[i] = scale * (A->dinv[i] * b[i]);
   } else {
     memcpy(pkm1, x, sizeof(double) * n);
     spmv(A, x, r);
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i)
       pk[i] = x[i] + scale * (A->dinv[i] * (b[i] - r[i]));
   }
   for (int it = 0; it < nu - 1; ++it) {
     double c_kp1 = 2.0 * mu * c_k - c_km1, omega = omegaprod * c_k / c_kp1;
     spmv(A, pk, r);
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i)
       pkp1[i] = (1.0 - omega) * pkm1[i] + omega * pk[i]
                 + omega * scale * (A->dinv[i] * (b[i] - r[i]));
@@ -265,11 +304,13 @@ static void mg_vcycle(const inner_t *s, const csr_t *Afine, int l,
   mg_smooth(A, s->mg_emin[l], s->mg_emax[l], s->nu_pre, b, x, 1);
   if (s->nu_pre) {
     spmv(A, x, r);
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
   } else memcpy(r, b, sizeof(double) * n);
-  spmv_t(P, r, bc);
+  spmv(&s->mgR[l], r, bc);                 /* restrict: bc = P^T r */
   mg_vcycle(s, Afine, l - 1, bc, ec);
   spmv(P, ec, r);
+  OMP_FOR
   for (int64_t i = 0; i < n; ++i) x[i] += r[i];
   mg_smooth(A, s->mg_emin[l], s->mg_emax[l], s->nu_post, b, x, 0);
   free(r);
@@ -286,6 +327,7 @@ static int solve_mg(const csr_t *A, inner_t *s, const double *b, double *x,
     if (it == 0) memcpy(r, b, sizeof(double) * n);
     else { spmv(A, x, r); for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i]; }
     mg_vcycle(s, A, s->mg_levels - 1, r, z);
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) x[i] += z[i];
   }
   s->last_its = its;
@@ -344,6 +386,7 @@ int pcdo_destroy(pcdo_t *h) {
   for (int s = 0; s < SLOT_COUNT; ++s)
     for (int l = 0; l < MG_MAX_LEVELS; ++l) {
       csr_free(&h->inner[s].mgA[l]); csr_free(&h->inner[s].mgP[l]);
+      csr_free(&h->inner[s].mgR[l]);
     }
   free(h->bc_idx); free(h->bc_val); free(h->perm);
   for (int i = 0; i < 8; ++i) free(h->w[i]);
@@ -499,7 +542,7 @@ int pcdo_mg_begin(pcdo_t *h, int slot, int nlevels, int nu_pre, int nu_post) {
     return fail(1, "mg_begin: bad level / smoothing counts");
   inner_t *s = &h->inner[slot];
   for (int l = 0; l < MG_MAX_LEVELS; ++l) {
-    csr_free(&s->mgA[l]); csr_free(&s->mgP[l]);
+    csr_free(&s->mgA[l]); csr_free(&s->mgP[l]); csr_free(&s->mgR[l]);
   }
   s->mg_levels = nlevels; s->nu_pre = nu_pre; s->nu_post = nu_post;
   return 0;
@@ -524,6 +567,7 @@ int pcdo_mg_set_level(pcdo_t *h, int slot, int level, int64_t n,
   if (level > 0) {
     if (!prowptr) return fail(1, "mg_set_level: prolongation missing");
     csr_store(&s->mgP[level], p_rows, p_cols, prowptr, pcol, pval);
+    csr_transpose(&s->mgR[level], &s->mgP[level]);
   }
   s->mg_emin[level] = emin; s->mg_emax[level] = emax;
   return 0;
@@ -590,12 +634,15 @@ static int pcd_apply_core(pcdo_t *h, const double *x, double *y) {
     apply_bc(h, z);                                 /* bcs_applier(z)      */
     if ((rc = inner_solve(h, SLOT_AP, z, y))) return rc; /* y = Ap^-1 z   */
     spmv(&h->mat[MAT_KP], y, z);                    /* z = Kp y            */
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) z[i] += 1.0 * x[i]; /* z.axpy(1, x)   */
     if ((rc = inner_solve(h, SLOT_MP, z, y))) return rc; /* y = Mp^-1 z   */
     if (h->variant == RBRM1) {
       if ((rc = inner_solve(h, SLOT_RP, x, z))) return rc; /* z = Rp^-1 x */
+      OMP_FOR
       for (int64_t i = 0; i < n; ++i) y[i] += 1.0 * z[i];  /* y.axpy(1,z) */
     }
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) y[i] *= -1.0;   /* y.scale(-1)         */
   } else {
     double *z0 = h->w[0], *z1 = h->w[1];            /* get_work_vecs(x, 2) */
@@ -604,11 +651,14 @@ static int pcd_apply_core(pcdo_t *h, const double *x, double *y) {
     spmv(&h->mat[MAT_KP], z0, z1);                  /* z1 = Kp z0          */
     apply_bc(h, z1);                                /* bcs_applier(z1)     */
     if ((rc = inner_solve(h, SLOT_AP, z1, z0))) return rc; /* z0=Ap^-1 z1 */
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) y[i] += 1.0 * z0[i]; /* y.axpy(1,z0)  */
     if (h->variant == RBRM2) {
       if ((rc = inner_solve(h, SLOT_RP, x, z0))) return rc; /* z0=Rp^-1 x */
+      OMP_FOR
       for (int64_t i = 0; i < n; ++i) y[i] += 1.0 * z0[i];
     }
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) y[i] *= -1.0;   /* y.scale(-1)         */
   }
   ++h->num_pcd;
@@ -629,6 +679,7 @@ static int fs_apply_split(pcdo_t *h, const double *x, double *y) {
   int rc;
   if ((rc = pcd_apply_core(h, xp, yp))) return rc;      /* y_p = S^-1 x_p */
   spmv(&h->mat[MAT_A01], yp, t);
+  OMP_FOR
   for (int64_t i = 0; i < nu; ++i) t[i] = xu[i] - t[i]; /* x_u - A01 y_p  */
   if ((rc = inner_solve(h, SLOT_A00, t, yu))) return rc; /* A00^-1 (...)  */
   ++h->num_fs;
@@ -641,9 +692,11 @@ int pcdo_fieldsplit_apply(pcdo_t *h, const double *x, double *y, int mem) {
     return fail(4, "fieldsplit_apply: system/setup missing");
   int64_t n = h->n_u + h->n_p;
   double *xs = h->ws[0], *ys = h->ws[1];
+  OMP_FOR
   for (int64_t i = 0; i < n; ++i) xs[i] = x[h->perm[i]];
   int rc = fs_apply_split(h, xs, ys);
   if (rc) return rc;
+  OMP_FOR
   for (int64_t i = 0; i < n; ++i) y[h->perm[i]] = ys[i];
   return 0;
 }
@@ -668,6 +721,7 @@ int pcdo_gmres_solve(pcdo_t *h, const double *b, double *x, int mem,
   double *bs = (double *)malloc(sizeof(double) * n);
   double *z = (double *)malloc(sizeof(double) * n);
   double *w = (double *)malloc(sizeof(double) * n);
+  OMP_FOR
   for (int64_t i = 0; i < n; ++i) bs[i] = b[h->perm[i]];
   double bnorm = sqrt(dot(n, bs, bs));
   double tol = rtol * bnorm; if (atol > tol) tol = atol;
@@ -677,6 +731,7 @@ int pcdo_gmres_solve(pcdo_t *h, const double *b, double *x, int mem,
     double beta = sqrt(dot(n, w, w));
     res = beta;
     if (beta <= tol) break;
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) V[i] = w[i] / beta;
     memset(g, 0, sizeof(double) * (m + 1)); g[0] = beta;
     int k = 0;
@@ -688,6 +743,7 @@ int pcdo_gmres_solve(pcdo_t *h, const double *b, double *x, int mem,
       for (int j = 0; j <= k; ++j) hc[j] = dot(n, V + (size_t)j * n, vn);
       for (int j = 0; j <= k; ++j) {
         const double *vj = V + (size_t)j * n; double hj = hc[j];
+        OMP_FOR
         for (int64_t i = 0; i < n; ++i) vn[i] -= hj * vj[i];
       }
       double hn = sqrt(dot(n, vn, vn));
@@ -714,15 +770,19 @@ int pcdo_gmres_solve(pcdo_t *h, const double *b, double *x, int mem,
     memset(w, 0, sizeof(double) * n);
     for (int j = 0; j < k; ++j) {
       const double *vj = V + (size_t)j * n;
+      OMP_FOR
       for (int64_t i = 0; i < n; ++i) w[i] += yk[j] * vj[i];
     }
     if ((rc = fs_apply_split(h, w, z))) goto done;
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) xs[i] += z[i];
     if (res <= tol || it >= max_it) break;
     spmv(&h->mat[MAT_A], xs, z);                       /* restart: true r */
+    OMP_FOR
     for (int64_t i = 0; i < n; ++i) w[i] = bs[i] - z[i];
   }
 done:
+  OMP_FOR
   for (int64_t i = 0; i < n; ++i) x[h->perm[i]] = xs[i];
   h->gmres_its = it; h->gmres_rnorm = res;
   if (its) *its = it;
@@ -769,3 +829,15 @@ int pcdo_get_info(pcdo_t *h, int key, double *out) {
 }
 
 int pcdo_synchronize(pcdo_t *h) { (void)h; return 0; }
+
+/* threads of the OpenMP timing build; returns the count in effect (1 when
+ * built without OpenMP) */
+int pcdo_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
