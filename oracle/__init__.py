@@ -61,4 +61,6 @@ def omp_engine(variant="BRM1", threads=None):
     f = lib.lib.pcdo_set_threads
     f.argtypes, f.restype = [ctypes.c_int], ctypes.c_int
     n = f(int(threads or 0))
-    return _Engine(lib, variant, 0), n
+    eng = _Engine(lib, variant, 0)
+    eng.set_threads = lambda k: f(int(k))
+    return eng, n
