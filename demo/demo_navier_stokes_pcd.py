@@ -31,6 +31,10 @@ p.add_argument("--stabilize", action="store_true",
                help="SUPG-stabilised 00-block in the preconditioner matrix "
                     "(the reference's J_pc for --ls iterative)")
 p.add_argument("--cycles", type=int, default=1)
+p.add_argument("--smooth", type=int, default=2)
+p.add_argument("--mg-coarse", default="galerkin",
+               choices=["galerkin", "rediscretize"],
+               help="coarse velocity operators of the multigrid cycle")
 p.add_argument("--a00-its", type=int, default=60)
 p.add_argument("--a00-ratio", type=float, default=0.01)
 args = p.parse_args()
@@ -47,7 +51,9 @@ else:
     print("Reynolds number: Re = %g" % (1.0 / pb.nu))
 print("Dimension of the function space: %d" % pb.space.ndof)
 if args.ls == "mg":
-    multigrid_inner_options(cycles_u=args.cycles, cycles_p=args.cycles)
+    multigrid_inner_options(cycles_u=args.cycles, cycles_p=args.cycles,
+                            smooth=args.smooth,
+                            galerkin_u=args.mg_coarse == "galerkin")
 else:
     default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio)
 out = solve_steady(pb, max_newton=25)

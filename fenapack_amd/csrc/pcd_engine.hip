@@ -156,7 +156,6 @@ struct pcd_engine_s {
   CommBackend* comm = nullptr;
   int rank = 0, nranks = 1;
   Space sp_u, sp_p, sp_sys;
-  DBuf<int> l2g_u, l2g_p;             // local -> global index of each field
   DBuf<double> loc_x, loc_y;          // local slices for host-pointer calls
   std::vector<double> bc_val_host;
   DBuf<int> perm;                     // LOCAL split position -> caller's index
@@ -1151,7 +1150,7 @@ int pcd_destroy(pcd_handle h) {
   h->xs.release(); h->ys.release(); h->io_x.release(); h->io_y.release();
   h->V.release(); h->gz.release(); h->gw.release(); h->gparts.release();
   h->gh.release(); h->gy.release(); h->gxs.release(); h->gbs.release();
-  h->loc_x.release(); h->loc_y.release(); h->l2g_u.release(); h->l2g_p.release();
+  h->loc_x.release(); h->loc_y.release();
   delete h->comm;
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->gexec) (void)hipGraphExecDestroy(h->gexec);

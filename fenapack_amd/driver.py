@@ -12,7 +12,7 @@ from .fem.forms import navier_stokes_forms
 
 
 def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
-                            mp_its=5, pcdr=False):
+                            mp_its=5, pcdr=False, galerkin_u=True):
     """The reference's "iterative" configuration (demo_navier-stokes-pcd.py:
     152-165: Richardson + one/two multigrid cycles for A00 and Ap, Chebyshev +
     Jacobi for Mp) with hypre BoomerAMG replaced by the engine's geometric
@@ -25,6 +25,10 @@ def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
         S(prefix + key + "ksp_max_it", cycles)
         S(prefix + key + "pc_type", "mg")
         S(prefix + key + "mg_levels_ksp_max_it", smooth)
+    if not galerkin_u:
+        # re-discretised (SUPG-stabilised) coarse velocity operators instead
+        # of Galerkin products: needed at cell Peclet numbers > 1
+        S(prefix + "fieldsplit_u_pc_mg_galerkin", "none")
     S(prefix + "fieldsplit_p_PCD_Mp_ksp_type", "chebyshev")
     S(prefix + "fieldsplit_p_PCD_Mp_ksp_max_it", mp_its)
     S(prefix + "fieldsplit_p_PCD_Mp_ksp_chebyshev_eigenvalues", "0.5, 2.0")

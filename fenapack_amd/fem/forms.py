@@ -119,6 +119,9 @@ def navier_stokes_forms(problem, w=None):
     w = Function(V) if w is None else w
     fa = FormAssembler(problem, w)
     mk = lambda kind: _BoundForm(kind, problem, w, fa)
+    # coarse-level operators at the current iterate (pc_mg_galerkin none)
+    V.coarse_velocity_operators = lambda nlev: \
+        problem.coarse_velocity_operators(w.split()[0], nlev)
     bc_u = DirichletBC(V, V.is_u[problem.bc_u_idx],
                        problem.bc_u_values(problem.t))
     bc_p = DirichletBC(V, V.is_p[problem.bc_p_idx], problem.bc_p_val)

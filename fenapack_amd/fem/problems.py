@@ -114,6 +114,40 @@ class FlowProblem(object):
             self._interp = Interpolations(self.hierarchy, self.space)
         return self._interp
 
+    def coarse_velocity_operators(self, xu, nlev):
+        """Re-discretised velocity blocks of the preconditioner matrix on the
+        ``nlev - 1`` levels below the finest one (coarsest first), for
+        ``pc_mg_galerkin none``: the iterate is injected to the coarse nodes
+        and every level is assembled with its own SUPG parameter, so coarse
+        levels stay stable at cell Peclet numbers > 1 where Galerkin products
+        of the fine operator are not (BASELINE config 3)."""
+        chain = self.interpolations().velocity
+        L = len(chain) - 1                              # finest level index
+        ops, x_l = [], xu
+        if not hasattr(self, "_coarse_problems"):
+            self._coarse_problems = {}
+        for l in range(L, L - nlev + 1, -1):            # level l -> l - 1
+            P = chain[l].tocsr()
+            unit = np.nonzero((np.diff(P.indptr) == 1)
+                              & (np.abs(P.data[P.indptr[:-1]] - 1.0) < 1e-12))[0]
+            x_c = np.zeros(P.shape[1])
+            x_c[P.indices[P.indptr[unit]]] = x_l[unit]  # injection
+            if l - 1 not in self._coarse_problems:
+                self._coarse_problems[l - 1] = self._same_problem_on_level(l - 1)
+            pc = self._coarse_problems[l - 1]
+            pc.t = self.t
+            lin = pc.linearise(x_c, np.zeros(pc.space.n_p))
+            ops.append(lin.get("P00", lin["A00"]))
+            x_l = x_c
+        return ops[::-1]
+
+    def _same_problem_on_level(self, level):
+        kw = dict(nu=self.nu, variant=self.variant, nls=self.nls,
+                  pcdr=self.pcdr, stabilize=self.stabilize)
+        if self.idt:
+            kw["dt"] = 1.0 / self.idt
+        return type(self)(level, **kw)
+
     # -- helpers -----------------------------------------------------------
     def _edge_dofs_u(self, edges):
         """Velocity-local dofs (both components) living on ``edges``."""

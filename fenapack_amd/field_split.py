@@ -94,6 +94,8 @@ class PCDKSP(KSP):
         ksp0.bind(self.engine, c.KSP_A00)
         if ksp0.pc.type == "mg" and ksp0.pc._mg_chain is None:
             ksp0.pc.setMGInterpolations(V.interpolations().chain("u"))
+            if not ksp0.pc.mg_galerkin and ksp0.pc._mg_ops_cb is None:
+                ksp0.pc.setMGOperators(V.coarse_velocity_operators)
         ksp0.setUp()
 
         ksp1.pc.setPythonContext(pcd_pc)

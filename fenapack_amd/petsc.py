@@ -280,7 +280,14 @@ class PC(object):
         self.mg_coarse_eq_limit = 2000     # like -pc_gamg_coarse_eq_limit
         self.mg_smooth_its = 2
         self.mg_esteig = (0.0, 0.1, 0.0, 1.1)
+        self.mg_galerkin = True            # -pc_mg_galerkin both | none
+        self._mg_ops_cb = None
         self._mg_pushed = None
+
+    def setMGOperators(self, callback):
+        """``callback(nlev)`` -> operators of the ``nlev - 1`` coarse levels,
+        coarsest first (used with ``-pc_mg_galerkin none``)."""
+        self._mg_ops_cb = callback
 
     def setMGInterpolations(self, chain):
         """``chain[l]`` maps level l-1 to l, ``chain[0] is None``
@@ -414,6 +421,12 @@ class KSP(object):
         self.pc.mg_levels = o.getInt("pc_mg_levels", self.pc.mg_levels)
         self.pc.mg_coarse_eq_limit = o.getInt("pc_mg_coarse_eq_limit",
                                               self.pc.mg_coarse_eq_limit)
+        g = o.getString("pc_mg_galerkin")
+        if g is not None:
+            if g not in ("both", "none"):
+                raise ValueError("%spc_mg_galerkin %s: use both | none"
+                                 % (self._prefix, g))
+            self.pc.mg_galerkin = g == "both"
         self.pc.mg_smooth_its = o.getInt("mg_levels_ksp_max_it",
                                          self.pc.mg_smooth_its)
         e = o.getString("mg_levels_ksp_chebyshev_esteig")
@@ -470,7 +483,16 @@ class KSP(object):
                 nlev -= 1
         if nlev < len(chain):
             chain = [None] + chain[len(chain) - nlev + 1:]
-        ops = galerkin_chain(self._ops[1].A, chain)
+        if pc.mg_galerkin:
+            ops = galerkin_chain(self._ops[1].A, chain)
+        else:
+            if pc._mg_ops_cb is None:
+                raise RuntimeError("%spc_mg_galerkin none needs coarse "
+                                   "operators (pc.setMGOperators)"
+                                   % self._prefix)
+            ops = [sp.csr_matrix(o) for o in pc._mg_ops_cb(len(chain))] \
+                + [sp.csr_matrix(self._ops[1].A)]
+            assert len(ops) == len(chain)
         a, b, cc, d = pc.mg_esteig
         bounds = [None]
         if not hasattr(pc, "_mg_warm"):

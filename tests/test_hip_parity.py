@@ -346,3 +346,42 @@ def test_two_component_fast_path_and_its_fallback(hip_lib):
             3.0 * M.data, M.data))
         assert relerr(e.spmv_np(c.MAT_A00, xx, M.shape[0]),
                       o.spmv_np(c.MAT_A00, xx, M.shape[0])) < 1e-13
+
+
+def test_supg_preconditioner_matrix_path(hip_lib):
+    """BASELINE config 3 in miniature: the operator A stays unstabilised while
+    the preconditioner matrix P carries the SUPG term in its 00-block
+    (demo_navier-stokes-pcd.py:122-125; nonlinear_solvers.py:75-76).  A00/A01
+    of the engine must come from P, the GMRES operator from A."""
+    from fenapack_amd.fem import BackwardStep
+    pb = BackwardStep(3, nu=0.005, stabilize=True)
+    V = pb.space
+    rng = np.random.default_rng(21)
+    xu = 0.3 * rng.standard_normal(V.n_u)
+    L = pb.linearise(xu, np.zeros(V.n_p))
+    assert abs(L["P00"] - L["A00"]).max() > 0
+    A = V.monolithic(L["A00"], L["A01"], L["A10"])
+    P = V.monolithic(L["P00"], L["A01"], L["A10"])
+    b = V.to_mixed(L["bu"], L["bp"])
+    res = []
+    for eng in (hip_engine(hip_lib, "BRM1"), oracle.Engine("BRM1")):
+        eng.set_csr(c.MAT_AP, pb.Ap)
+        eng.set_csr(c.MAT_MP, pb.Mp)
+        eng.set_csr(c.MAT_KP, pb.Kp(xu))
+        eng.set_bc(pb.bc_p_idx, pb.bc_p_val)
+        eng.set_system(A, V.is_u, V.is_p, P)
+        eng.set_inner(c.KSP_AP, "cg", "jacobi", 3000, 1e-12)
+        eng.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+        eng.set_inner(c.KSP_A00, "chebyshev", "jacobi", 20, 0.0, 0.05, 2.2)
+        eng.setup()
+        xs = rng.standard_normal(V.n_u) if not res else res[0][3]
+        y00 = eng.spmv_np(c.MAT_A00, xs, V.n_u)
+        ya = eng.spmv_np(c.MAT_A, np.concatenate([xs, np.zeros(V.n_p)]),
+                         V.ndof)
+        x, its, _ = eng.gmres_np(b, rtol=1e-6, restart=100, max_it=200)
+        res.append((y00, ya, (x, its), xs))
+    (y00e, yae, (xe, ie), xs), (y00o, yao, (xo, io), _) = res
+    assert relerr(y00e, L["P00"] @ xs) < 1e-13          # A00 slot holds P00
+    assert relerr(yae[:V.n_u], L["A00"] @ xs) < 1e-13   # operator holds A00
+    assert relerr(y00e, y00o) < 1e-13 and relerr(yae, yao) < 1e-13
+    assert ie == io and relerr(xe, xo) < 1e-6
