@@ -378,10 +378,12 @@ def test_supg_preconditioner_matrix_path(hip_lib):
         y00 = eng.spmv_np(c.MAT_A00, xs, V.n_u)
         ya = eng.spmv_np(c.MAT_A, np.concatenate([xs, np.zeros(V.n_p)]),
                          V.ndof)
-        x, its, _ = eng.gmres_np(b, rtol=1e-6, restart=100, max_it=200)
+        # a fixed, short Krylov run: the comparison is about which matrix
+        # feeds which slot, not about convergence at this Peclet number
+        x, its, _ = eng.gmres_np(b, rtol=1e-30, restart=12, max_it=12)
         res.append((y00, ya, (x, its), xs))
     (y00e, yae, (xe, ie), xs), (y00o, yao, (xo, io), _) = res
     assert relerr(y00e, L["P00"] @ xs) < 1e-13          # A00 slot holds P00
     assert relerr(yae[:V.n_u], L["A00"] @ xs) < 1e-13   # operator holds A00
     assert relerr(y00e, y00o) < 1e-13 and relerr(yae, yao) < 1e-13
-    assert ie == io and relerr(xe, xo) < 1e-6
+    assert ie == io == 12 and relerr(xe, xo) < 1e-8
