@@ -173,6 +173,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # the same call with HOST pointers (PCIe both ways + synchronisation per
+    # call): reported for reference, never as `value`
+    rate_host = None
+    if world == 1:
+        xh, yh = xg.copy(), np.empty_like(xg)
+        eng.fieldsplit_apply(xh, yh)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            eng.fieldsplit_apply(xh, yh)
+        rate_host = 20 / (time.perf_counter() - t1)
+
     # executed inner iteration counts -> algorithmic bytes of one PCApply
     k_a = int(eng.info(c.INFO_ITS_AP))
     k_m = int(eng.info(c.INFO_ITS_MP))
@@ -234,6 +245,7 @@ def main():
             "parallelism": "row partition x%d" % world,
         },
         "gmres_its_per_newton_step": gmres_per_step,
+        "pcapply_per_s_host_pointers_pcie_inclusive": rate_host,
         "algorithmic_bytes_per_pcapply": int(bytes_pc),
         "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
         "roofline": {
