@@ -66,6 +66,7 @@ _HIP_ONLY = {
     "comm_init": [C.c_int, C.c_int, C.c_void_p],
     "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "graph_enable": [C.c_int],
+    "set_velocity_block": [C.c_int],
 }
 
 #: every symbol include/pcd_engine.h declares (checked by the CPU test-suite)
@@ -268,6 +269,10 @@ class Engine(object):
     # -- HIP only -------------------------------------------------------------
     def set_stream(self, stream_ptr):
         self._call("set_stream", C.c_void_p(stream_ptr))
+
+    def set_velocity_block(self, ncomp):
+        if self.L.hip:
+            self._call("set_velocity_block", int(ncomp))
 
     def graph_enable(self, on=True):
         self._call("graph_enable", int(bool(on)))

@@ -38,18 +38,20 @@ struct Space {
   int64_t goff[2] = {0, 0};
   std::vector<int64_t> bounds[2];
 
-  static std::vector<int64_t> cut(int64_t n, int R, bool even) {
+  // cuts fall on multiples of `block` (velocity: the components of a node
+  // stay on one rank)
+  static std::vector<int64_t> cut(int64_t n, int R, int block) {
     std::vector<int64_t> b(R + 1);
     for (int r = 0; r <= R; ++r) {
       int64_t v = n * r / R;
-      if (even) v -= v % 2;
+      if (block > 1) v -= v % block;
       b[r] = v;
     }
     b[R] = n;
     return b;
   }
-  static Space field(int64_t n, int R, bool even) {
-    Space s; s.nf = 1; s.bounds[0] = cut(n, R, even); return s;
+  static Space field(int64_t n, int R, int block) {
+    Space s; s.nf = 1; s.bounds[0] = cut(n, R, block); return s;
   }
   static Space system(const Space& u, const Space& p) {
     Space s; s.nf = 2; s.bounds[0] = u.bounds[0]; s.bounds[1] = p.bounds[0];

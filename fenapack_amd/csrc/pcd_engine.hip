@@ -155,6 +155,7 @@ struct pcd_engine_s {
   // multi-GPU: contiguous row blocks per rank
   CommBackend* comm = nullptr;
   int rank = 0, nranks = 1;
+  int vel_block = 2;                  // velocity components per node
   Space sp_u, sp_p, sp_sys;
   DBuf<double> loc_x, loc_y;          // local slices for host-pointer calls
   std::vector<double> bc_val_host;
@@ -1029,9 +1030,9 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
 }
 
 // field spaces are fixed by the first operator that shows their size
-static int ensure_space(Engine* h, Space& sp, int64_t n, bool even, const char* what) {
+static int ensure_space(Engine* h, Space& sp, int64_t n, bool velocity, const char* what) {
   if (!h->comm) return 0;
-  if (sp.nf == 0) { sp = Space::field(n, h->nranks, even); return 0; }
+  if (sp.nf == 0) { sp = Space::field(n, h->nranks, velocity ? h->vel_block : 1); return 0; }
   if (sp.total() != n)
     return fail(PCD_ERR_ARG, "%s: size %lld does not match the partitioned space (%lld)",
                 what, (long long)n, (long long)sp.total());
@@ -1359,7 +1360,7 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
   // multi-GPU: large levels are cut into contiguous row blocks like the finest
   // one (velocity levels keep the two components of a node together); levels
   // of at most PCD_REPLICATE_BELOW rows (default 60000) are replicated
-  const bool even = slot == PCD_KSP_A00;
+  const int even = slot == PCD_KSP_A00 ? h->vel_block : 1;   // cut granule
   const Space *sl = nullptr, *sc = nullptr;
   const int64_t nl = rowptr ? n : p_rows;
   bool rep_l = false, rep_c = false;
@@ -1801,6 +1802,14 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
   return fail(PCD_ERR_ARG, "get_info: unknown key %d", key);
 }
 
+int pcd_set_velocity_block(pcd_handle h, int ncomp) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (ncomp < 1 || ncomp > 3) return fail(PCD_ERR_ARG, "set_velocity_block: 1..3 components");
+  for (auto& m : h->mat) if (m.set) return fail(PCD_ERR_STATE, "set_velocity_block: call before any operator is handed over");
+  h->vel_block = ncomp;
+  return 0;
+}
+
 int pcd_graph_enable(pcd_handle h, int on) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   h->graph_on = on != 0;
@@ -1871,8 +1880,8 @@ int pcd_dist_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
                    int32_t* recv_peers, int32_t* recv_off) {
   if (!rowptr || !colidx || !vals || !counts || nranks < 1 || rank < 0 || rank >= nranks)
     return fail(PCD_ERR_ARG, "dist_probe: bad arguments");
-  const Space rs = Space::field(nrows, nranks, even_rows != 0);
-  const Space cs = Space::field(ncols, nranks, even_cols != 0);
+  const Space rs = Space::field(nrows, nranks, even_rows ? (even_rows > 1 ? even_rows : 2) : 1);
+  const Space cs = Space::field(ncols, nranks, even_cols ? (even_cols > 1 ? even_cols : 2) : 1);
   std::vector<int32_t> orp, oc; std::vector<double> ov; std::vector<int64_t> osrc;
   HaloPlan plan;
   localize(rs, cs, rank, nranks, rowptr, colidx, vals, nullptr, orp, oc, ov, osrc, plan);

@@ -32,6 +32,8 @@ _LSHAPE_CELLS = np.array([
 
 class Mesh(object):
     """Conforming triangle mesh with unique edges.
+    ``dim`` / ``local_edges`` give the dimension-independent view the P2/P1
+    producer uses (``TetMesh`` is the 3D counterpart).
 
     Attributes
     ----------
@@ -41,6 +43,9 @@ class Mesh(object):
     cell_edges : (nc, 3) int64; local edge k is *opposite* local vertex k
     boundary_edges : (nbe,) int64 ids of edges with a single adjacent cell
     """
+
+    dim = 2
+    local_edges = ((1, 2), (2, 0), (0, 1))      # edge k opposite vertex k
 
     def __init__(self, vertices, cells):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float64)
@@ -66,6 +71,7 @@ class Mesh(object):
         self.edges = np.stack([ukey // nv, ukey % nv], axis=1)
         self.cell_edges = inv.reshape(-1, 3)
         self.boundary_edges = np.nonzero(counts == 1)[0]
+        self.boundary_vertices = np.unique(self.edges[self.boundary_edges])
 
     @property
     def num_vertices(self):
@@ -133,3 +139,97 @@ def cavity_mesh(level):
     for _ in range(level):
         mesh = mesh.refine()
     return mesh
+
+
+# --------------------------------------------------------------------- 3D
+_TET_EDGES = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+_KUHN = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+
+
+class TetMesh(object):
+    """Conforming tetrahedral mesh with unique edges.  ``cell_edges[:, k]`` is
+    the edge joining the local vertices ``_TET_EDGES[k]``.  Boundary vertices
+    and edges come from the faces that belong to a single cell."""
+
+    dim = 3
+    local_edges = _TET_EDGES
+
+    def __init__(self, vertices, cells):
+        self.vertices = np.ascontiguousarray(vertices, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int64)
+        p = self.vertices[cells]
+        T = np.stack([p[:, 1] - p[:, 0], p[:, 2] - p[:, 0],
+                      p[:, 3] - p[:, 0]], axis=2)
+        flip = np.linalg.det(T) < 0
+        cells[flip] = cells[flip][:, [0, 2, 1, 3]]
+        self.cells = cells
+        nv = self.num_vertices
+        pairs = np.stack([cells[:, list(e)] for e in _TET_EDGES], axis=1)
+        pairs = np.sort(pairs.reshape(-1, 2), axis=1)
+        key = pairs[:, 0] * nv + pairs[:, 1]
+        ukey, inv = np.unique(key, return_inverse=True)
+        self.edges = np.stack([ukey // nv, ukey % nv], axis=1)
+        self.cell_edges = inv.reshape(-1, 6)
+        faces = np.stack([cells[:, [1, 2, 3]], cells[:, [0, 2, 3]],
+                          cells[:, [0, 1, 3]], cells[:, [0, 1, 2]]], axis=1)
+        faces = np.sort(faces.reshape(-1, 3), axis=1)
+        fkey = (faces[:, 0] * nv + faces[:, 1]) * nv + faces[:, 2]
+        uf, first, cnt = np.unique(fkey, return_index=True,
+                                   return_counts=True)
+        bfaces = faces[first[cnt == 1]]
+        self.boundary_vertices = np.unique(bfaces)
+        bpairs = np.sort(np.concatenate([bfaces[:, [0, 1]], bfaces[:, [0, 2]],
+                                         bfaces[:, [1, 2]]]), axis=1)
+        bkey = np.unique(bpairs[:, 0] * nv + bpairs[:, 1])
+        self.boundary_edges = np.searchsorted(ukey, bkey)
+
+    @property
+    def num_vertices(self):
+        return self.vertices.shape[0]
+
+    @property
+    def num_cells(self):
+        return self.cells.shape[0]
+
+    @property
+    def num_edges(self):
+        return self.edges.shape[0]
+
+    def edge_midpoints(self):
+        return 0.5 * (self.vertices[self.edges[:, 0]]
+                      + self.vertices[self.edges[:, 1]])
+
+
+def unit_cube_mesh(n):
+    """``n^3`` cubes, each cut into the 6 Kuhn tetrahedra (all share the main
+    diagonal); the mesh of ``2n`` is the uniform refinement of the mesh of
+    ``n``, which is what the 3D multigrid hierarchy relies on."""
+    xs = np.linspace(0.0, 1.0, n + 1)
+    Z, Y, X = np.meshgrid(xs, xs, xs, indexing="ij")
+    verts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    k, j, i = np.meshgrid(np.arange(n), np.arange(n), np.arange(n),
+                          indexing="ij")
+    base = ((k * (n + 1) + j) * (n + 1) + i).ravel()
+    step = np.array([1, n + 1, (n + 1) ** 2])
+    cells = []
+    for perm in _KUHN:
+        v0 = base
+        v1 = v0 + step[perm[0]]
+        v2 = v1 + step[perm[1]]
+        v3 = v2 + step[perm[2]]
+        cells.append(np.stack([v0, v1, v2, v3], axis=1))
+    return TetMesh(verts, np.concatenate(cells, axis=0))
+
+
+def kuhn_parents(coarse_n, fine_mesh):
+    """Coarse Kuhn tetrahedron (index into ``unit_cube_mesh(coarse_n)``'s
+    cell list) containing each cell of the twice finer mesh."""
+    c = fine_mesh.vertices[fine_mesh.cells].mean(axis=1) * coarse_n
+    ijk = np.minimum(np.floor(c).astype(np.int64), coarse_n - 1)
+    loc = c - ijk
+    # the Kuhn tet of permutation pi is {x_pi0 >= x_pi1 >= x_pi2}
+    order = np.argsort(-loc, axis=1, kind="stable")
+    perm_id = {p: q for q, p in enumerate(_KUHN)}
+    pid = np.array([perm_id[tuple(o)] for o in order])
+    cube = (ijk[:, 2] * coarse_n + ijk[:, 1]) * coarse_n + ijk[:, 0]
+    return pid * coarse_n ** 3 + cube

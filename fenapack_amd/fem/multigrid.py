@@ -39,6 +39,21 @@ class MeshHierarchy(object):
         return self._spaces[level]
 
 
+class CubeHierarchy(MeshHierarchy):
+    """Kuhn-triangulated unit cubes of ``n0 * 2**l`` cells per side; the mesh
+    of level l is the uniform refinement of level l-1, parents are located
+    geometrically (``kuhn_parents``)."""
+
+    def __init__(self, n0, levels):
+        from .mesh import unit_cube_mesh, kuhn_parents
+        self.meshes, self.parents = [unit_cube_mesh(n0)], [None]
+        for l in range(1, levels + 1):
+            fine = unit_cube_mesh(n0 * 2 ** l)
+            self.parents.append(kuhn_parents(n0 * 2 ** (l - 1), fine))
+            self.meshes.append(fine)
+        self._spaces = {}
+
+
 def _unique_entries(rows, cols, vals, shape):
     key = rows.ravel().astype(np.int64) * shape[1] + cols.ravel()
     u, idx = np.unique(key, return_index=True)
@@ -51,37 +66,38 @@ def _unique_entries(rows, cols, vals, shape):
 
 
 def prolongations(Vc, Vf, parent):
-    """(scalar P2, P1) prolongation matrices coarse -> fine."""
+    """(scalar P2, P1) prolongation matrices coarse -> fine; any dimension."""
     mc, mf = Vc.mesh, Vf.mesh
-    pc = mc.vertices[mc.cells[parent]]                 # parent triangles
+    d = Vf.dim
+    pc = mc.vertices[mc.cells[parent]]                 # parent simplices
     pf = mf.vertices[mf.cells]
-    mids = np.stack([0.5 * (pf[:, 1] + pf[:, 2]), 0.5 * (pf[:, 2] + pf[:, 0]),
-                     0.5 * (pf[:, 0] + pf[:, 1])], axis=1)
-    pts = np.concatenate([pf, mids], axis=1)           # 6 P2 nodes per cell
-    e1, e2 = pc[:, 1] - pc[:, 0], pc[:, 2] - pc[:, 0]
-    det = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
-    d = pts - pc[:, None, 0, :]
-    l1 = (d[..., 0] * e2[:, None, 1] - d[..., 1] * e2[:, None, 0]) \
-        / det[:, None]
-    l2 = (d[..., 1] * e1[:, None, 0] - d[..., 0] * e1[:, None, 1]) \
-        / det[:, None]
-    lam = np.stack([1.0 - l1 - l2, l1, l2], axis=2)    # (nf, 6, 3)
-    phi, _ = _p2_basis(lam.reshape(-1, 3))
-    phi = phi.reshape(lam.shape[0], 6, 6)
-    rows = np.repeat(Vf.cell_dofs2[:, :, None], 6, axis=2)
-    cols = np.repeat(Vc.cell_dofs2[parent][:, None, :], 6, axis=1)
+    mids = np.stack([0.5 * (pf[:, i] + pf[:, j]) for i, j in Vf.local_edges],
+                    axis=1)
+    pts = np.concatenate([pf, mids], axis=1)           # P2 nodes of the cell
+    T = np.stack([pc[:, k + 1] - pc[:, 0] for k in range(d)], axis=2)
+    Tinv = np.linalg.inv(T)                            # (nf, d, d)
+    l1d = np.einsum('cij,cnj->cni', Tinv, pts - pc[:, None, 0, :])
+    lam = np.concatenate([1.0 - l1d.sum(axis=2, keepdims=True), l1d], axis=2)
+    na, nvl = Vf.na, Vf.nvl
+    phi, _ = _p2_basis(lam.reshape(-1, nvl), Vc.local_edges)
+    phi = phi.reshape(lam.shape[0], na, na)
+    rows = np.repeat(Vf.cell_dofs2[:, :, None], na, axis=2)
+    cols = np.repeat(Vc.cell_dofs2[parent][:, None, :], na, axis=1)
     P2 = _unique_entries(rows, cols, phi, (Vf.nn, Vc.nn))
-    rows1 = np.repeat(Vf.cell_dofs1[:, :, None], 3, axis=2)
-    cols1 = np.repeat(Vc.cell_dofs1[parent][:, None, :], 3, axis=1)
-    P1 = _unique_entries(rows1, cols1, lam[:, :3, :], (Vf.n_p, Vc.n_p))
+    rows1 = np.repeat(Vf.cell_dofs1[:, :, None], nvl, axis=2)
+    cols1 = np.repeat(Vc.cell_dofs1[parent][:, None, :], nvl, axis=1)
+    P1 = _unique_entries(rows1, cols1, lam[:, :nvl, :], (Vf.n_p, Vc.n_p))
     return P2, P1
 
 
-def interleave2(P):
-    """Scalar P2 prolongation -> velocity prolongation (dofs 2*node+comp)."""
-    P = sp.kron(P, sp.identity(2, format="csr"), format="csr")
+def interleave(P, d=2):
+    """Scalar P2 prolongation -> velocity prolongation (dofs d*node+comp)."""
+    P = sp.kron(P, sp.identity(d, format="csr"), format="csr")
     P.sort_indices()
     return P
+
+
+interleave2 = interleave
 
 
 class Interpolations(object):
@@ -95,7 +111,7 @@ class Interpolations(object):
             Vc = hierarchy.space(l - 1)
             Vf = hierarchy.space(l, finest_space)
             P2, P1 = prolongations(Vc, Vf, hierarchy.parents[l])
-            self.velocity.append(interleave2(P2))
+            self.velocity.append(interleave(P2, finest_space.dim))
             self.pressure.append(P1)
 
     def chain(self, field, nlevels=None):

@@ -19,7 +19,7 @@ import scipy.sparse as sp
 
 from .mesh import Mesh, unit_square_mesh
 from .mesh import _LSHAPE_VERTICES, _LSHAPE_CELLS
-from .multigrid import MeshHierarchy, Interpolations
+from .multigrid import MeshHierarchy, CubeHierarchy, Interpolations
 from .taylor_hood import TaylorHood
 
 
@@ -90,8 +90,8 @@ class FlowProblem(object):
         # residual norms the nonlinear stopping test sees, not the solution).
         assert dirichlet_diag in ("unit", "multiplicity")
         mult = np.bincount(V.cell_dofs2.ravel(), minlength=V.nn).astype(float)
-        self._bc_mult = np.repeat(mult, 2) if dirichlet_diag == "multiplicity" \
-            else np.ones(V.n_u)
+        self._bc_mult = np.repeat(mult, V.dim) \
+            if dirichlet_diag == "multiplicity" else np.ones(V.n_u)
         self._classify_boundary()
         self.bc_u = _Dirichlet(V.n_u, self.bc_u_idx)
         self.bc_p = _Dirichlet(V.n_p, self.bc_p_idx)
@@ -161,7 +161,12 @@ class FlowProblem(object):
         return np.unique(V._pnum[m.edges[edges].ravel()])
 
     def nodal_velocity(self, xu):
-        return xu.reshape(-1, 2)
+        return xu.reshape(-1, self.space.dim)
+
+    def _velocity_dofs(self, nodes):
+        """All components of the given P2 nodes (interleaved numbering)."""
+        d = self.space.dim
+        return (d * np.asarray(nodes)[:, None] + np.arange(d)).ravel()
 
     # -- operators refreshed every nonlinear iteration ----------------------
     def Kp(self, xu):
@@ -247,7 +252,7 @@ class BackwardStep(FlowProblem):
         nodes = np.union1d(wall_nodes, inlet_nodes)
         self._bc_nodes = nodes
         self._inlet_nodes = inlet_nodes
-        self.bc_u_idx = np.stack([2 * nodes, 2 * nodes + 1], axis=1).ravel()
+        self.bc_u_idx = self._velocity_dofs(nodes)
         pe = inlet if self.variant == "BRM1" else outlet
         self.bc_p_idx = self._edge_dofs_p(pe)
         self.bc_p_val = np.zeros(self.bc_p_idx.size)
@@ -279,7 +284,7 @@ class Cavity(FlowProblem):
         V, m = self.space, self.space.mesh
         nodes = self._edge_dofs_u(m.boundary_edges)
         self._bc_nodes = nodes
-        self.bc_u_idx = np.stack([2 * nodes, 2 * nodes + 1], axis=1).ravel()
+        self.bc_u_idx = self._velocity_dofs(nodes)
         self.robin_edges = np.zeros(0, dtype=np.int64)
         # enclosed flow has no inlet/outlet: pin the Laplacian at one vertex
         # so that A_p is SPD (hard part 2)
@@ -293,5 +298,44 @@ class Cavity(FlowProblem):
         val = np.zeros((xy.shape[0], 2))
         lid = (np.abs(xy[:, 1] - 1.0) < 1e-12) & (xy[:, 0] > 1e-12) \
             & (xy[:, 0] < 1.0 - 1e-12)
+        val[lid, 0] = 1.0
+        return val.ravel()
+
+
+class Cavity3D(FlowProblem):
+    """Lid-driven unit-cube cavity (BASELINE config 5), P2/P1 on the Kuhn
+    triangulation of ``n0 * 2**level`` cubes per side; lid ``z = 1`` moves
+    with ``u = (1, 0, 0)`` (watertight: the lid's rim belongs to the walls)."""
+
+    def __init__(self, level, nu=0.01, n0=2, **kw):
+        self.level, self.n0 = level, n0
+        FlowProblem.__init__(self, CubeHierarchy(n0, level), nu, **kw)
+
+    def _same_problem_on_level(self, level):
+        kw = dict(nu=self.nu, variant=self.variant, nls=self.nls,
+                  pcdr=self.pcdr, stabilize=self.stabilize, n0=self.n0)
+        if self.idt:
+            kw["dt"] = 1.0 / self.idt
+        return Cavity3D(level, **kw)
+
+    def _classify_boundary(self):
+        V, m = self.space, self.space.mesh
+        nodes = np.unique(np.concatenate([
+            V._rank[m.boundary_vertices], V._rank[V.nv + m.boundary_edges]]))
+        self._bc_nodes = nodes
+        self.bc_u_idx = self._velocity_dofs(nodes)
+        self.robin_edges = np.zeros(0, dtype=np.int64)
+        c = V.p_coords
+        self.bc_p_idx = np.array([int(np.argmin(c.sum(axis=1)))])
+        self.bc_p_val = np.zeros(1)
+
+    def bc_u_values(self, t):
+        V = self.space
+        xyz = V.node_coords[self._bc_nodes]
+        val = np.zeros((xyz.shape[0], 3))
+        eps = 1e-12
+        lid = (np.abs(xyz[:, 2] - 1.0) < eps) \
+            & (xyz[:, 0] > eps) & (xyz[:, 0] < 1 - eps) \
+            & (xyz[:, 1] > eps) & (xyz[:, 1] < 1 - eps)
         val[lid, 0] = 1.0
         return val.ravel()

@@ -1,4 +1,5 @@
-"""P2/P1 Taylor-Hood discretisation on triangles, vectorised with numpy.
+"""P2/P1 Taylor-Hood discretisation on simplices (triangles, tetrahedra),
+vectorised with numpy.
 
 This is the *input producer* of the PCD engine: it stands in for the
 DOLFIN/FFC assembly the reference delegates to (``fenapack/assembling.py:
@@ -13,46 +14,70 @@ values (``fenapack/field_split_backend.py:79-83, 285-291``).
 Numbering
 ---------
 Nodes (vertices, then edge midpoints) are sorted lexicographically along the
-longest axis of the domain, so contiguous row blocks are geometric strips
-(at most two neighbours per strip: the row partition of SURVEY 8e).  The mixed
-space ``W = P2^2 x P1`` is numbered node-major: ``[ux, uy, p]`` on vertices,
-``[ux, uy]`` on edge midpoints - interleaved like DOLFIN's mixed dofmaps, so
-the fieldsplit index sets ``is_u`` / ``is_p`` are genuinely non-contiguous
-(``fenapack/field_split.py:71-73``).
+longest axis of the domain, so contiguous row blocks are geometric slabs
+(at most two neighbours per slab: the row partition of SURVEY 8e).  The mixed
+space ``W = P2^d x P1`` is numbered node-major: ``[u_0 .. u_{d-1}, p]`` on
+vertices, ``[u_0 .. u_{d-1}]`` on edge midpoints - interleaved like DOLFIN's
+mixed dofmaps, so the fieldsplit index sets ``is_u`` / ``is_p`` are genuinely
+non-contiguous (``fenapack/field_split.py:71-73``).
 """
 
 import numpy as np
 import scipy.sparse as sp
+from scipy.special import roots_jacobi
 
 # Dunavant 7-point rule, exact to degree 5 (enough for w(P2).grad u(P1) v(P2))
 _A1, _B1 = 0.059715871789770, 0.470142064105115
 _A2, _B2 = 0.797426985353087, 0.101286507323456
-_QP = np.array([[1 / 3., 1 / 3., 1 / 3.],
-                [_A1, _B1, _B1], [_B1, _A1, _B1], [_B1, _B1, _A1],
-                [_A2, _B2, _B2], [_B2, _A2, _B2], [_B2, _B2, _A2]])
-_QW = np.array([0.225] + [0.132394152788506] * 3 + [0.125939180544827] * 3)
+_QP2 = np.array([[1 / 3., 1 / 3., 1 / 3.],
+                 [_A1, _B1, _B1], [_B1, _A1, _B1], [_B1, _B1, _A1],
+                 [_A2, _B2, _B2], [_B2, _A2, _B2], [_B2, _B2, _A2]])
+_QW2 = np.array([0.225] + [0.132394152788506] * 3 + [0.125939180544827] * 3)
 
 # 3-point Gauss rule on [0, 1] (degree 5) for boundary integrals
 _G3X = 0.5 + 0.5 * np.array([-np.sqrt(0.6), 0.0, np.sqrt(0.6)])
 _G3W = 0.5 * np.array([5 / 9., 8 / 9., 5 / 9.])
 
 
-def _p2_basis(lam):
-    """P2 basis at barycentric points ``lam`` (nq, 3).
+def _tet_rule(n=3):
+    """Conical (Stroud) product of Gauss-Jacobi rules on the unit tetrahedron,
+    exact to degree 2n - 1 (n = 3: degree 5, 27 points, positive weights).
+    Returns barycentric points (nq, 4) and weights summing to 1."""
+    xa, wa = roots_jacobi(n, 2, 0)
+    xb, wb = roots_jacobi(n, 1, 0)
+    xc, wc = roots_jacobi(n, 0, 0)
+    xa, xb, xc = 0.5 * (xa + 1), 0.5 * (xb + 1), 0.5 * (xc + 1)
+    wa, wb, wc = wa / 8, wb / 4, wc / 2
+    pts, wts = [], []
+    for i in range(n):
+        for j in range(n):
+            for k in range(n):
+                x = xa[i]
+                y = xb[j] * (1 - xa[i])
+                z = xc[k] * (1 - xa[i]) * (1 - xb[j])
+                pts.append([1 - x - y - z, x, y, z])
+                wts.append(wa[i] * wb[j] * wc[k])
+    wts = np.array(wts)
+    return np.array(pts), wts / wts.sum()
 
-    Local dofs: vertices 0..2, then edge k (opposite vertex k) 3..5.
-    Returns (phi (nq, 6), dphi/dlam (nq, 6, 3)).
+
+def _p2_basis(lam, edges=((1, 2), (2, 0), (0, 1))):
+    """P2 basis at barycentric points ``lam`` (nq, d+1).
+
+    Local dofs: the d+1 vertices, then one per local edge (i, j) in the order
+    of ``edges``.  Returns (phi (nq, na), dphi/dlam (nq, na, d+1)).
     """
-    nq = lam.shape[0]
-    phi = np.empty((nq, 6))
-    dphi = np.zeros((nq, 6, 3))
-    for i in range(3):
+    nq, nvl = lam.shape
+    na = nvl + len(edges)
+    phi = np.empty((nq, na))
+    dphi = np.zeros((nq, na, nvl))
+    for i in range(nvl):
         phi[:, i] = lam[:, i] * (2 * lam[:, i] - 1)
         dphi[:, i, i] = 4 * lam[:, i] - 1
-    for k, (i, j) in enumerate(((1, 2), (2, 0), (0, 1))):
-        phi[:, 3 + k] = 4 * lam[:, i] * lam[:, j]
-        dphi[:, 3 + k, i] = 4 * lam[:, j]
-        dphi[:, 3 + k, j] = 4 * lam[:, i]
+    for k, (i, j) in enumerate(edges):
+        phi[:, nvl + k] = 4 * lam[:, i] * lam[:, j]
+        dphi[:, nvl + k, i] = 4 * lam[:, j]
+        dphi[:, nvl + k, j] = 4 * lam[:, i]
     return phi, dphi
 
 
@@ -94,20 +119,25 @@ class FixedPattern(object):
 
 
 class TaylorHood(object):
-    """P2 velocity / P1 pressure spaces on a :class:`Mesh`."""
+    """P2 velocity / P1 pressure spaces on a :class:`Mesh` (d = 2) or a
+    :class:`TetMesh` (d = 3)."""
 
     def __init__(self, mesh):
         self.mesh = mesh
+        self.dim = d = mesh.dim
+        self.local_edges = tuple(mesh.local_edges)
+        self.nvl = d + 1                              # vertices per cell
+        self.na = self.nvl + len(self.local_edges)    # P2 dofs per cell
         nv, ne = mesh.num_vertices, mesh.num_edges
         self.nv, self.ne = nv, ne
         self.nn = nn = nv + ne                       # scalar P2 dofs
         coords = np.concatenate([mesh.vertices, mesh.edge_midpoints()])
         ext = coords.max(axis=0) - coords.min(axis=0)
-        major = int(np.argmax(ext))
+        axes = list(np.argsort(-ext, kind="stable"))  # longest axis first
         # round so that nodes meant to share a coordinate compare equal
         # whatever sequence of midpoint averages produced them
         key = np.round(coords * 2.0 ** 30)
-        order = np.lexsort((key[:, 1 - major], key[:, major]))
+        order = np.lexsort(tuple(key[:, a] for a in reversed(axes)))
         rank = np.empty(nn, dtype=np.int64)
         rank[order] = np.arange(nn)
         self.node_coords = coords[order]             # by scalar P2 dof
@@ -123,44 +153,43 @@ class TaylorHood(object):
         self.cell_dofs1 = pnum[mesh.cells]
         self._rank, self._pnum = rank, pnum
         # sizes and fieldsplit index sets (mixed, node-major numbering)
-        self.n_u, self.n_p = 2 * nn, nv
+        self.n_u, self.n_p = d * nn, nv
         self.ndof = self.n_u + self.n_p
-        width = np.where(is_vertex_sorted, 3, 2)
+        width = np.where(is_vertex_sorted, d + 1, d)
         start = np.concatenate([[0], np.cumsum(width)[:-1]])
-        self.is_u = np.stack([start, start + 1], axis=1).ravel()
-        self.is_p = start[is_vertex_sorted] + 2
+        self.is_u = (start[:, None] + np.arange(d)).ravel()
+        self.is_p = start[is_vertex_sorted] + d
         self._geometry()
 
     # ------------------------------------------------------------------ geo
     def _geometry(self):
-        m = self.mesh
-        p = m.vertices[m.cells]                       # (nc, 3, 2)
-        e1, e2 = p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]
-        det = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
-        self.area = 0.5 * det
-        g = np.empty((m.num_cells, 3, 2))
-        # grad lambda_k = rot(edge opposite k) / det
-        g[:, 0, 0] = (p[:, 1, 1] - p[:, 2, 1]) / det
-        g[:, 0, 1] = (p[:, 2, 0] - p[:, 1, 0]) / det
-        g[:, 1, 0] = (p[:, 2, 1] - p[:, 0, 1]) / det
-        g[:, 1, 1] = (p[:, 0, 0] - p[:, 2, 0]) / det
-        g[:, 2, 0] = (p[:, 0, 1] - p[:, 1, 1]) / det
-        g[:, 2, 1] = (p[:, 1, 0] - p[:, 0, 0]) / det
+        m, d = self.mesh, self.dim
+        p = m.vertices[m.cells]                       # (nc, d+1, d)
+        # affine map x = p0 + T lam_{1..d}; rows of T^-1 are grad lam_{1..d}
+        T = np.stack([p[:, k + 1] - p[:, 0] for k in range(d)], axis=2)
+        det = np.linalg.det(T)
+        Tinv = np.linalg.inv(T)                       # (nc, d, d)
+        g = np.empty((m.num_cells, d + 1, d))
+        g[:, 1:, :] = Tinv
+        g[:, 0, :] = -Tinv.sum(axis=1)
         self.gradlam = g
-        self.phi, dphi = _p2_basis(_QP)                        # (nq,6)
-        self.gphi = np.einsum('qak,ckd->cqad', dphi, g)         # (nc,nq,6,2)
-        self.psi = _QP                                          # (nq,3)
-        self.wq = _QW[None, :] * self.area[:, None]             # (nc,nq)
-        longest = np.maximum.reduce([
-            np.linalg.norm(p[:, 1] - p[:, 0], axis=1),
-            np.linalg.norm(p[:, 2] - p[:, 1], axis=1),
-            np.linalg.norm(p[:, 0] - p[:, 2], axis=1)])
-        # DOLFIN Cell::h() = 2 * circumradius for simplices
-        self.cell_h = (np.linalg.norm(p[:, 1] - p[:, 0], axis=1)
-                       * np.linalg.norm(p[:, 2] - p[:, 1], axis=1)
-                       * np.linalg.norm(p[:, 0] - p[:, 2], axis=1)
-                       / (2.0 * self.area))
-        self.cell_hmax = longest
+        self.area = det / (2.0 if d == 2 else 6.0)    # cell measure
+        if d == 2:
+            qp, qw = _QP2, _QW2
+        else:
+            qp, qw = _tet_rule(3)
+        self.phi, dphi = _p2_basis(qp, self.local_edges)       # (nq, na)
+        self.gphi = np.einsum('qak,ckd->cqad', dphi, g)         # (nc,nq,na,d)
+        self.psi = qp                                           # (nq, d+1)
+        self.wq = qw[None, :] * self.area[:, None]              # (nc, nq)
+        edges = [np.linalg.norm(p[:, i] - p[:, j], axis=1)
+                 for i in range(d + 1) for j in range(i)]
+        self.cell_hmax = np.maximum.reduce(edges)
+        if d == 2:
+            # DOLFIN Cell::h() = 2 * circumradius for simplices
+            self.cell_h = edges[0] * edges[1] * edges[2] / (2.0 * self.area)
+        else:
+            self.cell_h = self.cell_hmax
 
     # ------------------------------------------------------------- patterns
     def _patterns(self, coupled):
@@ -168,29 +197,30 @@ class TaylorHood(object):
         key = "_pat_%d" % int(coupled)
         if hasattr(self, key):
             return getattr(self, key)
+        d, na, nvl = self.dim, self.na, self.nvl
         d2, d1 = self.cell_dofs2, self.cell_dofs1
-        r2 = np.repeat(d2[:, :, None], 6, axis=2)     # (nc,6,6) row = a
-        c2 = np.repeat(d2[:, None, :], 6, axis=1)     # col = b
+        r2 = np.repeat(d2[:, :, None], na, axis=2)    # (nc,na,na) row = a
+        c2 = np.repeat(d2[:, None, :], na, axis=1)    # col = b
+        comp = np.arange(d)
         pat = {}
         if coupled:
-            # rows (a,c) x cols (b,d), all four component pairs: (nc,6,6,2,2)
-            comp = np.arange(2)
-            rows = np.broadcast_to(2 * r2[..., None, None]
-                                   + comp[:, None], r2.shape + (2, 2))
-            cols = np.broadcast_to(2 * c2[..., None, None]
-                                   + comp[None, :], c2.shape + (2, 2))
+            # rows (a,c) x cols (b,e), all component pairs: (nc,na,na,d,d)
+            rows = np.broadcast_to(d * r2[..., None, None]
+                                   + comp[:, None], r2.shape + (d, d))
+            cols = np.broadcast_to(d * c2[..., None, None]
+                                   + comp[None, :], c2.shape + (d, d))
         else:
-            rows = 2 * r2[..., None] + np.arange(2)
-            cols = 2 * c2[..., None] + np.arange(2)
+            rows = d * r2[..., None] + comp
+            cols = d * c2[..., None] + comp
         pat["A00"] = FixedPattern(rows, cols, (self.n_u, self.n_u))
         # A01 rows (a,c) x cols j
-        r = 2 * np.repeat(d2[:, :, None], 3, axis=2)[..., None] + np.arange(2)
-        c = np.repeat(np.repeat(d1[:, None, :], 6, axis=1)[..., None], 2,
+        r = d * np.repeat(d2[:, :, None], nvl, axis=2)[..., None] + comp
+        c = np.repeat(np.repeat(d1[:, None, :], na, axis=1)[..., None], d,
                       axis=3)
         pat["A01"] = FixedPattern(r, c, (self.n_u, self.n_p))
         pat["A10"] = FixedPattern(c, r, (self.n_p, self.n_u))
-        r1 = np.repeat(d1[:, :, None], 3, axis=2)
-        c1 = np.repeat(d1[:, None, :], 3, axis=1)
+        r1 = np.repeat(d1[:, :, None], nvl, axis=2)
+        c1 = np.repeat(d1[:, None, :], nvl, axis=1)
         pat["PP"] = FixedPattern(r1, c1, (self.n_p, self.n_p))
         pat["SS"] = FixedPattern(r2, c2, (self.nn, self.nn))
         setattr(self, key, pat)
@@ -198,9 +228,9 @@ class TaylorHood(object):
 
     # ----------------------------------------------------- scalar P2 pieces
     def wind_at_qp(self, U):
-        """``U`` (nn, 2) nodal P2 velocity -> (nc, nq, 2) and its gradient
-        (nc, nq, 2[comp], 2[d])."""
-        Uc = U[self.cell_dofs2]                                 # (nc,6,2)
+        """``U`` (nn, d) nodal P2 velocity -> (nc, nq, d) and its gradient
+        (nc, nq, d[comp], d[deriv])."""
+        Uc = U[self.cell_dofs2]                                 # (nc,na,d)
         w = np.einsum('qa,cak->cqk', self.phi, Uc)
         gw = np.einsum('cqad,cak->cqkd', self.gphi, Uc)
         return w, gw
@@ -225,6 +255,7 @@ class TaylorHood(object):
     def assemble_A00(self, nu, U=None, idt=0.0, newton=False, delta=None):
         """Velocity block: nu*(grad u, grad v) + ((w.grad)u, v) [+ idt*(u,v)]
         [+ Newton term ((u.grad)w, v)] [+ SUPG]."""
+        d = self.dim
         pat = self._patterns(newton)["A00"]
         S = nu * self.p2_stiffness_cells()
         if idt:
@@ -235,13 +266,13 @@ class TaylorHood(object):
             if delta is not None:
                 S = S + self.p2_supg_cells(w, delta)
         if not newton:
-            vals = np.repeat(S[..., None], 2, axis=3)           # (nc,6,6,2)
+            vals = np.repeat(S[..., None], d, axis=3)           # (nc,na,na,d)
             return pat.assemble(vals)
-        vals = np.zeros(S.shape + (2, 2))
-        vals[..., 0, 0] = S
-        vals[..., 1, 1] = S
+        vals = np.zeros(S.shape + (d, d))
+        for k in range(d):
+            vals[..., k, k] = S
         if U is not None:
-            # N[(a,c),(b,d)] = int phi_a phi_b d_d w_c
+            # N[(a,c),(b,e)] = int phi_a phi_b d_e w_c
             N = np.einsum('cq,qa,qb,cqkd->cabkd', self.wq, self.phi, self.phi,
                           gw)
             vals += N
@@ -251,7 +282,7 @@ class TaylorHood(object):
         """Velocity mass matrix scale*(u, v) on the decoupled pattern."""
         pat = self._patterns(False)["A00"]
         M = scale * self.p2_mass_cells()
-        return pat.assemble(np.repeat(M[..., None], 2, axis=3))
+        return pat.assemble(np.repeat(M[..., None], self.dim, axis=3))
 
     def assemble_A01(self):
         """Discrete gradient block from ``-p div v`` (rows velocity)."""
@@ -296,7 +327,10 @@ class TaylorHood(object):
         return K
 
     def _boundary_flux_mass(self, U, edges):
-        """int_edges (w.n) p q ds as an n_p x n_p matrix on the PP pattern."""
+        """int_edges (w.n) p q ds as an n_p x n_p matrix on the PP pattern
+        (2D: boundary facets are edges)."""
+        if self.dim != 2:
+            raise NotImplementedError("Robin boundary term: 2D only")
         m = self.mesh
         pat = self._patterns(False)["PP"]
         ev = m.edges[edges]                                     # (nb,2)
@@ -338,8 +372,8 @@ class TaylorHood(object):
         """Streamline-diffusion parameter per cell, formula of
         ``fenapack/stabilization.py:66-67`` evaluated at the cell midpoint:
         ``Pe = 0.5*|w|*h*rho/nu; delta = Pe>1 ? 0.5*h*(1-1/Pe)/|w| : 0``."""
-        lam = np.full((1, 3), 1 / 3.)
-        phi, _ = _p2_basis(lam)
+        lam = np.full((1, self.nvl), 1.0 / self.nvl)
+        phi, _ = _p2_basis(lam, self.local_edges)
         wmid = np.einsum('a,cak->ck', phi[0], U[self.cell_dofs2])
         wnorm = np.linalg.norm(wmid, axis=1)
         h = self.cell_h

@@ -80,6 +80,7 @@ class PCDKSP(KSP):
 
         # the engine: one handle = PCD context + fieldsplit shell + GMRES
         self.engine = c.Engine(c.hip_library(), pcd_pc.variant, self.device)
+        self.engine.set_velocity_block(getattr(V, "dim", 2))
         import os
         forced = os.environ.get("PCD_FORCE_COMM") == "1"   # 1-rank RCCL test
         if self.comm is not None and (getattr(self.comm, "size", 1) > 1

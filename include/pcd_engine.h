@@ -206,6 +206,9 @@ int pcd_graph_enable(pcd_handle h, int on);
  * (pcd_comm_unique_id) and broadcast by the host (torch.distributed store).
  * After this call set_csr/set_system take GLOBAL matrices on every rank and
  * keep only the owned row block [row_begin, row_end) of each field. */
+/* velocity components per node (2 or 3): row cuts of velocity operators fall
+ * on node boundaries.  Call before handing operators over; default 2. */
+int pcd_set_velocity_block(pcd_handle h, int ncomp);
 int pcd_comm_unique_id(void* out128);
 int pcd_comm_init(pcd_handle h, int rank, int nranks,
                   const void* nccl_unique_id);

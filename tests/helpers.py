@@ -55,9 +55,9 @@ def flow_state(kind, level, variant="BRM1", picard_steps=2, **kw):
     if key in _state_cache:
         return _state_cache[key]
     import scipy.sparse.linalg as spla
-    from fenapack_amd.fem import BackwardStep, Cavity
-    pb = (BackwardStep if kind == "lshape" else Cavity)(level, variant=variant,
-                                                        **kw)
+    from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
+    cls = {"lshape": BackwardStep, "cavity": Cavity, "cube": Cavity3D}[kind]
+    pb = cls(level, variant=variant, **kw)
     V = pb.space
     xu, xp = pb.initial_guess()
     for _ in range(picard_steps):
@@ -78,6 +78,7 @@ def flow_state(kind, level, variant="BRM1", picard_steps=2, **kw):
 
 def configure_engine(e, st, with_system=True):
     pb = st["pb"]
+    e.set_velocity_block(st["V"].dim)
     e.set_csr(c.MAT_AP, pb.Ap)
     e.set_csr(c.MAT_MP, pb.Mp)
     e.set_csr(c.MAT_KP, st["Kp"])

@@ -140,3 +140,28 @@ def test_rccl_backend_single_rank_smoke(hip_lib, monkeypatch):
     x0, its0, _ = run(c.Engine(hip_lib, "BRM1", 0))
     assert its1 == its0
     assert relerr(x1, x0) < 1e-9
+
+
+def test_three_dimensional_problem_partitioned(hip_lib):
+    """3D (three velocity components per node): single engine and 2 / 3
+    threaded ranks against the oracle; row cuts must fall on node boundaries."""
+    st = flow_state("cube", 1, nu=0.1)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    I = pb.interpolations()
+
+    def work(e, rank):
+        configure_engine(e, st)
+        push_multigrid(e, c.KSP_AP, pb.Ap, I.chain("p"))
+        push_multigrid(e, c.KSP_A00, L["A00"], I.chain("u"))
+        e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 8, 0.0, 0.3, 2.6)
+        e.setup()
+        x, its, _ = e.gmres_np(st["b"], rtol=1e-8, restart=80, max_it=200)
+        return x, its, e.info(c.INFO_N_U_LOCAL)
+
+    xr, ir, _ = work(oracle.Engine("BRM1"), 0)
+    x1, i1, _ = work(c.Engine(hip_lib, "BRM1", 0), 0)
+    assert i1 == ir and relerr(x1, xr) < 1e-7
+    for R in (2, 3):
+        for x, its, nu_loc in run_ranks(hip_lib, R, "BRM1", work):
+            assert its == ir and relerr(x, xr) < 1e-7
+            assert nu_loc % 3 == 0

@@ -230,3 +230,36 @@ def test_prolongations_reproduce_polynomials():
     g = lambda xy: xy @ np.array([1.0, 2.0]) - 0.5
     assert abs(I.pressure[-1] @ g(Vc.p_coords) - g(V.p_coords)).max() < 1e-12
     assert len(I.chain("u", 2)) == 2 and I.chain("u", 2)[0] is None
+
+
+def test_three_dimensional_producer_and_solver_chain():
+    """BASELINE config 5 in miniature: lid-driven unit cube, P2/P1 on Kuhn
+    tetrahedra.  Checks the producer (volume, kernel of the Laplacian and of
+    the convection operator, divergence of a linear field, polynomial
+    exactness of the 3D prolongations) and the oracle's solver chain with
+    multigrid inner solves on it."""
+    from helpers import push_multigrid
+    st = flow_state("cube", 1, nu=0.1)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    assert V.dim == 3 and V.n_u == 3 * V.nn
+    one = np.ones(V.n_p)
+    assert abs(one @ pb.Mp @ one * pb.nu - 1.0) < 1e-12          # |cube| = 1
+    assert abs(V.assemble_Ap() @ one).max() < 1e-12
+    assert abs(st["Kp"] @ one).max() < 1e-12
+    U = np.zeros((V.nn, 3))
+    U[:, 1] = V.node_coords[:, 1]                                # div = 1
+    assert abs((pb._A10_raw @ U.ravel()).sum() + 1.0) < 1e-12
+    I = pb.interpolations()
+    Vc = pb.hierarchy.space(0)
+    f = lambda x: x[:, 0] ** 2 - 2 * x[:, 1] * x[:, 2] + x[:, 2]
+    P2 = I.velocity[-1][0::3, 0::3]
+    assert abs(P2 @ f(Vc.node_coords) - f(V.node_coords)).max() < 1e-12
+    e = oracle.Engine("BRM1")
+    configure_engine(e, st)
+    push_multigrid(e, c.KSP_AP, pb.Ap, I.chain("p"))
+    push_multigrid(e, c.KSP_A00, L["A00"], I.chain("u"))
+    e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 8, 0.0, 0.3, 2.6)
+    e.setup()
+    x, its, _ = e.gmres_np(st["b"], rtol=1e-8, restart=80, max_it=200)
+    assert its < 80
+    assert relerr(st["A"] @ x, st["b"]) < 1e-6
