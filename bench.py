@@ -32,7 +32,9 @@ def parse():
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--level", type=int, default=6)
-    p.add_argument("--geometry", default="cavity", choices=["cavity", "lshape"])
+    p.add_argument("--geometry", default="cavity",
+                   choices=["cavity", "lshape", "cube"])
+    p.add_argument("--n0", type=int, default=4)
     p.add_argument("--variant", default="BRM1", choices=["BRM1", "BRM2"])
     p.add_argument("--inner", default="mg", choices=["mg", "jacobi"])
     p.add_argument("--cycles-u", type=int, default=1)
@@ -71,12 +73,14 @@ def main():
     from fenapack_amd import roofline as rf
     from fenapack_amd.driver import (default_inner_options, make_solver,
                                      multigrid_inner_options)
-    from fenapack_amd.fem import BackwardStep, Cavity
+    from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
     from fenapack_amd.petsc import Vec
 
     t_setup = time.time()
     if args.geometry == "cavity":
         pb = Cavity(args.level, nu=0.01, variant=args.variant)   # Re = 100
+    elif args.geometry == "cube":                                # 3D, Re = 100
+        pb = Cavity3D(args.level, nu=0.01, n0=args.n0, variant=args.variant)
     else:
         pb = BackwardStep(args.level, nu=0.02, variant=args.variant)
     V = pb.space
@@ -224,7 +228,8 @@ def main():
                    % (k_f, args.a00_ratio)}
 
     out = {
-        "metric": "fieldsplit PCApply calls/sec (2D cavity Re=100, P2/P1)",
+        "metric": "fieldsplit PCApply calls/sec (%s Re=100, P2/P1)"
+                  % ("3D cavity" if args.geometry == "cube" else "2D cavity"),
         "value": args.steps / dt,
         "unit": "PCApply/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

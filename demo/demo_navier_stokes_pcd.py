@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from fenapack_amd.driver import (default_inner_options,               # noqa
                                  multigrid_inner_options, solve_steady)
-from fenapack_amd.fem import BackwardStep, Cavity                    # noqa
+from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D          # noqa
 
 p = argparse.ArgumentParser(description=__doc__)
 p.add_argument("-l", type=int, dest="level", default=4)
@@ -22,7 +22,10 @@ p.add_argument("--nu", type=float, dest="viscosity", default=None)
 p.add_argument("--pcd", dest="pcd_variant", default="BRM1",
                choices=["BRM1", "BRM2"])
 p.add_argument("--nls", default="picard", choices=["picard", "newton"])
-p.add_argument("--geometry", default="lshape", choices=["lshape", "cavity"])
+p.add_argument("--geometry", default="lshape",
+               choices=["lshape", "cavity", "cube"])
+p.add_argument("--n0", type=int, default=4,
+               help="cube: cells per side of the coarsest mesh")
 p.add_argument("--ls", default="mg", choices=["mg", "jacobi"],
                help="inner solvers: multigrid V-cycles (counterpart of the "
                     "reference's 'iterative' AMG setting) or plain "
@@ -44,10 +47,15 @@ if args.geometry == "lshape":
                       variant=args.pcd_variant, nls=args.nls,
                       stabilize=args.stabilize)
     print("Reynolds number: Re = %g" % (2.0 / pb.nu))
-else:
+elif args.geometry == "cavity":
     pb = Cavity(args.level, nu=args.viscosity or 0.01,
                 variant=args.pcd_variant, nls=args.nls,
                 stabilize=args.stabilize)
+    print("Reynolds number: Re = %g" % (1.0 / pb.nu))
+else:
+    pb = Cavity3D(args.level, nu=args.viscosity or 0.01, n0=args.n0,
+                  variant=args.pcd_variant, nls=args.nls,
+                  stabilize=args.stabilize)
     print("Reynolds number: Re = %g" % (1.0 / pb.nu))
 print("Dimension of the function space: %d" % pb.space.ndof)
 if args.ls == "mg":
