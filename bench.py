@@ -72,6 +72,7 @@ def main():
     from fenapack_amd import _cabi as c
     from fenapack_amd import roofline as rf
     from fenapack_amd.driver import (default_inner_options, make_solver,
+                                     mass_matrix_bounds,
                                      multigrid_inner_options)
     from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
     from fenapack_amd.petsc import Vec
@@ -87,11 +88,12 @@ def main():
     PETScOptions.clear()
     if args.inner == "mg":
         multigrid_inner_options(cycles_u=args.cycles_u, cycles_p=args.cycles_p,
-                                smooth=args.smooth, mp_its=args.mp_its)
+                                smooth=args.smooth, mp_its=args.mp_its,
+                                dim=V.dim)
     else:
         default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
                               ap_rtol=args.ap_rtol, ap_its=args.ap_its,
-                              mp_its=args.mp_its)
+                              mp_its=args.mp_its, dim=V.dim)
     from fenapack_amd.parallel import Comm
     comm = Comm.world()
     w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150,
@@ -211,7 +213,8 @@ def main():
             "Ap": "richardson x%d + mg V(%d,%d), %d levels"
                   % (k_a, args.smooth, args.smooth,
                      len(pcd.ksp_Ap.pc.mg_data["ops"])),
-            "Mp": "chebyshev+jacobi its %d eig [0.5,2]" % k_m,
+            "Mp": "chebyshev+jacobi its %d eig [%s]"
+                  % (k_m, mass_matrix_bounds(V.dim)),
             "A00": "richardson x%d + mg V(%d,%d), %d levels"
                    % (k_f, args.smooth, args.smooth,
                       len(ksp0.pc.mg_data["ops"]))}
@@ -223,7 +226,8 @@ def main():
                                    nnz(c.MAT_A01), bytes_pcd, k_f, ksp0.type)
         inner_desc = {
             "Ap": "cg+jacobi rtol %g (k_A=%d executed)" % (args.ap_rtol, k_a),
-            "Mp": "chebyshev+jacobi its %d eig [0.5,2]" % k_m,
+            "Mp": "chebyshev+jacobi its %d eig [%s]"
+                  % (k_m, mass_matrix_bounds(V.dim)),
             "A00": "chebyshev+jacobi its %d eig ratio %g"
                    % (k_f, args.a00_ratio)}
 

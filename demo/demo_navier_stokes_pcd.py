@@ -60,10 +60,11 @@ else:
 print("Dimension of the function space: %d" % pb.space.ndof)
 if args.ls == "mg":
     multigrid_inner_options(cycles_u=args.cycles, cycles_p=args.cycles,
-                            smooth=args.smooth,
+                            smooth=args.smooth, dim=pb.space.dim,
                             galerkin_u=args.mg_coarse == "galerkin")
 else:
-    default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio)
+    default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
+                          dim=pb.space.dim)
 out = solve_steady(pb, max_newton=25)
 print("Newton iterations: %d, converged: %s" % (out["newton_its"],
                                                 out["converged"]))

@@ -11,8 +11,16 @@ from . import (PCDAssembler, PCDKrylovSolver, PCDNewtonSolver,
 from .fem.forms import navier_stokes_forms
 
 
+def mass_matrix_bounds(dim):
+    """Eigenvalue bounds of ``diag(M)^-1 M`` for P1: [1/2, 2] on triangles
+    (the demos' setting, valid in 2D only:
+    demo/navier-stokes-pcd/documentation.rst:143-147), [1/2, 5/2] on
+    tetrahedra (Wathen 1987)."""
+    return "0.5, 2.0" if dim == 2 else "0.5, 2.5"
+
+
 def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
-                            mp_its=5, pcdr=False, galerkin_u=True):
+                            mp_its=5, pcdr=False, galerkin_u=True, dim=2):
     """The reference's "iterative" configuration (demo_navier-stokes-pcd.py:
     152-165: Richardson + one/two multigrid cycles for A00 and Ap, Chebyshev +
     Jacobi for Mp) with hypre BoomerAMG replaced by the engine's geometric
@@ -31,12 +39,13 @@ def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
         S(prefix + "fieldsplit_u_pc_mg_galerkin", "none")
     S(prefix + "fieldsplit_p_PCD_Mp_ksp_type", "chebyshev")
     S(prefix + "fieldsplit_p_PCD_Mp_ksp_max_it", mp_its)
-    S(prefix + "fieldsplit_p_PCD_Mp_ksp_chebyshev_eigenvalues", "0.5, 2.0")
+    S(prefix + "fieldsplit_p_PCD_Mp_ksp_chebyshev_eigenvalues",
+      mass_matrix_bounds(dim))
     S(prefix + "fieldsplit_p_PCD_Mp_pc_type", "jacobi")
 
 
 def default_inner_options(prefix="", a00_its=60, a00_ratio=0.01, ap_rtol=1e-8,
-                          ap_its=10000, mp_its=5, pcdr=False):
+                          ap_its=10000, mp_its=5, pcdr=False, dim=2):
     """North-star inner solvers expressed with the reference's option names
     (demo_navier-stokes-pcd.py:151-165 sets the same keys)."""
     S = PETScOptions.set
@@ -51,7 +60,8 @@ def default_inner_options(prefix="", a00_its=60, a00_ratio=0.01, ap_rtol=1e-8,
     S(prefix + "fieldsplit_p_PCD_Ap_pc_type", "jacobi")
     S(prefix + "fieldsplit_p_PCD_Mp_ksp_type", "chebyshev")
     S(prefix + "fieldsplit_p_PCD_Mp_ksp_max_it", mp_its)
-    S(prefix + "fieldsplit_p_PCD_Mp_ksp_chebyshev_eigenvalues", "0.5, 2.0")
+    S(prefix + "fieldsplit_p_PCD_Mp_ksp_chebyshev_eigenvalues",
+      mass_matrix_bounds(dim))
     S(prefix + "fieldsplit_p_PCD_Mp_pc_type", "jacobi")
     if pcdr:
         S(prefix + "fieldsplit_p_PCD_Rp_ksp_type", "cg")
