@@ -1132,6 +1132,9 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   HIPCHK(hipSetDevice(device));
   { const char* e = getenv("PCD_FORCE_CSR_VECTOR"); g_force_vector = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_KRON2"); g_no_kron = e && e[0] == '1'; }
+  { const char* e = getenv("PCD_NO_XCD_REMAP");
+    const int remap = (e && e[0] == '1') ? 0 : 1;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pcd::g_xcd_remap), &remap, sizeof(int))); }
   Engine* h = new (std::nothrow) Engine();
   if (!h) return fail(PCD_ERR_NOMEM, "create: out of host memory");
   h->variant = variant; h->device = device;

@@ -246,10 +246,15 @@ struct XCg {
   }
 };
 
+// 1: XCD-aware mapping (default); 0: workgroup b takes slot b (A/B switch
+// PCD_NO_XCD_REMAP=1, for measuring what the mapping is worth)
+__constant__ int g_xcd_remap = 1;
+
 // contiguous range of row blocks of this workgroup (gridDim.x multiple of 8)
 __device__ __forceinline__ void row_block_range(int nrb, int& begin, int& end) {
   const int G = gridDim.x;
-  const int slot = (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
+  const int slot = g_xcd_remap ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8
+                               : (int)blockIdx.x;
   begin = (int)((long long)slot * nrb / G);
   end = (int)((long long)(slot + 1) * nrb / G);
 }

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Time the fused Chebyshev step on the A00 of a cavity level (A/B switches:
+PCD_NO_XCD_REMAP, PCD_NO_KRON2, PCD_FORCE_CSR_VECTOR)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fenapack_amd import _cabi as c                       # noqa: E402
+from fenapack_amd.fem import Cavity                        # noqa: E402
+
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+pb = Cavity(level, nu=0.01)
+V = pb.space
+x, y = V.node_coords[:, 0], V.node_coords[:, 1]
+U = np.stack([np.sin(np.pi * x) ** 2 * np.sin(2 * np.pi * y),
+              -np.sin(2 * np.pi * x) * np.sin(np.pi * y) ** 2], axis=1)
+A00 = pb.linearise(U.ravel(), np.zeros(V.n_p))["A00"]
+import torch                                               # noqa: E402
+e = c.Engine(c.hip_library(), "BRM1", 0)
+e.set_csr(c.MAT_A00, A00)
+b = torch.randn(V.n_u, dtype=torch.float64, device="cuda")
+out = torch.empty_like(b)
+
+
+def t(m, reps=10):
+    e.set_inner(c.KSP_A00, "chebyshev", "jacobi", m, 0.0, 0.2, 2.2)
+    e.inner_solve(c.KSP_A00, b, out, c.MEM_DEVICE)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e.inner_solve(c.KSP_A00, b, out, c.MEM_DEVICE)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / reps)
+    return best
+
+
+us = (t(65) - t(1)) / 64 * 1e6
+nbytes = 12 * A00.nnz + 92 * V.n_u + 4
+print("level %d n_u %d nnz %d: %.2f us per launch, %.0f GB/s algorithmic (%s)"
+      % (level, V.n_u, A00.nnz, us, nbytes / us / 1e3,
+         " ".join(k for k in ("PCD_NO_XCD_REMAP", "PCD_NO_KRON2",
+                              "PCD_FORCE_CSR_VECTOR")
+                  if os.environ.get(k) == "1") or "default"))
