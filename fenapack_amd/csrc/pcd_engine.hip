@@ -76,11 +76,12 @@ struct DCsr {
   int lpr = 8;
   int rb = 0;             // rows per workgroup of the CSR-stream kernels (0: n/a)
   bool long_rows = false; // >= 256 nonzeros per row on average: workgroup per row
-  // two-component structure A = F (x) I_2 (kron2): F stored once
-  bool kron2 = false;
+  // multi-component structure A = F (x) I_kron (kron = 2, 3; 0: none): F
+  // stored once
+  int kron = 0;
   int rb2 = 0;
   int64_t nnz2 = 0;
-  DBuf<int> rowptr2, col2, pos_even, pos_odd;
+  DBuf<int> rowptr2, col2, kron_pos;
   DBuf<double> val2;
   DBuf<int> kron_flag;
   // multi-GPU: nrows / ncols are LOCAL counts (ncols = owned columns); ghost
@@ -93,8 +94,8 @@ struct DCsr {
   void release() {
     rowptr.release(); col.release(); val.release(); dinv.release();
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
-    rowptr2.release(); col2.release(); pos_even.release(); pos_odd.release();
-    val2.release(); kron_flag.release(); kron2 = false; rb2 = 0; nnz2 = 0;
+    rowptr2.release(); col2.release(); kron_pos.release();
+    val2.release(); kron_flag.release(); kron = 0; rb2 = 0; nnz2 = 0;
     plan = HaloPlan(); replicated = false;
     set = false; nrows = ncols = nnz = 0; has_src = false;
   }
@@ -301,37 +302,54 @@ static int reduce_global(Engine* h, double* parts, int nparts, double* slot,
   return 0;
 }
 
-#define LAUNCH_RB2(A, KERNEL, GRID, ...)                                        \
+#define LAUNCH_RBC_(NC, A, KERNEL, GRID, ...)                                   \
   do {                                                                          \
     switch ((A).rb2) {                                                          \
-      case 256: hipLaunchKernelGGL((KERNEL<256>), dim3(GRID), dim3(kBlock), 0,  \
-                                   h->stream, __VA_ARGS__); break;              \
-      case 128: hipLaunchKernelGGL((KERNEL<128>), dim3(GRID), dim3(kBlock), 0,  \
-                                   h->stream, __VA_ARGS__); break;              \
-      default: hipLaunchKernelGGL((KERNEL<64>), dim3(GRID), dim3(kBlock), 0,    \
-                                  h->stream, __VA_ARGS__); break;               \
+      case 256: hipLaunchKernelGGL((KERNEL<256, NC>), dim3(GRID), dim3(kBlock), \
+                                   0, h->stream, __VA_ARGS__); break;           \
+      case 128: hipLaunchKernelGGL((KERNEL<128, NC>), dim3(GRID), dim3(kBlock), \
+                                   0, h->stream, __VA_ARGS__); break;           \
+      default: hipLaunchKernelGGL((KERNEL<64, NC>), dim3(GRID), dim3(kBlock),   \
+                                  0, h->stream, __VA_ARGS__); break;            \
     }                                                                           \
   } while (0)
+#define LAUNCH_RBC(A, KERNEL, GRID, ...)                                        \
+  do {                                                                          \
+    if ((A).kron == 2) LAUNCH_RBC_(2, A, KERNEL, GRID, __VA_ARGS__);            \
+    else LAUNCH_RBC_(3, A, KERNEL, GRID, __VA_ARGS__);                          \
+  } while (0)
 
-static inline const double2* d2(const double* p) { return reinterpret_cast<const double2*>(p); }
-static inline double2* d2(double* p) { return reinterpret_cast<double2*>(p); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// the two-component kernels move 16-byte pairs; three components need no
+// more than the 8-byte alignment every double* has
+static inline bool kron_ok(const DCsr& A, const void* a, const void* b = nullptr,
+                           const void* c = nullptr, const void* d = nullptr) {
+  if (!A.kron) return false;
+  if (A.kron != 2) return true;
+  return aligned16(a) && aligned16(b) && aligned16(c) && aligned16(d);
+}
 
-// two-component operator: F streamed once, vectors as double2
+// multi-component operator: F streamed once, all components of a node together
+template <int MODE, int NC>
+static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
+                                const double* add, double* y) {
+  const int nn = (int)(A.nrows / NC);
+  const int g = grid_stream(nn, A.rb2);
+  const int nloc = (int)(A.ncols / NC);
+  switch (A.rb2) {
+    case 256: hipLaunchKernelGGL((k_spmv_sc<256, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
+                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
+    case 128: hipLaunchKernelGGL((k_spmv_sc<128, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
+                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
+    default: hipLaunchKernelGGL((k_spmv_sc<64, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
+                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
+  }
+}
 template <int MODE>
 static void launch_spmv_kron(Engine* h, const DCsr& A, const double* x,
                              const double* add, double* y) {
-  const int n2 = (int)(A.nrows / 2);
-  const int g = grid_stream(n2, A.rb2);
-  const XVec2 xv{d2(x), d2(A.ghost.p), (int)(A.ncols / 2)};
-  switch (A.rb2) {
-    case 256: hipLaunchKernelGGL((k_spmv_s2<256, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 n2, A.rowptr2.p, A.col2.p, A.val2.p, xv, d2(add), d2(y)); break;
-    case 128: hipLaunchKernelGGL((k_spmv_s2<128, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 n2, A.rowptr2.p, A.col2.p, A.val2.p, xv, d2(add), d2(y)); break;
-    default: hipLaunchKernelGGL((k_spmv_s2<64, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                n2, A.rowptr2.p, A.col2.p, A.val2.p, xv, d2(add), d2(y)); break;
-  }
+  if (A.kron == 2) launch_spmv_kron_nc<MODE, 2>(h, A, x, add, y);
+  else launch_spmv_kron_nc<MODE, 3>(h, A, x, add, y);
 }
 
 template <int MODE>
@@ -371,7 +389,7 @@ static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
                 int mode = 0, const double* add = nullptr) {
   if (!A.set) return fail(PCD_ERR_STATE, "spmv: operator not set");
   CHK(halo_exchange(h, A, x));
-  if (A.kron2 && aligned16(x) && aligned16(y) && aligned16(add)) {
+  if (kron_ok(A, x, y, add)) {
     if (mode == 0) launch_spmv_kron<0>(h, A, x, add, y);
     else if (mode == 1) launch_spmv_kron<1>(h, A, x, add, y);
     else launch_spmv_kron<2>(h, A, x, add, y);
@@ -445,11 +463,11 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                             double* pn, double c0, double c1, double c2) {
   const int n = (int)A.nrows;
   CHK(halo_exchange(h, A, pk));
-  if (A.kron2 && dinv && aligned16(b) && aligned16(pm) && aligned16(pk) && aligned16(pn)) {
-    const int n2 = n / 2;
-    LAUNCH_RB2(A, k_cheb_step_s2, grid_stream(n2, A.rb2), n2, A.rowptr2.p, A.col2.p,
-               A.val2.p, d2(dinv), d2(b), d2(pm), d2(pk), d2(pn), c0, c1, c2,
-               d2(A.ghost.p), (int)(A.ncols / 2));
+  if (dinv && kron_ok(A, b, pm, pk, pn)) {
+    const int nn = n / A.kron;
+    LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
+               A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
+               (int)(A.ncols / A.kron));
   } else if (A.rb) {
     LAUNCH_RB(A, k_cheb_step_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
               A.val.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, (int)A.ncols);
@@ -469,10 +487,10 @@ static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
                               const double* b, double* p0, double* pn, double s,
                               double c1, double c2) {
   const int n = (int)A.nrows;
-  if (A.kron2 && aligned16(b) && aligned16(p0) && aligned16(pn)) {
-    const int n2 = n / 2;
-    LAUNCH_RB2(A, k_cheb_first_s2, grid_stream(n2, A.rb2), n2, A.rowptr2.p, A.col2.p,
-               A.val2.p, d2(dinv), d2(b), d2(p0), d2(pn), s, c1, c2);
+  if (kron_ok(A, b, p0, pn)) {
+    const int nn = n / A.kron;
+    LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
+               A.val2.p, dinv, b, p0, pn, s, c1, c2);
     return;
   }
   LAUNCH_RB(A, k_cheb_first_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
@@ -950,57 +968,76 @@ static int io_end(IoMap& io) {
 
 static bool g_no_kron = false;         // PCD_NO_KRON2=1: A/B switch
 
-// After new values arrived: refresh F's values and verify that both
+// After new values arrived: refresh F's values and verify that all
 // components still carry the same numbers; otherwise drop to the general path.
 static int refresh_kron(Engine* h, DCsr& A) {
-  if (!A.kron2 || !A.nnz2) return 0;
+  if (!A.kron || !A.nnz2) return 0;
   HIPCHK(hipMemsetAsync(A.kron_flag.p, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(k_kron_gather, dim3(grid1d(A.nnz2, 4)), dim3(kBlock), 0,
-                     h->stream, (int)A.nnz2, A.pos_even.p, A.pos_odd.p, A.val.p,
+                     h->stream, (int)A.nnz2, A.kron, A.kron_pos.p, A.val.p,
                      A.val2.p, A.kron_flag.p);
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, A.kron_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (flag) A.kron2 = false;             // values differ between components
+  if (flag) A.kron = 0;                  // values differ between components
   return 0;
 }
 
-// pattern test for A = F (x) I_2 on interleaved dofs + compressed arrays
+// pattern test for A = F (x) I_nc on interleaved dofs
+static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                         const int32_t* col) {
+  if (nrows < nc || nrows % nc || ncols % nc) return false;
+  for (int64_t s = 0; s < nrows / nc; ++s) {
+    const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a;
+    for (int c = 1; c < nc; ++c)
+      if (rowptr[nc * s + c + 1] - rowptr[nc * s + c] != len) return false;
+    for (int32_t k = 0; k < len; ++k) {
+      if (col[a + k] % nc) return false;
+      for (int c = 1; c < nc; ++c)
+        if (col[rowptr[nc * s + c] + k] != col[a + k] + c) return false;
+    }
+  }
+  return true;
+}
+
+// detect the structure (the velocity block size first) + compressed arrays
 static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
                        const int32_t* rowptr, const int32_t* col, bool have_vals) {
-  A.kron2 = false; A.rb2 = 0; A.nnz2 = 0;
-  if (g_no_kron || nrows < 2 || (nrows & 1) || (ncols & 1) || rowptr[nrows] == 0) return 0;
-  const int64_t n2 = nrows / 2;
-  for (int64_t s = 0; s < n2; ++s) {
-    const int32_t a = rowptr[2 * s], b = rowptr[2 * s + 1], c = rowptr[2 * s + 2];
-    if (b - a != c - b) return 0;
-    for (int32_t k = 0; k < b - a; ++k)
-      if ((col[a + k] & 1) || col[b + k] != col[a + k] + 1) return 0;
-  }
-  std::vector<int32_t> rp2(n2 + 1, 0), c2, pe, po;
-  for (int64_t s = 0; s < n2; ++s) {
-    const int32_t a = rowptr[2 * s], b = rowptr[2 * s + 1];
-    for (int32_t k = 0; k < b - a; ++k) {
-      c2.push_back(col[a + k] / 2); pe.push_back(a + k); po.push_back(b + k);
+  A.kron = 0; A.rb2 = 0; A.nnz2 = 0;
+  if (g_no_kron || rowptr[nrows] == 0) return 0;
+  int nc = 0;
+  const int first = h->vel_block == 3 ? 3 : 2;
+  for (int cand : {first, 5 - first})
+    if (kron_pattern(cand, nrows, ncols, rowptr, col)) { nc = cand; break; }
+  if (!nc) return 0;
+  const int64_t nn = nrows / nc;
+  std::vector<int32_t> rpc(nn + 1, 0), cc;
+  std::vector<std::vector<int32_t>> pos(nc);
+  for (int64_t s = 0; s < nn; ++s) {
+    const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a;
+    for (int32_t k = 0; k < len; ++k) {
+      cc.push_back(col[a + k] / nc);
+      for (int c = 0; c < nc; ++c) pos[c].push_back(rowptr[nc * s + c] + k);
     }
-    rp2[s + 1] = (int32_t)c2.size();
+    rpc[s + 1] = (int32_t)cc.size();
   }
   int rb2 = 0;
   for (int rb : {256, 128, 64}) {
     bool ok = true;
-    for (int64_t r = 0; r < n2 && ok; r += rb)
-      if (rp2[std::min<int64_t>(r + rb, n2)] - rp2[r] > kTile2) ok = false;
+    for (int64_t r = 0; r < nn && ok; r += rb)
+      if (rpc[std::min<int64_t>(r + rb, nn)] - rpc[r] > kTileC) ok = false;
     if (ok) { rb2 = rb; break; }
   }
   if (!rb2) return 0;
-  A.nnz2 = (int64_t)c2.size();
-  CHK(A.rowptr2.ensure(n2 + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2));
-  CHK(A.pos_even.ensure(A.nnz2)); CHK(A.pos_odd.ensure(A.nnz2)); CHK(A.kron_flag.ensure(1));
-  HIPCHK(hipMemcpy(A.rowptr2.p, rp2.data(), (n2 + 1) * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(A.col2.p, c2.data(), A.nnz2 * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(A.pos_even.p, pe.data(), A.nnz2 * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(A.pos_odd.p, po.data(), A.nnz2 * sizeof(int), hipMemcpyHostToDevice));
-  A.kron2 = true; A.rb2 = rb2;
+  A.nnz2 = (int64_t)cc.size();
+  CHK(A.rowptr2.ensure(nn + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2));
+  CHK(A.kron_pos.ensure(nc * A.nnz2)); CHK(A.kron_flag.ensure(1));
+  HIPCHK(hipMemcpy(A.rowptr2.p, rpc.data(), (nn + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(A.col2.p, cc.data(), A.nnz2 * sizeof(int), hipMemcpyHostToDevice));
+  for (int c = 0; c < nc; ++c)
+    HIPCHK(hipMemcpy(A.kron_pos.p + c * A.nnz2, pos[c].data(), A.nnz2 * sizeof(int),
+                     hipMemcpyHostToDevice));
+  A.kron = nc; A.rb2 = rb2;
   if (have_vals) CHK(refresh_kron(h, A));
   return 0;
 }
@@ -1133,8 +1170,10 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_FORCE_CSR_VECTOR"); g_force_vector = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_KRON2"); g_no_kron = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_XCD_REMAP");
-    const int remap = (e && e[0] == '1') ? 0 : 1;
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pcd::g_xcd_remap), &remap, sizeof(int))); }
+    if (e && e[0] == '1') {
+      const int none = 0;
+      HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pcd::g_xcd_remap_max_rows), &none, sizeof(int)));
+    } }
   Engine* h = new (std::nothrow) Engine();
   if (!h) return fail(PCD_ERR_NOMEM, "create: out of host memory");
   h->variant = variant; h->device = device;

@@ -246,15 +246,18 @@ struct XCg {
   }
 };
 
-// 1: XCD-aware mapping (default); 0: workgroup b takes slot b (A/B switch
-// PCD_NO_XCD_REMAP=1, for measuring what the mapping is worth)
-__constant__ int g_xcd_remap = 1;
+// XCD-aware mapping for operators of up to this many (block) rows, i.e. while
+// matrix + vectors stay cache-resident between launches; larger operators
+// stream from HBM and do better with all XCDs walking one front (DESIGN.md
+// section 4 has the A/B).  PCD_NO_XCD_REMAP=1 sets it to 0.
+__constant__ int g_xcd_remap_max_rows = 1 << 20;
 
 // contiguous range of row blocks of this workgroup (gridDim.x multiple of 8)
-__device__ __forceinline__ void row_block_range(int nrb, int& begin, int& end) {
+__device__ __forceinline__ void row_block_range(int nrb, int rb_rows, int& begin, int& end) {
   const int G = gridDim.x;
-  const int slot = g_xcd_remap ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8
-                               : (int)blockIdx.x;
+  const bool remap = (long long)nrb * rb_rows <= g_xcd_remap_max_rows;
+  const int slot = remap ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8
+                         : (int)blockIdx.x;
   begin = (int)((long long)slot * nrb / G);
   end = (int)((long long)(slot + 1) * nrb / G);
 }
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_s(
   __shared__ double lds[kTile];
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, rb0, rb1);
+  row_block_range(nrb, RB, rb0, rb1);
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_s(
   __shared__ double lds[kTile];
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, rb0, rb1);
+  row_block_range(nrb, RB, rb0, rb1);
   const XVec xf{pk, ghost, nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_s(
   __shared__ double lds[kTile];
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, rb0, rb1);
+  row_block_range(nrb, RB, rb0, rb1);
   const XScaled xf{b, dinv, s};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_spmv_s(
   }
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, rb0, rb1);
+  row_block_range(nrb, RB, rb0, rb1);
   const XCg xf{z, p_old, beta, first != 0};
   double acc = 0.0;
   for (int rb = rb0; rb < rb1; ++rb) {
@@ -462,34 +465,60 @@ __global__ __launch_bounds__(kBlock) void k_cg_spmv_s(
 }
 
 // ==========================================================================
-// Two-component (Kronecker) operators: A = F (x) I_2 on interleaved dofs
-// (2*node + component).  Picard velocity blocks, their Galerkin coarse levels
-// and the velocity prolongations have this structure: both components of a
-// node see the same scalar stencil.  The engine then streams F ONCE (half the
-// matrix bytes) and carries both components as double2: 16-byte gathers and
-// coalesced 16-byte vector traffic.  Same three phases as the stream kernels.
+// Multi-component (Kronecker) operators: A = F (x) I_NC on interleaved dofs
+// (NC*node + component), NC = 2 (plane) or 3 (space).  Picard velocity blocks,
+// their Galerkin coarse levels and the velocity prolongations have this
+// structure: every component of a node sees the same scalar stencil.  The
+// engine then streams F ONCE (1/NC of the matrix bytes) and carries all
+// components of a node together: 16/24-byte gathers and coalesced vector
+// traffic.  Same three phases as the stream kernels.
 // ==========================================================================
-constexpr int kTile2 = 2048;      // LDS double2 per workgroup (32 KiB)
+constexpr int kTileC = 2048;      // LDS nodes per workgroup (32 / 48 KiB)
 
-struct XVec2 {
-  const double2* x; const double2* ghost; int nloc;      // in node units
-  __device__ __forceinline__ double2 operator()(int c) const {
+template <int NC>
+struct alignas(NC == 2 ? 16 : 8) VecC {
+  double c[NC];
+};
+template <int NC>
+__device__ __forceinline__ VecC<NC> vzero() {
+  VecC<NC> r;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) r.c[i] = 0.0;
+  return r;
+}
+template <int NC>
+__device__ __forceinline__ const VecC<NC>* vc(const double* p) {
+  return reinterpret_cast<const VecC<NC>*>(p);
+}
+template <int NC>
+__device__ __forceinline__ VecC<NC>* vc(double* p) {
+  return reinterpret_cast<VecC<NC>*>(p);
+}
+
+template <int NC>
+struct XVecC {
+  const VecC<NC>* x; const VecC<NC>* ghost; int nloc;      // in node units
+  __device__ __forceinline__ VecC<NC> operator()(int c) const {
     return c < nloc ? x[c] : ghost[c - nloc];
   }
 };
-struct XScaled2 {
-  const double2* b; const double2* dinv; double s;
-  __device__ __forceinline__ double2 operator()(int c) const {
-    const double2 d = dinv[c], v = b[c];
-    return make_double2(s * d.x * v.x, s * d.y * v.y);
+template <int NC>
+struct XScaledC {
+  const VecC<NC>* b; const VecC<NC>* dinv; double s;
+  __device__ __forceinline__ VecC<NC> operator()(int c) const {
+    const VecC<NC> d = dinv[c], v = b[c];
+    VecC<NC> r;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) r.c[i] = s * d.c[i] * v.c[i];
+    return r;
   }
 };
 
-template <int RB, class XF>
-__device__ __forceinline__ double2 stream_row_block2(
+template <int RB, int NC, class XF>
+__device__ __forceinline__ VecC<NC> stream_row_block_c(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const XF& xf, int r0, int nrows,
-    double2* lds) {
+    VecC<NC>* lds) {
   const int r1 = min(r0 + RB, nrows);
   const int k0 = rowptr[r0], k1 = rowptr[r1];
   const int row = r0 + threadIdx.x;
@@ -506,111 +535,142 @@ __device__ __forceinline__ double2 stream_row_block2(
       c[u] = in ? col[k] : -1;
       v[u] = in ? val[k] : 0.0;
     }
-    double2 xv[kUnroll];
+    VecC<NC> xv[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u)
-      xv[u] = c[u] >= 0 ? xf(c[u]) : make_double2(0.0, 0.0);
+      xv[u] = c[u] >= 0 ? xf(c[u]) : vzero<NC>();
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int k = base + u * kBlock + threadIdx.x;
-      if (k < k1) lds[k - k0] = make_double2(v[u] * xv[u].x, v[u] * xv[u].y);
+      if (k < k1) {
+        VecC<NC> t;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) t.c[i] = v[u] * xv[u].c[i];
+        lds[k - k0] = t;
+      }
     }
   }
   __syncthreads();
-  double2 s = make_double2(0.0, 0.0);
-  for (int j = ra; j < rb; ++j) { const double2 t = lds[j]; s.x += t.x; s.y += t.y; }
+  VecC<NC> s = vzero<NC>();
+  for (int j = ra; j < rb; ++j) {
+    const VecC<NC> t = lds[j];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] += t.c[i];
+  }
   return s;
 }
 
-template <int RB, int MODE>
-__global__ __launch_bounds__(kBlock) void k_spmv_s2(
+// vectors arrive as plain double* (node-interleaved) and are viewed as VecC
+template <int RB, int MODE, int NC>
+__global__ __launch_bounds__(kBlock) void k_spmv_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const XVec2 xf, const double2* add,
-    double2* y) {
-  __shared__ double2 lds[kTile2];
+    const double* __restrict__ val, const double* x, const double* ghost,
+    int nloc, const double* add_, double* y_) {
+  __shared__ VecC<NC> lds[kTileC];
+  const XVecC<NC> xf{vc<NC>(x), vc<NC>(ghost), nloc};
+  const VecC<NC>* add = vc<NC>(add_);
+  VecC<NC>* y = vc<NC>(y_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, rb0, rb1);
+  row_block_range(nrb, RB, rb0, rb1);
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x;
     const bool mine = threadIdx.x < RB && row < nrows;
-    double2 a = make_double2(0.0, 0.0);
+    VecC<NC> a = vzero<NC>();
     if (MODE != 0 && mine) a = add[row];          // early: hides under phase 1
-    const double2 s = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const VecC<NC> s = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
     if (mine) {
-      if (MODE == 0) y[row] = s;
-      if (MODE == 1) y[row] = make_double2(a.x + s.x, a.y + s.y);
-      if (MODE == 2) y[row] = make_double2(a.x - s.x, a.y - s.y);
+      VecC<NC> o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i] : a.c[i] - s.c[i]);
+      y[row] = o;
     }
     __syncthreads();
   }
 }
 
-template <int RB>
-__global__ __launch_bounds__(kBlock) void k_cheb_step_s2(
+template <int RB, int NC>
+__global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double2* __restrict__ dinv,
-    const double2* b, const double2* pm, const double2* pk, double2* pn,
-    double c0, double c1, double c2, const double2* ghost, int nloc) {
-  __shared__ double2 lds[kTile2];
+    const double* __restrict__ val, const double* __restrict__ dinv_,
+    const double* b_, const double* pm_, const double* pk_, double* pn_,
+    double c0, double c1, double c2, const double* ghost, int nloc) {
+  __shared__ VecC<NC> lds[kTileC];
+  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_), *pm = vc<NC>(pm_),
+               *pk = vc<NC>(pk_);
+  VecC<NC>* pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, rb0, rb1);
-  const XVec2 xf{pk, ghost, nloc};
+  row_block_range(nrb, RB, rb0, rb1);
+  const XVecC<NC> xf{pk, vc<NC>(ghost), nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x;
     const bool mine = threadIdx.x < RB && row < nrows;
     // the epilogue operands do not depend on the row sums: issue their loads
     // first so that their latency hides under the streaming phase
-    double2 bi = make_double2(0.0, 0.0), d = bi, xk = bi, xm = bi;
+    VecC<NC> bi = vzero<NC>(), d = bi, xk = bi, xm = bi;
     if (mine) {
       bi = b[row]; d = dinv[row]; xk = pk[row];
       if (c0 != 0.0) xm = pm[row];
     }
-    const double2 s = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
-    if (mine)
-      pn[row] = make_double2(c0 * xm.x + c1 * xk.x + c2 * d.x * (bi.x - s.x),
-                             c0 * xm.y + c1 * xk.y + c2 * d.y * (bi.y - s.y));
-    __syncthreads();
-  }
-}
-
-template <int RB>
-__global__ __launch_bounds__(kBlock) void k_cheb_first_s2(
-    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double2* __restrict__ dinv,
-    const double2* b, double2* p0, double2* pn, double s, double c1, double c2) {
-  __shared__ double2 lds[kTile2];
-  const int nrb = (nrows + RB - 1) / RB;
-  int rb0, rb1;
-  row_block_range(nrb, rb0, rb1);
-  const XScaled2 xf{b, dinv, s};
-  for (int rb = rb0; rb < rb1; ++rb) {
-    const int r0 = rb * RB;
-    const double2 sum = stream_row_block2<RB>(rowptr, col, val, xf, r0, nrows, lds);
-    const int row = r0 + threadIdx.x;
-    if (threadIdx.x < RB && row < nrows) {
-      const double2 d = dinv[row], bi = b[row];
-      const double2 x0 = make_double2(s * d.x * bi.x, s * d.y * bi.y);
-      if (p0) p0[row] = x0;
-      pn[row] = make_double2(c1 * x0.x + c2 * d.x * (bi.x - sum.x),
-                             c1 * x0.y + c2 * d.y * (bi.y - sum.y));
+    const VecC<NC> s = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
+    if (mine) {
+      VecC<NC> o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = c0 * xm.c[i] + c1 * xk.c[i] + c2 * d.c[i] * (bi.c[i] - s.c[i]);
+      pn[row] = o;
     }
     __syncthreads();
   }
 }
 
-// val2[k] = val[pos_even[k]]; *mismatch |= (val[pos_even[k]] != val[pos_odd[k]])
+template <int RB, int NC>
+__global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* __restrict__ dinv_,
+    const double* b_, double* p0_, double* pn_, double s, double c1, double c2) {
+  __shared__ VecC<NC> lds[kTileC];
+  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
+  VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, RB, rb0, rb1);
+  const XScaledC<NC> xf{b, dinv, s};
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const VecC<NC> sum = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
+    const int row = r0 + threadIdx.x;
+    if (threadIdx.x < RB && row < nrows) {
+      const VecC<NC> d = dinv[row], bi = b[row];
+      VecC<NC> x0, o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        x0.c[i] = s * d.c[i] * bi.c[i];
+        o.c[i] = c1 * x0.c[i] + c2 * d.c[i] * (bi.c[i] - sum.c[i]);
+      }
+      if (p0) p0[row] = x0;
+      pn[row] = o;
+    }
+    __syncthreads();
+  }
+}
+
+// valc[k] = val[pos[k]]; *mismatch |= (val[pos[c*nnzc + k]] differs, c >= 1):
+// pos holds, component-major, where the entry k of F sits in each component's
+// rows of the full matrix
 __global__ __launch_bounds__(kBlock) void k_kron_gather(
-    int nnz2, const int* __restrict__ pos_even, const int* __restrict__ pos_odd,
-    const double* val, double* val2, int* mismatch) {
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < nnz2;
+    int nnzc, int nc, const int* __restrict__ pos, const double* val,
+    double* valc, int* mismatch) {
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < nnzc;
        k += gridDim.x * kBlock) {
-    const double a = val[pos_even[k]], b = val[pos_odd[k]];
-    val2[k] = a;
-    if (a != b) *mismatch = 1;
+    const double a = val[pos[k]];
+    valc[k] = a;
+    for (int c = 1; c < nc; ++c)
+      if (val[pos[(int64_t)c * nnzc + k]] != a) *mismatch = 1;
   }
 }
 

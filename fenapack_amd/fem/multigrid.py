@@ -14,11 +14,30 @@ import scipy.sparse as sp
 from .taylor_hood import TaylorHood, _p2_basis
 
 
+#: the numpy producer holds every element matrix of a level at once; beyond this
+#: many cells on the finest level (largest sizes exercised: 819 200 triangles,
+#: 196 608 tetrahedra) it may exhaust host memory before anything reaches the
+#: GPU.  A mistyped level must fail here, not take the machine down; override
+#: with FENAPACK_AMD_MAX_CELLS on a host with the memory for it.
+MAX_FINEST_CELLS = {2: 1_000_000, 3: 800_000}
+
+
+def _check_size(cells, dim, what):
+    import os
+    limit = int(os.environ.get("FENAPACK_AMD_MAX_CELLS", MAX_FINEST_CELLS[dim]))
+    if cells > limit:
+        raise ValueError("%s: %.3g cells on the finest level exceed the host "
+                         "assembler's limit of %d (FENAPACK_AMD_MAX_CELLS)"
+                         % (what, cells, limit))
+
+
 class MeshHierarchy(object):
     """``meshes[0]`` (coarsest) ... ``meshes[-1]``; ``parents[l][f]`` = cell of
     level ``l-1`` containing fine cell ``f`` of level ``l``."""
 
     def __init__(self, base, levels):
+        _check_size(float(base.num_cells) * float(2 ** base.dim) ** levels,
+                    base.dim, "MeshHierarchy(levels=%d)" % levels)
         self.meshes, self.parents = [base], [None]
         for _ in range(levels):
             m = self.meshes[-1]
@@ -46,6 +65,8 @@ class CubeHierarchy(MeshHierarchy):
 
     def __init__(self, n0, levels):
         from .mesh import unit_cube_mesh, kuhn_parents
+        _check_size(6.0 * (float(n0) * 2.0 ** levels) ** 3, 3,
+                    "CubeHierarchy(n0=%d, levels=%d)" % (n0, levels))
         self.meshes, self.parents = [unit_cube_mesh(n0)], [None]
         for l in range(1, levels + 1):
             fine = unit_cube_mesh(n0 * 2 ** l)

@@ -49,14 +49,15 @@ def test_spmv_random_shapes(hip_lib, n, m, avg, long_rows):
         assert relerr(e.spmv_np(c.MAT_KP, x, n), ref) < 1e-13
 
 
+@pytest.mark.parametrize("nc", [2, 3])
 @pytest.mark.parametrize("nodes,mnodes", [(1, 1), (33, 33), (500, 321),
                                           (4000, 4000)])
-def test_two_component_operators_and_near_misses(hip_lib, nodes, mnodes):
+def test_multi_component_operators_and_near_misses(hip_lib, nodes, mnodes, nc):
     rng = np.random.default_rng(nodes)
     F = _random_csr(rng, nodes, mnodes, 9, empty_frac=0.0)
-    K = sp.kron(F, sp.identity(2), format="csr")
+    K = sp.kron(F, sp.identity(nc), format="csr")
     K.sort_indices()
-    x = rng.standard_normal(2 * mnodes)
+    x = rng.standard_normal(nc * mnodes)
     variants = [K]
     # near misses: one value differs / one entry removed / odd size
     K2 = K.copy()
@@ -74,6 +75,32 @@ def test_two_component_operators_and_near_misses(hip_lib, nodes, mnodes):
         e = c.Engine(hip_lib, "BRM1", 0)
         e.set_csr(c.MAT_A01, M)
         assert relerr(e.spmv_np(c.MAT_A01, x, M.shape[0]), M @ x) < 1e-13
+
+
+@pytest.mark.parametrize("nc", [2, 3])
+@pytest.mark.parametrize("nodes", [1, 70, 2500])
+def test_smoother_on_multi_component_spd(hip_lib, nodes, nc):
+    """F (x) I_nc with F SPD: the fused multi-component Chebyshev start/step
+    (and their fall-back when one value breaks the structure)."""
+    rng = np.random.default_rng(nodes + nc)
+    B = _random_csr(rng, nodes, nodes, 6, empty_frac=0.0)
+    F = (B @ B.T + sp.identity(nodes) * (1.0 + abs(B).sum(axis=1).max())).tocsr()
+    A = sp.kron(F, sp.identity(nc), format="csr")
+    A.sort_indices()
+    b = rng.standard_normal(nc * nodes)
+    A_broken = A.copy()
+    A_broken.data[A.indptr[-1] - 1] *= 1.25
+    for M in (A, A_broken):
+        e, o = c.Engine(hip_lib, "BRM1", 0), oracle.Engine("BRM1")
+        for eng in (e, o):
+            eng.set_csr(c.MAT_AP, M)
+        for cfg in (("chebyshev", "jacobi", 1, 0.0, 0.3, 1.8),
+                    ("chebyshev", "jacobi", 6, 0.0, 0.3, 1.8),
+                    ("richardson", "jacobi", 3, 0.0)):
+            e.set_inner(c.KSP_AP, *cfg)
+            o.set_inner(c.KSP_AP, *cfg)
+            assert relerr(e.inner_solve_np(c.KSP_AP, b),
+                          o.inner_solve_np(c.KSP_AP, b)) < 1e-11, cfg
 
 
 @pytest.mark.parametrize("n", [1, 64, 257, 3000])
