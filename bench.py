@@ -259,7 +259,7 @@ def main():
         "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_cheb_step_s2 / k_cheb_step_s (finest A00)",
+            "kernel": "k_cheb_step_sc (F x I_dim) / k_cheb_step_s (finest A00)",
             "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / rf.HBM_PEAK_GBS,
             "bytes_per_launch": int(b_kernel),

@@ -207,8 +207,10 @@ static int choose_lpr(const DCsr& A) {
 
 // rows per workgroup for the CSR-stream kernels: the largest of 256/128/64
 // whose every row block fits the LDS tile; 0 = some row block is too long
+static int g_max_rb = 256;              // PCD_MAX_RB: A/B switch
 static int choose_rb(int64_t nrows, const int32_t* rowptr) {
-  for (int rb : {256, 128, 64}) {
+  for (int rb : {256, 128, 64, 32}) {
+    if (rb > g_max_rb) continue;
     bool ok = true;
     for (int64_t r = 0; r < nrows && ok; r += rb) {
       const int64_t r1 = std::min<int64_t>(r + rb, nrows);
@@ -257,7 +259,9 @@ static int ensure_pinned(Engine* h, size_t n) {
                                    h->stream, __VA_ARGS__); break;              \
       case 128: hipLaunchKernelGGL((KERNEL<128>), dim3(GRID), dim3(kBlock), 0,  \
                                    h->stream, __VA_ARGS__); break;              \
-      default: hipLaunchKernelGGL((KERNEL<64>), dim3(GRID), dim3(kBlock), 0,    \
+      case 64: hipLaunchKernelGGL((KERNEL<64>), dim3(GRID), dim3(kBlock), 0,    \
+                                  h->stream, __VA_ARGS__); break;               \
+      default: hipLaunchKernelGGL((KERNEL<32>), dim3(GRID), dim3(kBlock), 0,    \
                                   h->stream, __VA_ARGS__); break;               \
     }                                                                           \
   } while (0)
@@ -309,7 +313,9 @@ static int reduce_global(Engine* h, double* parts, int nparts, double* slot,
                                    0, h->stream, __VA_ARGS__); break;           \
       case 128: hipLaunchKernelGGL((KERNEL<128, NC>), dim3(GRID), dim3(kBlock), \
                                    0, h->stream, __VA_ARGS__); break;           \
-      default: hipLaunchKernelGGL((KERNEL<64, NC>), dim3(GRID), dim3(kBlock),   \
+      case 64: hipLaunchKernelGGL((KERNEL<64, NC>), dim3(GRID), dim3(kBlock),   \
+                                  0, h->stream, __VA_ARGS__); break;            \
+      default: hipLaunchKernelGGL((KERNEL<32, NC>), dim3(GRID), dim3(kBlock),   \
                                   0, h->stream, __VA_ARGS__); break;            \
     }                                                                           \
   } while (0)
@@ -341,7 +347,9 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
                                  nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
     case 128: hipLaunchKernelGGL((k_spmv_sc<128, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
                                  nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
-    default: hipLaunchKernelGGL((k_spmv_sc<64, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
+    case 64: hipLaunchKernelGGL((k_spmv_sc<64, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
+                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
+    default: hipLaunchKernelGGL((k_spmv_sc<32, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
   }
 }
@@ -362,7 +370,9 @@ static void launch_spmv_stream(Engine* h, const DCsr& A, const double* x,
                                  (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
     case 128: hipLaunchKernelGGL((k_spmv_s<128, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
                                  (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
-    default: hipLaunchKernelGGL((k_spmv_s<64, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+    case 64: hipLaunchKernelGGL((k_spmv_s<64, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+    default: hipLaunchKernelGGL((k_spmv_s<32, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
   }
 }
@@ -1022,7 +1032,8 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     rpc[s + 1] = (int32_t)cc.size();
   }
   int rb2 = 0;
-  for (int rb : {256, 128, 64}) {
+  for (int rb : {256, 128, 64, 32}) {
+    if (rb > g_max_rb) continue;
     bool ok = true;
     for (int64_t r = 0; r < nn && ok; r += rb)
       if (rpc[std::min<int64_t>(r + rb, nn)] - rpc[r] > kTileC) ok = false;
@@ -1169,6 +1180,7 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   HIPCHK(hipSetDevice(device));
   { const char* e = getenv("PCD_FORCE_CSR_VECTOR"); g_force_vector = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_KRON2"); g_no_kron = e && e[0] == '1'; }
+  { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
   { const char* e = getenv("PCD_NO_XCD_REMAP");
     if (e && e[0] == '1') {
       const int none = 0;

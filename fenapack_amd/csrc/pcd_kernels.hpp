@@ -227,10 +227,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(
 // CSR-stream kernels (the fast path).  One workgroup owns RB consecutive rows.
 // Phase 1 streams that row block's val/col arrays with unit-stride lanes
 // (fully coalesced, several independent loads in flight per lane), multiplies
-// by the gathered vector entry and parks the products in LDS.  Phase 2: one
-// thread per row sums its LDS segment in index order (same order as a scalar
-// CPU loop).  Phase 3: the fused epilogue runs thread-per-row, so the vector
-// operands (b, p_k, p_{k-1}, diag) are read and written coalesced as well.
+// by the gathered vector entry and parks the products in LDS.  Phase 2: the
+// 256/RB lanes of a row sum its LDS segment (strided, then a xor-butterfly:
+// a fixed order, so results are reproducible; RB = 256 is the scalar CPU
+// order).  Phase 3: the fused epilogue runs on the first lane of each row, so
+// the vector operands (b, p_k, p_{k-1}, diag) stay coalesced as well.
 // Workgroups are mapped to row blocks XCD-aware: workgroups b, b+8, b+16, ...
 // share an XCD (round-robin dispatch), so they are given CONTIGUOUS row-block
 // ranges - each XCD's private L2 then holds one slab of the gathered vector
@@ -274,8 +275,10 @@ __device__ __forceinline__ double stream_row_block(
     double* lds) {
   const int r1 = min(r0 + RB, nrows);
   const int k0 = rowptr[r0], k1 = rowptr[r1];
-  const int row = r0 + threadIdx.x;
-  const bool mine = threadIdx.x < RB && row < r1;
+  constexpr int TPR = kBlock / RB;          // lanes that share one row's sum
+  const int row = r0 + threadIdx.x / TPR;
+  const int sub = threadIdx.x % TPR;
+  const bool mine = row < r1;
   // this lane's own row bounds, fetched up front (used after the barrier)
   const int ra = mine ? rowptr[row] - k0 : 0;
   const int rb = mine ? rowptr[row + 1] - k0 : 0;
@@ -300,8 +303,10 @@ __device__ __forceinline__ double stream_row_block(
   }
   __syncthreads();
   double s = 0.0;
-  for (int j = ra; j < rb; ++j) s += lds[j];
-  return s;
+  for (int j = ra + sub; j < rb; j += TPR) s += lds[j];
+#pragma unroll
+  for (int m = TPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m);
+  return s;                                  // on every lane of the row
 }
 
 template <int RB, int MODE>
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_s(
   row_block_range(nrb, RB, rb0, rb1);
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const int row = r0 + threadIdx.x;
-    const bool mine = threadIdx.x < RB && row < nrows;
+    const int row = r0 + threadIdx.x / (kBlock / RB);
+    const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     double a = 0.0;
     if (MODE != 0 && mine) a = add[row];          // early: hides under phase 1
     const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
@@ -342,8 +347,8 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_s(
   const XVec xf{pk, ghost, nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const int row = r0 + threadIdx.x;
-    const bool mine = threadIdx.x < RB && row < nrows;
+    const int row = r0 + threadIdx.x / (kBlock / RB);
+    const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     // epilogue operands first: their latency hides under the streaming phase
     double bi = 0.0, d = 1.0, xk = 0.0, xm = 0.0;
     if (mine) {
@@ -380,8 +385,8 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_s(
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const double sum = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
-    const int row = r0 + threadIdx.x;
-    if (threadIdx.x < RB && row < nrows) {
+    const int row = r0 + threadIdx.x / (kBlock / RB);
+    if (threadIdx.x % (kBlock / RB) == 0 && row < nrows) {
       const double d = dinv[row], bi = b[row];
       const double x0 = s * d * bi;
       if (p0) p0[row] = x0;
@@ -451,8 +456,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_spmv_s(
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
-    const int row = r0 + threadIdx.x;
-    if (threadIdx.x < RB && row < nrows) {
+    const int row = r0 + threadIdx.x / (kBlock / RB);
+    if (threadIdx.x % (kBlock / RB) == 0 && row < nrows) {
       const double pn = xf(row);
       p_new[row] = pn;
       q[row] = s;
@@ -521,8 +526,10 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
     VecC<NC>* lds) {
   const int r1 = min(r0 + RB, nrows);
   const int k0 = rowptr[r0], k1 = rowptr[r1];
-  const int row = r0 + threadIdx.x;
-  const bool mine = threadIdx.x < RB && row < r1;
+  constexpr int TPR = kBlock / RB;          // lanes that share one row's sum
+  const int row = r0 + threadIdx.x / TPR;
+  const int sub = threadIdx.x % TPR;
+  const bool mine = row < r1;
   const int ra = mine ? rowptr[row] - k0 : 0;
   const int rb = mine ? rowptr[row + 1] - k0 : 0;
   for (int base = k0; base < k1; base += kUnroll * kBlock) {
@@ -552,12 +559,17 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
   }
   __syncthreads();
   VecC<NC> s = vzero<NC>();
-  for (int j = ra; j < rb; ++j) {
+  for (int j = ra + sub; j < rb; j += TPR) {
     const VecC<NC> t = lds[j];
 #pragma unroll
     for (int i = 0; i < NC; ++i) s.c[i] += t.c[i];
   }
-  return s;
+#pragma unroll
+  for (int m = TPR / 2; m > 0; m >>= 1) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] += __shfl_xor(s.c[i], m);
+  }
+  return s;                                  // on every lane of the row
 }
 
 // vectors arrive as plain double* (node-interleaved) and are viewed as VecC
@@ -575,8 +587,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
   row_block_range(nrb, RB, rb0, rb1);
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const int row = r0 + threadIdx.x;
-    const bool mine = threadIdx.x < RB && row < nrows;
+    const int row = r0 + threadIdx.x / (kBlock / RB);
+    const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     VecC<NC> a = vzero<NC>();
     if (MODE != 0 && mine) a = add[row];          // early: hides under phase 1
     const VecC<NC> s = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
@@ -607,8 +619,8 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
   const XVecC<NC> xf{pk, vc<NC>(ghost), nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const int row = r0 + threadIdx.x;
-    const bool mine = threadIdx.x < RB && row < nrows;
+    const int row = r0 + threadIdx.x / (kBlock / RB);
+    const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     // the epilogue operands do not depend on the row sums: issue their loads
     // first so that their latency hides under the streaming phase
     VecC<NC> bi = vzero<NC>(), d = bi, xk = bi, xm = bi;
@@ -643,8 +655,8 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const VecC<NC> sum = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
-    const int row = r0 + threadIdx.x;
-    if (threadIdx.x < RB && row < nrows) {
+    const int row = r0 + threadIdx.x / (kBlock / RB);
+    if (threadIdx.x % (kBlock / RB) == 0 && row < nrows) {
       const VecC<NC> d = dinv[row], bi = b[row];
       VecC<NC> x0, o;
 #pragma unroll

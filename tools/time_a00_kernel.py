@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the fused Chebyshev step on the A00 of a cavity level (A/B switches:
-PCD_NO_XCD_REMAP, PCD_NO_KRON2, PCD_FORCE_CSR_VECTOR)."""
+PCD_NO_XCD_REMAP, PCD_NO_KRON2, PCD_FORCE_CSR_VECTOR, PCD_MAX_RB)."""
 import os
 import sys
 import time
@@ -43,6 +43,6 @@ us = (t(65) - t(1)) / 64 * 1e6
 nbytes = 12 * A00.nnz + 92 * V.n_u + 4
 print("level %d n_u %d nnz %d: %.2f us per launch, %.0f GB/s algorithmic (%s)"
       % (level, V.n_u, A00.nnz, us, nbytes / us / 1e3,
-         " ".join(k for k in ("PCD_NO_XCD_REMAP", "PCD_NO_KRON2",
-                              "PCD_FORCE_CSR_VECTOR")
-                  if os.environ.get(k) == "1") or "default"))
+         " ".join("%s=%s" % (k, os.environ[k]) for k in
+                  ("PCD_NO_XCD_REMAP", "PCD_NO_KRON2", "PCD_FORCE_CSR_VECTOR",
+                   "PCD_MAX_RB") if k in os.environ) or "default"))
