@@ -179,6 +179,46 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # SURVEY 8(d) extras, outside the timed region, rank-local:
+    #  * per-call latency distribution (each call synchronised: includes the
+    #    launch/sync overhead that back-to-back calls hide)
+    #  * the pressure-only PCD apply rate (PCDPC_*.apply alone)
+    #  * the practical bandwidth roof of this box: device-to-device copy of
+    #    1 GiB (read + write bytes / time)
+    lat = []
+    for _ in range(100):
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    lat = np.sort(np.array(lat)) * 1e3
+    xp_, yp_ = x.t[nu_loc:nu_loc + np_loc].clone(), None
+    yp_ = torch.empty_like(xp_)
+    for _ in range(10):
+        eng.apply(xp_, yp_, c.MEM_DEVICE)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(100):
+        eng.apply(xp_, yp_, c.MEM_DEVICE)
+    torch.cuda.synchronize()
+    rate_pcd = 100 / (time.perf_counter() - t1)
+    src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    try:
+        import petsc4py                                    # noqa: F401
+        have_petsc = True       # never the case on this image
+    except Exception:
+        have_petsc = False
+
     # the same call with HOST pointers (PCIe both ways + synchronisation per
     # call): reported for reference, never as `value`
     rate_host = None
@@ -254,7 +294,11 @@ def main():
             "parallelism": "row partition x%d" % world,
         },
         "gmres_its_per_newton_step": gmres_per_step,
+        "pcapply_ms_synchronised_p10_median_p90": [
+            float(lat[10]), float(lat[50]), float(lat[90])],
+        "pcd_apply_per_s_pressure_only": rate_pcd,
         "pcapply_per_s_host_pointers_pcie_inclusive": rate_host,
+        "petsc4py_available": have_petsc,
         "algorithmic_bytes_per_pcapply": int(bytes_pc),
         "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
         "roofline": {
@@ -264,6 +308,7 @@ def main():
             "frac": achieved / rf.HBM_PEAK_GBS,
             "bytes_per_launch": int(b_kernel),
             "us_per_launch": 1e6 * t_kernel,
+            "measured_d2d_copy_gbs": copy_gbs,
             "traffic": pmc_traffic(int(V.n_u), nnz_a00, world),
         },
         "setup_seconds": t_setup,

@@ -67,6 +67,20 @@ _HIP_ONLY = {
     "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "graph_enable": [C.c_int],
     "set_velocity_block": [C.c_int],
+    # device operator producer
+    "fe_begin": [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                 C.c_void_p, C.c_void_p],
+    "fe_set_level": [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                     C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                     C.c_void_p, C.c_void_p],
+    "fe_bind_system": [C.c_void_p],
+    "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
+    "fe_bind_mg": [C.c_int, C.c_double, C.c_double, C.c_int],
+    "fe_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
+    "fe_get_level_values": [C.c_int, C.c_void_p],
+    "fe_get_kp_values": [C.c_void_p],
+    "fe_get_bounds": [C.c_int, _f64p, _f64p],
 }
 
 #: every symbol include/pcd_engine.h declares (checked by the CPU test-suite)
@@ -276,6 +290,59 @@ class Engine(object):
 
     def graph_enable(self, on=True):
         self._call("graph_enable", int(bool(on)))
+
+    # -- device operator producer (HIP only) ------------------------------------
+    def fe_begin(self, dim, nlevels, qw, phi, dphi, psi):
+        qw, phi, dphi, psi = _f64(qw), _f64(phi), _f64(dphi), _f64(psi)
+        self._call("fe_begin", int(dim), int(nlevels), int(qw.size), _ptr(qw),
+                   _ptr(phi), _ptr(dphi), _ptr(psi))
+
+    def fe_set_level(self, level, dofs2, gradlam, measure, f_ptr, f_src,
+                     f_const, f_keep, diag_pos, diag_val, inject, nn2):
+        """Arrays already component-major (see include/pcd_engine.h)."""
+        dofs2, f_ptr, f_src = _i32(dofs2), _i32(f_ptr), _i32(f_src)
+        gradlam, measure = _f64(gradlam), _f64(measure)
+        f_const, diag_val = _f64(f_const), _f64(diag_val)
+        f_keep = np.ascontiguousarray(f_keep, dtype=np.uint8)
+        diag_pos = _i32(diag_pos)
+        inj = None if inject is None else _i32(inject)
+        self._call("fe_set_level", int(level), int(measure.size), int(nn2),
+                   _ptr(dofs2), _ptr(gradlam), _ptr(measure),
+                   int(f_const.size), _ptr(f_ptr), _ptr(f_src), _ptr(f_const),
+                   _ptr(f_keep), int(diag_pos.size), _ptr(diag_pos),
+                   _ptr(diag_val), _ptr(inj))
+
+    def fe_bind_system(self, sys_pos):
+        sys_pos = np.ascontiguousarray(sys_pos, dtype=np.int64)
+        self._call("fe_bind_system", _ptr(sys_pos))
+
+    def fe_bind_kp(self, kp_ptr, kp_src, kp_const, scale):
+        kp_ptr, kp_src = _i32(kp_ptr), _i32(kp_src)
+        cst = None if kp_const is None else _f64(kp_const)
+        self._call("fe_bind_kp", int(kp_ptr.size - 1), _ptr(kp_ptr),
+                   _ptr(kp_src), _ptr(cst), float(scale))
+
+    def fe_bind_mg(self, slot, emin_factor, emax_factor, iters=12):
+        self._call("fe_bind_mg", int(slot), float(emin_factor),
+                   float(emax_factor), int(iters))
+
+    def fe_update(self, xu, v=None, ru=None, mem=MEM_HOST):
+        self._call("fe_update", _ptr(xu), _ptr(v), _ptr(ru), mem)
+
+    def fe_level_values(self, level, nnz):
+        out = np.empty(int(nnz))
+        self._call("fe_get_level_values", int(level), _ptr(out))
+        return out
+
+    def fe_kp_values(self, nnz):
+        out = np.empty(int(nnz))
+        self._call("fe_get_kp_values", _ptr(out))
+        return out
+
+    def fe_bounds(self, level):
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        self._call("fe_get_bounds", int(level), C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def comm_init(self, rank, nranks, unique_id_bytes):
         buf = C.create_string_buffer(bytes(unique_id_bytes), 128)

@@ -15,6 +15,7 @@
 
 #include "../../include/pcd_engine.h"
 #include "pcd_kernels.hpp"
+#include "pcd_fe.hpp"
 #include "pcd_dist.hpp"
 
 using namespace pcd;
@@ -140,7 +141,10 @@ struct Inner {
   }
 };
 
+struct FeState;                        // device operator producer (pcd_fe_host.hpp)
+
 struct pcd_engine_s {
+  FeState* fe = nullptr;
   int variant = PCD_BRM1;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -184,6 +188,8 @@ struct pcd_engine_s {
 };
 
 typedef pcd_engine_s Engine;
+
+static void fe_release(pcd_engine_s* h);
 
 static const int kSlotMat[PCD_KSP_COUNT] = {PCD_MAT_AP, PCD_MAT_MP, PCD_MAT_RP,
                                             PCD_MAT_A00};
@@ -1197,6 +1203,7 @@ int pcd_destroy(pcd_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  fe_release(h);
   for (auto& m : h->mat) m.release();
   for (auto& s : h->inner) s.release();
   h->bc_idx.release(); h->bc_val.release(); h->bc_slot.release(); h->perm.release();
@@ -1954,3 +1961,5 @@ int pcd_dist_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
 }
 
 }  // extern "C"
+
+#include "pcd_fe_host.hpp"

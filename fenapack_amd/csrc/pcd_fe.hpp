@@ -1,0 +1,215 @@
+// Device operator producer: the matrices that change every nonlinear iteration
+// (convection part of the velocity block on every multigrid level, Kp) are
+// assembled in HBM from the iterate, straight into the engine's operators.
+//
+// Replaces, for the fixed P2/P1 Picard forms, the per-iteration callbacks of
+// fenapack/assembling.py:151-189 (`system_matrix`, `kp`) that the reference
+// hands to DOLFIN's assembler [ext]; SURVEY.md section 8(f1).
+//
+// Design (MI355X): element loops are embarrassingly parallel and tiny per
+// cell, so the layout is what matters -
+//   * every per-cell array is stored component-major ([entry][cell]) so that
+//     consecutive lanes (= consecutive cells) read and write unit-stride;
+//   * one thread per (cell, local row) keeps the register footprint at one
+//     element-matrix row (10 doubles in 3-D) instead of the full 10 x 10;
+//   * the scatter is a GATHER: every CSR entry sums its (<= ~6 in 2-D)
+//     element contributions from a precomputed list, in a fixed order - no
+//     atomics, bitwise reproducible, and the Dirichlet treatment
+//     (`keep` mask + diagonal values) rides on the same pass.
+// Included by pcd_engine.hip after the engine types.
+#pragma once
+
+namespace pcd {
+
+struct FeTables {
+  int nq;
+  const double* qw;     // nq          reference weights (sum = 1)
+  const double* phi;    // nq * NA     P2 basis at the quadrature points
+  const double* dphi;   // nq * NA * NV  d phi_a / d lambda_k
+  const double* psi;    // nq * NV     P1 basis (= barycentric coordinates)
+};
+
+// One thread per (cell c, local row a): row a of the P2 convection matrix
+//   C[a][b] = sum_q w_q |K| phi_a(q) (w(q) . grad phi_b(q)),
+//   w(q) = sum_a phi_a(q) U_a.
+// dofs2 [a][c], gradlam [(k*DIM+d)][c], cells out [(a*NA+b)][c].
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void k_fe_convection_p2(
+    int nc, const int* __restrict__ dofs2, const double* __restrict__ gradlam,
+    const double* __restrict__ measure, const FeTables T,
+    const double* __restrict__ U, double* __restrict__ cells) {
+  constexpr int NV = DIM + 1, NA = DIM == 2 ? 6 : 10;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= (int64_t)NA * nc) return;
+  const int a = (int)(t / nc), c = (int)(t % nc);
+  double g[NV][DIM], Uc[NA][DIM], acc[NA];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) g[k][d] = gradlam[(int64_t)(k * DIM + d) * nc + c];
+#pragma unroll
+  for (int b = 0; b < NA; ++b) {
+    const int node = dofs2[(int64_t)b * nc + c];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) Uc[b][d] = U[(int64_t)DIM * node + d];
+    acc[b] = 0.0;
+  }
+  const double meas = measure[c];
+  for (int q = 0; q < T.nq; ++q) {
+    double w[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) w[d] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NA; ++b) {
+      const double ph = T.phi[q * NA + b];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) w[d] += ph * Uc[b][d];
+    }
+    double wl[NV];                       // w . grad lambda_k
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) s += w[d] * g[k][d];
+      wl[k] = s;
+    }
+    const double f = T.qw[q] * meas * T.phi[q * NA + a];
+#pragma unroll
+    for (int b = 0; b < NA; ++b) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) s += T.dphi[(q * NA + b) * NV + k] * wl[k];
+      acc[b] += f * s;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NA; ++b) cells[(int64_t)(a * NA + b) * nc + c] = acc[b];
+}
+
+// One thread per cell: P1 convection matrix of the pressure space
+//   K[i][j] = scale * sum_q w_q |K| psi_i(q) (w(q) . grad lambda_j)
+// (grad lambda_j is constant on the cell); cells out [(i*NV+j)][c].
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void k_fe_convection_p1(
+    int nc, const int* __restrict__ dofs2, const double* __restrict__ gradlam,
+    const double* __restrict__ measure, const FeTables T,
+    const double* __restrict__ U, double scale, double* __restrict__ cells) {
+  constexpr int NV = DIM + 1, NA = DIM == 2 ? 6 : 10;
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= nc) return;
+  double g[NV][DIM], Uc[NA][DIM], m[NV][DIM];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      g[k][d] = gradlam[(int64_t)(k * DIM + d) * nc + c];
+      m[k][d] = 0.0;
+    }
+#pragma unroll
+  for (int b = 0; b < NA; ++b) {
+    const int node = dofs2[(int64_t)b * nc + c];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) Uc[b][d] = U[(int64_t)DIM * node + d];
+  }
+  const double meas = measure[c] * scale;
+  for (int q = 0; q < T.nq; ++q) {
+    double w[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) w[d] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NA; ++b) {
+      const double ph = T.phi[q * NA + b];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) w[d] += ph * Uc[b][d];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const double f = T.qw[q] * meas * T.psi[q * NV + i];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) m[i][d] += f * w[d];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) s += m[i][d] * g[j][d];
+      cells[(int64_t)(i * NV + j) * nc + c] = s;
+    }
+}
+
+// entry k = cst[k] + sum of its element contributions (list order); `unc`
+// (optional) receives the unconstrained value, `out` the one with Dirichlet
+// rows/columns removed (keep[k] == 0)
+__global__ __launch_bounds__(kBlock) void k_fe_gather(
+    int64_t nnz, const int* __restrict__ ptr, const int* __restrict__ src,
+    const double* __restrict__ cells, const double* __restrict__ cst,
+    const unsigned char* __restrict__ keep, double* unc, double* out) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
+       k += (int64_t)gridDim.x * kBlock) {
+    double s = cst ? cst[k] : 0.0;
+    for (int t = ptr[k]; t < ptr[k + 1]; ++t) s += cells[src[t]];
+    if (unc) unc[k] = s;
+    out[k] = (keep && !keep[k]) ? 0.0 : s;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fe_set(
+    int n, const int* __restrict__ pos, const double* __restrict__ val,
+    double* out) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    out[pos[i]] = val[i];
+}
+
+// dst[pos[c * nnz + k]] = F[k], c < ncomp: the scalar operator written into
+// every component's entries of an interleaved (F x I) matrix
+template <class I>
+__global__ __launch_bounds__(kBlock) void k_fe_scatter(
+    int64_t nnz, int ncomp, const I* __restrict__ pos,
+    const double* __restrict__ F, double* dst) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
+       k += (int64_t)gridDim.x * kBlock) {
+    const double v = F[k];
+    for (int c = 0; c < ncomp; ++c) dst[pos[(int64_t)c * nnz + k]] = v;
+  }
+}
+
+// wind of the next coarser level by injection (P2 spaces are nested)
+__global__ __launch_bounds__(kBlock) void k_fe_inject(
+    int64_t nn, int dim, const int* __restrict__ inject,
+    const double* __restrict__ Uf, double* Uc) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nn;
+       i += (int64_t)gridDim.x * kBlock) {
+    const int64_t j = inject[i];
+    for (int d = 0; d < dim; ++d) Uc[dim * i + d] = Uf[dim * j + d];
+  }
+}
+
+// power iteration helper: y *= dinv (if given); parts[block] = sum y^2
+__global__ __launch_bounds__(kBlock) void k_fe_scale_sqnorm(
+    int64_t n, const double* __restrict__ dinv, double* y, double* parts) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kBlock) {
+    const double v = dinv ? y[i] * dinv[i] : y[i];
+    y[i] = v;
+    s += v * v;
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) parts[blockIdx.x] = s;
+}
+
+// deterministic start vector of the power iteration
+__global__ __launch_bounds__(kBlock) void k_fe_seed(int64_t n, double* v) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kBlock) {
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+    v[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  }
+}
+
+}  // namespace pcd

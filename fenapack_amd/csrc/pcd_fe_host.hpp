@@ -1,0 +1,374 @@
+// Host side of the device operator producer (kernels: pcd_fe.hpp); included at
+// the end of pcd_engine.hip.  One FE level per multigrid level of the velocity
+// block (coarsest first); the finest level writes the caller's system values,
+// the intermediate ones the multigrid operators, the coarsest one is handed
+// back to the host (its explicit inverse is a host computation).
+#pragma once
+
+struct FeLevel {
+  int64_t nc = 0, nn2 = 0, nnzf = 0, ndiag = 0;
+  DBuf<int> dofs2, f_ptr, f_src, diag_pos, inject;
+  DBuf<double> gradlam, measure, f_const, diag_val;
+  DBuf<unsigned char> f_keep;
+  DBuf<double> U, cells, F, ev;
+  bool set = false, ev_init = false;
+  void release() {
+    dofs2.release(); f_ptr.release(); f_src.release(); diag_pos.release();
+    inject.release(); gradlam.release(); measure.release(); f_const.release();
+    diag_val.release(); f_keep.release(); U.release(); cells.release();
+    F.release(); ev.release();
+  }
+};
+
+struct FeState {
+  int dim = 0, nlev = 0, nq = 0;
+  DBuf<double> qw, phi, dphi, psi;
+  std::vector<FeLevel> lev;
+  DBuf<double> Func;                 // unconstrained finest values (residual)
+  DBuf<int64_t> sys_pos; bool sys_bound = false;
+  int64_t nnz_kp = 0; double kp_scale = 1.0; bool kp_bound = false;
+  DBuf<int> kp_ptr, kp_src;
+  DBuf<double> kp_const, kp_cells, kp_vals;
+  int mg_slot = -1, est_iters = 12;
+  double emin_f = 0.1, emax_f = 1.1;
+  DBuf<double> xu, v, ru, y, parts, slot;
+  void release() {
+    for (auto& l : lev) l.release();
+    lev.clear();
+    qw.release(); phi.release(); dphi.release(); psi.release(); Func.release();
+    sys_pos.release(); kp_ptr.release(); kp_src.release(); kp_const.release();
+    kp_cells.release(); kp_vals.release(); xu.release(); v.release();
+    ru.release(); y.release(); parts.release(); slot.release();
+  }
+};
+
+static void fe_release(Engine* h) {
+  if (!h->fe) return;
+  h->fe->release();
+  delete h->fe;
+  h->fe = nullptr;
+}
+
+template <class T>
+static int fe_upload(DBuf<T>& b, const T* src, size_t n) {
+  CHK(b.ensure(n));
+  if (n) HIPCHK(hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static FeTables fe_tables(const FeState& fe) {
+  return FeTables{fe.nq, fe.qw.p, fe.phi.p, fe.dphi.p, fe.psi.p};
+}
+
+// assemble the scalar velocity operator of one level from the wind `U`
+static int fe_assemble_level(Engine* h, FeState& fe, FeLevel& L, const double* U,
+                             double* unc) {
+  const int na = fe.dim == 2 ? 6 : 10;
+  const int64_t nt = (int64_t)na * L.nc;
+  const int g = (int)((nt + kBlock - 1) / kBlock);
+  if (fe.dim == 2)
+    hipLaunchKernelGGL(k_fe_convection_p2<2>, dim3(g), dim3(kBlock), 0, h->stream,
+                       (int)L.nc, L.dofs2.p, L.gradlam.p, L.measure.p, fe_tables(fe), U, L.cells.p);
+  else
+    hipLaunchKernelGGL(k_fe_convection_p2<3>, dim3(g), dim3(kBlock), 0, h->stream,
+                       (int)L.nc, L.dofs2.p, L.gradlam.p, L.measure.p, fe_tables(fe), U, L.cells.p);
+  hipLaunchKernelGGL(k_fe_gather, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
+                     L.nnzf, L.f_ptr.p, L.f_src.p, L.cells.p, L.f_const.p, L.f_keep.p, unc, L.F.p);
+  if (L.ndiag)
+    hipLaunchKernelGGL(k_fe_set, dim3(grid1d(L.ndiag)), dim3(kBlock), 0, h->stream,
+                       (int)L.ndiag, L.diag_pos.p, L.diag_val.p, L.F.p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// largest eigenvalue (modulus) of D^-1 A by power iteration, warm-started
+static int fe_estimate_emax(Engine* h, FeState& fe, FeLevel& L, const DCsr& A,
+                            double* lam_out) {
+  const int64_t n = A.nrows;
+  CHK(L.ev.ensure(n)); CHK(fe.y.ensure(n));
+  CHK(fe.parts.ensure(1024)); CHK(fe.slot.ensure(1));
+  const int g = grid1d(n, 4, 1024);
+  int iters = fe.est_iters;
+  double lam = 1.0;
+  auto sqnorm_of_y = [&](const double* dinv, double* out) -> int {
+    hipLaunchKernelGGL(k_fe_scale_sqnorm, dim3(g), dim3(kBlock), 0, h->stream, n, dinv, fe.y.p, fe.parts.p);
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, h->stream, fe.parts.p, g, 0, fe.slot.p);
+    double s = 0.0;
+    HIPCHK(hipMemcpyAsync(&s, fe.slot.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = std::sqrt(s);
+    return 0;
+  };
+  if (!L.ev_init) {
+    hipLaunchKernelGGL(k_fe_seed, dim3(g), dim3(kBlock), 0, h->stream, n, fe.y.p);
+    double nrm = 0.0;
+    CHK(sqnorm_of_y(nullptr, &nrm));
+    if (!(nrm > 0.0)) return fail(PCD_ERR_STATE, "fe: zero start vector");
+    hipLaunchKernelGGL(k_axpby, dim3(grid1d(n, 4)), dim3(kBlock), 0, h->stream, (int)n, 1.0 / nrm, fe.y.p, 0.0, L.ev.p);
+    L.ev_init = true;
+  } else {
+    iters = std::max(3, iters / 4);
+  }
+  for (int it = 0; it < iters; ++it) {
+    CHK(spmv(h, A, L.ev.p, fe.y.p));
+    CHK(sqnorm_of_y(A.dinv.p, &lam));
+    if (!(lam > 0.0) || !std::isfinite(lam))
+      return fail(PCD_ERR_STATE, "fe: eigenvalue estimate broke down (%g)", lam);
+    hipLaunchKernelGGL(k_axpby, dim3(grid1d(n, 4)), dim3(kBlock), 0, h->stream, (int)n, 1.0 / lam, fe.y.p, 0.0, L.ev.p);
+  }
+  *lam_out = lam;
+  return 0;
+}
+
+extern "C" {
+
+int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
+                 const double* phi, const double* dphi, const double* psi) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (dim != 2 && dim != 3) return fail(PCD_ERR_ARG, "fe_begin: dim must be 2 or 3");
+  if (nlevels < 1 || nlevels > 32 || nq < 1 || !qw || !phi || !dphi || !psi)
+    return fail(PCD_ERR_ARG, "fe_begin: bad arguments");
+  if (h->comm) return fail(PCD_ERR_STATE, "fe_begin: the device producer runs on one GPU");
+  HIPCHK(hipSetDevice(h->device));
+  fe_release(h);
+  h->fe = new FeState();
+  FeState& fe = *h->fe;
+  fe.dim = dim; fe.nlev = nlevels; fe.nq = nq;
+  const int na = dim == 2 ? 6 : 10, nv = dim + 1;
+  CHK(fe_upload(fe.qw, qw, nq));
+  CHK(fe_upload(fe.phi, phi, (size_t)nq * na));
+  CHK(fe_upload(fe.dphi, dphi, (size_t)nq * na * nv));
+  CHK(fe_upload(fe.psi, psi, (size_t)nq * nv));
+  fe.lev.resize(nlevels);
+  return 0;
+}
+
+int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
+                     const int32_t* dofs2, const double* gradlam,
+                     const double* measure, int64_t nnz_f, const int32_t* f_ptr,
+                     const int32_t* f_src, const double* f_const,
+                     const unsigned char* f_keep, int64_t n_diag,
+                     const int32_t* diag_pos, const double* diag_val,
+                     const int32_t* inject) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_level: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev) return fail(PCD_ERR_ARG, "fe_set_level: bad level %d", level);
+  if (ncells < 1 || nn2 < 1 || nnz_f < 1 || !dofs2 || !gradlam || !measure || !f_ptr || !f_src ||
+      !f_const || !f_keep || n_diag < 0 || (n_diag && (!diag_pos || !diag_val)))
+    return fail(PCD_ERR_ARG, "fe_set_level: bad arguments");
+  if ((level == fe.nlev - 1) != (inject == nullptr))
+    return fail(PCD_ERR_ARG, "fe_set_level: every level but the finest needs an injection map");
+  const int na = fe.dim == 2 ? 6 : 10, nv = fe.dim + 1;
+  if ((int64_t)na * na * ncells >= INT32_MAX)
+    return fail(PCD_ERR_ARG, "fe_set_level: element storage exceeds int32 indexing");
+  HIPCHK(hipSetDevice(h->device));
+  FeLevel& L = fe.lev[level];
+  L.nc = ncells; L.nn2 = nn2; L.nnzf = nnz_f; L.ndiag = n_diag;
+  CHK(fe_upload(L.dofs2, dofs2, (size_t)na * ncells));
+  CHK(fe_upload(L.gradlam, gradlam, (size_t)nv * fe.dim * ncells));
+  CHK(fe_upload(L.measure, measure, (size_t)ncells));
+  CHK(fe_upload(L.f_ptr, f_ptr, (size_t)nnz_f + 1));
+  CHK(fe_upload(L.f_src, f_src, (size_t)f_ptr[nnz_f]));
+  CHK(fe_upload(L.f_const, f_const, (size_t)nnz_f));
+  CHK(fe_upload(L.f_keep, f_keep, (size_t)nnz_f));
+  CHK(fe_upload(L.diag_pos, diag_pos, (size_t)n_diag));
+  CHK(fe_upload(L.diag_val, diag_val, (size_t)n_diag));
+  if (inject) CHK(fe_upload(L.inject, inject, (size_t)nn2));
+  CHK(L.cells.ensure((size_t)na * na * ncells));
+  CHK(L.F.ensure(nnz_f));
+  CHK(L.U.ensure((size_t)fe.dim * nn2));
+  L.set = true; L.ev_init = false;
+  return 0;
+}
+
+// sys_pos[c * nnz_f + k]: where entry k of the finest scalar operator sits, for
+// component c, in the caller's system values (pcd_set_system's array)
+int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_system: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  FeLevel& L = fe.lev[fe.nlev - 1];
+  if (!L.set || !sys_pos) return fail(PCD_ERR_ARG, "fe_bind_system: finest level not set / null map");
+  if (!h->mat[PCD_MAT_A].set) return fail(PCD_ERR_STATE, "fe_bind_system: no system set");
+  for (int64_t i = 0; i < fe.dim * L.nnzf; ++i)
+    if (sys_pos[i] < 0 || sys_pos[i] >= h->sys_nnz)
+      return fail(PCD_ERR_ARG, "fe_bind_system: position outside the system values");
+  HIPCHK(hipSetDevice(h->device));
+  CHK(fe_upload(fe.sys_pos, sys_pos, (size_t)fe.dim * L.nnzf));
+  fe.sys_bound = true;
+  return 0;
+}
+
+int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
+                   const int32_t* kp_src, const double* kp_const, double scale) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_kp: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  FeLevel& L = fe.lev[fe.nlev - 1];
+  if (!L.set || nnz_kp < 1 || !kp_ptr || !kp_src)
+    return fail(PCD_ERR_ARG, "fe_bind_kp: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const int nv = fe.dim + 1;
+  fe.nnz_kp = nnz_kp; fe.kp_scale = scale;
+  CHK(fe_upload(fe.kp_ptr, kp_ptr, (size_t)nnz_kp + 1));
+  CHK(fe_upload(fe.kp_src, kp_src, (size_t)kp_ptr[nnz_kp]));
+  if (kp_const) CHK(fe_upload(fe.kp_const, kp_const, (size_t)nnz_kp));
+  else fe.kp_const.release();
+  CHK(fe.kp_cells.ensure((size_t)nv * nv * L.nc));
+  CHK(fe.kp_vals.ensure(nnz_kp));
+  fe.kp_bound = true;
+  return 0;
+}
+
+// multigrid hierarchy of inner solve `slot` follows the FE levels; smoother
+// bounds after every update: [emin_factor, emax_factor] * lambda_max(D^-1 A)
+int pcd_fe_bind_mg(pcd_handle h, int slot, double emin_factor,
+                   double emax_factor, int iters) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_mg: call pcd_fe_begin first");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "fe_bind_mg: bad slot %d", slot);
+  FeState& fe = *h->fe;
+  if ((int)h->inner[slot].mg.size() != fe.nlev)
+    return fail(PCD_ERR_STATE, "fe_bind_mg: %d multigrid levels, %d FE levels",
+                (int)h->inner[slot].mg.size(), fe.nlev);
+  if (!(emax_factor > emin_factor && emin_factor > 0.0) || iters < 1)
+    return fail(PCD_ERR_ARG, "fe_bind_mg: bad smoother factors");
+  fe.mg_slot = slot; fe.emin_f = emin_factor; fe.emax_f = emax_factor; fe.est_iters = iters;
+  return 0;
+}
+
+// Re-assemble everything that depends on the iterate `xu` (velocity dofs,
+// fieldsplit-local numbering) and refresh the engine's operators in place.
+// Optional: ru = (unconstrained velocity operator) * v, the matrix-dependent
+// part of the nonlinear residual (nonlinear_solvers.py:85-112 `F`).
+int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
+                  int mem) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_update: call pcd_fe_begin first");
+  if (!xu || ((v == nullptr) != (ru == nullptr))) return fail(PCD_ERR_ARG, "fe_update: bad vectors");
+  FeState& fe = *h->fe;
+  for (auto& L : fe.lev) if (!L.set) return fail(PCD_ERR_STATE, "fe_update: a level is not set");
+  HIPCHK(hipSetDevice(h->device));
+  const int top = fe.nlev - 1;
+  FeLevel& Lt = fe.lev[top];
+  const int64_t nu = fe.dim * Lt.nn2;
+  const double *dxu = xu, *dv = v;
+  double* dru = ru;
+  if (mem == PCD_MEM_HOST) {
+    CHK(fe.xu.ensure(nu));
+    HIPCHK(hipMemcpyAsync(fe.xu.p, xu, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    dxu = fe.xu.p;
+    if (v) {
+      CHK(fe.v.ensure(nu)); CHK(fe.ru.ensure(nu));
+      HIPCHK(hipMemcpyAsync(fe.v.p, v, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      dv = fe.v.p; dru = fe.ru.p;
+    }
+  }
+  // winds: finest = iterate, coarser levels by injection
+  HIPCHK(hipMemcpyAsync(Lt.U.p, dxu, nu * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  for (int l = top - 1; l >= 0; --l) {
+    FeLevel& L = fe.lev[l];
+    hipLaunchKernelGGL(k_fe_inject, dim3(grid1d(L.nn2, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
+                       L.nn2, fe.dim, L.inject.p, fe.lev[l + 1].U.p, L.U.p);
+  }
+  if (v) CHK(fe.Func.ensure(Lt.nnzf));
+  for (int l = top; l >= 0; --l)
+    CHK(fe_assemble_level(h, fe, fe.lev[l], fe.lev[l].U.p, (l == top && v) ? fe.Func.p : nullptr));
+
+  // finest level -> the caller's system values -> A, A00, A01 (+ diagonal)
+  if (fe.sys_bound) {
+    if (!h->sysvals.p || (int64_t)h->sysvals.n < h->sys_nnz)
+      return fail(PCD_ERR_STATE, "fe_update: system values were never staged from the host");
+    if (h->psysvals.p)
+      return fail(PCD_ERR_STATE, "fe_update: a separate preconditioner matrix is not supported");
+    hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                       h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, h->sysvals.p);
+    CHK(pcd_update_system(h, h->sysvals.p, nullptr, PCD_MEM_DEVICE));
+  }
+  // intermediate multigrid levels + smoother bounds
+  if (fe.mg_slot >= 0) {
+    Inner& s = h->inner[fe.mg_slot];
+    if ((int)s.mg.size() != fe.nlev) return fail(PCD_ERR_STATE, "fe_update: multigrid hierarchy changed");
+    for (int l = 1; l <= top; ++l) {
+      FeLevel& L = fe.lev[l];
+      MgLevel& M = s.mg[l];
+      const DCsr* A = &h->mat[kSlotMat[fe.mg_slot]];
+      if (l < top) {
+        if (!M.A.set || M.A.kron != fe.dim || M.A.nnz2 != L.nnzf)
+          return fail(PCD_ERR_STATE, "fe_update: multigrid level %d is not F x I_%d on the FE pattern", l, fe.dim);
+        hipLaunchKernelGGL(k_fe_scatter<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                           h->stream, L.nnzf, fe.dim, M.A.kron_pos.p, L.F.p, M.A.val.p);
+        CHK(refresh_dinv(h, M.A));
+        A = &M.A;
+      }
+      double lam = 0.0;
+      CHK(fe_estimate_emax(h, fe, L, *A, &lam));
+      M.emin = fe.emin_f * lam; M.emax = fe.emax_f * lam;
+    }
+    ++h->gen;                            // Chebyshev coefficients are baked in
+  }
+  // Kp
+  if (fe.kp_bound) {
+    const int g = (int)((Lt.nc + kBlock - 1) / kBlock);
+    if (fe.dim == 2)
+      hipLaunchKernelGGL(k_fe_convection_p1<2>, dim3(g), dim3(kBlock), 0, h->stream, (int)Lt.nc,
+                         Lt.dofs2.p, Lt.gradlam.p, Lt.measure.p, fe_tables(fe), Lt.U.p, fe.kp_scale, fe.kp_cells.p);
+    else
+      hipLaunchKernelGGL(k_fe_convection_p1<3>, dim3(g), dim3(kBlock), 0, h->stream, (int)Lt.nc,
+                         Lt.dofs2.p, Lt.gradlam.p, Lt.measure.p, fe_tables(fe), Lt.U.p, fe.kp_scale, fe.kp_cells.p);
+    hipLaunchKernelGGL(k_fe_gather, dim3(grid1d(fe.nnz_kp, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
+                       fe.nnz_kp, fe.kp_ptr.p, fe.kp_src.p, fe.kp_cells.p, fe.kp_const.p,
+                       (const unsigned char*)nullptr, (double*)nullptr, fe.kp_vals.p);
+    HIPCHK(hipGetLastError());
+    if (h->mat[PCD_MAT_KP].set) {
+      if (h->mat[PCD_MAT_KP].nnz != fe.nnz_kp)
+        return fail(PCD_ERR_STATE, "fe_update: Kp pattern differs from the FE pattern");
+      CHK(pcd_update_values(h, PCD_MAT_KP, fe.kp_vals.p, PCD_MEM_DEVICE));
+    }
+  }
+  // residual part: ru = (F_unconstrained x I) v on the pattern of A00
+  if (v) {
+    DCsr& A = h->mat[PCD_MAT_A00];
+    if (!A.set || A.kron != fe.dim || A.nnz2 != Lt.nnzf)
+      return fail(PCD_ERR_STATE, "fe_update: A00 is not F x I_%d on the FE pattern", fe.dim);
+    std::swap(A.val2.p, fe.Func.p);
+    const int rc = spmv(h, A, dv, dru);
+    std::swap(A.val2.p, fe.Func.p);
+    if (rc) return rc;
+    if (mem == PCD_MEM_HOST)
+      HIPCHK(hipMemcpyAsync(ru, dru, nu * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// scalar operator of one level as last assembled (host array of nnz_f values)
+int pcd_fe_get_level_values(pcd_handle h, int level, double* out) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_get_level_values: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev || !fe.lev[level].set || !out)
+    return fail(PCD_ERR_ARG, "fe_get_level_values: bad level / null output");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(out, fe.lev[level].F.p, fe.lev[level].nnzf * sizeof(double),
+                        hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pcd_fe_get_kp_values(pcd_handle h, double* out) {
+  if (!h || !h->fe || !h->fe->kp_bound || !out)
+    return fail(PCD_ERR_STATE, "fe_get_kp_values: Kp is not bound");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(out, h->fe->kp_vals.p, h->fe->nnz_kp * sizeof(double),
+                        hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// smoother bounds the producer installed on a multigrid level (diagnostics)
+int pcd_fe_get_bounds(pcd_handle h, int level, double* emin, double* emax) {
+  if (!h || !h->fe || h->fe->mg_slot < 0) return fail(PCD_ERR_STATE, "fe_get_bounds: no multigrid bound");
+  Inner& s = h->inner[h->fe->mg_slot];
+  if (level < 1 || level >= (int)s.mg.size() || !emin || !emax)
+    return fail(PCD_ERR_ARG, "fe_get_bounds: bad level");
+  *emin = s.mg[level].emin; *emax = s.mg[level].emax;
+  return 0;
+}
+
+}  // extern "C"

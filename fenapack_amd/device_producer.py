@@ -1,0 +1,277 @@
+"""Device operator producer: the operators that change with the iterate are
+assembled in HBM by the engine (``pcd_fe_*``) instead of on the host.
+
+What the reference re-assembles through DOLFIN every nonlinear iteration
+(``fenapack/assembling.py:151-155`` system matrix, ``:165-171`` ``kp``; the
+residual ``F`` of ``fenapack/nonlinear_solvers.py:85-112``) is, for the fixed
+P2/P1 Picard forms of ``demo_navier-stokes-pcd.py:104-137``, a function of the
+velocity iterate only:
+
+* the velocity block ``F x I_d`` with ``F = nu K + idt M + C(w)`` on every
+  multigrid level (coarse levels re-discretised with the injected iterate,
+  ``-pc_mg_galerkin none``),
+* ``Kp = (1/nu) (w . grad p, q) [+ idt/nu (p, q)]``,
+* the residual part ``(F_unconstrained x I_d) (x_u - d)``.
+
+This module builds the static plans (element -> CSR-entry contribution lists,
+Dirichlet masks, injection maps, positions in the caller's system values) from
+the host spaces once, hands them to the engine, and drives the Picard loop
+with ``pcd_fe_update`` + the outer GMRES; per iteration the host only applies
+constant blocks to vectors and inverts the coarsest scalar operator.
+"""
+
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _cabi as c
+from .fem.multigrid import dense_csr, injection_map
+
+__all__ = ["DeviceProducer", "solve_steady_device"]
+
+
+def _contribution_plan(inv, ncells, nloc2, nnz):
+    """CSR-of-contributions for a FixedPattern: entry k sums the element
+    values ``f_src[f_ptr[k]:f_ptr[k+1]]``; element storage is component-major
+    (``ab * ncells + cell``), contributions in ascending cell order (the order
+    ``numpy.bincount`` adds them on the host)."""
+    inv = np.asarray(inv).ravel()
+    order = np.argsort(inv, kind="stable")
+    ptr = np.zeros(nnz + 1, dtype=np.int64)
+    np.cumsum(np.bincount(inv, minlength=nnz), out=ptr[1:])
+    cell, ab = np.divmod(order, nloc2)
+    src = ab * ncells + cell
+    assert src.size < 2 ** 31
+    return ptr.astype(np.int32), src.astype(np.int32)
+
+
+class DeviceProducer(object):
+    """Plans for ``problem`` (a :class:`fenapack_amd.fem.FlowProblem`) and the
+    engine behind ``ksp`` (a set-up :class:`PCDKSP`)."""
+
+    def __init__(self, problem, ksp):
+        pb, V = problem, problem.space
+        if pb.nls != "picard":
+            raise ValueError("device producer: Picard linearisation only "
+                             "(the Newton block is not F x I)")
+        if pb.stabilize:
+            raise ValueError("device producer: SUPG preconditioner matrix "
+                             "is assembled on the host")
+        if pb.variant == "BRM2" and len(pb.robin_edges):
+            raise ValueError("device producer: the BRM2 boundary term of Kp "
+                             "is assembled on the host")
+        self.pb, self.V, self.ksp = pb, V, ksp
+        self.eng = eng = ksp.engine
+        if not eng.L.hip:
+            raise c.EngineError("device producer needs the HIP engine")
+        d = V.dim
+        ksp0, ksp1 = ksp.pc.getFieldSplitSubKSP()
+        self.ksp0 = ksp0
+        self.mg = ksp0.pc.type == "mg"
+        if not self.mg:
+            raise ValueError("device producer: the velocity solve must be "
+                             "-fieldsplit_u_pc_type mg (its smoother bounds "
+                             "are re-estimated on the device)")
+        if ksp0.pc.mg_galerkin:
+            raise ValueError("device producer: set -fieldsplit_u_pc_mg_"
+                             "galerkin none (coarse levels are "
+                             "re-discretised on the device)")
+        nlev = len(ksp0.pc.mg_data["ops"]) if self.mg else 1
+        self.nlev = nlev
+        top_h = len(pb.hierarchy.meshes) - 1
+        self.levels = []                       # host problems, coarsest first
+        for l in range(nlev):
+            lh = top_h - (nlev - 1) + l
+            if lh == top_h:
+                self.levels.append(pb)
+            else:
+                if not hasattr(pb, "_coarse_problems"):
+                    pb._coarse_problems = {}
+                if lh not in pb._coarse_problems:
+                    pb._coarse_problems[lh] = pb._same_problem_on_level(lh)
+                self.levels.append(pb._coarse_problems[lh])
+        dphi = self._dphi(V)
+        qw = V.wq[0] / V.area[0]
+        eng.fe_begin(d, nlev, qw, V.phi, dphi, V.psi)
+        chain = pb.interpolations().velocity if nlev > 1 else None
+        self.nnzf = []
+        for l, pl in enumerate(self.levels):
+            inject = None
+            if l < nlev - 1:
+                lh = top_h - (nlev - 1) + l
+                inject = injection_map(chain[lh + 1], d)
+            self._set_level(l, pl, inject)
+        self._bind_system()
+        self._bind_kp(ksp1)
+        if self.mg:
+            a, b, cc, dd = ksp0.pc.mg_esteig
+            eng.fe_bind_mg(c.KSP_A00, b, dd, 12)
+        # constant host pieces of the residual
+        self._bc_idx = pb.bc_u_idx
+        self.timing = {"update": 0.0, "coarse_inverse": 0.0, "host": 0.0}
+
+    # ------------------------------------------------------------------ plans
+    @staticmethod
+    def _dphi(V):
+        from .fem.taylor_hood import _p2_basis
+        _, dphi = _p2_basis(V.psi, V.local_edges)
+        return dphi
+
+    def _set_level(self, l, pl, inject):
+        V, d = pl.space, pl.space.dim
+        nc, na = V.mesh.num_cells, V.na
+        pat = V._patterns(False)["SS"]
+        ptr, src = _contribution_plan(pat.inv, nc, na * na, pat.nnz)
+        S0 = pl.nu * V.p2_stiffness_cells()
+        if pl.idt:
+            S0 = S0 + pl.idt * V.p2_mass_cells()
+        f_const = np.bincount(pat.inv, weights=S0.ravel(), minlength=pat.nnz)
+        nodes = np.unique(pl.bc_u_idx // d)
+        assert nodes.size * d == pl.bc_u_idx.size, \
+            "device producer: Dirichlet data must constrain whole nodes"
+        flag = np.zeros(V.nn, dtype=bool)
+        flag[nodes] = True
+        rows, cols = pat.rows, pat.indices
+        keep = ~(flag[rows] | flag[cols])
+        diag_pos = np.nonzero((rows == cols) & flag[rows])[0]
+        diag_val = pl._bc_mult[d * rows[diag_pos]]
+        g = V.gradlam                                  # (nc, d+1, d)
+        self.eng.fe_set_level(
+            l, V.cell_dofs2.T, g.reshape(nc, -1).T, V.area, ptr, src, f_const,
+            keep, diag_pos, diag_val, inject, V.nn)
+        self.nnzf.append(pat.nnz)
+
+    def _bind_system(self):
+        V, d = self.V, self.V.dim
+        patS = V._patterns(False)["SS"]
+        patA = V._patterns(False)["A00"]
+        lin_nnz = (patA.nnz, V._patterns(False)["A01"].nnz,
+                   V._patterns(False)["A10"].nnz)
+        mono = getattr(V, "_mono_%d_%d_%d" % lin_nnz)
+        rows, cols = patS.rows.astype(np.int64), patS.indices.astype(np.int64)
+        pos = np.empty((d, patS.nnz), dtype=np.int64)
+        for k in range(d):
+            pos[k] = mono.inv[patA.locate(d * rows + k, d * cols + k)]
+        self.eng.fe_bind_system(pos)
+
+    def _bind_kp(self, ksp1):
+        pb, V = self.pb, self.V
+        nvl, nc = V.nvl, V.mesh.num_cells
+        pat = V._patterns(False)["PP"]
+        ptr, src = _contribution_plan(pat.inv, nc, nvl * nvl, pat.nnz)
+        cst = None
+        idt = 0.0 if pb.pcdr else pb.idt
+        if idt:
+            M = np.einsum('cq,qi,qj->cij', V.wq, V.psi, V.psi) * (idt / pb.nu)
+            cst = np.bincount(pat.inv, weights=M.ravel(), minlength=pat.nnz)
+        self.eng.fe_bind_kp(ptr, src, cst, 1.0 / pb.nu)
+        self.nnz_kp = pat.nnz
+
+    # ----------------------------------------------------------------- update
+    def update(self, xu, xp):
+        """Refresh every iterate-dependent operator of the engine at
+        ``(xu, xp)`` and return the nonlinear residual in the mixed
+        numbering (same definition as ``FlowProblem.linearise``)."""
+        pb, V = self.pb, self.V
+        t0 = time.perf_counter()
+        g = pb.bc_u_values(pb.t)
+        dd = np.zeros(V.n_u)
+        dd[self._bc_idx] = xu[self._bc_idx] - g
+        v = xu - dd
+        ru = np.empty(V.n_u)
+        t1 = time.perf_counter()
+        self.eng.fe_update(np.ascontiguousarray(xu), v, ru)
+        t2 = time.perf_counter()
+        if self.mg:
+            self._refresh_coarsest()
+        t3 = time.perf_counter()
+        Fu = ru + pb._A01_raw @ xp
+        if pb.idt:
+            Fu -= pb.idt * (pb._Mmass @ pb.u0)
+        Fp = pb._A10_raw @ v
+        Fu[self._bc_idx] = pb._bc_mult[self._bc_idx] * dd[self._bc_idx]
+        b = V.to_mixed(Fu, Fp)
+        t4 = time.perf_counter()
+        self.timing["update"] += t2 - t1
+        self.timing["coarse_inverse"] += t3 - t2
+        self.timing["host"] += (t1 - t0) + (t4 - t3)
+        return b
+
+    def _refresh_coarsest(self):
+        """inv(F x I) = inv(F) x I: invert the scalar coarsest operator on the
+        host and hand the dense inverse to the multigrid's level 0."""
+        V0, d = self.levels[0].space, self.V.dim
+        pat = V0._patterns(False)["SS"]
+        F0 = pat.matrix(self.eng.fe_level_values(0, pat.nnz)).toarray()
+        Finv = np.linalg.inv(F0)
+        C = dense_csr(np.kron(Finv, np.eye(d)))
+        self.eng.mg_update_values(c.KSP_A00, 0, C.data)
+
+    def level_matrix(self, l):
+        """Velocity operator of FE level ``l`` as assembled on the device
+        (scipy CSR, F x I_d) - for tests and diagnostics."""
+        Vl, d = self.levels[l].space, self.V.dim
+        pat = Vl._patterns(False)["SS"]
+        F = pat.matrix(self.eng.fe_level_values(l, pat.nnz))
+        K = sp.kron(F, sp.identity(d), format="csr")
+        K.sort_indices()
+        return K
+
+    def kp_matrix(self):
+        pat = self.V._patterns(False)["PP"]
+        return pat.matrix(self.eng.fe_kp_values(pat.nnz))
+
+
+def solve_steady_device(problem, **kw):
+    """Steady Picard solve with the device producer: the first step (from
+    ``w = 0``) runs through the reference-shaped stack and sets everything up;
+    from then on operators never leave HBM.  Same stopping rules and the same
+    stats dict as :func:`fenapack_amd.driver.solve_steady`."""
+    from .driver import make_solver
+    max_newton = kw.pop("max_newton", 25)
+    w, nls, nlp = make_solver(problem, max_newton=1, **kw)
+    nls.parameters["error_on_nonconvergence"] = False
+    prm = nls.parameters
+    V = problem.space
+    t0 = time.time()
+    it, converged = nls.solve(nlp, w.vector(), on_update=w.touch)
+    krylov, residuals = list(nls.krylov_history), list(nls.residual_history)
+    r0 = residuals[0]
+    solver = nls.linear_solver()
+    ksp = solver.ksp()
+    t_plan = time.time()
+    producer = DeviceProducer(problem, ksp)
+    t_plan = time.time() - t_plan
+    x = w.vector()
+    eng = ksp.engine
+    dx = np.zeros_like(x)
+    t_loop = time.time()
+    b = producer.update(x[V.is_u], x[V.is_p])
+    residuals[-1] = float(np.linalg.norm(b))
+    t_gmres = 0.0
+    while not converged and it < max_newton:
+        dx[:] = 0.0
+        t1 = time.perf_counter()
+        its, _ = eng.gmres_solve(b, dx, c.MEM_HOST,
+                                 solver.parameters["relative_tolerance"],
+                                 solver.parameters["absolute_tolerance"],
+                                 ksp.restart,
+                                 solver.parameters["maximum_iterations"])
+        t_gmres += time.perf_counter() - t1
+        krylov.append(its)
+        x -= prm["relaxation_parameter"] * dx
+        w.touch()
+        it += 1
+        b = producer.update(x[V.is_u], x[V.is_p])
+        r = float(np.linalg.norm(b))
+        residuals.append(r)
+        converged = (r < prm["absolute_tolerance"]
+                     or r / r0 < prm["relative_tolerance"])
+    t_loop = time.time() - t_loop
+    return {"w": w, "newton_its": it, "converged": converged,
+            "krylov_its": int(sum(krylov)), "krylov_per_step": krylov,
+            "residuals": residuals, "time": time.time() - t0,
+            "time_plan": t_plan, "time_device_steps": t_loop,
+            "time_gmres": t_gmres, "producer_timing": dict(producer.timing),
+            "solver": nls, "producer": producer}

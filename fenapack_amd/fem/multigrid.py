@@ -156,6 +156,24 @@ def galerkin_chain(A, chain):
     return ops
 
 
+def injection_map(P, block=1):
+    """``inject[j]`` = fine node that coincides with coarse node ``j`` (P2
+    spaces on nested meshes: every coarse node is a fine node), read off the
+    prolongation ``P`` (fine x coarse, ``block`` interleaved components): the
+    entry of column ``j`` that equals one."""
+    Pc = sp.csc_matrix(P)
+    cols = np.repeat(np.arange(Pc.shape[1]), np.diff(Pc.indptr))
+    one = np.abs(Pc.data - 1.0) < 1e-9
+    rows, cols = Pc.indices[one], cols[one]
+    sel = (rows % block == 0) & (cols % block == 0)
+    inject = np.full(Pc.shape[1] // block, -1, dtype=np.int64)
+    inject[cols[sel] // block] = rows[sel] // block
+    if np.any(inject < 0) or np.count_nonzero(sel) != inject.size:
+        raise ValueError("prolongation does not contain an injection "
+                         "(spaces not nested?)")
+    return inject
+
+
 def dense_csr(C):
     """Dense matrix as CSR with the FULL pattern (explicit zeros kept), so a
     refreshed coarse inverse always fits the pattern handed over first."""

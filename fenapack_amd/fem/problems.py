@@ -19,7 +19,8 @@ import scipy.sparse as sp
 
 from .mesh import Mesh, unit_square_mesh
 from .mesh import _LSHAPE_VERTICES, _LSHAPE_CELLS
-from .multigrid import MeshHierarchy, CubeHierarchy, Interpolations
+from .multigrid import (MeshHierarchy, CubeHierarchy, Interpolations,
+                        injection_map)
 from .taylor_hood import TaylorHood
 
 
@@ -126,12 +127,13 @@ class FlowProblem(object):
         ops, x_l = [], xu
         if not hasattr(self, "_coarse_problems"):
             self._coarse_problems = {}
+        if not hasattr(self, "_inject"):
+            self._inject = {}
         for l in range(L, L - nlev + 1, -1):            # level l -> l - 1
-            P = chain[l].tocsr()
-            unit = np.nonzero((np.diff(P.indptr) == 1)
-                              & (np.abs(P.data[P.indptr[:-1]] - 1.0) < 1e-12))[0]
-            x_c = np.zeros(P.shape[1])
-            x_c[P.indices[P.indptr[unit]]] = x_l[unit]  # injection
+            if l not in self._inject:
+                self._inject[l] = injection_map(chain[l], self.space.dim)
+            d = self.space.dim
+            x_c = x_l.reshape(-1, d)[self._inject[l]].ravel()   # injection
             if l - 1 not in self._coarse_problems:
                 self._coarse_problems[l - 1] = self._same_problem_on_level(l - 1)
             pc = self._coarse_problems[l - 1]

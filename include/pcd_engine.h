@@ -229,6 +229,62 @@ int pcd_dist_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
                    int32_t* send_peers, int32_t* send_off, int32_t* send_idx,
                    int32_t* recv_peers, int32_t* recv_off);
 
+/* ---- device operator producer ------------------------------ *
+ * Replaces, for the fixed P2/P1 Picard forms, what the reference re-assembles
+ * on the host every nonlinear iteration through DOLFIN [ext]:
+ *   fenapack/assembling.py:151-155  system_matrix (the velocity block changes),
+ *   fenapack/assembling.py:165-171  kp,
+ *   fenapack/nonlinear_solvers.py:85-112  F (the matrix-dependent part),
+ * plus the re-discretised coarse velocity operators of `-pc_mg_galerkin none`
+ * and their smoother bounds.  Everything is assembled in HBM from the iterate
+ * and written into the engine's operators in place.  One GPU.  Arrays are
+ * host pointers, stored COMPONENT-MAJOR ([entry][cell]) so that device lanes
+ * read unit-stride; `nv = dim + 1`, `na = 6 (dim 2) | 10 (dim 3)`.            */
+
+/* quadrature / basis tables: qw[nq] (weights, sum 1), phi[nq][na] (P2 basis),
+ * dphi[nq][na][nv] (d phi_a / d lambda_k), psi[nq][nv] (P1 basis).  `nlevels`
+ * FE levels, coarsest first - one per multigrid level of the velocity solve. */
+int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
+                 const double* phi, const double* dphi, const double* psi);
+/* Mesh + plan of one level: dofs2[na][ncells] scalar P2 nodes of each cell,
+ * gradlam[nv*dim][ncells] barycentric gradients, measure[ncells].  The scalar
+ * operator F (velocity block = F x I_dim) has nnz_f entries in CSR order;
+ * entry k = f_const[k] + sum_{t in f_ptr[k]..f_ptr[k+1]} cell_matrix[f_src[t]]
+ * with f_src indexing the component-major element storage
+ * ((a*na + b)*ncells + cell); f_keep[k] = 0 removes Dirichlet rows/columns,
+ * diag_pos/diag_val then set the Dirichlet diagonal.  inject[nn2] = the same
+ * node on the next finer level (NULL on the finest level).                   */
+int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
+                     const int32_t* dofs2, const double* gradlam,
+                     const double* measure, int64_t nnz_f, const int32_t* f_ptr,
+                     const int32_t* f_src, const double* f_const,
+                     const unsigned char* f_keep, int64_t n_diag,
+                     const int32_t* diag_pos, const double* diag_val,
+                     const int32_t* inject);
+/* sys_pos[c*nnz_f + k] = position, in the value array given to
+ * pcd_set_system, of entry k of the finest F for velocity component c        */
+int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos);
+/* Kp = scale * (w . grad p, q) + kp_const on the pattern of PCD_MAT_KP
+ * (same plan layout with nv x nv element matrices; kp_const may be NULL)     */
+int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
+                   const int32_t* kp_src, const double* kp_const, double scale);
+/* the multigrid hierarchy of inner solve `slot` follows the FE levels; after
+ * every update the smoother bounds of level l >= 1 become
+ * [emin_factor, emax_factor] * lambda_max(D^-1 A_l) (power iteration, `iters`
+ * steps cold, a quarter of that warm) - [ext PETSc] -mg_levels_esteig        */
+int pcd_fe_bind_mg(pcd_handle h, int slot, double emin_factor,
+                   double emax_factor, int iters);
+/* Assemble at the iterate xu (velocity dofs, fieldsplit-local numbering) and
+ * refresh system, A00, A01, Kp, multigrid levels in place.  If v/ru are given:
+ * ru = (unconstrained velocity operator) v.  The coarsest level is left to
+ * the caller: fetch it with pcd_fe_get_level_values(h, 0, .), invert, hand the
+ * inverse to pcd_mg_update_values.                                           */
+int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
+                  int mem);
+int pcd_fe_get_level_values(pcd_handle h, int level, double* out);
+int pcd_fe_get_kp_values(pcd_handle h, double* out);
+int pcd_fe_get_bounds(pcd_handle h, int level, double* emin, double* emax);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,106 @@
+"""Device operator producer (pcd_fe_*) against the host producer: assembled
+operators on every multigrid level, Kp, the nonlinear residual, and a whole
+Picard solve."""
+import numpy as np
+import pytest
+
+from fenapack_amd import PETScOptions
+from fenapack_amd.device_producer import solve_steady_device
+from fenapack_amd.driver import multigrid_inner_options, solve_steady
+from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _problem(kind, **kw):
+    if kind == "cavity":
+        return Cavity(3, nu=0.01, **kw)
+    if kind == "lshape":
+        return BackwardStep(3, nu=0.02, **kw)
+    return Cavity3D(1, nu=0.02, n0=3, **kw)
+
+
+def _options(dim, coarse_limit=None):
+    PETScOptions.clear()
+    multigrid_inner_options(dim=dim, galerkin_u=False)
+    if coarse_limit is not None:
+        PETScOptions.set("fieldsplit_u_pc_mg_coarse_eq_limit", coarse_limit)
+
+
+@pytest.mark.parametrize("kind", ["cavity", "lshape", "cube"])
+def test_operators_and_residual_match_the_host_producer(hip_lib, kind):
+    pb = _problem(kind)
+    V = pb.space
+    _options(V.dim, coarse_limit=300)
+    out = solve_steady_device(pb, max_newton=1)
+    prod = out["producer"]
+    assert prod.nlev >= 2
+    rng = np.random.default_rng(7)
+    xu = rng.standard_normal(V.n_u)
+    xp = rng.standard_normal(V.n_p)
+    b = prod.update(xu, xp)
+    lin = pb.linearise(xu, xp)
+    assert relerr(b, V.to_mixed(lin["bu"], lin["bp"])) < 1e-12
+    A00 = prod.level_matrix(prod.nlev - 1)
+    assert A00.nnz == lin["A00"].nnz
+    assert relerr(A00.data, lin["A00"].data) < 1e-13
+    assert relerr(prod.kp_matrix().data, pb.Kp(xu).data) < 1e-13
+    coarse = pb.coarse_velocity_operators(xu, prod.nlev)
+    for l, ref in enumerate(coarse):
+        got = prod.level_matrix(l)
+        assert got.nnz == ref.nnz
+        assert relerr(got.data, ref.data) < 1e-13, l
+    # the engine's own operators were refreshed in place: A x through the
+    # engine equals the host's monolithic matrix at this iterate
+    from fenapack_amd import _cabi as c
+    A = V.monolithic(lin["A00"], lin["A01"], lin["A10"])
+    x = rng.standard_normal(V.ndof)
+    eng = out["solver"].linear_solver().ksp().engine
+    perm = np.concatenate([V.is_u, V.is_p])      # the engine's split ordering
+    y = eng.spmv_np(c.MAT_A, x[perm], V.ndof)
+    assert relerr(y, (A @ x)[perm]) < 1e-12
+    # smoother bounds were re-estimated on the device (level 1 and up)
+    from fenapack_amd.petsc import estimate_emax
+    for l in range(1, prod.nlev):
+        emin, emax = eng.fe_bounds(l)
+        ref = estimate_emax(prod.level_matrix(l), iters=60)
+        assert 0.0 < emin < emax
+        assert 0.5 * ref < emax / 1.1 < 1.1 * ref, (l, emax, ref)
+
+
+@pytest.mark.parametrize("kind,kw", [("cavity", {}), ("lshape", {}),
+                                      ("cube", {})])
+def test_picard_solve_matches_the_host_driven_solve(hip_lib, kind, kw):
+    pb = _problem(kind, **kw)
+    _options(pb.space.dim)
+    ref = solve_steady(pb, max_newton=8)
+    pb2 = _problem(kind, **kw)
+    _options(pb2.space.dim)
+    out = solve_steady_device(pb2, max_newton=8)
+    assert out["converged"] and ref["converged"]
+    assert out["newton_its"] == ref["newton_its"]
+    # GMRES counts: equal up to a few percent (the smoother bounds come from
+    # power iterations with different start vectors, so the two multigrid
+    # cycles are not the same operator to the last digit)
+    assert len(out["krylov_per_step"]) == len(ref["krylov_per_step"])
+    for a, b in zip(out["krylov_per_step"], ref["krylov_per_step"]):
+        assert abs(a - b) <= max(1, 0.05 * b), \
+            (out["krylov_per_step"], ref["krylov_per_step"])
+    assert np.allclose(out["residuals"], ref["residuals"], rtol=1e-3)
+    assert relerr(out["w"].vector(), ref["w"].vector()) < 1e-5
+
+
+def test_refuses_what_it_does_not_assemble(hip_lib):
+    pb = _problem("cavity", nls="newton")
+    _options(2)
+    with pytest.raises(ValueError):
+        solve_steady_device(pb, max_newton=2)
+    pb = _problem("cavity")
+    PETScOptions.clear()
+    multigrid_inner_options(dim=2, galerkin_u=True)
+    with pytest.raises(ValueError):
+        solve_steady_device(pb, max_newton=2)

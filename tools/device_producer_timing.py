@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""End-to-end steady Picard solve: host producer vs device producer
+(time per nonlinear step, GMRES counts)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fenapack_amd import PETScOptions                                   # noqa
+from fenapack_amd.device_producer import solve_steady_device            # noqa
+from fenapack_amd.driver import multigrid_inner_options, solve_steady   # noqa
+from fenapack_amd.fem import Cavity, Cavity3D                           # noqa
+
+geometry = sys.argv[1] if len(sys.argv) > 1 else "cavity"
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+newton_rtol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-8
+
+
+def problem():
+    return Cavity(level, nu=0.01) if geometry == "cavity" \
+        else Cavity3D(level, nu=0.01, n0=4)
+
+
+res = {}
+for name, fn in (("host", solve_steady), ("device", solve_steady_device)):
+    pb = problem()
+    PETScOptions.clear()
+    multigrid_inner_options(dim=pb.space.dim, galerkin_u=False)
+    t0 = time.time()
+    out = fn(pb, max_newton=25, newton_rtol=newton_rtol)
+    res[name] = {
+        "ndof": pb.space.ndof, "newton_its": out["newton_its"],
+        "converged": bool(out["converged"]),
+        "krylov_per_step": out["krylov_per_step"],
+        "solve_seconds": out["time"],
+        "final_residual": out["residuals"][-1]}
+    if name == "device":
+        steps = out["newton_its"] - 1
+        res[name].update(
+            plan_seconds=out["time_plan"],
+            device_steps=steps,
+            seconds_per_device_step=out["time_device_steps"] / max(steps, 1),
+            gmres_seconds=out["time_gmres"],
+            producer_timing=out["producer_timing"])
+    else:
+        res[name]["seconds_per_step"] = out["time"] / max(out["newton_its"], 1)
+print(json.dumps(res, indent=1))
