@@ -76,6 +76,7 @@ _HIP_ONLY = {
                      C.c_void_p, C.c_void_p],
     "fe_bind_system": [C.c_void_p],
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
+    "fe_set_kp_const": [C.c_void_p],
     "fe_bind_mg": [C.c_int, C.c_double, C.c_double, C.c_int],
     "fe_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
     "fe_get_level_values": [C.c_int, C.c_void_p],
@@ -321,6 +322,10 @@ class Engine(object):
         cst = None if kp_const is None else _f64(kp_const)
         self._call("fe_bind_kp", int(kp_ptr.size - 1), _ptr(kp_ptr),
                    _ptr(kp_src), _ptr(cst), float(scale))
+
+    def fe_set_kp_const(self, kp_const):
+        cst = None if kp_const is None else _f64(kp_const)
+        self._call("fe_set_kp_const", _ptr(cst))
 
     def fe_bind_mg(self, slot, emin_factor, emax_factor, iters=12):
         self._call("fe_bind_mg", int(slot), float(emin_factor),

@@ -218,6 +218,19 @@ int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
   return 0;
 }
 
+// new constant part of Kp (terms the host keeps assembling, e.g. the BRM2
+// boundary integral); NULL = none
+int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const) {
+  if (!h || !h->fe || !h->fe->kp_bound) return fail(PCD_ERR_STATE, "fe_set_kp_const: Kp is not bound");
+  HIPCHK(hipSetDevice(h->device));
+  FeState& fe = *h->fe;
+  if (!kp_const) { fe.kp_const.release(); return 0; }
+  CHK(fe.kp_const.ensure(fe.nnz_kp));
+  HIPCHK(hipMemcpyAsync(fe.kp_const.p, kp_const, fe.nnz_kp * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // multigrid hierarchy of inner solve `slot` follows the FE levels; smoother
 // bounds after every update: [emin_factor, emax_factor] * lambda_max(D^-1 A)
 int pcd_fe_bind_mg(pcd_handle h, int slot, double emin_factor,

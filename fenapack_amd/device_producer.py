@@ -28,7 +28,8 @@ import scipy.sparse as sp
 from . import _cabi as c
 from .fem.multigrid import dense_csr, injection_map
 
-__all__ = ["DeviceProducer", "solve_steady_device"]
+__all__ = ["DeviceProducer", "DevicePicardSolver", "solve_steady_device",
+           "solve_unsteady_device"]
 
 
 def _contribution_plan(inv, ncells, nloc2, nnz):
@@ -57,9 +58,6 @@ class DeviceProducer(object):
                              "(the Newton block is not F x I)")
         if pb.stabilize:
             raise ValueError("device producer: SUPG preconditioner matrix "
-                             "is assembled on the host")
-        if pb.variant == "BRM2" and len(pb.robin_edges):
-            raise ValueError("device producer: the BRM2 boundary term of Kp "
                              "is assembled on the host")
         self.pb, self.V, self.ksp = pb, V, ksp
         self.eng = eng = ksp.engine
@@ -167,6 +165,11 @@ class DeviceProducer(object):
             cst = np.bincount(pat.inv, weights=M.ravel(), minlength=pat.nnz)
         self.eng.fe_bind_kp(ptr, src, cst, 1.0 / pb.nu)
         self.nnz_kp = pat.nnz
+        # BRM2: - (1/nu) int_inflow (w.n) p q ds depends on the iterate too;
+        # it lives on a few boundary edges and stays a host computation
+        # whose result replaces the constant part before every update
+        self._kp_base = cst
+        self._robin = pb.variant == "BRM2" and len(pb.robin_edges) > 0
 
     # ----------------------------------------------------------------- update
     def update(self, xu, xp):
@@ -180,6 +183,10 @@ class DeviceProducer(object):
         dd[self._bc_idx] = xu[self._bc_idx] - g
         v = xu - dd
         ru = np.empty(V.n_u)
+        if self._robin:
+            R = V._boundary_flux_mass(pb.nodal_velocity(xu), pb.robin_edges)
+            base = 0.0 if self._kp_base is None else self._kp_base
+            self.eng.fe_set_kp_const(base - R.data / pb.nu)
         t1 = time.perf_counter()
         self.eng.fe_update(np.ascontiguousarray(xu), v, ru)
         t2 = time.perf_counter()
@@ -223,55 +230,112 @@ class DeviceProducer(object):
         return pat.matrix(self.eng.fe_kp_values(pat.nnz))
 
 
+class DevicePicardSolver(object):
+    """Picard iteration with the device producer.  The first nonlinear step of
+    the first solve runs through the reference-shaped stack
+    (``PCDNewtonSolver`` -> ``init_pcd`` -> host producer) and sets everything
+    up; from then on operators never leave HBM.  Stopping rules, relaxation and
+    bookkeeping are those of :class:`fenapack_amd.PCDNewtonSolver`."""
+
+    def __init__(self, problem, **kw):
+        from .driver import make_solver
+        self.max_newton = kw.pop("max_newton", 25)
+        self.problem = problem
+        self.w, self.nls, self.nlp = make_solver(problem, max_newton=1, **kw)
+        self.nls.parameters["error_on_nonconvergence"] = False
+        self.producer = None
+        self.time_plan = 0.0
+        self.time_gmres = 0.0
+        self.krylov_history, self.residual_history = [], []
+
+    def krylov_iterations(self):
+        return int(sum(self.krylov_history))
+
+    def solve(self):
+        """One nonlinear solve from the current ``w``; returns
+        ``(iterations, converged)``."""
+        pb, V, w, nls = self.problem, self.problem.space, self.w, self.nls
+        prm = nls.parameters
+        x = w.vector()
+        if self.producer is None:
+            it, converged = nls.solve(self.nlp, x, on_update=w.touch)
+            self.krylov_history = list(nls.krylov_history)
+            self.residual_history = list(nls.residual_history)
+            r0 = self.residual_history[0]
+            t0 = time.time()
+            self.producer = DeviceProducer(pb, nls.linear_solver().ksp())
+            self.time_plan = time.time() - t0
+            b = self.producer.update(x[V.is_u], x[V.is_p])
+            self.residual_history[-1] = float(np.linalg.norm(b))
+        else:
+            it = 0
+            b = self.producer.update(x[V.is_u], x[V.is_p])
+            r0 = float(np.linalg.norm(b))
+            self.krylov_history, self.residual_history = [], [r0]
+            converged = r0 < prm["absolute_tolerance"]
+        solver = nls.linear_solver()
+        ksp = solver.ksp()
+        dx = np.zeros_like(x)
+        while not converged and it < self.max_newton:
+            dx[:] = 0.0
+            t1 = time.perf_counter()
+            its, _ = ksp.engine.gmres_solve(
+                b, dx, c.MEM_HOST, solver.parameters["relative_tolerance"],
+                solver.parameters["absolute_tolerance"], ksp.restart,
+                solver.parameters["maximum_iterations"])
+            self.time_gmres += time.perf_counter() - t1
+            self.krylov_history.append(its)
+            x -= prm["relaxation_parameter"] * dx
+            w.touch()
+            it += 1
+            b = self.producer.update(x[V.is_u], x[V.is_p])
+            r = float(np.linalg.norm(b))
+            self.residual_history.append(r)
+            converged = (r < prm["absolute_tolerance"]
+                         or r / r0 < prm["relative_tolerance"])
+        return it, converged
+
+
 def solve_steady_device(problem, **kw):
-    """Steady Picard solve with the device producer: the first step (from
-    ``w = 0``) runs through the reference-shaped stack and sets everything up;
-    from then on operators never leave HBM.  Same stopping rules and the same
-    stats dict as :func:`fenapack_amd.driver.solve_steady`."""
-    from .driver import make_solver
-    max_newton = kw.pop("max_newton", 25)
-    w, nls, nlp = make_solver(problem, max_newton=1, **kw)
-    nls.parameters["error_on_nonconvergence"] = False
-    prm = nls.parameters
-    V = problem.space
+    """Steady solve; same stats dict as
+    :func:`fenapack_amd.driver.solve_steady` plus a time breakdown."""
     t0 = time.time()
-    it, converged = nls.solve(nlp, w.vector(), on_update=w.touch)
-    krylov, residuals = list(nls.krylov_history), list(nls.residual_history)
-    r0 = residuals[0]
-    solver = nls.linear_solver()
-    ksp = solver.ksp()
-    t_plan = time.time()
-    producer = DeviceProducer(problem, ksp)
-    t_plan = time.time() - t_plan
-    x = w.vector()
-    eng = ksp.engine
-    dx = np.zeros_like(x)
-    t_loop = time.time()
-    b = producer.update(x[V.is_u], x[V.is_p])
-    residuals[-1] = float(np.linalg.norm(b))
-    t_gmres = 0.0
-    while not converged and it < max_newton:
-        dx[:] = 0.0
-        t1 = time.perf_counter()
-        its, _ = eng.gmres_solve(b, dx, c.MEM_HOST,
-                                 solver.parameters["relative_tolerance"],
-                                 solver.parameters["absolute_tolerance"],
-                                 ksp.restart,
-                                 solver.parameters["maximum_iterations"])
-        t_gmres += time.perf_counter() - t1
-        krylov.append(its)
-        x -= prm["relaxation_parameter"] * dx
+    s = DevicePicardSolver(problem, **kw)
+    it, converged = s.solve()
+    t_total = time.time() - t0
+    return {"w": s.w, "newton_its": it, "converged": converged,
+            "krylov_its": s.krylov_iterations(),
+            "krylov_per_step": list(s.krylov_history),
+            "residuals": list(s.residual_history), "time": t_total,
+            "time_plan": s.time_plan, "time_gmres": s.time_gmres,
+            "producer_timing": dict(s.producer.timing),
+            "solver": s.nls, "producer": s.producer}
+
+
+def solve_unsteady_device(problem, dt, t_end, **kw):
+    """Backward-Euler loop of the unsteady demo (:188-208) with the device
+    producer; same stats dict as :func:`fenapack_amd.driver.solve_unsteady`."""
+    s = DevicePicardSolver(problem, **kw)
+    V, w = problem.space, s.w
+    t, steps, krylov, newton = 0.0, 0, 0, 0
+    per_step, newton_per_step, residuals = [], [], []
+    t0 = time.time()
+    while t < t_end - 0.1 * dt:
+        t += dt
+        steps += 1
+        problem.t = t                           # inflow.t = t
         w.touch()
-        it += 1
-        b = producer.update(x[V.is_u], x[V.is_p])
-        r = float(np.linalg.norm(b))
-        residuals.append(r)
-        converged = (r < prm["absolute_tolerance"]
-                     or r / r0 < prm["relative_tolerance"])
-    t_loop = time.time() - t_loop
-    return {"w": w, "newton_its": it, "converged": converged,
-            "krylov_its": int(sum(krylov)), "krylov_per_step": krylov,
-            "residuals": residuals, "time": time.time() - t0,
-            "time_plan": t_plan, "time_device_steps": t_loop,
-            "time_gmres": t_gmres, "producer_timing": dict(producer.timing),
-            "solver": nls, "producer": producer}
+        n_it, _ = s.solve()
+        krylov += s.krylov_iterations()
+        newton += n_it
+        per_step.append(s.krylov_iterations())
+        newton_per_step.append(list(s.krylov_history))
+        residuals.append(list(s.residual_history))
+        problem.u0 = w.split()[0].copy()        # w0.assign(w)
+        w.touch()
+    return {"w": w, "steps": steps, "krylov_its": krylov,
+            "krylov_per_step": per_step, "newton_its": newton,
+            "krylov_per_newton": newton_per_step, "residuals": residuals,
+            "time": time.time() - t0, "ndof": V.ndof,
+            "producer_timing": dict(s.producer.timing),
+            "time_gmres": s.time_gmres}

@@ -268,6 +268,9 @@ int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos);
  * (same plan layout with nv x nv element matrices; kp_const may be NULL)     */
 int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
                    const int32_t* kp_src, const double* kp_const, double scale);
+/* replace kp_const (terms the host keeps assembling every iteration, e.g. the
+ * BRM2 boundary integral of demo_navier-stokes-pcd.py:131-135); NULL = none  */
+int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const);
 /* the multigrid hierarchy of inner solve `slot` follows the FE levels; after
  * every update the smoother bounds of level l >= 1 become
  * [emin_factor, emax_factor] * lambda_max(D^-1 A_l) (power iteration, `iters`

@@ -104,3 +104,31 @@ def test_refuses_what_it_does_not_assemble(hip_lib):
     multigrid_inner_options(dim=2, galerkin_u=True)
     with pytest.raises(ValueError):
         solve_steady_device(pb, max_newton=2)
+
+
+@pytest.mark.parametrize("variant,pcdr", [("BRM1", False), ("BRM2", False),
+                                           ("BRM1", True)])
+def test_unsteady_loop_matches_the_host_driven_loop(hip_lib, variant, pcdr):
+    """Config 4 shape (backward-Euler, time-dependent inflow) at a small
+    level: PCD BRM1, PCD BRM2 (host-assembled boundary term folded into the
+    device Kp) and PCDR."""
+    from fenapack_amd.device_producer import solve_unsteady_device
+    from fenapack_amd.driver import solve_unsteady
+    outs = []
+    for fn in (solve_unsteady, solve_unsteady_device):
+        pb = BackwardStep(2, nu=0.02, variant=variant, dt=0.2, pcdr=pcdr,
+                          dirichlet_diag="multiplicity")
+        PETScOptions.clear()
+        multigrid_inner_options(cycles_u=2, cycles_p=2, pcdr=pcdr,
+                                galerkin_u=False)
+        outs.append(fn(pb, dt=0.2, t_end=0.8, newton_rtol=1e-5,
+                       gmres_rtol=1e-6))
+    ref, out = outs
+    assert out["steps"] == ref["steps"] == 4
+    assert out["newton_its"] == ref["newton_its"]
+    for a, b in zip(out["krylov_per_newton"], ref["krylov_per_newton"]):
+        assert len(a) == len(b)
+        for i, j in zip(a, b):
+            assert abs(i - j) <= max(1, 0.05 * j), (out["krylov_per_newton"],
+                                                    ref["krylov_per_newton"])
+    assert relerr(out["w"].vector(), ref["w"].vector()) < 1e-5
