@@ -38,6 +38,10 @@ p.add_argument("--smooth", type=int, default=2)
 p.add_argument("--mg-coarse", default="galerkin",
                choices=["galerkin", "rediscretize"],
                help="coarse velocity operators of the multigrid cycle")
+p.add_argument("--producer", default="host", choices=["host", "device"],
+               help="who re-assembles the iterate-dependent operators: the "
+                    "numpy producer, or the engine itself in HBM (pcd_fe_*; "
+                    "Picard, --ls mg)")
 p.add_argument("--a00-its", type=int, default=60)
 p.add_argument("--a00-ratio", type=float, default=0.01)
 args = p.parse_args()
@@ -65,9 +69,17 @@ if args.ls == "mg":
 else:
     default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
                           dim=pb.space.dim)
-out = solve_steady(pb, max_newton=25)
+if args.producer == "device":
+    from fenapack_amd.device_producer import solve_steady_device
+    out = solve_steady_device(pb, max_newton=25)
+else:
+    out = solve_steady(pb, max_newton=25)
 print("Newton iterations: %d, converged: %s" % (out["newton_its"],
                                                 out["converged"]))
 print("GMRES iterations per Newton step:", out["krylov_per_step"])
 print("residuals:", ["%.3e" % r for r in out["residuals"]])
 print("solve time: %.2f s" % out["time"])
+if args.producer == "device":
+    print("  of which: plans %.2f s, outer GMRES %.2f s, producer %s"
+          % (out["time_plan"], out["time_gmres"],
+             {k: round(v, 3) for k, v in out["producer_timing"].items()}))

@@ -32,22 +32,35 @@ p.add_argument("--dirichlet-diag", default="multiplicity",
                choices=["unit", "multiplicity"],
                help="diagonal of Dirichlet rows: 1, or the number of cells "
                     "sharing the dof as DOLFIN's SystemAssembler produces")
+p.add_argument("--producer", default="host", choices=["host", "device"],
+               help="host (numpy) producer or the engine's device producer "
+                    "(pcd_fe_*; Picard, --ls mg)")
+p.add_argument("--mg-coarse", default=None,
+               choices=["galerkin", "rediscretize", "rediscretize-supg"],
+               help="coarse velocity operators (default: galerkin)")
 p.add_argument("--dt", type=float, default=0.2)
 p.add_argument("--t_end", type=float, default=5.0)
 args = p.parse_args()
 
+if args.mg_coarse is None:
+    args.mg_coarse = "galerkin"
 pb = BackwardStep(args.level, nu=args.viscosity, variant=args.pcd_variant,
                   nls=args.nls, dt=args.dt, pcdr=args.pcdr,
-                  dirichlet_diag=args.dirichlet_diag)
+                  dirichlet_diag=args.dirichlet_diag,
+                  coarse_stabilize=args.mg_coarse == "rediscretize-supg")
 print("Reynolds number: Re = %g" % (2.0 / pb.nu))
 print("Dimension of the function space: %d" % pb.space.ndof)
 PETScOptions.clear()
 if args.ls == "mg":
     multigrid_inner_options(cycles_u=args.cycles, cycles_p=args.cycles,
-                            pcdr=args.pcdr)
+                            pcdr=args.pcdr,
+                            galerkin_u=args.mg_coarse == "galerkin")
 else:
     default_inner_options(a00_its=30, a00_ratio=0.03, ap_rtol=1e-10,
                           pcdr=args.pcdr)
+if args.producer == "device":
+    from fenapack_amd.device_producer import solve_unsteady_device
+    solve_unsteady = solve_unsteady_device
 out = solve_unsteady(pb, dt=args.dt, t_end=args.t_end, newton_rtol=1e-5,
                      gmres_rtol=1e-6)
 tab = "{:^15} | {:^15} | {:^15} | {:^19} | {:^15}\n".format(

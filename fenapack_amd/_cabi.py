@@ -74,6 +74,9 @@ _HIP_ONLY = {
                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                      C.c_void_p, C.c_void_p],
+    "fe_set_level_galerkin": [C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p],
     "fe_bind_system": [C.c_void_p],
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
     "fe_set_kp_const": [C.c_void_p],
@@ -312,6 +315,16 @@ class Engine(object):
                    int(f_const.size), _ptr(f_ptr), _ptr(f_src), _ptr(f_const),
                    _ptr(f_keep), int(diag_pos.size), _ptr(diag_pos),
                    _ptr(diag_val), _ptr(inj))
+
+    def fe_set_level_galerkin(self, level, b_ptr, b_src, b_w, c_ptr, c_src,
+                              c_w):
+        b_ptr = np.ascontiguousarray(b_ptr, dtype=np.int64)
+        c_ptr = np.ascontiguousarray(c_ptr, dtype=np.int64)
+        b_src, c_src = _i32(b_src), _i32(c_src)
+        b_w, c_w = _f64(b_w), _f64(c_w)
+        self._call("fe_set_level_galerkin", int(level), int(c_ptr.size - 1),
+                   int(b_ptr.size - 1), _ptr(b_ptr), _ptr(b_src), _ptr(b_w),
+                   _ptr(c_ptr), _ptr(c_src), _ptr(c_w))
 
     def fe_bind_system(self, sys_pos):
         sys_pos = np.ascontiguousarray(sys_pos, dtype=np.int64)

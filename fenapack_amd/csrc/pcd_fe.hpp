@@ -156,6 +156,20 @@ __global__ __launch_bounds__(kBlock) void k_fe_gather(
   }
 }
 
+// out[k] = sum_t w[t] * in[src[t]]: one stage of the numeric Galerkin triple
+// product P^T F P on fixed patterns (B = F P, then F_c = P^T B); the lists
+// carry the prolongation weights, so the product is two weighted gathers
+__global__ __launch_bounds__(kBlock) void k_fe_wgather(
+    int64_t nnz, const int64_t* __restrict__ ptr, const int* __restrict__ src,
+    const double* __restrict__ w, const double* __restrict__ in, double* out) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
+       k += (int64_t)gridDim.x * kBlock) {
+    double s = 0.0;
+    for (int64_t t = ptr[k]; t < ptr[k + 1]; ++t) s += w[t] * in[src[t]];
+    out[k] = s;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_fe_set(
     int n, const int* __restrict__ pos, const double* __restrict__ val,
     double* out) {

@@ -12,7 +12,15 @@ struct FeLevel {
   DBuf<unsigned char> f_keep;
   DBuf<double> U, cells, F, ev;
   bool set = false, ev_init = false;
+  // Galerkin level: F = P^T F_finer P by two weighted gathers (no mesh data)
+  bool galerkin = false;
+  int64_t nnzb = 0;
+  DBuf<int64_t> b_ptr, c_ptr;
+  DBuf<int> b_src, c_src;
+  DBuf<double> b_w, c_w, B;
   void release() {
+    b_ptr.release(); c_ptr.release(); b_src.release(); c_src.release();
+    b_w.release(); c_w.release(); B.release();
     dofs2.release(); f_ptr.release(); f_src.release(); diag_pos.release();
     inject.release(); gradlam.release(); measure.release(); f_const.release();
     diag_val.release(); f_keep.release(); U.release(); cells.release();
@@ -58,6 +66,16 @@ static int fe_upload(DBuf<T>& b, const T* src, size_t n) {
 
 static FeTables fe_tables(const FeState& fe) {
   return FeTables{fe.nq, fe.qw.p, fe.phi.p, fe.dphi.p, fe.psi.p};
+}
+
+// coarse operator as the Galerkin product of the next finer level's one
+static int fe_galerkin_level(Engine* h, FeLevel& L, const FeLevel& finer) {
+  hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(L.nnzb, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
+                     L.nnzb, L.b_ptr.p, L.b_src.p, L.b_w.p, finer.F.p, L.B.p);
+  hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
+                     L.nnzf, L.c_ptr.p, L.c_src.p, L.c_w.p, L.B.p, L.F.p);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 // assemble the scalar velocity operator of one level from the wind `U`
@@ -163,6 +181,7 @@ int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
     return fail(PCD_ERR_ARG, "fe_set_level: element storage exceeds int32 indexing");
   HIPCHK(hipSetDevice(h->device));
   FeLevel& L = fe.lev[level];
+  L.galerkin = false;
   L.nc = ncells; L.nn2 = nn2; L.nnzf = nnz_f; L.ndiag = n_diag;
   CHK(fe_upload(L.dofs2, dofs2, (size_t)na * ncells));
   CHK(fe_upload(L.gradlam, gradlam, (size_t)nv * fe.dim * ncells));
@@ -177,6 +196,36 @@ int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
   CHK(L.cells.ensure((size_t)na * na * ncells));
   CHK(L.F.ensure(nnz_f));
   CHK(L.U.ensure((size_t)fe.dim * nn2));
+  L.set = true; L.ev_init = false;
+  return 0;
+}
+
+// A coarse level whose operator is the Galerkin product of the next finer one
+// (-pc_mg_galerkin both): B = F_finer P (nnz_b entries, entry e = sum
+// b_w[t] * F_finer[b_src[t]]), F = P^T B (nnz_f entries, entry k = sum
+// c_w[t] * B[c_src[t]]).
+int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f, int64_t nnz_b,
+                              const int64_t* b_ptr, const int32_t* b_src,
+                              const double* b_w, const int64_t* c_ptr,
+                              const int32_t* c_src, const double* c_w) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_level_galerkin: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev - 1)
+    return fail(PCD_ERR_ARG, "fe_set_level_galerkin: level %d is not a coarse level", level);
+  if (nnz_f < 1 || nnz_b < 1 || !b_ptr || !b_src || !b_w || !c_ptr || !c_src || !c_w)
+    return fail(PCD_ERR_ARG, "fe_set_level_galerkin: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  FeLevel& L = fe.lev[level];
+  L.release();
+  L.galerkin = true; L.nnzf = nnz_f; L.nnzb = nnz_b;
+  CHK(fe_upload(L.b_ptr, b_ptr, (size_t)nnz_b + 1));
+  CHK(fe_upload(L.b_src, b_src, (size_t)b_ptr[nnz_b]));
+  CHK(fe_upload(L.b_w, b_w, (size_t)b_ptr[nnz_b]));
+  CHK(fe_upload(L.c_ptr, c_ptr, (size_t)nnz_f + 1));
+  CHK(fe_upload(L.c_src, c_src, (size_t)c_ptr[nnz_f]));
+  CHK(fe_upload(L.c_w, c_w, (size_t)c_ptr[nnz_f]));
+  CHK(L.B.ensure(nnz_b));
+  CHK(L.F.ensure(nnz_f));
   L.set = true; L.ev_init = false;
   return 0;
 }
@@ -257,6 +306,9 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
   if (!xu || ((v == nullptr) != (ru == nullptr))) return fail(PCD_ERR_ARG, "fe_update: bad vectors");
   FeState& fe = *h->fe;
   for (auto& L : fe.lev) if (!L.set) return fail(PCD_ERR_STATE, "fe_update: a level is not set");
+  for (int l = 1; l < fe.nlev; ++l)
+    if (fe.lev[l].galerkin && !fe.lev[l - 1].galerkin)
+      return fail(PCD_ERR_STATE, "fe_update: level %d is re-discretised below the Galerkin level %d", l - 1, l);
   HIPCHK(hipSetDevice(h->device));
   const int top = fe.nlev - 1;
   FeLevel& Lt = fe.lev[top];
@@ -277,12 +329,15 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
   HIPCHK(hipMemcpyAsync(Lt.U.p, dxu, nu * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   for (int l = top - 1; l >= 0; --l) {
     FeLevel& L = fe.lev[l];
+    if (L.galerkin) break;               // Galerkin levels (and below) need no wind
     hipLaunchKernelGGL(k_fe_inject, dim3(grid1d(L.nn2, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
                        L.nn2, fe.dim, L.inject.p, fe.lev[l + 1].U.p, L.U.p);
   }
   if (v) CHK(fe.Func.ensure(Lt.nnzf));
-  for (int l = top; l >= 0; --l)
-    CHK(fe_assemble_level(h, fe, fe.lev[l], fe.lev[l].U.p, (l == top && v) ? fe.Func.p : nullptr));
+  for (int l = top; l >= 0; --l) {
+    if (fe.lev[l].galerkin) CHK(fe_galerkin_level(h, fe.lev[l], fe.lev[l + 1]));
+    else CHK(fe_assemble_level(h, fe, fe.lev[l], fe.lev[l].U.p, (l == top && v) ? fe.Func.p : nullptr));
+  }
 
   // finest level -> the caller's system values -> A, A00, A01 (+ diagonal)
   if (fe.sys_bound) {

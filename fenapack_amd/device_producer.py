@@ -47,6 +47,70 @@ def _contribution_plan(inv, ncells, nloc2, nnz):
     return ptr.astype(np.int32), src.astype(np.int32)
 
 
+def _expand_by_rows(P, row_of):
+    """For every item t with ``row_of[t] = i``: all entries of row ``i`` of
+    the CSR matrix ``P``.  Returns (item index, entry index) pairs."""
+    plen = np.diff(P.indptr)
+    cnt = plen[row_of]
+    rep = np.repeat(np.arange(row_of.size, dtype=np.int64), cnt)
+    start = np.cumsum(cnt) - cnt
+    off = np.arange(rep.size, dtype=np.int64) - np.repeat(start, cnt)
+    return rep, P.indptr[row_of[rep]].astype(np.int64) + off
+
+
+def _group(key, nkeys_hint=None):
+    """Unique sorted keys + CSR-of-members (stable: members keep input order)."""
+    ukey, inv = np.unique(key, return_inverse=True)
+    inv = inv.ravel()
+    order = np.argsort(inv, kind="stable")
+    ptr = np.zeros(ukey.size + 1, dtype=np.int64)
+    np.cumsum(np.bincount(inv, minlength=ukey.size), out=ptr[1:])
+    return ukey, ptr, order
+
+
+#: refuse Galerkin plans beyond this many (entry, weight) pairs: the lists are
+#: built with numpy temporaries several times their size
+MAX_GALERKIN_PAIRS = 400_000_000
+
+
+def galerkin_plan(rows_f, cols_f, P):
+    """Fixed-pattern numeric ``P^T F P``: two weighted-gather stages.
+
+    ``rows_f, cols_f``: CSR-ordered pattern of the fine scalar operator;
+    ``P``: scalar prolongation (fine nodes x coarse nodes).  Returns
+    ``(b_ptr, b_src, b_w, c_ptr, c_src, c_w, indptr_c, indices_c)``."""
+    P = sp.csr_matrix(P)
+    P.sort_indices()
+    ncoarse = P.shape[1]
+    rows_f = np.asarray(rows_f, dtype=np.int64)
+    cols_f = np.asarray(cols_f, dtype=np.int64)
+    est = float(np.diff(P.indptr).mean()) * rows_f.size
+    if est * 8 > MAX_GALERKIN_PAIRS:
+        raise ValueError("Galerkin plan of ~%.3g pairs exceeds the limit; use "
+                         "-pc_mg_galerkin none" % (est * 8))
+    # B = F P: entry (i, J) collects F[i, j] * P[j, J]
+    k_rep, pidx = _expand_by_rows(P, cols_f)
+    key = rows_f[k_rep] * ncoarse + P.indices[pidx]
+    ukey, b_ptr, order = _group(key)
+    b_src, b_w = k_rep[order], P.data[pidx][order]
+    rows_b, cols_b = ukey // ncoarse, ukey % ncoarse
+    del key, k_rep, pidx, order
+    # F_c = P^T B: entry (I, J) collects P[i, I] * B[i, J]
+    e_rep, pidx = _expand_by_rows(P, rows_b)
+    if e_rep.size > MAX_GALERKIN_PAIRS:
+        raise ValueError("Galerkin plan of %d pairs exceeds the limit; use "
+                         "-pc_mg_galerkin none" % e_rep.size)
+    key = P.indices[pidx].astype(np.int64) * ncoarse + cols_b[e_rep]
+    ukey, c_ptr, order = _group(key)
+    c_src, c_w = e_rep[order], P.data[pidx][order]
+    rows_c, cols_c = ukey // ncoarse, ukey % ncoarse
+    indptr = np.zeros(ncoarse + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows_c, minlength=ncoarse), out=indptr[1:])
+    assert b_src.size < 2 ** 31 and ukey.size < 2 ** 31
+    return (b_ptr, b_src.astype(np.int32), b_w, c_ptr, c_src.astype(np.int32),
+            c_w, indptr.astype(np.int32), cols_c.astype(np.int32))
+
+
 class DeviceProducer(object):
     """Plans for ``problem`` (a :class:`fenapack_amd.fem.FlowProblem`) and the
     engine behind ``ksp`` (a set-up :class:`PCDKSP`)."""
@@ -71,10 +135,7 @@ class DeviceProducer(object):
             raise ValueError("device producer: the velocity solve must be "
                              "-fieldsplit_u_pc_type mg (its smoother bounds "
                              "are re-estimated on the device)")
-        if ksp0.pc.mg_galerkin:
-            raise ValueError("device producer: set -fieldsplit_u_pc_mg_"
-                             "galerkin none (coarse levels are "
-                             "re-discretised on the device)")
+        self.galerkin = bool(ksp0.pc.mg_galerkin)
         nlev = len(ksp0.pc.mg_data["ops"]) if self.mg else 1
         self.nlev = nlev
         top_h = len(pb.hierarchy.meshes) - 1
@@ -83,6 +144,8 @@ class DeviceProducer(object):
             lh = top_h - (nlev - 1) + l
             if lh == top_h:
                 self.levels.append(pb)
+            elif self.galerkin:
+                self.levels.append(None)       # no mesh data on these levels
             else:
                 if not hasattr(pb, "_coarse_problems"):
                     pb._coarse_problems = {}
@@ -93,13 +156,16 @@ class DeviceProducer(object):
         qw = V.wq[0] / V.area[0]
         eng.fe_begin(d, nlev, qw, V.phi, dphi, V.psi)
         chain = pb.interpolations().velocity if nlev > 1 else None
-        self.nnzf = []
-        for l, pl in enumerate(self.levels):
-            inject = None
-            if l < nlev - 1:
-                lh = top_h - (nlev - 1) + l
-                inject = injection_map(chain[lh + 1], d)
-            self._set_level(l, pl, inject)
+        self._pat = [None] * nlev       # (indptr, indices, n) of scalar F_l
+        for l in range(nlev - 1, -1, -1):
+            pl = self.levels[l]
+            lh = top_h - (nlev - 1) + l
+            if l == nlev - 1:
+                self._set_level(l, pl, None)
+            elif self.galerkin:
+                self._set_level_galerkin(l, chain[lh + 1])
+            else:
+                self._set_level(l, pl, injection_map(chain[lh + 1], d))
         self._bind_system()
         self._bind_kp(ksp1)
         if self.mg:
@@ -138,7 +204,31 @@ class DeviceProducer(object):
         self.eng.fe_set_level(
             l, V.cell_dofs2.T, g.reshape(nc, -1).T, V.area, ptr, src, f_const,
             keep, diag_pos, diag_val, inject, V.nn)
-        self.nnzf.append(pat.nnz)
+        self._pat[l] = (pat.indptr, pat.indices, V.nn)
+
+    def _set_level_galerkin(self, l, P):
+        """Level ``l`` = P^T (level l+1) P with the scalar part of the
+        velocity prolongation ``P`` (= P_s x I_d)."""
+        d = self.V.dim
+        Ps = sp.csr_matrix(P)[::d, ::d]
+        indptr_f, indices_f, n_f = self._pat[l + 1]
+        rows_f = np.repeat(np.arange(n_f), np.diff(indptr_f))
+        plan = galerkin_plan(rows_f, indices_f, Ps)
+        indptr_c, indices_c = plan[6], plan[7]
+        # scipy's SpGEMM drops entries that cancel to an exact zero, so the
+        # host's Galerkin pattern depends on the values it was built from;
+        # the device product needs the structural pattern: re-create the
+        # engine's level with it (values arrive with the first update)
+        if 0 < l < self.nlev - 1:
+            ones = sp.csr_matrix((np.ones(indices_c.size), indices_c,
+                                  indptr_c), shape=(Ps.shape[1],) * 2)
+            K = sp.kron(ones, sp.identity(d), format="csr")
+            K.sort_indices()
+            mg = self.ksp0.pc.mg_data
+            self.eng.mg_set_level(c.KSP_A00, l, K, mg["chain"][l],
+                                  *mg["bounds"][l])
+        self.eng.fe_set_level_galerkin(l, *plan[:6])
+        self._pat[l] = (indptr_c, indices_c, Ps.shape[1])
 
     def _bind_system(self):
         V, d = self.V, self.V.dim
@@ -208,19 +298,22 @@ class DeviceProducer(object):
     def _refresh_coarsest(self):
         """inv(F x I) = inv(F) x I: invert the scalar coarsest operator on the
         host and hand the dense inverse to the multigrid's level 0."""
-        V0, d = self.levels[0].space, self.V.dim
-        pat = V0._patterns(False)["SS"]
-        F0 = pat.matrix(self.eng.fe_level_values(0, pat.nnz)).toarray()
+        d = self.V.dim
+        F0 = self._scalar(0).toarray()
         Finv = np.linalg.inv(F0)
         C = dense_csr(np.kron(Finv, np.eye(d)))
         self.eng.mg_update_values(c.KSP_A00, 0, C.data)
 
+    def _scalar(self, l):
+        indptr, indices, n = self._pat[l]
+        vals = self.eng.fe_level_values(l, indices.size)
+        return sp.csr_matrix((vals, indices, indptr), shape=(n, n))
+
     def level_matrix(self, l):
         """Velocity operator of FE level ``l`` as assembled on the device
         (scipy CSR, F x I_d) - for tests and diagnostics."""
-        Vl, d = self.levels[l].space, self.V.dim
-        pat = Vl._patterns(False)["SS"]
-        F = pat.matrix(self.eng.fe_level_values(l, pat.nnz))
+        d = self.V.dim
+        F = self._scalar(l)
         K = sp.kron(F, sp.identity(d), format="csr")
         K.sort_indices()
         return K

@@ -72,7 +72,8 @@ class FlowProblem(object):
     """Common machinery; subclasses define geometry and boundary data."""
 
     def __init__(self, hierarchy, nu, variant="BRM1", nls="picard", dt=None,
-                 pcdr=False, stabilize=False, dirichlet_diag="unit"):
+                 pcdr=False, stabilize=False, dirichlet_diag="unit",
+                 coarse_stabilize=False):
         assert variant in ("BRM1", "BRM2")
         assert nls in ("picard", "newton")
         self.hierarchy = hierarchy
@@ -83,6 +84,10 @@ class FlowProblem(object):
         self.idt = 0.0 if dt is None else 1.0 / float(dt)
         self.pcdr = pcdr
         self.stabilize = stabilize
+        # SUPG on the re-discretised COARSE multigrid levels only (cells with
+        # Peclet number > 1 there; the finest level and the operator itself
+        # stay unstabilised): keeps `-pc_mg_galerkin none` hierarchies stable
+        self.coarse_stabilize = coarse_stabilize
         self.t = 0.0
         # [ext DOLFIN] SystemAssembler writes 1 on the diagonal of a Dirichlet
         # row once per cell tensor, so the assembled diagonal (and the
@@ -145,7 +150,8 @@ class FlowProblem(object):
 
     def _same_problem_on_level(self, level):
         kw = dict(nu=self.nu, variant=self.variant, nls=self.nls,
-                  pcdr=self.pcdr, stabilize=self.stabilize)
+                  pcdr=self.pcdr,
+                  stabilize=self.stabilize or self.coarse_stabilize)
         if self.idt:
             kw["dt"] = 1.0 / self.idt
         return type(self)(level, **kw)
@@ -315,7 +321,8 @@ class Cavity3D(FlowProblem):
 
     def _same_problem_on_level(self, level):
         kw = dict(nu=self.nu, variant=self.variant, nls=self.nls,
-                  pcdr=self.pcdr, stabilize=self.stabilize, n0=self.n0)
+                  pcdr=self.pcdr, n0=self.n0,
+                  stabilize=self.stabilize or self.coarse_stabilize)
         if self.idt:
             kw["dt"] = 1.0 / self.idt
         return Cavity3D(level, **kw)

@@ -261,6 +261,16 @@ int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
                      const unsigned char* f_keep, int64_t n_diag,
                      const int32_t* diag_pos, const double* diag_val,
                      const int32_t* inject);
+/* A coarse level as the Galerkin product of the next finer one
+ * (-pc_mg_galerkin both, [ext PETSc] MatPtAP) instead of a re-discretisation:
+ * B = F_finer P has nnz_b entries, entry e = sum_t b_w[t] * F_finer[b_src[t]],
+ * t in b_ptr[e]..b_ptr[e+1]; this level's F = P^T B likewise from c_*.  The
+ * weights are the prolongation's entries: numeric product = two gathers.    */
+int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f,
+                              int64_t nnz_b, const int64_t* b_ptr,
+                              const int32_t* b_src, const double* b_w,
+                              const int64_t* c_ptr, const int32_t* c_src,
+                              const double* c_w);
 /* sys_pos[c*nnz_f + k] = position, in the value array given to
  * pcd_set_system, of entry k of the finest F for velocity component c        */
 int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos);

@@ -15,6 +15,7 @@ from fenapack_amd.fem import Cavity, Cavity3D                           # noqa
 geometry = sys.argv[1] if len(sys.argv) > 1 else "cavity"
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 newton_rtol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-8
+galerkin = (sys.argv[4] if len(sys.argv) > 4 else "galerkin") == "galerkin"
 
 
 def problem():
@@ -26,11 +27,13 @@ res = {}
 for name, fn in (("host", solve_steady), ("device", solve_steady_device)):
     pb = problem()
     PETScOptions.clear()
-    multigrid_inner_options(dim=pb.space.dim, galerkin_u=False)
+    multigrid_inner_options(dim=pb.space.dim, galerkin_u=galerkin)
     t0 = time.time()
     out = fn(pb, max_newton=25, newton_rtol=newton_rtol)
     res[name] = {
-        "ndof": pb.space.ndof, "newton_its": out["newton_its"],
+        "ndof": pb.space.ndof, "coarse_operators":
+        "galerkin" if galerkin else "rediscretised",
+        "newton_its": out["newton_its"],
         "converged": bool(out["converged"]),
         "krylov_per_step": out["krylov_per_step"],
         "solve_seconds": out["time"],
