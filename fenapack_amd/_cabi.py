@@ -81,6 +81,7 @@ _HIP_ONLY = {
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
     "fe_set_kp_const": [C.c_void_p],
     "fe_bind_mg": [C.c_int, C.c_double, C.c_double, C.c_int],
+    "fe_bind_coarse_inverse": [C.c_int64, C.c_void_p, C.c_void_p],
     "fe_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
     "fe_get_level_values": [C.c_int, C.c_void_p],
     "fe_get_kp_values": [C.c_void_p],
@@ -343,6 +344,11 @@ class Engine(object):
     def fe_bind_mg(self, slot, emin_factor, emax_factor, iters=12):
         self._call("fe_bind_mg", int(slot), float(emin_factor),
                    float(emax_factor), int(iters))
+
+    def fe_bind_coarse_inverse(self, indptr, indices):
+        ip, ix = _i32(indptr), _i32(indices)
+        self._call("fe_bind_coarse_inverse", int(ip.size - 1), _ptr(ip),
+                   _ptr(ix))
 
     def fe_update(self, xu, v=None, ru=None, mem=MEM_HOST):
         self._call("fe_update", _ptr(xu), _ptr(v), _ptr(ru), mem)

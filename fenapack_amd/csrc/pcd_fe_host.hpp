@@ -37,6 +37,10 @@ struct FeState {
   int64_t nnz_kp = 0; double kp_scale = 1.0; bool kp_bound = false;
   DBuf<int> kp_ptr, kp_src;
   DBuf<double> kp_const, kp_cells, kp_vals;
+  // coarsest level inverted on the device (pattern of its scalar operator)
+  int64_t inv_n = 0; bool inv_bound = false;
+  DBuf<int> inv_rowptr, inv_col, inv_flag;
+  DBuf<double> inv_W;
   int mg_slot = -1, est_iters = 12;
   double emin_f = 0.1, emax_f = 1.1;
   DBuf<double> xu, v, ru, y, parts, slot;
@@ -47,6 +51,7 @@ struct FeState {
     sys_pos.release(); kp_ptr.release(); kp_src.release(); kp_const.release();
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
     ru.release(); y.release(); parts.release(); slot.release();
+    inv_rowptr.release(); inv_col.release(); inv_flag.release(); inv_W.release();
   }
 };
 
@@ -138,7 +143,51 @@ static int fe_estimate_emax(Engine* h, FeState& fe, FeLevel& L, const DCsr& A,
   return 0;
 }
 
+// level 0 of the multigrid = dense inverse of the coarsest operator F_0 x I_d
+static int fe_invert_coarsest(Engine* h, FeState& fe, MgLevel& M0) {
+  const int n = (int)fe.inv_n, d = fe.dim;
+  const int64_t N = (int64_t)n * d;
+  if (!M0.A.set || M0.A.nrows != N || M0.A.nnz != N * N)
+    return fail(PCD_ERR_STATE, "fe: multigrid level 0 is not the dense %lld x %lld inverse",
+                (long long)N, (long long)N);
+  HIPCHK(hipMemsetAsync(fe.inv_flag.p, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_gj_init, dim3(n), dim3(kBlock), 0, h->stream, n, fe.inv_rowptr.p,
+                     fe.inv_col.p, fe.lev[0].F.p, fe.inv_W.p);
+  for (int k = 0; k < n; ++k) {
+    hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(kBlock), 0, h->stream, n, k, fe.inv_W.p, fe.inv_flag.p);
+    hipLaunchKernelGGL(k_gj_eliminate, dim3(n), dim3(kBlock), 0, h->stream, n, k, fe.inv_W.p);
+  }
+  hipLaunchKernelGGL(k_gj_store, dim3(grid1d(N * N, 4, 1 << 16)), dim3(kBlock), 0, h->stream, n, d,
+                     fe.inv_W.p, M0.A.val.p);
+  HIPCHK(hipGetLastError());
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, fe.inv_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (flag) return fail(PCD_ERR_STATE, "fe: the coarsest operator is singular");
+  CHK(refresh_dinv(h, M0.A));
+  return 0;
+}
+
 extern "C" {
+
+// invert the coarsest level on the device after every update: rowptr/col =
+// CSR pattern of its scalar operator (n0 rows, the order of
+// pcd_fe_get_level_values(h, 0, .)); needs pcd_fe_bind_mg
+int pcd_fe_bind_coarse_inverse(pcd_handle h, int64_t n0, const int32_t* rowptr,
+                               const int32_t* colidx) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_coarse_inverse: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (n0 < 1 || n0 > 8192 || !rowptr || !colidx || !fe.lev[0].set || rowptr[n0] != fe.lev[0].nnzf)
+    return fail(PCD_ERR_ARG, "fe_bind_coarse_inverse: bad pattern (n0 <= 8192)");
+  HIPCHK(hipSetDevice(h->device));
+  fe.inv_n = n0;
+  CHK(fe_upload(fe.inv_rowptr, rowptr, (size_t)n0 + 1));
+  CHK(fe_upload(fe.inv_col, colidx, (size_t)rowptr[n0]));
+  CHK(fe.inv_W.ensure((size_t)2 * n0 * n0));
+  CHK(fe.inv_flag.ensure(1));
+  fe.inv_bound = true;
+  return 0;
+}
 
 int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
                  const double* phi, const double* dphi, const double* psi) {
@@ -369,6 +418,7 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
       CHK(fe_estimate_emax(h, fe, L, *A, &lam));
       M.emin = fe.emin_f * lam; M.emax = fe.emax_f * lam;
     }
+    if (fe.inv_bound) CHK(fe_invert_coarsest(h, fe, s.mg[0]));
     ++h->gen;                            // Chebyshev coefficients are baked in
   }
   // Kp

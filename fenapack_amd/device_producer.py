@@ -20,6 +20,7 @@ with ``pcd_fe_update`` + the outer GMRES; per iteration the host only applies
 constant blocks to vectors and inverts the coarsest scalar operator.
 """
 
+import os
 import time
 
 import numpy as np
@@ -168,9 +169,14 @@ class DeviceProducer(object):
                 self._set_level(l, pl, injection_map(chain[lh + 1], d))
         self._bind_system()
         self._bind_kp(ksp1)
-        if self.mg:
-            a, b, cc, dd = ksp0.pc.mg_esteig
-            eng.fe_bind_mg(c.KSP_A00, b, dd, 12)
+        a, b, cc, dd = ksp0.pc.mg_esteig
+        eng.fe_bind_mg(c.KSP_A00, b, dd, 12)
+        # the coarsest level's dense inverse: on the device as well, unless
+        # asked otherwise (host LAPACK; kept as a cross-check)
+        self.device_inverse = os.environ.get("PCD_FE_HOST_INVERSE") != "1" \
+            and self._pat[0][2] <= 8192
+        if self.device_inverse:
+            eng.fe_bind_coarse_inverse(self._pat[0][0], self._pat[0][1])
         # constant host pieces of the residual
         self._bc_idx = pb.bc_u_idx
         self.timing = {"update": 0.0, "coarse_inverse": 0.0, "host": 0.0}
@@ -280,7 +286,7 @@ class DeviceProducer(object):
         t1 = time.perf_counter()
         self.eng.fe_update(np.ascontiguousarray(xu), v, ru)
         t2 = time.perf_counter()
-        if self.mg:
+        if not self.device_inverse:
             self._refresh_coarsest()
         t3 = time.perf_counter()
         Fu = ru + pb._A01_raw @ xp

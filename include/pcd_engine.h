@@ -287,6 +287,13 @@ int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const);
  * steps cold, a quarter of that warm) - [ext PETSc] -mg_levels_esteig        */
 int pcd_fe_bind_mg(pcd_handle h, int slot, double emin_factor,
                    double emax_factor, int iters);
+/* Invert the coarsest level on the device after every update (Gauss-Jordan
+ * with partial pivoting; level 0 of the hierarchy must be the dense
+ * (dim n0)^2 inverse): rowptr/colidx = CSR pattern of the coarsest scalar
+ * operator, n0 <= 8192.  Without it the caller fetches level 0, inverts and
+ * calls pcd_mg_update_values itself.                                         */
+int pcd_fe_bind_coarse_inverse(pcd_handle h, int64_t n0, const int32_t* rowptr,
+                               const int32_t* colidx);
 /* Assemble at the iterate xu (velocity dofs, fieldsplit-local numbering) and
  * refresh system, A00, A01, Kp, multigrid levels in place.  If v/ru are given:
  * ru = (unconstrained velocity operator) v.  The coarsest level is left to

@@ -152,3 +152,20 @@ def test_unsteady_loop_matches_the_host_driven_loop(hip_lib, variant, pcdr,
             assert abs(i - j) <= max(1, 0.05 * j), (out["krylov_per_newton"],
                                                     ref["krylov_per_newton"])
     assert relerr(out["w"].vector(), ref["w"].vector()) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["cavity", "cube"])
+def test_device_coarse_inverse_equals_the_host_one(hip_lib, kind, monkeypatch):
+    """Gauss-Jordan on the device vs LAPACK on the host for the coarsest
+    level: same Picard history."""
+    outs = []
+    for host_inverse in ("1", "0"):
+        monkeypatch.setenv("PCD_FE_HOST_INVERSE", host_inverse)
+        pb = _problem(kind)
+        _options(pb.space.dim, galerkin=True)
+        outs.append(solve_steady_device(pb, max_newton=6))
+        assert outs[-1]["producer"].device_inverse == (host_inverse == "0")
+    ref, out = outs
+    assert out["krylov_per_step"] == ref["krylov_per_step"]
+    assert np.allclose(out["residuals"], ref["residuals"], rtol=1e-6)
+    assert relerr(out["w"].vector(), ref["w"].vector()) < 1e-9
