@@ -330,7 +330,7 @@ def pmc_traffic(n_u, nnz_a00, world):
     measurement is for exactly this operator."""
     name = "r01_pmc_cheb_step_level6.json" \
         if os.environ.get("PCD_NO_KRON2") == "1" \
-        else "r01_pmc_cheb_step_kron2_level6.json"
+        else "r01_m_pmc_cheb_step_sc_level6.json"
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         k = d.get("k_cheb_step_s<256>", d)
