@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--no-graph", action="store_true",
                    help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-producer", action="store_true",
+                   help="skip the end-to-end Picard-step timing at the end")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
 
@@ -102,7 +104,13 @@ def main():
     nls.parameters["error_on_nonconvergence"] = False
     # M2: real Picard steps from w = 0 on the GPU; the matrices of the last
     # one (Picard iterate `picard_steps`) are the frozen microbench state
+    t_nls = time.time()
     nls.solve(nlp, w.vector(), on_update=w.touch)
+    # host-producer time per step of this solve; it includes the one-off
+    # set-up of the first step (tools/device_producer_timing.py separates
+    # the two: 2.6 s per step at level 6)
+    HOST_STEP_SECONDS["value"] = (time.time() - t_nls) / max(
+        len(nls.krylov_history), 1)
     gmres_per_step = list(nls.krylov_history)
     ksp = nls.linear_solver().ksp()
     eng = ksp.engine
@@ -316,10 +324,52 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, pb, ksp, eng, c, x)
+    if world == 1 and args.inner == "mg" and not args.no_producer:
+        # end-to-end context, after everything that is reported above: two
+        # more Picard steps with the device operator producer
+        # against the host producer's time for the steps done during setup
+        try:
+            out["picard_step"] = picard_step_times(pb, w, nls, ksp, c)
+        except Exception as exc:                  # never lose the bench line
+            out["picard_step"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def picard_step_times(pb, w, nls, ksp, c):
+    """Seconds per nonlinear step: host (numpy) producer as timed by the
+    set-up solve vs. the engine's device producer for two further steps."""
+    from fenapack_amd.device_producer import DeviceProducer
+    V = pb.space
+    t0 = time.perf_counter()
+    prod = DeviceProducer(pb, ksp)
+    t_plan = time.perf_counter() - t0
+    x = w.vector()
+    solver = nls.linear_solver()
+    dx = np.zeros_like(x)
+    b = prod.update(x[V.is_u], x[V.is_p])
+    steps, its_hist = 2, []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dx[:] = 0.0
+        its, _ = ksp.engine.gmres_solve(
+            b, dx, c.MEM_HOST, solver.parameters["relative_tolerance"],
+            solver.parameters["absolute_tolerance"], ksp.restart,
+            solver.parameters["maximum_iterations"])
+        its_hist.append(its)
+        x -= dx
+        b = prod.update(x[V.is_u], x[V.is_p])
+    dt = (time.perf_counter() - t0) / steps
+    return {"device_producer_seconds": dt, "gmres_its": its_hist,
+            "plan_seconds": t_plan,
+            "host_producer_seconds_incl_setup": HOST_STEP_SECONDS.get("value"),
+            "what": "assemble operators of all multigrid levels + Kp + "
+                    "residual, outer GMRES to rtol 1e-6, update"}
+
+
+HOST_STEP_SECONDS = {}
 
 
 def pmc_traffic(n_u, nnz_a00, world):

@@ -86,9 +86,9 @@ def galerkin_plan(rows_f, cols_f, P):
     rows_f = np.asarray(rows_f, dtype=np.int64)
     cols_f = np.asarray(cols_f, dtype=np.int64)
     est = float(np.diff(P.indptr).mean()) * rows_f.size
-    if est * 8 > MAX_GALERKIN_PAIRS:
+    if est > MAX_GALERKIN_PAIRS:
         raise ValueError("Galerkin plan of ~%.3g pairs exceeds the limit; use "
-                         "-pc_mg_galerkin none" % (est * 8))
+                         "-pc_mg_galerkin none" % est)
     # B = F P: entry (i, J) collects F[i, j] * P[j, J]
     k_rep, pidx = _expand_by_rows(P, cols_f)
     key = rows_f[k_rep] * ncoarse + P.indices[pidx]
