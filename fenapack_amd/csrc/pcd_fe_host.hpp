@@ -445,7 +445,9 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
     DCsr& A = h->mat[PCD_MAT_A00];
     if (!A.set || A.kron != fe.dim || A.nnz2 != Lt.nnzf)
       return fail(PCD_ERR_STATE, "fe_update: A00 is not F x I_%d on the FE pattern", fe.dim);
-    std::swap(A.val2.p, fe.Func.p);
+    if (!kron_ok(A, dv, dru))
+      return fail(PCD_ERR_ARG, "fe_update: v / ru must be 16-byte aligned for the two-component SpMV");
+    std::swap(A.val2.p, fe.Func.p);      // same pattern, unmasked values
     const int rc = spmv(h, A, dv, dru);
     std::swap(A.val2.p, fe.Func.p);
     if (rc) return rc;

@@ -169,3 +169,28 @@ def test_device_coarse_inverse_equals_the_host_one(hip_lib, kind, monkeypatch):
     assert out["krylov_per_step"] == ref["krylov_per_step"]
     assert np.allclose(out["residuals"], ref["residuals"], rtol=1e-6)
     assert relerr(out["w"].vector(), ref["w"].vector()) < 1e-9
+
+
+def test_c_abi_error_behaviour(hip_lib):
+    """Nonzero status + message for calls out of order or with bad data."""
+    from fenapack_amd import _cabi as c
+    e = c.Engine(hip_lib, "BRM1", 0)
+    z = np.zeros(4)
+    with pytest.raises(c.EngineError, match="pcd_fe_begin first"):
+        e.fe_update(z)
+    with pytest.raises(c.EngineError, match="dim must be 2 or 3"):
+        e.fe_begin(4, 1, z, z, z, z)
+    pb = Cavity(1, nu=0.01)
+    V = pb.space
+    from fenapack_amd.fem.taylor_hood import _p2_basis
+    _, dphi = _p2_basis(V.psi, V.local_edges)
+    e.fe_begin(2, 2, V.wq[0] / V.area[0], V.phi, dphi, V.psi)
+    with pytest.raises(c.EngineError, match="a level is not set"):
+        e.fe_update(np.zeros(V.n_u))
+    with pytest.raises(c.EngineError, match="multigrid levels"):
+        e.fe_bind_mg(c.KSP_A00, 0.1, 1.1)
+    with pytest.raises(c.EngineError, match="not a coarse level"):
+        e.fe_set_level_galerkin(1, np.zeros(2, dtype=np.int64), [0], [1.0],
+                                np.zeros(2, dtype=np.int64), [0], [1.0])
+    with pytest.raises(c.EngineError, match="Kp is not bound"):
+        e.fe_kp_values(3)
