@@ -58,6 +58,13 @@ def parse():
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner
+    # through C stdio on file descriptor 1 when a communicator is created
+    # (flushed at exit, i.e. after our line), so keep a private handle on the
+    # real stdout for the JSON line and point fd 1 at stderr for everyone else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -333,7 +340,8 @@ def main():
         except Exception as exc:                  # never lose the bench line
             out["picard_step"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.destroy_process_group()
 
