@@ -168,6 +168,12 @@ def main():
     else:
         ksp0.push_settings()
     nnz_a00 = int(eng.info(c.INFO_NNZ_BASE + c.MAT_A00))
+    ncomp = int(eng.info(c.INFO_A00_COMPONENTS))
+    rows_wg = int(eng.info(c.INFO_A00_ROWS_PER_WG))
+    kernel_name = ("pcd::k_cheb_step_sc<%d, %d>" % (rows_wg, ncomp)) if ncomp \
+        else ("pcd::k_cheb_step_s<%d>" % rows_wg if rows_wg
+              else "pcd::k_cheb_step<LPR>")
+    kernel_name += " on the finest A00"
     b_kernel = rf.b_cheb(V.n_u, nnz_a00) / world      # per GPU
     achieved = b_kernel / t_kernel / 1e9
 
@@ -318,7 +324,7 @@ def main():
         "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_cheb_step_sc (F x I_dim) / k_cheb_step_s (finest A00)",
+            "kernel": kernel_name,
             "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / rf.HBM_PEAK_GBS,
             "bytes_per_launch": int(b_kernel),

@@ -214,17 +214,27 @@ static int choose_lpr(const DCsr& A) {
 // rows per workgroup for the CSR-stream kernels: the largest of 256/128/64
 // whose every row block fits the LDS tile; 0 = some row block is too long
 static int g_max_rb = 256;              // PCD_MAX_RB: A/B switch
-static int choose_rb(int64_t nrows, const int32_t* rowptr) {
+static int g_min_wgs = 512;             // PCD_MIN_WGS: A/B switch (see rb_for)
+// rows per workgroup: the largest RB whose every row block fits the LDS tile
+// and - optionally - that still yields `g_min_wgs` workgroups (small
+// operators then take smaller row blocks: more, shorter workgroups)
+static int rb_for(int64_t nrows, const int32_t* rowptr, int tile) {
+  int fit = 0;
   for (int rb : {256, 128, 64, 32}) {
     if (rb > g_max_rb) continue;
     bool ok = true;
     for (int64_t r = 0; r < nrows && ok; r += rb) {
       const int64_t r1 = std::min<int64_t>(r + rb, nrows);
-      if (rowptr[r1] - rowptr[r] > kTile) ok = false;
+      if (rowptr[r1] - rowptr[r] > tile) ok = false;
     }
-    if (ok) return rb;
+    if (!ok) continue;
+    fit = rb;                            // smaller ones fit as well
+    if ((nrows + rb - 1) / rb >= g_min_wgs) return rb;
   }
-  return 0;
+  return fit;                            // 0: nothing fits; else the smallest
+}
+static int choose_rb(int64_t nrows, const int32_t* rowptr) {
+  return rb_for(nrows, rowptr, kTile);
 }
 // workgroups for a stream kernel: one per row block (capped), multiple of 8
 static inline int grid_stream(int64_t nrows, int rb, int cap = 1 << 20) {
@@ -1037,14 +1047,7 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     }
     rpc[s + 1] = (int32_t)cc.size();
   }
-  int rb2 = 0;
-  for (int rb : {256, 128, 64, 32}) {
-    if (rb > g_max_rb) continue;
-    bool ok = true;
-    for (int64_t r = 0; r < nn && ok; r += rb)
-      if (rpc[std::min<int64_t>(r + rb, nn)] - rpc[r] > kTileC) ok = false;
-    if (ok) { rb2 = rb; break; }
-  }
+  const int rb2 = rb_for(nn, rpc.data(), kTileC);
   if (!rb2) return 0;
   A.nnz2 = (int64_t)cc.size();
   CHK(A.rowptr2.ensure(nn + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2));
@@ -1187,6 +1190,7 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_FORCE_CSR_VECTOR"); g_force_vector = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_KRON2"); g_no_kron = e && e[0] == '1'; }
   { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
+  { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
   { const char* e = getenv("PCD_NO_XCD_REMAP");
     if (e && e[0] == '1') {
       const int none = 0;
@@ -1853,6 +1857,10 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_GMRES_RNORM: *out = h->gmres_rnorm; return 0;
     case PCD_INFO_N_U_LOCAL: *out = (double)h->nu_loc; return 0;
     case PCD_INFO_N_P_LOCAL: *out = (double)h->np_loc; return 0;
+    case PCD_INFO_A00_COMPONENTS: *out = (double)h->mat[PCD_MAT_A00].kron; return 0;
+    case PCD_INFO_A00_ROWS_PER_WG:
+      *out = (double)(h->mat[PCD_MAT_A00].kron ? h->mat[PCD_MAT_A00].rb2 : h->mat[PCD_MAT_A00].rb);
+      return 0;
     default:
       if (key >= PCD_INFO_NNZ_BASE && key < PCD_INFO_NNZ_BASE + PCD_MAT_COUNT) {
         const DCsr& A = h->mat[key - PCD_INFO_NNZ_BASE];

@@ -79,6 +79,10 @@ enum pcd_info {
   PCD_INFO_NUM_PCD_APPLY = 6, PCD_INFO_NUM_FS_APPLY = 7,
   PCD_INFO_GMRES_ITS = 8, PCD_INFO_GMRES_RNORM = 9,
   PCD_INFO_N_U_LOCAL = 10, PCD_INFO_N_P_LOCAL = 11,  /* rows of this rank */
+  /* kernel path of the velocity block: components carried together by the
+   * multi-component kernels (2 / 3; 0 = scalar path) and rows (nodes) per
+   * workgroup of its stream kernels (0 = CSR-vector fallback) */
+  PCD_INFO_A00_COMPONENTS = 12, PCD_INFO_A00_ROWS_PER_WG = 13,
   PCD_INFO_NNZ_BASE = 16     /* + pcd_mat: stored nonzeros of that operator */
 };
 
