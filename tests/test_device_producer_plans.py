@@ -1,0 +1,82 @@
+"""CPU suite: the static plans the device operator producer is driven by
+(contribution lists, Galerkin gather lists, injection maps) evaluated with
+numpy against the host assembler / scipy products."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from fenapack_amd.device_producer import (_contribution_plan, galerkin_plan)
+from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
+from fenapack_amd.fem.multigrid import injection_map
+
+
+def _gather(ptr, src, cells, const=None):
+    """What k_fe_gather computes (component-major element storage)."""
+    s = np.add.reduceat(np.concatenate([cells[src], [0.0]]), ptr[:-1])
+    s[np.diff(ptr) == 0] = 0.0
+    return s if const is None else s + const
+
+
+@pytest.mark.parametrize("make", [lambda: Cavity(2), lambda: BackwardStep(2),
+                                  lambda: Cavity3D(1, n0=2)])
+def test_contribution_plan_reproduces_bincount_assembly(make):
+    pb = make()
+    V = pb.space
+    rng = np.random.default_rng(0)
+    for name, nloc in (("SS", V.na), ("PP", V.nvl)):
+        pat = V._patterns(False)[name]
+        nc = V.mesh.num_cells
+        vals = rng.standard_normal((nc, nloc, nloc))
+        ptr, src = _contribution_plan(pat.inv, nc, nloc * nloc, pat.nnz)
+        assert ptr[-1] == nc * nloc * nloc
+        # component-major storage: [ab][cell]
+        cells = vals.reshape(nc, -1).T.ravel()
+        got = _gather(ptr.astype(np.int64), src, cells)
+        ref = pat.assemble(vals).data
+        assert np.allclose(got, ref, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("make,d", [(lambda: Cavity(3), 2),
+                                    (lambda: BackwardStep(2), 2),
+                                    (lambda: Cavity3D(1, n0=2), 3)])
+def test_galerkin_plan_equals_the_triple_product(make, d):
+    pb = make()
+    V = pb.space
+    rng = np.random.default_rng(1)
+    xu = rng.standard_normal(V.n_u)
+    A00 = pb.linearise(xu, np.zeros(V.n_p))["A00"]
+    F = sp.csr_matrix(A00)[::d, ::d]
+    F.sort_indices()
+    pat = V._patterns(False)["SS"]
+    assert np.array_equal(F.indices, pat.indices)      # F x I_d on SS
+    Ps = sp.csr_matrix(pb.interpolations().velocity[-1])[::d, ::d]
+    rows = np.repeat(np.arange(V.nn), np.diff(pat.indptr))
+    b_ptr, b_src, b_w, c_ptr, c_src, c_w, indptr, indices = \
+        galerkin_plan(rows, pat.indices, Ps)
+    B = np.add.reduceat(b_w * F.data[b_src], b_ptr[:-1])
+    C = np.add.reduceat(c_w * B[c_src], c_ptr[:-1])
+    got = sp.csr_matrix((C, indices, indptr), shape=(Ps.shape[1],) * 2)
+    ref = (Ps.T @ F @ Ps).tocsr()
+    # scipy drops exact cancellations: structural pattern >= scipy's
+    assert got.nnz >= ref.nnz
+    assert abs(got - ref).max() < 1e-13 * abs(ref).max()
+    # the pattern does not depend on the values
+    F2 = F.copy()
+    F2.data[:] = 1.0
+    ref2 = (Ps.T @ F2 @ Ps).tocsr()
+    ref2.sort_indices()
+    assert np.array_equal(ref2.indices, indices)
+
+
+@pytest.mark.parametrize("make,d", [(lambda: Cavity(3), 2),
+                                    (lambda: Cavity3D(1, n0=2), 3)])
+def test_injection_map_picks_coincident_nodes(make, d):
+    pb = make()
+    chain = pb.interpolations().velocity
+    fine = pb.space
+    coarse = pb._same_problem_on_level(len(chain) - 2).space
+    inj = injection_map(chain[-1], d)
+    assert inj.size == coarse.nn and np.unique(inj).size == inj.size
+    assert np.allclose(fine.node_coords[inj], coarse.node_coords, atol=1e-12)
+    with pytest.raises(ValueError):
+        injection_map(sp.csr_matrix(chain[-1]) * 0.5, d)
