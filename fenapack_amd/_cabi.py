@@ -78,6 +78,7 @@ _HIP_ONLY = {
     "fe_set_level_galerkin": [C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p],
+    "fe_set_supg": [C.c_int, C.c_void_p, C.c_double, C.c_void_p],
     "fe_bind_system": [C.c_void_p],
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
     "fe_set_kp_const": [C.c_void_p],
@@ -327,6 +328,11 @@ class Engine(object):
         self._call("fe_set_level_galerkin", int(level), int(c_ptr.size - 1),
                    int(b_ptr.size - 1), _ptr(b_ptr), _ptr(b_src), _ptr(b_w),
                    _ptr(c_ptr), _ptr(c_src), _ptr(c_w))
+
+    def fe_set_supg(self, level, cell_h, nu, phi_mid):
+        cell_h, phi_mid = _f64(cell_h), _f64(phi_mid)
+        self._call("fe_set_supg", int(level), _ptr(cell_h), float(nu),
+                   _ptr(phi_mid))
 
     def fe_bind_system(self, sys_pos):
         sys_pos = np.ascontiguousarray(sys_pos, dtype=np.int64)

@@ -27,17 +27,24 @@ struct FeTables {
   const double* phi;    // nq * NA     P2 basis at the quadrature points
   const double* dphi;   // nq * NA * NV  d phi_a / d lambda_k
   const double* psi;    // nq * NV     P1 basis (= barycentric coordinates)
+  const double* phic;   // NA          P2 basis at the cell midpoint (SUPG)
 };
 
 // One thread per (cell c, local row a): row a of the P2 convection matrix
 //   C[a][b] = sum_q w_q |K| phi_a(q) (w(q) . grad phi_b(q)),
 //   w(q) = sum_a phi_a(q) U_a.
 // dofs2 [a][c], gradlam [(k*DIM+d)][c], cells out [(a*NA+b)][c].
+// With `cells_s` (optional): the streamline-diffusion term of the SUPG
+// preconditioner matrix (demo_navier-stokes-pcd.py:122-125),
+//   S[a][b] = delta_c sum_q w_q |K| (w.grad phi_a)(w.grad phi_b),
+//   Pe = |w_mid| h rho / (2 nu),  delta_c = Pe > 1 ? h (1 - 1/Pe) / (2 |w_mid|) : 0
+// (fenapack/stabilization.py:66-67, rho = 1, h = `cell_h`).
 template <int DIM>
 __global__ __launch_bounds__(kBlock) void k_fe_convection_p2(
     int nc, const int* __restrict__ dofs2, const double* __restrict__ gradlam,
     const double* __restrict__ measure, const FeTables T,
-    const double* __restrict__ U, double* __restrict__ cells) {
+    const double* __restrict__ U, double* __restrict__ cells,
+    const double* __restrict__ cell_h, double nu, double* __restrict__ cells_s) {
   constexpr int NV = DIM + 1, NA = DIM == 2 ? 6 : 10;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= (int64_t)NA * nc) return;
@@ -55,6 +62,23 @@ __global__ __launch_bounds__(kBlock) void k_fe_convection_p2(
     acc[b] = 0.0;
   }
   const double meas = measure[c];
+  double delta = 0.0, accs[NA];
+  if (cells_s) {
+    double wm[DIM], n2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) wm[d] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NA; ++b)
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) wm[d] += T.phic[b] * Uc[b][d];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) n2 += wm[d] * wm[d];
+    const double wn = sqrt(n2), hc = cell_h[c];
+    const double pe = 0.5 * wn * hc / nu;
+    if (pe > 1.0) delta = 0.5 * hc * (1.0 - 1.0 / pe) / wn;
+#pragma unroll
+    for (int b = 0; b < NA; ++b) accs[b] = 0.0;
+  }
   for (int q = 0; q < T.nq; ++q) {
     double w[DIM];
 #pragma unroll
@@ -74,16 +98,27 @@ __global__ __launch_bounds__(kBlock) void k_fe_convection_p2(
       wl[k] = s;
     }
     const double f = T.qw[q] * meas * T.phi[q * NA + a];
+    double sa = 0.0;                     // (w . grad phi_a)(q)
+    if (cells_s) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) sa += T.dphi[(q * NA + a) * NV + k] * wl[k];
+      sa *= T.qw[q] * meas * delta;
+    }
 #pragma unroll
     for (int b = 0; b < NA; ++b) {
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < NV; ++k) s += T.dphi[(q * NA + b) * NV + k] * wl[k];
       acc[b] += f * s;
+      if (cells_s) accs[b] += sa * s;
     }
   }
 #pragma unroll
   for (int b = 0; b < NA; ++b) cells[(int64_t)(a * NA + b) * nc + c] = acc[b];
+  if (cells_s) {
+#pragma unroll
+    for (int b = 0; b < NA; ++b) cells_s[(int64_t)(a * NA + b) * nc + c] = accs[b];
+  }
 }
 
 // One thread per cell: P1 convection matrix of the pressure space
@@ -143,16 +178,25 @@ __global__ __launch_bounds__(kBlock) void k_fe_convection_p1(
 // entry k = cst[k] + sum of its element contributions (list order); `unc`
 // (optional) receives the unconstrained value, `out` the one with Dirichlet
 // rows/columns removed (keep[k] == 0)
+// `cells_s` / `out_s` (optional): the same entry with the stabilisation
+// contributions added (the preconditioner's operator); `out` may then be null
 __global__ __launch_bounds__(kBlock) void k_fe_gather(
     int64_t nnz, const int* __restrict__ ptr, const int* __restrict__ src,
     const double* __restrict__ cells, const double* __restrict__ cst,
-    const unsigned char* __restrict__ keep, double* unc, double* out) {
+    const unsigned char* __restrict__ keep, double* unc, double* out,
+    const double* __restrict__ cells_s, double* out_s) {
   for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
        k += (int64_t)gridDim.x * kBlock) {
     double s = cst ? cst[k] : 0.0;
     for (int t = ptr[k]; t < ptr[k + 1]; ++t) s += cells[src[t]];
+    const bool kept = !(keep && !keep[k]);
     if (unc) unc[k] = s;
-    out[k] = (keep && !keep[k]) ? 0.0 : s;
+    if (out) out[k] = kept ? s : 0.0;
+    if (out_s) {
+      double s2 = s;
+      for (int t = ptr[k]; t < ptr[k + 1]; ++t) s2 += cells_s[src[t]];
+      out_s[k] = kept ? s2 : 0.0;
+    }
   }
 }
 

@@ -11,7 +11,10 @@ struct FeLevel {
   DBuf<double> gradlam, measure, f_const, diag_val;
   DBuf<unsigned char> f_keep;
   DBuf<double> U, cells, F, ev;
+  DBuf<double> cell_h, cells_s, Fa;    // SUPG: cell sizes, its element storage,
+                                       // the unstabilised operator (finest level)
   bool set = false, ev_init = false;
+  double ev_lam = 0.0;                 // last eigenvalue estimate (warm starts)
   // Galerkin level: F = P^T F_finer P by two weighted gathers (no mesh data)
   bool galerkin = false;
   int64_t nnzb = 0;
@@ -21,6 +24,7 @@ struct FeLevel {
   void release() {
     b_ptr.release(); c_ptr.release(); b_src.release(); c_src.release();
     b_w.release(); c_w.release(); B.release();
+    cell_h.release(); cells_s.release(); Fa.release();
     dofs2.release(); f_ptr.release(); f_src.release(); diag_pos.release();
     inject.release(); gradlam.release(); measure.release(); f_const.release();
     diag_val.release(); f_keep.release(); U.release(); cells.release();
@@ -30,7 +34,8 @@ struct FeLevel {
 
 struct FeState {
   int dim = 0, nlev = 0, nq = 0;
-  DBuf<double> qw, phi, dphi, psi;
+  DBuf<double> qw, phi, dphi, psi, phic;
+  bool supg = false; double nu = 0.0;
   std::vector<FeLevel> lev;
   DBuf<double> Func;                 // unconstrained finest values (residual)
   DBuf<int64_t> sys_pos; bool sys_bound = false;
@@ -48,6 +53,7 @@ struct FeState {
     for (auto& l : lev) l.release();
     lev.clear();
     qw.release(); phi.release(); dphi.release(); psi.release(); Func.release();
+    phic.release();
     sys_pos.release(); kp_ptr.release(); kp_src.release(); kp_const.release();
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
     ru.release(); y.release(); parts.release(); slot.release();
@@ -70,7 +76,7 @@ static int fe_upload(DBuf<T>& b, const T* src, size_t n) {
 }
 
 static FeTables fe_tables(const FeState& fe) {
-  return FeTables{fe.nq, fe.qw.p, fe.phi.p, fe.dphi.p, fe.psi.p};
+  return FeTables{fe.nq, fe.qw.p, fe.phi.p, fe.dphi.p, fe.psi.p, fe.phic.p};
 }
 
 // coarse operator as the Galerkin product of the next finer level's one
@@ -83,23 +89,35 @@ static int fe_galerkin_level(Engine* h, FeLevel& L, const FeLevel& finer) {
   return 0;
 }
 
-// assemble the scalar velocity operator of one level from the wind `U`
+// assemble the scalar velocity operator of one level from the wind `U`.
+// Without SUPG: L.F.  With SUPG: L.F = the stabilised operator (what the
+// preconditioner and its multigrid use); on the finest level (`top`) also
+// L.Fa = the unstabilised one (the system matrix).
 static int fe_assemble_level(Engine* h, FeState& fe, FeLevel& L, const double* U,
-                             double* unc) {
+                             double* unc, bool top) {
   const int na = fe.dim == 2 ? 6 : 10;
   const int64_t nt = (int64_t)na * L.nc;
   const int g = (int)((nt + kBlock - 1) / kBlock);
+  const bool supg = fe.supg;
+  if (supg && !L.cell_h.p) return fail(PCD_ERR_STATE, "fe: SUPG is on but a level has no cell sizes");
+  double* cs = supg ? L.cells_s.p : nullptr;
   if (fe.dim == 2)
-    hipLaunchKernelGGL(k_fe_convection_p2<2>, dim3(g), dim3(kBlock), 0, h->stream,
-                       (int)L.nc, L.dofs2.p, L.gradlam.p, L.measure.p, fe_tables(fe), U, L.cells.p);
+    hipLaunchKernelGGL(k_fe_convection_p2<2>, dim3(g), dim3(kBlock), 0, h->stream, (int)L.nc, L.dofs2.p,
+                       L.gradlam.p, L.measure.p, fe_tables(fe), U, L.cells.p, L.cell_h.p, fe.nu, cs);
   else
-    hipLaunchKernelGGL(k_fe_convection_p2<3>, dim3(g), dim3(kBlock), 0, h->stream,
-                       (int)L.nc, L.dofs2.p, L.gradlam.p, L.measure.p, fe_tables(fe), U, L.cells.p);
+    hipLaunchKernelGGL(k_fe_convection_p2<3>, dim3(g), dim3(kBlock), 0, h->stream, (int)L.nc, L.dofs2.p,
+                       L.gradlam.p, L.measure.p, fe_tables(fe), U, L.cells.p, L.cell_h.p, fe.nu, cs);
+  double* plain = supg ? (top ? L.Fa.p : nullptr) : L.F.p;
   hipLaunchKernelGGL(k_fe_gather, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
-                     L.nnzf, L.f_ptr.p, L.f_src.p, L.cells.p, L.f_const.p, L.f_keep.p, unc, L.F.p);
-  if (L.ndiag)
+                     L.nnzf, L.f_ptr.p, L.f_src.p, L.cells.p, L.f_const.p, L.f_keep.p, unc, plain,
+                     cs, supg ? L.F.p : nullptr);
+  if (L.ndiag) {
     hipLaunchKernelGGL(k_fe_set, dim3(grid1d(L.ndiag)), dim3(kBlock), 0, h->stream,
                        (int)L.ndiag, L.diag_pos.p, L.diag_val.p, L.F.p);
+    if (supg && top)
+      hipLaunchKernelGGL(k_fe_set, dim3(grid1d(L.ndiag)), dim3(kBlock), 0, h->stream,
+                         (int)L.ndiag, L.diag_pos.p, L.diag_val.p, L.Fa.p);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -138,7 +156,11 @@ static int fe_estimate_emax(Engine* h, FeState& fe, FeLevel& L, const DCsr& A,
     if (!(lam > 0.0) || !std::isfinite(lam))
       return fail(PCD_ERR_STATE, "fe: eigenvalue estimate broke down (%g)", lam);
     hipLaunchKernelGGL(k_axpby, dim3(grid1d(n, 4)), dim3(kBlock), 0, h->stream, (int)n, 1.0 / lam, fe.y.p, 0.0, L.ev.p);
+    // a warm start is trusted only while the estimate stays near the last one
+    if (it == iters - 1 && iters < fe.est_iters && std::fabs(lam - L.ev_lam) > 0.1 * lam)
+      iters = fe.est_iters;
   }
+  L.ev_lam = lam;
   *lam_out = lam;
   return 0;
 }
@@ -279,6 +301,29 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f, int64_t nn
   return 0;
 }
 
+// SUPG-stabilised preconditioner matrix (fenapack/stabilization.py:39-68 and
+// its use at demo_navier-stokes-pcd.py:122-127): per re-discretised level the
+// cell sizes h (DOLFIN Cell::h()); nu and the P2 basis at the cell midpoint
+// are shared.  From then on the multigrid and A00/A01 are built from the
+// stabilised operator, the system matrix from the unstabilised one.
+int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
+                    const double* phi_mid) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_supg: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev || !fe.lev[level].set || fe.lev[level].galerkin)
+    return fail(PCD_ERR_ARG, "fe_set_supg: level %d is not a re-discretised level", level);
+  if (!cell_h || !phi_mid || !(nu > 0.0)) return fail(PCD_ERR_ARG, "fe_set_supg: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  FeLevel& L = fe.lev[level];
+  const int na = fe.dim == 2 ? 6 : 10;
+  CHK(fe_upload(L.cell_h, cell_h, (size_t)L.nc));
+  CHK(L.cells_s.ensure((size_t)na * na * L.nc));
+  if (level == fe.nlev - 1) CHK(L.Fa.ensure(L.nnzf));
+  CHK(fe_upload(fe.phic, phi_mid, (size_t)na));
+  fe.nu = nu; fe.supg = true;
+  return 0;
+}
+
 // sys_pos[c * nnz_f + k]: where entry k of the finest scalar operator sits, for
 // component c, in the caller's system values (pcd_set_system's array)
 int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos) {
@@ -385,18 +430,30 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
   if (v) CHK(fe.Func.ensure(Lt.nnzf));
   for (int l = top; l >= 0; --l) {
     if (fe.lev[l].galerkin) CHK(fe_galerkin_level(h, fe.lev[l], fe.lev[l + 1]));
-    else CHK(fe_assemble_level(h, fe, fe.lev[l], fe.lev[l].U.p, (l == top && v) ? fe.Func.p : nullptr));
+    else CHK(fe_assemble_level(h, fe, fe.lev[l], fe.lev[l].U.p, (l == top && v) ? fe.Func.p : nullptr, l == top));
   }
 
   // finest level -> the caller's system values -> A, A00, A01 (+ diagonal)
   if (fe.sys_bound) {
     if (!h->sysvals.p || (int64_t)h->sysvals.n < h->sys_nnz)
       return fail(PCD_ERR_STATE, "fe_update: system values were never staged from the host");
-    if (h->psysvals.p)
-      return fail(PCD_ERR_STATE, "fe_update: a separate preconditioner matrix is not supported");
-    hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
-                       h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, h->sysvals.p);
-    CHK(pcd_update_system(h, h->sysvals.p, nullptr, PCD_MEM_DEVICE));
+    if (fe.supg) {
+      // operator A from the unstabilised values, preconditioner blocks from
+      // the stabilised ones (nonlinear_solvers.py:75-76: P != A)
+      if (!h->psysvals.p || (int64_t)h->psysvals.n < h->sys_nnz)
+        return fail(PCD_ERR_STATE, "fe_update: SUPG needs the preconditioner values staged (pvals of pcd_set_system)");
+      hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                         h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.Fa.p, h->sysvals.p);
+      hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                         h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, h->psysvals.p);
+      CHK(pcd_update_system(h, h->sysvals.p, h->psysvals.p, PCD_MEM_DEVICE));
+    } else {
+      if (h->psysvals.p)
+        return fail(PCD_ERR_STATE, "fe_update: a separate preconditioner matrix needs pcd_fe_set_supg");
+      hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                         h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, h->sysvals.p);
+      CHK(pcd_update_system(h, h->sysvals.p, nullptr, PCD_MEM_DEVICE));
+    }
   }
   // intermediate multigrid levels + smoother bounds
   if (fe.mg_slot >= 0) {
@@ -432,7 +489,8 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
                          Lt.dofs2.p, Lt.gradlam.p, Lt.measure.p, fe_tables(fe), Lt.U.p, fe.kp_scale, fe.kp_cells.p);
     hipLaunchKernelGGL(k_fe_gather, dim3(grid1d(fe.nnz_kp, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
                        fe.nnz_kp, fe.kp_ptr.p, fe.kp_src.p, fe.kp_cells.p, fe.kp_const.p,
-                       (const unsigned char*)nullptr, (double*)nullptr, fe.kp_vals.p);
+                       (const unsigned char*)nullptr, (double*)nullptr, fe.kp_vals.p,
+                       (const double*)nullptr, (double*)nullptr);
     HIPCHK(hipGetLastError());
     if (h->mat[PCD_MAT_KP].set) {
       if (h->mat[PCD_MAT_KP].nnz != fe.nnz_kp)

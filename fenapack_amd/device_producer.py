@@ -121,9 +121,6 @@ class DeviceProducer(object):
         if pb.nls != "picard":
             raise ValueError("device producer: Picard linearisation only "
                              "(the Newton block is not F x I)")
-        if pb.stabilize:
-            raise ValueError("device producer: SUPG preconditioner matrix "
-                             "is assembled on the host")
         self.pb, self.V, self.ksp = pb, V, ksp
         self.eng = eng = ksp.engine
         if not eng.L.hip:
@@ -137,6 +134,12 @@ class DeviceProducer(object):
                              "-fieldsplit_u_pc_type mg (its smoother bounds "
                              "are re-estimated on the device)")
         self.galerkin = bool(ksp0.pc.mg_galerkin)
+        self.supg = bool(pb.stabilize)
+        if self.supg and self.galerkin:
+            raise ValueError("device producer: the SUPG preconditioner "
+                             "matrix goes with -fieldsplit_u_pc_mg_galerkin "
+                             "none (every level re-discretised with its own "
+                             "stabilisation parameter)")
         nlev = len(ksp0.pc.mg_data["ops"]) if self.mg else 1
         self.nlev = nlev
         top_h = len(pb.hierarchy.meshes) - 1
@@ -211,6 +214,11 @@ class DeviceProducer(object):
             l, V.cell_dofs2.T, g.reshape(nc, -1).T, V.area, ptr, src, f_const,
             keep, diag_pos, diag_val, inject, V.nn)
         self._pat[l] = (pat.indptr, pat.indices, V.nn)
+        if self.supg:
+            from .fem.taylor_hood import _p2_basis
+            lam = np.full((1, V.nvl), 1.0 / V.nvl)
+            phi_mid, _ = _p2_basis(lam, V.local_edges)
+            self.eng.fe_set_supg(l, V.cell_h, pl.nu, phi_mid[0])
 
     def _set_level_galerkin(self, l, P):
         """Level ``l`` = P^T (level l+1) P with the scalar part of the

@@ -563,18 +563,28 @@ def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None):
     d[d == 0.0] = 1.0
     dinv = 1.0 / d if jacobi else np.ones_like(d)
     v = None if warm is None else warm.get("v")
-    if v is None or v.size != A.shape[0]:
+    cold = v is None or v.size != A.shape[0]
+    if cold:
         v = np.random.default_rng(seed).standard_normal(A.shape[0])
-    else:
+    full = iters
+    if not cold:
         iters = max(3, iters // 4)
-    lam = 1.0
-    for _ in range(iters):
+    lam, it = 1.0, 0
+    while it < iters:
         v = v / np.linalg.norm(v)
         w = dinv * (A @ v)
         lam = np.linalg.norm(w)
         v = w
+        it += 1
+        # a warm start is only trusted while the estimate stays near the last
+        # one; after a large change of the operator (Stokes -> Oseen step)
+        # iterate as long as a cold start would
+        if it == iters and iters < full and \
+                abs(lam - warm.get("lam", lam)) > 0.1 * lam:
+            iters = full
     if warm is not None:
         warm["v"] = v
+        warm["lam"] = float(lam)
     return float(lam)
 
 

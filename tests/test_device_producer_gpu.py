@@ -118,7 +118,7 @@ def test_refuses_what_it_does_not_assemble(hip_lib):
     with pytest.raises(ValueError):
         solve_steady_device(pb, max_newton=2)
     pb = _problem("cavity", stabilize=True)
-    _options(2)
+    _options(2, galerkin=True)          # SUPG goes with re-discretised levels
     with pytest.raises(ValueError):
         solve_steady_device(pb, max_newton=2)
 
@@ -194,3 +194,54 @@ def test_c_abi_error_behaviour(hip_lib):
                                 np.zeros(2, dtype=np.int64), [0], [1.0])
     with pytest.raises(c.EngineError, match="Kp is not bound"):
         e.fe_kp_values(3)
+
+
+@pytest.mark.parametrize("kind", ["cavity", "cube"])
+def test_supg_preconditioner_matrix_on_the_device(hip_lib, kind):
+    """Config 3 shape: operator A unstabilised, preconditioner blocks and
+    every multigrid level SUPG-stabilised with their own delta(cell)."""
+    nu = 0.002 if kind == "cavity" else 0.01
+    mk = (lambda: Cavity(3, nu=nu, stabilize=True)) if kind == "cavity" \
+        else (lambda: Cavity3D(1, nu=nu, n0=3, stabilize=True))
+    pb = mk()
+    V = pb.space
+    _options(V.dim, coarse_limit=300)
+    out = solve_steady_device(pb, max_newton=1)
+    prod = out["producer"]
+    rng = np.random.default_rng(3)
+    xu = 0.3 * rng.standard_normal(V.n_u)
+    xp = rng.standard_normal(V.n_p)
+    b = prod.update(xu, xp)
+    lin = pb.linearise(xu, xp)
+    assert np.any(V.supg_delta(pb.nodal_velocity(xu), pb.nu) > 0)
+    assert relerr(b, V.to_mixed(lin["bu"], lin["bp"])) < 1e-12
+    # preconditioner operator (stabilised) on every level
+    assert relerr(prod.level_matrix(prod.nlev - 1).data, lin["P00"].data) < 1e-12
+    for l, ref in enumerate(pb.coarse_velocity_operators(xu, prod.nlev)):
+        assert relerr(prod.level_matrix(l).data, ref.data) < 1e-12, l
+    # system operator (unstabilised) as the engine applies it
+    from fenapack_amd import _cabi as c
+    A = V.monolithic(lin["A00"], lin["A01"], lin["A10"])
+    x = rng.standard_normal(V.ndof)
+    eng = out["solver"].linear_solver().ksp().engine
+    perm = np.concatenate([V.is_u, V.is_p])
+    assert relerr(eng.spmv_np(c.MAT_A, x[perm], V.ndof), (A @ x)[perm]) < 1e-12
+    assert relerr(eng.spmv_np(c.MAT_A00, x[:V.n_u], V.n_u),
+                  lin["P00"] @ x[:V.n_u]) < 1e-12
+    # and the whole Picard iteration against the host-driven one
+    outs = []
+    for fn in (solve_steady, solve_steady_device):
+        pb2 = mk()
+        _options(V.dim)
+        outs.append(fn(pb2, max_newton=5))
+    ref, dev = outs
+    assert dev["newton_its"] == ref["newton_its"]
+    # Smoother bounds come from power iterations with different start vectors
+    # (numpy normal vs. a device hash); on these strongly non-normal SUPG
+    # operators the estimates - and with them single GMRES counts - can differ
+    # noticeably (seen: host 191 vs device 89 in one step of the 3-D case), so
+    # the device path is only required to be no worse than the host path
+    for i, j in zip(dev["krylov_per_step"], ref["krylov_per_step"]):
+        assert i <= max(j + 1, 1.05 * j), (dev["krylov_per_step"],
+                                           ref["krylov_per_step"])
+    assert relerr(dev["w"].vector(), ref["w"].vector()) < 1e-5
