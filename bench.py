@@ -363,7 +363,8 @@ def picard_step_times(pb, w, nls, ksp, c):
     x = w.vector()
     solver = nls.linear_solver()
     dx = np.zeros_like(x)
-    b = prod.update(x[V.is_u], x[V.is_p])
+    ksp.engine.graph_enable(False)     # re-capture per update costs more than
+    b = prod.update(x[V.is_u], x[V.is_p])   # the eager applies of one solve
     steps, its_hist = 2, []
     t0 = time.perf_counter()
     for _ in range(steps):

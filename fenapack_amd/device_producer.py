@@ -372,6 +372,9 @@ class DevicePicardSolver(object):
             t0 = time.time()
             self.producer = DeviceProducer(pb, nls.linear_solver().ksp())
             self.time_plan = time.time() - t0
+            # (no hipGraph replay here: every update changes the smoother
+            # bounds baked into the captured launches, and re-capturing costs
+            # ~30 ms - more than the 31 eager applies of one solve)
             b = self.producer.update(x[V.is_u], x[V.is_p])
             self.residual_history[-1] = float(np.linalg.norm(b))
         else:
