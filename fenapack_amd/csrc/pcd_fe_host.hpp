@@ -150,9 +150,14 @@ static int fe_estimate_emax(Engine* h, FeState& fe, FeLevel& L, const DCsr& A,
   } else {
     iters = std::max(3, iters / 4);
   }
+  const bool cold = iters == fe.est_iters;
+  double best = 0.0;
   for (int it = 0; it < iters; ++it) {
     CHK(spmv(h, A, L.ev.p, fe.y.p));
     CHK(sqnorm_of_y(A.dinv.p, &lam));
+    // envelope over the iterations (non-normal operators oscillate); the
+    // first two steps of a cold start only shake off the random start
+    if (!(cold && it < 2)) best = std::max(best, lam);
     if (!(lam > 0.0) || !std::isfinite(lam))
       return fail(PCD_ERR_STATE, "fe: eigenvalue estimate broke down (%g)", lam);
     hipLaunchKernelGGL(k_axpby, dim3(grid1d(n, 4)), dim3(kBlock), 0, h->stream, (int)n, 1.0 / lam, fe.y.p, 0.0, L.ev.p);
@@ -160,6 +165,7 @@ static int fe_estimate_emax(Engine* h, FeState& fe, FeLevel& L, const DCsr& A,
     if (it == iters - 1 && iters < fe.est_iters && std::fabs(lam - L.ev_lam) > 0.1 * lam)
       iters = fe.est_iters;
   }
+  lam = std::max(best, lam);
   L.ev_lam = lam;
   *lam_out = lam;
   return 0;

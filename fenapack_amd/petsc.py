@@ -569,19 +569,26 @@ def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None):
     full = iters
     if not cold:
         iters = max(3, iters // 4)
-    lam, it = 1.0, 0
+    lam, best, it = 1.0, 0.0, 0
     while it < iters:
         v = v / np.linalg.norm(v)
         w = dinv * (A @ v)
         lam = np.linalg.norm(w)
         v = w
         it += 1
+        # non-normal operators (convection, SUPG) make |D^-1 A v| / |v|
+        # oscillate instead of increasing: keep the envelope - an
+        # over-estimate only slows the smoother, an under-estimate breaks it
+        if cold and it <= 2:
+            continue
+        best = max(best, lam)
         # a warm start is only trusted while the estimate stays near the last
         # one; after a large change of the operator (Stokes -> Oseen step)
         # iterate as long as a cold start would
         if it == iters and iters < full and \
                 abs(lam - warm.get("lam", lam)) > 0.1 * lam:
             iters = full
+    lam = max(best, lam) if best > 0.0 else lam
     if warm is not None:
         warm["v"] = v
         warm["lam"] = float(lam)
