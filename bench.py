@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--no-graph", action="store_true",
                    help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--skip-u", default="", help="pc_mg_skip_levels of the "
+                   "velocity multigrid (experiment)")
+    p.add_argument("--skip-p", default="", help="same for Ap")
     p.add_argument("--no-producer", action="store_true",
                    help="skip the end-to-end Picard-step timing at the end")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -103,6 +106,10 @@ def main():
         default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
                               ap_rtol=args.ap_rtol, ap_its=args.ap_its,
                               mp_its=args.mp_its, dim=V.dim)
+    if args.skip_u:
+        PETScOptions.set("fieldsplit_u_pc_mg_skip_levels", args.skip_u)
+    if args.skip_p:
+        PETScOptions.set("fieldsplit_p_PCD_Ap_pc_mg_skip_levels", args.skip_p)
     from fenapack_amd.parallel import Comm
     comm = Comm.world()
     w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150,

@@ -20,7 +20,8 @@ def mass_matrix_bounds(dim):
 
 
 def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
-                            mp_its=5, pcdr=False, galerkin_u=True, dim=2):
+                            mp_its=5, pcdr=False, galerkin_u=True, dim=2,
+                            two_grid_p=True):
     """The reference's "iterative" configuration (demo_navier-stokes-pcd.py:
     152-165: Richardson + one/two multigrid cycles for A00 and Ap, Chebyshev +
     Jacobi for Mp) with hypre BoomerAMG replaced by the engine's geometric
@@ -33,6 +34,12 @@ def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
         S(prefix + key + "ksp_max_it", cycles)
         S(prefix + key + "pc_type", "mg")
         S(prefix + key + "mg_levels_ksp_max_it", smooth)
+    if two_grid_p:
+        # Pressure Laplacian: finest level + explicit coarse inverse, nothing
+        # in between.  On an MI355X a kernel on <= 10^5 rows costs a fixed
+        # 4-6 us whatever it does, and the intermediate levels of this SPD
+        # solve buy no outer iterations for their ~18 launches
+        S(prefix + "fieldsplit_p_PCD_Ap_pc_mg_skip_levels", "all")
     if not galerkin_u:
         # re-discretised (SUPG-stabilised) coarse velocity operators instead
         # of Galerkin products: needed at cell Peclet numbers > 1

@@ -278,6 +278,10 @@ class PC(object):
         self._mg_chain = None
         self.mg_levels = None
         self.mg_coarse_eq_limit = 2000     # like -pc_gamg_coarse_eq_limit
+        # -pc_mg_skip_levels: intermediate levels (1 = first above the
+        # coarsest) left out of the cycle, "all" = two-grid (finest level +
+        # explicit coarse inverse); their interpolations are composed
+        self.mg_skip_levels = ()
         self.mg_smooth_its = 2
         self.mg_esteig = (0.0, 0.1, 0.0, 1.1)
         self.mg_galerkin = True            # -pc_mg_galerkin both | none
@@ -421,6 +425,11 @@ class KSP(object):
         self.pc.mg_levels = o.getInt("pc_mg_levels", self.pc.mg_levels)
         self.pc.mg_coarse_eq_limit = o.getInt("pc_mg_coarse_eq_limit",
                                               self.pc.mg_coarse_eq_limit)
+        skip = o.getString("pc_mg_skip_levels")
+        if skip:
+            self.pc.mg_skip_levels = "all" if str(skip).strip() == "all" \
+                else tuple(int(t) for t in
+                           str(skip).replace(",", " ").split())
         g = o.getString("pc_mg_galerkin")
         if g is not None:
             if g not in ("both", "none"):
@@ -483,6 +492,16 @@ class KSP(object):
                 nlev -= 1
         if nlev < len(chain):
             chain = [None] + chain[len(chain) - nlev + 1:]
+        skip = range(1, len(chain) - 1) if pc.mg_skip_levels == "all" \
+            else pc.mg_skip_levels
+        for k in sorted(skip, reverse=True):
+            # drop level k: level k+1 interpolates straight from level k-1
+            if not 1 <= k < len(chain) - 1:
+                raise ValueError("%spc_mg_skip_levels %d: no such intermediate "
+                                 "level" % (self._prefix, k))
+            merged = sp.csr_matrix(chain[k + 1] @ chain[k])
+            merged.sort_indices()
+            chain = chain[:k] + [merged] + chain[k + 2:]
         if pc.mg_galerkin:
             ops = galerkin_chain(self._ops[1].A, chain)
         else:
