@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--no-graph", action="store_true",
                    help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--smooth-p", type=int, default=None,
+                   help="smoothing steps of the Ap cycle (default: --smooth)")
     p.add_argument("--skip-u", default="", help="pc_mg_skip_levels of the "
                    "velocity multigrid (experiment)")
     p.add_argument("--skip-p", default="", help="same for Ap")
@@ -106,6 +108,9 @@ def main():
         default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
                               ap_rtol=args.ap_rtol, ap_its=args.ap_its,
                               mp_its=args.mp_its, dim=V.dim)
+    if args.smooth_p is not None:
+        PETScOptions.set("fieldsplit_p_PCD_Ap_mg_levels_ksp_max_it",
+                         args.smooth_p)
     if args.skip_u:
         PETScOptions.set("fieldsplit_u_pc_mg_skip_levels", args.skip_u)
     if args.skip_p:
@@ -279,7 +284,8 @@ def main():
                     + rf.b_axpy(V.n_u) + b_a00 + 16 * (V.n_u + V.n_p))
         inner_desc = {
             "Ap": "richardson x%d + mg V(%d,%d), %d levels"
-                  % (k_a, args.smooth, args.smooth,
+                  % (k_a, pcd.ksp_Ap.pc.mg_smooth_its,
+                     pcd.ksp_Ap.pc.mg_smooth_its,
                      len(pcd.ksp_Ap.pc.mg_data["ops"])),
             "Mp": "chebyshev+jacobi its %d eig [%s]"
                   % (k_m, mass_matrix_bounds(V.dim)),
