@@ -80,6 +80,7 @@ print("GMRES iterations per Newton step:", out["krylov_per_step"])
 print("residuals:", ["%.3e" % r for r in out["residuals"]])
 print("solve time: %.2f s" % out["time"])
 if args.producer == "device":
-    print("  of which: plans %.2f s, outer GMRES %.2f s, producer %s"
-          % (out["time_plan"], out["time_gmres"],
+    print("  of which: plans %.2f s, device Picard loop %.3f s "
+          "(host-driven loop: GMRES %.2f s, producer %s)"
+          % (out["time_plan"], out["time_device_loop"], out["time_gmres"],
              {k: round(v, 3) for k, v in out["producer_timing"].items()}))

@@ -85,6 +85,16 @@ _HIP_ONLY = {
     "fe_bind_mg": [C.c_int, C.c_double, C.c_double, C.c_int],
     "fe_bind_coarse_inverse": [C.c_int64, C.c_void_p, C.c_void_p],
     "fe_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
+    "fe_bind_residual": [C.c_void_p] * 6 + [C.c_int64, C.c_void_p,
+                                            C.c_void_p, C.c_void_p,
+                                            C.c_double],
+    "fe_set_bc_values": [C.c_void_p],
+    "fe_set_previous": [C.c_void_p, C.c_int],
+    "fe_residual": [C.c_void_p, C.c_void_p, C.c_int, _f64p],
+    "fe_picard_solve": [C.c_void_p, C.c_int, C.c_double, C.c_double,
+                        C.c_double, C.c_int, C.c_double, C.c_double,
+                        C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int),
+                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int)],
     "fe_get_level_values": [C.c_int, C.c_void_p],
     "fe_get_kp_values": [C.c_void_p],
     "fe_get_bounds": [C.c_int, _f64p, _f64p],
@@ -359,6 +369,46 @@ class Engine(object):
 
     def fe_update(self, xu, v=None, ru=None, mem=MEM_HOST):
         self._call("fe_update", _ptr(xu), _ptr(v), _ptr(ru), mem)
+
+    def fe_bind_residual(self, Bt, B, bc_idx, bc_mult, mass_vals=None,
+                         idt=0.0):
+        keep = [_i32(Bt.indptr), _i32(Bt.indices), _f64(Bt.data),
+                _i32(B.indptr), _i32(B.indices), _f64(B.data),
+                _i32(bc_idx), _f64(bc_mult),
+                None if mass_vals is None else _f64(mass_vals)]
+        self._call("fe_bind_residual", *[_ptr(a) for a in keep[:6]],
+                   int(keep[6].size), _ptr(keep[6]), _ptr(keep[7]),
+                   _ptr(keep[8]), float(idt))
+
+    def fe_set_bc_values(self, g):
+        g = _f64(g)
+        self._call("fe_set_bc_values", _ptr(g))
+
+    def fe_set_previous(self, u0, mem=MEM_HOST):
+        if u0 is not None and mem == MEM_HOST:
+            u0 = _f64(u0)
+        self._call("fe_set_previous", _ptr(u0), mem)
+
+    def fe_residual(self, x, b, mem=MEM_HOST):
+        nrm = C.c_double(0.0)
+        self._call("fe_residual", _ptr(x), _ptr(b), mem, C.byref(nrm))
+        return nrm.value
+
+    def fe_picard_solve(self, x, mem=MEM_HOST, r0=0.0, rtol=1e-9, atol=1e-10,
+                        max_it=50, relax=1.0, lin_rtol=1e-6, lin_atol=0.0,
+                        restart=150, lin_max_it=10000):
+        """Returns (iterations, converged, GMRES counts, residual norms);
+        ``x`` is updated in place."""
+        n_it, conv = C.c_int(0), C.c_int(0)
+        lin = np.zeros(max(max_it, 1), dtype=np.int32)
+        res = np.zeros(max_it + 1)
+        self._call("fe_picard_solve", _ptr(x), mem, float(r0), float(rtol),
+                   float(atol), int(max_it), float(relax), float(lin_rtol),
+                   float(lin_atol), int(restart), int(lin_max_it),
+                   C.byref(n_it), _ptr(lin), _ptr(res), C.byref(conv))
+        k = n_it.value
+        return k, bool(conv.value), [int(v) for v in lin[:k]], \
+            [float(v) for v in res[:k + 1]]
 
     def fe_level_values(self, level, nnz):
         out = np.empty(int(nnz))

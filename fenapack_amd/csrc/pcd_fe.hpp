@@ -338,6 +338,22 @@ __global__ __launch_bounds__(kBlock) void k_gj_store(int n, int d, const double*
   }
 }
 
+// ---- nonlinear residual on the device ---------------------------------------
+// v = x_u with the Dirichlet entries replaced by their boundary values g
+// (v = x_u - d, d = the boundary defect of the iterate)
+__global__ __launch_bounds__(kBlock) void k_fe_bc_replace(
+    int n, const int* __restrict__ idx, const double* __restrict__ g, double* v) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    v[idx[i]] = g[i];
+}
+// Dirichlet rows of the residual: F_u[idx] = mult * (x_u[idx] - g)
+__global__ __launch_bounds__(kBlock) void k_fe_bc_rows(
+    int n, const int* __restrict__ idx, const double* __restrict__ g,
+    const double* __restrict__ mult, const double* __restrict__ xu, double* Fu) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    Fu[idx[i]] = mult[i] * (xu[idx[i]] - g[i]);
+}
+
 // deterministic start vector of the power iteration
 __global__ __launch_bounds__(kBlock) void k_fe_seed(int64_t n, double* v) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;

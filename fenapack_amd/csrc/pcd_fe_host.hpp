@@ -46,6 +46,13 @@ struct FeState {
   int64_t inv_n = 0; bool inv_bound = false;
   DBuf<int> inv_rowptr, inv_col, inv_flag;
   DBuf<double> inv_W;
+  // nonlinear residual on the device (pcd_fe_bind_residual)
+  bool res_bound = false, have_mu0 = false;
+  DCsr A01raw, A10raw;                 // unconstrained constant blocks
+  int64_t n_bc = 0; double idt = 0.0;
+  DBuf<int> bc_idx;
+  DBuf<double> bc_mult, bc_g, mass, mu0, u0;
+  DBuf<double> xd, bd, dxd, xs, bs, vv;
   int mg_slot = -1, est_iters = 12;
   double emin_f = 0.1, emax_f = 1.1;
   DBuf<double> xu, v, ru, y, parts, slot;
@@ -58,6 +65,9 @@ struct FeState {
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
     ru.release(); y.release(); parts.release(); slot.release();
     inv_rowptr.release(); inv_col.release(); inv_flag.release(); inv_W.release();
+    A01raw.release(); A10raw.release(); bc_idx.release(); bc_mult.release();
+    bc_g.release(); mass.release(); mu0.release(); u0.release(); xd.release();
+    bd.release(); dxd.release(); xs.release(); bs.release(); vv.release();
   }
 };
 
@@ -400,31 +410,18 @@ int pcd_fe_bind_mg(pcd_handle h, int slot, double emin_factor,
 // fieldsplit-local numbering) and refresh the engine's operators in place.
 // Optional: ru = (unconstrained velocity operator) * v, the matrix-dependent
 // part of the nonlinear residual (nonlinear_solvers.py:85-112 `F`).
-int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
-                  int mem) {
-  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_update: call pcd_fe_begin first");
-  if (!xu || ((v == nullptr) != (ru == nullptr))) return fail(PCD_ERR_ARG, "fe_update: bad vectors");
-  FeState& fe = *h->fe;
+}  // extern "C" (helpers below are internal)
+
+// Everything that depends on the iterate, refreshed in place from the device
+// vector dxu; `want_unc`: also keep the unmasked finest operator (residual).
+static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) {
   for (auto& L : fe.lev) if (!L.set) return fail(PCD_ERR_STATE, "fe_update: a level is not set");
   for (int l = 1; l < fe.nlev; ++l)
     if (fe.lev[l].galerkin && !fe.lev[l - 1].galerkin)
       return fail(PCD_ERR_STATE, "fe_update: level %d is re-discretised below the Galerkin level %d", l - 1, l);
-  HIPCHK(hipSetDevice(h->device));
   const int top = fe.nlev - 1;
   FeLevel& Lt = fe.lev[top];
   const int64_t nu = fe.dim * Lt.nn2;
-  const double *dxu = xu, *dv = v;
-  double* dru = ru;
-  if (mem == PCD_MEM_HOST) {
-    CHK(fe.xu.ensure(nu));
-    HIPCHK(hipMemcpyAsync(fe.xu.p, xu, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    dxu = fe.xu.p;
-    if (v) {
-      CHK(fe.v.ensure(nu)); CHK(fe.ru.ensure(nu));
-      HIPCHK(hipMemcpyAsync(fe.v.p, v, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
-      dv = fe.v.p; dru = fe.ru.p;
-    }
-  }
   // winds: finest = iterate, coarser levels by injection
   HIPCHK(hipMemcpyAsync(Lt.U.p, dxu, nu * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   for (int l = top - 1; l >= 0; --l) {
@@ -433,10 +430,10 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
     hipLaunchKernelGGL(k_fe_inject, dim3(grid1d(L.nn2, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
                        L.nn2, fe.dim, L.inject.p, fe.lev[l + 1].U.p, L.U.p);
   }
-  if (v) CHK(fe.Func.ensure(Lt.nnzf));
+  if (want_unc) CHK(fe.Func.ensure(Lt.nnzf));
   for (int l = top; l >= 0; --l) {
     if (fe.lev[l].galerkin) CHK(fe_galerkin_level(h, fe.lev[l], fe.lev[l + 1]));
-    else CHK(fe_assemble_level(h, fe, fe.lev[l], fe.lev[l].U.p, (l == top && v) ? fe.Func.p : nullptr, l == top));
+    else CHK(fe_assemble_level(h, fe, fe.lev[l], fe.lev[l].U.p, (l == top && want_unc) ? fe.Func.p : nullptr, l == top));
   }
 
   // finest level -> the caller's system values -> A, A00, A01 (+ diagonal)
@@ -504,21 +501,226 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
       CHK(pcd_update_values(h, PCD_MAT_KP, fe.kp_vals.p, PCD_MEM_DEVICE));
     }
   }
-  // residual part: ru = (F_unconstrained x I) v on the pattern of A00
+  return 0;
+}
+
+// y = (F_unconstrained x I_d) v on the pattern of A00 (needs fe_refresh with
+// want_unc)
+static int fe_apply_unconstrained(Engine* h, FeState& fe, const double* dv, double* dy) {
+  DCsr& A = h->mat[PCD_MAT_A00];
+  FeLevel& Lt = fe.lev[fe.nlev - 1];
+  if (!A.set || A.kron != fe.dim || A.nnz2 != Lt.nnzf)
+    return fail(PCD_ERR_STATE, "fe_update: A00 is not F x I_%d on the FE pattern", fe.dim);
+  if (!kron_ok(A, dv, dy))
+    return fail(PCD_ERR_ARG, "fe_update: v / ru must be 16-byte aligned for the two-component SpMV");
+  std::swap(A.val2.p, fe.Func.p);        // same pattern, unmasked values
+  const int rc = spmv(h, A, dv, dy);
+  std::swap(A.val2.p, fe.Func.p);
+  return rc;
+}
+
+extern "C" {
+
+int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
+                  int mem) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_update: call pcd_fe_begin first");
+  if (!xu || ((v == nullptr) != (ru == nullptr))) return fail(PCD_ERR_ARG, "fe_update: bad vectors");
+  FeState& fe = *h->fe;
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t nu = fe.dim * fe.lev[fe.nlev - 1].nn2;
+  const double *dxu = xu, *dv = v;
+  double* dru = ru;
+  if (mem == PCD_MEM_HOST) {
+    CHK(fe.xu.ensure(nu));
+    HIPCHK(hipMemcpyAsync(fe.xu.p, xu, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    dxu = fe.xu.p;
+    if (v) {
+      CHK(fe.v.ensure(nu)); CHK(fe.ru.ensure(nu));
+      HIPCHK(hipMemcpyAsync(fe.v.p, v, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      dv = fe.v.p; dru = fe.ru.p;
+    }
+  }
+  CHK(fe_refresh(h, fe, dxu, v != nullptr));
   if (v) {
-    DCsr& A = h->mat[PCD_MAT_A00];
-    if (!A.set || A.kron != fe.dim || A.nnz2 != Lt.nnzf)
-      return fail(PCD_ERR_STATE, "fe_update: A00 is not F x I_%d on the FE pattern", fe.dim);
-    if (!kron_ok(A, dv, dru))
-      return fail(PCD_ERR_ARG, "fe_update: v / ru must be 16-byte aligned for the two-component SpMV");
-    std::swap(A.val2.p, fe.Func.p);      // same pattern, unmasked values
-    const int rc = spmv(h, A, dv, dru);
-    std::swap(A.val2.p, fe.Func.p);
-    if (rc) return rc;
+    CHK(fe_apply_unconstrained(h, fe, dv, dru));
     if (mem == PCD_MEM_HOST)
       HIPCHK(hipMemcpyAsync(ru, dru, nu * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+}  // extern "C"
+
+// b (caller's mixed numbering, device) = nonlinear residual at the device
+// iterate x, with every iterate-dependent operator refreshed on the way:
+//   F_u = (F_unc x I)(x_u - d) + B^T_raw x_p - idt M u0,  F_p = B_raw (x_u - d),
+//   d = boundary defect, Dirichlet rows F_u[bc] = mult d[bc]
+// (the residual of demo_navier-stokes-pcd.py:104-120 with DOLFIN's symmetric
+// BC application, fenapack/assembling.py:143-155)
+static int fe_residual_dev(Engine* h, FeState& fe, const double* xd, double* bd, double* norm) {
+  const int64_t nu = h->n_u, np = h->n_p, n = nu + np;
+  CHK(fe.xs.ensure(n)); CHK(fe.bs.ensure(n)); CHK(fe.vv.ensure(nu));
+  CHK(h->gparts.ensure(2 * 512)); CHK(h->gh.ensure(4)); CHK(ensure_pinned(h, 8));
+  const int g1 = grid1d(n, 1);
+  hipLaunchKernelGGL(k_gather, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, xd, fe.xs.p);
+  const double *xu = fe.xs.p, *xp = fe.xs.p + nu;
+  double *Fu = fe.bs.p, *Fp = fe.bs.p + nu;
+  CHK(fe_refresh(h, fe, xu, true));
+  HIPCHK(hipMemcpyAsync(fe.vv.p, xu, nu * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (fe.n_bc)
+    hipLaunchKernelGGL(k_fe_bc_replace, dim3(grid1d(fe.n_bc)), dim3(kBlock), 0, h->stream,
+                       (int)fe.n_bc, fe.bc_idx.p, fe.bc_g.p, fe.vv.p);
+  CHK(fe_apply_unconstrained(h, fe, fe.vv.p, Fu));
+  CHK(spmv(h, fe.A01raw, xp, Fu, 1, Fu));
+  if (fe.have_mu0)
+    hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, -1.0, fe.mu0.p, 1.0, Fu);
+  CHK(spmv(h, fe.A10raw, fe.vv.p, Fp));
+  if (fe.n_bc)
+    hipLaunchKernelGGL(k_fe_bc_rows, dim3(grid1d(fe.n_bc)), dim3(kBlock), 0, h->stream,
+                       (int)fe.n_bc, fe.bc_idx.p, fe.bc_g.p, fe.bc_mult.p, xu, Fu);
+  hipLaunchKernelGGL(k_scatter, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, fe.bs.p, bd);
+  HIPCHK(hipGetLastError());
+  return dev_norm(h, n, fe.bs.p, norm);
+}
+
+extern "C" {
+
+// Constant pieces of the nonlinear residual: the unconstrained blocks
+// B^T (n_u x n_p) and B (n_p x n_u), the Dirichlet dofs of the velocity
+// (fieldsplit-local indices) with the diagonal values of their rows, and for
+// time stepping the scalar mass values on the pattern of F with idt.
+int pcd_fe_bind_residual(pcd_handle h, const int32_t* bt_rowptr, const int32_t* bt_col,
+                         const double* bt_val, const int32_t* b_rowptr,
+                         const int32_t* b_col, const double* b_val, int64_t n_bc,
+                         const int32_t* bc_idx, const double* bc_mult,
+                         const double* mass_vals, double idt) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_residual: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (!fe.sys_bound) return fail(PCD_ERR_STATE, "fe_bind_residual: bind the system first");
+  if (!bt_rowptr || !bt_col || !bt_val || !b_rowptr || !b_col || !b_val || n_bc < 0 ||
+      (n_bc && (!bc_idx || !bc_mult)) || (idt != 0.0 && !mass_vals))
+    return fail(PCD_ERR_ARG, "fe_bind_residual: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t nu = h->n_u, np = h->n_p;
+  for (int64_t i = 0; i < n_bc; ++i)
+    if (bc_idx[i] < 0 || bc_idx[i] >= nu) return fail(PCD_ERR_ARG, "fe_bind_residual: bc index out of range");
+  CHK(upload_csr(h, fe.A01raw, nu, np, bt_rowptr, bt_col, bt_val, nullptr));
+  CHK(upload_csr(h, fe.A10raw, np, nu, b_rowptr, b_col, b_val, nullptr));
+  fe.n_bc = n_bc; fe.idt = idt;
+  CHK(fe_upload(fe.bc_idx, bc_idx, (size_t)n_bc));
+  CHK(fe_upload(fe.bc_mult, bc_mult, (size_t)n_bc));
+  CHK(fe.bc_g.ensure((size_t)n_bc));
+  if (n_bc) HIPCHK(hipMemset(fe.bc_g.p, 0, n_bc * sizeof(double)));
+  if (mass_vals) CHK(fe_upload(fe.mass, mass_vals, (size_t)fe.lev[fe.nlev - 1].nnzf));
+  fe.have_mu0 = false;
+  fe.res_bound = true;
+  return 0;
+}
+
+// boundary values of the Dirichlet dofs (order of bc_idx); time dependent
+int pcd_fe_set_bc_values(pcd_handle h, const double* g) {
+  if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_set_bc_values: bind the residual first");
+  if (!g && h->fe->n_bc) return fail(PCD_ERR_ARG, "fe_set_bc_values: null values");
+  HIPCHK(hipSetDevice(h->device));
+  if (h->fe->n_bc)
+    HIPCHK(hipMemcpyAsync(h->fe->bc_g.p, g, h->fe->n_bc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// previous time level u0 (velocity dofs): the residual subtracts idt M u0
+// (demo_unsteady-navier-stokes-pcd.py:104-120); NULL drops the term
+int pcd_fe_set_previous(pcd_handle h, const double* u0, int mem) {
+  if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_set_previous: bind the residual first");
+  FeState& fe = *h->fe;
+  if (!u0) { fe.have_mu0 = false; return 0; }
+  if (fe.idt == 0.0 || !fe.mass.p) return fail(PCD_ERR_STATE, "fe_set_previous: no mass term was bound");
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t nu = h->n_u;
+  CHK(fe.u0.ensure(nu)); CHK(fe.mu0.ensure(nu));
+  HIPCHK(hipMemcpyAsync(fe.u0.p, u0, nu * sizeof(double),
+                        mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  DCsr& A = h->mat[PCD_MAT_A00];
+  if (!A.set || A.kron != fe.dim || A.nnz2 != fe.lev[fe.nlev - 1].nnzf || !kron_ok(A, fe.u0.p, fe.mu0.p))
+    return fail(PCD_ERR_STATE, "fe_set_previous: A00 is not F x I_%d on the FE pattern", fe.dim);
+  std::swap(A.val2.p, fe.mass.p);        // (M x I) u0 on the pattern of F
+  const int rc = spmv(h, A, fe.u0.p, fe.mu0.p);
+  std::swap(A.val2.p, fe.mass.p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, fe.idt, fe.mu0.p, 0.0, fe.mu0.p);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  fe.have_mu0 = true;
+  return 0;
+}
+
+// Refresh the operators at the iterate x (caller's mixed numbering) and
+// return the nonlinear residual b (same numbering) and its 2-norm.
+int pcd_fe_residual(pcd_handle h, const double* x, double* b, int mem, double* norm) {
+  if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_residual: bind the residual first");
+  if (!x || !b || !norm) return fail(PCD_ERR_ARG, "fe_residual: null argument");
+  FeState& fe = *h->fe;
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t n = h->n_u + h->n_p;
+  const double* dx = x; double* db = b;
+  if (mem == PCD_MEM_HOST) {
+    CHK(fe.xd.ensure(n)); CHK(fe.bd.ensure(n));
+    HIPCHK(hipMemcpyAsync(fe.xd.p, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    dx = fe.xd.p; db = fe.bd.p;
+  }
+  CHK(fe_residual_dev(h, fe, dx, db, norm));
+  if (mem == PCD_MEM_HOST) {
+    HIPCHK(hipMemcpyAsync(b, db, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+// The whole Picard iteration on the device (the loop of
+// fenapack/nonlinear_solvers.py:28-82 around dolfin::NewtonSolver [ext]):
+//   repeat: b = F(x) (operators refreshed), stop on |b| < atol or |b|/r0 < rtol,
+//           GMRES: J dx = b, x -= relax dx.
+// r0 <= 0: the first residual of this call is the reference norm.  lin_its /
+// res_hist receive the GMRES count of every step and every residual norm
+// (max_it and max_it + 1 entries).  x is updated in place.
+int pcd_fe_picard_solve(pcd_handle h, double* x, int mem, double r0, double rtol,
+                        double atol, int max_it, double relax, double lin_rtol,
+                        double lin_atol, int restart, int lin_max_it, int* n_it,
+                        int* lin_its, double* res_hist, int* converged) {
+  if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_picard_solve: bind the residual first");
+  if (!x || !n_it || !converged || max_it < 0 || (max_it && (!lin_its || !res_hist)))
+    return fail(PCD_ERR_ARG, "fe_picard_solve: bad arguments");
+  FeState& fe = *h->fe;
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t n = h->n_u + h->n_p;
+  CHK(fe.bd.ensure(n)); CHK(fe.dxd.ensure(n));
+  double* xd = x;
+  if (mem == PCD_MEM_HOST) {
+    CHK(fe.xd.ensure(n));
+    HIPCHK(hipMemcpyAsync(fe.xd.p, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    xd = fe.xd.p;
+  }
+  int it = 0;
+  double r = 0.0;
+  CHK(fe_residual_dev(h, fe, xd, fe.bd.p, &r));
+  if (res_hist) res_hist[0] = r;
+  if (!(r0 > 0.0)) r0 = r;
+  bool conv = r < atol || (r0 > 0.0 && r / r0 < rtol);
+  while (!conv && it < max_it) {
+    HIPCHK(hipMemsetAsync(fe.dxd.p, 0, n * sizeof(double), h->stream));
+    int its = 0; double rn = 0.0;
+    CHK(pcd_gmres_solve(h, fe.bd.p, fe.dxd.p, PCD_MEM_DEVICE, lin_rtol, lin_atol, restart, lin_max_it, &its, &rn));
+    lin_its[it] = its;
+    hipLaunchKernelGGL(k_axpby, dim3(grid1d(n, 4)), dim3(kBlock), 0, h->stream, (int)n, -relax, fe.dxd.p, 1.0, xd);
+    ++it;
+    CHK(fe_residual_dev(h, fe, xd, fe.bd.p, &r));
+    res_hist[it] = r;
+    conv = r < atol || r / r0 < rtol;
+  }
+  if (mem == PCD_MEM_HOST)
+    HIPCHK(hipMemcpyAsync(x, xd, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *n_it = it; *converged = conv ? 1 : 0;
   return 0;
 }
 

@@ -180,6 +180,20 @@ class DeviceProducer(object):
             and self._pat[0][2] <= 8192
         if self.device_inverse:
             eng.fe_bind_coarse_inverse(self._pat[0][0], self._pat[0][1])
+        # the residual and the Picard loop on the device as well - unless the
+        # BRM2 boundary term (or a host-side coarse inverse) needs the iterate
+        # on the host every iteration
+        self.device_loop = not self._robin and self.device_inverse \
+            and os.environ.get("PCD_FE_HOST_LOOP") != "1"
+        if self.device_loop:
+            mass = None
+            if pb.idt:
+                pat = V._patterns(False)["SS"]
+                mass = np.bincount(pat.inv, weights=V.p2_mass_cells().ravel(),
+                                   minlength=pat.nnz)
+            eng.fe_bind_residual(sp.csr_matrix(pb._A01_raw),
+                                 sp.csr_matrix(pb._A10_raw), pb.bc_u_idx,
+                                 pb._bc_mult[pb.bc_u_idx], mass, pb.idt)
         # constant host pieces of the residual
         self._bc_idx = pb.bc_u_idx
         self.timing = {"update": 0.0, "coarse_inverse": 0.0, "host": 0.0}
@@ -275,6 +289,21 @@ class DeviceProducer(object):
         self._kp_base = cst
         self._robin = pb.variant == "BRM2" and len(pb.robin_edges) > 0
 
+    # ------------------------------------------------------------ device loop
+    def set_time_level(self):
+        """Boundary values at ``problem.t`` and the previous velocity for the
+        device residual."""
+        pb = self.pb
+        self.eng.fe_set_bc_values(pb.bc_u_values(pb.t))
+        if pb.idt:
+            self.eng.fe_set_previous(pb.u0)
+
+    def residual(self, x):
+        """Device residual at the mixed vector ``x`` (operators refreshed)."""
+        b = np.empty_like(x)
+        self.eng.fe_residual(np.ascontiguousarray(x), b)
+        return b
+
     # ----------------------------------------------------------------- update
     def update(self, xu, xp):
         """Refresh every iterate-dependent operator of the engine at
@@ -353,6 +382,7 @@ class DevicePicardSolver(object):
         self.producer = None
         self.time_plan = 0.0
         self.time_gmres = 0.0
+        self.time_device_loop = 0.0
         self.krylov_history, self.residual_history = [], []
 
     def krylov_iterations(self):
@@ -375,16 +405,41 @@ class DevicePicardSolver(object):
             # (no hipGraph replay here: every update changes the smoother
             # bounds baked into the captured launches, and re-capturing costs
             # ~30 ms - more than the 31 eager applies of one solve)
-            b = self.producer.update(x[V.is_u], x[V.is_p])
-            self.residual_history[-1] = float(np.linalg.norm(b))
+            first = True
         else:
-            it = 0
-            b = self.producer.update(x[V.is_u], x[V.is_p])
-            r0 = float(np.linalg.norm(b))
-            self.krylov_history, self.residual_history = [], [r0]
-            converged = r0 < prm["absolute_tolerance"]
+            it, r0, first, converged = 0, 0.0, False, False
+            self.krylov_history, self.residual_history = [], []
         solver = nls.linear_solver()
         ksp = solver.ksp()
+        if self.producer.device_loop:
+            # the rest of the iteration is one call: residual, GMRES and
+            # update stay on the device (pcd_fe_picard_solve)
+            t1 = time.perf_counter()
+            self.producer.set_time_level()
+            k, converged, lin, res = ksp.engine.fe_picard_solve(
+                x, c.MEM_HOST, r0, prm["relative_tolerance"],
+                prm["absolute_tolerance"], max(self.max_newton - it, 0),
+                prm["relaxation_parameter"],
+                solver.parameters["relative_tolerance"],
+                solver.parameters["absolute_tolerance"], ksp.restart,
+                solver.parameters["maximum_iterations"])
+            self.time_device_loop += time.perf_counter() - t1
+            self.krylov_history += lin
+            if first:
+                self.residual_history[-1] = res[0]
+                self.residual_history += res[1:]
+            else:
+                self.residual_history = res
+            w.touch()
+            return it + k, converged
+        b = self.producer.update(x[V.is_u], x[V.is_p])
+        r = float(np.linalg.norm(b))
+        if first:
+            self.residual_history[-1] = r
+        else:
+            r0 = r
+            self.residual_history = [r0]
+            converged = r0 < prm["absolute_tolerance"]
         dx = np.zeros_like(x)
         while not converged and it < self.max_newton:
             dx[:] = 0.0
@@ -418,6 +473,7 @@ def solve_steady_device(problem, **kw):
             "krylov_per_step": list(s.krylov_history),
             "residuals": list(s.residual_history), "time": t_total,
             "time_plan": s.time_plan, "time_gmres": s.time_gmres,
+            "time_device_loop": s.time_device_loop,
             "producer_timing": dict(s.producer.timing),
             "solver": s.nls, "producer": s.producer}
 
@@ -448,4 +504,5 @@ def solve_unsteady_device(problem, dt, t_end, **kw):
             "krylov_per_newton": newton_per_step, "residuals": residuals,
             "time": time.time() - t0, "ndof": V.ndof,
             "producer_timing": dict(s.producer.timing),
-            "time_gmres": s.time_gmres}
+            "time_gmres": s.time_gmres,
+            "time_device_loop": s.time_device_loop}

@@ -312,6 +312,36 @@ int pcd_fe_bind_coarse_inverse(pcd_handle h, int64_t n0, const int32_t* rowptr,
  * inverse to pcd_mg_update_values.                                           */
 int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
                   int mem);
+/* ---- the nonlinear iteration itself -------------------------- *
+ * Constant pieces of the residual F (fenapack/nonlinear_solvers.py:85-112 ->
+ * assembling.py:143-148 with DOLFIN's symmetric BC application [ext]): the
+ * unconstrained blocks B^T (n_u x n_p) and B (n_p x n_u) as CSR, the velocity
+ * Dirichlet dofs (fieldsplit-local indices) with the diagonal values of their
+ * rows, and for time stepping the scalar mass values on the pattern of F with
+ * idt = 1/dt (mass_vals may be NULL when idt == 0).                           */
+int pcd_fe_bind_residual(pcd_handle h, const int32_t* bt_rowptr,
+                         const int32_t* bt_col, const double* bt_val,
+                         const int32_t* b_rowptr, const int32_t* b_col,
+                         const double* b_val, int64_t n_bc,
+                         const int32_t* bc_idx, const double* bc_mult,
+                         const double* mass_vals, double idt);
+/* boundary values of those dofs (time dependent inflow: demo_unsteady-...:88) */
+int pcd_fe_set_bc_values(pcd_handle h, const double* g);
+/* previous time level (velocity dofs); NULL drops the idt M u0 term          */
+int pcd_fe_set_previous(pcd_handle h, const double* u0, int mem);
+/* operators refreshed at x (caller's mixed numbering), b = F(x), *norm = |b| */
+int pcd_fe_residual(pcd_handle h, const double* x, double* b, int mem,
+                    double* norm);
+/* The whole Picard loop on the device (nonlinear_solvers.py:28-82 around
+ * dolfin::NewtonSolver [ext]): b = F(x); stop on |b| < atol or |b|/r0 < rtol;
+ * right-preconditioned GMRES for J dx = b; x -= relax dx.  r0 <= 0: the first
+ * residual of this call is the reference norm.  lin_its[max_it] and
+ * res_hist[max_it + 1] receive the history.  x is updated in place.          */
+int pcd_fe_picard_solve(pcd_handle h, double* x, int mem, double r0,
+                        double rtol, double atol, int max_it, double relax,
+                        double lin_rtol, double lin_atol, int restart,
+                        int lin_max_it, int* n_it, int* lin_its,
+                        double* res_hist, int* converged);
 int pcd_fe_get_level_values(pcd_handle h, int level, double* out);
 int pcd_fe_get_kp_values(pcd_handle h, double* out);
 int pcd_fe_get_bounds(pcd_handle h, int level, double* emin, double* emax);

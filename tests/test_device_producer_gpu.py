@@ -245,3 +245,40 @@ def test_supg_preconditioner_matrix_on_the_device(hip_lib, kind):
         assert i <= max(j + 1, 1.05 * j), (dev["krylov_per_step"],
                                            ref["krylov_per_step"])
     assert relerr(dev["w"].vector(), ref["w"].vector()) < 1e-5
+
+
+@pytest.mark.parametrize("kind,dt", [("cavity", None), ("lshape", 0.2),
+                                      ("cube", None)])
+def test_device_residual_and_picard_loop(hip_lib, kind, dt, monkeypatch):
+    """pcd_fe_residual against the host residual, and the one-call Picard
+    loop (pcd_fe_picard_solve) against the host-driven loop over the same
+    device producer."""
+    kw = {} if dt is None else {"dt": dt}
+    pb = _problem(kind, **kw)
+    pb.t = 0.4                      # (time-dependent inflow: zero at t = 0)
+    V = pb.space
+    _options(V.dim, galerkin=True)
+    out = solve_steady_device(pb, max_newton=1)
+    prod = out["producer"]
+    assert prod.device_loop
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(V.ndof)
+    if dt is not None:
+        pb.u0 = rng.standard_normal(V.n_u)
+    prod.set_time_level()
+    b = prod.residual(x)
+    lin = pb.linearise(x[V.is_u], x[V.is_p])
+    assert relerr(b, V.to_mixed(lin["bu"], lin["bp"])) < 1e-12
+    outs = []
+    for host_loop in ("1", "0"):
+        monkeypatch.setenv("PCD_FE_HOST_LOOP", host_loop)
+        pb2 = _problem(kind, **kw)
+        pb2.t = 0.4
+        _options(V.dim, galerkin=True)
+        outs.append(solve_steady_device(pb2, max_newton=6))
+        assert outs[-1]["producer"].device_loop == (host_loop == "0")
+    ref, dev = outs
+    assert dev["newton_its"] == ref["newton_its"]
+    assert dev["krylov_per_step"] == ref["krylov_per_step"]
+    assert np.allclose(dev["residuals"], ref["residuals"], rtol=1e-6)
+    assert relerr(dev["w"].vector(), ref["w"].vector()) < 1e-9

@@ -44,8 +44,10 @@ for name, fn in (("host", solve_steady), ("device", solve_steady_device)):
         res[name].update(
             plan_seconds=out["time_plan"],
             device_steps=steps,
-            seconds_per_device_step=(out["time_gmres"] + sum(pt.values()))
+            seconds_per_device_step=(out["time_gmres"] + sum(pt.values())
+                                     + out["time_device_loop"])
             / max(steps, 1),
+            device_loop_seconds=out["time_device_loop"],
             gmres_seconds=out["time_gmres"],
             producer_timing=pt)
     else:
