@@ -78,7 +78,8 @@ _HIP_ONLY = {
     "fe_set_level_galerkin": [C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p],
-    "fe_set_supg": [C.c_int, C.c_void_p, C.c_double, C.c_void_p],
+    "fe_set_supg": [C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
+                    C.c_void_p, C.c_void_p, C.c_void_p],
     "fe_bind_system": [C.c_void_p],
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
     "fe_set_kp_const": [C.c_void_p],
@@ -339,10 +340,12 @@ class Engine(object):
                    int(b_ptr.size - 1), _ptr(b_ptr), _ptr(b_src), _ptr(b_w),
                    _ptr(c_ptr), _ptr(c_src), _ptr(c_w))
 
-    def fe_set_supg(self, level, cell_h, nu, phi_mid):
+    def fe_set_supg(self, level, cell_h, nu, phi_mid, qw_s, phi_s, dphi_s):
         cell_h, phi_mid = _f64(cell_h), _f64(phi_mid)
+        qw_s, phi_s, dphi_s = _f64(qw_s), _f64(phi_s), _f64(dphi_s)
         self._call("fe_set_supg", int(level), _ptr(cell_h), float(nu),
-                   _ptr(phi_mid))
+                   _ptr(phi_mid), int(qw_s.size), _ptr(qw_s), _ptr(phi_s),
+                   _ptr(dphi_s))
 
     def fe_bind_system(self, sys_pos):
         sys_pos = np.ascontiguousarray(sys_pos, dtype=np.int64)

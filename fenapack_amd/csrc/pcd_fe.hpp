@@ -28,6 +28,11 @@ struct FeTables {
   const double* dphi;   // nq * NA * NV  d phi_a / d lambda_k
   const double* psi;    // nq * NV     P1 basis (= barycentric coordinates)
   const double* phic;   // NA          P2 basis at the cell midpoint (SUPG)
+  // the streamline-diffusion term has degree 6 with a P2 wind: its own rule
+  int nq_s;
+  const double* qw_s;   // nq_s
+  const double* phi_s;  // nq_s * NA
+  const double* dphi_s; // nq_s * NA * NV
 };
 
 // One thread per (cell c, local row a): row a of the P2 convection matrix
@@ -98,19 +103,44 @@ __global__ __launch_bounds__(kBlock) void k_fe_convection_p2(
       wl[k] = s;
     }
     const double f = T.qw[q] * meas * T.phi[q * NA + a];
-    double sa = 0.0;                     // (w . grad phi_a)(q)
-    if (cells_s) {
-#pragma unroll
-      for (int k = 0; k < NV; ++k) sa += T.dphi[(q * NA + a) * NV + k] * wl[k];
-      sa *= T.qw[q] * meas * delta;
-    }
 #pragma unroll
     for (int b = 0; b < NA; ++b) {
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < NV; ++k) s += T.dphi[(q * NA + b) * NV + k] * wl[k];
       acc[b] += f * s;
-      if (cells_s) accs[b] += sa * s;
+    }
+  }
+  if (cells_s && delta != 0.0) {
+    for (int q = 0; q < T.nq_s; ++q) {
+      double w[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) w[d] = 0.0;
+#pragma unroll
+      for (int b = 0; b < NA; ++b) {
+        const double ph = T.phi_s[q * NA + b];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) w[d] += ph * Uc[b][d];
+      }
+      double wl[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) s += w[d] * g[k][d];
+        wl[k] = s;
+      }
+      double sa = 0.0;                   // (w . grad phi_a)(q)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) sa += T.dphi_s[(q * NA + a) * NV + k] * wl[k];
+      sa *= T.qw_s[q] * meas * delta;
+#pragma unroll
+      for (int b = 0; b < NA; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s += T.dphi_s[(q * NA + b) * NV + k] * wl[k];
+        accs[b] += sa * s;
+      }
     }
   }
 #pragma unroll

@@ -34,7 +34,8 @@ struct FeLevel {
 
 struct FeState {
   int dim = 0, nlev = 0, nq = 0;
-  DBuf<double> qw, phi, dphi, psi, phic;
+  DBuf<double> qw, phi, dphi, psi, phic, qw_s, phi_s, dphi_s;
+  int nq_s = 0;
   bool supg = false; double nu = 0.0;
   std::vector<FeLevel> lev;
   DBuf<double> Func;                 // unconstrained finest values (residual)
@@ -60,7 +61,7 @@ struct FeState {
     for (auto& l : lev) l.release();
     lev.clear();
     qw.release(); phi.release(); dphi.release(); psi.release(); Func.release();
-    phic.release();
+    phic.release(); qw_s.release(); phi_s.release(); dphi_s.release();
     sys_pos.release(); kp_ptr.release(); kp_src.release(); kp_const.release();
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
     ru.release(); y.release(); parts.release(); slot.release();
@@ -86,7 +87,8 @@ static int fe_upload(DBuf<T>& b, const T* src, size_t n) {
 }
 
 static FeTables fe_tables(const FeState& fe) {
-  return FeTables{fe.nq, fe.qw.p, fe.phi.p, fe.dphi.p, fe.psi.p, fe.phic.p};
+  return FeTables{fe.nq, fe.qw.p, fe.phi.p, fe.dphi.p, fe.psi.p, fe.phic.p,
+                  fe.nq_s, fe.qw_s.p, fe.phi_s.p, fe.dphi_s.p};
 }
 
 // coarse operator as the Galerkin product of the next finer level's one
@@ -319,16 +321,19 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f, int64_t nn
 
 // SUPG-stabilised preconditioner matrix (fenapack/stabilization.py:39-68 and
 // its use at demo_navier-stokes-pcd.py:122-127): per re-discretised level the
-// cell sizes h (DOLFIN Cell::h()); nu and the P2 basis at the cell midpoint
-// are shared.  From then on the multigrid and A00/A01 are built from the
+// cell sizes h (DOLFIN Cell::h()); nu, the P2 basis at the cell midpoint and
+// the quadrature tables of the streamline-diffusion term (degree 6 with a P2
+// wind: its own, higher rule) are shared.  From then on the multigrid and A00/A01 are built from the
 // stabilised operator, the system matrix from the unstabilised one.
 int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
-                    const double* phi_mid) {
+                    const double* phi_mid, int nq_s, const double* qw_s,
+                    const double* phi_s, const double* dphi_s) {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_supg: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (level < 0 || level >= fe.nlev || !fe.lev[level].set || fe.lev[level].galerkin)
     return fail(PCD_ERR_ARG, "fe_set_supg: level %d is not a re-discretised level", level);
-  if (!cell_h || !phi_mid || !(nu > 0.0)) return fail(PCD_ERR_ARG, "fe_set_supg: bad arguments");
+  if (!cell_h || !phi_mid || !(nu > 0.0) || nq_s < 1 || !qw_s || !phi_s || !dphi_s)
+    return fail(PCD_ERR_ARG, "fe_set_supg: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   FeLevel& L = fe.lev[level];
   const int na = fe.dim == 2 ? 6 : 10;
@@ -336,6 +341,10 @@ int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
   CHK(L.cells_s.ensure((size_t)na * na * L.nc));
   if (level == fe.nlev - 1) CHK(L.Fa.ensure(L.nnzf));
   CHK(fe_upload(fe.phic, phi_mid, (size_t)na));
+  CHK(fe_upload(fe.qw_s, qw_s, (size_t)nq_s));
+  CHK(fe_upload(fe.phi_s, phi_s, (size_t)nq_s * na));
+  CHK(fe_upload(fe.dphi_s, dphi_s, (size_t)nq_s * na * (fe.dim + 1)));
+  fe.nq_s = nq_s;
   fe.nu = nu; fe.supg = true;
   return 0;
 }

@@ -232,7 +232,8 @@ class DeviceProducer(object):
             from .fem.taylor_hood import _p2_basis
             lam = np.full((1, V.nvl), 1.0 / V.nvl)
             phi_mid, _ = _p2_basis(lam, V.local_edges)
-            self.eng.fe_set_supg(l, V.cell_h, pl.nu, phi_mid[0])
+            self.eng.fe_set_supg(l, V.cell_h, pl.nu, phi_mid[0], V.qw_s,
+                                 V.phi_s, V.dphi_s)
 
     def _set_level_galerkin(self, l, P):
         """Level ``l`` = P^T (level l+1) P with the scalar part of the

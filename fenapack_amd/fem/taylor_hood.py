@@ -61,6 +61,28 @@ def _tet_rule(n=3):
     return np.array(pts), wts / wts.sum()
 
 
+def _conical_rule(d, n):
+    """Conical (Stroud) product of Gauss-Jacobi rules on the unit d-simplex,
+    exact to degree 2n - 1, positive weights; barycentric points (nq, d+1),
+    weights summing to 1."""
+    axes = []
+    for k in range(d):                      # Jacobi weight (1 - x)^(d-1-k)
+        x, w = roots_jacobi(n, d - 1 - k, 0)
+        axes.append((0.5 * (x + 1), w))
+    pts, wts = [], []
+    for idx in np.ndindex(*([n] * d)):
+        rest, coords, wt = 1.0, [], 1.0
+        for k in range(d):
+            x, w = axes[k]
+            coords.append(x[idx[k]] * rest)
+            rest *= 1.0 - x[idx[k]]
+            wt *= w[idx[k]]
+        pts.append([1.0 - sum(coords)] + coords)
+        wts.append(wt)
+    wts = np.array(wts)
+    return np.array(pts), wts / wts.sum()
+
+
 def _p2_basis(lam, edges=((1, 2), (2, 0), (0, 1))):
     """P2 basis at barycentric points ``lam`` (nq, d+1).
 
@@ -180,6 +202,10 @@ class TaylorHood(object):
             qp, qw = _tet_rule(3)
         self.phi, dphi = _p2_basis(qp, self.local_edges)       # (nq, na)
         self.gphi = np.einsum('qak,ckd->cqad', dphi, g)         # (nc,nq,na,d)
+        # the streamline-diffusion term with a P2 wind has degree 6 (FFC
+        # would pick a degree-6 scheme for it): its own rule, exact to 7
+        self.qp_s, self.qw_s = _conical_rule(d, 4)
+        self.phi_s, self.dphi_s = _p2_basis(self.qp_s, self.local_edges)
         self.psi = qp                                           # (nq, d+1)
         self.wq = qw[None, :] * self.area[:, None]              # (nc, nq)
         edges = [np.linalg.norm(p[:, i] - p[:, j], axis=1)
@@ -245,11 +271,16 @@ class TaylorHood(object):
         wg = np.einsum('cqd,cqbd->cqb', w, self.gphi)           # w.grad phi_b
         return np.einsum('cq,qa,cqb->cab', self.wq, self.phi, wg)
 
-    def p2_supg_cells(self, w, delta):
+    def p2_supg_cells(self, U, delta):
         """delta * (w.grad u, w.grad v): streamline diffusion added to the
-        preconditioner's 00-block (demo_navier-stokes-pcd.py:122-125)."""
-        wg = np.einsum('cqd,cqbd->cqb', w, self.gphi)
-        return np.einsum('c,cq,cqa,cqb->cab', delta, self.wq, wg, wg)
+        preconditioner's 00-block (demo_navier-stokes-pcd.py:122-125);
+        ``U`` (nn, d) nodal wind, integrated with the degree-7 rule."""
+        Uc = U[self.cell_dofs2]                                 # (nc,na,d)
+        w = np.einsum('qa,cak->cqk', self.phi_s, Uc)
+        wl = np.einsum('cqd,ckd->cqk', w, self.gradlam)         # w.grad lam_k
+        wg = np.einsum('qbk,cqk->cqb', self.dphi_s, wl)         # w.grad phi_b
+        return np.einsum('c,c,q,cqa,cqb->cab', delta, self.area, self.qw_s,
+                         wg, wg)
 
     # ------------------------------------------------------------- velocity
     def assemble_A00(self, nu, U=None, idt=0.0, newton=False, delta=None):
@@ -264,7 +295,7 @@ class TaylorHood(object):
             w, gw = self.wind_at_qp(U)
             S = S + self.p2_convection_cells(w)
             if delta is not None:
-                S = S + self.p2_supg_cells(w, delta)
+                S = S + self.p2_supg_cells(U, delta)
         if not newton:
             vals = np.repeat(S[..., None], d, axis=3)           # (nc,na,na,d)
             return pat.assemble(vals)

@@ -277,11 +277,14 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f,
                               const double* c_w);
 /* SUPG-stabilised preconditioner matrix (fenapack/stabilization.py:39-68, used
  * at demo_navier-stokes-pcd.py:122-127): cell sizes h of one re-discretised
- * level (ncells values), viscosity, P2 basis at the cell midpoint (na values).
+ * level (ncells values), viscosity, P2 basis at the cell midpoint (na values),
+ * and the rule the streamline-diffusion term is integrated with (its integrand
+ * has degree 6 with a P2 wind): qw_s[nq_s], phi_s[nq_s][na], dphi_s[nq_s][na][nv].
  * Afterwards A00/A01 and the multigrid come from the stabilised operator, the
  * system matrix from the unstabilised one (P != A: pvals of pcd_set_system).  */
 int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
-                    const double* phi_mid);
+                    const double* phi_mid, int nq_s, const double* qw_s,
+                    const double* phi_s, const double* dphi_s);
 /* sys_pos[c*nnz_f + k] = position, in the value array given to
  * pcd_set_system, of entry k of the finest F for velocity component c        */
 int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos);

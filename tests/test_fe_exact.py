@@ -1,0 +1,39 @@
+"""CPU suite: the host producer's element matrices against closed-form
+integration (oracle/fe_exact.py) - no quadrature rule or basis table shared."""
+import numpy as np
+import pytest
+
+from oracle.fe_exact import element_matrices
+from fenapack_amd.fem import Cavity, Cavity3D, BackwardStep
+
+
+@pytest.mark.parametrize("make", [lambda: Cavity(1), lambda: BackwardStep(1),
+                                  lambda: Cavity3D(1, n0=2)])
+def test_element_matrices_are_exact(make):
+    pb = make()
+    V, m = pb.space, pb.space.mesh
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((V.nn, V.dim))
+    nu = 0.37
+    w, _ = V.wind_at_qp(U)
+    mass, stiff = V.p2_mass_cells(), V.p2_stiffness_cells()
+    conv = V.p2_convection_cells(w)
+    supg = V.p2_supg_cells(U, np.ones(m.num_cells))
+    wg = np.einsum('cqd,cjd->cqj', w, V.gradlam)
+    kp = np.einsum('cq,qi,cqj->cij', V.wq, V.psi, wg) / nu
+    cells = rng.choice(m.num_cells, size=4, replace=False)
+    for c in cells:
+        ex = element_matrices(m.vertices[m.cells[c]], V.local_edges,
+                              U[V.cell_dofs2[c]], nu)
+        assert abs(ex["measure"] - V.area[c]) < 1e-14
+        scale = lambda a: max(np.abs(a).max(), 1e-300)
+        assert np.abs(mass[c] - ex["mass"]).max() < 1e-13 * scale(ex["mass"])
+        assert np.abs(stiff[c] - ex["stiffness"]).max() \
+            < 1e-12 * scale(ex["stiffness"])
+        # degree 5 integrand, degree 5 rules: exact
+        assert np.abs(conv[c] - ex["convection"]).max() \
+            < 1e-12 * scale(ex["convection"])
+        assert np.abs(kp[c] - ex["kp"]).max() < 1e-12 * scale(ex["kp"])
+        # streamline diffusion with a P2 wind has degree 6: its own rule
+        # (exact to degree 7; the degree-5 rules were off by 10-25 % here)
+        assert np.abs(supg[c] - ex["supg"]).max() < 1e-12 * scale(ex["supg"])
