@@ -129,6 +129,20 @@ def element_matrices(vertices, edges, U=None, nu=1.0):
                         _mul(dphi[a][k], dphi[b][l]), measure)
             K[a, b] = s
     out["mass"], out["stiffness"] = M, K
+    # pressure space (P1 = the barycentric coordinates) and the coupling
+    # -(p, div v): div[a, j, c] = - int lambda_j d phi_a / d x_c
+    lam = [_mono(nv, i) for i in range(nv)]
+    out["mass_p1"] = np.array([[_integrate(_mul(lam[i], lam[j]), measure)
+                                for j in range(nv)] for i in range(nv)])
+    out["stiffness_p1"] = measure * (g @ g.T)
+    D = np.empty((na, nv, d))
+    for a in range(na):
+        for j in range(nv):
+            v = np.zeros(d)
+            for k in range(nv):
+                v += g[k] * _integrate(_mul(lam[j], dphi[a][k]), measure)
+            D[a, j] = -v
+    out["div"] = D
     if U is None:
         return out
     U = np.asarray(U, dtype=float)

@@ -21,6 +21,10 @@ def test_element_matrices_are_exact(make):
     supg = V.p2_supg_cells(U, np.ones(m.num_cells))
     wg = np.einsum('cqd,cjd->cqj', w, V.gradlam)
     kp = np.einsum('cq,qi,cqj->cij', V.wq, V.psi, wg) / nu
+    mass1 = np.einsum('cq,qi,qj->cij', V.wq, V.psi, V.psi)
+    stiff1 = V.area[:, None, None] * np.einsum('cid,cjd->cij', V.gradlam,
+                                               V.gradlam)
+    div = -np.einsum('cq,qj,cqak->cajk', V.wq, V.psi, V.gphi)
     cells = rng.choice(m.num_cells, size=4, replace=False)
     for c in cells:
         ex = element_matrices(m.vertices[m.cells[c]], V.local_edges,
@@ -34,6 +38,11 @@ def test_element_matrices_are_exact(make):
         assert np.abs(conv[c] - ex["convection"]).max() \
             < 1e-12 * scale(ex["convection"])
         assert np.abs(kp[c] - ex["kp"]).max() < 1e-12 * scale(ex["kp"])
+        assert np.abs(mass1[c] - ex["mass_p1"]).max() \
+            < 1e-13 * scale(ex["mass_p1"])
+        assert np.abs(stiff1[c] - ex["stiffness_p1"]).max() \
+            < 1e-12 * scale(ex["stiffness_p1"])
+        assert np.abs(div[c] - ex["div"]).max() < 1e-12 * scale(ex["div"])
         # streamline diffusion with a P2 wind has degree 6: its own rule
         # (exact to degree 7; the degree-5 rules were off by 10-25 % here)
         assert np.abs(supg[c] - ex["supg"]).max() < 1e-12 * scale(ex["supg"])
