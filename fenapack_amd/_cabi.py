@@ -83,6 +83,9 @@ _HIP_ONLY = {
     "fe_bind_system": [C.c_void_p],
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
     "fe_set_kp_const": [C.c_void_p],
+    "fe_bind_robin": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_void_p],
     "fe_bind_mg": [C.c_int, C.c_double, C.c_double, C.c_int],
     "fe_bind_coarse_inverse": [C.c_int64, C.c_void_p, C.c_void_p],
     "fe_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
@@ -360,6 +363,16 @@ class Engine(object):
     def fe_set_kp_const(self, kp_const):
         cst = None if kp_const is None else _f64(kp_const)
         self._call("fe_set_kp_const", _ptr(cst))
+
+    def fe_bind_robin(self, nodes, normals, lengths, aff_pos, aff_ptr,
+                      aff_src, aff_w):
+        """``nodes`` (3, nb), ``normals`` (2, nb): component-major."""
+        nodes, aff_pos, aff_src = _i32(nodes), _i32(aff_pos), _i32(aff_src)
+        normals, lengths, aff_w = _f64(normals), _f64(lengths), _f64(aff_w)
+        aff_ptr = np.ascontiguousarray(aff_ptr, dtype=np.int64)
+        self._call("fe_bind_robin", int(lengths.size), _ptr(nodes),
+                   _ptr(normals), _ptr(lengths), int(aff_pos.size),
+                   _ptr(aff_pos), _ptr(aff_ptr), _ptr(aff_src), _ptr(aff_w))
 
     def fe_bind_mg(self, slot, emin_factor, emax_factor, iters=12):
         self._call("fe_bind_mg", int(slot), float(emin_factor),

@@ -368,6 +368,43 @@ __global__ __launch_bounds__(kBlock) void k_gj_store(int n, int d, const double*
   }
 }
 
+// ---- BRM2 boundary term of Kp: - (1/nu) int_{inflow} (w.n) p q ds ------------
+// (demo_navier-stokes-pcd.py:131-135).  One thread per boundary edge (2-D):
+// the P2 wind along the edge from its end points and midpoint, 3-point Gauss
+// rule (degree 5; the integrand has degree 4), local 2 x 2 matrix
+// loc[(i*2+j)][e] = L_e sum_q w_q (w.n)(q) psi_i(q) psi_j(q).
+__global__ __launch_bounds__(kBlock) void k_fe_robin_edges(
+    int nb, const int* __restrict__ nodes, const double* __restrict__ normal,
+    const double* __restrict__ length, const double* __restrict__ U, double* loc) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nb) return;
+  const double gx[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
+  const double gw[3] = {0.5 * 5.0 / 9.0, 0.5 * 8.0 / 9.0, 0.5 * 5.0 / 9.0};
+  const double nx = normal[e], ny = normal[nb + e];
+  double un[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int64_t node = nodes[(int64_t)k * nb + e];
+    un[k] = U[2 * node] * nx + U[2 * node + 1] * ny;
+  }
+  double m00 = 0.0, m01 = 0.0, m11 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const double lb = gx[q], la = 1.0 - lb;
+    const double wn = la * (2 * la - 1) * un[0] + lb * (2 * lb - 1) * un[1] + 4 * la * lb * un[2];
+    const double f = gw[q] * wn * length[e];
+    m00 += f * la * la; m01 += f * la * lb; m11 += f * lb * lb;
+  }
+  loc[e] = m00; loc[(int64_t)nb + e] = m01; loc[(int64_t)2 * nb + e] = m01; loc[(int64_t)3 * nb + e] = m11;
+}
+
+// out[pos[i]] += vals[i]   (positions distinct)
+__global__ __launch_bounds__(kBlock) void k_fe_add_at(
+    int n, const int* __restrict__ pos, const double* __restrict__ vals, double* out) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    out[pos[i]] += vals[i];
+}
+
 // ---- nonlinear residual on the device ---------------------------------------
 // v = x_u with the Dirichlet entries replaced by their boundary values g
 // (v = x_u - d, d = the boundary defect of the iterate)

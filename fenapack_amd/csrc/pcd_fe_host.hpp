@@ -47,6 +47,11 @@ struct FeState {
   int64_t inv_n = 0; bool inv_bound = false;
   DBuf<int> inv_rowptr, inv_col, inv_flag;
   DBuf<double> inv_W;
+  // BRM2 boundary term of Kp (pcd_fe_bind_robin)
+  bool robin_bound = false; int64_t rb_nb = 0, rb_naff = 0;
+  DBuf<int> rb_nodes, rb_pos, rb_src;
+  DBuf<int64_t> rb_ptr;
+  DBuf<double> rb_normal, rb_length, rb_w, rb_loc, rb_tmp;
   // nonlinear residual on the device (pcd_fe_bind_residual)
   bool res_bound = false, have_mu0 = false;
   DCsr A01raw, A10raw;                 // unconstrained constant blocks
@@ -66,6 +71,8 @@ struct FeState {
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
     ru.release(); y.release(); parts.release(); slot.release();
     inv_rowptr.release(); inv_col.release(); inv_flag.release(); inv_W.release();
+    rb_nodes.release(); rb_pos.release(); rb_src.release(); rb_ptr.release();
+    rb_normal.release(); rb_length.release(); rb_w.release(); rb_loc.release(); rb_tmp.release();
     A01raw.release(); A10raw.release(); bc_idx.release(); bc_mult.release();
     bc_g.release(); mass.release(); mu0.release(); u0.release(); xd.release();
     bd.release(); dxd.release(); xs.release(); bs.release(); vv.release();
@@ -399,6 +406,36 @@ int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const) {
   return 0;
 }
 
+// BRM2 boundary term of Kp on the device (2-D): per inflow edge the P2 nodes
+// [3][nb] (start, end, midpoint), outward normals [2][nb], lengths; the
+// affected entries of Kp: aff_pos[n_aff] (distinct positions), each the sum of
+// aff_w[t] * loc[aff_src[t]] over aff_ptr (loc = local 2 x 2 matrices stored
+// [(i*2+j)][edge]; the weights carry the factor -1/nu).
+int pcd_fe_bind_robin(pcd_handle h, int64_t nb, const int32_t* nodes,
+                      const double* normals, const double* lengths, int64_t n_aff,
+                      const int32_t* aff_pos, const int64_t* aff_ptr,
+                      const int32_t* aff_src, const double* aff_w) {
+  if (!h || !h->fe || !h->fe->kp_bound) return fail(PCD_ERR_STATE, "fe_bind_robin: bind Kp first");
+  FeState& fe = *h->fe;
+  if (fe.dim != 2) return fail(PCD_ERR_ARG, "fe_bind_robin: the boundary term is implemented in 2-D");
+  if (nb < 0 || n_aff < 0 || (nb && (!nodes || !normals || !lengths || !aff_pos || !aff_ptr || !aff_src || !aff_w)))
+    return fail(PCD_ERR_ARG, "fe_bind_robin: bad arguments");
+  for (int64_t i = 0; i < n_aff; ++i)
+    if (aff_pos[i] < 0 || aff_pos[i] >= fe.nnz_kp) return fail(PCD_ERR_ARG, "fe_bind_robin: position outside Kp");
+  HIPCHK(hipSetDevice(h->device));
+  fe.rb_nb = nb; fe.rb_naff = n_aff;
+  CHK(fe_upload(fe.rb_nodes, nodes, (size_t)3 * nb));
+  CHK(fe_upload(fe.rb_normal, normals, (size_t)2 * nb));
+  CHK(fe_upload(fe.rb_length, lengths, (size_t)nb));
+  CHK(fe_upload(fe.rb_pos, aff_pos, (size_t)n_aff));
+  CHK(fe_upload(fe.rb_ptr, aff_ptr, (size_t)n_aff + 1));
+  CHK(fe_upload(fe.rb_src, aff_src, (size_t)(n_aff ? aff_ptr[n_aff] : 0)));
+  CHK(fe_upload(fe.rb_w, aff_w, (size_t)(n_aff ? aff_ptr[n_aff] : 0)));
+  CHK(fe.rb_loc.ensure((size_t)4 * nb)); CHK(fe.rb_tmp.ensure((size_t)n_aff));
+  fe.robin_bound = true;
+  return 0;
+}
+
 // multigrid hierarchy of inner solve `slot` follows the FE levels; smoother
 // bounds after every update: [emin_factor, emax_factor] * lambda_max(D^-1 A)
 int pcd_fe_bind_mg(pcd_handle h, int slot, double emin_factor,
@@ -503,6 +540,14 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
                        fe.nnz_kp, fe.kp_ptr.p, fe.kp_src.p, fe.kp_cells.p, fe.kp_const.p,
                        (const unsigned char*)nullptr, (double*)nullptr, fe.kp_vals.p,
                        (const double*)nullptr, (double*)nullptr);
+    if (fe.robin_bound && fe.rb_nb) {
+      hipLaunchKernelGGL(k_fe_robin_edges, dim3(grid1d(fe.rb_nb)), dim3(kBlock), 0, h->stream, (int)fe.rb_nb,
+                         fe.rb_nodes.p, fe.rb_normal.p, fe.rb_length.p, Lt.U.p, fe.rb_loc.p);
+      hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(fe.rb_naff)), dim3(kBlock), 0, h->stream, fe.rb_naff,
+                         fe.rb_ptr.p, fe.rb_src.p, fe.rb_w.p, fe.rb_loc.p, fe.rb_tmp.p);
+      hipLaunchKernelGGL(k_fe_add_at, dim3(grid1d(fe.rb_naff)), dim3(kBlock), 0, h->stream, (int)fe.rb_naff,
+                         fe.rb_pos.p, fe.rb_tmp.p, fe.kp_vals.p);
+    }
     HIPCHK(hipGetLastError());
     if (h->mat[PCD_MAT_KP].set) {
       if (h->mat[PCD_MAT_KP].nnz != fe.nnz_kp)

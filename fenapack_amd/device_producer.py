@@ -180,10 +180,10 @@ class DeviceProducer(object):
             and self._pat[0][2] <= 8192
         if self.device_inverse:
             eng.fe_bind_coarse_inverse(self._pat[0][0], self._pat[0][1])
-        # the residual and the Picard loop on the device as well - unless the
-        # BRM2 boundary term (or a host-side coarse inverse) needs the iterate
-        # on the host every iteration
-        self.device_loop = not self._robin and self.device_inverse \
+        # the residual and the Picard loop on the device as well - unless a
+        # host-side coarse inverse needs the iterate on the host every
+        # iteration
+        self.device_loop = self.device_inverse \
             and os.environ.get("PCD_FE_HOST_LOOP") != "1"
         if self.device_loop:
             mass = None
@@ -284,11 +284,22 @@ class DeviceProducer(object):
             cst = np.bincount(pat.inv, weights=M.ravel(), minlength=pat.nnz)
         self.eng.fe_bind_kp(ptr, src, cst, 1.0 / pb.nu)
         self.nnz_kp = pat.nnz
-        # BRM2: - (1/nu) int_inflow (w.n) p q ds depends on the iterate too;
-        # it lives on a few boundary edges and stays a host computation
-        # whose result replaces the constant part before every update
-        self._kp_base = cst
-        self._robin = pb.variant == "BRM2" and len(pb.robin_edges) > 0
+        # BRM2: - (1/nu) int_inflow (w.n) p q ds depends on the iterate too:
+        # a few boundary edges, local 2 x 2 matrices, gathered into the
+        # entries of Kp they touch (pcd_fe_bind_robin)
+        if pb.variant == "BRM2" and len(pb.robin_edges) > 0:
+            pl = V.robin_plan(pb.robin_edges)
+            nb = pl["length"].size
+            pd = pl["pdofs"]
+            rows = np.repeat(pd[:, :, None], 2, axis=2).ravel()
+            cols = np.repeat(pd[:, None, :], 2, axis=1).ravel()
+            where = pat.locate(rows, cols)           # (e, i, j) -> Kp entry
+            e_idx, ij = np.divmod(np.arange(where.size), 4)
+            aff_pos, aff_ptr, order = _group(where)
+            self.eng.fe_bind_robin(pl["nodes"].T, pl["normal"].T,
+                                   pl["length"], aff_pos, aff_ptr,
+                                   (ij * nb + e_idx)[order],
+                                   np.full(where.size, -1.0 / pb.nu))
 
     # ------------------------------------------------------------ device loop
     def set_time_level(self):
@@ -317,10 +328,6 @@ class DeviceProducer(object):
         dd[self._bc_idx] = xu[self._bc_idx] - g
         v = xu - dd
         ru = np.empty(V.n_u)
-        if self._robin:
-            R = V._boundary_flux_mass(pb.nodal_velocity(xu), pb.robin_edges)
-            base = 0.0 if self._kp_base is None else self._kp_base
-            self.eng.fe_set_kp_const(base - R.data / pb.nu)
         t1 = time.perf_counter()
         self.eng.fe_update(np.ascontiguousarray(xu), v, ru)
         t2 = time.perf_counter()

@@ -357,13 +357,17 @@ class TaylorHood(object):
             K = pat.matrix(K.data - R.data / nu)
         return K
 
-    def _boundary_flux_mass(self, U, edges):
-        """int_edges (w.n) p q ds as an n_p x n_p matrix on the PP pattern
-        (2D: boundary facets are edges)."""
+    def robin_plan(self, edges):
+        """Geometry of the boundary integral over ``edges`` (2D): P2 nodes
+        (start, end, midpoint), outward unit normals, lengths, pressure dofs
+        of the end points."""
         if self.dim != 2:
             raise NotImplementedError("Robin boundary term: 2D only")
+        key = ("_robin", tuple(np.asarray(edges).tolist()))
+        if getattr(self, "_robin_cache", (None,))[0] == key:
+            return self._robin_cache[1]
         m = self.mesh
-        pat = self._patterns(False)["PP"]
+        edges = np.asarray(edges)
         ev = m.edges[edges]                                     # (nb,2)
         a, b = m.vertices[ev[:, 0]], m.vertices[ev[:, 1]]
         t = b - a
@@ -379,10 +383,21 @@ class TaylorHood(object):
         inward = m.vertices[opp] - a
         sgn = np.where((inward * n).sum(axis=1) > 0, -1.0, 1.0)
         n = n * sgn[:, None]
-        # P2 wind along the edge: endpoints + midpoint dofs
         r = self._rank
-        Ua, Ub = U[r[ev[:, 0]]], U[r[ev[:, 1]]]
-        Um = U[r[self.nv + np.asarray(edges)]]
+        nodes = np.stack([r[ev[:, 0]], r[ev[:, 1]], r[self.nv + edges]], axis=1)
+        plan = {"nodes": nodes, "normal": n, "length": length,
+                "pdofs": self._pnum[ev]}
+        self._robin_cache = (key, plan)
+        return plan
+
+    def _boundary_flux_mass(self, U, edges):
+        """int_edges (w.n) p q ds as an n_p x n_p matrix on the PP pattern
+        (2D: boundary facets are edges)."""
+        pl = self.robin_plan(edges)
+        pat = self._patterns(False)["PP"]
+        n, length, nodes = pl["normal"], pl["length"], pl["nodes"]
+        # P2 wind along the edge: endpoints + midpoint dofs
+        Ua, Ub, Um = U[nodes[:, 0]], U[nodes[:, 1]], U[nodes[:, 2]]
         s = _G3X
         la, lb = 1 - s, s                                       # (3,)
         wn = ((la * (2 * la - 1))[None, :] * (Ua * n).sum(1)[:, None]
@@ -391,7 +406,7 @@ class TaylorHood(object):
         psi = np.stack([la, lb], axis=1)                        # (3q, 2)
         loc = np.einsum('q,eq,qi,qj->eij', _G3W, wn, psi, psi) \
             * length[:, None, None]
-        pd = self._pnum[ev]                                     # (nb,2)
+        pd = pl["pdofs"]                                        # (nb,2)
         rows = np.repeat(pd[:, :, None], 2, axis=2).ravel()
         cols = np.repeat(pd[:, None, :], 2, axis=1).ravel()
         data = np.bincount(pat.locate(rows, cols), weights=loc.ravel(),

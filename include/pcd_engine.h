@@ -295,6 +295,18 @@ int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
 /* replace kp_const (terms the host keeps assembling every iteration, e.g. the
  * BRM2 boundary integral of demo_navier-stokes-pcd.py:131-135); NULL = none  */
 int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const);
+/* BRM2 boundary term of Kp, -(1/nu) int_inflow (w.n) p q ds
+ * (demo_navier-stokes-pcd.py:131-135), on the device (2-D): per inflow edge
+ * its P2 nodes nodes[3][nb] (start, end, midpoint), outward unit normals
+ * normals[2][nb], lengths[nb]; aff_pos[n_aff] = the distinct entries of Kp
+ * it touches, entry i += sum_t aff_w[t] * loc[aff_src[t]], t in
+ * aff_ptr[i]..aff_ptr[i+1], loc = the local 2 x 2 edge matrices stored
+ * [(i*2+j)][edge]; aff_w carries -1/nu.                                      */
+int pcd_fe_bind_robin(pcd_handle h, int64_t nb, const int32_t* nodes,
+                      const double* normals, const double* lengths,
+                      int64_t n_aff, const int32_t* aff_pos,
+                      const int64_t* aff_ptr, const int32_t* aff_src,
+                      const double* aff_w);
 /* the multigrid hierarchy of inner solve `slot` follows the FE levels; after
  * every update the smoother bounds of level l >= 1 become
  * [emin_factor, emax_factor] * lambda_max(D^-1 A_l) (power iteration, `iters`

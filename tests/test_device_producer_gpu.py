@@ -332,3 +332,33 @@ def test_element_kernels_against_closed_form_integration(hip_lib, make):
     assert relerr(got_conv, patS.assemble(conv).data) < 1e-12
     assert relerr(got_kp, patP.assemble(kp).data) < 1e-12
     assert relerr(got_stab, patS.assemble(stab).data) < 1e-12
+
+
+def test_brm2_boundary_term_of_kp_on_the_device(hip_lib):
+    """BRM2 on the reference geometry: Kp includes -(1/nu) int_inflow (w.n) p q
+    (demo_navier-stokes-pcd.py:131-135), assembled by k_fe_robin_edges; the
+    Picard loop stays on the device."""
+    pb = BackwardStep(3, nu=0.02, variant="BRM2")
+    assert len(pb.robin_edges) > 0
+    V = pb.space
+    _options(2, galerkin=True)
+    out = solve_steady_device(pb, max_newton=1)
+    prod = out["producer"]
+    assert prod.device_loop
+    rng = np.random.default_rng(13)
+    xu, xp = rng.standard_normal(V.n_u), rng.standard_normal(V.n_p)
+    prod.update(xu, xp)
+    ref = pb.Kp(xu)
+    plain = V.assemble_Kp(pb.nu, pb.nodal_velocity(xu))
+    assert relerr(ref.data, plain.data) > 1e-3          # the term is there
+    assert relerr(prod.kp_matrix().data, ref.data) < 1e-13
+    outs = []
+    for fn in (solve_steady, solve_steady_device):
+        pb2 = BackwardStep(3, nu=0.02, variant="BRM2")
+        _options(2, galerkin=True)
+        outs.append(fn(pb2, max_newton=6))
+    ref, dev = outs
+    assert dev["newton_its"] == ref["newton_its"]
+    for i, j in zip(dev["krylov_per_step"], ref["krylov_per_step"]):
+        assert abs(i - j) <= max(1, 0.1 * j)       # (smoother bounds differ)
+    assert relerr(dev["w"].vector(), ref["w"].vector()) < 1e-5
