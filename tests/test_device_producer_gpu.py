@@ -362,3 +362,33 @@ def test_brm2_boundary_term_of_kp_on_the_device(hip_lib):
     for i, j in zip(dev["krylov_per_step"], ref["krylov_per_step"]):
         assert abs(i - j) <= max(1, 0.1 * j)       # (smoother bounds differ)
     assert relerr(dev["w"].vector(), ref["w"].vector()) < 1e-5
+
+
+def test_constant_part_of_kp_can_be_replaced(hip_lib):
+    """pcd_fe_set_kp_const: terms a caller keeps assembling itself."""
+    from fenapack_amd import _cabi as c
+    from fenapack_amd.device_producer import _contribution_plan
+    from fenapack_amd.fem.taylor_hood import _p2_basis
+    pb = Cavity(0)
+    V, m = pb.space, pb.space.mesh
+    nc, na, nvl = m.num_cells, V.na, V.nvl
+    patS, patP = V._patterns(False)["SS"], V._patterns(False)["PP"]
+    e = c.Engine(hip_lib, "BRM1", 0)
+    _, dphi = _p2_basis(V.psi, V.local_edges)
+    e.fe_begin(2, 1, V.wq[0] / V.area[0], V.phi, dphi, V.psi)
+    ptr, src = _contribution_plan(patS.inv, nc, na * na, patS.nnz)
+    e.fe_set_level(0, V.cell_dofs2.T, V.gradlam.reshape(nc, -1).T, V.area,
+                   ptr, src, np.zeros(patS.nnz), np.ones(patS.nnz, np.uint8),
+                   np.zeros(0, np.int32), np.zeros(0), None, V.nn)
+    kptr, ksrc = _contribution_plan(patP.inv, nc, nvl * nvl, patP.nnz)
+    e.fe_bind_kp(kptr, ksrc, None, 2.0)
+    xu = np.random.default_rng(2).standard_normal(V.n_u)
+    e.fe_update(xu)
+    base = e.fe_kp_values(patP.nnz)
+    cst = np.random.default_rng(3).standard_normal(patP.nnz)
+    e.fe_set_kp_const(cst)
+    e.fe_update(xu)
+    assert relerr(e.fe_kp_values(patP.nnz), base + cst) < 1e-14
+    e.fe_set_kp_const(None)
+    e.fe_update(xu)
+    assert relerr(e.fe_kp_values(patP.nnz), base) < 1e-15
