@@ -673,7 +673,7 @@ int pcdo_apply(pcdo_t *h, const double *x, double *y, int mem) {
 
 /* [ext PETSc] PCApply_FieldSplit_Schur, UPPER, on split-ordered vectors */
 static int fs_apply_split(pcdo_t *h, const double *x, double *y) {
-  int64_t nu = h->n_u, np = h->n_p;
+  int64_t nu = h->n_u;
   const double *xu = x, *xp = x + nu;
   double *yu = y, *yp = y + nu, *t = h->wu[0];
   int rc;
