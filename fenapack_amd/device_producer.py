@@ -403,10 +403,14 @@ class DevicePicardSolver(object):
         prm = nls.parameters
         x = w.vector()
         if self.producer is None:
-            it, converged = nls.solve(self.nlp, x, on_update=w.touch)
+            # (the residual at the new iterate is evaluated by the producer)
+            it, converged = nls.solve(self.nlp, x, on_update=w.touch,
+                                      final_residual=False)
             self.krylov_history = list(nls.krylov_history)
             self.residual_history = list(nls.residual_history)
             r0 = self.residual_history[0]
+            if len(self.residual_history) == it:       # final one skipped
+                self.residual_history.append(float("nan"))
             t0 = time.time()
             self.producer = DeviceProducer(pb, nls.linear_solver().ksp())
             self.time_plan = time.time() - t0

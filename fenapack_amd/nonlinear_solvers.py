@@ -60,10 +60,13 @@ class PCDNewtonSolver(object):
         self._solver.init_pcd(nonlinear_problem.pcd_assembler,
                               self._pcd_pc_class)
 
-    def solve(self, problem, x, on_update=None):
+    def solve(self, problem, x, on_update=None, final_residual=True):
         """``x``: host vector of the iterate, updated in place.
         ``on_update()`` is invoked after every update of ``x`` (it plays the
-        role of DOLFIN forms seeing the new coefficient values)."""
+        role of DOLFIN forms seeing the new coefficient values).
+        ``final_residual=False``: when the iteration limit is reached the
+        residual at the last iterate is not assembled (a caller that
+        continues the iteration by other means evaluates it itself)."""
         prm = self.parameters
         self._krylov_iterations = 0
         self.krylov_history, self.residual_history = [], []
@@ -85,6 +88,8 @@ class PCDNewtonSolver(object):
             if on_update is not None:
                 on_update()
             it += 1
+            if not final_residual and it >= prm["maximum_iterations"]:
+                break
             problem.F(b, x)
             r = float(np.linalg.norm(b))
             self.residual_history.append(r)
