@@ -121,6 +121,33 @@ class FixedPattern(object):
         np.cumsum(np.bincount(urow, minlength=shape[0]), out=self.indptr[1:])
         self.rows = urow.astype(np.int32)
 
+    @classmethod
+    def from_unique(cls, rows, cols, shape):
+        """Pattern of entries known to be pairwise distinct: a counting sort
+        through scipy's COO -> CSR conversion instead of ``numpy.unique`` on
+        the keys (several times faster at 10^7 entries)."""
+        rows = np.asarray(rows).ravel()
+        cols = np.asarray(cols).ravel()
+        n = rows.size
+        tag = sp.coo_matrix((np.arange(1, n + 1, dtype=np.float64),
+                             (rows, cols)), shape=shape).tocsr()
+        tag.sort_indices()
+        if tag.nnz != n:
+            raise ValueError("from_unique: duplicate entries")
+        self = cls.__new__(cls)
+        self.shape = shape
+        self.nnz = n
+        order = tag.data.astype(np.int64) - 1          # CSR slot -> input
+        self.inv = np.empty(n, dtype=np.int64)
+        self.inv[order] = np.arange(n)
+        self.order = order
+        self.indices = tag.indices.astype(np.int32)
+        self.indptr = tag.indptr.astype(np.int32)
+        self.rows = np.repeat(np.arange(shape[0], dtype=np.int32),
+                              np.diff(self.indptr))
+        self.keys = self.rows.astype(np.int64) * shape[1] + self.indices
+        return self
+
     def assemble(self, vals):
         data = np.bincount(self.inv, weights=np.asarray(vals).ravel(),
                            minlength=self.nnz)
@@ -450,13 +477,9 @@ class TaylorHood(object):
             r2, c2 = rc(A10, ip, iu)
             rows = np.concatenate([r0, r1, r2, ip])
             cols = np.concatenate([c0, c1, c2, ip])
-            pat = FixedPattern(rows, cols, (self.ndof, self.ndof))
             # every (row, col) of the blocks is unique: assembly is a pure
-            # permutation, so keep its inverse and gather instead of summing
-            assert pat.nnz == rows.size
-            order = np.empty(pat.nnz, dtype=np.int64)
-            order[pat.inv] = np.arange(pat.nnz)
-            pat.order = order
+            # permutation (pat.order), gathered instead of summed
+            pat = FixedPattern.from_unique(rows, cols, (self.ndof, self.ndof))
             setattr(self, key, pat)
         pat = getattr(self, key)
         vals = np.concatenate([A00.data, A01.data, A10.data,
