@@ -305,6 +305,7 @@ def main():
             "A00": "chebyshev+jacobi its %d eig ratio %g"
                    % (k_f, args.a00_ratio)}
 
+    traffic = pmc_traffic(int(V.n_u), nnz_a00, world)
     out = {
         "metric": "fieldsplit PCApply calls/sec (%s Re=100, P2/P1)"
                   % ("3D cavity" if args.geometry == "cube" else "2D cavity"),
@@ -343,7 +344,13 @@ def main():
             "bytes_per_launch": int(b_kernel),
             "us_per_launch": 1e6 * t_kernel,
             "measured_d2d_copy_gbs": copy_gbs,
-            "traffic": pmc_traffic(int(V.n_u), nnz_a00, world),
+            "traffic": traffic,
+            # what the kernel really moves (PMC) per second, and that rate
+            # against the copy bandwidth measured on this box just now
+            "traffic_gbs": None if traffic is None
+            else traffic / t_kernel / 1e9,
+            "traffic_over_measured_copy": None if traffic is None
+            else traffic / t_kernel / 1e9 / copy_gbs,
         },
         "setup_seconds": t_setup,
     }
