@@ -428,17 +428,26 @@ def pmc_traffic(n_u, nnz_a00, world):
     a kernel of known byte count: profiles/r01_pmc_cheb_step_level6.json).
     PMC cannot be collected inside this process; null unless the committed
     measurement is for exactly this operator."""
-    name = "r01_pmc_cheb_step_level6.json" \
-        if os.environ.get("PCD_NO_KRON2") == "1" \
-        else "r01_m_pmc_cheb_step_sc_level6.json"
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", name)))
-        k = d.get("k_cheb_step_s<256>", d)
-        if world == 1 and k["algorithmic_bytes_per_launch"] == \
-                12 * nnz_a00 + 92 * n_u + 4:
-            return k["traffic_bytes_per_launch"]
-    except Exception:
-        pass
+    import glob
+    want = 12 * nnz_a00 + 92 * n_u + 4
+    scalar = os.environ.get("PCD_NO_KRON2") == "1"
+    if world != 1:
+        return None
+    paths = glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))
+    # newest measurement first: r01_<letter>_pmc_* (later letters = later in
+    # the round) before the early r01_pmc_* files
+    paths.sort(key=lambda q: (not os.path.basename(q).startswith("r01_pmc"),
+                              os.path.basename(q)), reverse=True)
+    for path in paths:
+        try:
+            d = json.load(open(path))
+            k = d.get("k_cheb_step_s<256>", d)
+            is_scalar = "k_cheb_step_s<" in str(k.get("kernel", "k_cheb_step_s<"))
+            if k["algorithmic_bytes_per_launch"] == want \
+                    and is_scalar == scalar:
+                return k["traffic_bytes_per_launch"]
+        except Exception:
+            continue
     return None
 
 

@@ -215,9 +215,14 @@ static int choose_lpr(const DCsr& A) {
 // whose every row block fits the LDS tile; 0 = some row block is too long
 static int g_max_rb = 256;              // PCD_MAX_RB: A/B switch
 static int g_min_wgs = 512;             // PCD_MIN_WGS: A/B switch (see rb_for)
+static int g_max_chunks = 2;            // PCD_MAX_CHUNKS: LDS-tile passes per row block
 // rows per workgroup: the largest RB whose every row block fits the LDS tile
-// and - optionally - that still yields `g_min_wgs` workgroups (small
-// operators then take smaller row blocks: more, shorter workgroups)
+// and that still yields `g_min_wgs` workgroups (small operators then take
+// smaller row blocks: more, shorter workgroups).  Blocks of 64 rows and
+// fewer may take two passes through the tile - the way out of 32-row blocks
+// for operators with long rows: on the 3-D velocity block (28 entries per
+// row) 64 rows in two passes beat 32 in one by 16 %; larger blocks in two
+// passes lose ~1 % to smaller ones in one pass on the 2-D operators.
 static int rb_for(int64_t nrows, const int32_t* rowptr, int tile) {
   int fit = 0;
   for (int rb : {256, 128, 64, 32}) {
@@ -225,7 +230,7 @@ static int rb_for(int64_t nrows, const int32_t* rowptr, int tile) {
     bool ok = true;
     for (int64_t r = 0; r < nrows && ok; r += rb) {
       const int64_t r1 = std::min<int64_t>(r + rb, nrows);
-      if (rowptr[r1] - rowptr[r] > tile) ok = false;
+      if (rowptr[r1] - rowptr[r] > (int64_t)tile * (rb > 64 ? 1 : g_max_chunks)) ok = false;
     }
     if (!ok) continue;
     fit = rb;                            // smaller ones fit as well
@@ -1191,6 +1196,7 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_NO_KRON2"); g_no_kron = e && e[0] == '1'; }
   { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
   { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
+  { const char* e = getenv("PCD_MAX_CHUNKS"); if (e && atoi(e) >= 1) g_max_chunks = atoi(e); }
   { const char* e = getenv("PCD_NO_XCD_REMAP");
     if (e && e[0] == '1') {
       const int none = 0;

@@ -282,28 +282,37 @@ __device__ __forceinline__ double stream_row_block(
   // this lane's own row bounds, fetched up front (used after the barrier)
   const int ra = mine ? rowptr[row] - k0 : 0;
   const int rb = mine ? rowptr[row + 1] - k0 : 0;
-  for (int base = k0; base < k1; base += kUnroll * kBlock) {
-    int c[kUnroll];
-    double v[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int k = base + u * kBlock + threadIdx.x;
-      const bool in = k < k1;
-      c[u] = in ? col[k] : -1;
-      v[u] = in ? val[k] : 0.0;
-    }
-    double xv[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : 0.0;
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int k = base + u * kBlock + threadIdx.x;
-      if (k < k1) lds[k - k0] = v[u] * xv[u];
-    }
-  }
-  __syncthreads();
   double s = 0.0;
-  for (int j = ra + sub; j < rb; j += TPR) s += lds[j];
+  // the block's entries pass through the LDS tile in chunks (normally one;
+  // the host admits a few more for operators with long rows)
+  for (int c0 = 0; c0 < k1 - k0; c0 += kTile) {
+    const int c1 = min(c0 + kTile, k1 - k0);
+    if (c0) __syncthreads();                // readers of the previous chunk
+    for (int base = k0 + c0; base < k0 + c1; base += kUnroll * kBlock) {
+      int c[kUnroll];
+      double v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int k = base + u * kBlock + threadIdx.x;
+        const bool in = k < k0 + c1;
+        c[u] = in ? col[k] : -1;
+        v[u] = in ? val[k] : 0.0;
+      }
+      double xv[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : 0.0;
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int k = base + u * kBlock + threadIdx.x;
+        if (k < k0 + c1) lds[k - k0 - c0] = v[u] * xv[u];
+      }
+    }
+    __syncthreads();
+    const int lo = max(ra, c0), hi = min(rb, c1);
+    int j = ra + sub;                       // lane `sub` owns j = ra+sub (mod TPR)
+    if (j < lo) j += (lo - j + TPR - 1) / TPR * TPR;
+    for (; j < hi; j += TPR) s += lds[j - c0];
+  }
 #pragma unroll
   for (int m = TPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m);
   return s;                                  // on every lane of the row
@@ -532,37 +541,44 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
   const bool mine = row < r1;
   const int ra = mine ? rowptr[row] - k0 : 0;
   const int rb = mine ? rowptr[row + 1] - k0 : 0;
-  for (int base = k0; base < k1; base += kUnroll * kBlock) {
-    int c[kUnroll];
-    double v[kUnroll];
+  VecC<NC> s = vzero<NC>();
+  for (int c0 = 0; c0 < k1 - k0; c0 += kTileC) {   // chunks of the LDS tile
+    const int c1 = min(c0 + kTileC, k1 - k0);
+    if (c0) __syncthreads();
+    for (int base = k0 + c0; base < k0 + c1; base += kUnroll * kBlock) {
+      int c[kUnroll];
+      double v[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int k = base + u * kBlock + threadIdx.x;
-      const bool in = k < k1;
-      c[u] = in ? col[k] : -1;
-      v[u] = in ? val[k] : 0.0;
-    }
-    VecC<NC> xv[kUnroll];
+      for (int u = 0; u < kUnroll; ++u) {
+        const int k = base + u * kBlock + threadIdx.x;
+        const bool in = k < k0 + c1;
+        c[u] = in ? col[k] : -1;
+        v[u] = in ? val[k] : 0.0;
+      }
+      VecC<NC> xv[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u)
-      xv[u] = c[u] >= 0 ? xf(c[u]) : vzero<NC>();
+      for (int u = 0; u < kUnroll; ++u)
+        xv[u] = c[u] >= 0 ? xf(c[u]) : vzero<NC>();
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int k = base + u * kBlock + threadIdx.x;
-      if (k < k1) {
-        VecC<NC> t;
+      for (int u = 0; u < kUnroll; ++u) {
+        const int k = base + u * kBlock + threadIdx.x;
+        if (k < k0 + c1) {
+          VecC<NC> t;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) t.c[i] = v[u] * xv[u].c[i];
-        lds[k - k0] = t;
+          for (int i = 0; i < NC; ++i) t.c[i] = v[u] * xv[u].c[i];
+          lds[k - k0 - c0] = t;
+        }
       }
     }
-  }
-  __syncthreads();
-  VecC<NC> s = vzero<NC>();
-  for (int j = ra + sub; j < rb; j += TPR) {
-    const VecC<NC> t = lds[j];
+    __syncthreads();
+    const int lo = max(ra, c0), hi = min(rb, c1);
+    int j = ra + sub;
+    if (j < lo) j += (lo - j + TPR - 1) / TPR * TPR;
+    for (; j < hi; j += TPR) {
+      const VecC<NC> t = lds[j - c0];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) s.c[i] += t.c[i];
+      for (int i = 0; i < NC; ++i) s.c[i] += t.c[i];
+    }
   }
 #pragma unroll
   for (int m = TPR / 2; m > 0; m >>= 1) {

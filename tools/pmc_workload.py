@@ -20,18 +20,20 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fenapack_amd import _cabi as c                       # noqa: E402
-from fenapack_amd.fem import Cavity                        # noqa: E402
+from fenapack_amd.fem import Cavity, Cavity3D              # noqa: E402
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-pb = Cavity(level, nu=0.01)
+cube = len(sys.argv) > 2 and sys.argv[2] == "cube"     # level = refinements
+pb = Cavity3D(level, nu=0.01, n0=4) if cube else Cavity(level, nu=0.01)
 V = pb.space
 xy = V.node_coords
 x, y = xy[:, 0], xy[:, 1]
 U = np.stack([np.sin(np.pi * x) ** 2 * np.sin(np.pi * y) * np.cos(np.pi * y),
-              -np.sin(np.pi * x) * np.cos(np.pi * x) * np.sin(np.pi * y) ** 2],
-             axis=1)
+              -np.sin(np.pi * x) * np.cos(np.pi * x) * np.sin(np.pi * y) ** 2]
+             + ([0.1 * np.sin(np.pi * xy[:, 2])] if cube else []), axis=1)
 L = pb.linearise(U.ravel(), np.zeros(V.n_p))
 e = c.Engine(c.hip_library(), "BRM1", 0)
+e.set_velocity_block(V.dim)
 e.set_csr(c.MAT_A00, L["A00"])
 b = np.random.default_rng(0).standard_normal(V.n_u)
 out = np.empty_like(b)
