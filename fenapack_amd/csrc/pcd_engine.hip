@@ -1052,7 +1052,7 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     }
     rpc[s + 1] = (int32_t)cc.size();
   }
-  const int rb2 = rb_for(nn, rpc.data(), kTileC);
+  const int rb2 = rb_for(nn, rpc.data(), nc == 3 ? tile_c<3>() : tile_c<2>());
   if (!rb2) return 0;
   A.nnz2 = (int64_t)cc.size();
   CHK(A.rowptr2.ensure(nn + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2));

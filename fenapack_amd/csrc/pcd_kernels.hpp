@@ -487,7 +487,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_spmv_s(
 // components of a node together: 16/24-byte gathers and coalesced vector
 // traffic.  Same three phases as the stream kernels.
 // ==========================================================================
-constexpr int kTileC = 2048;      // LDS nodes per workgroup (32 / 48 KiB)
+#ifndef PCD_TILE3
+#define PCD_TILE3 2048
+#endif
+// LDS nodes per workgroup: 2048 pairs = 32 KiB; triples: PCD_TILE3 x 24 B
+template <int NC> constexpr int tile_c() { return NC == 3 ? PCD_TILE3 : 2048; }
 
 template <int NC>
 struct alignas(NC == 2 ? 16 : 8) VecC {
@@ -542,6 +546,7 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
   const int ra = mine ? rowptr[row] - k0 : 0;
   const int rb = mine ? rowptr[row + 1] - k0 : 0;
   VecC<NC> s = vzero<NC>();
+  constexpr int kTileC = tile_c<NC>();
   for (int c0 = 0; c0 < k1 - k0; c0 += kTileC) {   // chunks of the LDS tile
     const int c1 = min(c0 + kTileC, k1 - k0);
     if (c0) __syncthreads();
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* x, const double* ghost,
     int nloc, const double* add_, double* y_) {
-  __shared__ VecC<NC> lds[kTileC];
+  __shared__ VecC<NC> lds[tile_c<NC>()];
   const XVecC<NC> xf{vc<NC>(x), vc<NC>(ghost), nloc};
   const VecC<NC>* add = vc<NC>(add_);
   VecC<NC>* y = vc<NC>(y_);
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
     const double* __restrict__ val, const double* __restrict__ dinv_,
     const double* b_, const double* pm_, const double* pk_, double* pn_,
     double c0, double c1, double c2, const double* ghost, int nloc) {
-  __shared__ VecC<NC> lds[kTileC];
+  __shared__ VecC<NC> lds[tile_c<NC>()];
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_), *pm = vc<NC>(pm_),
                *pk = vc<NC>(pk_);
   VecC<NC>* pn = vc<NC>(pn_);
@@ -661,7 +666,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* __restrict__ dinv_,
     const double* b_, double* p0_, double* pn_, double s, double c1, double c2) {
-  __shared__ VecC<NC> lds[kTileC];
+  __shared__ VecC<NC> lds[tile_c<NC>()];
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
