@@ -46,3 +46,44 @@ def test_element_matrices_are_exact(make):
         # streamline diffusion with a P2 wind has degree 6: its own rule
         # (exact to degree 7; the degree-5 rules were off by 10-25 % here)
         assert np.abs(supg[c] - ex["supg"]).max() < 1e-12 * scale(ex["supg"])
+
+
+@pytest.mark.parametrize("d,n", [(2, 3), (2, 4), (3, 3), (3, 4)])
+def test_conical_rules_integrate_monomials_exactly(d, n):
+    """Stroud conical Gauss-Jacobi rules: exact to degree 2n - 1 against
+    int lambda^alpha = d! prod(alpha_i!) / (d + |alpha|)! on the unit simplex
+    (measure 1/d! divided out: weights sum to one)."""
+    from itertools import product
+    from math import factorial
+    from fenapack_amd.fem.taylor_hood import _conical_rule
+    pts, wts = _conical_rule(d, n)
+    assert abs(wts.sum() - 1.0) < 1e-14 and np.all(wts > 0)
+    assert np.allclose(pts.sum(axis=1), 1.0) and np.all(pts > 0)
+    for alpha in product(range(2 * n), repeat=d + 1):
+        if sum(alpha) > 2 * n - 1:
+            continue
+        exact = factorial(d)
+        for a in alpha:
+            exact *= factorial(a)
+        exact /= factorial(d + sum(alpha))
+        got = float(wts @ np.prod(pts ** np.array(alpha), axis=1))
+        assert abs(got - exact) < 1e-13, alpha
+
+
+def test_pattern_of_distinct_entries_matches_the_general_constructor():
+    from fenapack_amd.fem.taylor_hood import FixedPattern
+    rng = np.random.default_rng(0)
+    n, m = 300, 170
+    keys = rng.choice(n * m, size=4000, replace=False)
+    rows, cols = keys // m, keys % m
+    a = FixedPattern(rows, cols, (n, m))
+    b = FixedPattern.from_unique(rows, cols, (n, m))
+    assert a.nnz == b.nnz == 4000
+    assert np.array_equal(a.indptr, b.indptr)
+    assert np.array_equal(a.indices, b.indices)
+    assert np.array_equal(a.inv, b.inv)
+    vals = rng.standard_normal(4000)
+    assert np.array_equal(a.assemble(vals).data, vals[b.order])
+    with pytest.raises(ValueError):
+        FixedPattern.from_unique(np.r_[rows, rows[:1]], np.r_[cols, cols[:1]],
+                                 (n, m))
