@@ -166,6 +166,11 @@ struct pcd_engine_s {
   std::vector<double> bc_val_host;
   DBuf<int> perm;                     // LOCAL split position -> caller's index
   DBuf<double> sysvals, psysvals;     // staging of the caller's value arrays
+  // (1,0) and (1,1) blocks of the system (one GPU): w = A z is then applied
+  // block-wise, so the velocity block goes through its F x I fast path
+  DCsr a10, a11;
+  std::vector<int64_t> a11_src_host;
+  bool a11_zero = true, p_is_a = true;
   bool ready = false;
   DBuf<double> w[2];                  // pressure work vectors (get_work_vecs)
   DBuf<double> wu;                    // velocity work vector
@@ -1214,6 +1219,7 @@ int pcd_destroy(pcd_handle h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   fe_release(h);
+  h->a10.release(); h->a11.release();
   for (auto& m : h->mat) m.release();
   for (auto& s : h->inner) s.release();
   h->bc_idx.release(); h->bc_val.release(); h->bc_slot.release(); h->perm.release();
@@ -1333,6 +1339,16 @@ int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
     }
   }
   if (!dp) dp = dv;                      // P = A  (nonlinear_solvers.py:75)
+  h->p_is_a = (dp == dv);
+  if (h->a10.set) {
+    CHK(gather_block_values(h, h->a10, dv));
+    CHK(gather_block_values(h, h->a11, dv));
+    if (mem == PCD_MEM_HOST) {            // (device-side updates leave A11 alone)
+      h->a11_zero = true;
+      for (int64_t k : h->a11_src_host)
+        if (vals[k] != 0.0) { h->a11_zero = false; break; }
+    }
+  }
   CHK(gather_block_values(h, h->mat[PCD_MAT_A], dv));
   CHK(gather_block_values(h, h->mat[PCD_MAT_A00], dp));
   CHK(gather_block_values(h, h->mat[PCD_MAT_A01], dp));
@@ -1378,6 +1394,14 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   CHK(upload_global(h, h->mat[PCD_MAT_A00], &h->sp_u, &h->sp_u, n_u, n_u, rp.data(), cc.data(), nullptr, src.data()));
   extract_block(n_u, is_u, rowptr, colidx, mp, rp, cc, src);
   CHK(upload_global(h, h->mat[PCD_MAT_A01], &h->sp_u, &h->sp_p, n_u, n_p, rp.data(), cc.data(), nullptr, src.data()));
+  h->a10.release(); h->a11.release(); h->a11_src_host.clear();
+  if (!h->comm) {
+    extract_block(n_p, is_p, rowptr, colidx, mu, rp, cc, src);
+    CHK(upload_csr(h, h->a10, n_p, n_u, rp.data(), cc.data(), nullptr, src.data()));
+    extract_block(n_p, is_p, rowptr, colidx, mp, rp, cc, src);
+    CHK(upload_csr(h, h->a11, n_p, n_p, rp.data(), cc.data(), nullptr, src.data()));
+    h->a11_src_host = src;
+  }
   extract_block(n, perm.data(), rowptr, colidx, ma, rp, cc, src);
   CHK(upload_global(h, h->mat[PCD_MAT_A], &h->sp_sys, &h->sp_sys, n, n, rp.data(), cc.data(), nullptr, src.data()));
   h->ready = false; ++h->gen;
@@ -1675,6 +1699,20 @@ static int dev_norm(Engine* h, int64_t n, const double* v, double* out) {
   return 0;
 }
 
+// w = A z on split-ordered vectors.  One GPU with P = A: block-wise through
+// A00 (F x I fast path), A01, A10 (and A11 if it is not zero) - about half
+// the bytes of the monolithic CSR; otherwise the monolithic operator.
+static int apply_system(Engine* h, const double* z, double* w) {
+  if (h->comm || !h->p_is_a || !h->a10.set || !h->mat[PCD_MAT_A00].set || !h->mat[PCD_MAT_A01].set)
+    return spmv(h, h->mat[PCD_MAT_A], z, w);
+  const int64_t nu = h->n_u;
+  CHK(spmv(h, h->mat[PCD_MAT_A00], z, w));
+  CHK(spmv(h, h->mat[PCD_MAT_A01], z + nu, w, 1, w));
+  CHK(spmv(h, h->a10, z, w + nu));
+  if (!h->a11_zero) CHK(spmv(h, h->a11, z + nu, w + nu, 1, w + nu));
+  return 0;
+}
+
 int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
                     double rtol, double atol, int m, int max_it, int* its,
                     double* rnorm) {
@@ -1682,6 +1720,7 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
   if (!h->ready || !h->mat[PCD_MAT_A].set)
     return fail(PCD_ERR_STATE, "gmres_solve: pcd_set_system + pcd_setup first");
   if (!b || !x || m < 1 || max_it < 0) return fail(PCD_ERR_ARG, "gmres_solve: bad arguments");
+  if (m > 255) return fail(PCD_ERR_ARG, "gmres_solve: restart %d exceeds 255", m);
   const int64_t nglob = h->n_u + h->n_p;
   const int64_t n = h->nu_loc + h->np_loc;               // rows of this rank
   const bool local_io = h->comm && mem == PCD_MEM_DEVICE;
@@ -1724,7 +1763,7 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
       double* vk = V + (size_t)k * ld;
       double* vn = V + (size_t)(k + 1) * ld;
       CHK(fs_apply_split(h, vk, z));                           // z = M^-1 v_k
-      CHK(spmv(h, A, z, vn));                                  // w = A z
+      CHK(apply_system(h, z, vn));                             // w = A z
       const int nvec = k + 1;
       const int tiles = (nvec + kDotTile - 1) / kDotTile;
       // classical Gram-Schmidt: all k+1 dots in one batch, ONE all-reduce

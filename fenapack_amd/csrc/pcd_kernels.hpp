@@ -831,16 +831,30 @@ __global__ __launch_bounds__(kBlock) void k_mdot_reduce(const double* parts,
   if (threadIdx.x == 0) h[blockIdx.x] = s;
 }
 
-// w -= sum_j h[j] V_j ; parts[blk] = sum w^2
+// w -= sum_j h[j] V_j ; parts[blk] = sum w^2.  The basis vectors are read
+// eight at a time into independent registers (the coefficients sit in LDS):
+// a dependent chain of nvec loads per element left most of the bandwidth idle.
 __global__ __launch_bounds__(kBlock) void k_maxpy_norm(
-    int64_t n, const double* V, int64_t ld, int nvec, const double* h,
-    double* w, double sign, double* parts) {
+    int64_t n, const double* __restrict__ V, int64_t ld, int nvec,
+    const double* __restrict__ h, double* __restrict__ w, double sign,
+    double* __restrict__ parts) {
   __shared__ double sm[4];
+  __shared__ double hs[256];                 // restart <= 255 (checked by the host)
+  for (int j = threadIdx.x; j < nvec; j += kBlock) hs[j] = sign * h[j];
+  __syncthreads();
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * kBlock) {
     double wi = w[i];
-    for (int j = 0; j < nvec; ++j) wi += sign * h[j] * V[(int64_t)j * ld + i];
+    int j = 0;
+    for (; j + 8 <= nvec; j += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = V[(int64_t)(j + u) * ld + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wi += hs[j + u] * v[u];
+    }
+    for (; j < nvec; ++j) wi += hs[j] * V[(int64_t)j * ld + i];
     w[i] = wi;
     acc += wi * wi;
   }
