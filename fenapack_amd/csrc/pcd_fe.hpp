@@ -290,34 +290,41 @@ __global__ __launch_bounds__(kBlock) void k_fe_scale_sqnorm(
   if (threadIdx.x == 0) parts[blockIdx.x] = s;
 }
 
-// ---- dense inverse of the coarsest scalar operator (Gauss-Jordan with
-// partial pivoting on [F | I], row-major, ld = 2n).  n is ~10^3: the whole
-// elimination is 2n short launches (~10 ms) - it replaces a device->host->
-// device round trip around LAPACK that cost 10x more and was the last host
-// computation of a nonlinear step.
+// ---- dense inverse of the coarsest scalar operator: Gauss-Jordan with
+// partial pivoting on [F | I] (row-major, ld = 2n), rows never physically
+// swapped: step k picks the unused row p with the largest |W[i][k]|, eliminates
+// column k from every other row, and row p becomes row k of the inverse after a
+// final scaling.  ONE launch per step: every workgroup (= one row) first finds
+// the pivot itself from `colcur` (the column's moduli as left by the previous
+// step, -1 for rows already used), so there is no separate pivot kernel and no
+// grid-wide synchronisation.  n ~ 10^3: n short launches (~2 ms) replace a
+// device->host->device round trip around LAPACK that cost 20x more.
 __global__ __launch_bounds__(kBlock) void k_gj_init(
     int n, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, double* W) {
+    const double* __restrict__ val, double* W, double* colcur) {
   const int i = blockIdx.x;
   const int ld = 2 * n;
   for (int j = threadIdx.x; j < ld; j += kBlock) W[(int64_t)i * ld + j] = (j == n + i) ? 1.0 : 0.0;
   __syncthreads();
   for (int k = rowptr[i] + threadIdx.x; k < rowptr[i + 1]; k += kBlock)
     W[(int64_t)i * ld + col[k]] = val[k];
+  __syncthreads();
+  if (threadIdx.x == 0) colcur[i] = fabs(W[(int64_t)i * ld]);
 }
 
-// one workgroup: pivot row of column k (largest modulus, lowest index on
-// ties), swap it into row k, scale row k to a unit pivot
-__global__ __launch_bounds__(kBlock) void k_gj_pivot(int n, int k, double* W,
-                                                      int* singular) {
+__global__ __launch_bounds__(kBlock) void k_gj_step(
+    int n, int k, double* W, const double* __restrict__ colcur, double* colnext,
+    int* pivrow, int* singular) {
   __shared__ double sv[kBlock];
   __shared__ int si[kBlock];
+  const int i = blockIdx.x;
   const int ld = 2 * n;
+  // pivot: largest modulus among the unused rows, lowest index on ties
   double best = -1.0;
-  int bi = k;
-  for (int i = k + threadIdx.x; i < n; i += kBlock) {
-    const double a = fabs(W[(int64_t)i * ld + k]);
-    if (a > best) { best = a; bi = i; }
+  int bi = -1;
+  for (int r = threadIdx.x; r < n; r += kBlock) {
+    const double a = colcur[r];
+    if (a > best) { best = a; bi = r; }
   }
   sv[threadIdx.x] = best; si[threadIdx.x] = bi;
   __syncthreads();
@@ -325,46 +332,46 @@ __global__ __launch_bounds__(kBlock) void k_gj_pivot(int n, int k, double* W,
     if (threadIdx.x < s) {
       const double o = sv[threadIdx.x + s];
       const int oi = si[threadIdx.x + s];
-      if (o > sv[threadIdx.x] || (o == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+      if (o > sv[threadIdx.x] || (o == sv[threadIdx.x] && oi >= 0 && (si[threadIdx.x] < 0 || oi < si[threadIdx.x]))) {
         sv[threadIdx.x] = o; si[threadIdx.x] = oi;
       }
     }
     __syncthreads();
   }
   const int p = si[0];
-  const double piv = W[(int64_t)p * ld + k];
-  if (!(fabs(piv) > 0.0)) { if (threadIdx.x == 0) *singular = 1; return; }
-  __syncthreads();
-  const double inv = 1.0 / piv;
-  for (int j = threadIdx.x; j < ld; j += kBlock) {
-    const double a = W[(int64_t)p * ld + j], b = W[(int64_t)k * ld + j];
-    W[(int64_t)p * ld + j] = b;          // (p == k: plain scaling)
-    W[(int64_t)k * ld + j] = a * inv;
+  if (!(sv[0] > 0.0) || p < 0) { if (i == 0 && threadIdx.x == 0) *singular = 1; return; }
+  const bool used = colcur[i] < 0.0;
+  if (i == p) {                            // the pivot row stays as it is
+    if (threadIdx.x == 0) { pivrow[k] = p; colnext[i] = -1.0; }
+    return;
   }
+  const double f = W[(int64_t)i * ld + k] / W[(int64_t)p * ld + k];
+  __syncthreads();                          // every lane has read f's operands
+  if (f != 0.0) {
+    for (int j = threadIdx.x; j < ld; j += kBlock)
+      if (j != k) W[(int64_t)i * ld + j] -= f * W[(int64_t)p * ld + j];
+    if (threadIdx.x == 0) W[(int64_t)i * ld + k] = 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    colnext[i] = used ? -1.0 : (k + 1 < n ? fabs(W[(int64_t)i * ld + k + 1]) : 0.0);
 }
 
-// row i != k: W[i] -= W[i][k] * W[k]   (one workgroup per row)
-__global__ __launch_bounds__(kBlock) void k_gj_eliminate(int n, int k, double* W) {
-  const int i = blockIdx.x;
-  if (i == k) return;
-  const int ld = 2 * n;
-  const double f = W[(int64_t)i * ld + k];
-  if (f == 0.0) return;
-  __syncthreads();                        // every lane has read f
-  for (int j = threadIdx.x; j < ld; j += kBlock)
-    if (j != k) W[(int64_t)i * ld + j] -= f * W[(int64_t)k * ld + j];
-  if (threadIdx.x == 0) W[(int64_t)i * ld + k] = 0.0;
-}
-
-// dense (d n)^2 row-major out = inv(F) x I_d from the right half of W
+// dense (d n)^2 row-major out = inv(F) x I_d: row k of inv(F) is the right half
+// of the row that served as pivot of column k, divided by that pivot
 __global__ __launch_bounds__(kBlock) void k_gj_store(int n, int d, const double* __restrict__ W,
-                                                      double* out) {
+                                                      const int* __restrict__ pivrow, double* out) {
   const int64_t N = (int64_t)n * d, total = N * N;
   for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * kBlock) {
     const int64_t r = t / N, cidx = t % N;
-    const int i = (int)(r / d), ci = (int)(r % d), j = (int)(cidx / d), cj = (int)(cidx % d);
-    out[t] = ci == cj ? W[(int64_t)i * 2 * n + n + j] : 0.0;
+    const int k = (int)(r / d), ci = (int)(r % d), j = (int)(cidx / d), cj = (int)(cidx % d);
+    double v = 0.0;
+    if (ci == cj) {
+      const int64_t p = pivrow[k];
+      v = W[p * 2 * n + n + j] / W[p * 2 * n + k];
+    }
+    out[t] = v;
   }
 }
 

@@ -45,8 +45,8 @@ struct FeState {
   DBuf<double> kp_const, kp_cells, kp_vals;
   // coarsest level inverted on the device (pattern of its scalar operator)
   int64_t inv_n = 0; bool inv_bound = false;
-  DBuf<int> inv_rowptr, inv_col, inv_flag;
-  DBuf<double> inv_W;
+  DBuf<int> inv_rowptr, inv_col, inv_flag, inv_piv;
+  DBuf<double> inv_W, inv_col0, inv_col1;
   // BRM2 boundary term of Kp (pcd_fe_bind_robin)
   bool robin_bound = false; int64_t rb_nb = 0, rb_naff = 0;
   DBuf<int> rb_nodes, rb_pos, rb_src;
@@ -71,6 +71,7 @@ struct FeState {
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
     ru.release(); y.release(); parts.release(); slot.release();
     inv_rowptr.release(); inv_col.release(); inv_flag.release(); inv_W.release();
+    inv_piv.release(); inv_col0.release(); inv_col1.release();
     rb_nodes.release(); rb_pos.release(); rb_src.release(); rb_ptr.release();
     rb_normal.release(); rb_length.release(); rb_w.release(); rb_loc.release(); rb_tmp.release();
     A01raw.release(); A10raw.release(); bc_idx.release(); bc_mult.release();
@@ -199,13 +200,13 @@ static int fe_invert_coarsest(Engine* h, FeState& fe, MgLevel& M0) {
                 (long long)N, (long long)N);
   HIPCHK(hipMemsetAsync(fe.inv_flag.p, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(k_gj_init, dim3(n), dim3(kBlock), 0, h->stream, n, fe.inv_rowptr.p,
-                     fe.inv_col.p, fe.lev[0].F.p, fe.inv_W.p);
-  for (int k = 0; k < n; ++k) {
-    hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(kBlock), 0, h->stream, n, k, fe.inv_W.p, fe.inv_flag.p);
-    hipLaunchKernelGGL(k_gj_eliminate, dim3(n), dim3(kBlock), 0, h->stream, n, k, fe.inv_W.p);
-  }
+                     fe.inv_col.p, fe.lev[0].F.p, fe.inv_W.p, fe.inv_col0.p);
+  double* cc[2] = {fe.inv_col0.p, fe.inv_col1.p};
+  for (int k = 0; k < n; ++k)
+    hipLaunchKernelGGL(k_gj_step, dim3(n), dim3(kBlock), 0, h->stream, n, k, fe.inv_W.p,
+                       cc[k & 1], cc[(k + 1) & 1], fe.inv_piv.p, fe.inv_flag.p);
   hipLaunchKernelGGL(k_gj_store, dim3(grid1d(N * N, 4, 1 << 16)), dim3(kBlock), 0, h->stream, n, d,
-                     fe.inv_W.p, M0.A.val.p);
+                     fe.inv_W.p, fe.inv_piv.p, M0.A.val.p);
   HIPCHK(hipGetLastError());
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, fe.inv_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -231,7 +232,8 @@ int pcd_fe_bind_coarse_inverse(pcd_handle h, int64_t n0, const int32_t* rowptr,
   CHK(fe_upload(fe.inv_rowptr, rowptr, (size_t)n0 + 1));
   CHK(fe_upload(fe.inv_col, colidx, (size_t)rowptr[n0]));
   CHK(fe.inv_W.ensure((size_t)2 * n0 * n0));
-  CHK(fe.inv_flag.ensure(1));
+  CHK(fe.inv_flag.ensure(1)); CHK(fe.inv_piv.ensure(n0));
+  CHK(fe.inv_col0.ensure(n0)); CHK(fe.inv_col1.ensure(n0));
   fe.inv_bound = true;
   return 0;
 }
