@@ -392,3 +392,20 @@ def test_constant_part_of_kp_can_be_replaced(hip_lib):
     e.fe_set_kp_const(None)
     e.fe_update(xu)
     assert relerr(e.fe_kp_values(patP.nnz), base) < 1e-15
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_tiny_hierarchies(hip_lib, level):
+    """One- and two-level velocity hierarchies (the finest level is, or sits
+    right above, the explicitly inverted one)."""
+    outs = []
+    for fn in (solve_steady, solve_steady_device):
+        pb = Cavity(level, nu=0.02)
+        _options(2, galerkin=True)
+        outs.append(fn(pb, max_newton=6))
+    ref, dev = outs
+    assert dev["producer"].nlev == level
+    assert dev["newton_its"] == ref["newton_its"]
+    for i, j in zip(dev["krylov_per_step"], ref["krylov_per_step"]):
+        assert abs(i - j) <= max(1, 0.05 * j)
+    assert relerr(dev["w"].vector(), ref["w"].vector()) < 1e-6
