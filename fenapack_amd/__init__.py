@@ -18,8 +18,9 @@ from fenapack_amd.preconditioners import (PCDPC_BRM1, PCDPC_BRM2,
                                           PCDRPC_BRM1, PCDRPC_BRM2)
 from fenapack_amd.stabilization import StabilizationParameterSD
 from fenapack_amd.petsc import PETScOptions
+from fenapack_amd.timing import Timer, timed, timings, list_timings
 
 __all__ = ["PCDKSP", "PCDKrylovSolver", "PCDAssembler", "PCDForm",
            "PCDNewtonSolver", "PCDNonlinearProblem", "PCDPC_BRM1",
            "PCDPC_BRM2", "PCDRPC_BRM1", "PCDRPC_BRM2", "StabilizationParameterSD",
-           "PETScOptions"]
+           "PETScOptions", "Timer", "timed", "timings", "list_timings"]

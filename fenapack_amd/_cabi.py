@@ -1,9 +1,9 @@
 """ctypes binding of the C ABI declared in ``include/pcd_engine.h``.
 
-The product binds ``libpcd_hip.so`` (prefix ``pcd_``).  The binding class is
-parameterised by (library, prefix) only so that the test oracle, which exports
-the same signatures under ``pcdo_``, can be driven by the same test code; the
-product never loads anything but the HIP library and raises if it is missing.
+The product binds ``libpcd_hip.so`` (prefix ``pcd_``) and nothing else, and
+raises if it is missing.  (The test oracle exports the same signatures under
+``pcdo_``; the subclass that binds it lives in ``oracle/__init__.py`` - test
+infrastructure - not here.)
 """
 
 import ctypes as C
@@ -125,6 +125,50 @@ def _ptr(a):
     return int(a)
 
 
+def _out(a, n=None, what="output"):
+    """Pointer of an OUTPUT / in-place vector.  The engine writes ``n``
+    doubles through it, so anything but a writeable C-contiguous float64
+    buffer of at least that length would be silent memory corruption."""
+    if isinstance(a, np.ndarray):
+        if a.dtype != np.float64 or not a.flags.c_contiguous \
+                or not a.flags.writeable or a.ndim != 1:
+            raise EngineError("%s vector must be a writeable C-contiguous 1-d "
+                              "float64 array (got %s, contiguous=%s, "
+                              "writeable=%s)" % (what, a.dtype,
+                                                 a.flags.c_contiguous,
+                                                 a.flags.writeable))
+        if n is not None and a.size < n:
+            raise EngineError("%s vector holds %d entries, the engine writes "
+                              "%d" % (what, a.size, n))
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):           # torch tensor
+        import torch
+        if a.dtype != torch.float64 or not a.is_contiguous():
+            raise EngineError("%s tensor must be contiguous float64 (got %s)"
+                              % (what, a.dtype))
+        if n is not None and a.numel() < n:
+            raise EngineError("%s tensor holds %d entries, the engine writes "
+                              "%d" % (what, a.numel(), n))
+        return a.data_ptr()
+    if a is None:
+        raise EngineError("%s vector is None" % what)
+    return int(a)                        # raw pointer: the caller's business
+
+
+def _in(a, mem):
+    """Pointer of an INPUT vector; host arrays are normalised to contiguous
+    float64 (the returned object must be kept alive by the caller)."""
+    if mem == MEM_HOST and not hasattr(a, "data_ptr") \
+            and not isinstance(a, int):
+        a = _f64(a)
+    elif hasattr(a, "data_ptr"):
+        import torch
+        if a.dtype != torch.float64 or not a.is_contiguous():
+            raise EngineError("input tensor must be contiguous float64 "
+                              "(got %s)" % a.dtype)
+    return a
+
+
 def _i32(a):
     a = np.ascontiguousarray(a, dtype=np.int32)
     return a
@@ -135,14 +179,18 @@ def _f64(a):
 
 
 class Library(object):
-    """A loaded shared object exporting ``<prefix>*`` per pcd_engine.h."""
+    """The loaded ``libpcd_hip.so``: every symbol of pcd_engine.h bound."""
 
-    def __init__(self, path, prefix="pcd_", hip=True):
+    prefix = "pcd_"
+    hip = True
+
+    def __init__(self, path):
         if not os.path.exists(path):
             raise EngineError(
                 "%s not found: build it first (python -c 'import "
                 "__graft_entry__ as g; g.build()')" % path)
-        self.path, self.prefix, self.hip = path, prefix, hip
+        self.path = path
+        prefix, hip = self.prefix, self.hip
         self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL if hip else C.DEFAULT_MODE)
         self.fn = {}
         sigs = dict(_SIGNATURES)
@@ -270,28 +318,55 @@ class Engine(object):
                    float(emin), float(emax), mem)
 
     # -- hot path -----------------------------------------------------------
+    # Host-pointer calls carry GLOBAL vectors, so their lengths are known
+    # here and outputs are checked; device-pointer calls of a partitioned
+    # engine carry the rank's slice (length known to the engine only).
+    def _n_p(self, mem):
+        s = self.shapes.get(MAT_AP)
+        return s[0] if (s and mem == MEM_HOST) else None
+
+    def _n_sys(self, mem):
+        n = getattr(self, "n_u", None)
+        return n + self.n_p if (n is not None and mem == MEM_HOST) else None
+
     def apply(self, x, y, mem=MEM_HOST):
-        self._call("apply", _ptr(x), _ptr(y), mem)
+        x = _in(x, mem)
+        self._call("apply", _ptr(x), _out(y, self._n_p(mem), "apply: y"), mem)
 
     def fieldsplit_apply(self, x, y, mem=MEM_HOST):
-        self._call("fieldsplit_apply", _ptr(x), _ptr(y), mem)
+        x = _in(x, mem)
+        self._call("fieldsplit_apply", _ptr(x),
+                   _out(y, self._n_sys(mem), "fieldsplit_apply: y"), mem)
 
     def gmres_solve(self, b, x, mem=MEM_HOST, rtol=1e-6, atol=0.0,
                     restart=150, max_it=10000):
         its, rn = C.c_int(0), C.c_double(0.0)
-        self._call("gmres_solve", _ptr(b), _ptr(x), mem, float(rtol),
-                   float(atol), int(restart), int(max_it), C.byref(its),
-                   C.byref(rn))
+        b = _in(b, mem)
+        self._call("gmres_solve", _ptr(b),
+                   _out(x, self._n_sys(mem), "gmres_solve: x"), mem,
+                   float(rtol), float(atol), int(restart), int(max_it),
+                   C.byref(its), C.byref(rn))
         return its.value, rn.value
 
     def spmv(self, which, x, y, mem=MEM_HOST):
-        self._call("spmv", which, _ptr(x), _ptr(y), mem)
+        x = _in(x, mem)
+        s = self.shapes.get(which)
+        n = s[0] if (s and mem == MEM_HOST) else None
+        if which == MAT_A:
+            n = self._n_sys(mem)
+        elif which in (MAT_A00, MAT_A01) and mem == MEM_HOST:
+            n = getattr(self, "n_u", n)
+        self._call("spmv", which, _ptr(x), _out(y, n, "spmv: y"), mem)
 
     def inner_solve(self, slot, b, x, mem=MEM_HOST):
-        self._call("inner_solve", slot, _ptr(b), _ptr(x), mem)
+        b = _in(b, mem)
+        n = self._n_p(mem) if slot != KSP_A00 else (
+            getattr(self, "n_u", None) if mem == MEM_HOST else None)
+        self._call("inner_solve", slot, _ptr(b),
+                   _out(x, n, "inner_solve: x"), mem)
 
     def apply_bc(self, x, mem=MEM_HOST):
-        self._call("apply_bc", _ptr(x), mem)
+        self._call("apply_bc", _out(x, self._n_p(mem), "apply_bc: x"), mem)
 
     def info(self, key):
         out = C.c_double(0.0)
@@ -418,7 +493,8 @@ class Engine(object):
         n_it, conv = C.c_int(0), C.c_int(0)
         lin = np.zeros(max(max_it, 1), dtype=np.int32)
         res = np.zeros(max_it + 1)
-        self._call("fe_picard_solve", _ptr(x), mem, float(r0), float(rtol),
+        self._call("fe_picard_solve",
+                   _out(x, self._n_sys(mem), "fe_picard_solve: x"), mem, float(r0), float(rtol),
                    float(atol), int(max_it), float(relax), float(lin_rtol),
                    float(lin_atol), int(restart), int(lin_max_it),
                    C.byref(n_it), _ptr(lin), _ptr(res), C.byref(conv))
@@ -538,5 +614,5 @@ def hip_library():
     """The product library.  Fails loudly when it has not been built."""
     global _hip_library
     if _hip_library is None:
-        _hip_library = Library(HIP_LIBRARY_PATH, "pcd_", hip=True)
+        _hip_library = Library(HIP_LIBRARY_PATH)
     return _hip_library

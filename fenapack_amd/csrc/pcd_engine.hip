@@ -80,6 +80,7 @@ struct DCsr {
   // multi-component structure A = F (x) I_kron (kron = 2, 3; 0: none): F
   // stored once
   int kron = 0;
+  int kron_pat = 0;       // components the PATTERN admits (kron: values agree too)
   int rb2 = 0;
   int64_t nnz2 = 0;
   DBuf<int> rowptr2, col2, kron_pos;
@@ -96,7 +97,7 @@ struct DCsr {
     rowptr.release(); col.release(); val.release(); dinv.release();
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); kron_pos.release();
-    val2.release(); kron_flag.release(); kron = 0; rb2 = 0; nnz2 = 0;
+    val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
     plan = HaloPlan(); replicated = false;
     set = false; nrows = ncols = nnz = 0; has_src = false;
   }
@@ -1007,15 +1008,19 @@ static bool g_no_kron = false;         // PCD_NO_KRON2=1: A/B switch
 // After new values arrived: refresh F's values and verify that all
 // components still carry the same numbers; otherwise drop to the general path.
 static int refresh_kron(Engine* h, DCsr& A) {
-  if (!A.kron || !A.nnz2) return 0;
+  if (!A.kron_pat || !A.nnz2) return 0;
   HIPCHK(hipMemsetAsync(A.kron_flag.p, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(k_kron_gather, dim3(grid1d(A.nnz2, 4)), dim3(kBlock), 0,
-                     h->stream, (int)A.nnz2, A.kron, A.kron_pos.p, A.val.p,
+                     h->stream, (int)A.nnz2, A.kron_pat, A.kron_pos.p, A.val.p,
                      A.val2.p, A.kron_flag.p);
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, A.kron_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (flag) A.kron = 0;                  // values differ between components
+  // values differ between components: general path - until a later refresh
+  // brings equal components back.  Either way the set of kernels a PCApply
+  // launches changes, so a captured graph is stale.
+  const int now = flag ? 0 : A.kron_pat;
+  if (now != A.kron) { A.kron = now; ++h->gen; }
   return 0;
 }
 
@@ -1039,7 +1044,7 @@ static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* ro
 // detect the structure (the velocity block size first) + compressed arrays
 static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
                        const int32_t* rowptr, const int32_t* col, bool have_vals) {
-  A.kron = 0; A.rb2 = 0; A.nnz2 = 0;
+  A.kron = 0; A.kron_pat = 0; A.rb2 = 0; A.nnz2 = 0;
   if (g_no_kron || rowptr[nrows] == 0) return 0;
   int nc = 0;
   const int first = h->vel_block == 3 ? 3 : 2;
@@ -1067,7 +1072,7 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   for (int c = 0; c < nc; ++c)
     HIPCHK(hipMemcpy(A.kron_pos.p + c * A.nnz2, pos[c].data(), A.nnz2 * sizeof(int),
                      hipMemcpyHostToDevice));
-  A.kron = nc; A.rb2 = rb2;
+  A.kron = A.kron_pat = nc; A.rb2 = rb2;
   if (have_vals) CHK(refresh_kron(h, A));
   return 0;
 }
@@ -1287,6 +1292,8 @@ int pcd_update_values(pcd_handle h, int which, const double* vals, int mem) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (which < 0 || which >= PCD_MAT_A || !h->mat[which].set)
     return fail(PCD_ERR_STATE, "update_values: operator %d not set", which);
+  if (!vals) return fail(PCD_ERR_ARG, "update_values: null vals");
+  if (mem != PCD_MEM_HOST && mem != PCD_MEM_DEVICE) return fail(PCD_ERR_ARG, "update_values: bad mem flag %d", mem);
   DCsr& A = h->mat[which];
   CHK(refresh_values(h, A, vals, mem));
   CHK(refresh_dinv(h, A));
@@ -1787,6 +1794,11 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
         hc[j] = t;
       }
       const double d = std::hypot(hc[k], hc[k + 1]);
+      // a zero (or non-finite) column: A M^-1 v_k lies in the span already
+      // searched with a vanishing component along v_k - the least-squares
+      // problem is singular, not a lucky breakdown
+      if (!(d > 0.0) || !std::isfinite(d))
+        return fail(PCD_ERR_BREAKDOWN, "gmres: singular Hessenberg column at iteration %d (|h| = %g)", it, d);
       cs[k] = hc[k] / d; sn[k] = hc[k + 1] / d;
       hc[k] = d; hc[k + 1] = 0.0;
       gvec[k + 1] = -sn[k] * gvec[k]; gvec[k] = cs[k] * gvec[k];

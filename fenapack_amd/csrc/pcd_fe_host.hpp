@@ -761,7 +761,8 @@ int pcd_fe_picard_solve(pcd_handle h, double* x, int mem, double r0, double rtol
   CHK(fe_residual_dev(h, fe, xd, fe.bd.p, &r));
   if (res_hist) res_hist[0] = r;
   if (!(r0 > 0.0)) r0 = r;
-  bool conv = r < atol || (r0 > 0.0 && r / r0 < rtol);
+  // a zero first residual (r0 == 0) is a solved problem, not 0/0
+  bool conv = r < atol || r == 0.0 || (r0 > 0.0 && r / r0 < rtol);
   while (!conv && it < max_it) {
     HIPCHK(hipMemsetAsync(fe.dxd.p, 0, n * sizeof(double), h->stream));
     int its = 0; double rn = 0.0;
@@ -771,7 +772,9 @@ int pcd_fe_picard_solve(pcd_handle h, double* x, int mem, double r0, double rtol
     ++it;
     CHK(fe_residual_dev(h, fe, xd, fe.bd.p, &r));
     res_hist[it] = r;
-    conv = r < atol || r / r0 < rtol;
+    if (!std::isfinite(r))
+      return fail(PCD_ERR_BREAKDOWN, "fe_picard_solve: non-finite residual norm after step %d", it);
+    conv = r < atol || r == 0.0 || r / r0 < rtol;
   }
   if (mem == PCD_MEM_HOST)
     HIPCHK(hipMemcpyAsync(x, xd, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -20,6 +20,7 @@ from . import _cabi as c
 from .field_split_backend import PCDInterface
 from .petsc import KSP, PC, IS, Mat, Options
 from .preconditioners import PCDPC_BRM1, PCD_CLASSES
+from .timing import Timer
 from .utils import allow_only_one_call
 
 
@@ -54,7 +55,10 @@ class PCDKSP(KSP):
         self.pc.setFieldSplitIS(["u", is0], ["p", is1])
         # from now on the options prefix is frozen (PETSc issue #160)
         self.setOptionsPrefix = self._forbid_setOptionsPrefix
-        self.pc.setUp()
+        # timer names of field_split.py:89,104,143
+        with Timer("FENaPack: PCDKSP PC {} setup".format(
+                self.pc.getOptionsPrefix() or "")):
+            self.pc.setUp()
         ksp0, ksp1 = self.pc.getFieldSplitSubKSP()
         # device-native defaults (see module docstring)
         ksp0.setType(KSP.Type.CHEBYSHEV)
@@ -90,14 +94,15 @@ class PCDKSP(KSP):
             self.engine.comm_init(self.comm.rank, self.comm.size,
                                   self.comm.unique_id())
         A, P = self.getOperators()
-        self._upload_system(A, P, is0, is1, first=True)
-        ksp0.setOperators(Mat(self._A00_host(A, P, is0)))
-        ksp0.bind(self.engine, c.KSP_A00)
-        if ksp0.pc.type == "mg" and ksp0.pc._mg_chain is None:
-            ksp0.pc.setMGInterpolations(V.interpolations().chain("u"))
-            if not ksp0.pc.mg_galerkin and ksp0.pc._mg_ops_cb is None:
-                ksp0.pc.setMGOperators(V.coarse_velocity_operators)
-        ksp0.setUp()
+        with Timer("FENaPack: {} setup".format(ksp0.getOptionsPrefix() or "")):
+            self._upload_system(A, P, is0, is1, first=True)
+            ksp0.setOperators(Mat(self._A00_host(A, P, is0)))
+            ksp0.bind(self.engine, c.KSP_A00)
+            if ksp0.pc.type == "mg" and ksp0.pc._mg_chain is None:
+                ksp0.pc.setMGInterpolations(V.interpolations().chain("u"))
+                if not ksp0.pc.mg_galerkin and ksp0.pc._mg_ops_cb is None:
+                    ksp0.pc.setMGOperators(V.coarse_velocity_operators)
+            ksp0.setUp()
 
         ksp1.pc.setPythonContext(pcd_pc)
         ksp1.setFromOptions()
@@ -110,7 +115,8 @@ class PCDKSP(KSP):
             print("Initialization of PCD PC from PCDAssembler failed!")
             print("Maybe wrong PCD PC class or PCDAssembler instance.")
             raise
-        ksp1.pc.setUp()
+        with Timer("FENaPack: {} setup".format(pcd_pc_prefix or "")):
+            ksp1.pc.setUp()
         self._is = (is0, is1)
 
     def _forbid_setOptionsPrefix(self, prefix):

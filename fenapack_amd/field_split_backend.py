@@ -10,6 +10,7 @@ import numpy as np
 from . import _cabi as c
 from .assembling import PCDAssembler
 from .petsc import Mat, DeviceMat, IS, Vec
+from .timing import Timer
 
 
 class SubfieldBC(object):
@@ -122,7 +123,9 @@ class PCDInterface(object):
             ksp.setOperators(mat, mat)
             ksp.bind(self.engine, c.KSP_RP)
             self._give_interpolations(ksp)
-            ksp.setUp()
+            with Timer("FENaPack: {} setup".format(
+                    ksp.getOptionsPrefix() or "")):      # :138
+                ksp.setUp()
 
     def _build_approx_Ap(self, Mu, Bt, mat=None):
         """``R_p = B diag(Mu)^-1 B^T`` built exactly like
@@ -175,12 +178,16 @@ class PCDInterface(object):
             ksp.setOperators(mat, mat)
             ksp.bind(self.engine, slot)
             self._give_interpolations(ksp)
-            ksp.setUp()
+            with Timer("FENaPack: {} setup".format(
+                    ksp.getOptionsPrefix() or "")):      # :254
+                ksp.setUp()
         elif not const:
             work = Mat()
             assemble_func(work)
             mat.update(self._get_deep_submat(work, iset).A)
-            ksp.setUp()
+            with Timer("FENaPack: {} setup".format(
+                    ksp.getOptionsPrefix() or "")):      # :262
+                ksp.setUp()
 
     def _assemble_operator_deep(self, assemble_func, isrow, iscol=None,
                                 submat=None, which=None):

@@ -75,7 +75,8 @@ class PCDNewtonSolver(object):
         problem.F(b, x)
         r0 = r = float(np.linalg.norm(b))
         self.residual_history.append(r)
-        it, converged = 0, r < prm["absolute_tolerance"]
+        # a zero first residual is a solved problem (never 0/0 below)
+        it, converged = 0, (r < prm["absolute_tolerance"] or r == 0.0)
         while not converged and it < prm["maximum_iterations"]:
             problem.J(self._A, x)
             problem.J_pc(self._P, x)
@@ -93,9 +94,10 @@ class PCDNewtonSolver(object):
             problem.F(b, x)
             r = float(np.linalg.norm(b))
             self.residual_history.append(r)
-            converged = (r < prm["absolute_tolerance"]
+            converged = (r < prm["absolute_tolerance"] or r == 0.0
                          or r / r0 < prm["relative_tolerance"])
         if not converged and prm["error_on_nonconvergence"]:
             raise RuntimeError("Newton solver did not converge: |r|/|r0| = "
-                               "%g after %d iterations" % (r / r0, it))
+                               "%g after %d iterations"
+                               % (r / r0 if r0 else float("inf"), it))
         return it, converged

@@ -13,6 +13,13 @@ the same option names, e.g. ``-..._PCD_Mp_ksp_type chebyshev``).
 
 from . import _cabi as c
 from .petsc import KSP, PC
+from .timing import timed
+
+
+def _dev(v):
+    """Device buffer behind a vector argument of ``apply``."""
+    t = getattr(v, "t", None)
+    return v if t is None else t
 
 
 class BasePCDPC(object):
@@ -77,8 +84,12 @@ class BasePCDPC(object):
         self.interface.engine.setup()
 
     def apply(self, pc, x, y):
-        """``y = -S^-1 x``: the fused HIP path (x borrowed, y overwritten)."""
-        self.interface.engine.apply(x.t, y.t, c.MEM_DEVICE)
+        """``y = -S^-1 x``: the fused HIP path (x borrowed, y overwritten).
+        ``x`` / ``y``: the package's device ``Vec`` (``.t`` = torch tensor), a
+        torch tensor, or anything exposing the device pointer the way a
+        petsc4py ``Vec`` of type ``hip`` does (``getCUDAHandle``-style: see
+        INTEGRATION.md)."""
+        self.interface.engine.apply(_dev(x), _dev(y), c.MEM_DEVICE)
 
     def apply_by_parts(self, pc, x, y):
         """Testing aid: the same operator assembled from per-operation ABI
@@ -114,6 +125,9 @@ class PCDPC_BRM1(BasePCDPC):
     (``fenapack/preconditioners.py:89-135``)."""
     variant = "BRM1"
 
+    @timed("FENaPack: PCDPC_BRM1 apply")
+    def apply(self, pc, x, y):
+        return BasePCDPC.apply(self, pc, x, y)
 
 
 class PCDPC_BRM2(BasePCDPC):
@@ -121,6 +135,9 @@ class PCDPC_BRM2(BasePCDPC):
     (``fenapack/preconditioners.py:139-169``)."""
     variant = "BRM2"
 
+    @timed("FENaPack: PCDPC_BRM2 apply")
+    def apply(self, pc, x, y):
+        return BasePCDPC.apply(self, pc, x, y)
 
 
 class BasePCDRPC(BasePCDPC):
@@ -161,6 +178,9 @@ class PCDRPC_BRM1(BasePCDRPC):
     (``fenapack/preconditioners.py:211-252``)."""
     variant = "RBRM1"
 
+    @timed("FENaPack: PCDRPC_BRM1 apply")
+    def apply(self, pc, x, y):
+        return BasePCDRPC.apply(self, pc, x, y)
 
 
 class PCDRPC_BRM2(BasePCDRPC):
@@ -168,6 +188,9 @@ class PCDRPC_BRM2(BasePCDRPC):
     (``fenapack/preconditioners.py:256-298``)."""
     variant = "RBRM2"
 
+    @timed("FENaPack: PCDRPC_BRM2 apply")
+    def apply(self, pc, x, y):
+        return BasePCDRPC.apply(self, pc, x, y)
 
 
 PCD_CLASSES = {"PCDPC_BRM1": PCDPC_BRM1, "PCDPC_BRM2": PCDPC_BRM2,

@@ -19,11 +19,12 @@ class _DeltaSD(object):
         self.nu, self.rho = float(viscosity), float(density)
 
     def cell_values(self):
-        """delta per cell for the current wind (nodal P2 velocity (nn, 2), or
-        a ``Function`` whose velocity part is used)."""
+        """delta per cell for the current wind (nodal P2 velocity (nn, dim),
+        or a ``Function`` whose velocity part is used)."""
         w = self.wind
-        U = w.split()[0].reshape(-1, 2) if hasattr(w, "split") \
-            else np.asarray(w).reshape(-1, 2)
+        d = self.V.dim
+        U = w.split()[0].reshape(-1, d) if hasattr(w, "split") \
+            else np.asarray(w).reshape(-1, d)
         return self.V.supg_delta(U, self.nu, self.rho)
 
     __call__ = cell_values

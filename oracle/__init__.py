@@ -30,14 +30,26 @@ def build(force=False):
     return ORACLE_LIBRARY_PATH
 
 
+def _oracle_library_class():
+    """The product binding (``fenapack_amd._cabi.Library``) binds the HIP
+    library only; the oracle exports the common part of the same ABI under
+    the prefix ``pcdo_``, so that one test body can drive both.  The switch
+    lives HERE, in test infrastructure."""
+    from fenapack_amd._cabi import Library
+
+    class OracleLibrary(Library):
+        prefix = "pcdo_"
+        hip = False                      # no pcd_fe_* / comm / graph symbols
+    return OracleLibrary
+
+
 def library():
     """PCD_ORACLE_LIB overrides the path (e.g. the -fsanitize build made by
     ``make -C oracle asan``)."""
     global _library
     if _library is None:
-        from fenapack_amd._cabi import Library
         path = os.environ.get("PCD_ORACLE_LIB") or build()
-        _library = Library(path, "pcdo_", hip=False)
+        _library = _oracle_library_class()(path)
     return _library
 
 
@@ -55,9 +67,9 @@ def omp_engine(variant="BRM1", threads=None):
     bench.py's cpu_baseline only, never for parity.  Returns (engine,
     threads in effect)."""
     import ctypes
-    from fenapack_amd._cabi import Engine as _Engine, Library
+    from fenapack_amd._cabi import Engine as _Engine
     build()
-    lib = Library(OMP_LIBRARY_PATH, "pcdo_", hip=False)
+    lib = _oracle_library_class()(OMP_LIBRARY_PATH)
     f = lib.lib.pcdo_set_threads
     f.argtypes, f.restype = [ctypes.c_int], ctypes.c_int
     n = f(int(threads or 0))

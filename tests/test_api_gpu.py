@@ -104,8 +104,23 @@ def test_steady_solve_same_krylov_counts_as_cpu_restatement(monkeypatch):
                                        cpu["krylov_per_step"])]
     assert max(diff) <= 1, (gpu["krylov_per_step"], cpu["krylov_per_step"])
     assert relerr(gpu["w"].vector(), cpu["w"].vector()) < 1e-6
-    # outlet flux equals inlet flux (2/3) for the converged solution
-    V = mk().space
+    # outlet flux equals inlet flux for the converged solution: q = 1 is a
+    # P1 test function, so the discrete continuity equation balances the two
+    # to solver accuracy; the inflow 4y(1-y) is a P2 function, its flux is
+    # integrated exactly by Simpson's rule on every edge: 2/3
+    pb = mk()
+    V = pb.space
+    for run in (gpu, cpu):
+        U = run["w"].split()[0].reshape(-1, 2)
+        flux = {}
+        for name, edges in (("in", pb.inlet_edges), ("out", pb.outlet_edges)):
+            pl = V.robin_plan(edges)
+            nodes = pl["nodes"]
+            wmean = (U[nodes[:, 0]] + U[nodes[:, 1]] + 4.0 * U[nodes[:, 2]]) / 6.0
+            flux[name] = float(((wmean * pl["normal"]).sum(axis=1)
+                                * pl["length"]).sum())
+        assert abs(flux["in"] + 2.0 / 3.0) < 1e-12, flux     # outward normal
+        assert abs(flux["out"] - 2.0 / 3.0) < 1e-4, flux
 
 
 def test_cavity_steady_converges():

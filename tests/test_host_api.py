@@ -162,3 +162,103 @@ def test_krylov_solver_requires_the_hip_library(monkeypatch, tmp_path):
     s.set_operators(A, A)
     with pytest.raises(_cabi.EngineError):
         s.init_pcd(a)                       # no silent CPU fallback
+
+
+def test_pcd_context_guards_and_timers():
+    # preconditioners.py:59-60 (work-vec count is frozen) and :66-67
+    # (re-initialisation); timer names of preconditioners.py:98,148,219,264
+    from fenapack_amd import (PCDPC_BRM1, PCDPC_BRM2, PCDRPC_BRM1,
+                              PCDRPC_BRM2, timings, list_timings)
+
+    class FakeVec(object):
+        def duplicate(self):
+            return FakeVec()
+
+    for cls in (PCDPC_BRM1, PCDPC_BRM2, PCDRPC_BRM1, PCDRPC_BRM2):
+        ctx = cls()
+        v = FakeVec()
+        w1 = ctx.get_work_vecs(v, 2)
+        assert len(w1) == 2 and ctx.get_work_vecs(v, 2) is w1    # cached
+        with pytest.raises(ValueError, match="Changing number of work vecs"):
+            ctx.get_work_vecs(v, 1)
+        marker = object()
+        ctx.init_pcd(marker)
+        assert ctx.interface is marker
+        with pytest.raises(RuntimeError, match="Reinitialization"):
+            ctx.init_pcd(marker)
+
+    class FakeEngine(object):
+        calls = 0
+
+        def apply(self, x, y, mem):
+            FakeEngine.calls += 1
+
+    class FakeInterface(object):
+        engine = FakeEngine()
+
+    timings(clear=True)
+    for cls in (PCDPC_BRM1, PCDPC_BRM2, PCDRPC_BRM1, PCDRPC_BRM2):
+        ctx = cls()
+        ctx.init_pcd(FakeInterface())
+        ctx.apply(None, 1, 2)
+        ctx.apply(None, 1, 2)
+    t = timings()
+    for cls in ("PCDPC_BRM1", "PCDPC_BRM2", "PCDRPC_BRM1", "PCDRPC_BRM2"):
+        assert t["FENaPack: %s apply" % cls][0] == 2
+    assert FakeEngine.calls == 8
+    assert "FENaPack: PCDPC_BRM1 apply" in list_timings(file=open("/dev/null", "w"))
+
+
+def test_setup_timers_carry_the_reference_names():
+    # field_split.py:89 - the one set-up that needs no engine
+    from fenapack_amd import timings
+    timings(clear=True)
+    ksp = PCDKSP()
+    ksp.setOptionsPrefix("foo_")
+
+    class A(object):
+        def function_space(self):
+            class V(object):
+                is_u, is_p = [0, 1], [2]
+            return V()
+    with pytest.raises(Exception):
+        ksp.init_pcd(A())          # dies at the engine; the PC was set up
+    assert "FENaPack: PCDKSP PC foo_ setup" in timings()
+
+
+def test_output_vectors_are_validated_before_the_engine_writes():
+    from fenapack_amd import _cabi
+    ok = np.zeros(5)
+    assert _cabi._out(ok, 5) == ok.ctypes.data
+    for bad in (np.zeros(5, dtype=np.float32), np.zeros(10)[::2],
+                np.zeros((5, 1))):
+        with pytest.raises(_cabi.EngineError):
+            _cabi._out(bad, 5)
+    with pytest.raises(_cabi.EngineError, match="holds 4 entries"):
+        _cabi._out(np.zeros(4), 5)
+    ro = np.zeros(5)
+    ro.setflags(write=False)
+    with pytest.raises(_cabi.EngineError):
+        _cabi._out(ro, 5)
+    with pytest.raises(_cabi.EngineError):
+        _cabi._out(None, 5)
+
+
+def test_stabilization_parameter_in_three_dimensions():
+    # the public wrapper must shape the nodal wind by the space dimension
+    from fenapack_amd import StabilizationParameterSD
+    from fenapack_amd.fem import Cavity3D
+    pb = Cavity3D(0, nu=1e-3, n0=2)
+    V = pb.space
+    U = np.random.default_rng(3).standard_normal((V.n_u // 3, 3))
+
+    class Wind(object):                       # nodal velocity array + space
+        def __init__(self):
+            self.V = V
+
+        def __array__(self, *args, **kwargs):
+            return U.ravel()
+    delta = StabilizationParameterSD(Wind(), 1e-3)()
+    ref = V.supg_delta(U, 1e-3, 1.0)
+    assert delta.shape == ref.shape and np.array_equal(delta, ref)
+    assert (delta > 0).any()
