@@ -58,11 +58,125 @@ def parse():
     p.add_argument("--no-producer", action="store_true",
                    help="skip the end-to-end Picard-step timing at the end")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--dist-backend", default=None,
+                   help="torch.distributed backend of the bootstrap group "
+                        "(default: nccl = RCCL on a GPU box, gloo without)")
+    p.add_argument("--stub-step", action="store_true",
+                   help="TEST ONLY: replace the engine workload by a no-op "
+                        "step so that the launch / barrier / max-over-ranks "
+                        "/ one-JSON-line path runs on a box without N GPUs")
     return p.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without an external launcher: start one
+    child process per GPU (the reference's ``mpirun -np N`` over the same
+    script, test/regression/test.py:186-195) and wait for them.
+
+    This parent never imports torch and never touches the GPU: the children
+    are started BEFORE any HIP call exists in this process tree, and nothing
+    is exec'ed from a process that has initialised the GPU.  Rank 0 inherits
+    this process's stdout (the one JSON line); the other ranks' stdout goes
+    to stderr.  Any child failing ends the others (by PID) and the launcher
+    exits non-zero."""
+    import signal
+    import subprocess
+    n = args.gpus
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(
+            cmd, env=e, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with %d; "
+                                     "stopping the other ranks\n" % (r, code))
+                    for q in alive:
+                        procs[q].send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def timed_steps(step, sync, args, dist, world, device):
+    """The contract's timed region: W untimed warm-up steps, then EXACTLY K
+    steps bracketed by barrier + device synchronise on both sides; the MAX
+    over ranks is the job's time."""
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def stub_main(args, json_out, rank, world):
+    """--stub-step: everything of a multi-rank run except the GPU work."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.dist_backend or "gloo")
+    dt = timed_steps(lambda: None, lambda: None, args, dist, world, "cpu")
+    if rank == 0:
+        json_out.write(json.dumps({
+            "metric": "stub (launch path only)", "value": args.steps / dt,
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "none",
+            "config": {"workload": "stub", "parallelism":
+                       "row partition x%d" % world}}) + "\n")
+        json_out.flush()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner
     # through C stdio on file descriptor 1 when a communicator is created
     # (flushed at exit, i.e. after our line), so keep a private handle on the
@@ -70,17 +184,26 @@ def main():
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (start it as `python "
+                         "bench.py --gpus N`, or through torch.distributed."
+                         "run with --nproc-per-node N)" % (args.gpus, world))
+    if args.stub_step:
+        return stub_main(args, json_out, rank, world)
+    import torch
+    import torch.distributed as dist
+    if torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but this node shows %d GPU(s): one "
+                         "process drives one GPU (RCCL refuses two ranks on "
+                         "one device)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group(args.dist_backend or "nccl",
+                                device_id=torch.device("cuda", local))
 
     from fenapack_amd import PETScOptions
     from fenapack_amd import _cabi as c
@@ -193,24 +316,7 @@ def main():
     def step():
         eng.fieldsplit_apply(x.t, y.t, c.MEM_DEVICE)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = timed_steps(step, torch.cuda.synchronize, args, dist, world, "cuda")
 
     # SURVEY 8(d) extras, outside the timed region, rank-local:
     #  * per-call latency distribution (each call synchronised: includes the
@@ -458,35 +564,9 @@ def cpu_baseline(args, pb, ksp, eng, c, x):
     build).  ``value`` is the faster of the two.  A reported baseline, not the
     target; "CPU restatement, not PETSc" (BASELINE.md 3)."""
     import oracle
-    V = pb.space
-    ksp0, ksp1 = ksp.pc.getFieldSplitSubKSP()
-    pcd = ksp1.pc.getPythonContext()
-    A, P = ksp.getOperators()
 
     def configure(o):
-        o.set_csr(c.MAT_AP, pcd.ksp_Ap.getOperators()[0].A)
-        o.set_csr(c.MAT_MP, pcd.ksp_Mp.getOperators()[0].A)
-        o.set_csr(c.MAT_KP, pcd.mat_Kp.A)
-        o.set_bc(pb.bc_p_idx, pb.bc_p_val)
-        o.set_system(A.A, V.is_u, V.is_p, None if P is A else P.A)
-        for k, slot in ((ksp0, c.KSP_A00), (pcd.ksp_Ap, c.KSP_AP),
-                        (pcd.ksp_Mp, c.KSP_MP)):
-            if k.pc.type == "mg":
-                d = k.pc.mg_data
-                L = len(d["ops"])
-                o.mg_begin(slot, L, d["nu"], d["nu"])
-                o.mg_set_level(slot, 0, d["C"])
-                for l in range(1, L):
-                    o.mg_set_level(slot, l,
-                                   d["ops"][l] if l < L - 1 else None,
-                                   d["chain"][l], *d["bounds"][l])
-                o.set_inner(slot, k.type, "mg", k.max_it, 0.0)
-            else:
-                lo, hi = (k._chebyshev_bounds() if k.type == "chebyshev"
-                          else (0.5, 2.0))
-                o.set_inner(slot, k.type, "jacobi", k.max_it,
-                            k.rtol if k.type == "cg" else 0.0, lo, hi)
-        o.setup()
+        oracle.mirror(o, pb, ksp)
 
     xh = x.getArray()
 

@@ -76,3 +76,46 @@ def omp_engine(variant="BRM1", threads=None):
     eng = _Engine(lib, variant, 0)
     eng.set_threads = lambda k: f(int(k))
     return eng, n
+
+
+def mirror(o, pb, ksp):
+    """Configure the oracle engine ``o`` with exactly what the Python stack
+    handed to the HIP engine behind ``ksp`` (a set-up ``PCDKSP``): the three
+    (four) pressure operators, the subfield BC, the system with its index
+    sets (and the preconditioner matrix when it differs), every inner solver
+    with its multigrid hierarchy and smoother bounds.  Used by the full-size
+    parity tests and by bench.py's cpu_baseline leg - the checker sees the
+    same inputs as the product, at the sizes the product runs."""
+    from fenapack_amd import _cabi as c
+    V = pb.space
+    ksp0, ksp1 = ksp.pc.getFieldSplitSubKSP()
+    pcd = ksp1.pc.getPythonContext()
+    A, P = ksp.getOperators()
+    o.set_velocity_block(V.dim)
+    o.set_csr(c.MAT_AP, pcd.ksp_Ap.getOperators()[0].A)
+    o.set_csr(c.MAT_MP, pcd.ksp_Mp.getOperators()[0].A)
+    o.set_csr(c.MAT_KP, pcd.mat_Kp.A)
+    slots = [(ksp0, c.KSP_A00), (pcd.ksp_Ap, c.KSP_AP), (pcd.ksp_Mp, c.KSP_MP)]
+    if hasattr(pcd, "ksp_Rp"):
+        o.set_csr(c.MAT_RP, pcd.ksp_Rp.getOperators()[0].A)
+        slots.append((pcd.ksp_Rp, c.KSP_RP))
+    o.set_bc(pb.bc_p_idx, pb.bc_p_val)
+    pmat = None if (P is None or P is A or not P.isAssembled()) else P.A
+    o.set_system(A.A, V.is_u, V.is_p, pmat)
+    for k, slot in slots:
+        if k.pc.type == "mg":
+            d = k.pc.mg_data
+            L = len(d["ops"])
+            o.mg_begin(slot, L, d["nu"], d["nu"])
+            o.mg_set_level(slot, 0, d["C"])
+            for l in range(1, L):
+                o.mg_set_level(slot, l, d["ops"][l] if l < L - 1 else None,
+                               d["chain"][l], *d["bounds"][l])
+            o.set_inner(slot, k.type, "mg", k.max_it, 0.0)
+        else:
+            lo, hi = (k._chebyshev_bounds() if k.type == "chebyshev"
+                      else (0.5, 2.0))
+            o.set_inner(slot, k.type, "jacobi", k.max_it,
+                        k.rtol if k.type == "cg" else 0.0, lo, hi)
+    o.setup()
+    return o
