@@ -16,7 +16,7 @@ BRM1, BRM2, RBRM1, RBRM2 = 1, 2, 3, 4
 MAT_AP, MAT_MP, MAT_KP, MAT_RP, MAT_A00, MAT_A01, MAT_A = range(7)
 KSP_AP, KSP_MP, KSP_RP, KSP_A00 = range(4)
 PREONLY, RICHARDSON, CHEBYSHEV, CG = range(4)
-PC_NONE, PC_JACOBI, PC_MG = 0, 1, 2
+PC_NONE, PC_JACOBI, PC_MG, PC_EXPLICIT = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
     INFO_NUM_PCD_APPLY, INFO_NUM_FS_APPLY, INFO_GMRES_ITS, \
@@ -26,7 +26,8 @@ INFO_NNZ_BASE = 16
 
 KSP_TYPES = {"preonly": PREONLY, "richardson": RICHARDSON,
              "chebyshev": CHEBYSHEV, "cg": CG}
-PC_TYPES = {"none": PC_NONE, "jacobi": PC_JACOBI, "mg": PC_MG}
+PC_TYPES = {"none": PC_NONE, "jacobi": PC_JACOBI, "mg": PC_MG,
+            "explicit": PC_EXPLICIT}
 VARIANTS = {"BRM1": BRM1, "BRM2": BRM2, "RBRM1": RBRM1, "RBRM2": RBRM2}
 
 _i32p = C.POINTER(C.c_int32)
@@ -68,6 +69,12 @@ _HIP_ONLY = {
     "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "graph_enable": [C.c_int],
     "set_velocity_block": [C.c_int],
+    # pre-composed inner solves
+    "mg_set_fused": [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                     C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                     C.c_void_p, C.c_void_p],
+    "set_inner_factor": [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                         C.c_void_p, C.c_void_p],
     # device operator producer
     "fe_begin": [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                  C.c_void_p, C.c_void_p],
@@ -317,6 +324,26 @@ class Engine(object):
         self._call("mg_update_values", slot, int(level), _ptr(vals),
                    float(emin), float(emax), mem)
 
+    def mg_set_fused(self, slot, level, Wd=None, Wu=None):
+        """Pre-composed form of one level (``compose.vcycle_level``); ``None``
+        drops it."""
+        if Wd is None:
+            self._call("mg_set_fused", slot, int(level), 0, 0, None, None,
+                       None, 0, 0, None, None, None)
+            return
+        a = (_i32(Wd.indptr), _i32(Wd.indices), _f64(Wd.data))
+        b = (_i32(Wu.indptr), _i32(Wu.indices), _f64(Wu.data))
+        self._call("mg_set_fused", slot, int(level), Wd.shape[0], Wd.shape[1],
+                   _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), Wu.shape[0],
+                   Wu.shape[1], _ptr(b[0]), _ptr(b[1]), _ptr(b[2]))
+
+    def set_inner_factors(self, slot, factors):
+        """``x = factors[-1] @ ... @ factors[0] @ b`` (pc type "explicit")."""
+        for k, W in enumerate(factors):
+            ip, ix, dv = _i32(W.indptr), _i32(W.indices), _f64(W.data)
+            self._call("set_inner_factor", slot, k, len(factors), W.shape[0],
+                       _ptr(ip), _ptr(ix), _ptr(dv))
+
     # -- hot path -----------------------------------------------------------
     # Host-pointer calls carry GLOBAL vectors, so their lengths are known
     # here and outputs are checked; device-pointer calls of a partitioned
@@ -381,6 +408,7 @@ class Engine(object):
         self._call("set_stream", C.c_void_p(stream_ptr))
 
     def set_velocity_block(self, ncomp):
+        self.velocity_block = int(ncomp)
         if self.L.hip:
             self._call("set_velocity_block", int(ncomp))
 

@@ -115,9 +115,19 @@ struct MgLevel {
   bool replicated = false, transition = false;
   int64_t n_coarse = 0;
   DBuf<double> x, t0, t1, r, b;
+  // Pre-composed form of this level (pcd_mg_set_fused): two sparse products
+  // around the coarse solve instead of nu_pre + nu_post + 3 launches,
+  //   [x1; r_c] = Wd b            T = [x1 (n) | r_c (n_c) | e_c (n_c)]
+  //   x = Wu [T | b]
+  // valid for the values / smoother bounds it was composed from: any update
+  // of those drops it (the step-by-step cycle takes over) until it is set again
+  DCsr Wd, Wu;
+  DBuf<double> T;
+  bool fused = false;
   void release() {
     A.release(); P.release(); R.release();
     x.release(); t0.release(); t1.release(); r.release(); b.release();
+    Wd.release(); Wu.release(); T.release(); fused = false;
   }
 };
 
@@ -126,6 +136,10 @@ struct Inner {
   double rtol = 1e-12, emin = 0.5, emax = 2.0;
   int nu_pre = 2, nu_post = 2;
   std::vector<MgLevel> mg;
+  // PCD_PC_EXPLICIT: the solve is x = W_{m-1} ... W_0 b with sparse factors
+  // the caller composed (pcd_set_inner_factor)
+  std::vector<DCsr> chain;
+  bool chain_stale = false;          // the operator changed after composition
   // device scratch, sized at setup
   DBuf<double> t0, t1, t2, t3, t4;   // r,z,p,q,p'  or the Chebyshev ring
   DBuf<double> parts;                // 3 * kMaxParts
@@ -139,6 +153,8 @@ struct Inner {
     parts.release(); slots.release(); state.release();
     for (auto& l : mg) l.release();
     mg.clear();
+    for (auto& f : chain) f.release();
+    chain.clear();
   }
 };
 
@@ -363,86 +379,92 @@ static inline bool kron_ok(const DCsr& A, const void* a, const void* b = nullptr
 }
 
 // multi-component operator: F streamed once, all components of a node together
+// (`ghost` / `ncols`: the second segment of the gathered vector and where it
+// starts - the operator's own halo buffer, or the second piece of a two-piece
+// input)
 template <int MODE, int NC>
 static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
-                                const double* add, double* y) {
+                                const double* add, double* y,
+                                const double* ghost, int64_t ncols) {
   const int nn = (int)(A.nrows / NC);
   const int g = grid_stream(nn, A.rb2);
-  const int nloc = (int)(A.ncols / NC);
+  const int nloc = (int)(ncols / NC);
   switch (A.rb2) {
     case 256: hipLaunchKernelGGL((k_spmv_sc<256, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
+                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
     case 128: hipLaunchKernelGGL((k_spmv_sc<128, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
+                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
     case 64: hipLaunchKernelGGL((k_spmv_sc<64, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
+                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
     default: hipLaunchKernelGGL((k_spmv_sc<32, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, A.ghost.p, nloc, add, y); break;
-  }
-}
-template <int MODE>
-static void launch_spmv_kron(Engine* h, const DCsr& A, const double* x,
-                             const double* add, double* y) {
-  if (A.kron == 2) launch_spmv_kron_nc<MODE, 2>(h, A, x, add, y);
-  else launch_spmv_kron_nc<MODE, 3>(h, A, x, add, y);
-}
-
-template <int MODE>
-static void launch_spmv_stream(Engine* h, const DCsr& A, const double* x,
-                               const double* add, double* y) {
-  const int g = grid_stream(A.nrows, A.rb);
-  const XVec xv = xvec(A, x);
-  switch (A.rb) {
-    case 256: hipLaunchKernelGGL((k_spmv_s<256, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
-    case 128: hipLaunchKernelGGL((k_spmv_s<128, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
-    case 64: hipLaunchKernelGGL((k_spmv_s<64, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
-    default: hipLaunchKernelGGL((k_spmv_s<32, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
   }
 }
 
 template <int MODE>
-static void launch_spmv_mode(Engine* h, const DCsr& A, const double* x,
-                             const double* add, double* y) {
-  const int g = grid_rows(A.nrows, A.lpr);
-  const XVec xv = xvec(A, x);
-  switch (A.lpr) {
-    case 4: hipLaunchKernelGGL((k_spmv<4, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                               (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
-    case 8: hipLaunchKernelGGL((k_spmv<8, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                               (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
-    case 16: hipLaunchKernelGGL((k_spmv<16, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
-    default: hipLaunchKernelGGL((k_spmv<32, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
-                                (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
-  }
-}
-
-// y = A x (mode 0) | add + A x (1) | add - A x (2)
-static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
-                int mode = 0, const double* add = nullptr) {
-  if (!A.set) return fail(PCD_ERR_STATE, "spmv: operator not set");
-  CHK(halo_exchange(h, A, x));
-  if (kron_ok(A, x, y, add)) {
-    if (mode == 0) launch_spmv_kron<0>(h, A, x, add, y);
-    else if (mode == 1) launch_spmv_kron<1>(h, A, x, add, y);
-    else launch_spmv_kron<2>(h, A, x, add, y);
+static void launch_spmv_any(Engine* h, const DCsr& A, const double* x,
+                            const double* add, double* y, const double* ghost,
+                            int64_t ncols, bool kron) {
+  const XVec xv{x, ghost, (int)ncols};
+  if (kron) {
+    if (A.kron == 2) launch_spmv_kron_nc<MODE, 2>(h, A, x, add, y, ghost, ncols);
+    else launch_spmv_kron_nc<MODE, 3>(h, A, x, add, y, ghost, ncols);
   } else if (A.long_rows) {
     const int g = (int)std::min<int64_t>(A.nrows, 65535);
-    const XVec xv = xvec(A, x);
-    if (mode == 0) hipLaunchKernelGGL((k_spmv_long<0>), dim3(g), dim3(kBlock), 0, h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
-    else if (mode == 1) hipLaunchKernelGGL((k_spmv_long<1>), dim3(g), dim3(kBlock), 0, h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
-    else hipLaunchKernelGGL((k_spmv_long<2>), dim3(g), dim3(kBlock), 0, h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
+    hipLaunchKernelGGL((k_spmv_long<MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                       (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
   } else if (A.rb) {
-    if (mode == 0) launch_spmv_stream<0>(h, A, x, add, y);
-    else if (mode == 1) launch_spmv_stream<1>(h, A, x, add, y);
-    else launch_spmv_stream<2>(h, A, x, add, y);
-  } else if (mode == 0) launch_spmv_mode<0>(h, A, x, add, y);
-  else if (mode == 1) launch_spmv_mode<1>(h, A, x, add, y);
-  else launch_spmv_mode<2>(h, A, x, add, y);
+    const int g = grid_stream(A.nrows, A.rb);
+    switch (A.rb) {
+      case 256: hipLaunchKernelGGL((k_spmv_s<256, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                   (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      case 128: hipLaunchKernelGGL((k_spmv_s<128, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                   (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      case 64: hipLaunchKernelGGL((k_spmv_s<64, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                  (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      default: hipLaunchKernelGGL((k_spmv_s<32, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                  (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+    }
+  } else {
+    const int g = grid_rows(A.nrows, A.lpr);
+    switch (A.lpr) {
+      case 4: hipLaunchKernelGGL((k_spmv<4, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      case 8: hipLaunchKernelGGL((k_spmv<8, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                 (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      case 16: hipLaunchKernelGGL((k_spmv<16, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                  (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      default: hipLaunchKernelGGL((k_spmv<32, MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                                  (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+    }
+  }
+}
+
+// y = A x (mode 0) | add + A x (1) | add - A x (2) | -A x (3)
+// `x2` (optional, operators WITHOUT a halo only): the input is the
+// concatenation [x (n1 entries) | x2] - the ghost segment of the gather
+// functor carries the second piece, so no extra kernel is needed.
+static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
+                int mode = 0, const double* add = nullptr,
+                const double* x2 = nullptr, int64_t n1 = 0) {
+  if (!A.set) return fail(PCD_ERR_STATE, "spmv: operator not set");
+  const double* ghost = A.ghost.p;
+  int64_t ncols = A.ncols;
+  if (x2) {
+    if (A.plan.nghost || (h->comm && !A.replicated))
+      return fail(PCD_ERR_STATE, "spmv: two-piece input on an operator with a halo");
+    if (A.kron && n1 % A.kron) return fail(PCD_ERR_ARG, "spmv: piece boundary splits a node");
+    ghost = x2; ncols = n1;
+  } else {
+    CHK(halo_exchange(h, A, x));
+  }
+  const bool kron = kron_ok(A, x, y, add, x2);
+  switch (mode) {
+    case 0: launch_spmv_any<0>(h, A, x, add, y, ghost, ncols, kron); break;
+    case 1: launch_spmv_any<1>(h, A, x, add, y, ghost, ncols, kron); break;
+    case 2: launch_spmv_any<2>(h, A, x, add, y, ghost, ncols, kron); break;
+    default: launch_spmv_any<3>(h, A, x, add, y, ghost, ncols, kron); break;
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -474,7 +496,12 @@ static int inner_prepare(Engine* h, int slot) {
       if (!nl) continue;
       CHK(M.x.ensure(nl)); CHK(M.b.ensure(nl));
       if (l > 0) { CHK(M.t0.ensure(nl)); CHK(M.t1.ensure(nl)); CHK(M.r.ensure(nl)); }
+      if (l > 0 && M.fused) CHK(M.T.ensure(nl + 2 * (size_t)M.P.ncols));
     }
+    return 0;
+  }
+  if (s.pc == PCD_PC_EXPLICIT) {
+    CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n));
     return 0;
   }
   switch (s.ksp) {
@@ -742,12 +769,27 @@ static int mg_vcycle(Engine* h, const DCsr& Afine, Inner& s, int l,
                      const double* b, double** out, double* target = nullptr) {
   MgLevel& L = s.mg[l];
   if (l == 0) {
-    CHK(spmv(h, L.A, b, L.x.p));              // explicit coarse inverse
-    *out = L.x.p;
+    double* dst = target ? target : L.x.p;
+    CHK(spmv(h, L.A, b, dst));                // explicit coarse inverse
+    *out = dst;
     return 0;
   }
   const DCsr& A = (l == (int)s.mg.size() - 1) ? Afine : L.A;
   MgLevel& C = s.mg[l - 1];
+  if (L.fused) {
+    // pre-composed level: [x1; r_c] = Wd b;  e_c = cycle(r_c);  x = Wu [T | b]
+    const int64_t n = A.nrows, nc = L.P.ncols;
+    double* T = L.T.p;
+    CHK(spmv(h, L.Wd, b, T));
+    double* pe = nullptr;
+    CHK(mg_vcycle(h, Afine, s, l - 1, T + n, &pe, T + n + nc));
+    if (pe != T + n + nc)
+      HIPCHK(hipMemcpyAsync(T + n + nc, pe, nc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    double* dst = target ? target : L.x.p;
+    CHK(spmv(h, L.Wu, T, dst, 0, nullptr, b, n + 2 * nc));
+    *out = dst;
+    return 0;
+  }
   double* bufs[3] = {L.x.p, L.t0.p, L.t1.p};
   double* px = nullptr;
   CHK(mg_smooth(h, A, L.emin, L.emax, s.nu_pre, b, bufs, true, &px));
@@ -833,6 +875,28 @@ static int inner_solve(Engine* h, int slot, const double* b, double* x,
     if (s.ksp != PCD_KSP_PREONLY && s.ksp != PCD_KSP_RICHARDSON)
       return fail(PCD_ERR_ARG, "pc mg is supported under preonly / richardson only");
     return solve_mg(h, A, s, b, x);
+  }
+  if (s.pc == PCD_PC_EXPLICIT) {
+    // x = W_{m-1} ... W_0 b: one sparse product per factor; a sign asked for
+    // by the caller rides on the last one
+    const int m = (int)s.chain.size();
+    if (m < 1) return fail(PCD_ERR_STATE, "pc explicit: no factors (pcd_set_inner_factor)");
+    if (s.chain_stale)
+      return fail(PCD_ERR_STATE, "pc explicit: the operator of slot %d was updated after its factors "
+                                 "were composed; hand over new factors (pcd_set_inner_factor)", slot);
+    for (const DCsr& F : s.chain)
+      if (!F.set || F.nrows != A.nrows || F.ncols != A.ncols)
+        return fail(PCD_ERR_STATE, "pc explicit: factors incomplete or of the wrong size");
+    const bool neg = scaled && out_scale == -1.0;
+    if (scaled) *scaled = neg || out_scale == 1.0;
+    const double* in = b;
+    for (int j = 0; j < m; ++j) {
+      double* dst = (j == m - 1) ? x : ((j & 1) ? s.t1.p : s.t0.p);
+      CHK(spmv(h, s.chain[j], in, dst, (j == m - 1 && neg) ? 3 : 0));
+      in = dst;
+    }
+    s.last_its = s.max_it; s.its_on_device = false;
+    return 0;
   }
   switch (s.ksp) {
     case PCD_KSP_PREONLY: {
@@ -1188,6 +1252,17 @@ static int slice_out(Engine* h, const Space& sp, const double* loc, double* full
   return 0;
 }
 
+// new values of operator `which`: everything composed from the old ones (a
+// fused finest multigrid level, explicit factors) is stale
+static void values_changed(Engine* h, int which) {
+  for (int slot = 0; slot < PCD_KSP_COUNT; ++slot) {
+    if (kSlotMat[slot] != which) continue;
+    Inner& s = h->inner[slot];
+    if (!s.mg.empty() && s.mg.back().fused) { s.mg.back().fused = false; ++h->gen; }
+    if (!s.chain.empty()) s.chain_stale = true;
+  }
+}
+
 // ================================================================= C ABI
 extern "C" {
 
@@ -1284,6 +1359,7 @@ int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
   }
   CHK(upload_global(h, A, rs, cs, nrows, ncols, rowptr, colidx, vals, nullptr));
   CHK(refresh_dinv(h, A));
+  values_changed(h, which);
   h->ready = false; ++h->gen;
   return 0;
 }
@@ -1297,6 +1373,7 @@ int pcd_update_values(pcd_handle h, int which, const double* vals, int mem) {
   DCsr& A = h->mat[which];
   CHK(refresh_values(h, A, vals, mem));
   CHK(refresh_dinv(h, A));
+  values_changed(h, which);
   if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1360,6 +1437,7 @@ int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
   CHK(gather_block_values(h, h->mat[PCD_MAT_A00], dp));
   CHK(gather_block_values(h, h->mat[PCD_MAT_A01], dp));
   CHK(refresh_dinv(h, h->mat[PCD_MAT_A00]));
+  values_changed(h, PCD_MAT_A00);
   if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1529,8 +1607,85 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
     }
   }
   M.emin = emin; M.emax = emax;
+  M.fused = false;                       // composed from other values
   ++h->gen;
   if (h->ready) CHK(inner_prepare(h, slot));
+  return 0;
+}
+
+// Pre-composed form of one level (see MgLevel): Wd is (n + n_c) x n, Wu is
+// n x (2 n + 2 n_c) over [x1 | r_c | e_c | b].  wd_rowptr == NULL drops it.
+// Partitioned levels of a multi-GPU run keep the step-by-step cycle (their
+// kernels exchange halos); replicated ones may be fused.
+int pcd_mg_set_fused(pcd_handle h, int slot, int level,
+                     int64_t wd_rows, int64_t wd_cols, const int32_t* wd_rowptr,
+                     const int32_t* wd_col, const double* wd_val,
+                     int64_t wu_rows, int64_t wu_cols, const int32_t* wu_rowptr,
+                     const int32_t* wu_col, const double* wu_val) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_set_fused: bad slot %d", slot);
+  Inner& s = h->inner[slot];
+  const int L = (int)s.mg.size();
+  if (level < 1 || level >= L) return fail(PCD_ERR_ARG, "mg_set_fused: level %d outside [1,%d)", level, L);
+  MgLevel& M = s.mg[level];
+  HIPCHK(hipSetDevice(h->device));
+  ++h->gen;
+  if (!wd_rowptr) { M.fused = false; return 0; }
+  if (!M.P.set) return fail(PCD_ERR_STATE, "mg_set_fused: level %d has no prolongation yet", level);
+  if (h->comm && !(M.P.replicated && !M.transition && (level == L - 1 || M.replicated))) {
+    M.fused = false;                     // partitioned level: not fused
+    return 0;
+  }
+  if (!wd_col || !wd_val || !wu_rowptr || !wu_col || !wu_val)
+    return fail(PCD_ERR_ARG, "mg_set_fused: null arrays");
+  const int64_t n = M.P.nrows, nc = M.P.ncols;
+  if (wd_rows != n + nc || wd_cols != n || wu_rows != n || wu_cols != 2 * n + 2 * nc)
+    return fail(PCD_ERR_ARG, "mg_set_fused: level %d is %lld -> %lld, got Wd %lld x %lld, Wu %lld x %lld",
+                level, (long long)nc, (long long)n, (long long)wd_rows, (long long)wd_cols,
+                (long long)wu_rows, (long long)wu_cols);
+  if (s.nu_pre < 1 || s.nu_post < 1)
+    return fail(PCD_ERR_STATE, "mg_set_fused: needs at least one pre- and one post-smoothing step");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  CHK(upload_csr(h, M.Wd, wd_rows, wd_cols, wd_rowptr, wd_col, wd_val, nullptr));
+  CHK(upload_csr(h, M.Wu, wu_rows, wu_cols, wu_rowptr, wu_col, wu_val, nullptr));
+  M.Wd.replicated = M.Wu.replicated = h->comm != nullptr;
+  M.fused = true;
+  if (h->ready) CHK(inner_prepare(h, slot));
+  return 0;
+}
+
+// Factor k of nfactors of an explicitly composed inner solve
+// (pc_type = PCD_PC_EXPLICIT): x = W_{nfactors-1} ... W_0 b.  Factors are
+// square operators on the slot's space; k == 0 starts a new chain.
+int pcd_set_inner_factor(pcd_handle h, int slot, int k, int nfactors, int64_t n,
+                         const int32_t* rowptr, const int32_t* colidx,
+                         const double* vals) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "set_inner_factor: bad slot %d", slot);
+  if (nfactors < 1 || nfactors > 8 || k < 0 || k >= nfactors)
+    return fail(PCD_ERR_ARG, "set_inner_factor: factor %d of %d", k, nfactors);
+  if (!rowptr || !colidx || !vals || n < 0 || n >= INT32_MAX)
+    return fail(PCD_ERR_ARG, "set_inner_factor: bad arrays");
+  const DCsr& A = h->mat[kSlotMat[slot]];
+  if (!A.set) return fail(PCD_ERR_STATE, "set_inner_factor: operator of slot %d not set", slot);
+  HIPCHK(hipSetDevice(h->device));
+  Inner& s = h->inner[slot];
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (k == 0 || (int)s.chain.size() != nfactors) {
+    for (auto& f : s.chain) f.release();
+    s.chain.clear();
+    s.chain.resize(nfactors);
+    s.chain_stale = false;
+  }
+  const Space* sp = nullptr;
+  if (h->comm) sp = (slot == PCD_KSP_A00) ? &h->sp_u : &h->sp_p;
+  if (h->comm && sp->total() != n)
+    return fail(PCD_ERR_ARG, "set_inner_factor: size %lld does not match the partitioned space", (long long)n);
+  CHK(upload_global(h, s.chain[k], sp, sp, n, n, rowptr, colidx, vals, nullptr));
+  if (s.chain[k].nrows != A.nrows)
+    return fail(PCD_ERR_ARG, "set_inner_factor: factor has %lld rows, the operator %lld",
+                (long long)s.chain[k].nrows, (long long)A.nrows);
+  ++h->gen;
   return 0;
 }
 
@@ -1541,6 +1696,8 @@ int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
   Inner& s = h->inner[slot];
   if (level < 0 || level >= (int)s.mg.size()) return fail(PCD_ERR_STATE, "mg_update_values: level %d not set", level);
   MgLevel& M = s.mg[level];
+  M.fused = false;                       // composed from the old values / bounds
+  ++h->gen;
   if (vals) {
     if (!M.A.set) return fail(PCD_ERR_STATE, "mg_update_values: level %d has no operator", level);
     CHK(refresh_values(h, M.A, vals, mem));
@@ -1561,14 +1718,22 @@ int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type, int max_it,
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "set_inner: bad slot %d", slot);
   if (ksp_type < PCD_KSP_PREONLY || ksp_type > PCD_KSP_CG)
     return fail(PCD_ERR_ARG, "set_inner: unsupported ksp type %d", ksp_type);
-  if (pc_type != PCD_PC_NONE && pc_type != PCD_PC_JACOBI && pc_type != PCD_PC_MG)
+  if (pc_type != PCD_PC_NONE && pc_type != PCD_PC_JACOBI && pc_type != PCD_PC_MG &&
+      pc_type != PCD_PC_EXPLICIT)
     return fail(PCD_ERR_ARG, "set_inner: unsupported pc type %d", pc_type);
+  if (pc_type == PCD_PC_EXPLICIT && ksp_type != PCD_KSP_PREONLY)
+    return fail(PCD_ERR_ARG, "set_inner: pc explicit runs under preonly (the factors ARE the solve)");
   if (pc_type == PCD_PC_MG && ksp_type != PCD_KSP_PREONLY && ksp_type != PCD_KSP_RICHARDSON)
     return fail(PCD_ERR_ARG, "set_inner: pc mg is supported under preonly / richardson only");
   if (max_it < 0) return fail(PCD_ERR_ARG, "set_inner: negative max_it");
   if (ksp_type == PCD_KSP_CHEBYSHEV && !(emax > emin && emin > 0.0))
     return fail(PCD_ERR_ARG, "set_inner: chebyshev needs 0 < emin < emax");
   Inner& s = h->inner[slot];
+  if (pc_type != PCD_PC_EXPLICIT && !s.chain.empty()) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (auto& f : s.chain) f.release();
+    s.chain.clear();
+  }
   ++h->gen;
   s.ksp = ksp_type; s.pc = pc_type; s.max_it = max_it; s.rtol = rtol;
   s.emin = emin; s.emax = emax;

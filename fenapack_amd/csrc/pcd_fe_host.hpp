@@ -513,6 +513,7 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
     for (int l = 1; l <= top; ++l) {
       FeLevel& L = fe.lev[l];
       MgLevel& M = s.mg[l];
+      M.fused = false;                   // composed from the previous iterate
       const DCsr* A = &h->mat[kSlotMat[fe.mg_slot]];
       if (l < top) {
         if (!M.A.set || M.A.kron != fe.dim || M.A.nnz2 != L.nnzf)

@@ -66,7 +66,7 @@ __device__ __forceinline__ double row_dot(const int* __restrict__ rowptr,
   return s;
 }
 
-// MODE 0: y = A x      MODE 1: y = add + A x      MODE 2: y = add - A x
+// MODE 0: y = A x   MODE 1: y = add + A x   MODE 2: y = add - A x   MODE 3: y = -A x
 template <int LPR, int MODE>
 __global__ __launch_bounds__(kBlock) void k_spmv(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(
       if (MODE == 0) y[row] = s;
       if (MODE == 1) y[row] = add[row] + s;
       if (MODE == 2) y[row] = add[row] - s;
+      if (MODE == 3) y[row] = -s;
     }
   }
 }
@@ -332,12 +333,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_s(
     const int row = r0 + threadIdx.x / (kBlock / RB);
     const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     double a = 0.0;
-    if (MODE != 0 && mine) a = add[row];          // early: hides under phase 1
+    if ((MODE == 1 || MODE == 2) && mine) a = add[row];   // early: hides under phase 1
     const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
     if (mine) {
       if (MODE == 0) y[row] = s;
       if (MODE == 1) y[row] = a + s;
       if (MODE == 2) y[row] = a - s;
+      if (MODE == 3) y[row] = -s;
     }
     __syncthreads();
   }
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_long(
       if (MODE == 0) y[row] = s;
       if (MODE == 1) y[row] = add[row] + s;
       if (MODE == 2) y[row] = add[row] - s;
+      if (MODE == 3) y[row] = -s;
     }
   }
 }
@@ -611,13 +614,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
     const int row = r0 + threadIdx.x / (kBlock / RB);
     const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     VecC<NC> a = vzero<NC>();
-    if (MODE != 0 && mine) a = add[row];          // early: hides under phase 1
+    if ((MODE == 1 || MODE == 2) && mine) a = add[row];   // early: hides under phase 1
     const VecC<NC> s = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
       for (int i = 0; i < NC; ++i)
-        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i] : a.c[i] - s.c[i]);
+        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i]
+                                        : (MODE == 2 ? a.c[i] - s.c[i] : -s.c[i]));
       y[row] = o;
     }
     __syncthreads();

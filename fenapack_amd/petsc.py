@@ -287,6 +287,13 @@ class PC(object):
         self.mg_galerkin = True            # -pc_mg_galerkin both | none
         self._mg_ops_cb = None
         self._mg_pushed = None
+        # -pc_mg_fuse_nnz: levels whose pre-composed up-sweep operator holds
+        # at most this many stored entries (per velocity component) run as two
+        # sparse products instead of nu_pre + nu_post + 3 launches
+        # (compose.vcycle_level; 0 = never).  Such levels are latency-bound,
+        # not bandwidth-bound: DESIGN.md 4.
+        self.mg_fuse_nnz = 4500000
+        self.mg_fuse_rows = 160000         # never even try above this size
 
     def setMGOperators(self, callback):
         """``callback(nlev)`` -> operators of the ``nlev - 1`` coarse levels,
@@ -371,6 +378,12 @@ class KSP(object):
         self.norm_type = "default"
         self.cheb_eigs = None          # (emin, emax) or None -> estimate
         self.cheb_esteig = (0.0, 0.1, 0.0, 1.1)
+        # -ksp_chebyshev_precompose k: Chebyshev + Jacobi with a FIXED step
+        # count on a small operator is applied as <= k sparse factors composed
+        # on the host (compose.chebyshev_factors) instead of max_it dependent
+        # launches; 0 = step by step
+        self.cheb_precompose = 2
+        self.cheb_precompose_rows = 160000
         self.restart = 30
         self.engine = None
         self.slot = None
@@ -438,6 +451,9 @@ class KSP(object):
             self.pc.mg_galerkin = g == "both"
         self.pc.mg_smooth_its = o.getInt("mg_levels_ksp_max_it",
                                          self.pc.mg_smooth_its)
+        self.pc.mg_fuse_nnz = o.getInt("pc_mg_fuse_nnz", self.pc.mg_fuse_nnz)
+        self.cheb_precompose = o.getInt("ksp_chebyshev_precompose",
+                                        self.cheb_precompose)
         e = o.getString("mg_levels_ksp_chebyshev_esteig")
         if e is not None:
             self.pc.mg_esteig = tuple(float(v)
@@ -539,6 +555,29 @@ class KSP(object):
                 eng.mg_update_values(slot, l,
                                      ops[l].data if l < L - 1 else None,
                                      *bounds[l])
+        self._push_fused_levels(ops, chain, bounds)
+
+    def _push_fused_levels(self, ops, chain, bounds):
+        """Small levels of the cycle as pre-composed operators."""
+        from .compose import vcycle_level
+        pc, eng, slot = self.pc, self.engine, self.slot
+        pc.mg_fused = []
+        if not getattr(eng.L, "hip", False) or pc.mg_fuse_nnz <= 0 \
+                or pc.mg_smooth_its < 1:
+            return
+        blk = 1
+        if slot == c.KSP_A00:
+            blk = getattr(eng, "velocity_block", 2)
+        for l in range(1, len(ops)):
+            A = ops[l]
+            if A.shape[0] // blk > pc.mg_fuse_rows:
+                break                       # larger levels are bandwidth-bound
+            Wd, Wu = vcycle_level(A, chain[l], bounds[l][0], bounds[l][1],
+                                  pc.mg_smooth_its, pc.mg_smooth_its)
+            if Wu.nnz // (blk * blk) > pc.mg_fuse_nnz:
+                break
+            eng.mg_set_fused(slot, l, Wd, Wu)
+            pc.mg_fused.append((l, Wd.nnz, Wu.nnz))
 
     def push_settings(self):
         """Translate the PETSc-style description into ``pcd_set_inner``."""
@@ -562,6 +601,23 @@ class KSP(object):
         if self.type != "cg" or self.norm_type == "none":
             rtol = 0.0                      # fixed iteration count
         max_it = 1 if self.type == "preonly" else self.max_it
+        self.precomposed = None
+        if self.type == "chebyshev" and pc == "jacobi" \
+                and self.cheb_precompose > 0 and 2 <= max_it <= 12 \
+                and getattr(self.engine.L, "hip", False) \
+                and self._ops[1].A is not None \
+                and self._ops[1].A.shape[0] <= self.cheb_precompose_rows:
+            # a fixed number of Chebyshev-Jacobi steps from a zero guess is a
+            # polynomial in D^-1 A: hand over its factors (the step count is
+            # kept for the statistics: these ARE max_it steps)
+            from .compose import chebyshev_factors
+            F = chebyshev_factors(self._ops[1].A, lo, hi, max_it,
+                                  max_factors=self.cheb_precompose)
+            self.engine.set_inner_factors(self.slot, F)
+            self.engine.set_inner(self.slot, "preonly", "explicit", max_it,
+                                  0.0, lo, hi)
+            self.precomposed = [W.nnz for W in F]
+            return
         self.engine.set_inner(self.slot, self.type, pc, max_it, rtol, lo, hi)
 
     def setUp(self):

@@ -67,7 +67,10 @@ enum pcd_slot { PCD_KSP_AP = 0, PCD_KSP_MP = 1, PCD_KSP_RP = 2,
 enum pcd_ksp_type { PCD_KSP_PREONLY = 0, PCD_KSP_RICHARDSON = 1,
                     PCD_KSP_CHEBYSHEV = 2, PCD_KSP_CG = 3 };
 /* [ext PETSc] PC types honoured (-<prefix>pc_type) */
-enum pcd_pc_type { PCD_PC_NONE = 0, PCD_PC_JACOBI = 1, PCD_PC_MG = 2 };
+enum pcd_pc_type { PCD_PC_NONE = 0, PCD_PC_JACOBI = 1, PCD_PC_MG = 2,
+                   /* the solve is a product of sparse factors the caller
+                    * composed: pcd_set_inner_factor (under PCD_KSP_PREONLY) */
+                   PCD_PC_EXPLICIT = 3 };
 
 enum pcd_mem { PCD_MEM_HOST = 0, PCD_MEM_DEVICE = 1 };
 
@@ -162,6 +165,34 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
  * vals == NULL only refreshes the bounds (finest level) */
 int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
                          double emin, double emax, int mem);
+
+/* ---- pre-composed inner solves -------------------------------------------
+ * A fixed number of Chebyshev steps, or one level of a V(nu1, nu2) cycle, is
+ * a fixed linear operator.  Where a launch is latency-bound (operators of
+ * <= ~10^5 rows: DESIGN.md 4) the caller may multiply adjacent steps out on
+ * the host (fenapack_amd/compose.py) and hand over the products; the engine
+ * then applies ONE sparse product where it ran several dependent kernels.
+ * Same role as PETSc composing a KSP from fewer, fatter operators would have
+ * ([ext PETSc]: none of this is visible in the reference, whose KSPSolve calls
+ * at preconditioners.py:130,133,162,167 are opaque); identical results up to
+ * re-association (tests: 1e-11 against the step-by-step path and the oracle).
+ *
+ * pcd_mg_set_fused: level `level` (>= 1) of slot's hierarchy as
+ *   [x1; r_c] = Wd b  and  x = Wu [x1 | r_c | e_c | b]
+ *   (Wd: (n + n_c) x n;  Wu: n x (2n + 2n_c)); wd_rowptr == NULL drops it.
+ *   Any later update of that level's values or smoother bounds drops it too.
+ * pcd_set_inner_factor: factor k of nfactors of x = W_{nfactors-1} ... W_0 b
+ *   for pc_type PCD_PC_EXPLICIT (e.g. Chebyshev(5)+Jacobi on the constant
+ *   M_p as two factors).  Updating the slot's operator afterwards makes the
+ *   solve fail until new factors arrive. */
+int pcd_mg_set_fused(pcd_handle h, int slot, int level,
+                     int64_t wd_rows, int64_t wd_cols, const int32_t* wd_rowptr,
+                     const int32_t* wd_col, const double* wd_val,
+                     int64_t wu_rows, int64_t wu_cols, const int32_t* wu_rowptr,
+                     const int32_t* wu_col, const double* wu_val);
+int pcd_set_inner_factor(pcd_handle h, int slot, int k, int nfactors, int64_t n,
+                         const int32_t* rowptr, const int32_t* colidx,
+                         const double* vals);
 
 /* BasePCDPC.setUp / BasePCDRPC.setUp (preconditioners.py:71-85,191-207) and
  * ksp.setUp() of field_split_backend.py:254-263: checks every operator the
