@@ -75,6 +75,30 @@ def omp_engine(variant="BRM1", threads=None):
     n = f(int(threads or 0))
     eng = _Engine(lib, variant, 0)
     eng.set_threads = lambda k: f(int(k))
+    # the TEAM port (one parallel region per PCApply, first-touch placement)
+    prep = lib.lib.pcdo_team_prepare
+    prep.argtypes, prep.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
+    app = lib.lib.pcdo_team_fieldsplit_apply
+    app.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    app.restype = ctypes.c_int
+
+    def team_prepare(k):
+        if prep(eng._h, int(k)):
+            raise RuntimeError(lib.error())
+
+    def team_fieldsplit_apply(x, y):
+        import numpy as np
+        assert x.dtype == np.float64 and y.dtype == np.float64
+        assert x.flags.c_contiguous and y.flags.c_contiguous
+        if app(eng._h, x.ctypes.data, y.ctypes.data):
+            raise RuntimeError(lib.error())
+    eng.team_prepare, eng.team_fieldsplit_apply = team_prepare, \
+        team_fieldsplit_apply
+    tri = lib.lib.pcdo_stream_triad
+    tri.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    tri.restype = ctypes.c_double
+    eng.stream_triad = lambda n=1 << 26, reps=3, k=0: tri(int(n), int(reps),
+                                                          int(k))
     return eng, n
 
 

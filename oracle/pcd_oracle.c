@@ -829,6 +829,379 @@ int pcdo_get_info(pcdo_t *h, int key, double *out) {
   return 0;
 }
 
+
+/* ==========================================================================
+ * TEAM build (make omp): the multi-core TIMING port behind bench.py's
+ * cpu_baseline - never used for parity.  Same algorithm and the same data as
+ * the serial functions above, organised the way a bandwidth-bound host wants
+ * it ("credible CPU baseline"):
+ *   - ONE parallel region per fieldsplit PCApply; inside it every loop is an
+ *     orphaned `omp for schedule(static)` (implicit barrier), no fork/join
+ *     per kernel;
+ *   - a static row partition that is the same in every loop, and first-touch
+ *     placement: pcdo_team_prepare() re-allocates every matrix and work
+ *     vector and lets the thread that will stream a row block copy / zero it,
+ *     so pages sit on the NUMA node of their reader (the thread count is
+ *     frozen by prepare for that reason);
+ *   - the same loop fusion the GPU kernels have: a Chebyshev step is one pass
+ *     (SpMV + residual + Jacobi + three-term update), residuals and
+ *     prolongation-adds are SpMV epilogues.
+ * Checked against the serial path by tests/test_oracle.py (<= 1e-12).
+ * ========================================================================== */
+#ifdef _OPENMP
+#define T_FOR _Pragma("omp for schedule(static)")
+
+typedef struct {
+  int levels, nu_pre, nu_post;
+  csr_t A[MG_MAX_LEVELS], P[MG_MAX_LEVELS], R[MG_MAX_LEVELS];
+  double emin[MG_MAX_LEVELS], emax[MG_MAX_LEVELS];
+  double *x[MG_MAX_LEVELS], *t0[MG_MAX_LEVELS], *t1[MG_MAX_LEVELS],
+         *r[MG_MAX_LEVELS], *b[MG_MAX_LEVELS];
+} team_mg_t;
+
+typedef struct {
+  int threads;
+  csr_t mat[MAT_COUNT];
+  team_mg_t mg[SLOT_COUNT];
+  double *cw[SLOT_COUNT][3];          /* Chebyshev ring per slot */
+  double *w0, *w1, *wu, *xs, *ys;
+  int32_t *perm;
+  double pq, rz;                      /* shared reduction targets (CG) */
+} team_t;
+
+static team_t *g_team[64];
+static pcdo_t *g_team_owner[64];
+
+static void *t_alloc(size_t bytes) { return malloc(bytes ? bytes : 8); }
+
+/* first-touch copy: the thread that owns a row block copies its rows */
+static void t_copy_csr(csr_t *d, const csr_t *s, int threads) {
+  memset(d, 0, sizeof *d);
+  if (!s->set) return;
+  d->nrows = s->nrows; d->ncols = s->ncols; d->nnz = s->nnz; d->set = 1;
+  d->rowptr = (int32_t *)t_alloc(sizeof(int32_t) * (s->nrows + 1));
+  d->col = (int32_t *)t_alloc(sizeof(int32_t) * s->nnz);
+  d->val = (double *)t_alloc(sizeof(double) * s->nnz);
+  if (s->dinv) d->dinv = (double *)t_alloc(sizeof(double) * s->nrows);
+#pragma omp parallel num_threads(threads)
+  {
+    T_FOR
+    for (int64_t i = 0; i < s->nrows; ++i) {
+      d->rowptr[i] = s->rowptr[i];
+      for (int32_t k = s->rowptr[i]; k < s->rowptr[i + 1]; ++k) {
+        d->col[k] = s->col[k]; d->val[k] = s->val[k];
+      }
+      if (s->dinv) d->dinv[i] = s->dinv[i];
+    }
+  }
+  d->rowptr[s->nrows] = s->rowptr[s->nrows];
+}
+
+static double *t_vec(int64_t n, int threads) {
+  double *v = (double *)t_alloc(sizeof(double) * n);
+#pragma omp parallel num_threads(threads)
+  {
+    T_FOR
+    for (int64_t i = 0; i < n; ++i) v[i] = 0.0;
+  }
+  return v;
+}
+
+/* ---- team kernels: called by EVERY thread of the region ------------------ */
+/* mode 0: y = A x; 1: y = add + A x; 2: y = add - A x */
+static void t_spmv(const csr_t *A, const double *x, double *y, int mode,
+                   const double *add) {
+  T_FOR
+  for (int64_t i = 0; i < A->nrows; ++i) {
+    double s = 0.0;
+    for (int32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+      s += A->val[k] * x[A->col[k]];
+    y[i] = mode == 0 ? s : (mode == 1 ? add[i] + s : add[i] - s);
+  }
+}
+
+/* pn = c0 pm + c1 pk + c2 dinv (b - A pk) in one pass */
+static void t_cheb_step(const csr_t *A, const double *b, const double *pm,
+                        const double *pk, double *pn, double c0, double c1,
+                        double c2) {
+  T_FOR
+  for (int64_t i = 0; i < A->nrows; ++i) {
+    double s = 0.0;
+    for (int32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+      s += A->val[k] * pk[A->col[k]];
+    double v = c1 * pk[i] + c2 * (A->dinv[i] * (b[i] - s));
+    if (c0 != 0.0) v += c0 * pm[i];
+    pn[i] = v;
+  }
+}
+
+static void t_scale_dinv(const csr_t *A, const double *b, double s, double *x) {
+  T_FOR
+  for (int64_t i = 0; i < A->nrows; ++i) x[i] = s * (A->dinv[i] * b[i]);
+}
+
+/* nu Chebyshev-Jacobi steps; iterates rotate through bufs; returns the
+ * buffer that holds the result (mg_smooth of the serial path) */
+static double *t_smooth(const csr_t *A, double emin, double emax, int nu,
+                        const double *b, double *bufs[3], int zero_guess) {
+  double scale = 2.0 / (emax + emin), alpha = 1.0 - scale * emin;
+  double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, c_km1 = 1.0, c_k = mu;
+  int cur = 0, have_pm = 0;
+  if (nu == 0) return bufs[0];
+  if (zero_guess) {
+    t_scale_dinv(A, b, scale, bufs[0]);
+  } else {
+    t_cheb_step(A, b, bufs[0], bufs[0], bufs[1], 0.0, 1.0, scale);
+    cur = 1; have_pm = 1;
+  }
+  for (int it = 0; it < nu - 1; ++it) {
+    double c_kp1 = 2.0 * mu * c_k - c_km1, omega = omegaprod * c_k / c_kp1;
+    double *pk = bufs[cur % 3], *pn = bufs[(cur + 1) % 3];
+    double *pm = have_pm ? bufs[(cur + 2) % 3] : pk;
+    t_cheb_step(A, b, pm, pk, pn, have_pm ? 1.0 - omega : 0.0, omega,
+                omega * scale);
+    c_km1 = c_k; c_k = c_kp1; ++cur; have_pm = 1;
+  }
+  return bufs[cur % 3];
+}
+
+static double *t_vcycle(team_mg_t *g, const csr_t *Afine, int l,
+                        const double *b) {
+  if (l == 0) { t_spmv(&g->A[0], b, g->x[0], 0, NULL); return g->x[0]; }
+  const csr_t *A = (l == g->levels - 1) ? Afine : &g->A[l];
+  double *bufs[3] = {g->x[l], g->t0[l], g->t1[l]};
+  double *px = t_smooth(A, g->emin[l], g->emax[l], g->nu_pre, b, bufs, 1);
+  if (g->nu_pre == 0) {
+    T_FOR
+    for (int64_t i = 0; i < A->nrows; ++i) px[i] = 0.0;
+  }
+  const double *r = b;
+  if (g->nu_pre > 0) { t_spmv(A, px, g->r[l], 2, b); r = g->r[l]; }
+  t_spmv(&g->R[l], r, g->b[l - 1], 0, NULL);
+  double *pe = t_vcycle(g, Afine, l - 1, g->b[l - 1]);
+  double *post[3]; int j = 0;
+  post[0] = px;
+  for (int q = 0; q < 3; ++q) if (bufs[q] != px) post[++j] = bufs[q];
+  t_spmv(&g->P[l], pe, post[0], 1, px);            /* x += P e (in place) */
+  return t_smooth(A, g->emin[l], g->emax[l], g->nu_post, b, post, 0);
+}
+
+/* x = solve(b); x is written by the last loop */
+static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) {
+  const csr_t *A = &T->mat[slot_mat[slot]];
+  inner_t *s = &h->inner[slot];
+  int64_t n = A->nrows;
+  if (s->pc == PC_MG) {
+    int its = (s->ksp == KSP_PREONLY) ? 1 : s->max_it;
+    for (int it = 0; it < its; ++it) {
+      const double *r = b;
+      if (it > 0) { t_spmv(A, x, T->cw[slot][0], 2, b); r = T->cw[slot][0]; }
+      double *z = t_vcycle(&T->mg[slot], A, T->mg[slot].levels - 1, r);
+      if (it == 0) { T_FOR for (int64_t i = 0; i < n; ++i) x[i] = z[i]; }
+      else { T_FOR for (int64_t i = 0; i < n; ++i) x[i] += z[i]; }
+    }
+    return;
+  }
+  if (s->ksp == KSP_CHEBYSHEV) {
+    double *ring[3] = {T->cw[slot][0], T->cw[slot][1], T->cw[slot][2]};
+    double scale = 2.0 / (s->emax + s->emin), alpha = 1.0 - scale * s->emin;
+    double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, c_km1 = 1.0, c_k = mu;
+    if (s->pc == PC_JACOBI) t_scale_dinv(A, b, scale, ring[0]);
+    else { T_FOR for (int64_t i = 0; i < n; ++i) ring[0][i] = scale * b[i]; }
+    for (int it = 0; it < s->max_it; ++it) {
+      double c_kp1 = 2.0 * mu * c_k - c_km1, omega = omegaprod * c_k / c_kp1;
+      double *pk = ring[it % 3], *pn = ring[(it + 1) % 3];
+      double *pm = it ? ring[(it + 2) % 3] : pk;
+      t_cheb_step(A, b, pm, pk, pn, it ? 1.0 - omega : 0.0, omega, omega * scale);
+      c_km1 = c_k; c_k = c_kp1;
+    }
+    const double *res = ring[s->max_it % 3];
+    T_FOR
+    for (int64_t i = 0; i < n; ++i) x[i] = res[i];
+    return;
+  }
+  if (s->ksp == KSP_PREONLY) { t_scale_dinv(A, b, 1.0, x); return; }
+  if (s->ksp == KSP_RICHARDSON) {
+    t_scale_dinv(A, b, 1.0, x);
+    for (int it = 1; it < s->max_it; ++it) {
+      t_cheb_step(A, b, x, x, T->cw[slot][0], 0.0, 1.0, 1.0);
+      T_FOR
+      for (int64_t i = 0; i < n; ++i) x[i] = T->cw[slot][0][i];
+    }
+    return;
+  }
+  /* KSP_CG + Jacobi, natural norm; the reductions go through two shared
+   * scalars, every thread takes the same decision */
+  double *r = T->cw[slot][0], *z = T->cw[slot][1], *p = T->cw[slot][2];
+  double *q = T->mg[slot].x[MG_MAX_LEVELS - 1];
+  T_FOR
+  for (int64_t i = 0; i < n; ++i) {
+    x[i] = 0.0; r[i] = b[i]; z[i] = A->dinv[i] * b[i]; p[i] = z[i];
+  }
+#pragma omp single
+  T->rz = 0.0;
+  { double acc = 0.0;
+    _Pragma("omp for schedule(static) nowait")
+    for (int64_t i = 0; i < n; ++i) acc += r[i] * z[i];
+    _Pragma("omp atomic") T->rz += acc; }
+#pragma omp barrier
+  double rz = T->rz, rz0 = rz;
+  for (int it = 0; it < s->max_it; ++it) {
+    if (rz == 0.0) break;
+    if (s->rtol > 0.0 && sqrt(fabs(rz)) <= s->rtol * sqrt(fabs(rz0))) break;
+#pragma omp single
+    T->pq = 0.0;
+    { double acc = 0.0;
+      _Pragma("omp for schedule(static) nowait")
+      for (int64_t i = 0; i < n; ++i) {
+        double sum = 0.0;
+        for (int32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+          sum += A->val[k] * p[A->col[k]];
+        q[i] = sum; acc += p[i] * sum;
+      }
+      _Pragma("omp atomic") T->pq += acc; }
+#pragma omp barrier
+    double alpha_ = rz / T->pq;
+#pragma omp barrier
+#pragma omp single
+    T->rz = 0.0;
+    { double acc = 0.0;
+      _Pragma("omp for schedule(static) nowait")
+      for (int64_t i = 0; i < n; ++i) {
+        x[i] += alpha_ * p[i];
+        double ri = r[i] - alpha_ * q[i], zi = A->dinv[i] * ri;
+        r[i] = ri; z[i] = zi; acc += ri * zi;
+      }
+      _Pragma("omp atomic") T->rz += acc; }
+#pragma omp barrier
+    double rz_new = T->rz, beta = rz_new / rz;
+    rz = rz_new;
+    T_FOR
+    for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+  }
+}
+
+static void t_pcd(pcdo_t *h, team_t *T, const double *x, double *y) {
+  int64_t n = h->n_p;
+  double *z = T->w0, *z1 = T->w1;
+  if (h->variant == BRM1 || h->variant == RBRM1) {
+    T_FOR
+    for (int64_t i = 0; i < n; ++i) z[i] = x[i];
+#pragma omp single
+    for (int64_t i = 0; i < h->n_bc; ++i) z[h->bc_idx[i]] = h->bc_val[i];
+    t_inner(h, T, SLOT_AP, z, y);
+    t_spmv(&T->mat[MAT_KP], y, z1, 1, x);              /* z1 = Kp y + x */
+    t_inner(h, T, SLOT_MP, z1, y);
+    if (h->variant == RBRM1) {
+      t_inner(h, T, SLOT_RP, x, z);
+      T_FOR for (int64_t i = 0; i < n; ++i) y[i] = -(y[i] + z[i]);
+    } else { T_FOR for (int64_t i = 0; i < n; ++i) y[i] = -y[i]; }
+  } else {
+    t_inner(h, T, SLOT_MP, x, y);
+    t_spmv(&T->mat[MAT_KP], y, z1, 0, NULL);
+#pragma omp single
+    for (int64_t i = 0; i < h->n_bc; ++i) z1[h->bc_idx[i]] = h->bc_val[i];
+    t_inner(h, T, SLOT_AP, z1, z);
+    if (h->variant == RBRM2) {
+      T_FOR for (int64_t i = 0; i < n; ++i) y[i] += z[i];
+      t_inner(h, T, SLOT_RP, x, z);
+    }
+    T_FOR for (int64_t i = 0; i < n; ++i) y[i] = -(y[i] + z[i]);
+  }
+}
+
+static int team_slot(pcdo_t *h) {
+  for (int i = 0; i < 64; ++i) if (g_team_owner[i] == h) return i;
+  return -1;
+}
+
+/* first-touch copies of everything the apply streams; freezes the threads */
+int pcdo_team_prepare(pcdo_t *h, int threads) {
+  if (!h->ready || !h->mat[MAT_A00].set)
+    return fail(4, "team_prepare: system/setup missing");
+  if (threads < 1) threads = omp_get_max_threads();
+  int slot = team_slot(h);
+  if (slot < 0) for (int i = 0; i < 64 && slot < 0; ++i) if (!g_team_owner[i]) slot = i;
+  if (slot < 0) return fail(3, "team_prepare: too many engines");
+  /* (a re-prepare leaks the previous copies: timing tool, few calls) */
+  team_t *T = (team_t *)calloc(1, sizeof *T);
+  T->threads = threads;
+  for (int m = 0; m < MAT_COUNT; ++m) t_copy_csr(&T->mat[m], &h->mat[m], threads);
+  for (int s = 0; s < SLOT_COUNT; ++s) {
+    inner_t *in = &h->inner[s];
+    const csr_t *A = &h->mat[slot_mat[s]];
+    if (!A->set) continue;
+    for (int k = 0; k < 3; ++k) T->cw[s][k] = t_vec(A->nrows, threads);
+    T->mg[s].x[MG_MAX_LEVELS - 1] = t_vec(A->nrows, threads);   /* CG's q */
+    if (in->pc != PC_MG) continue;
+    team_mg_t *g = &T->mg[s];
+    g->levels = in->mg_levels; g->nu_pre = in->nu_pre; g->nu_post = in->nu_post;
+    for (int l = 0; l < in->mg_levels; ++l) {
+      t_copy_csr(&g->A[l], &in->mgA[l], threads);
+      t_copy_csr(&g->P[l], &in->mgP[l], threads);
+      t_copy_csr(&g->R[l], &in->mgR[l], threads);
+      g->emin[l] = in->mg_emin[l]; g->emax[l] = in->mg_emax[l];
+      int64_t nl = (l == in->mg_levels - 1) ? A->nrows : in->mgA[l].nrows;
+      g->x[l] = t_vec(nl, threads); g->t0[l] = t_vec(nl, threads);
+      g->t1[l] = t_vec(nl, threads); g->r[l] = t_vec(nl, threads);
+      g->b[l] = t_vec(nl, threads);
+    }
+  }
+  int64_t n = h->n_u + h->n_p;
+  T->w0 = t_vec(h->n_p, threads); T->w1 = t_vec(h->n_p, threads);
+  T->wu = t_vec(h->n_u, threads);
+  T->xs = t_vec(n, threads); T->ys = t_vec(n, threads);
+  T->perm = (int32_t *)t_alloc(sizeof(int32_t) * n);
+#pragma omp parallel num_threads(threads)
+  {
+    T_FOR
+    for (int64_t i = 0; i < n; ++i) T->perm[i] = h->perm[i];
+  }
+  g_team[slot] = T; g_team_owner[slot] = h;
+  return 0;
+}
+
+int pcdo_team_fieldsplit_apply(pcdo_t *h, const double *x, double *y) {
+  int slot = team_slot(h);
+  if (slot < 0) return fail(4, "team_fieldsplit_apply: call pcdo_team_prepare first");
+  team_t *T = g_team[slot];
+  int64_t nu = h->n_u, n = h->n_u + h->n_p;
+#pragma omp parallel num_threads(T->threads)
+  {
+    T_FOR
+    for (int64_t i = 0; i < n; ++i) T->xs[i] = x[T->perm[i]];
+    t_pcd(h, T, T->xs + nu, T->ys + nu);                /* y_p = S^-1 x_p */
+    t_spmv(&T->mat[MAT_A01], T->ys + nu, T->wu, 2, T->xs);   /* x_u - A01 y_p */
+    t_inner(h, T, SLOT_A00, T->wu, T->ys);
+    T_FOR
+    for (int64_t i = 0; i < n; ++i) y[T->perm[i]] = T->ys[i];
+  }
+  ++h->num_fs;
+  return 0;
+}
+
+/* STREAM triad a = b + s*c on first-touched arrays: GB/s (24 B per entry) */
+double pcdo_stream_triad(int64_t n, int reps, int threads) {
+  if (threads < 1) threads = omp_get_max_threads();
+  double *a = t_vec(n, threads), *b = t_vec(n, threads), *c = t_vec(n, threads);
+  double best = 0.0;
+  for (int r = 0; r < reps + 1; ++r) {
+    double t0 = omp_get_wtime();
+#pragma omp parallel num_threads(threads)
+    {
+      T_FOR
+      for (int64_t i = 0; i < n; ++i) a[i] = b[i] + 3.0 * c[i];
+    }
+    double dt = omp_get_wtime() - t0;
+    double gbs = 24.0 * (double)n / dt / 1e9;
+    if (r > 0 && gbs > best) best = gbs;
+    b[r % n] += a[(r * 7) % n];          /* keep the loop alive */
+  }
+  free(a); free(b); free(c);
+  return best;
+}
+#endif /* _OPENMP */
+
 int pcdo_synchronize(pcdo_t *h) { (void)h; return 0; }
 
 /* threads of the OpenMP timing build; returns the count in effect (1 when

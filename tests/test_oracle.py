@@ -263,3 +263,38 @@ def test_three_dimensional_producer_and_solver_chain():
     x, its, _ = e.gmres_np(st["b"], rtol=1e-8, restart=80, max_it=200)
     assert its < 80
     assert relerr(st["A"] @ x, st["b"]) < 1e-6
+
+
+@pytest.mark.parametrize("variant,mg", [("BRM1", True), ("BRM2", True),
+                                        ("RBRM1", False), ("BRM1", False)])
+def test_team_timing_port_equals_the_serial_oracle(variant, mg):
+    """bench.py's cpu_baseline times the OpenMP TEAM port (one parallel region
+    per PCApply, first-touch placement, fused loops); it must compute what
+    the serial parity oracle computes."""
+    from helpers import push_multigrid
+    st = flow_state("lshape", 3, dt=0.2 if variant.startswith("R") else None)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    par, _ = oracle.omp_engine(variant)
+    ser = oracle.Engine(variant)
+    for eng in (ser, par):
+        configure_engine(eng, st)
+        if mg:
+            I = pb.interpolations()
+            push_multigrid(eng, c.KSP_AP, pb.Ap, I.chain("p"), cycles=2)
+            push_multigrid(eng, c.KSP_A00, L["A00"], I.chain("u"), nu=2)
+            eng.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+        else:
+            eng.set_inner(c.KSP_AP, "cg", "jacobi", 300, 1e-10)
+            eng.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+            eng.set_inner(c.KSP_RP, "cg", "jacobi", 25, 0.0)
+            eng.set_inner(c.KSP_A00, "chebyshev", "jacobi", 6, 0.0, 0.2, 2.2)
+        eng.setup()
+    x = np.random.default_rng(3).standard_normal(V.ndof)
+    ref = ser.fieldsplit_apply_np(x)
+    for threads in (1, 3, 4):
+        par.team_prepare(threads)
+        y = np.empty_like(x)
+        par.team_fieldsplit_apply(x, y)
+        par.team_fieldsplit_apply(x, y)             # buffers are reusable
+        assert relerr(y, ref) < 1e-11, threads
+    assert par.stream_triad(1 << 20, 2, 2) > 0.0

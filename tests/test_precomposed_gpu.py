@@ -143,7 +143,7 @@ def test_python_stack_composes_by_itself(hip_lib):
     from fenapack_amd import PETScOptions
     from fenapack_amd.driver import make_solver, multigrid_inner_options
     from fenapack_amd.fem import Cavity
-    pb = Cavity(3, nu=0.01)
+    pb = Cavity(4, nu=0.01)      # n_p = 6561: the Ap hierarchy has two levels
     PETScOptions.clear()
     multigrid_inner_options()
     w, nls, nlp = make_solver(pb, max_newton=2)
