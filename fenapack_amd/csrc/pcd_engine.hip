@@ -71,6 +71,7 @@ struct DCsr {
   int64_t nrows = 0, ncols = 0, nnz = 0;
   DBuf<int> rowptr, col;
   DBuf<double> val, dinv;
+  DBuf<double> vals, val2s;   // column-scaled copies val .* dinv[col] (zero-guess first step)
   DBuf<int64_t> src;      // provenance in the caller's monolithic values
   bool has_src = false;
   bool set = false;
@@ -95,6 +96,7 @@ struct DCsr {
   DBuf<int> send_idx;
   void release() {
     rowptr.release(); col.release(); val.release(); dinv.release();
+    vals.release(); val2s.release();
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); kron_pos.release();
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
@@ -238,6 +240,11 @@ static int choose_lpr(const DCsr& A) {
 static int g_max_rb = 256;              // PCD_MAX_RB: A/B switch
 static int g_min_wgs = 512;             // PCD_MIN_WGS: A/B switch (see rb_for)
 static int g_max_chunks = 2;            // PCD_MAX_CHUNKS: LDS-tile passes per row block
+// Pre-composed operators (fused multigrid levels, explicit factors) have long
+// and very uneven rows (a stacked restriction row holds hundreds of entries):
+// while they are handed over, small row blocks may take this many passes
+// through the tile instead of falling back to the CSR-vector kernels.
+static int g_chunks_override = 0;
 // rows per workgroup: the largest RB whose every row block fits the LDS tile
 // and that still yields `g_min_wgs` workgroups (small operators then take
 // smaller row blocks: more, shorter workgroups).  Blocks of 64 rows and
@@ -252,7 +259,8 @@ static int rb_for(int64_t nrows, const int32_t* rowptr, int tile) {
     bool ok = true;
     for (int64_t r = 0; r < nrows && ok; r += rb) {
       const int64_t r1 = std::min<int64_t>(r + rb, nrows);
-      if (rowptr[r1] - rowptr[r] > (int64_t)tile * (rb > 64 ? 1 : g_max_chunks)) ok = false;
+      const int chunks = rb > 64 ? 1 : (g_chunks_override ? g_chunks_override : g_max_chunks);
+      if (rowptr[r1] - rowptr[r] > (int64_t)tile * chunks) ok = false;
     }
     if (!ok) continue;
     fit = rb;                            // smaller ones fit as well
@@ -477,6 +485,20 @@ static int refresh_dinv(Engine* h, DCsr& A) {
   hipLaunchKernelGGL(k_dinv, dim3(grid1d(A.nrows, 1, 1 << 30)), dim3(kBlock), 0,
                      h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p,
                      A.dinv.p);
+  // column-scaled values for the fused zero-guess first step (single GPU:
+  // with a halo the first step is not fused, see can_fuse_first)
+  if (!h->comm && A.nnz) {
+    if (A.kron && A.nnz2) {
+      CHK(A.val2s.ensure(A.nnz2));
+      hipLaunchKernelGGL(k_scale_cols, dim3(grid1d(A.nnz2, 4)), dim3(kBlock), 0, h->stream,
+                         A.nnz2, A.col2.p, A.val2.p, A.dinv.p, A.kron, A.val2s.p);
+    }
+    if (A.rb) {
+      CHK(A.vals.ensure(A.nnz));
+      hipLaunchKernelGGL(k_scale_cols, dim3(grid1d(A.nnz, 4)), dim3(kBlock), 0, h->stream,
+                         A.nnz, A.col.p, A.val.p, A.dinv.p, 1, A.vals.p);
+    }
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -554,11 +576,11 @@ static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
   if (kron_ok(A, b, p0, pn)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
-               A.val2.p, dinv, b, p0, pn, s, c1, c2);
+               A.val2s.p, dinv, b, p0, pn, s, c1, c2);
     return;
   }
   LAUNCH_RB(A, k_cheb_first_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
-            A.val.p, dinv, b, p0, pn, s, c1, c2);
+            A.vals.p, dinv, b, p0, pn, s, c1, c2);
 }
 
 // CG with the direction update fused into the SpMV: two launches per
@@ -1646,8 +1668,11 @@ int pcd_mg_set_fused(pcd_handle h, int slot, int level,
   if (s.nu_pre < 1 || s.nu_post < 1)
     return fail(PCD_ERR_STATE, "mg_set_fused: needs at least one pre- and one post-smoothing step");
   HIPCHK(hipStreamSynchronize(h->stream));
-  CHK(upload_csr(h, M.Wd, wd_rows, wd_cols, wd_rowptr, wd_col, wd_val, nullptr));
-  CHK(upload_csr(h, M.Wu, wu_rows, wu_cols, wu_rowptr, wu_col, wu_val, nullptr));
+  g_chunks_override = 64;
+  int rc_up = upload_csr(h, M.Wd, wd_rows, wd_cols, wd_rowptr, wd_col, wd_val, nullptr);
+  if (!rc_up) rc_up = upload_csr(h, M.Wu, wu_rows, wu_cols, wu_rowptr, wu_col, wu_val, nullptr);
+  g_chunks_override = 0;
+  CHK(rc_up);
   M.Wd.replicated = M.Wu.replicated = h->comm != nullptr;
   M.fused = true;
   if (h->ready) CHK(inner_prepare(h, slot));
@@ -1681,7 +1706,10 @@ int pcd_set_inner_factor(pcd_handle h, int slot, int k, int nfactors, int64_t n,
   if (h->comm) sp = (slot == PCD_KSP_A00) ? &h->sp_u : &h->sp_p;
   if (h->comm && sp->total() != n)
     return fail(PCD_ERR_ARG, "set_inner_factor: size %lld does not match the partitioned space", (long long)n);
-  CHK(upload_global(h, s.chain[k], sp, sp, n, n, rowptr, colidx, vals, nullptr));
+  g_chunks_override = 64;
+  const int rc_up = upload_global(h, s.chain[k], sp, sp, n, n, rowptr, colidx, vals, nullptr);
+  g_chunks_override = 0;
+  CHK(rc_up);
   if (s.chain[k].nrows != A.nrows)
     return fail(PCD_ERR_ARG, "set_inner_factor: factor has %lld rows, the operator %lld",
                 (long long)s.chain[k].nrows, (long long)A.nrows);

@@ -374,37 +374,47 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_s(
 }
 
 // First smoothing step from a ZERO guess, fused with the Jacobi start:
-//   p0 = s * dinv .* b  (formed on the fly for the gathered columns and
-//   written once for the owned rows);  pn = c1 p0 + c2 dinv .* (b - A p0)
-struct XScaled {
-  const double* b; const double* dinv; double s;
-  __device__ __forceinline__ double operator()(int c) const {
-    return s * dinv[c] * b[c];
-  }
-};
-
+//   p0 = s * dinv .* b  (written once for the owned rows);
+//   pn = c1 p0 + c2 dinv .* (b - A p0)
+// A p0 = s * (A D^-1) b is taken from the COLUMN-SCALED values `vals`
+// (val[k] * dinv[col[k]], refreshed with the diagonal by k_scale_cols), so the
+// gather reads b alone - one gathered stream, like every other step (forming
+// p0 on the fly for the gathered columns cost two: 27 vs 20 us on the finest
+// velocity level).
 template <int RB>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_s(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double* __restrict__ dinv,
+    const double* __restrict__ vals, const double* __restrict__ dinv,
     const double* b, double* p0, double* pn, double s, double c1, double c2) {
   __shared__ double lds[kTile];
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, RB, rb0, rb1);
-  const XScaled xf{b, dinv, s};
+  const XVec xf{b, nullptr, nrows};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const double sum = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
     const int row = r0 + threadIdx.x / (kBlock / RB);
-    if (threadIdx.x % (kBlock / RB) == 0 && row < nrows) {
-      const double d = dinv[row], bi = b[row];
+    const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
+    double d = 0.0, bi = 0.0;
+    if (mine) { d = dinv[row]; bi = b[row]; }     // early: hides under phase 1
+    const double sum = s * stream_row_block<RB>(rowptr, col, vals, xf, r0, nrows, lds);
+    if (mine) {
       const double x0 = s * d * bi;
       if (p0) p0[row] = x0;
       pn[row] = c1 * x0 + c2 * d * (bi - sum);
     }
     __syncthreads();
   }
+}
+
+// vals[k] = val[k] * dinv[col[k] * stride]   (stride = components per node
+// when `val` holds the scalar stencil F of an F (x) I operator)
+__global__ __launch_bounds__(kBlock) void k_scale_cols(
+    int64_t nnz, const int* __restrict__ col, const double* __restrict__ val,
+    const double* __restrict__ dinv, int stride, double* vals) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
+       k += (int64_t)gridDim.x * kBlock)
+    vals[k] = val[k] * dinv[(int64_t)col[k] * stride];
 }
 
 // long rows (dense coarse inverse): one workgroup per row, 4 loads in flight
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
 template <int RB, int NC>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double* __restrict__ dinv_,
+    const double* __restrict__ vals, const double* __restrict__ dinv_,
     const double* b_, double* p0_, double* pn_, double s, double c1, double c2) {
   __shared__ VecC<NC> lds[tile_c<NC>()];
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
@@ -676,18 +686,20 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, RB, rb0, rb1);
-  const XScaledC<NC> xf{b, dinv, s};
+  const XVecC<NC> xf{b, nullptr, nrows};          // vals carry D^-1 (see k_cheb_first_s)
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
-    const VecC<NC> sum = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
     const int row = r0 + threadIdx.x / (kBlock / RB);
-    if (threadIdx.x % (kBlock / RB) == 0 && row < nrows) {
-      const VecC<NC> d = dinv[row], bi = b[row];
+    const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
+    VecC<NC> d = vzero<NC>(), bi = d;
+    if (mine) { d = dinv[row]; bi = b[row]; }
+    const VecC<NC> sum = stream_row_block_c<RB, NC>(rowptr, col, vals, xf, r0, nrows, lds);
+    if (mine) {
       VecC<NC> x0, o;
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         x0.c[i] = s * d.c[i] * bi.c[i];
-        o.c[i] = c1 * x0.c[i] + c2 * d.c[i] * (bi.c[i] - sum.c[i]);
+        o.c[i] = c1 * x0.c[i] + c2 * d.c[i] * (bi.c[i] - s * sum.c[i]);
       }
       if (p0) p0[row] = x0;
       pn[row] = o;

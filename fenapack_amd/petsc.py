@@ -383,7 +383,11 @@ class KSP(object):
         # on the host (compose.chebyshev_factors) instead of max_it dependent
         # launches; 0 = step by step
         self.cheb_precompose = 2
-        self.cheb_precompose_rows = 160000
+        # measured on an MI355X (profiles/r02_c_timeline.txt): at 103 041 rows
+        # the two factors of Chebyshev(5) on a P1 mass matrix (5.0x and 2.65x
+        # its entries) take 28 us against 25 us for the five steps - streaming
+        # bytes already matter there; composition pays below ~3 10^4 rows
+        self.cheb_precompose_rows = 30000
         self.restart = 30
         self.engine = None
         self.slot = None
