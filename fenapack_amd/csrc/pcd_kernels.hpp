@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_s(
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, RB, rb0, rb1);
-  const XVec xf{b, nullptr, nrows};
+  const XVec xf{b, b, nrows};   // (no halo: the ghost segment is never read)
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x / (kBlock / RB);
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, RB, rb0, rb1);
-  const XVecC<NC> xf{b, nullptr, nrows};          // vals carry D^-1 (see k_cheb_first_s)
+  const XVecC<NC> xf{b, b, nrows};    // vals carry D^-1 (see k_cheb_first_s)
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x / (kBlock / RB);
