@@ -197,6 +197,9 @@ struct pcd_engine_s {
   DBuf<double> io_x, io_y;            // staging for host-pointer calls
   // GMRES
   DBuf<double> V, gz, gw, gparts, gh, gy, gxs, gbs;
+  DBuf<double> gH, gcs, gsn, gg;      // Hessenberg, rotations, rotated rhs (device)
+  DBuf<GmresStatus> gstat;
+  hipEvent_t gev[2] = {nullptr, nullptr};
   int64_t V_ld = 0;
   int V_m = 0;
   double* pinned = nullptr;           // host-pinned scratch
@@ -1330,6 +1333,8 @@ int pcd_destroy(pcd_handle h) {
   h->xs.release(); h->ys.release(); h->io_x.release(); h->io_y.release();
   h->V.release(); h->gz.release(); h->gw.release(); h->gparts.release();
   h->gh.release(); h->gy.release(); h->gxs.release(); h->gbs.release();
+  h->gH.release(); h->gcs.release(); h->gsn.release(); h->gg.release(); h->gstat.release();
+  for (auto& e : h->gev) if (e) (void)hipEventDestroy(e);
   h->loc_x.release(); h->loc_y.release();
   delete h->comm;
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -1944,7 +1949,18 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
   double bnorm = 0.0;
   CHK(dev_norm(h, n, bs, &bnorm));
   const double tol = std::max(rtol * bnorm, atol);
-  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m, 0.0), sn(m, 0.0), gvec(m + 1, 0.0), yk(m, 0.0);
+  // Hessenberg matrix, Givens rotations and the stopping test live on the
+  // device (k_gmres_column); the host reads a 32-byte status ONE ITERATION
+  // LATE: iteration k is queued before the status of iteration k-1 is waited
+  // for, so the device never idles on the host and every rank of a
+  // partitioned run takes the same decision at the same point (the status is
+  // computed from all-reduced numbers).  Price: one over-run iteration per
+  // solve, whose results are ignored (the state is frozen once `done`).
+  CHK(h->gH.ensure((size_t)(m + 1) * m)); CHK(h->gcs.ensure(m)); CHK(h->gsn.ensure(m));
+  CHK(h->gg.ensure(m + 1)); CHK(h->gstat.ensure(1));
+  for (auto& e : h->gev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  GmresStatus* pst = reinterpret_cast<GmresStatus*>(h->pinned);   // 2 slots
+  static_assert(sizeof(GmresStatus) == 24 || sizeof(GmresStatus) == 32, "status layout");
   int it = 0;
   double res = bnorm;
   // r0 = b (zero initial guess), kept in V_0 storage
@@ -1955,16 +1971,16 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
     res = beta;
     if (beta <= tol) break;
     hipLaunchKernelGGL(k_axpby, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, 1.0 / beta, V, 0.0, V);
-    std::fill(gvec.begin(), gvec.end(), 0.0);
-    gvec[0] = beta;
-    int k = 0;
-    bool breakdown = false;
-    for (; k < m && it < max_it;) {
-      double* vk = V + (size_t)k * ld;
-      double* vn = V + (size_t)(k + 1) * ld;
+    hipLaunchKernelGGL(k_gmres_reset, dim3(1), dim3(64), 0, h->stream, beta, m, h->gg.p, h->gstat.p);
+    int k = 0;                 // iterations of this cycle queued so far
+    int kfin = -1;             // columns that count, once known
+    GmresStatus fin = {};
+    auto enqueue = [&](int kk) -> int {
+      double* vk = V + (size_t)kk * ld;
+      double* vn = V + (size_t)(kk + 1) * ld;
       CHK(fs_apply_split(h, vk, z));                           // z = M^-1 v_k
       CHK(apply_system(h, z, vn));                             // w = A z
-      const int nvec = k + 1;
+      const int nvec = kk + 1;
       const int tiles = (nvec + kDotTile - 1) / kDotTile;
       // classical Gram-Schmidt: all k+1 dots in one batch, ONE all-reduce
       hipLaunchKernelGGL(k_mdot, dim3(G, tiles), dim3(kBlock), 0, h->stream, n, V, ld, nvec, vn, h->gparts.p, G);
@@ -1975,43 +1991,39 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
       PartsRef nr;
       CHK(reduce_global(h, h->gparts.p, G, h->gy.p + m + 1, &nr));
       hipLaunchKernelGGL(k_normalize, dim3(G), dim3(kBlock), 0, h->stream, n, vn, nr.p, nr.n, h->gh.p + nvec);
-      HIPCHK(hipMemcpyAsync(h->pinned, h->gh.p, (nvec + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      double* hc = &H[(size_t)k * (m + 1)];
-      for (int j = 0; j <= nvec; ++j) hc[j] = h->pinned[j];
-      const double hn = hc[k + 1];
-      if (!std::isfinite(hn)) return fail(PCD_ERR_BREAKDOWN, "gmres: non-finite Hessenberg entry at iteration %d", it);
-      for (int j = 0; j < k; ++j) {
-        const double t = cs[j] * hc[j] + sn[j] * hc[j + 1];
-        hc[j + 1] = -sn[j] * hc[j] + cs[j] * hc[j + 1];
-        hc[j] = t;
+      hipLaunchKernelGGL(k_gmres_column, dim3(1), dim3(64), 0, h->stream, kk, m, h->gh.p, h->gH.p,
+                         h->gcs.p, h->gsn.p, h->gg.p, tol, h->gstat.p);
+      HIPCHK(hipMemcpyAsync(&pst[kk & 1], h->gstat.p, sizeof(GmresStatus), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipEventRecord(h->gev[kk & 1], h->stream));
+      return 0;
+    };
+    while (k < m && it + k < max_it) {
+      CHK(enqueue(k));
+      ++k;
+      if (k >= 2) {                       // status of iteration k-2, one late
+        HIPCHK(hipEventSynchronize(h->gev[(k - 2) & 1]));
+        const GmresStatus st = pst[(k - 2) & 1];
+        if (st.done) { fin = st; kfin = st.kconv; break; }
       }
-      const double d = std::hypot(hc[k], hc[k + 1]);
-      // a zero (or non-finite) column: A M^-1 v_k lies in the span already
-      // searched with a vanishing component along v_k - the least-squares
-      // problem is singular, not a lucky breakdown
-      if (!(d > 0.0) || !std::isfinite(d))
-        return fail(PCD_ERR_BREAKDOWN, "gmres: singular Hessenberg column at iteration %d (|h| = %g)", it, d);
-      cs[k] = hc[k] / d; sn[k] = hc[k + 1] / d;
-      hc[k] = d; hc[k + 1] = 0.0;
-      gvec[k + 1] = -sn[k] * gvec[k]; gvec[k] = cs[k] * gvec[k];
-      res = std::fabs(gvec[k + 1]);
-      ++it; ++k;
-      if (hn == 0.0) breakdown = true;
-      if (res <= tol || breakdown) break;
     }
-    for (int i = k - 1; i >= 0; --i) {
-      double s = gvec[i];
-      for (int j = i + 1; j < k; ++j) s -= H[(size_t)j * (m + 1) + i] * yk[j];
-      yk[i] = s / H[(size_t)i * (m + 1) + i];
+    if (kfin < 0) {                       // natural end of the cycle
+      HIPCHK(hipEventSynchronize(h->gev[(k - 1) & 1]));
+      fin = pst[(k - 1) & 1];
+      kfin = fin.done ? fin.kconv : k;
     }
-    // x += M^-1 (V y)
-    for (int j = 0; j < k; ++j) h->pinned[j] = yk[j];
-    HIPCHK(hipMemcpyAsync(h->gy.p, h->pinned, k * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_combine, dim3(G), dim3(kBlock), 0, h->stream, n, V, ld, k, h->gy.p, h->gw.p);
-    CHK(fs_apply_split(h, h->gw.p, z));
-    hipLaunchKernelGGL(k_axpby, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, 1.0, z, 1.0, xs);
-    HIPCHK(hipStreamSynchronize(h->stream));   // pinned reused next cycle
+    if (fin.code == 1) return fail(PCD_ERR_BREAKDOWN, "gmres: non-finite Hessenberg entry at iteration %d", it + kfin);
+    if (fin.code == 2) return fail(PCD_ERR_BREAKDOWN, "gmres: singular Hessenberg column at iteration %d", it + kfin);
+    const bool breakdown = fin.code == 3;
+    it += kfin;
+    res = fin.res;
+    k = kfin;
+    // y = H^-1 g on the device; x += M^-1 (V y)
+    if (k > 0) {
+      hipLaunchKernelGGL(k_gmres_ysolve, dim3(1), dim3(64), 0, h->stream, k, m, h->gH.p, h->gg.p, h->gy.p);
+      hipLaunchKernelGGL(k_combine, dim3(G), dim3(kBlock), 0, h->stream, n, V, ld, k, h->gy.p, h->gw.p);
+      CHK(fs_apply_split(h, h->gw.p, z));
+      hipLaunchKernelGGL(k_axpby, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, 1.0, z, 1.0, xs);
+    }
     if (res <= tol || it >= max_it || breakdown) break;
     CHK(spmv(h, A, xs, V, 2, bs));                              // r = b - A x
     CHK(dev_norm(h, n, V, &beta));

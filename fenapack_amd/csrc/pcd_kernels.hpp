@@ -890,6 +890,68 @@ __global__ __launch_bounds__(kBlock) void k_normalize(
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_nrm = nrm;
 }
 
+// ---- GMRES bookkeeping on the device ----------------------------------------
+// The Hessenberg column of iteration k arrives in hcol[0..k+1] (k+1 dots and
+// the norm of the orthogonalised vector).  One wave applies the stored Givens
+// rotations, forms the new one, updates the rotated right-hand side g and the
+// residual estimate |g[k+1]| and decides on convergence - what the host did
+// after a D2H copy + stream synchronise per iteration.  The host now only
+// reads the 32-byte status, one iteration LATE (so that the next iteration is
+// already queued while it waits): after `done` the state is frozen, later
+// calls (the one over-run iteration) change nothing.
+struct GmresStatus {
+  double res;        // residual estimate after the last counted iteration
+  int done;          // 1: converged or broke down at iteration kconv
+  int kconv;         // columns of this cycle that belong to the solution
+  int code;          // 0 ok, 1 non-finite entry, 2 singular column, 3 lucky breakdown
+  int pad;
+};
+
+__global__ void k_gmres_reset(double beta, int m, double* g, GmresStatus* st) {
+  for (int i = threadIdx.x; i <= m; i += blockDim.x) g[i] = (i == 0) ? beta : 0.0;
+  if (threadIdx.x == 0) { st->res = beta; st->done = 0; st->kconv = 0; st->code = 0; }
+}
+
+// H: column-major, leading dimension m + 1
+__global__ void k_gmres_column(int k, int m, const double* hcol, double* H,
+                               double* cs, double* sn, double* g, double tol,
+                               GmresStatus* st) {
+  if (threadIdx.x != 0 || st->done) return;
+  double* hc = H + (size_t)k * (m + 1);
+  for (int j = 0; j <= k + 1; ++j) hc[j] = hcol[j];
+  const double hn = hc[k + 1];
+  if (!isfinite(hn)) { st->done = 1; st->code = 1; st->kconv = k; return; }
+  for (int j = 0; j < k; ++j) {
+    const double t = cs[j] * hc[j] + sn[j] * hc[j + 1];
+    hc[j + 1] = -sn[j] * hc[j] + cs[j] * hc[j + 1];
+    hc[j] = t;
+  }
+  const double d = hypot(hc[k], hc[k + 1]);
+  if (!(d > 0.0) || !isfinite(d)) { st->done = 1; st->code = 2; st->kconv = k; return; }
+  cs[k] = hc[k] / d; sn[k] = hc[k + 1] / d;
+  hc[k] = d; hc[k + 1] = 0.0;
+  g[k + 1] = -sn[k] * g[k]; g[k] = cs[k] * g[k];
+  const double res = fabs(g[k + 1]);
+  st->res = res; st->kconv = k + 1;
+  if (res <= tol) st->done = 1;
+  else if (hn == 0.0) { st->done = 1; st->code = 3; }
+}
+
+// y = H(0:k,0:k)^-1 g(0:k) by back substitution (one wave; k <= 255)
+__global__ void k_gmres_ysolve(int k, int m, const double* H, const double* g,
+                               double* y) {
+  __shared__ double ys[256];
+  const int lane = threadIdx.x;
+  for (int i = k - 1; i >= 0; --i) {
+    double s = 0.0;
+    for (int j = i + 1 + lane; j < k; j += 64) s += H[(size_t)j * (m + 1) + i] * ys[j];
+    s = wave_sum(s);
+    if (lane == 0) ys[i] = (g[i] - s) / H[(size_t)i * (m + 1) + i];
+    __syncthreads();
+  }
+  for (int i = lane; i < k; i += 64) y[i] = ys[i];
+}
+
 // out = sum_j y[j] V_j
 __global__ __launch_bounds__(kBlock) void k_combine(
     int64_t n, const double* V, int64_t ld, int nvec, const double* y,
