@@ -415,7 +415,20 @@ def main():
             "A00": "chebyshev+jacobi its %d eig ratio %g"
                    % (k_f, args.a00_ratio)}
 
-    traffic = pmc_traffic(int(V.n_u), nnz_a00, world)
+    pmc = pmc_measurement(int(V.n_u), world)
+    traffic = None if pmc is None else \
+        pmc["roofline_kernel"]["traffic_bytes_per_launch"]
+    pc_traffic = None if pmc is None or args.inner != "mg" else \
+        pmc["pcapply"]["traffic_bytes_per_apply"]
+    # the practical roof, measured by a kernel of this library on this box
+    triad_gbs = eng.bandwidth_probe("triad", 1 << 30, 5)
+    kcopy_gbs = eng.bandwidth_probe("copy", 1 << 30, 5)
+    # what the launched kernel must move by construction: F once (values +
+    # column indices + row pointers) and five vector streams (b, D^-1, p_k,
+    # p_{k-1} read, p_{k+1} written); the gathered p_k is served from cache
+    nn_k = V.n_u // ncomp if ncomp else V.n_u
+    b_model = (12 * (nnz_a00 // ncomp if ncomp else nnz_a00)
+               + 4 * (nn_k + 1) + 40 * V.n_u) / world
     out = {
         "metric": "fieldsplit PCApply calls/sec (%s Re=100, P2/P1)"
                   % ("3D cavity" if args.geometry == "cube" else "2D cavity"),
@@ -446,22 +459,15 @@ def main():
         "petsc4py_available": have_petsc,
         "algorithmic_bytes_per_pcapply": int(bytes_pc),
         "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
-        "roofline": {
-            "bound": "hbm",
-            "kernel": kernel_name,
-            "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / rf.HBM_PEAK_GBS,
-            "bytes_per_launch": int(b_kernel),
-            "us_per_launch": 1e6 * t_kernel,
-            "measured_d2d_copy_gbs": copy_gbs,
-            "traffic": traffic,
-            # what the kernel really moves (PMC) per second, and that rate
-            # against the copy bandwidth measured on this box just now
-            "traffic_gbs": None if traffic is None
-            else traffic / t_kernel / 1e9,
-            "traffic_over_measured_copy": None if traffic is None
-            else traffic / t_kernel / 1e9 / copy_gbs,
-        },
+        "roofline": roofline_block(
+            kernel_name, b_kernel, t_kernel, traffic, b_model, triad_gbs,
+            kcopy_gbs, copy_gbs, pmc, rf.HBM_PEAK_GBS),
+        # the same three numbers for the WHOLE PCApply (all its launches)
+        "pcapply_roofline": roofline_block(
+            "all %s launches of one fieldsplit PCApply"
+            % ("?" if pmc is None else pmc["pcapply"]["launches_per_apply"]),
+            bytes_pc / world, dt / args.steps, pc_traffic, None, triad_gbs,
+            kcopy_gbs, copy_gbs, pmc, rf.HBM_PEAK_GBS),
         "setup_seconds": t_setup,
     }
 
@@ -533,33 +539,73 @@ def picard_step_times(pb, w, nls, ksp, c):
 HOST_STEP_SECONDS = {}
 
 
-def pmc_traffic(n_u, nnz_a00, world):
-    """HBM bytes per launch of the roofline kernel from the committed
-    rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, calibrated on
-    a kernel of known byte count: profiles/r01_pmc_cheb_step_level6.json).
-    PMC cannot be collected inside this process; null unless the committed
-    measurement is for exactly this operator."""
+def kernels_sha16():
+    """Hash of the kernel sources a PMC measurement is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pcd_kernels.hpp", "pcd_engine.hip"):
+        h.update(open(os.path.join(ROOT, "fenapack_amd", "csrc", f),
+                      "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_measurement(n_u, world):
+    """The committed rocprofv3 --pmc measurement (tools/gpu_pmc.sh ->
+    profiles/*pmc_roofline*.json) for THIS workload and THESE kernels, or
+    None: PMC counters cannot be collected inside this process, and a
+    measurement taken on other kernel sources is not quoted (the file carries
+    the hash of csrc/pcd_kernels.hpp + pcd_engine.hip it was taken on)."""
     import glob
-    want = 12 * nnz_a00 + 92 * n_u + 4
-    scalar = os.environ.get("PCD_NO_KRON2") == "1"
     if world != 1:
         return None
-    paths = glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))
-    # newest measurement first: r01_<letter>_pmc_* (later letters = later in
-    # the round) before the early r01_pmc_* files
-    paths.sort(key=lambda q: (not os.path.basename(q).startswith("r01_pmc"),
-                              os.path.basename(q)), reverse=True)
-    for path in paths:
+    sha = kernels_sha16()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles",
+                                              "*pmc_roofline*.json")),
+                       reverse=True):
         try:
             d = json.load(open(path))
-            k = d.get("k_cheb_step_s<256>", d)
-            is_scalar = "k_cheb_step_s<" in str(k.get("kernel", "k_cheb_step_s<"))
-            if k["algorithmic_bytes_per_launch"] == want \
-                    and is_scalar == scalar:
-                return k["traffic_bytes_per_launch"]
+            if d.get("kernels_sha16") == sha and d.get("n_u") == n_u:
+                d["file"] = os.path.relpath(path, ROOT)
+                return d
         except Exception:
             continue
     return None
+
+
+def roofline_block(kernel, b_alg, t, traffic, b_model, triad_gbs, kcopy_gbs,
+                   torch_copy_gbs, pmc, peak):
+    """`achieved` / `frac` as the contract defines them (SURVEY 8d algorithmic
+    bytes - the unfused textbook count, which a fused kernel may beat, hence
+    frac can exceed 1) next to the physical readings: PMC traffic and the
+    bytes the kernel must move by construction, each over the same time,
+    against the 8 TB/s spec and against the streaming rate a kernel of this
+    library reaches on this box."""
+    gbs = lambda nbytes: None if nbytes is None else nbytes / t / 1e9
+    achieved = gbs(b_alg)
+    out = {
+        "bound": "hbm", "kernel": kernel,
+        "achieved": achieved, "peak": peak, "unit": "GB/s",
+        "frac": achieved / peak,
+        "frac_definition": "SURVEY 8(d) algorithmic bytes / time / 8 TB/s; "
+                           "unfused textbook bytes, so a fused kernel that "
+                           "moves fewer can exceed 1 - see frac_traffic",
+        "bytes_per_launch": int(b_alg),
+        "us_per_launch": 1e6 * t,
+        "traffic": traffic,
+        "traffic_source": None if pmc is None else pmc["file"],
+        "traffic_stale": pmc is None,
+        "traffic_gbs": gbs(traffic),
+        "frac_traffic": None if traffic is None else gbs(traffic) / peak,
+        "measured_triad_gbs": triad_gbs,
+        "measured_copy_gbs": kcopy_gbs,
+        "measured_torch_copy_gbs": torch_copy_gbs,
+        "frac_vs_measured_roof": None if traffic is None
+        else gbs(traffic) / max(triad_gbs, kcopy_gbs),
+    }
+    if b_model is not None:
+        out["kernel_model_bytes_per_launch"] = int(b_model)
+        out["frac_kernel_model"] = gbs(b_model) / peak
+    return out
 
 
 def physical_cores():

@@ -68,6 +68,7 @@ _HIP_ONLY = {
     "comm_init": [C.c_int, C.c_int, C.c_void_p],
     "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "graph_enable": [C.c_int],
+    "bandwidth_probe": [C.c_int, C.c_int64, C.c_int, _f64p],
     "set_velocity_block": [C.c_int],
     # pre-composed inner solves
     "mg_set_fused": [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
@@ -414,6 +415,13 @@ class Engine(object):
 
     def graph_enable(self, on=True):
         self._call("graph_enable", int(bool(on)))
+
+    def bandwidth_probe(self, kind="triad", nbytes=1 << 30, reps=5):
+        """GB/s (reads + writes) of a streaming copy / triad kernel."""
+        out = C.c_double(0.0)
+        self._call("bandwidth_probe", {"copy": 0, "triad": 1}[kind],
+                   int(nbytes), int(reps), C.byref(out))
+        return out.value
 
     # -- device operator producer (HIP only) ------------------------------------
     def fe_begin(self, dim, nlevels, qw, phi, dphi, psi):

@@ -2141,6 +2141,42 @@ int pcd_set_velocity_block(pcd_handle h, int ncomp) {
   return 0;
 }
 
+// Streaming bandwidth of this GPU as a kernel of this library sees it:
+// kind 0 copy, 1 triad, on arrays of `bytes` each (>= 256 MiB: beyond the
+// Infinity Cache), best of `reps` launches, timed with events on the engine's
+// stream.  *gbs = bytes moved (reads + writes) per second / 1e9.
+int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double* gbs) {
+  if (!h || !gbs) return fail(PCD_ERR_ARG, "bandwidth_probe: null argument");
+  if (kind < 0 || kind > 1 || bytes < 1024 || reps < 1) return fail(PCD_ERR_ARG, "bandwidth_probe: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t n2 = bytes / 16;
+  DBuf<double> a, b, c;
+  CHK(a.ensure(2 * n2)); CHK(b.ensure(2 * n2));
+  if (kind == 1) CHK(c.ensure(2 * n2));
+  HIPCHK(hipMemsetAsync(b.p, 0, 16 * n2, h->stream));
+  if (kind == 1) HIPCHK(hipMemsetAsync(c.p, 0, 16 * n2, h->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  const int grid = 256 * 8 * 4;              // 32 workgroups per CU
+  double best = 0.0;
+  for (int r = 0; r < reps + 1; ++r) {
+    HIPCHK(hipEventRecord(e0, h->stream));
+    hipLaunchKernelGGL(k_bw_probe, dim3(grid), dim3(kBlock), 0, h->stream, kind, n2,
+                       reinterpret_cast<const double2*>(b.p), reinterpret_cast<const double2*>(c.p),
+                       3.0, reinterpret_cast<double2*>(a.p));
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    const double moved = (kind == 1 ? 3.0 : 2.0) * 16.0 * (double)n2;
+    if (r > 0 && ms > 0.f) best = std::max(best, moved / (ms * 1e-3) / 1e9);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  a.release(); b.release(); c.release();
+  *gbs = best;
+  return 0;
+}
+
 int pcd_graph_enable(pcd_handle h, int on) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   h->graph_on = on != 0;

@@ -890,6 +890,23 @@ __global__ __launch_bounds__(kBlock) void k_normalize(
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_nrm = nrm;
 }
 
+// ---- bandwidth probe: the practical roof next to which the path is priced ---
+// 16 bytes per lane, unit stride, grid-stride loop: what a streaming kernel of
+// this engine can reach on this box ("confirm with a device-to-
+// device copy/triad microbench on the box and report THAT as the practical
+// roof").  kind 0: a = b (16 B/entry-pair moved: 1 read + 1 write);
+// kind 1: a = b + s c (triad: 2 reads + 1 write).
+__global__ __launch_bounds__(kBlock) void k_bw_probe(
+    int kind, int64_t n2, const double2* __restrict__ b,
+    const double2* __restrict__ c, double s, double2* __restrict__ a) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+       i += (int64_t)gridDim.x * kBlock) {
+    double2 v = b[i];
+    if (kind == 1) { const double2 w = c[i]; v.x += s * w.x; v.y += s * w.y; }
+    a[i] = v;
+  }
+}
+
 // ---- GMRES bookkeeping on the device ----------------------------------------
 // The Hessenberg column of iteration k arrives in hcol[0..k+1] (k+1 dots and
 // the norm of the orthogonalised vector).  One wave applies the stored Givens

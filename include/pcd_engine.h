@@ -234,6 +234,11 @@ int pcd_synchronize(pcd_handle h);
 /* capture the fixed-iteration fieldsplit apply into a hipGraph and replay it
  * (launch-bound at the 2D sizes: SURVEY 7, hard part 3); 0 = eager launches */
 int pcd_graph_enable(pcd_handle h, int on);
+/* Streaming bandwidth of this GPU measured by a kernel of this library
+ * (16 B per lane, unit stride): kind 0 copy, 1 triad, arrays of `bytes` each.
+ * The practical roof the roofline numbers are quoted next to. */
+int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps,
+                        double* gbs);
 
 /* ---- multi-GPU: contiguous row blocks per rank, RCCL over xGMI ----------- */
 

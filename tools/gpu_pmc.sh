@@ -1,0 +1,14 @@
+#!/bin/bash
+# The two PMC passes behind roofline.traffic (GPU box, repo root):
+#   tools/gpu_pmc.sh TAG [pmc_pcapply args]   ->  gpurun_out/TAG_pmc_roofline.json
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/${TAG}_pmc_$C
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/tools/pmc_pcapply.py "$@" > $OUT/${TAG}_pmc_$C.log 2>&1
+done
+cd $ROOT
+python3 tools/pmc_roofline.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE > $OUT/${TAG}_pmc_roofline.json 2> $OUT/${TAG}_pmc_roofline.err
+rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE

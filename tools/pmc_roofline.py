@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes of tools/pmc_pcapply.py into the JSON
+that bench.py quotes as `roofline.traffic` (and refuses to quote once
+csrc/pcd_kernels.hpp has changed: the file carries the hash of the kernels it
+was measured on).
+
+    pmc_roofline.py OUT_FETCH OUT_WRITE [n_u] > profiles/rNN_pmc_roofline.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  Calibration and correction
+as /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3) prescribes:
+separate passes; FETCH_SIZE reads one half of a streamed read on gfx950 - the
+factor is measured here on k_scale_dinv (known 16 n bytes read, 8 n written),
+not assumed; WRITE_SIZE is exact."""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dispatches(root, counter):
+    rows = []
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"),
+                       recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "") \
+                .replace("pcd::", "").strip()
+            rows.append((int(r["Dispatch_Id"]), name, int(r["Grid_Size"]),
+                         float(r["Counter_Value"]) * 1024.0,
+                         int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows.sort()
+    return rows
+
+
+def kernels_sha16():
+    h = hashlib.sha256()
+    for f in ("pcd_kernels.hpp", "pcd_engine.hip"):
+        h.update(open(os.path.join(ROOT, "fenapack_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    F = dispatches(sys.argv[1], "FETCH_SIZE")
+    W = dispatches(sys.argv[2], "WRITE_SIZE")
+    assert [r[1] for r in F] == [r[1] for r in W], "passes ran different kernels"
+    # (1) calibration on the 20 standalone k_scale_dinv of the finest level
+    sd = [i for i, r in enumerate(F) if r[1] == "k_scale_dinv"]
+    big = max(F[i][2] for i in sd)
+    sd = [i for i in sd if F[i][2] == big][-20:]
+    n_u = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    fetch_sd = sum(F[i][3] for i in sd) / len(sd)
+    write_sd = sum(W[i][3] for i in sd) / len(sd)
+    if n_u is None:
+        n_u = int(round(write_sd / 8.0))          # WRITE_SIZE is exact
+    corr = 16.0 * n_u / fetch_sd
+    # (2) the roofline kernel: k_cheb_step* with the largest grid
+    ks = [i for i, r in enumerate(F) if r[1].startswith("k_cheb_step")]
+    big = max(F[i][2] for i in ks)
+    ks = [i for i in ks if F[i][2] == big]
+    kname = F[ks[0]][1]
+    kread = corr * sum(F[i][3] for i in ks) / len(ks)
+    kwrite = sum(W[i][3] for i in ks) / len(ks)
+    kus = sum(F[i][4] for i in ks) / len(ks) / 1e3
+    # (3) whole PCApplies: k_gather ... k_scatter windows, the last ten
+    ends = [i for i, r in enumerate(F) if r[1] == "k_scatter"][-10:]
+    starts = [max(j for j, r in enumerate(F[:e]) if r[1] == "k_gather")
+              for e in ends]
+    per = []
+    for s, e in zip(starts, ends):
+        rd = corr * sum(F[i][3] for i in range(s, e + 1))
+        wr = sum(W[i][3] for i in range(s, e + 1))
+        per.append((rd, wr, e - s + 1))
+    out = {
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace "
+                   "--output-format csv -- python3 tools/pmc_pcapply.py "
+                   "(two separate passes), summarised by tools/pmc_roofline.py",
+        "kernels_sha16": kernels_sha16(),
+        "n_u": n_u,
+        "calibration": {"kernel": "k_scale_dinv", "launches": len(sd),
+                        "known_read_bytes": 16 * n_u,
+                        "known_write_bytes": 8 * n_u,
+                        "read_correction": corr,
+                        "write_check": write_sd / (8.0 * n_u)},
+        "roofline_kernel": {
+            "kernel": kname, "grid": big, "launches": len(ks),
+            "read_bytes_per_launch": kread, "write_bytes_per_launch": kwrite,
+            "traffic_bytes_per_launch": kread + kwrite,
+            "us_per_launch_under_the_counter_pass": kus},
+        "pcapply": {
+            "applies": len(per),
+            "launches_per_apply": per[-1][2],
+            "read_bytes_per_apply": sum(p[0] for p in per) / len(per),
+            "write_bytes_per_apply": sum(p[1] for p in per) / len(per),
+            "traffic_bytes_per_apply": sum(p[0] + p[1] for p in per) / len(per)},
+    }
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
