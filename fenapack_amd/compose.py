@@ -12,7 +12,8 @@ multiplied out once on the host and applied as ONE sparse product:
   polynomial ``q`` of degree ``k``: factored into <= 2 sparse factors;
 * one level of a multigrid V(nu1, nu2) cycle is two affine maps around the
   coarse solve:
-    down:  [x1; r_c] = W_d b          W_d = [H1; R (I - A H1)]
+    down:  x1 = H1 b (the ordinary smoothing kernels),
+           r_c = W_d b                W_d = R (I - A H1)
     up:    x = W_u [x1; r_c; e_c; b]  W_u = [G2 | 0 | G2 P | H2]
   where ``p_k = G x_in + H b`` is what ``nu`` smoothing steps do.
 
@@ -95,8 +96,10 @@ def vcycle_level(A, P, emin, emax, nu_pre, nu_post):
     """(W_d, W_u) of one multigrid level: operator ``A`` (n x n), prolongation
     ``P`` (n x nc), restriction ``P^T``.
 
-    ``W_d`` is (n + nc) x n;  ``W_u`` is n x (n + 2 nc + n) over the stacked
-    input ``[x1 (n); r_c (nc, unused); e_c (nc); b (n)]``."""
+    ``W_d = R (I - A H1)`` is nc x n: the coarse right-hand side straight from
+    ``b`` (the pre-smoothed ``x1 = H1 b`` itself comes from the ordinary
+    smoothing kernels);  ``W_u`` is n x (n + 2 nc + n) over the stacked input
+    ``[x1 (n); r_c (nc, unused); e_c (nc); b (n)]``."""
     A, P = sp.csr_matrix(A), sp.csr_matrix(P)
     n, nc = P.shape
     if nu_pre < 1 or nu_post < 1:
@@ -104,7 +107,7 @@ def vcycle_level(A, P, emin, emax, nu_pre, nu_post):
     I = sp.identity(n, format="csr")
     _, H1 = smoother_maps(A, emin, emax, nu_pre, True)
     R = P.T.tocsr()
-    Wd = sp.vstack([H1, R @ (I - A @ H1)], format="csr")
+    Wd = (R @ (I - A @ H1)).tocsr()
     G2, H2 = smoother_maps(A, emin, emax, nu_post, False)
     Wu = sp.hstack([G2, sp.csr_matrix((n, nc)), G2 @ P, H2], format="csr")
     return _clean(Wd), _clean(Wu)

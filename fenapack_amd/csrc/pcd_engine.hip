@@ -78,6 +78,7 @@ struct DCsr {
   int lpr = 8;
   int rb = 0;             // rows per workgroup of the CSR-stream kernels (0: n/a)
   bool long_rows = false; // >= 256 nonzeros per row on average: workgroup per row
+  bool wave_rows = false; // composed operator with 24..255 entries per row: wave per row
   // multi-component structure A = F (x) I_kron (kron = 2, 3; 0: none): F
   // stored once
   int kron = 0;
@@ -117,10 +118,12 @@ struct MgLevel {
   bool replicated = false, transition = false;
   int64_t n_coarse = 0;
   DBuf<double> x, t0, t1, r, b;
-  // Pre-composed form of this level (pcd_mg_set_fused): two sparse products
-  // around the coarse solve instead of nu_pre + nu_post + 3 launches,
-  //   [x1; r_c] = Wd b            T = [x1 (n) | r_c (n_c) | e_c (n_c)]
-  //   x = Wu [T | b]
+  // Pre-composed form of this level (pcd_mg_set_fused): three launches around
+  // the coarse solve instead of nu_pre + nu_post + 3,
+  //   x1  = pre-smoothing of b (the ordinary kernels)
+  //   r_c = Wd b    (Wd = R (I - A H1): residual + restriction in one product)
+  //   x   = Wu [T | b],  T = [x1 (n) | r_c (n_c) | e_c (n_c)]
+  //         (prolongation + correction + all post-smoothing steps)
   // valid for the values / smoother bounds it was composed from: any update
   // of those drops it (the step-by-step cycle takes over) until it is set again
   DCsr Wd, Wu;
@@ -248,6 +251,7 @@ static int g_max_chunks = 2;            // PCD_MAX_CHUNKS: LDS-tile passes per r
 // while they are handed over, small row blocks may take this many passes
 // through the tile instead of falling back to the CSR-vector kernels.
 static int g_chunks_override = 0;
+static bool g_want_wave = false;        // the operator being handed over is a composed one
 // rows per workgroup: the largest RB whose every row block fits the LDS tile
 // and that still yields `g_min_wgs` workgroups (small operators then take
 // smaller row blocks: more, shorter workgroups).  Blocks of 64 rows and
@@ -398,8 +402,14 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
                                 const double* add, double* y,
                                 const double* ghost, int64_t ncols) {
   const int nn = (int)(A.nrows / NC);
-  const int g = grid_stream(nn, A.rb2);
   const int nloc = (int)(ncols / NC);
+  if (A.wave_rows) {
+    const int gw = (int)std::min<int64_t>((nn + 3) / 4, 1 << 16);
+    hipLaunchKernelGGL((k_spmv_wc<MODE, NC>), dim3(gw), dim3(kBlock), 0, h->stream,
+                       nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y);
+    return;
+  }
+  const int g = grid_stream(nn, A.rb2);
   switch (A.rb2) {
     case 256: hipLaunchKernelGGL((k_spmv_sc<256, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
                                  nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
@@ -423,6 +433,10 @@ static void launch_spmv_any(Engine* h, const DCsr& A, const double* x,
   } else if (A.long_rows) {
     const int g = (int)std::min<int64_t>(A.nrows, 65535);
     hipLaunchKernelGGL((k_spmv_long<MODE>), dim3(g), dim3(kBlock), 0, h->stream,
+                       (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
+  } else if (A.wave_rows) {
+    const int g = (int)std::min<int64_t>((A.nrows + 3) / 4, 1 << 16);
+    hipLaunchKernelGGL((k_spmv_w<MODE>), dim3(g), dim3(kBlock), 0, h->stream,
                        (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
   } else if (A.rb) {
     const int g = grid_stream(A.nrows, A.rb);
@@ -802,10 +816,21 @@ static int mg_vcycle(Engine* h, const DCsr& Afine, Inner& s, int l,
   const DCsr& A = (l == (int)s.mg.size() - 1) ? Afine : L.A;
   MgLevel& C = s.mg[l - 1];
   if (L.fused) {
-    // pre-composed level: [x1; r_c] = Wd b;  e_c = cycle(r_c);  x = Wu [T | b]
+    // pre-composed level: x1 = smooth(b); r_c = Wd b; e_c = cycle(r_c);
+    // x = Wu [T | b]
     const int64_t n = A.nrows, nc = L.P.ncols;
     double* T = L.T.p;
-    CHK(spmv(h, L.Wd, b, T));
+    {
+      // ring arranged so that the smoothed vector lands in T[0, n)
+      const int last = (s.nu_pre - 1) % 3;
+      double* ring[3];
+      ring[last] = T; ring[(last + 1) % 3] = L.t0.p; ring[(last + 2) % 3] = L.t1.p;
+      double* px = nullptr;
+      CHK(mg_smooth(h, A, L.emin, L.emax, s.nu_pre, b, ring, true, &px));
+      if (px != T)
+        HIPCHK(hipMemcpyAsync(T, px, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    CHK(spmv(h, L.Wd, b, T + n));
     double* pe = nullptr;
     CHK(mg_vcycle(h, Afine, s, l - 1, T + n, &pe, T + n + nc));
     if (pe != T + n + nc)
@@ -1152,7 +1177,7 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     rpc[s + 1] = (int32_t)cc.size();
   }
   const int rb2 = rb_for(nn, rpc.data(), nc == 3 ? tile_c<3>() : tile_c<2>());
-  if (!rb2) return 0;
+  if (!rb2 && !g_want_wave) return 0;    // (the wave-per-row kernels need no tile)
   A.nnz2 = (int64_t)cc.size();
   CHK(A.rowptr2.ensure(nn + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2));
   CHK(A.kron_pos.ensure(nc * A.nnz2)); CHK(A.kron_flag.ensure(1));
@@ -1186,6 +1211,7 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.lpr = choose_lpr(A);
   A.rb = g_force_vector ? 0 : choose_rb(nrows, rowptr);
   A.long_rows = A.rb == 0 && nrows > 0 && nnz / nrows >= 256;
+  A.wave_rows = g_want_wave && !A.long_rows && nrows > 0 && nnz / nrows >= 24;
   CHK(detect_kron(h, A, nrows, ncols, rowptr, col, val != nullptr));
   return 0;
 }
@@ -1640,7 +1666,7 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
   return 0;
 }
 
-// Pre-composed form of one level (see MgLevel): Wd is (n + n_c) x n, Wu is
+// Pre-composed form of one level (see MgLevel): Wd is n_c x n, Wu is
 // n x (2 n + 2 n_c) over [x1 | r_c | e_c | b].  wd_rowptr == NULL drops it.
 // Partitioned levels of a multi-GPU run keep the step-by-step cycle (their
 // kernels exchange halos); replicated ones may be fused.
@@ -1666,17 +1692,17 @@ int pcd_mg_set_fused(pcd_handle h, int slot, int level,
   if (!wd_col || !wd_val || !wu_rowptr || !wu_col || !wu_val)
     return fail(PCD_ERR_ARG, "mg_set_fused: null arrays");
   const int64_t n = M.P.nrows, nc = M.P.ncols;
-  if (wd_rows != n + nc || wd_cols != n || wu_rows != n || wu_cols != 2 * n + 2 * nc)
+  if (wd_rows != nc || wd_cols != n || wu_rows != n || wu_cols != 2 * n + 2 * nc)
     return fail(PCD_ERR_ARG, "mg_set_fused: level %d is %lld -> %lld, got Wd %lld x %lld, Wu %lld x %lld",
                 level, (long long)nc, (long long)n, (long long)wd_rows, (long long)wd_cols,
                 (long long)wu_rows, (long long)wu_cols);
   if (s.nu_pre < 1 || s.nu_post < 1)
     return fail(PCD_ERR_STATE, "mg_set_fused: needs at least one pre- and one post-smoothing step");
   HIPCHK(hipStreamSynchronize(h->stream));
-  g_chunks_override = 64;
+  g_chunks_override = 64; g_want_wave = true;
   int rc_up = upload_csr(h, M.Wd, wd_rows, wd_cols, wd_rowptr, wd_col, wd_val, nullptr);
   if (!rc_up) rc_up = upload_csr(h, M.Wu, wu_rows, wu_cols, wu_rowptr, wu_col, wu_val, nullptr);
-  g_chunks_override = 0;
+  g_chunks_override = 0; g_want_wave = false;
   CHK(rc_up);
   M.Wd.replicated = M.Wu.replicated = h->comm != nullptr;
   M.fused = true;
@@ -1711,9 +1737,9 @@ int pcd_set_inner_factor(pcd_handle h, int slot, int k, int nfactors, int64_t n,
   if (h->comm) sp = (slot == PCD_KSP_A00) ? &h->sp_u : &h->sp_p;
   if (h->comm && sp->total() != n)
     return fail(PCD_ERR_ARG, "set_inner_factor: size %lld does not match the partitioned space", (long long)n);
-  g_chunks_override = 64;
+  g_chunks_override = 64; g_want_wave = true;
   const int rc_up = upload_global(h, s.chain[k], sp, sp, n, n, rowptr, colidx, vals, nullptr);
-  g_chunks_override = 0;
+  g_chunks_override = 0; g_want_wave = false;
   CHK(rc_up);
   if (s.chain[k].nrows != A.nrows)
     return fail(PCD_ERR_ARG, "set_inner_factor: factor has %lld rows, the operator %lld",

@@ -890,6 +890,85 @@ __global__ __launch_bounds__(kBlock) void k_normalize(
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_nrm = nrm;
 }
 
+// ==========================================================================
+// Wave-per-row kernels for operators with LONG rows (pre-composed multigrid
+// operators: 30 ... 300 entries per row).  One wave64 owns one row: lanes
+// stride over its entries (coalesced 12-byte records), gather, and a shuffle
+// tree sums - no LDS, no workgroup barrier, 8 waves per SIMD in flight.  The
+// CSR-stream kernels above lose here: a row block of 32 such rows overflows
+// the LDS tile several times over and serialises its passes.
+// ==========================================================================
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_spmv_w(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const XVec x, const double* add,
+    double* y) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = kBlock / 64;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < nrows;
+       row += gridDim.x * wpb) {
+    const int b = rowptr[row], e = rowptr[row + 1];
+    double s0 = 0.0, s1 = 0.0;
+    int k = b + lane;
+    for (; k + 64 < e; k += 128) {           // two independent records in flight
+      const int c0 = col[k], c1 = col[k + 64];
+      const double v0 = val[k], v1 = val[k + 64];
+      s0 += v0 * x(c0); s1 += v1 * x(c1);
+    }
+    if (k < e) s0 += val[k] * x(col[k]);
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0) {
+      if (MODE == 0) y[row] = s;
+      if (MODE == 1) y[row] = add[row] + s;
+      if (MODE == 2) y[row] = add[row] - s;
+      if (MODE == 3) y[row] = -s;
+    }
+  }
+}
+
+template <int MODE, int NC>
+__global__ __launch_bounds__(kBlock) void k_spmv_wc(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* x_, const double* ghost_,
+    int nloc, const double* add_, double* y_) {
+  const XVecC<NC> x{vc<NC>(x_), vc<NC>(ghost_), nloc};
+  const VecC<NC>* add = vc<NC>(add_);
+  VecC<NC>* y = vc<NC>(y_);
+  const int lane = threadIdx.x & 63;
+  const int wpb = kBlock / 64;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < nrows;
+       row += gridDim.x * wpb) {
+    const int b = rowptr[row], e = rowptr[row + 1];
+    VecC<NC> s = vzero<NC>();
+    int k = b + lane;
+    for (; k + 64 < e; k += 128) {
+      const int c0 = col[k], c1 = col[k + 64];
+      const double v0 = val[k], v1 = val[k + 64];
+      const VecC<NC> x0 = x(c0), x1 = x(c1);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += v0 * x0.c[i] + v1 * x1.c[i];
+    }
+    if (k < e) {
+      const double v0 = val[k];
+      const VecC<NC> x0 = x(col[k]);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += v0 * x0.c[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] = wave_sum(s.c[i]);
+    if (lane == 0) {
+      VecC<NC> o;
+      VecC<NC> a = vzero<NC>();
+      if (MODE == 1 || MODE == 2) a = add[row];
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i]
+                                        : (MODE == 2 ? a.c[i] - s.c[i] : -s.c[i]));
+      y[row] = o;
+    }
+  }
+}
+
 // ---- bandwidth probe: the practical roof next to which the path is priced ---
 // 16 bytes per lane, unit stride, grid-stride loop: what a streaming kernel of
 // this engine can reach on this box ("confirm with a device-to-

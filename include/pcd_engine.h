@@ -178,8 +178,10 @@ int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
  * re-association (tests: 1e-11 against the step-by-step path and the oracle).
  *
  * pcd_mg_set_fused: level `level` (>= 1) of slot's hierarchy as
- *   [x1; r_c] = Wd b  and  x = Wu [x1 | r_c | e_c | b]
- *   (Wd: (n + n_c) x n;  Wu: n x (2n + 2n_c)); wd_rowptr == NULL drops it.
+ *   r_c = Wd b  (Wd = R (I - A H1): residual + restriction of the pre-smoothed
+ *   x1 = H1 b, which the ordinary kernels still compute) and
+ *   x = Wu [x1 | r_c | e_c | b]  (prolongation, correction, post-smoothing)
+ *   (Wd: n_c x n;  Wu: n x (2n + 2n_c)); wd_rowptr == NULL drops it.
  *   Any later update of that level's values or smoother bounds drops it too.
  * pcd_set_inner_factor: factor k of nfactors of x = W_{nfactors-1} ... W_0 b
  *   for pc_type PCD_PC_EXPLICIT (e.g. Chebyshev(5)+Jacobi on the constant
