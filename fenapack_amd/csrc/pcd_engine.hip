@@ -1211,7 +1211,13 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.lpr = choose_lpr(A);
   A.rb = g_force_vector ? 0 : choose_rb(nrows, rowptr);
   A.long_rows = A.rb == 0 && nrows > 0 && nnz / nrows >= 256;
-  A.wave_rows = g_want_wave && !A.long_rows && nrows > 0 && nnz / nrows >= 24;
+  // measured (profiles/r02_f_timeline.txt): a wave per row wins on the few,
+  // very long rows of a residual-restriction product (150-300 entries: 7 us
+  // against 13-38 us for the stream kernel's serialised tile passes) and
+  // loses on the many 30-80-entry rows of an up-sweep product (29 against
+  // 13 us at 10^5 rows): half of its lanes idle and every row pays its own
+  // dependent chain
+  A.wave_rows = g_want_wave && !A.long_rows && nrows > 0 && nnz / nrows >= 96;
   CHK(detect_kron(h, A, nrows, ncols, rowptr, col, val != nullptr));
   return 0;
 }
