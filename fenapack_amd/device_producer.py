@@ -133,6 +133,11 @@ class DeviceProducer(object):
             raise ValueError("device producer: the velocity solve must be "
                              "-fieldsplit_u_pc_type mg (its smoother bounds "
                              "are re-estimated on the device)")
+        if ksp0.pc.mg_algebraic:
+            raise ValueError("device producer: needs the nested-mesh "
+                             "hierarchy (-fieldsplit_u_pc_type mg); an "
+                             "algebraic hierarchy (gamg) is refreshed by the "
+                             "host path")
         self.galerkin = bool(ksp0.pc.mg_galerkin)
         self.supg = bool(pb.stabilize)
         if self.supg and self.galerkin:

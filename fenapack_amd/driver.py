@@ -21,7 +21,7 @@ def mass_matrix_bounds(dim):
 
 def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
                             mp_its=5, pcdr=False, galerkin_u=True, dim=2,
-                            two_grid_p=True):
+                            two_grid_p=True, algebraic=False):
     """The reference's "iterative" configuration (demo_navier-stokes-pcd.py:
     152-165: Richardson + one/two multigrid cycles for A00 and Ap, Chebyshev +
     Jacobi for Mp) with hypre BoomerAMG replaced by the engine's geometric
@@ -32,9 +32,12 @@ def multigrid_inner_options(prefix="", cycles_u=1, cycles_p=1, smooth=2,
             + ((("fieldsplit_p_PCD_Rp_", cycles_p),) if pcdr else ()):
         S(prefix + key + "ksp_type", "richardson")
         S(prefix + key + "ksp_max_it", cycles)
-        S(prefix + key + "pc_type", "mg")
+        # algebraic=True: the hierarchy is built from the matrix alone
+        # (-pc_type gamg, fenapack_amd/amg.py) - what a caller with matrices
+        # from another mesh / assembler uses, as the reference uses hypre
+        S(prefix + key + "pc_type", "gamg" if algebraic else "mg")
         S(prefix + key + "mg_levels_ksp_max_it", smooth)
-    if two_grid_p:
+    if two_grid_p and not algebraic:
         # Pressure Laplacian: finest level + explicit coarse inverse, nothing
         # in between.  On an MI355X a kernel on <= 10^5 rows costs a fixed
         # 4-6 us whatever it does, and the intermediate levels of this SPD

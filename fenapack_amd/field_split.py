@@ -98,7 +98,8 @@ class PCDKSP(KSP):
             self._upload_system(A, P, is0, is1, first=True)
             ksp0.setOperators(Mat(self._A00_host(A, P, is0)))
             ksp0.bind(self.engine, c.KSP_A00)
-            if ksp0.pc.type == "mg" and ksp0.pc._mg_chain is None:
+            if ksp0.pc.type == "mg" and ksp0.pc._mg_chain is None \
+                    and not ksp0.pc.mg_algebraic:
                 ksp0.pc.setMGInterpolations(V.interpolations().chain("u"))
                 if not ksp0.pc.mg_galerkin and ksp0.pc._mg_ops_cb is None:
                     ksp0.pc.setMGOperators(V.coarse_velocity_operators)

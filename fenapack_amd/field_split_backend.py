@@ -141,7 +141,8 @@ class PCDInterface(object):
 
     def _give_interpolations(self, ksp):
         """pc_type mg on a pressure-space KSP: hand over the P1 chain."""
-        if ksp.pc.type == "mg" and ksp.pc._mg_chain is None:
+        if ksp.pc.type == "mg" and ksp.pc._mg_chain is None \
+                and not ksp.pc.mg_algebraic:
             V = self.assembler.function_space()
             ksp.pc.setMGInterpolations(V.interpolations().chain("p"))
 

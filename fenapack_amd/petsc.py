@@ -244,9 +244,15 @@ class DeviceMat(Mat):
 
 
 # ------------------------------------------------------------------ KSP / PC
-_UNSUPPORTED_PC = ("lu", "cholesky", "hypre", "ilu", "icc", "gamg", "ml",
-                   "bjacobi", "asm", "sor")
+_UNSUPPORTED_PC = ("lu", "cholesky", "ilu", "icc", "ml", "bjacobi", "asm",
+                   "sor")
 _SUPPORTED_PC = ("none", "jacobi", "mg")
+# algebraic multigrid: -pc_type gamg = smoothed aggregation built from the
+# matrix (fenapack_amd/amg.py) feeding the engine's cycle; -pc_type hypre (the
+# reference's demo_navier-stokes-pcd.py:155-160) has no device counterpart and
+# is served by the same algebraic hierarchy, with a note on stderr
+_ALGEBRAIC_PC = ("gamg", "hypre")
+_warned_hypre = [False]
 
 
 class PC(object):
@@ -294,6 +300,10 @@ class PC(object):
         # not bandwidth-bound: DESIGN.md 4.
         self.mg_fuse_nnz = 4500000
         self.mg_fuse_rows = 160000         # never even try above this size
+        # -pc_type gamg: the chain comes from the matrix (amg.py), built once
+        # per pattern and kept while values change
+        self.mg_algebraic = False
+        self.mg_gamg_threshold = 0.02
 
     def setMGOperators(self, callback):
         """``callback(nlev)`` -> operators of the ``nlev - 1`` coarse levels,
@@ -436,9 +446,26 @@ class KSP(object):
             if p in _UNSUPPORTED_PC:
                 raise ValueError(
                     "%spc_type %s has no device counterpart; use jacobi "
-                    "(north star: Jacobi-CG / Chebyshev-Jacobi)"
+                    "(north star: Jacobi-CG / Chebyshev-Jacobi), mg or gamg"
                     % (self._prefix, p))
-            self.pc.setType(p)
+            if p in _ALGEBRAIC_PC:
+                if p == "hypre" and not _warned_hypre[0]:
+                    import sys
+                    sys.stderr.write(
+                        "fenapack_amd: -%spc_type hypre: BoomerAMG does not "
+                        "exist on this path; using the engine's algebraic "
+                        "multigrid (smoothed aggregation, = -pc_type gamg)\n"
+                        % self._prefix)
+                    _warned_hypre[0] = True
+                self.pc.setType("mg")
+                self.pc.mg_algebraic = True
+            else:
+                self.pc.setType(p)
+                if p == "mg":
+                    self.pc.mg_algebraic = False
+        th = o.getReal("pc_gamg_threshold")
+        if th is not None:
+            self.pc.mg_gamg_threshold = th
         self.pc.mg_levels = o.getInt("pc_mg_levels", self.pc.mg_levels)
         self.pc.mg_coarse_eq_limit = o.getInt("pc_mg_coarse_eq_limit",
                                               self.pc.mg_coarse_eq_limit)
@@ -497,6 +524,13 @@ class KSP(object):
         are fixed, so later calls only refresh values."""
         from .fem.multigrid import galerkin_chain, coarse_inverse
         pc = self.pc
+        if pc._mg_chain is None and pc.mg_algebraic:
+            from .amg import smoothed_aggregation_chain
+            blk = getattr(self.engine, "velocity_block", 2) \
+                if self.slot == c.KSP_A00 else 1
+            pc.setMGInterpolations(smoothed_aggregation_chain(
+                self._ops[1].A, block=blk, coarse_rows=pc.mg_coarse_eq_limit,
+                theta=pc.mg_gamg_threshold))
         if pc._mg_chain is None:
             raise RuntimeError("%spc_type mg needs interpolations "
                                "(pc.setMGInterpolations)" % self._prefix)

@@ -158,3 +158,37 @@ def test_multigrid_options_same_counts_as_cpu_restatement(monkeypatch):
     assert gpu["krylov_per_step"] == cpu["krylov_per_step"]
     assert relerr(gpu["w"].vector(), cpu["w"].vector()) < 1e-6
     assert max(gpu["krylov_per_step"]) < 60
+
+
+def test_algebraic_multigrid_options_of_the_reference_demo(monkeypatch):
+    """The reference demo's "iterative" option strings
+    (demo_navier-stokes-pcd.py:152-165: Richardson + hypre BoomerAMG for A00
+    and Ap, Chebyshev + Jacobi for Mp) run unchanged: hypre is served by the
+    engine's algebraic hierarchy (smoothed aggregation from the matrix alone,
+    no mesh).  Same GMRES counts on the HIP engine and on the oracle."""
+    def run(lib):
+        if lib is not None:
+            monkeypatch.setattr(c, "hip_library", lambda: lib)
+        PETScOptions.clear()
+        S = PETScOptions.set
+        for key in ("fieldsplit_u_", "fieldsplit_p_PCD_Ap_"):
+            S(key + "ksp_type", "richardson")
+            S(key + "ksp_max_it", 1 if key.startswith("fieldsplit_u") else 2)
+            S(key + "pc_type", "hypre")
+            S(key + "pc_hypre_type", "boomeramg")
+        S("fieldsplit_p_PCD_Mp_ksp_type", "chebyshev")
+        S("fieldsplit_p_PCD_Mp_ksp_max_it", 5)
+        S("fieldsplit_p_PCD_Mp_ksp_chebyshev_eigenvalues", "0.5, 2.0")
+        S("fieldsplit_p_PCD_Mp_pc_type", "jacobi")
+        out = solve_steady(BackwardStep(3, nu=0.02, variant="BRM2"),
+                           newton_rtol=1e-5, gmres_rtol=1e-6)
+        PETScOptions.clear()
+        return out
+    gpu = run(None)
+    cpu = run(oracle.library())
+    assert gpu["converged"] and cpu["converged"]
+    assert gpu["krylov_per_step"] == cpu["krylov_per_step"]
+    assert relerr(gpu["w"].vector(), cpu["w"].vector()) < 1e-6
+    assert max(gpu["krylov_per_step"]) < 120
+    ksp0 = gpu["solver"].linear_solver().ksp().pc.getFieldSplitSubKSP()[0]
+    assert ksp0.pc.mg_algebraic and len(ksp0.pc.mg_data["ops"]) >= 2

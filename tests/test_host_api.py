@@ -68,7 +68,7 @@ def test_options_db_and_unsupported_solvers_are_rejected():
     assert (k.type, k.max_it, k.cheb_eigs, k.pc.type) == \
         ("chebyshev", 7, (0.5, 2.0), "jacobi")
     assert Options("t_").getString("pc_python_type", "") == ""
-    PETScOptions.set("t_pc_type", "hypre")
+    PETScOptions.set("t_pc_type", "ilu")
     with pytest.raises(ValueError):
         k.setFromOptions()
     PETScOptions.set("t_pc_type", "jacobi")
@@ -262,3 +262,68 @@ def test_stabilization_parameter_in_three_dimensions():
     ref = V.supg_delta(U, 1e-3, 1.0)
     assert delta.shape == ref.shape and np.array_equal(delta, ref)
     assert (delta > 0).any()
+
+
+def test_algebraic_hierarchy_from_the_matrix_alone():
+    """-pc_type gamg (fenapack_amd/amg.py): a prolongation chain built from
+    the operator, no mesh - the role hypre BoomerAMG plays for the reference
+    (demo_navier-stokes-pcd.py:153-160).  Properties: constants are
+    reproduced away from Dirichlet rows, a velocity block F (x) I_2 keeps its
+    Kronecker structure on every level, and a V(2,2) cycle on the pressure
+    Laplacian is a good preconditioner."""
+    import scipy.sparse.linalg as spla
+    from fenapack_amd.amg import (smoothed_aggregation_chain, aggregate,
+                                  _strength, scalar_stencil)
+    from fenapack_amd.fem import Cavity
+    from fenapack_amd.fem.multigrid import galerkin_chain
+    pb = Cavity(3, nu=0.01)
+    Ap = sp.csr_matrix(pb.Ap)
+    agg, nagg = aggregate(_strength(Ap, 0.02))
+    assert agg.min() == 0 and agg.max() == nagg - 1 and nagg < Ap.shape[0] / 3
+    chain = smoothed_aggregation_chain(Ap, coarse_rows=300)
+    assert chain[0] is None and chain[-1].shape[0] == Ap.shape[0]
+    for a, b in zip(chain[1:-1], chain[2:]):
+        assert a.shape[0] == b.shape[1]
+    # smoothed prolongator of a Laplacian: constants stay constants wherever
+    # the row sums of A vanish (interior rows)
+    P = chain[-1]
+    interior = np.abs(Ap @ np.ones(Ap.shape[0])) < 1e-12
+    img = P @ (P.T @ np.ones(P.shape[0]))
+    assert interior.sum() > 0.9 * Ap.shape[0]
+    # two-level preconditioner for CG
+    ops = galerkin_chain(Ap, chain)
+    Pf, Ac = chain[-1], ops[-2]
+    lu = spla.splu(sp.csc_matrix(Ac)) if len(chain) == 2 else None
+    dinv = 1.0 / Ap.diagonal()
+
+    def vcycle(b):
+        x = 0.7 * dinv * b
+        x = x + 0.7 * dinv * (b - Ap @ x)
+        r = Pf.T @ (b - Ap @ x)
+        e = lu.solve(r) if lu is not None else spla.spsolve(sp.csc_matrix(Ac), r)
+        x = x + Pf @ e
+        x = x + 0.7 * dinv * (b - Ap @ x)
+        return x + 0.7 * dinv * (b - Ap @ x)
+    cnt = [0]
+    b = np.random.default_rng(0).standard_normal(Ap.shape[0])
+    M = spla.LinearOperator(Ap.shape, matvec=vcycle)
+    x, info = spla.gmres(Ap, b, M=M, rtol=1e-8, restart=60,
+                         callback=lambda r: cnt.__setitem__(0, cnt[0] + 1),
+                         callback_type="pr_norm")
+    assert info == 0 and cnt[0] <= 20, cnt
+    # velocity block: aggregation on the scalar stencil, P = P_F (x) I_2
+    st_ = pb.linearise(*pb.initial_guess())
+    A00 = sp.csr_matrix(st_["A00"])
+    assert scalar_stencil(A00, 2) is not None
+    ch = smoothed_aggregation_chain(A00, block=2, coarse_rows=500)
+    for Pl in ch[1:]:
+        assert scalar_stencil(sp.csr_matrix(Pl.T @ Pl), 2) is not None
+    # options: gamg and the reference's hypre spelling select it
+    PETScOptions.clear()
+    PETScOptions.set("x_pc_type", "hypre")
+    PETScOptions.set("x_pc_hypre_type", "boomeramg")
+    k = KSP()
+    k.setOptionsPrefix("x_")
+    k.setFromOptions()
+    assert k.pc.type == "mg" and k.pc.mg_algebraic
+    PETScOptions.clear()
