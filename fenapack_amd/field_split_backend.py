@@ -52,23 +52,28 @@ class PCDInterface(object):
         self._bcs_uploaded = False
 
     # -- BCs (field_split_backend.py:62-64, 294-308) -------------------------
-    def _subbcs_upload(self):
+    def subfield_bc_arrays(self):
+        """``(indices int32, values float64)`` of the PCD Dirichlet condition
+        in the contiguous pressure numbering - what ``pcd_set_bc`` takes
+        (``SubfieldBC.h:92-160`` for every bc of ``bcs_pcd``, merged the way
+        ``apply_bcs`` applies them: one after the other with INSERT, so on a
+        duplicate index the last bc wins; ``field_split_backend.py:294-308``)."""
         subbcs = getattr(self, "_subbcs", None)
         if subbcs is None:
             bcs = self.assembler.pcd_bcs()
             bcs = bcs if isinstance(bcs, (list, tuple)) else [bcs]
             self._subbcs = subbcs = [SubfieldBC(bc, self.is_p) for bc in bcs]
+        merged = {}
+        for bc in subbcs:
+            merged.update(bc.get_boundary_values())
+        idx = np.fromiter(merged.keys(), dtype=np.int32, count=len(merged))
+        val = np.fromiter(merged.values(), dtype=np.float64,
+                          count=len(merged))
+        return idx, val
+
+    def _subbcs_upload(self):
         if not self._bcs_uploaded:
-            # bc.apply(vec) one after the other == INSERT in list order:
-            # on duplicates the last one wins
-            merged = {}
-            for bc in subbcs:
-                merged.update(bc.get_boundary_values())
-            idx = np.fromiter(merged.keys(), dtype=np.int32,
-                              count=len(merged))
-            val = np.fromiter(merged.values(), dtype=np.float64,
-                              count=len(merged))
-            self.engine.set_bc(idx, val)
+            self.engine.set_bc(*self.subfield_bc_arrays())
             self._bcs_uploaded = True
 
     def apply_pcd_bcs(self, vec):

@@ -16,10 +16,26 @@ from .petsc import KSP, PC
 from .timing import timed
 
 
-def _dev(v):
-    """Device buffer behind a vector argument of ``apply``."""
+def _buffer(v, writable=False):
+    """(buffer, mem flag) behind a vector argument of ``apply``:
+
+    * this package's device ``Vec`` (``.t`` = torch tensor) or a bare torch
+      CUDA tensor -> device pointer, the call is enqueued on the engine's
+      stream;
+    * a petsc4py ``Vec`` (what PETSc hands a PCPYTHON context: it has
+      ``getArray``) -> its host array, the engine copies in and out and
+      synchronises (a PETSc built ``--with-hip`` can pass the device pointer
+      instead: INTEGRATION.md);
+    * a numpy array -> host pointer."""
     t = getattr(v, "t", None)
-    return v if t is None else t
+    if t is not None:
+        v = t
+    if hasattr(v, "data_ptr"):
+        return v, (c.MEM_DEVICE if v.is_cuda else c.MEM_HOST)
+    if hasattr(v, "getArray"):                      # petsc4py.PETSc.Vec
+        return (v.getArray() if writable
+                else v.getArray(readonly=True)), c.MEM_HOST
+    return v, c.MEM_HOST
 
 
 class BasePCDPC(object):
@@ -85,11 +101,14 @@ class BasePCDPC(object):
 
     def apply(self, pc, x, y):
         """``y = -S^-1 x``: the fused HIP path (x borrowed, y overwritten).
-        ``x`` / ``y``: the package's device ``Vec`` (``.t`` = torch tensor), a
-        torch tensor, or anything exposing the device pointer the way a
-        petsc4py ``Vec`` of type ``hip`` does (``getCUDAHandle``-style: see
-        INTEGRATION.md)."""
-        self.interface.engine.apply(_dev(x), _dev(y), c.MEM_DEVICE)
+        ``x`` / ``y``: this package's device ``Vec``, a torch tensor, a numpy
+        array or a petsc4py ``Vec`` (see ``_buffer``)."""
+        xb, mx = _buffer(x)
+        yb, my = _buffer(y, writable=True)
+        if mx != my:
+            raise TypeError("apply: x and y must both live on the device or "
+                            "both on the host")
+        self.interface.engine.apply(xb, yb, mx)
 
     def apply_by_parts(self, pc, x, y):
         """Testing aid: the same operator assembled from per-operation ABI

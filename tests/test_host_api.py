@@ -327,3 +327,52 @@ def test_algebraic_hierarchy_from_the_matrix_alone():
     k.setFromOptions()
     assert k.pc.type == "mg" and k.pc.mg_algebraic
     PETScOptions.clear()
+
+
+def test_apply_accepts_what_petsc_hands_a_pcpython_context():
+    """PETSc calls ``ctx.apply(pc, x, y)`` with petsc4py Vecs (host arrays
+    behind ``getArray``); the context must route them as HOST pointers, this
+    package's device Vecs as DEVICE pointers."""
+    from fenapack_amd import PCDPC_BRM1
+    from fenapack_amd import _cabi
+    from fenapack_amd.preconditioners import _buffer
+
+    class PetscVec(object):                # the two methods apply needs
+        def __init__(self, n):
+            self.a = np.arange(float(n))
+
+        def getArray(self, readonly=False):
+            v = self.a.view()
+            v.setflags(write=not readonly)
+            return v
+
+    seen = []
+
+    class FakeEngine(object):
+        def apply(self, x, y, mem):
+            seen.append((type(x).__name__, x.flags.writeable,
+                         y.flags.writeable, mem))
+            y[:] = 2.0 * x
+
+    class FakeInterface(object):
+        engine = FakeEngine()
+    ctx = PCDPC_BRM1()
+    ctx.init_pcd(FakeInterface())
+    x, y = PetscVec(4), PetscVec(4)
+    ctx.apply(None, x, y)
+    assert seen == [("ndarray", False, True, _cabi.MEM_HOST)]
+    assert np.array_equal(y.a, 2.0 * x.a)
+    buf, mem = _buffer(np.zeros(3))
+    assert mem == _cabi.MEM_HOST
+
+
+def test_subfield_bc_arrays_merge_in_application_order():
+    pb = BackwardStep(1)
+    w, forms = navier_stokes_forms(pb)
+    a = PCDAssembler(**forms)
+    V = pb.space
+    iface = PCDInterface(a, Mat(), IS(V.is_u), IS(V.is_p))
+    idx, val = iface.subfield_bc_arrays()
+    assert idx.dtype == np.int32 and val.dtype == np.float64
+    assert np.array_equal(np.sort(idx), np.sort(pb.bc_p_idx))
+    assert np.all(val == 0.0)
