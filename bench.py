@@ -244,9 +244,13 @@ def main():
         PETScOptions.set("fieldsplit_p_PCD_Ap_pc_mg_skip_levels", args.skip_p)
     from fenapack_amd.parallel import Comm
     comm = Comm.world()
+    # tolerances 0: EXACTLY `picard_steps` nonlinear iterations, so that the
+    # frozen operators always carry convection (on fine 3-D meshes the first,
+    # Stokes-like step already meets the demo's 1e-5 residual reduction)
     w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150,
-                              newton_rtol=1e-5, max_newton=args.picard_steps,
+                              newton_rtol=0.0, max_newton=args.picard_steps,
                               device=local, comm=comm)
+    nls.parameters["absolute_tolerance"] = 0.0
     nls.parameters["error_on_nonconvergence"] = False
     # M2: real Picard steps from w = 0 on the GPU; the matrices of the last
     # one (Picard iterate `picard_steps`) are the frozen microbench state

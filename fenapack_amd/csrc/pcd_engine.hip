@@ -1217,7 +1217,10 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   // loses on the many 30-80-entry rows of an up-sweep product (29 against
   // 13 us at 10^5 rows): half of its lanes idle and every row pays its own
   // dependent chain
-  A.wave_rows = g_want_wave && !A.long_rows && nrows > 0 && nnz / nrows >= 96;
+  // ... and on many rows (the up-sweep product of a 26 000-node level, 150
+  // entries per row: 15 against 12 us), so: long rows AND few of them
+  A.wave_rows = g_want_wave && !A.long_rows && nrows > 0 && nnz / nrows >= 96 &&
+                nrows <= 3 * 8192;
   CHK(detect_kron(h, A, nrows, ncols, rowptr, col, val != nullptr));
   return 0;
 }

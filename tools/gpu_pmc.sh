@@ -10,5 +10,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/tools/pmc_pcapply.py "$@" > $OUT/${TAG}_pmc_$C.log 2>&1
 done
 cd $ROOT
-python3 tools/pmc_roofline.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE > $OUT/${TAG}_pmc_roofline.json 2> $OUT/${TAG}_pmc_roofline.err
+NU=$(grep -o "n_u [0-9]*" $OUT/${TAG}_pmc_FETCH_SIZE.log | tail -1 | cut -d" " -f2)
+python3 tools/pmc_roofline.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $NU > $OUT/${TAG}_pmc_roofline.json 2> $OUT/${TAG}_pmc_roofline.err
 rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE

@@ -56,7 +56,8 @@ def main():
     fetch_sd = sum(F[i][3] for i in sd) / len(sd)
     write_sd = sum(W[i][3] for i in sd) / len(sd)
     if n_u is None:
-        n_u = int(round(write_sd / 8.0))          # WRITE_SIZE is exact
+        # WRITE_SIZE is exact up to the 32-byte granule of the last store
+        n_u = int(write_sd // 8.0)
     corr = 16.0 * n_u / fetch_sd
     # (2) the roofline kernel: k_cheb_step* with the largest grid
     ks = [i for i, r in enumerate(F) if r[1].startswith("k_cheb_step")]
