@@ -208,6 +208,14 @@ struct pcd_engine_s {
   double* pinned = nullptr;           // host-pinned scratch
   size_t pinned_n = 0;
   long num_pcd = 0, num_fs = 0;
+  // Side stream: work that is off the critical path of a cycle (the
+  // pre-smoothing of a pre-composed level is needed only on the way up) runs
+  // beside it; fork / join through events, which a stream capture turns into
+  // parallel branches of the graph.  One GPU only.
+  hipStream_t side = nullptr;
+  hipEvent_t sev[32] = {};
+  int sev_next = 0;
+  bool side_on = true;                // PCD_NO_SIDE_STREAM=1: A/B switch
   // hipGraph replay of the fixed-iteration fieldsplit apply
   bool graph_on = false;
   hipGraphExec_t gexec = nullptr;
@@ -749,6 +757,48 @@ static int solve_rich(Engine* h, const DCsr& A, Inner& s, const double* b,
   return 0;
 }
 
+// ---- fork / join on the side stream ------------------------------------------
+static int side_event(Engine* h, hipEvent_t* ev) {
+  hipEvent_t& e = h->sev[h->sev_next];
+  h->sev_next = (h->sev_next + 1) % 32;
+  if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *ev = e;
+  return 0;
+}
+static bool side_usable(Engine* h) { return h->side_on && !h->comm; }
+// stream and events exist before anything is captured (object creation inside
+// a stream capture is not something to rely on)
+static int side_prepare(Engine* h) {
+  if (!side_usable(h)) return 0;
+  if (!h->side) HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  for (auto& e : h->sev)
+    if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return 0;
+}
+// from here on launches go to the side stream, ordered after everything the
+// main stream has been given so far; *main_stream remembers where to return
+static int side_fork(Engine* h, hipStream_t* main_stream) {
+  if (!h->side) HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  hipEvent_t ev;
+  CHK(side_event(h, &ev));
+  HIPCHK(hipEventRecord(ev, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->side, ev, 0));
+  *main_stream = h->stream;
+  h->stream = h->side;
+  return 0;
+}
+// back to the main stream; *done fires when the side work has finished
+static int side_return(Engine* h, hipStream_t main_stream, hipEvent_t* done) {
+  CHK(side_event(h, done));
+  HIPCHK(hipEventRecord(*done, h->side));
+  h->stream = main_stream;
+  return 0;
+}
+static int side_join(Engine* h, hipEvent_t done) {
+  HIPCHK(hipStreamWaitEvent(h->stream, done, 0));
+  return 0;
+}
+
 // ---- [ext PETSc] PCMG: multiplicative V-cycle on the device -----------------
 // Chebyshev-Jacobi smoothing; every step is one fused k_cheb_step launch.
 // Iterates rotate through bufs[0..2]; with a nonzero guess the guess sits in
@@ -820,21 +870,31 @@ static int mg_vcycle(Engine* h, const DCsr& Afine, Inner& s, int l,
     // x = Wu [T | b]
     const int64_t n = A.nrows, nc = L.P.ncols;
     double* T = L.T.p;
+    // x1 = pre-smoothing of b is needed only by the up-sweep: it runs on the
+    // side stream while the main one goes down (r_c = Wd b reads b alone)
+    const bool fork = side_usable(h);
+    hipStream_t main_stream = nullptr;
+    hipEvent_t x1_ready = nullptr;
+    if (fork) CHK(side_fork(h, &main_stream));
     {
       // ring arranged so that the smoothed vector lands in T[0, n)
       const int last = (s.nu_pre - 1) % 3;
       double* ring[3];
       ring[last] = T; ring[(last + 1) % 3] = L.t0.p; ring[(last + 2) % 3] = L.t1.p;
       double* px = nullptr;
-      CHK(mg_smooth(h, A, L.emin, L.emax, s.nu_pre, b, ring, true, &px));
-      if (px != T)
-        HIPCHK(hipMemcpyAsync(T, px, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      int rc = mg_smooth(h, A, L.emin, L.emax, s.nu_pre, b, ring, true, &px);
+      if (!rc && px != T &&
+          hipMemcpyAsync(T, px, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+        rc = fail(PCD_ERR_HIP, "fused level: copy of the smoothed vector failed");
+      if (fork) { const int r2 = side_return(h, main_stream, &x1_ready); if (!rc) rc = r2; }
+      CHK(rc);
     }
     CHK(spmv(h, L.Wd, b, T + n));
     double* pe = nullptr;
     CHK(mg_vcycle(h, Afine, s, l - 1, T + n, &pe, T + n + nc));
     if (pe != T + n + nc)
       HIPCHK(hipMemcpyAsync(T + n + nc, pe, nc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (fork) CHK(side_join(h, x1_ready));
     double* dst = target ? target : L.x.p;
     CHK(spmv(h, L.Wu, T, dst, 0, nullptr, b, n + 2 * nc));
     *out = dst;
@@ -1050,7 +1110,9 @@ static int fs_apply_split(Engine* h, const double* x, double* y) {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     if (!h->cap_stream)
       HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    CHK(side_prepare(h));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(hipStreamSynchronize(h->side));
     hipStream_t saved = h->stream;
     h->stream = h->cap_stream;
     hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
@@ -1342,6 +1404,8 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
   { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
   { const char* e = getenv("PCD_MAX_CHUNKS"); if (e && atoi(e) >= 1) g_max_chunks = atoi(e); }
+  bool no_side = false;
+  { const char* e = getenv("PCD_NO_SIDE_STREAM"); no_side = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_XCD_REMAP");
     if (e && e[0] == '1') {
       const int none = 0;
@@ -1350,6 +1414,7 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   Engine* h = new (std::nothrow) Engine();
   if (!h) return fail(PCD_ERR_NOMEM, "create: out of host memory");
   h->variant = variant; h->device = device;
+  h->side_on = !no_side;
   *out = h;
   return 0;
 }
@@ -1375,6 +1440,8 @@ int pcd_destroy(pcd_handle h) {
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  for (auto& e : h->sev) if (e) (void)hipEventDestroy(e);
   delete h;
   return 0;
 }
@@ -1858,6 +1925,7 @@ int pcd_setup(pcd_handle h) {
   }
   CHK(h->w[0].ensure(np)); CHK(h->w[1].ensure(np));
   for (int s = 0; s < PCD_KSP_COUNT; ++s) CHK(inner_prepare(h, s));
+  CHK(side_prepare(h));
   h->ready = true; ++h->gen;
   return 0;
 }
