@@ -40,6 +40,10 @@ def parse():
     p.add_argument("--cycles-u", type=int, default=1)
     p.add_argument("--cycles-p", type=int, default=1)
     p.add_argument("--smooth", type=int, default=2)
+    p.add_argument("--smooth-down", type=int, default=None,
+                   help="pre-smoothing steps of the velocity cycle "
+                        "(-fieldsplit_u_pc_mg_smoothdown; default: --smooth)")
+    p.add_argument("--smooth-up", type=int, default=None)
     p.add_argument("--a00-its", type=int, default=240)
     p.add_argument("--a00-ratio", type=float, default=0.002)
     p.add_argument("--ap-rtol", type=float, default=1e-8)
@@ -238,6 +242,10 @@ def main():
     if args.smooth_p is not None:
         PETScOptions.set("fieldsplit_p_PCD_Ap_mg_levels_ksp_max_it",
                          args.smooth_p)
+    if args.smooth_down is not None:
+        PETScOptions.set("fieldsplit_u_pc_mg_smoothdown", args.smooth_down)
+    if args.smooth_up is not None:
+        PETScOptions.set("fieldsplit_u_pc_mg_smoothup", args.smooth_up)
     if args.skip_u:
         PETScOptions.set("fieldsplit_u_pc_mg_skip_levels", args.skip_u)
     if args.skip_p:
@@ -404,7 +412,7 @@ def main():
             "Mp": "chebyshev+jacobi its %d eig [%s]"
                   % (k_m, mass_matrix_bounds(V.dim)),
             "A00": "richardson x%d + mg V(%d,%d), %d levels"
-                   % (k_f, args.smooth, args.smooth,
+                   % (k_f, ksp0.pc.mg_data["nu"], ksp0.pc.mg_data["nu_post"],
                       len(ksp0.pc.mg_data["ops"]))}
     else:
         bytes_pcd = rf.b_pcd(V.n_p, nnz(c.MAT_AP), nnz(c.MAT_MP),

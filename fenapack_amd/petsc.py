@@ -289,6 +289,10 @@ class PC(object):
         # explicit coarse inverse); their interpolations are composed
         self.mg_skip_levels = ()
         self.mg_smooth_its = 2
+        # -pc_mg_smoothdown / -pc_mg_smoothup: different pre- and
+        # post-smoothing counts (default: mg_levels_ksp_max_it for both)
+        self.mg_smooth_down = None
+        self.mg_smooth_up = None
         self.mg_esteig = (0.0, 0.1, 0.0, 1.1)
         self.mg_galerkin = True            # -pc_mg_galerkin both | none
         self._mg_ops_cb = None
@@ -482,6 +486,10 @@ class KSP(object):
             self.pc.mg_galerkin = g == "both"
         self.pc.mg_smooth_its = o.getInt("mg_levels_ksp_max_it",
                                          self.pc.mg_smooth_its)
+        self.pc.mg_smooth_down = o.getInt("pc_mg_smoothdown",
+                                          self.pc.mg_smooth_down)
+        self.pc.mg_smooth_up = o.getInt("pc_mg_smoothup",
+                                        self.pc.mg_smooth_up)
         self.pc.mg_fuse_nnz = o.getInt("pc_mg_fuse_nnz", self.pc.mg_fuse_nnz)
         self.cheb_precompose = o.getInt("ksp_chebyshev_precompose",
                                         self.cheb_precompose)
@@ -577,11 +585,15 @@ class KSP(object):
         C = coarse_inverse(ops[0])
         eng, slot, L = self.engine, self.slot, len(ops)
         # kept for statistics (roofline bytes) and for the CPU baseline
+        nu_pre = pc.mg_smooth_its if pc.mg_smooth_down is None \
+            else pc.mg_smooth_down
+        nu_post = pc.mg_smooth_its if pc.mg_smooth_up is None \
+            else pc.mg_smooth_up
         pc.mg_data = {"ops": ops, "chain": chain, "bounds": bounds, "C": C,
-                      "nu": pc.mg_smooth_its}
-        sig = (L, pc.mg_smooth_its, tuple(o.nnz for o in ops))
+                      "nu": nu_pre, "nu_post": nu_post}
+        sig = (L, nu_pre, nu_post, tuple(o.nnz for o in ops))
         if pc._mg_pushed != sig:
-            eng.mg_begin(slot, L, pc.mg_smooth_its, pc.mg_smooth_its)
+            eng.mg_begin(slot, L, nu_pre, nu_post)
             eng.mg_set_level(slot, 0, C)
             for l in range(1, L):
                 eng.mg_set_level(slot, l, ops[l] if l < L - 1 else None,
@@ -600,8 +612,9 @@ class KSP(object):
         from .compose import vcycle_level
         pc, eng, slot = self.pc, self.engine, self.slot
         pc.mg_fused = []
+        nu_pre, nu_post = pc.mg_data["nu"], pc.mg_data["nu_post"]
         if not getattr(eng.L, "hip", False) or pc.mg_fuse_nnz <= 0 \
-                or pc.mg_smooth_its < 1:
+                or nu_pre < 1 or nu_post < 1:
             return
         blk = 1
         if slot == c.KSP_A00:
@@ -611,7 +624,7 @@ class KSP(object):
             if A.shape[0] // blk > pc.mg_fuse_rows:
                 break                       # larger levels are bandwidth-bound
             Wd, Wu = vcycle_level(A, chain[l], bounds[l][0], bounds[l][1],
-                                  pc.mg_smooth_its, pc.mg_smooth_its)
+                                  nu_pre, nu_post)
             if Wu.nnz // (blk * blk) > pc.mg_fuse_nnz:
                 break
             eng.mg_set_fused(slot, l, Wd, Wu)

@@ -66,13 +66,14 @@ def b_vcycle(mg_data, n_fine, nnz_fine):
     residual SpMV, restriction and prolongation-add SpMVs; level 0 is one
     dense SpMV; one final copy on the finest level."""
     ops, chain, nu = mg_data["ops"], mg_data["chain"], mg_data["nu"]
+    nu2 = mg_data.get("nu_post", nu)
     L = len(ops)
     total = b_spmv(ops[0].shape[0], ops[0].shape[0], mg_data["C"].nnz)
     for l in range(1, L):
         n = n_fine if l == L - 1 else ops[l].shape[0]
         nnz = nnz_fine if l == L - 1 else ops[l].nnz
         P = chain[l]
-        total += 24 * n + (2 * nu - 1) * b_cheb(n, nnz)
+        total += 24 * n + (nu + nu2 - 1) * b_cheb(n, nnz)
         total += b_spmv(n, n, nnz) + 8 * n
         total += b_spmv(P.shape[1], P.shape[0], P.nnz)
         total += b_spmv(P.shape[0], P.shape[1], P.nnz) + 8 * n

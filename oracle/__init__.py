@@ -130,7 +130,7 @@ def mirror(o, pb, ksp):
         if k.pc.type == "mg":
             d = k.pc.mg_data
             L = len(d["ops"])
-            o.mg_begin(slot, L, d["nu"], d["nu"])
+            o.mg_begin(slot, L, d["nu"], d.get("nu_post", d["nu"]))
             o.mg_set_level(slot, 0, d["C"])
             for l in range(1, L):
                 o.mg_set_level(slot, l, d["ops"][l] if l < L - 1 else None,
