@@ -107,9 +107,14 @@ def test_lshape_level6_reference_geometry():
     compare_with_oracle(pb, ksp)
 
 
-@pytest.mark.parametrize("pcdr,published,band", [(False, 3157, (0.95, 1.25)),
-                                                 (True, 1686, (0.95, 1.40))])
-def test_unsteady_anchor_against_the_published_table(pcdr, published, band):
+@pytest.mark.parametrize("pcdr,published,cycles,band", [
+    (False, 3157, 2, (0.95, 1.25)), (True, 1686, 2, (0.95, 1.40)),
+    # eight cycles per inner solve ~ the reference's exact factorisations:
+    # "a few %" of the published totals; what is left is the
+    # fifth Picard iteration this driver takes from step 6 on
+    (False, 3157, 8, (0.97, 1.08)), (True, 1686, 8, (0.97, 1.12))])
+def test_unsteady_anchor_against_the_published_table(pcdr, published, cycles,
+                                                     band):
     """SURVEY 8c G4, the reference's only published numbers
     (demo/unsteady-navier-stokes-pcd/documentation.rst:134-140): L-shape
     level 4 (25 987 DOF), dt = 0.2, 25 steps, Picard, BRM1 -> 3157 Krylov
@@ -118,13 +123,14 @@ def test_unsteady_anchor_against_the_published_table(pcdr, published, band):
     cycles per inner solve and its own driver decides on the Picard
     iteration count; the bands state what that costs (DESIGN.md 5 explains
     both excesses: a fifth Picard iteration from step 6 on, and inexact
-    R_p / A_p solves in PCDR)."""
+    R_p / A_p solves in PCDR - with 8 cycles the totals are 3266 / 1808 on the
+    CPU restatement, profiles/r02_pcd*_cpu.log)."""
     from fenapack_amd.device_producer import solve_unsteady_device
     pb = BackwardStep(4, nu=0.02, variant="BRM1", dt=0.2, pcdr=pcdr,
                       dirichlet_diag="multiplicity")
     assert pb.space.ndof == 25987
     PETScOptions.clear()
-    multigrid_inner_options(cycles_u=2, cycles_p=2, pcdr=pcdr)
+    multigrid_inner_options(cycles_u=cycles, cycles_p=cycles, pcdr=pcdr)
     out = solve_unsteady_device(pb, dt=0.2, t_end=5.0, newton_rtol=1e-5,
                                 gmres_rtol=1e-6)
     PETScOptions.clear()
@@ -135,3 +141,6 @@ def test_unsteady_anchor_against_the_published_table(pcdr, published, band):
     # per Picard iteration the count stays at the exact-solve level
     per_picard = [k for step in out["krylov_per_newton"] for k in step[1:]]
     assert max(per_picard) <= (24 if pcdr else 36), per_picard
+    if cycles >= 8:
+        # the published averages: 126.3 / 4 = 31.6 and 67.4 / 4 = 16.9
+        assert max(per_picard) <= (19 if pcdr else 33), per_picard
