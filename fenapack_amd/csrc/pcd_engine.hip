@@ -1423,6 +1423,7 @@ int pcd_destroy(pcd_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->side) (void)hipStreamSynchronize(h->side);
   fe_release(h);
   h->a10.release(); h->a11.release();
   for (auto& m : h->mat) m.release();

@@ -247,7 +247,18 @@ int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps,
 /* SURVEY 8e.  `nccl_unique_id` is the 128-byte ncclUniqueId produced on rank 0
  * (pcd_comm_unique_id) and broadcast by the host (torch.distributed store).
  * After this call set_csr/set_system take GLOBAL matrices on every rank and
- * keep only the owned row block [row_begin, row_end) of each field. */
+ * keep only the owned row block [row_begin, row_end) of each field.
+ *
+ * Errors and the communicator: every compute entry point of a partitioned
+ * engine is COLLECTIVE (same calls, same order on every rank - SURVEY 8b
+ * "Threading").  A nonzero status on one rank (a HIP error, a GMRES
+ * breakdown) is returned on that rank only; the others are then waiting in a
+ * collective the failed rank will never join.  Treat any engine error in a
+ * multi-rank run as fatal to the job: exit the process (the launcher of
+ * bench.py ends the other ranks), do not retry on the same communicator.
+ * Data-dependent decisions inside the engine (GMRES stopping test, CG
+ * convergence) are taken from all-reduced numbers, so they agree on all
+ * ranks by construction. */
 /* velocity components per node (2 or 3): row cuts of velocity operators fall
  * on node boundaries.  Call before handing operators over; default 2. */
 int pcd_set_velocity_block(pcd_handle h, int ncomp);
