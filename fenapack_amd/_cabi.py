@@ -650,5 +650,8 @@ def hip_library():
     """The product library.  Fails loudly when it has not been built."""
     global _hip_library
     if _hip_library is None:
-        _hip_library = Library(HIP_LIBRARY_PATH)
+        # FENAPACK_AMD_HIP_LIB: another BUILD of the same HIP library
+        # (compile-time A/B switches of the kernels, tools/tile_sweep.sh)
+        _hip_library = Library(os.environ.get("FENAPACK_AMD_HIP_LIB")
+                               or HIP_LIBRARY_PATH)
     return _hip_library

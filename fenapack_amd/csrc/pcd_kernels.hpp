@@ -503,8 +503,12 @@ __global__ __launch_bounds__(kBlock) void k_cg_spmv_s(
 #ifndef PCD_TILE3
 #define PCD_TILE3 2048
 #endif
-// LDS nodes per workgroup: 2048 pairs = 32 KiB; triples: PCD_TILE3 x 24 B
-template <int NC> constexpr int tile_c() { return NC == 3 ? PCD_TILE3 : 2048; }
+#ifndef PCD_TILE2
+#define PCD_TILE2 2048
+#endif
+// LDS nodes per workgroup: PCD_TILE2 pairs x 16 B (2048 = 32 KiB); triples:
+// PCD_TILE3 x 24 B (compile-time A/B switches, tools/tile_sweep.sh)
+template <int NC> constexpr int tile_c() { return NC == 3 ? PCD_TILE3 : PCD_TILE2; }
 
 template <int NC>
 struct alignas(NC == 2 ? 16 : 8) VecC {
