@@ -258,8 +258,8 @@ static int g_max_chunks = 2;            // PCD_MAX_CHUNKS: LDS-tile passes per r
 // and very uneven rows (a stacked restriction row holds hundreds of entries):
 // while they are handed over, small row blocks may take this many passes
 // through the tile instead of falling back to the CSR-vector kernels.
-static int g_chunks_override = 0;
-static bool g_want_wave = false;        // the operator being handed over is a composed one
+static thread_local int g_chunks_override = 0;
+static thread_local bool g_want_wave = false;   // the operator being handed over is a composed one
 // rows per workgroup: the largest RB whose every row block fits the LDS tile
 // and that still yields `g_min_wgs` workgroups (small operators then take
 // smaller row blocks: more, shorter workgroups).  Blocks of 64 rows and

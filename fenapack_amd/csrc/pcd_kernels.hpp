@@ -501,7 +501,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_spmv_s(
 // traffic.  Same three phases as the stream kernels.
 // ==========================================================================
 #ifndef PCD_TILE3
-#define PCD_TILE3 2048
+// 1536 triples = 36 KiB: four workgroups per CU instead of three; a 64-row
+// block of a 3-D P2 operator (29 entries per row) then takes two passes.
+// Measured on the cube N = 32 (profiles/r02_k_tile_sweep3d.txt): 39.9 us per
+// launch at 2048, 35.0 at 1536-1664, 38-44 at 1280-1408, 39.4 at 1792.
+#define PCD_TILE3 1536
 #endif
 #ifndef PCD_TILE2
 #define PCD_TILE2 2048
