@@ -654,7 +654,7 @@ class KSP(object):
         max_it = 1 if self.type == "preonly" else self.max_it
         self.precomposed = None
         if self.type == "chebyshev" and pc == "jacobi" \
-                and self.cheb_precompose > 0 and 2 <= max_it <= 12 \
+                and self.cheb_precompose > 0 and 2 <= max_it <= 8 \
                 and getattr(self.engine.L, "hip", False) \
                 and self._ops[1].A is not None \
                 and self._ops[1].A.shape[0] <= self.cheb_precompose_rows:
