@@ -267,7 +267,22 @@ __device__ __forceinline__ void row_block_range(int nrb, int rb_rows, int& begin
 // Loads of one pass are all issued before any use: kUnroll independent
 // (col, val) pairs per lane, then kUnroll independent gathers - one dependent
 // chain rowptr -> col/val -> x per row block instead of one per loop trip.
-constexpr int kUnroll = 8;
+#ifndef PCD_UNROLL
+#define PCD_UNROLL 8
+#endif
+constexpr int kUnroll = PCD_UNROLL;
+
+// The matrix arrays are read exactly once per launch; the gathered vector is
+// what should stay in L2.  -DPCD_NT_LOADS=1 marks the matrix stream
+// non-temporal (A/B switch: tools/nt_sweep.sh).
+#ifndef PCD_NT_LOADS
+#define PCD_NT_LOADS 0
+#endif
+#if PCD_NT_LOADS
+#define PCD_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define PCD_STREAM_LOAD(p) (*(p))
+#endif
 
 template <int RB, class XF>
 __device__ __forceinline__ double stream_row_block(
@@ -296,8 +311,8 @@ __device__ __forceinline__ double stream_row_block(
       for (int u = 0; u < kUnroll; ++u) {
         const int k = base + u * kBlock + threadIdx.x;
         const bool in = k < k0 + c1;
-        c[u] = in ? col[k] : -1;
-        v[u] = in ? val[k] : 0.0;
+        c[u] = in ? PCD_STREAM_LOAD(col + k) : -1;
+        v[u] = in ? PCD_STREAM_LOAD(val + k) : 0.0;
       }
       double xv[kUnroll];
 #pragma unroll
@@ -578,8 +593,8 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
       for (int u = 0; u < kUnroll; ++u) {
         const int k = base + u * kBlock + threadIdx.x;
         const bool in = k < k0 + c1;
-        c[u] = in ? col[k] : -1;
-        v[u] = in ? val[k] : 0.0;
+        c[u] = in ? PCD_STREAM_LOAD(col + k) : -1;
+        v[u] = in ? PCD_STREAM_LOAD(val + k) : 0.0;
       }
       VecC<NC> xv[kUnroll];
 #pragma unroll
