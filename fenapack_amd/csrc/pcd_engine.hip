@@ -215,7 +215,7 @@ struct pcd_engine_s {
   hipStream_t side = nullptr;
   hipEvent_t sev[32] = {};
   int sev_next = 0;
-  bool side_on = true;                // PCD_NO_SIDE_STREAM=1: A/B switch
+  bool side_on = false;               // PCD_SIDE_STREAM=1: A/B switch (off: see DESIGN.md 4)
   // hipGraph replay of the fixed-iteration fieldsplit apply
   bool graph_on = false;
   hipGraphExec_t gexec = nullptr;
@@ -1404,8 +1404,12 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
   { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
   { const char* e = getenv("PCD_MAX_CHUNKS"); if (e && atoi(e) >= 1) g_max_chunks = atoi(e); }
-  bool no_side = false;
-  { const char* e = getenv("PCD_NO_SIDE_STREAM"); no_side = e && e[0] == '1'; }
+  // measured (profiles/r02_l_*): every cross-stream event join costs 6-12 us
+  // on this stack, in eager launches and under graph replay alike - more than
+  // the 5 us kernel it takes off the critical path (0.324 -> 0.368 ms per
+  // PCApply).  The fork/join code stays as an experiment switch.
+  bool want_side = false;
+  { const char* e = getenv("PCD_SIDE_STREAM"); want_side = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_XCD_REMAP");
     if (e && e[0] == '1') {
       const int none = 0;
@@ -1414,7 +1418,7 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   Engine* h = new (std::nothrow) Engine();
   if (!h) return fail(PCD_ERR_NOMEM, "create: out of host memory");
   h->variant = variant; h->device = device;
-  h->side_on = !no_side;
+  h->side_on = want_side;
   *out = h;
   return 0;
 }
