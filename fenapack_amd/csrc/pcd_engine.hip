@@ -79,6 +79,8 @@ struct DCsr {
   int rb = 0;             // rows per workgroup of the CSR-stream kernels (0: n/a)
   bool long_rows = false; // >= 256 nonzeros per row on average: workgroup per row
   bool wave_rows = false; // composed operator with 24..255 entries per row: wave per row
+  bool dense = false;     // every entry stored (explicit coarse inverse): val is row-major
+  bool dense2 = false;    // the same for the scalar stencil F of F (x) I
   // multi-component structure A = F (x) I_kron (kron = 2, 3; 0: none): F
   // stored once
   int kron = 0;
@@ -435,9 +437,18 @@ static void launch_spmv_any(Engine* h, const DCsr& A, const double* x,
                             const double* add, double* y, const double* ghost,
                             int64_t ncols, bool kron) {
   const XVec xv{x, ghost, (int)ncols};
-  if (kron) {
+  if (kron && A.dense2) {
+    const int nn = (int)(A.nrows / A.kron), mm = (int)(A.ncols / A.kron);
+    const int g = std::min(nn, 65535);
+    if (A.kron == 2) hipLaunchKernelGGL((k_dense_c<MODE, 2>), dim3(g), dim3(kBlock), 0, h->stream, nn, mm, A.val2.p, x, add, y);
+    else hipLaunchKernelGGL((k_dense_c<MODE, 3>), dim3(g), dim3(kBlock), 0, h->stream, nn, mm, A.val2.p, x, add, y);
+  } else if (kron) {
     if (A.kron == 2) launch_spmv_kron_nc<MODE, 2>(h, A, x, add, y, ghost, ncols);
     else launch_spmv_kron_nc<MODE, 3>(h, A, x, add, y, ghost, ncols);
+  } else if (A.dense && ghost == A.ghost.p) {
+    const int g = (int)std::min<int64_t>(A.nrows, 65535);
+    hipLaunchKernelGGL((k_dense_c<MODE, 1>), dim3(g), dim3(kBlock), 0, h->stream,
+                       (int)A.nrows, (int)A.ncols, A.val.p, x, add, y);
   } else if (A.long_rows) {
     const int g = (int)std::min<int64_t>(A.nrows, 65535);
     hipLaunchKernelGGL((k_spmv_long<MODE>), dim3(g), dim3(kBlock), 0, h->stream,
@@ -1220,7 +1231,7 @@ static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* ro
 // detect the structure (the velocity block size first) + compressed arrays
 static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
                        const int32_t* rowptr, const int32_t* col, bool have_vals) {
-  A.kron = 0; A.kron_pat = 0; A.rb2 = 0; A.nnz2 = 0;
+  A.kron = 0; A.kron_pat = 0; A.rb2 = 0; A.nnz2 = 0; A.dense2 = false;
   if (g_no_kron || rowptr[nrows] == 0) return 0;
   int nc = 0;
   const int first = h->vel_block == 3 ? 3 : 2;
@@ -1239,7 +1250,9 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     rpc[s + 1] = (int32_t)cc.size();
   }
   const int rb2 = rb_for(nn, rpc.data(), nc == 3 ? tile_c<3>() : tile_c<2>());
-  if (!rb2 && !g_want_wave) return 0;    // (the wave-per-row kernels need no tile)
+  const bool dense2 = nn >= 64 && (int64_t)cc.size() == nn * (ncols / nc);
+  if (!rb2 && !g_want_wave && !dense2) return 0;   // (wave-per-row / dense kernels need no tile)
+  A.dense2 = dense2;
   A.nnz2 = (int64_t)cc.size();
   CHK(A.rowptr2.ensure(nn + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2));
   CHK(A.kron_pos.ensure(nc * A.nnz2)); CHK(A.kron_flag.ensure(1));
@@ -1273,6 +1286,7 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.lpr = choose_lpr(A);
   A.rb = g_force_vector ? 0 : choose_rb(nrows, rowptr);
   A.long_rows = A.rb == 0 && nrows > 0 && nnz / nrows >= 256;
+  A.dense = nrows >= 64 && nnz == nrows * ncols;
   // measured (profiles/r02_f_timeline.txt): a wave per row wins on the few,
   // very long rows of a residual-restriction product (150-300 entries: 7 us
   // against 13-38 us for the stream kernel's serialised tile passes) and

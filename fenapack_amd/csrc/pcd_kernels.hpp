@@ -992,6 +992,49 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wc(
   }
 }
 
+// Dense operator (explicit coarse inverse), row-major, no column indices: one
+// workgroup per (node) row; all NC components of a node share the row of the
+// scalar inverse (inv(F (x) I) = inv(F) (x) I).  8 B per entry instead of the
+// 12 B of a CSR record, and no dependent index load.
+template <int MODE, int NC>
+__global__ __launch_bounds__(kBlock) void k_dense_c(
+    int nrows, int ncols, const double* __restrict__ M, const double* x_,
+    const double* add_, double* y_) {
+  __shared__ double sm[4];
+  const VecC<NC>* x = vc<NC>(x_);
+  const VecC<NC>* add = vc<NC>(add_);
+  VecC<NC>* y = vc<NC>(y_);
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const double* r = M + (size_t)row * ncols;
+    VecC<NC> s0 = vzero<NC>(), s1 = vzero<NC>();
+    int k = threadIdx.x;
+    for (; k + kBlock < ncols; k += 2 * kBlock) {
+      const double a0 = r[k], a1 = r[k + kBlock];
+      const VecC<NC> x0 = x[k], x1 = x[k + kBlock];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) { s0.c[i] += a0 * x0.c[i]; s1.c[i] += a1 * x1.c[i]; }
+    }
+    if (k < ncols) {
+      const double a0 = r[k];
+      const VecC<NC> x0 = x[k];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s0.c[i] += a0 * x0.c[i];
+    }
+    VecC<NC> s;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] = block_sum(s0.c[i] + s1.c[i], sm);
+    if (threadIdx.x == 0) {
+      VecC<NC> o, a = vzero<NC>();
+      if (MODE == 1 || MODE == 2) a = add[row];
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i]
+                                        : (MODE == 2 ? a.c[i] - s.c[i] : -s.c[i]));
+      y[row] = o;
+    }
+  }
+}
+
 // ---- bandwidth probe: the practical roof next to which the path is priced ---
 // 16 bytes per lane, unit stride, grid-stride loop: what a streaming kernel of
 // this engine can reach on this box ("confirm with a device-to-
