@@ -413,6 +413,11 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
                                 const double* ghost, int64_t ncols) {
   const int nn = (int)(A.nrows / NC);
   const int nloc = (int)(ncols / NC);
+  if (A.long_rows) {
+    hipLaunchKernelGGL((k_spmv_longc<MODE, NC>), dim3(std::min(nn, 65535)), dim3(kBlock), 0, h->stream,
+                       nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y);
+    return;
+  }
   if (A.wave_rows) {
     const int gw = (int)std::min<int64_t>((nn + 3) / 4, 1 << 16);
     hipLaunchKernelGGL((k_spmv_wc<MODE, NC>), dim3(gw), dim3(kBlock), 0, h->stream,
@@ -1295,6 +1300,9 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   // dependent chain
   // ... and on many rows (the up-sweep product of a 26 000-node level, 150
   // entries per row: 15 against 12 us), so: long rows AND few of them
+  // ... and rows of thousands of entries (3-D: a coarse hat function covers
+  // thousands of fine nodes) want a whole workgroup each
+  if (g_want_wave && nrows > 0 && nnz / nrows >= 1024) A.long_rows = true;
   A.wave_rows = g_want_wave && !A.long_rows && nrows > 0 && nnz / nrows >= 96 &&
                 nrows <= 3 * 8192;
   CHK(detect_kron(h, A, nrows, ncols, rowptr, col, val != nullptr));

@@ -992,6 +992,50 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wc(
   }
 }
 
+// Very long rows (>= 1024 entries: the residual-restriction product of a 3-D
+// two-grid cycle has thousands per coarse row) of a multi-component operator:
+// one workgroup per node row, as k_spmv_long does for scalar operators.
+template <int MODE, int NC>
+__global__ __launch_bounds__(kBlock) void k_spmv_longc(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* x_, const double* ghost_,
+    int nloc, const double* add_, double* y_) {
+  __shared__ double sm[4];
+  const XVecC<NC> x{vc<NC>(x_), vc<NC>(ghost_), nloc};
+  const VecC<NC>* add = vc<NC>(add_);
+  VecC<NC>* y = vc<NC>(y_);
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int b = rowptr[row], e = rowptr[row + 1];
+    VecC<NC> s0 = vzero<NC>(), s1 = vzero<NC>();
+    int k = b + threadIdx.x;
+    for (; k + kBlock < e; k += 2 * kBlock) {
+      const int c0 = col[k], c1 = col[k + kBlock];
+      const double v0 = val[k], v1 = val[k + kBlock];
+      const VecC<NC> x0 = x(c0), x1 = x(c1);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) { s0.c[i] += v0 * x0.c[i]; s1.c[i] += v1 * x1.c[i]; }
+    }
+    if (k < e) {
+      const double v0 = val[k];
+      const VecC<NC> x0 = x(col[k]);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s0.c[i] += v0 * x0.c[i];
+    }
+    VecC<NC> s;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] = block_sum(s0.c[i] + s1.c[i], sm);
+    if (threadIdx.x == 0) {
+      VecC<NC> o, a = vzero<NC>();
+      if (MODE == 1 || MODE == 2) a = add[row];
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i]
+                                        : (MODE == 2 ? a.c[i] - s.c[i] : -s.c[i]));
+      y[row] = o;
+    }
+  }
+}
+
 // Dense operator (explicit coarse inverse), row-major, no column indices: one
 // workgroup per (node) row; all NC components of a node share the row of the
 // scalar inverse (inv(F (x) I) = inv(F) (x) I).  8 B per entry instead of the
