@@ -298,11 +298,18 @@ class PC(object):
         self._mg_ops_cb = None
         self._mg_pushed = None
         # -pc_mg_fuse_nnz: levels whose pre-composed up-sweep operator holds
-        # at most this many stored entries (per velocity component) run as two
-        # sparse products instead of nu_pre + nu_post + 3 launches
-        # (compose.vcycle_level; 0 = never).  Such levels are latency-bound,
-        # not bandwidth-bound: DESIGN.md 4.
-        self.mg_fuse_nnz = 4500000
+        # at most this many stored entries (of the scalar stencil for an
+        # F (x) I operator) run as three launches instead of nu_pre + nu_post
+        # + 3 (compose.vcycle_level; 0 = never).  Such levels are
+        # latency-bound, not bandwidth-bound: DESIGN.md 4.  Its rows must
+        # also suit a kernel: at most mg_fuse_row_nnz entries on average (the
+        # stream kernel then needs <= 3-4 passes through its LDS tile), or few
+        # enough rows for the wave-per-row kernel (3-D Galerkin levels have
+        # 400+ entries per row of W_u: measured 125 us composed against
+        # 28 us step by step on a 35 937-node level, profiles/r02_n_*)
+        self.mg_fuse_nnz = 8000000
+        self.mg_fuse_row_nnz = 200
+        self.mg_fuse_wave_nodes = 8192
         self.mg_fuse_rows = 160000         # never even try above this size
         # -pc_type gamg: the chain comes from the matrix (amg.py), built once
         # per pattern and kept while values change
@@ -625,7 +632,9 @@ class KSP(object):
                 break                       # larger levels are bandwidth-bound
             Wd, Wu = vcycle_level(A, chain[l], bounds[l][0], bounds[l][1],
                                   nu_pre, nu_post)
-            if Wu.nnz // (blk * blk) > pc.mg_fuse_nnz:
+            nnz_f, nodes = Wu.nnz // blk, A.shape[0] // blk
+            if nnz_f > pc.mg_fuse_nnz or (nnz_f > pc.mg_fuse_row_nnz * nodes
+                                          and nodes > pc.mg_fuse_wave_nodes):
                 break
             eng.mg_set_fused(slot, l, Wd, Wu)
             pc.mg_fused.append((l, Wd.nnz, Wu.nnz))
