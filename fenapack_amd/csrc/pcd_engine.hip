@@ -1304,7 +1304,7 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   // thousands of fine nodes) want a whole workgroup each
   if (g_want_wave && nrows > 0 && nnz / nrows >= 1024) A.long_rows = true;
   A.wave_rows = g_want_wave && !A.long_rows && nrows > 0 && nnz / nrows >= 96 &&
-                nrows <= 3 * 8192;
+                (nrows <= 3 * 8192 || nnz / nrows >= 300);
   CHK(detect_kron(h, A, nrows, ncols, rowptr, col, val != nullptr));
   return 0;
 }

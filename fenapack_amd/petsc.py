@@ -633,8 +633,10 @@ class KSP(object):
             Wd, Wu = vcycle_level(A, chain[l], bounds[l][0], bounds[l][1],
                                   nu_pre, nu_post)
             nnz_f, nodes = Wu.nnz // blk, A.shape[0] // blk
-            if nnz_f > pc.mg_fuse_nnz or (nnz_f > pc.mg_fuse_row_nnz * nodes
-                                          and nodes > pc.mg_fuse_wave_nodes):
+            avg = nnz_f / float(max(nodes, 1))
+            suits_stream = avg <= pc.mg_fuse_row_nnz
+            suits_wave = nodes <= pc.mg_fuse_wave_nodes or avg >= 300.0
+            if nnz_f > pc.mg_fuse_nnz or not (suits_stream or suits_wave):
                 break
             eng.mg_set_fused(slot, l, Wd, Wu)
             pc.mg_fused.append((l, Wd.nnz, Wu.nnz))
