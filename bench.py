@@ -455,8 +455,12 @@ def main():
         "data": "synthetic (own P2/P1 assembly; matrices frozen at Picard "
                 "iterate %d computed on the GPU)" % args.picard_steps,
         "config": {
-            "workload": "%s level %d, Re=100, P2/P1, PCD %s"
-                        % (args.geometry, args.level, args.variant),
+            "workload": ("cube N=%d (n0 %d, %d refinements), Re=100, P2/P1, "
+                         "PCD %s" % (args.n0 * 2 ** args.level, args.n0,
+                                     args.level, args.variant))
+            if args.geometry == "cube" else
+            "%s level %d, Re=100, P2/P1, PCD %s"
+            % (args.geometry, args.level, args.variant),
             "ndof": int(n), "n_u": int(V.n_u), "n_p": int(V.n_p),
             "inner": inner_desc,
             "gmres": "restart 150, rtol 1e-6, right PC",
