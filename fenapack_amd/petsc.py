@@ -628,8 +628,11 @@ class KSP(object):
             blk = getattr(eng, "velocity_block", 2)
         for l in range(1, len(ops)):
             A = ops[l]
-            if A.shape[0] // blk > pc.mg_fuse_rows:
-                break                       # larger levels are bandwidth-bound
+            if A.shape[0] // blk > pc.mg_fuse_rows \
+                    or 3 * (A.nnz // blk) > pc.mg_fuse_nnz:
+                break       # larger levels are bandwidth-bound (W_u holds
+                #             >= 3x the entries of A even for V(1,1): no
+                #             point in composing it just to measure it)
             Wd, Wu = vcycle_level(A, chain[l], bounds[l][0], bounds[l][1],
                                   nu_pre, nu_post)
             nnz_f, nodes = Wu.nnz // blk, A.shape[0] // blk
