@@ -628,11 +628,11 @@ class KSP(object):
             blk = getattr(eng, "velocity_block", 2)
         for l in range(1, len(ops)):
             A = ops[l]
+            grow = 3 if nu_post == 1 else 6     # nnz(W_u) / nnz(A), at least
             if A.shape[0] // blk > pc.mg_fuse_rows \
-                    or 3 * (A.nnz // blk) > pc.mg_fuse_nnz:
-                break       # larger levels are bandwidth-bound (W_u holds
-                #             >= 3x the entries of A even for V(1,1): no
-                #             point in composing it just to measure it)
+                    or grow * (A.nnz // blk) > pc.mg_fuse_nnz:
+                break       # larger levels are bandwidth-bound: no point in
+                #             composing W_u just to measure it
             Wd, Wu = vcycle_level(A, chain[l], bounds[l][0], bounds[l][1],
                                   nu_pre, nu_post)
             nnz_f, nodes = Wu.nnz // blk, A.shape[0] // blk
