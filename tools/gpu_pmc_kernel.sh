@@ -1,8 +1,9 @@
 #!/bin/bash
 # What bounds the roofline kernel?  SQ / TCC / TCP counter passes over
 # tools/time_a00_kernel.py (cavity level 6), one --pmc set per pass.
-#   tools/gpu_pmc_kernel.sh TAG  ->  gpurun_out/TAG_pmc_kernel.txt
-TAG=$1
+#   tools/gpu_pmc_kernel.sh TAG [time_a00_kernel args, e.g. "3 cube"]  ->  gpurun_out/TAG_pmc_kernel.txt
+TAG=$1; shift
+WL=${@:-6}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -16,7 +17,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TA_BUSY_avr TD_BUSY_avr" "TCP_TA_DATA_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"; do
   i=$((i+1))
   rm -rf $OUT/${TAG}_pk_$i
-  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/${TAG}_pk_$i -- python3 $ROOT/tools/time_a00_kernel.py 6 > $OUT/${TAG}_pk_$i.log 2>&1
+  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/${TAG}_pk_$i -- python3 $ROOT/tools/time_a00_kernel.py $WL > $OUT/${TAG}_pk_$i.log 2>&1
   python3 - $OUT/${TAG}_pk_$i "$SET" >> $OUT/${TAG}_pmc_kernel.txt <<'PY'
 import csv, glob, os, sys
 root, sets = sys.argv[1], sys.argv[2]
