@@ -278,6 +278,11 @@ constexpr int kUnroll = PCD_UNROLL;
 #ifndef PCD_NT_LOADS
 #define PCD_NT_LOADS 0
 #endif
+// products of three-component operators parked in LDS as three planes of
+// doubles instead of 24-byte records (A/B switch)
+#ifndef PCD_LDS_SOA
+#define PCD_LDS_SOA 1
+#endif
 #if PCD_NT_LOADS
 #define PCD_STREAM_LOAD(p) __builtin_nontemporal_load(p)
 #else
@@ -583,6 +588,7 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
   const int rb = mine ? rowptr[row + 1] - k0 : 0;
   VecC<NC> s = vzero<NC>();
   constexpr int kTileC = tile_c<NC>();
+  double* planes = reinterpret_cast<double*>(lds);   // NC planes of kTileC doubles
   for (int c0 = 0; c0 < k1 - k0; c0 += kTileC) {   // chunks of the LDS tile
     const int c1 = min(c0 + kTileC, k1 - k0);
     if (c0) __syncthreads();
@@ -604,10 +610,18 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
       for (int u = 0; u < kUnroll; ++u) {
         const int k = base + u * kBlock + threadIdx.x;
         if (k < k0 + c1) {
-          VecC<NC> t;
+          if (PCD_LDS_SOA && NC == 3) {
+            // 24-byte records put consecutive lanes 6 banks apart (2-way
+            // conflicts on every access); three planes of doubles do not
 #pragma unroll
-          for (int i = 0; i < NC; ++i) t.c[i] = v[u] * xv[u].c[i];
-          lds[k - k0 - c0] = t;
+            for (int i = 0; i < NC; ++i)
+              planes[i * kTileC + (k - k0 - c0)] = v[u] * xv[u].c[i];
+          } else {
+            VecC<NC> t;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) t.c[i] = v[u] * xv[u].c[i];
+            lds[k - k0 - c0] = t;
+          }
         }
       }
     }
@@ -616,9 +630,14 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
     int j = ra + sub;
     if (j < lo) j += (lo - j + TPR - 1) / TPR * TPR;
     for (; j < hi; j += TPR) {
-      const VecC<NC> t = lds[j - c0];
+      if (PCD_LDS_SOA && NC == 3) {
 #pragma unroll
-      for (int i = 0; i < NC; ++i) s.c[i] += t.c[i];
+        for (int i = 0; i < NC; ++i) s.c[i] += planes[i * kTileC + (j - c0)];
+      } else {
+        const VecC<NC> t = lds[j - c0];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) s.c[i] += t.c[i];
+      }
     }
   }
 #pragma unroll
