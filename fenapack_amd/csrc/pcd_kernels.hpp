@@ -295,14 +295,23 @@ __device__ __forceinline__ double stream_row_block(
     const double* __restrict__ val, const XF& xf, int r0, int nrows,
     double* lds) {
   const int r1 = min(r0 + RB, nrows);
-  const int k0 = rowptr[r0], k1 = rowptr[r1];
   constexpr int TPR = kBlock / RB;          // lanes that share one row's sum
   const int row = r0 + threadIdx.x / TPR;
   const int sub = threadIdx.x % TPR;
   const bool mine = row < r1;
+#ifdef PCD_FAKE_ROWLEN
+  // TIMING EXPERIMENT ONLY (wrong results): row bounds computed instead of
+  // loaded - what a storage format without the row-pointer round trip
+  // would save per launch (tools/time_small_solve.py)
+  const int k0 = r0 * PCD_FAKE_ROWLEN, k1 = r1 * PCD_FAKE_ROWLEN;
+  const int ra = mine ? (row - r0) * PCD_FAKE_ROWLEN : 0;
+  const int rb = mine ? (row + 1 - r0) * PCD_FAKE_ROWLEN : 0;
+#else
+  const int k0 = rowptr[r0], k1 = rowptr[r1];
   // this lane's own row bounds, fetched up front (used after the barrier)
   const int ra = mine ? rowptr[row] - k0 : 0;
   const int rb = mine ? rowptr[row + 1] - k0 : 0;
+#endif
   double s = 0.0;
   // the block's entries pass through the LDS tile in chunks (normally one;
   // the host admits a few more for operators with long rows)
