@@ -15,7 +15,7 @@ import numpy as np
 BRM1, BRM2, RBRM1, RBRM2 = 1, 2, 3, 4
 MAT_AP, MAT_MP, MAT_KP, MAT_RP, MAT_A00, MAT_A01, MAT_A = range(7)
 KSP_AP, KSP_MP, KSP_RP, KSP_A00 = range(4)
-PREONLY, RICHARDSON, CHEBYSHEV, CG = range(4)
+PREONLY, RICHARDSON, CHEBYSHEV, CG, CG_SR = range(5)
 PC_NONE, PC_JACOBI, PC_MG, PC_EXPLICIT = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
@@ -25,7 +25,7 @@ INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
 INFO_NNZ_BASE = 16
 
 KSP_TYPES = {"preonly": PREONLY, "richardson": RICHARDSON,
-             "chebyshev": CHEBYSHEV, "cg": CG}
+             "chebyshev": CHEBYSHEV, "cg": CG, "cgsr": CG_SR}
 PC_TYPES = {"none": PC_NONE, "jacobi": PC_JACOBI, "mg": PC_MG,
             "explicit": PC_EXPLICIT}
 VARIANTS = {"BRM1": BRM1, "BRM2": BRM2, "RBRM1": RBRM1, "RBRM2": RBRM2}

@@ -155,6 +155,7 @@ struct Inner {
   std::vector<Space> mg_space;       // multi-GPU: row space of every level
   int last_its = 0;
   bool its_on_device = false;
+  int state_idx = 0;                 // which of the two state records is final
   void release() {
     t0.release(); t1.release(); t2.release(); t3.release(); t4.release();
     parts.release(); slots.release(); state.release();
@@ -572,7 +573,13 @@ static int inner_prepare(Engine* h, int slot) {
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n)); CHK(s.t2.ensure(n));
       CHK(s.t3.ensure(n)); CHK(s.t4.ensure(n)); CHK(s.parts.ensure(3 * kMaxParts));
       CHK(s.slots.ensure(4));
-      CHK(s.state.ensure(1));
+      CHK(s.state.ensure(2));
+      break;
+    case PCD_KSP_CG_SR:
+      CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n)); CHK(s.t2.ensure(n));
+      CHK(s.t3.ensure(n)); CHK(s.t4.ensure(n)); CHK(s.parts.ensure(3 * kMaxParts));
+      CHK(s.slots.ensure(4));
+      CHK(s.state.ensure(2));
       break;
     case PCD_KSP_CHEBYSHEV:
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n));
@@ -658,7 +665,7 @@ static int solve_cg_stream(Engine* h, const DCsr& A, Inner& s, const double* b,
     }
   }
   HIPCHK(hipGetLastError());
-  s.its_on_device = true;
+  s.its_on_device = true; s.state_idx = 0;
   return 0;
 }
 
@@ -706,7 +713,53 @@ static int solve_cg(Engine* h, const DCsr& A, Inner& s, const double* b,
     }
   }
   HIPCHK(hipGetLastError());
+  s.its_on_device = true; s.state_idx = 0;
+  return 0;
+}
+
+// [ext PETSc] KSPCG with -ksp_cg_single_reduction: per iteration one SpMV
+// fused with both dot products, (several ranks: ONE all-reduce of two
+// doubles,) one kernel with every vector update.
+static int solve_cg_sr(Engine* h, const DCsr& A, Inner& s, const double* b,
+                       double* x) {
+  const int n = (int)A.nrows;
+  const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
+  double *r = s.t0.p, *z = s.t1.p, *p = s.t2.p, *sv = s.t3.p, *w = s.t4.p;
+  double *PB = s.parts.p, *PD = s.parts.p + kMaxParts;
+  double* slot = s.slots.p;                              // [beta, delta]
+  CgState* st = s.state.p;
+  const int ge = grid1d(n, 4, kMaxParts);
+  const int gs = grid_rows(n, A.lpr, kMaxParts);
+  hipLaunchKernelGGL(k_cgsr_init, dim3(ge), dim3(kBlock), 0, h->stream, n, dinv, b, x, r, z, st);
+  const int check = 16;
+  int it = 0;
+  for (; it < s.max_it; ++it) {
+    const CgState* sin = st + (it & 1);
+    CgState* sout = st + ((it + 1) & 1);
+    CHK(halo_exchange(h, A, z));
+    LAUNCH_LPR(A, k_cgsr_spmv_dots, gs, n, A.rowptr.p, A.col.p, A.val.p, z, r, sv,
+               PB, PD, sin, A.ghost.p, (int)A.ncols);
+    const double *pb = PB, *pd = PD;
+    int nb = gs, nd = gs;
+    if (h->comm) {
+      hipLaunchKernelGGL(k_sum_parts, dim3(2), dim3(kBlock), 0, h->stream, PB, gs, kMaxParts, slot);
+      if (h->comm->allreduce(slot, 2, h->stream))
+        return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+      pb = slot; pd = slot + 1; nb = nd = 1;
+    }
+    hipLaunchKernelGGL(k_cgsr_update, dim3(ge), dim3(kBlock), 0, h->stream, n, dinv, z, sv, p, w,
+                       x, r, pb, nb, pd, nd, s.rtol, it, sin, sout);
+    if (s.rtol > 0.0 && (it % check) == check - 1 && it + 1 < s.max_it) {
+      CHK(ensure_pinned(h, 8));
+      int* flag = reinterpret_cast<int*>(h->pinned);
+      HIPCHK(hipMemcpyAsync(flag, &sout->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (*flag) { ++it; break; }
+    }
+  }
+  HIPCHK(hipGetLastError());
   s.its_on_device = true;
+  s.state_idx = it & 1;                  // the record the last update wrote
   return 0;
 }
 
@@ -1036,6 +1089,7 @@ static int inner_solve(Engine* h, int slot, const double* b, double* x,
     case PCD_KSP_RICHARDSON: return solve_rich(h, A, s, b, x);
     case PCD_KSP_CHEBYSHEV: return solve_cheb(h, A, s, b, x);
     case PCD_KSP_CG: return solve_cg(h, A, s, b, x);
+    case PCD_KSP_CG_SR: return solve_cg_sr(h, A, s, b, x);
   }
   return fail(PCD_ERR_ARG, "inner_solve: unknown ksp type %d", s.ksp);
 }
@@ -1113,7 +1167,7 @@ static bool graph_capturable(const Engine* h) {
   for (int slot : {PCD_KSP_AP, PCD_KSP_MP, PCD_KSP_RP, PCD_KSP_A00}) {
     if (slot == PCD_KSP_RP && !reaction) continue;
     const Inner& s = h->inner[slot];
-    if (s.pc != PCD_PC_MG && s.ksp == PCD_KSP_CG && s.rtol > 0.0) return false;
+    if (s.pc != PCD_PC_MG && (s.ksp == PCD_KSP_CG || s.ksp == PCD_KSP_CG_SR) && s.rtol > 0.0) return false;
   }
   return true;
 }
@@ -1878,7 +1932,7 @@ int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type, int max_it,
                   double rtol, double emin, double emax) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "set_inner: bad slot %d", slot);
-  if (ksp_type < PCD_KSP_PREONLY || ksp_type > PCD_KSP_CG)
+  if (ksp_type < PCD_KSP_PREONLY || ksp_type > PCD_KSP_CG_SR)
     return fail(PCD_ERR_ARG, "set_inner: unsupported ksp type %d", ksp_type);
   if (pc_type != PCD_PC_NONE && pc_type != PCD_PC_JACOBI && pc_type != PCD_PC_MG &&
       pc_type != PCD_PC_EXPLICIT)
@@ -2236,7 +2290,7 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
       Inner& s = h->inner[key - PCD_INFO_ITS_AP];
       if (s.its_on_device && s.state.p) {
         CgState st;
-        HIPCHK(hipMemcpyAsync(&st, s.state.p, sizeof st, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(&st, s.state.p + s.state_idx, sizeof st, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         s.last_its = st.its;
       }

@@ -126,6 +126,7 @@ struct CgState {
   double rz0;
   int its;
   int done;
+  double betaold, dpiold;   // single-reduction variant only
 };
 
 // x = 0, r = b, z = dinv r, p = z; parts_rz[blk] = sum r.z
@@ -221,6 +222,97 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(
       if (it == 0) st->rz0 = rz;
       st->its = it + 1;
     }
+  }
+}
+
+// ---- CG with a single reduction per iteration ------------------------------
+// [ext PETSc] -ksp_cg_single_reduction (Chronopoulos-Gear): beta = (z, r) and
+// delta = (z, A z) are formed by ONE kernel, so several ranks need one
+// all-reduce of two numbers per iteration instead of two of one; p.Ap follows
+// from dpi = delta - beta^2 dpi_old / beta_old^2.  State ping-pongs between
+// st_in / st_out so that every workgroup reads the same snapshot.
+__global__ __launch_bounds__(kBlock) void k_cgsr_init(
+    int n, const double* __restrict__ dinv, const double* b, double* x,
+    double* r, double* z, CgState* st) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const double ri = b[i];
+    x[i] = 0.0; r[i] = ri; z[i] = dinv ? dinv[i] * ri : ri;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st[0].rz0 = 0.0; st[0].its = 0; st[0].done = 0; st[0].betaold = 0.0; st[0].dpiold = 0.0;
+    st[1] = st[0];
+  }
+}
+
+// s = A z; parts_b[blk] = sum z.r, parts_d[blk] = sum z.s
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_cgsr_spmv_dots(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* z, const double* r, double* sv,
+    double* parts_b, double* parts_d, const CgState* st, const double* ghost,
+    int nloc) {
+  __shared__ double sm[4];
+  if (st->done) return;
+  constexpr int RPB = kBlock / LPR;
+  const int lane = threadIdx.x % LPR;
+  const int nloop = (nrows + RPB - 1) / RPB * RPB;
+  const XVec xv{z, ghost, nloc};
+  double ab = 0.0, ad = 0.0;
+  for (int row = blockIdx.x * RPB + threadIdx.x / LPR; row < nloop;
+       row += gridDim.x * RPB) {
+    const double s = row_dot<LPR>(rowptr, col, val, xv, row, nrows, lane);
+    if (lane == 0 && row < nrows) {
+      const double zi = z[row];
+      sv[row] = s; ab += zi * r[row]; ad += zi * s;
+    }
+  }
+  ab = block_sum(ab, sm);
+  ad = block_sum(ad, sm);
+  if (threadIdx.x == 0) { parts_b[blockIdx.x] = ab; parts_d[blockIdx.x] = ad; }
+}
+
+// the iteration's scalars from the (reduced) dots, then all vector updates:
+// p = z + b p, w = s + b w, x += a p, r -= a w, z = dinv r
+__global__ __launch_bounds__(kBlock) void k_cgsr_update(
+    int n, const double* __restrict__ dinv, double* z, const double* sv,
+    double* p, double* w, double* x, double* r, const double* pb, int nb,
+    const double* pd, int nd, double rtol, int it, const CgState* st_in,
+    CgState* st_out) {
+  __shared__ double sm[4];
+  if (st_in->done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *st_out = *st_in;
+    return;
+  }
+  const double beta = reduce_parts(pb, nb, sm);
+  const double delta = reduce_parts(pd, nd, sm);
+  const double beta0 = it == 0 ? beta : st_in->rz0;
+  const bool conv = (beta == 0.0) ||
+      (rtol > 0.0 && sqrt(fabs(beta)) <= rtol * sqrt(fabs(beta0)));
+  if (conv) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *st_out = *st_in; st_out->rz0 = beta0; st_out->its = it; st_out->done = 1;
+    }
+    return;
+  }
+  double bb = 0.0, dpi = delta;
+  if (it > 0) {
+    const double bo = st_in->betaold;
+    bb = beta / bo;
+    dpi = delta - beta * beta * st_in->dpiold / (bo * bo);
+  }
+  const double a = beta / dpi;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const double pi = it > 0 ? z[i] + bb * p[i] : z[i];
+    const double wi = it > 0 ? sv[i] + bb * w[i] : sv[i];
+    p[i] = pi; w[i] = wi;
+    x[i] += a * pi;
+    const double ri = r[i] - a * wi;
+    r[i] = ri;
+    z[i] = dinv ? dinv[i] * ri : ri;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st_out->rz0 = beta0; st_out->its = it + 1; st_out->done = 0;
+    st_out->betaold = beta; st_out->dpiold = dpi;
   }
 }
 

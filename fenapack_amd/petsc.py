@@ -403,6 +403,10 @@ class KSP(object):
         # count on a small operator is applied as <= k sparse factors composed
         # on the host (compose.chebyshev_factors) instead of max_it dependent
         # launches; 0 = step by step
+        # -ksp_cg_single_reduction [ext PETSc]: both inner products of a CG
+        # iteration in one reduction (one 16-byte all-reduce per iteration on
+        # several ranks instead of two)
+        self.cg_single_reduction = False
         self.cheb_precompose = 2
         # measured on an MI355X (profiles/r02_c_timeline.txt): at 103 041 rows
         # the two factors of Chebyshev(5) on a P1 mass matrix (5.0x and 2.65x
@@ -508,6 +512,10 @@ class KSP(object):
         self.rtol = o.getReal("ksp_rtol", self.rtol)
         self.atol = o.getReal("ksp_atol", self.atol)
         self.norm_type = o.getString("ksp_norm_type", self.norm_type)
+        sr = o.getString("ksp_cg_single_reduction")
+        if sr is not None:
+            self.cg_single_reduction = str(sr).lower() in ("1", "true", "yes",
+                                                           "")
         self.restart = o.getInt("ksp_gmres_restart", self.restart)
         e = o.getString("ksp_chebyshev_eigenvalues")
         if e is not None:
@@ -683,7 +691,15 @@ class KSP(object):
                                   0.0, lo, hi)
             self.precomposed = [W.nnz for W in F]
             return
-        self.engine.set_inner(self.slot, self.type, pc, max_it, rtol, lo, hi)
+        self.engine.set_inner(self.slot, self.engine_type, pc, max_it, rtol,
+                              lo, hi)
+
+    @property
+    def engine_type(self):
+        """Name of the solver as the engine knows it."""
+        if self.type == "cg" and self.cg_single_reduction:
+            return "cgsr"
+        return self.type
 
     def setUp(self):
         if self.engine is not None and self.slot is not None:

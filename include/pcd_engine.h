@@ -65,7 +65,11 @@ enum pcd_slot { PCD_KSP_AP = 0, PCD_KSP_MP = 1, PCD_KSP_RP = 2,
 
 /* [ext PETSc] KSP types honoured (-<prefix>ksp_type), SURVEY 5 "Config" */
 enum pcd_ksp_type { PCD_KSP_PREONLY = 0, PCD_KSP_RICHARDSON = 1,
-                    PCD_KSP_CHEBYSHEV = 2, PCD_KSP_CG = 3 };
+                    PCD_KSP_CHEBYSHEV = 2, PCD_KSP_CG = 3,
+                    /* KSPCG with -ksp_cg_single_reduction [ext PETSc]: both
+                     * inner products of an iteration in one reduction (one
+                     * 16-byte all-reduce per iteration on several ranks) */
+                    PCD_KSP_CG_SR = 4 };
 /* [ext PETSc] PC types honoured (-<prefix>pc_type) */
 enum pcd_pc_type { PCD_PC_NONE = 0, PCD_PC_JACOBI = 1, PCD_PC_MG = 2,
                    /* the solve is a product of sparse factors the caller

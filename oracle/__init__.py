@@ -139,7 +139,7 @@ def mirror(o, pb, ksp):
         else:
             lo, hi = (k._chebyshev_bounds() if k.type == "chebyshev"
                       else (0.5, 2.0))
-            o.set_inner(slot, k.type, "jacobi", k.max_it,
+            o.set_inner(slot, k.engine_type, "jacobi", k.max_it,
                         k.rtol if k.type == "cg" else 0.0, lo, hi)
     o.setup()
     return o

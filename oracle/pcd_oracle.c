@@ -45,7 +45,7 @@
 
 enum { MAT_AP = 0, MAT_MP, MAT_KP, MAT_RP, MAT_A00, MAT_A01, MAT_A, MAT_COUNT };
 enum { SLOT_AP = 0, SLOT_MP, SLOT_RP, SLOT_A00, SLOT_COUNT };
-enum { KSP_PREONLY = 0, KSP_RICHARDSON, KSP_CHEBYSHEV, KSP_CG };
+enum { KSP_PREONLY = 0, KSP_RICHARDSON, KSP_CHEBYSHEV, KSP_CG, KSP_CG_SR };
 enum { PC_NONE = 0, PC_JACOBI };
 enum { BRM1 = 1, BRM2, RBRM1, RBRM2 };
 
@@ -177,6 +177,51 @@ static int solve_cg(const csr_t *A, inner_t *s, const double *b, double *x,
     ++it;
   }
   s->last_its = it;
+  return 0;
+}
+
+/* [ext PETSc] KSPCG with -ksp_cg_single_reduction (KSPCGUseSingleReduction;
+ * the Chronopoulos-Gear recurrence of KSPSolve_CG): the two inner products of
+ * an iteration, beta = (z, r) and delta = (z, A z), are formed together - ONE
+ * all-reduce of two numbers per iteration on several ranks instead of two of
+ * one - and p.Ap follows from the recurrence
+ *     dpi = delta - beta^2 dpi_old / beta_old^2.
+ * Same stopping rule as solve_cg (natural norm sqrt|beta|, zero guess). */
+static int solve_cg_sr(const csr_t *A, inner_t *s, const double *b, double *x,
+                       double *r, double *z, double *p, double *sv) {
+  int64_t n = A->nrows;
+  double *w = (double *)malloc(sizeof(double) * n);
+  memset(x, 0, sizeof(double) * n);
+  memcpy(r, b, sizeof(double) * n);
+  pc_apply(A, s->pc, r, z);
+  spmv(A, z, sv);                                  /* s = A z */
+  double beta = dot(n, z, r), delta = dot(n, z, sv);
+  double beta0 = beta, betaold = 0.0, dpi = 0.0, dpiold = 0.0;
+  int it = 0;
+  while (it < s->max_it) {
+    if (beta == 0.0) break;
+    if (s->rtol > 0.0 && sqrt(fabs(beta)) <= s->rtol * sqrt(fabs(beta0))) break;
+    if (it == 0) {
+      memcpy(p, z, sizeof(double) * n);
+      memcpy(w, sv, sizeof(double) * n);
+      dpi = delta;
+    } else {
+      double bb = beta / betaold;
+      for (int64_t i = 0; i < n; ++i) p[i] = z[i] + bb * p[i];
+      for (int64_t i = 0; i < n; ++i) w[i] = sv[i] + bb * w[i];
+      dpi = delta - beta * beta * dpiold / (betaold * betaold);
+    }
+    dpiold = dpi; betaold = beta;
+    double a = beta / dpi;
+    for (int64_t i = 0; i < n; ++i) x[i] += a * p[i];
+    for (int64_t i = 0; i < n; ++i) r[i] -= a * w[i];
+    pc_apply(A, s->pc, r, z);
+    spmv(A, z, sv);
+    beta = dot(n, z, r); delta = dot(n, z, sv);
+    ++it;
+  }
+  s->last_its = it;
+  free(w);
   return 0;
 }
 
@@ -357,6 +402,7 @@ static int inner_solve(pcdo_t *h, int slot, const double *b, double *x) {
     case KSP_RICHARDSON: rc = solve_rich(A, s, b, x, t0, t1); break;
     case KSP_CHEBYSHEV: rc = solve_cheb(A, s, b, x, t0, t1, t2, t3); break;
     case KSP_CG: rc = solve_cg(A, s, b, x, t0, t1, t2, t3); break;
+    case KSP_CG_SR: rc = solve_cg_sr(A, s, b, x, t0, t1, t2, t3); break;
     default: rc = fail(1, "unknown ksp type");
   }
   free(t0);
@@ -524,7 +570,7 @@ int pcdo_set_bc(pcdo_t *h, int64_t n_bc, const int32_t *idx,
 int pcdo_set_inner(pcdo_t *h, int slot, int ksp, int pc, int max_it,
                    double rtol, double emin, double emax) {
   if (slot < 0 || slot >= SLOT_COUNT) return fail(1, "set_inner: bad slot");
-  if (ksp < KSP_PREONLY || ksp > KSP_CG) return fail(1, "set_inner: bad ksp");
+  if (ksp < KSP_PREONLY || ksp > KSP_CG_SR) return fail(1, "set_inner: bad ksp");
   if (pc != PC_NONE && pc != PC_JACOBI && pc != PC_MG)
     return fail(1, "set_inner: bad pc");
   if (ksp == KSP_CHEBYSHEV && !(emax > emin && emin > 0.0))

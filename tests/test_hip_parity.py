@@ -387,3 +387,37 @@ def test_supg_preconditioner_matrix_path(hip_lib):
     assert relerr(yae[:V.n_u], L["A00"] @ xs) < 1e-13   # operator holds A00
     assert relerr(y00e, y00o) < 1e-13 and relerr(yae, yao) < 1e-13
     assert ie == io == 12 and relerr(xe, xo) < 1e-8
+
+
+def test_single_reduction_cg_vs_oracle(hip_lib):
+    """-ksp_cg_single_reduction on the HIP engine (one fused SpMV + two dots,
+    one update kernel per iteration) against the oracle's restatement."""
+    st = flow_state("lshape", 4)
+    V = st["V"]
+    e, o = hip_engine(hip_lib, "BRM1"), oracle.Engine("BRM1")
+    rng = np.random.default_rng(31)
+    b = rng.standard_normal(V.n_p)
+    for eng in (e, o):
+        configure_engine(eng, st)
+    for its in (0, 1, 2, 9, 40):
+        ys = []
+        for eng in (e, o):
+            eng.set_inner(c.KSP_AP, "cgsr", "jacobi", its, 0.0)
+            eng.setup()
+            ys.append(eng.inner_solve_np(c.KSP_AP, b))
+            assert int(eng.info(c.INFO_ITS_AP)) == its
+        assert its == 0 or relerr(ys[0], ys[1]) < 1e-11
+    got = []
+    for eng in (e, o):
+        eng.set_inner(c.KSP_AP, "cgsr", "jacobi", 5000, 1e-10)
+        eng.setup()
+        got.append((eng.inner_solve_np(c.KSP_AP, b), int(eng.info(c.INFO_ITS_AP))))
+    assert abs(got[0][1] - got[1][1]) <= 1, (got[0][1], got[1][1])
+    assert relerr(got[0][0], got[1][0]) < 1e-8
+    # inside the PCD apply, against standard CG on the same engine
+    xp = rng.standard_normal(V.n_p)
+    e.set_inner(c.KSP_MP, "cgsr", "jacobi", 200, 1e-12)
+    y1 = e.apply_np(xp)
+    e.set_inner(c.KSP_AP, "cg", "jacobi", 5000, 1e-10)
+    e.set_inner(c.KSP_MP, "cg", "jacobi", 200, 1e-12)
+    assert relerr(y1, e.apply_np(xp)) < 1e-7

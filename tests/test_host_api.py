@@ -71,6 +71,16 @@ def test_options_db_and_unsupported_solvers_are_rejected():
     PETScOptions.set("t_pc_type", "ilu")
     with pytest.raises(ValueError):
         k.setFromOptions()
+    # -ksp_cg_single_reduction [ext PETSc] selects the engine's fused variant
+    PETScOptions.set("t_pc_type", "jacobi")
+    PETScOptions.set("t_ksp_type", "cg")
+    PETScOptions.set("t_ksp_cg_single_reduction", "true")
+    k.setFromOptions()
+    assert (k.type, k.engine_type) == ("cg", "cgsr")
+    PETScOptions.set("t_ksp_cg_single_reduction", "false")
+    k.setFromOptions()
+    assert k.engine_type == "cg"
+    PETScOptions.set("t_ksp_type", "chebyshev")
     PETScOptions.set("t_pc_type", "jacobi")
     PETScOptions.set("t_ksp_type", "pipecr")
     with pytest.raises(ValueError):

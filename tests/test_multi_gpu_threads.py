@@ -68,6 +68,12 @@ def test_spmv_and_apply_partitioned_vs_single(hip_lib, R):
         e.set_inner(c.KSP_AP, "cg", "jacobi", 3000, 1e-10)
         res["cg_tol"] = e.inner_solve_np(c.KSP_AP, xp)
         res["cg_its"] = e.info(c.INFO_ITS_AP)
+        # -ksp_cg_single_reduction: one 2-double all-reduce per iteration
+        e.set_inner(c.KSP_AP, "cgsr", "jacobi", 8, 0.0)
+        res["cgsr"] = e.inner_solve_np(c.KSP_AP, xp)
+        e.set_inner(c.KSP_AP, "cgsr", "jacobi", 3000, 1e-10)
+        res["cgsr_tol"] = e.inner_solve_np(c.KSP_AP, xp)
+        res["cgsr_its"] = e.info(c.INFO_ITS_AP)
         return res
 
     outs = run_ranks(hip_lib, R, "RBRM1", work)
@@ -82,6 +88,9 @@ def test_spmv_and_apply_partitioned_vs_single(hip_lib, R):
             assert relerr(o[key], ref[key]) < 1e-11, key
         assert abs(o["cg_its"] - ref["cg_its"]) <= 1
         assert relerr(o["cg_tol"], ref["cg_tol"]) < 1e-8
+        assert relerr(o["cgsr"], ref["cgsr"]) < 1e-11
+        assert abs(o["cgsr_its"] - ref["cgsr_its"]) <= 1
+        assert relerr(o["cgsr_tol"], ref["cgsr_tol"]) < 1e-8
 
 
 @pytest.mark.parametrize("replicate_below", ["60000", "0", "700"])

@@ -298,3 +298,29 @@ def test_team_timing_port_equals_the_serial_oracle(variant, mg):
         par.team_fieldsplit_apply(x, y)             # buffers are reusable
         assert relerr(y, ref) < 1e-11, threads
     assert par.stream_triad(1 << 20, 2, 2) > 0.0
+
+
+def test_single_reduction_cg_is_cg():
+    """[ext PETSc] -ksp_cg_single_reduction (Chronopoulos-Gear recurrence):
+    the same Krylov iterates as standard CG in exact arithmetic."""
+    st = flow_state("lshape", 3)
+    V = st["V"]
+    o = oracle.Engine("BRM1")
+    configure_engine(o, st)
+    b = np.random.default_rng(8).standard_normal(V.n_p)
+    for its in (0, 1, 2, 7, 30):
+        out = []
+        for t in ("cg", "cgsr"):
+            o.set_inner(c.KSP_AP, t, "jacobi", its, 0.0)
+            o.setup()
+            out.append(o.inner_solve_np(c.KSP_AP, b))
+        assert relerr(out[1], out[0]) < 1e-12 or its == 0
+        assert its or not out[1].any()
+    counts = []
+    for t in ("cg", "cgsr"):
+        o.set_inner(c.KSP_AP, t, "jacobi", 2000, 1e-10)
+        o.setup()
+        x = o.inner_solve_np(c.KSP_AP, b)
+        counts.append(int(o.info(c.INFO_ITS_AP)))
+        assert np.linalg.norm(st["pb"].Ap @ x - b) < 1e-7 * np.linalg.norm(b)
+    assert abs(counts[0] - counts[1]) <= 1, counts
