@@ -239,6 +239,9 @@ def main():
         default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
                               ap_rtol=args.ap_rtol, ap_its=args.ap_its,
                               mp_its=args.mp_its, dim=V.dim)
+    if args.inner == "jacobi" and args.gpus > 1:
+        # several ranks: CG with one 2-double all-reduce per iteration
+        PETScOptions.set("fieldsplit_p_PCD_Ap_ksp_cg_single_reduction", "true")
     if args.smooth_p is not None:
         PETScOptions.set("fieldsplit_p_PCD_Ap_mg_levels_ksp_max_it",
                          args.smooth_p)
