@@ -88,9 +88,6 @@ struct DCsr {
   int rb2 = 0;
   int64_t nnz2 = 0;
   DBuf<int> rowptr2, col2, kron_pos;
-  DBuf<unsigned short> col2s;   // 16-bit column offsets per row block (ColRef), if they fit
-  DBuf<int> cbase2;
-  bool c16 = false;
   DBuf<double> val2;
   DBuf<int> kron_flag;
   // multi-GPU: nrows / ncols are LOCAL counts (ncols = owned columns); ghost
@@ -105,7 +102,6 @@ struct DCsr {
     vals.release(); val2s.release();
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); kron_pos.release();
-    col2s.release(); cbase2.release(); c16 = false;
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
     plan = HaloPlan(); replicated = false;
     set = false; nrows = ncols = nnz = 0; has_src = false;
@@ -339,10 +335,6 @@ static int ensure_pinned(Engine* h, size_t n) {
     }                                                                           \
   } while (0)
 
-static bool g_no_c16 = false;          // PCD_NO_COL16=1: A/B switch
-static inline ColRef colref(const DCsr& A) {
-  return ColRef{A.col2.p, A.c16 ? A.col2s.p : nullptr, A.cbase2.p};
-}
 static inline XVec xvec(const DCsr& A, const double* x) {
   return XVec{x, A.ghost.p, (int)A.ncols};
 }
@@ -436,13 +428,13 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
   const int g = grid_stream(nn, A.rb2);
   switch (A.rb2) {
     case 256: hipLaunchKernelGGL((k_spmv_sc<256, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 nn, A.rowptr2.p, colref(A), A.val2.p, x, ghost, nloc, add, y); break;
+                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
     case 128: hipLaunchKernelGGL((k_spmv_sc<128, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 nn, A.rowptr2.p, colref(A), A.val2.p, x, ghost, nloc, add, y); break;
+                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
     case 64: hipLaunchKernelGGL((k_spmv_sc<64, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                nn, A.rowptr2.p, colref(A), A.val2.p, x, ghost, nloc, add, y); break;
+                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
     default: hipLaunchKernelGGL((k_spmv_sc<32, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                nn, A.rowptr2.p, colref(A), A.val2.p, x, ghost, nloc, add, y); break;
+                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
   }
 }
 
@@ -607,7 +599,7 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
   CHK(halo_exchange(h, A, pk));
   if (dinv && kron_ok(A, b, pm, pk, pn)) {
     const int nn = n / A.kron;
-    LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, colref(A),
+    LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
                (int)(A.ncols / A.kron));
   } else if (A.rb) {
@@ -631,7 +623,7 @@ static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
   const int n = (int)A.nrows;
   if (kron_ok(A, b, p0, pn)) {
     const int nn = n / A.kron;
-    LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, colref(A),
+    LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2s.p, dinv, b, p0, pn, s, c1, c2);
     return;
   }
@@ -1329,29 +1321,6 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     HIPCHK(hipMemcpy(A.kron_pos.p + c * A.nnz2, pos[c].data(), A.nnz2 * sizeof(int),
                      hipMemcpyHostToDevice));
   A.kron = A.kron_pat = nc; A.rb2 = rb2;
-  // 16-bit column offsets per row block, if every block spans < 65 536 columns
-  A.c16 = false;
-  if (rb2 > 0 && !g_no_c16) {
-    const int64_t nb = (nn + rb2 - 1) / rb2;
-    std::vector<int32_t> base(nb, 0);
-    std::vector<unsigned short> c16(cc.size());
-    bool fits = true;
-    for (int64_t b = 0; b < nb && fits; ++b) {
-      const int64_t r0 = b * rb2, r1 = std::min<int64_t>(r0 + rb2, nn);
-      int32_t lo = INT32_MAX, hi = -1;
-      for (int32_t k = rpc[r0]; k < rpc[r1]; ++k) { lo = std::min(lo, cc[k]); hi = std::max(hi, cc[k]); }
-      if (hi < 0) { base[b] = 0; continue; }
-      if ((int64_t)hi - lo > 65535) { fits = false; break; }
-      base[b] = lo;
-      for (int32_t k = rpc[r0]; k < rpc[r1]; ++k) c16[k] = (unsigned short)(cc[k] - lo);
-    }
-    if (fits) {
-      CHK(A.col2s.ensure(cc.size())); CHK(A.cbase2.ensure(nb));
-      HIPCHK(hipMemcpy(A.col2s.p, c16.data(), cc.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(A.cbase2.p, base.data(), nb * sizeof(int), hipMemcpyHostToDevice));
-      A.c16 = true;
-    }
-  }
   if (have_vals) CHK(refresh_kron(h, A));
   return 0;
 }
@@ -1509,7 +1478,6 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_FORCE_CSR_VECTOR"); g_force_vector = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_KRON2"); g_no_kron = e && e[0] == '1'; }
   { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
-  { const char* e = getenv("PCD_NO_COL16"); g_no_c16 = e && e[0] == '1'; }
   { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
   { const char* e = getenv("PCD_MAX_CHUNKS"); if (e && atoi(e) >= 1) g_max_chunks = atoi(e); }
   // measured (profiles/r02_l_*): every cross-stream event join costs 6-12 us

@@ -674,20 +674,9 @@ struct XScaledC {
   }
 };
 
-// Column indices of a multi-component operator: 32-bit, or - where every row
-// block of RB rows spans fewer than 65 536 columns, which a locality-
-// preserving numbering gives - 16-bit offsets from a per-row-block base:
-// 10 instead of 12 bytes per stored entry on a stream that is bandwidth-bound
-// (DESIGN.md 4).  The branch is uniform over the workgroup.
-struct ColRef {
-  const int* c32;
-  const unsigned short* c16;   // null: use c32
-  const int* base;             // [row block]
-};
-
 template <int RB, int NC, class XF>
 __device__ __forceinline__ VecC<NC> stream_row_block_c(
-    const int* __restrict__ rowptr, const ColRef col,
+    const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const XF& xf, int r0, int nrows,
     VecC<NC>* lds) {
   const int r1 = min(r0 + RB, nrows);
@@ -701,8 +690,6 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
   VecC<NC> s = vzero<NC>();
   constexpr int kTileC = tile_c<NC>();
   double* planes = reinterpret_cast<double*>(lds);   // NC planes of kTileC doubles
-  const bool c16 = col.c16 != nullptr;
-  const int cbase = c16 ? col.base[r0 / RB] : 0;
   for (int c0 = 0; c0 < k1 - k0; c0 += kTileC) {   // chunks of the LDS tile
     const int c1 = min(c0 + kTileC, k1 - k0);
     if (c0) __syncthreads();
@@ -713,8 +700,7 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
       for (int u = 0; u < kUnroll; ++u) {
         const int k = base + u * kBlock + threadIdx.x;
         const bool in = k < k0 + c1;
-        c[u] = in ? (c16 ? cbase + (int)PCD_STREAM_LOAD(col.c16 + k)
-                         : PCD_STREAM_LOAD(col.c32 + k)) : -1;
+        c[u] = in ? PCD_STREAM_LOAD(col + k) : -1;
         v[u] = in ? PCD_STREAM_LOAD(val + k) : 0.0;
       }
       VecC<NC> xv[kUnroll];
@@ -766,7 +752,7 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
 // vectors arrive as plain double* (node-interleaved) and are viewed as VecC
 template <int RB, int MODE, int NC>
 __global__ __launch_bounds__(kBlock) void k_spmv_sc(
-    int nrows, const int* __restrict__ rowptr, const ColRef col,
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* x, const double* ghost,
     int nloc, const double* add_, double* y_) {
   __shared__ VecC<NC> lds[tile_c<NC>()];
@@ -797,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
 
 template <int RB, int NC>
 __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
-    int nrows, const int* __restrict__ rowptr, const ColRef col,
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* __restrict__ dinv_,
     const double* b_, const double* pm_, const double* pk_, double* pn_,
     double c0, double c1, double c2, const double* ghost, int nloc) {
@@ -834,7 +820,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
 
 template <int RB, int NC>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
-    int nrows, const int* __restrict__ rowptr, const ColRef col,
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ dinv_,
     const double* b_, double* p0_, double* pn_, double s, double c1, double c2) {
   __shared__ VecC<NC> lds[tile_c<NC>()];
