@@ -88,6 +88,7 @@ _HIP_ONLY = {
                               C.c_void_p],
     "fe_set_supg": [C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                     C.c_void_p, C.c_void_p, C.c_void_p],
+    "fe_set_newton": [C.c_int, C.c_void_p],
     "fe_bind_system": [C.c_void_p],
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
     "fe_set_kp_const": [C.c_void_p],
@@ -108,6 +109,7 @@ _HIP_ONLY = {
                         C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int),
                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int)],
     "fe_get_level_values": [C.c_int, C.c_void_p],
+    "fe_get_newton_values": [C.c_int, C.c_void_p],
     "fe_get_kp_values": [C.c_void_p],
     "fe_get_bounds": [C.c_int, _f64p, _f64p],
 }
@@ -461,6 +463,10 @@ class Engine(object):
                    _ptr(phi_mid), int(qw_s.size), _ptr(qw_s), _ptr(phi_s),
                    _ptr(dphi_s))
 
+    def fe_set_newton(self, level, pos):
+        pos = _i32(np.asarray(pos).ravel())
+        self._call("fe_set_newton", int(level), _ptr(pos))
+
     def fe_bind_system(self, sys_pos):
         sys_pos = np.ascontiguousarray(sys_pos, dtype=np.int64)
         self._call("fe_bind_system", _ptr(sys_pos))
@@ -541,6 +547,11 @@ class Engine(object):
     def fe_level_values(self, level, nnz):
         out = np.empty(int(nnz))
         self._call("fe_get_level_values", int(level), _ptr(out))
+        return out
+
+    def fe_newton_values(self, level, nnz, dim):
+        out = np.empty((dim * dim, int(nnz)))
+        self._call("fe_get_newton_values", int(level), _ptr(out))
         return out
 
     def fe_kp_values(self, nnz):

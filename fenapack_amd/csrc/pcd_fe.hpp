@@ -151,6 +151,113 @@ __global__ __launch_bounds__(kBlock) void k_fe_convection_p2(
   }
 }
 
+// Newton linearisation (demo_navier-stokes-pcd.py:113-116, `derivative(F, w)`):
+// the term ((du . grad) w, v) couples the velocity components,
+//   N_ij[a][b] = sum_q w_q |K| phi_a(q) phi_b(q) d_j w_i(q),
+// d x d scalar matrices on the pattern of F.  One thread per (cell, local row
+// a); the velocity gradient at a quadrature point is recomputed per column b
+// (a handful of flops) so that only d*d accumulators live in registers.
+// cells out [((i*DIM+j)*NA*NA + a*NA+b)][c].
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void k_fe_newton_p2(
+    int nc, const int* __restrict__ dofs2, const double* __restrict__ gradlam,
+    const double* __restrict__ measure, const FeTables T,
+    const double* __restrict__ U, double* __restrict__ cells) {
+  constexpr int NV = DIM + 1, NA = DIM == 2 ? 6 : 10;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= (int64_t)NA * nc) return;
+  const int a = (int)(t / nc), c = (int)(t % nc);
+  double g[NV][DIM], Uc[NA][DIM];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) g[k][d] = gradlam[(int64_t)(k * DIM + d) * nc + c];
+#pragma unroll
+  for (int b = 0; b < NA; ++b) {
+    const int node = dofs2[(int64_t)b * nc + c];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) Uc[b][d] = U[(int64_t)DIM * node + d];
+  }
+  const double meas = measure[c];
+  const int64_t plane = (int64_t)NA * NA * nc;
+  for (int b = 0; b < NA; ++b) {
+    double acc[DIM][DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) acc[i][j] = 0.0;
+    for (int q = 0; q < T.nq; ++q) {
+      double gw[DIM][DIM];               // gw[i][j] = d_j w_i at q
+#pragma unroll
+      for (int i = 0; i < DIM; ++i)
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) gw[i][j] = 0.0;
+#pragma unroll
+      for (int e = 0; e < NA; ++e) {
+        double ge[DIM];                  // grad phi_e at q
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < NV; ++k) s += T.dphi[(q * NA + e) * NV + k] * g[k][j];
+          ge[j] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) gw[i][j] += Uc[e][i] * ge[j];
+      }
+      const double f = T.qw[q] * meas * T.phi[q * NA + a] * T.phi[q * NA + b];
+#pragma unroll
+      for (int i = 0; i < DIM; ++i)
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) acc[i][j] += f * gw[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j)
+        cells[(int64_t)(i * DIM + j) * plane + (int64_t)(a * NA + b) * nc + c] = acc[i][j];
+  }
+}
+
+// the ncomp = d*d scalar matrices of the Newton term gathered on the pattern of
+// F: out[m*nnz + k] = sum of the element contributions of plane m (list order),
+// Dirichlet rows/columns removed (keep); `unc` (optional) without the mask
+__global__ __launch_bounds__(kBlock) void k_fe_gather_blocks(
+    int64_t nnz, int ncomp, int64_t plane, const int* __restrict__ ptr,
+    const int* __restrict__ src, const double* __restrict__ cells,
+    const unsigned char* __restrict__ keep, double* unc, double* out) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
+       k += (int64_t)gridDim.x * kBlock) {
+    const bool kept = !(keep && !keep[k]);
+    for (int m = 0; m < ncomp; ++m) {
+      const double* cm = cells + (int64_t)m * plane;
+      double s = 0.0;
+      for (int t = ptr[k]; t < ptr[k + 1]; ++t) s += cm[src[t]];
+      if (unc) unc[(int64_t)m * nnz + k] = s;
+      out[(int64_t)m * nnz + k] = kept ? s : 0.0;
+    }
+  }
+}
+
+// dst[pos[(i*d+j)*nnz + k]] = delta_ij F[k] + N[(i*d+j)*nnz + k]: the coupled
+// velocity block F x I_d + N written into a general CSR (F, N optional)
+template <class I>
+__global__ __launch_bounds__(kBlock) void k_fe_scatter_blocks(
+    int64_t nnz, int d, const I* __restrict__ pos, const double* __restrict__ F,
+    const double* __restrict__ N, double* dst) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
+       k += (int64_t)gridDim.x * kBlock) {
+    const double f = F ? F[k] : 0.0;
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) {
+        const int64_t m = (int64_t)(i * d + j) * nnz + k;
+        dst[pos[m]] = (i == j ? f : 0.0) + (N ? N[m] : 0.0);
+      }
+  }
+}
+
 // One thread per cell: P1 convection matrix of the pressure space
 //   K[i][j] = scale * sum_q w_q |K| psi_i(q) (w(q) . grad lambda_j)
 // (grad lambda_j is constant on the cell); cells out [(i*NV+j)][c].

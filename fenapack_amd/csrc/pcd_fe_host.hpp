@@ -21,9 +21,15 @@ struct FeLevel {
   DBuf<int64_t> b_ptr, c_ptr;
   DBuf<int> b_src, c_src;
   DBuf<double> b_w, c_w, B;
+  // Newton linearisation: the d*d scalar matrices N_ij (masked), their element
+  // storage, the Galerkin intermediate, and where block entry (i, j, k) sits in
+  // the values of this level's operator
+  DBuf<double> N, cellsN, BN;
+  DBuf<int> npos;
   void release() {
     b_ptr.release(); c_ptr.release(); b_src.release(); c_src.release();
     b_w.release(); c_w.release(); B.release();
+    N.release(); cellsN.release(); BN.release(); npos.release();
     cell_h.release(); cells_s.release(); Fa.release();
     dofs2.release(); f_ptr.release(); f_src.release(); diag_pos.release();
     inject.release(); gradlam.release(); measure.release(); f_const.release();
@@ -39,7 +45,9 @@ struct FeState {
   bool supg = false; double nu = 0.0;
   std::vector<FeLevel> lev;
   DBuf<double> Func;                 // unconstrained finest values (residual)
-  DBuf<int64_t> sys_pos; bool sys_bound = false;
+  bool newton = false;               // coupled block F x I + N (pcd_fe_set_newton)
+  DBuf<double> Nunc, Jv, inv_vals, dvec, y2;
+  DBuf<int64_t> sys_pos; bool sys_bound = false; int sys_blocks = 0;
   int64_t nnz_kp = 0; double kp_scale = 1.0; bool kp_bound = false;
   DBuf<int> kp_ptr, kp_src;
   DBuf<double> kp_const, kp_cells, kp_vals;
@@ -66,6 +74,7 @@ struct FeState {
     for (auto& l : lev) l.release();
     lev.clear();
     qw.release(); phi.release(); dphi.release(); psi.release(); Func.release();
+    Nunc.release(); Jv.release(); inv_vals.release(); dvec.release(); y2.release();
     phic.release(); qw_s.release(); phi_s.release(); dphi_s.release();
     sys_pos.release(); kp_ptr.release(); kp_src.release(); kp_const.release();
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
@@ -100,11 +109,23 @@ static FeTables fe_tables(const FeState& fe) {
 }
 
 // coarse operator as the Galerkin product of the next finer level's one
-static int fe_galerkin_level(Engine* h, FeLevel& L, const FeLevel& finer) {
+static int fe_galerkin_level(Engine* h, FeLevel& L, const FeLevel& finer, bool newton, int d2) {
   hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(L.nnzb, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
                      L.nnzb, L.b_ptr.p, L.b_src.p, L.b_w.p, finer.F.p, L.B.p);
   hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
                      L.nnzf, L.c_ptr.p, L.c_src.p, L.c_w.p, L.B.p, L.F.p);
+  if (newton) {
+    // P = P_s x I_d: every block of P^T (F x I + N) P is the scalar triple
+    // product of that block
+    for (int m = 0; m < d2; ++m) {
+      hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(L.nnzb, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
+                         L.nnzb, L.b_ptr.p, L.b_src.p, L.b_w.p, finer.N.p + (int64_t)m * finer.nnzf,
+                         L.BN.p + (int64_t)m * L.nnzb);
+      hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
+                         L.nnzf, L.c_ptr.p, L.c_src.p, L.c_w.p, L.BN.p + (int64_t)m * L.nnzb,
+                         L.N.p + (int64_t)m * L.nnzf);
+    }
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -137,6 +158,17 @@ static int fe_assemble_level(Engine* h, FeState& fe, FeLevel& L, const double* U
     if (supg && top)
       hipLaunchKernelGGL(k_fe_set, dim3(grid1d(L.ndiag)), dim3(kBlock), 0, h->stream,
                          (int)L.ndiag, L.diag_pos.p, L.diag_val.p, L.Fa.p);
+  }
+  if (fe.newton) {
+    if (fe.dim == 2)
+      hipLaunchKernelGGL(k_fe_newton_p2<2>, dim3(g), dim3(kBlock), 0, h->stream, (int)L.nc, L.dofs2.p,
+                         L.gradlam.p, L.measure.p, fe_tables(fe), U, L.cellsN.p);
+    else
+      hipLaunchKernelGGL(k_fe_newton_p2<3>, dim3(g), dim3(kBlock), 0, h->stream, (int)L.nc, L.dofs2.p,
+                         L.gradlam.p, L.measure.p, fe_tables(fe), U, L.cellsN.p);
+    hipLaunchKernelGGL(k_fe_gather_blocks, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
+                       L.nnzf, fe.dim * fe.dim, (int64_t)na * na * L.nc, L.f_ptr.p, L.f_src.p,
+                       L.cellsN.p, L.f_keep.p, (top && unc) ? fe.Nunc.p : (double*)nullptr, L.N.p);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -193,14 +225,22 @@ static int fe_estimate_emax(Engine* h, FeState& fe, FeLevel& L, const DCsr& A,
 
 // level 0 of the multigrid = dense inverse of the coarsest operator F_0 x I_d
 static int fe_invert_coarsest(Engine* h, FeState& fe, MgLevel& M0) {
-  const int n = (int)fe.inv_n, d = fe.dim;
+  // Newton: the coarsest operator is a coupled (d n0)^2 matrix, inverted whole
+  const int n = (int)fe.inv_n, d = fe.newton ? 1 : fe.dim;
   const int64_t N = (int64_t)n * d;
   if (!M0.A.set || M0.A.nrows != N || M0.A.nnz != N * N)
     return fail(PCD_ERR_STATE, "fe: multigrid level 0 is not the dense %lld x %lld inverse",
                 (long long)N, (long long)N);
   HIPCHK(hipMemsetAsync(fe.inv_flag.p, 0, sizeof(int), h->stream));
+  const double* vals0 = fe.lev[0].F.p;
+  if (fe.newton) {
+    FeLevel& L0 = fe.lev[0];
+    hipLaunchKernelGGL(k_fe_scatter_blocks<int>, dim3(grid1d(L0.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                       h->stream, L0.nnzf, fe.dim, L0.npos.p, L0.F.p, L0.N.p, fe.inv_vals.p);
+    vals0 = fe.inv_vals.p;
+  }
   hipLaunchKernelGGL(k_gj_init, dim3(n), dim3(kBlock), 0, h->stream, n, fe.inv_rowptr.p,
-                     fe.inv_col.p, fe.lev[0].F.p, fe.inv_W.p, fe.inv_col0.p);
+                     fe.inv_col.p, vals0, fe.inv_W.p, fe.inv_col0.p);
   double* cc[2] = {fe.inv_col0.p, fe.inv_col1.p};
   for (int k = 0; k < n; ++k)
     hipLaunchKernelGGL(k_gj_step, dim3(n), dim3(kBlock), 0, h->stream, n, k, fe.inv_W.p,
@@ -225,8 +265,13 @@ int pcd_fe_bind_coarse_inverse(pcd_handle h, int64_t n0, const int32_t* rowptr,
                                const int32_t* colidx) {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_coarse_inverse: call pcd_fe_begin first");
   FeState& fe = *h->fe;
-  if (n0 < 1 || n0 > 8192 || !rowptr || !colidx || !fe.lev[0].set || rowptr[n0] != fe.lev[0].nnzf)
+  const int64_t want = fe.newton ? (int64_t)fe.dim * fe.dim * fe.lev[0].nnzf : fe.lev[0].nnzf;
+  if (n0 < 1 || n0 > 8192 || !rowptr || !colidx || !fe.lev[0].set || rowptr[n0] != want)
     return fail(PCD_ERR_ARG, "fe_bind_coarse_inverse: bad pattern (n0 <= 8192)");
+  if (fe.newton) {
+    if (!fe.lev[0].npos.p) return fail(PCD_ERR_STATE, "fe_bind_coarse_inverse: level 0 has no Newton positions");
+    CHK(fe.inv_vals.ensure((size_t)want));
+  }
   HIPCHK(hipSetDevice(h->device));
   fe.inv_n = n0;
   CHK(fe_upload(fe.inv_rowptr, rowptr, (size_t)n0 + 1));
@@ -358,20 +403,54 @@ int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
   return 0;
 }
 
+// Newton linearisation (`--nls newton`, demo_navier-stokes-pcd.py:42,113-116):
+// the velocity block becomes F x I_d + N(w), N_ij = (phi_b d_j w_i, phi_a), on
+// the pattern (pattern of F) x ones(d, d).  Call once per level after
+// pcd_fe_set_level / _galerkin and before pcd_fe_bind_system /
+// pcd_fe_bind_coarse_inverse: pos[(i*d+j) * nnz_f + k] = where block entry
+// (i, j) of scalar entry k sits in the values of that level's operator - the
+// multigrid level's CSR (0 < level < finest), the engine's A00 (finest), the
+// CSR handed to pcd_fe_bind_coarse_inverse (level 0, then (d n0) rows).
+int pcd_fe_set_newton(pcd_handle h, int level, const int32_t* pos) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_newton: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev || !fe.lev[level].set || !pos)
+    return fail(PCD_ERR_ARG, "fe_set_newton: level %d is not set / null positions", level);
+  FeLevel& L = fe.lev[level];
+  const int d2 = fe.dim * fe.dim;
+  const int64_t total = (int64_t)d2 * L.nnzf;
+  if (total >= INT32_MAX) return fail(PCD_ERR_ARG, "fe_set_newton: block values exceed int32 indexing");
+  for (int64_t i = 0; i < total; ++i)
+    if (pos[i] < 0 || pos[i] >= total) return fail(PCD_ERR_ARG, "fe_set_newton: position outside the block values");
+  HIPCHK(hipSetDevice(h->device));
+  CHK(fe_upload(L.npos, pos, (size_t)total));
+  CHK(L.N.ensure((size_t)total));
+  if (L.galerkin) CHK(L.BN.ensure((size_t)d2 * L.nnzb));
+  else {
+    const int na = fe.dim == 2 ? 6 : 10;
+    CHK(L.cellsN.ensure((size_t)d2 * na * na * L.nc));
+  }
+  fe.newton = true;
+  fe.sys_bound = false;                  // positions of d blocks are not enough any more
+  return 0;
+}
+
 // sys_pos[c * nnz_f + k]: where entry k of the finest scalar operator sits, for
-// component c, in the caller's system values (pcd_set_system's array)
+// component c, in the caller's system values (pcd_set_system's array).  After
+// pcd_fe_set_newton: sys_pos[(i * d + j) * nnz_f + k] for every block (i, j).
 int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos) {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_system: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   FeLevel& L = fe.lev[fe.nlev - 1];
   if (!L.set || !sys_pos) return fail(PCD_ERR_ARG, "fe_bind_system: finest level not set / null map");
   if (!h->mat[PCD_MAT_A].set) return fail(PCD_ERR_STATE, "fe_bind_system: no system set");
-  for (int64_t i = 0; i < fe.dim * L.nnzf; ++i)
+  const int nb = fe.newton ? fe.dim * fe.dim : fe.dim;
+  for (int64_t i = 0; i < nb * L.nnzf; ++i)
     if (sys_pos[i] < 0 || sys_pos[i] >= h->sys_nnz)
       return fail(PCD_ERR_ARG, "fe_bind_system: position outside the system values");
   HIPCHK(hipSetDevice(h->device));
-  CHK(fe_upload(fe.sys_pos, sys_pos, (size_t)fe.dim * L.nnzf));
-  fe.sys_bound = true;
+  CHK(fe_upload(fe.sys_pos, sys_pos, (size_t)nb * L.nnzf));
+  fe.sys_bound = true; fe.sys_blocks = nb;
   return 0;
 }
 
@@ -479,8 +558,16 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
                        L.nn2, fe.dim, L.inject.p, fe.lev[l + 1].U.p, L.U.p);
   }
   if (want_unc) CHK(fe.Func.ensure(Lt.nnzf));
+  const int d2 = fe.dim * fe.dim;
+  if (fe.newton) {
+    for (auto& L : fe.lev)
+      if (!L.npos.p) return fail(PCD_ERR_STATE, "fe_update: pcd_fe_set_newton was not called for every level");
+    if (fe.sys_bound && fe.sys_blocks != d2)
+      return fail(PCD_ERR_STATE, "fe_update: bind the system after pcd_fe_set_newton (d*d blocks)");
+    if (want_unc) CHK(fe.Nunc.ensure((size_t)d2 * Lt.nnzf));
+  }
   for (int l = top; l >= 0; --l) {
-    if (fe.lev[l].galerkin) CHK(fe_galerkin_level(h, fe.lev[l], fe.lev[l + 1]));
+    if (fe.lev[l].galerkin) CHK(fe_galerkin_level(h, fe.lev[l], fe.lev[l + 1], fe.newton, fe.dim * fe.dim));
     else CHK(fe_assemble_level(h, fe, fe.lev[l], fe.lev[l].U.p, (l == top && want_unc) ? fe.Func.p : nullptr, l == top));
   }
 
@@ -493,16 +580,27 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
       // the stabilised ones (nonlinear_solvers.py:75-76: P != A)
       if (!h->psysvals.p || (int64_t)h->psysvals.n < h->sys_nnz)
         return fail(PCD_ERR_STATE, "fe_update: SUPG needs the preconditioner values staged (pvals of pcd_set_system)");
-      hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
-                         h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.Fa.p, h->sysvals.p);
-      hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
-                         h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, h->psysvals.p);
+      if (fe.newton) {
+        hipLaunchKernelGGL(k_fe_scatter_blocks<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                           h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.Fa.p, Lt.N.p, h->sysvals.p);
+        hipLaunchKernelGGL(k_fe_scatter_blocks<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                           h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, Lt.N.p, h->psysvals.p);
+      } else {
+        hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                           h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.Fa.p, h->sysvals.p);
+        hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                           h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, h->psysvals.p);
+      }
       CHK(pcd_update_system(h, h->sysvals.p, h->psysvals.p, PCD_MEM_DEVICE));
     } else {
       if (h->psysvals.p)
         return fail(PCD_ERR_STATE, "fe_update: a separate preconditioner matrix needs pcd_fe_set_supg");
-      hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
-                         h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, h->sysvals.p);
+      if (fe.newton)
+        hipLaunchKernelGGL(k_fe_scatter_blocks<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                           h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, Lt.N.p, h->sysvals.p);
+      else
+        hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                           h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, Lt.F.p, h->sysvals.p);
       CHK(pcd_update_system(h, h->sysvals.p, nullptr, PCD_MEM_DEVICE));
     }
   }
@@ -516,10 +614,17 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
       M.fused = false;                   // composed from the previous iterate
       const DCsr* A = &h->mat[kSlotMat[fe.mg_slot]];
       if (l < top) {
-        if (!M.A.set || M.A.kron != fe.dim || M.A.nnz2 != L.nnzf)
-          return fail(PCD_ERR_STATE, "fe_update: multigrid level %d is not F x I_%d on the FE pattern", l, fe.dim);
-        hipLaunchKernelGGL(k_fe_scatter<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
-                           h->stream, L.nnzf, fe.dim, M.A.kron_pos.p, L.F.p, M.A.val.p);
+        if (fe.newton) {
+          if (!M.A.set || M.A.nnz != (int64_t)d2 * L.nnzf)
+            return fail(PCD_ERR_STATE, "fe_update: multigrid level %d is not the coupled block on the FE pattern", l);
+          hipLaunchKernelGGL(k_fe_scatter_blocks<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                             h->stream, L.nnzf, fe.dim, L.npos.p, L.F.p, L.N.p, M.A.val.p);
+        } else {
+          if (!M.A.set || M.A.kron != fe.dim || M.A.nnz2 != L.nnzf)
+            return fail(PCD_ERR_STATE, "fe_update: multigrid level %d is not F x I_%d on the FE pattern", l, fe.dim);
+          hipLaunchKernelGGL(k_fe_scatter<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                             h->stream, L.nnzf, fe.dim, M.A.kron_pos.p, L.F.p, M.A.val.p);
+        }
         CHK(refresh_dinv(h, M.A));
         A = &M.A;
       }
@@ -563,9 +668,40 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
 
 // y = (F_unconstrained x I_d) v on the pattern of A00 (needs fe_refresh with
 // want_unc)
+// y = (S x I_d + [Nb]) v on the pattern of the coupled A00 (Newton): the values
+// are scattered into a scratch array that stands in for A00's own
+static int fe_apply_blocks(Engine* h, FeState& fe, const double* S, const double* Nb,
+                           const double* dv, double* dy) {
+  DCsr& A = h->mat[PCD_MAT_A00];
+  FeLevel& Lt = fe.lev[fe.nlev - 1];
+  if (!A.set || A.kron || A.nnz != (int64_t)fe.dim * fe.dim * Lt.nnzf)
+    return fail(PCD_ERR_STATE, "fe_update: A00 is not the coupled block on the FE pattern");
+  CHK(fe.Jv.ensure((size_t)A.nnz));
+  hipLaunchKernelGGL(k_fe_scatter_blocks<int>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                     h->stream, Lt.nnzf, fe.dim, Lt.npos.p, S, Nb, fe.Jv.p);
+  std::swap(A.val.p, fe.Jv.p);
+  const int rc = spmv(h, A, dv, dy);
+  std::swap(A.val.p, fe.Jv.p);
+  return rc;
+}
+
+// Newton: y -= N_unc (xu - v), the part of J d (d = boundary defect of the
+// iterate) that the Picard operator does not carry (FlowProblem.linearise:
+// F_u = A00_picard x_u - A00_newton d)
+static int fe_subtract_newton_defect(Engine* h, FeState& fe, const double* dxu, const double* dv, double* dy) {
+  const int64_t nu = fe.dim * fe.lev[fe.nlev - 1].nn2;
+  CHK(fe.dvec.ensure(nu)); CHK(fe.y2.ensure(nu));
+  HIPCHK(hipMemcpyAsync(fe.dvec.p, dxu, nu * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, -1.0, dv, 1.0, fe.dvec.p);
+  CHK(fe_apply_blocks(h, fe, nullptr, fe.Nunc.p, fe.dvec.p, fe.y2.p));
+  hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, -1.0, fe.y2.p, 1.0, dy);
+  return 0;
+}
+
 static int fe_apply_unconstrained(Engine* h, FeState& fe, const double* dv, double* dy) {
   DCsr& A = h->mat[PCD_MAT_A00];
   FeLevel& Lt = fe.lev[fe.nlev - 1];
+  if (fe.newton) return fe_apply_blocks(h, fe, fe.Func.p, nullptr, dv, dy);
   if (!A.set || A.kron != fe.dim || A.nnz2 != Lt.nnzf)
     return fail(PCD_ERR_STATE, "fe_update: A00 is not F x I_%d on the FE pattern", fe.dim);
   if (!kron_ok(A, dv, dy))
@@ -600,6 +736,7 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
   CHK(fe_refresh(h, fe, dxu, v != nullptr));
   if (v) {
     CHK(fe_apply_unconstrained(h, fe, dv, dru));
+    if (fe.newton) CHK(fe_subtract_newton_defect(h, fe, dxu, dv, dru));
     if (mem == PCD_MEM_HOST)
       HIPCHK(hipMemcpyAsync(ru, dru, nu * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
@@ -629,6 +766,7 @@ static int fe_residual_dev(Engine* h, FeState& fe, const double* xd, double* bd,
     hipLaunchKernelGGL(k_fe_bc_replace, dim3(grid1d(fe.n_bc)), dim3(kBlock), 0, h->stream,
                        (int)fe.n_bc, fe.bc_idx.p, fe.bc_g.p, fe.vv.p);
   CHK(fe_apply_unconstrained(h, fe, fe.vv.p, Fu));
+  if (fe.newton) CHK(fe_subtract_newton_defect(h, fe, xu, fe.vv.p, Fu));
   CHK(spmv(h, fe.A01raw, xp, Fu, 1, Fu));
   if (fe.have_mu0)
     hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, -1.0, fe.mu0.p, 1.0, Fu);
@@ -699,12 +837,16 @@ int pcd_fe_set_previous(pcd_handle h, const double* u0, int mem) {
   HIPCHK(hipMemcpyAsync(fe.u0.p, u0, nu * sizeof(double),
                         mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
   DCsr& A = h->mat[PCD_MAT_A00];
-  if (!A.set || A.kron != fe.dim || A.nnz2 != fe.lev[fe.nlev - 1].nnzf || !kron_ok(A, fe.u0.p, fe.mu0.p))
-    return fail(PCD_ERR_STATE, "fe_set_previous: A00 is not F x I_%d on the FE pattern", fe.dim);
-  std::swap(A.val2.p, fe.mass.p);        // (M x I) u0 on the pattern of F
-  const int rc = spmv(h, A, fe.u0.p, fe.mu0.p);
-  std::swap(A.val2.p, fe.mass.p);
-  if (rc) return rc;
+  if (fe.newton) {
+    CHK(fe_apply_blocks(h, fe, fe.mass.p, nullptr, fe.u0.p, fe.mu0.p));
+  } else {
+    if (!A.set || A.kron != fe.dim || A.nnz2 != fe.lev[fe.nlev - 1].nnzf || !kron_ok(A, fe.u0.p, fe.mu0.p))
+      return fail(PCD_ERR_STATE, "fe_set_previous: A00 is not F x I_%d on the FE pattern", fe.dim);
+    std::swap(A.val2.p, fe.mass.p);        // (M x I) u0 on the pattern of F
+    const int rc = spmv(h, A, fe.u0.p, fe.mu0.p);
+    std::swap(A.val2.p, fe.mass.p);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, fe.idt, fe.mu0.p, 0.0, fe.mu0.p);
   HIPCHK(hipStreamSynchronize(h->stream));
   fe.have_mu0 = true;
@@ -792,6 +934,20 @@ int pcd_fe_get_level_values(pcd_handle h, int level, double* out) {
     return fail(PCD_ERR_ARG, "fe_get_level_values: bad level / null output");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(out, fe.lev[level].F.p, fe.lev[level].nnzf * sizeof(double),
+                        hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// the d*d scalar matrices of the Newton term on one level as last assembled
+// (host array of d*d*nnz_f values, [(i*d+j)][k]; Dirichlet rows/columns zero)
+int pcd_fe_get_newton_values(pcd_handle h, int level, double* out) {
+  if (!h || !h->fe || !h->fe->newton) return fail(PCD_ERR_STATE, "fe_get_newton_values: pcd_fe_set_newton was not called");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev || !fe.lev[level].N.p || !out)
+    return fail(PCD_ERR_ARG, "fe_get_newton_values: bad level / null output");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(out, fe.lev[level].N.p, (size_t)fe.dim * fe.dim * fe.lev[level].nnzf * sizeof(double),
                         hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;

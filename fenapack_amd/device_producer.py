@@ -9,7 +9,10 @@ velocity iterate only:
 
 * the velocity block ``F x I_d`` with ``F = nu K + idt M + C(w)`` on every
   multigrid level (coarse levels re-discretised with the injected iterate,
-  ``-pc_mg_galerkin none``),
+  ``-pc_mg_galerkin none``, or Galerkin products of the finest one); with the
+  Newton linearisation (``--nls newton``, ``demo_navier-stokes-pcd.py:42,
+  113-116``) the coupled block ``F x I_d + N(w)``, ``N_ij = (phi_b d_j w_i,
+  phi_a)``, on the pattern ``(pattern of F) x ones(d, d)``,
 * ``Kp = (1/nu) (w . grad p, q) [+ idt/nu (p, q)]``,
 * the residual part ``(F_unconstrained x I_d) (x_u - d)``.
 
@@ -29,8 +32,8 @@ import scipy.sparse as sp
 from . import _cabi as c
 from .fem.multigrid import dense_csr, injection_map
 
-__all__ = ["DeviceProducer", "DevicePicardSolver", "solve_steady_device",
-           "solve_unsteady_device"]
+__all__ = ["DeviceProducer", "DevicePicardSolver", "DeviceNonlinearSolver",
+           "solve_steady_device", "solve_unsteady_device"]
 
 
 def _contribution_plan(inv, ncells, nloc2, nnz):
@@ -67,6 +70,43 @@ def _group(key, nkeys_hint=None):
     ptr = np.zeros(ukey.size + 1, dtype=np.int64)
     np.cumsum(np.bincount(inv, minlength=ukey.size), out=ptr[1:])
     return ukey, ptr, order
+
+
+def block_positions(A, indptr_f, indices_f, d):
+    """Where the ``d x d`` blocks of the scalar pattern ``(indptr_f,
+    indices_f)`` sit in the values of the CSR matrix ``A`` (interleaved dofs,
+    sorted indices): ``pos[i * d + j, k]`` = position of entry ``(d r_k + i,
+    d c_k + j)``."""
+    A = sp.csr_matrix(A)
+    if not A.has_sorted_indices:
+        raise ValueError("block_positions: the operator's indices must be "
+                         "sorted")
+    n = A.shape[1]
+    rows_a = np.repeat(np.arange(A.shape[0], dtype=np.int64),
+                       np.diff(A.indptr))
+    keys = rows_a * n + A.indices
+    rows = np.repeat(np.arange(indptr_f.size - 1, dtype=np.int64),
+                     np.diff(indptr_f))
+    cols = np.asarray(indices_f, dtype=np.int64)
+    pos = np.empty((d * d, cols.size), dtype=np.int64)
+    for i in range(d):
+        for j in range(d):
+            key = (d * rows + i) * n + d * cols + j
+            p = np.searchsorted(keys, key)
+            if p.max(initial=0) >= keys.size or np.any(keys[p] != key):
+                raise ValueError("block_positions: the operator lacks entries "
+                                 "of the coupled pattern")
+            pos[i * d + j] = p
+    return pos
+
+
+def coupled_pattern(indptr_f, indices_f, n, d):
+    """CSR pattern ``(pattern of F) x ones(d, d)`` (values 1)."""
+    ones = sp.csr_matrix((np.ones(len(indices_f)), indices_f, indptr_f),
+                         shape=(n, n))
+    K = sp.kron(ones, np.ones((d, d)), format="csr")
+    K.sort_indices()
+    return K
 
 
 #: refuse Galerkin plans beyond this many (entry, weight) pairs: the lists are
@@ -118,9 +158,7 @@ class DeviceProducer(object):
 
     def __init__(self, problem, ksp):
         pb, V = problem, problem.space
-        if pb.nls != "picard":
-            raise ValueError("device producer: Picard linearisation only "
-                             "(the Newton block is not F x I)")
+        self.newton = pb.nls == "newton"
         self.pb, self.V, self.ksp = pb, V, ksp
         self.eng = eng = ksp.engine
         if not eng.L.hip:
@@ -175,15 +213,24 @@ class DeviceProducer(object):
                 self._set_level_galerkin(l, chain[lh + 1])
             else:
                 self._set_level(l, pl, injection_map(chain[lh + 1], d))
+        if self.newton:
+            self._set_newton(ksp0)
         self._bind_system()
         self._bind_kp(ksp1)
         a, b, cc, dd = ksp0.pc.mg_esteig
         eng.fe_bind_mg(c.KSP_A00, b, dd, 12)
         # the coarsest level's dense inverse: on the device as well, unless
         # asked otherwise (host LAPACK; kept as a cross-check)
+        n0 = self._pat[0][2] * (V.dim if self.newton else 1)
         self.device_inverse = os.environ.get("PCD_FE_HOST_INVERSE") != "1" \
-            and self._pat[0][2] <= 8192
-        if self.device_inverse:
+            and n0 <= 8192
+        if self.newton and not self.device_inverse:
+            raise ValueError("device producer: with the Newton linearisation "
+                             "the coarsest level (%d rows) is inverted on the "
+                             "device, limit 8192 rows" % n0)
+        if self.newton:
+            eng.fe_bind_coarse_inverse(self._K0.indptr, self._K0.indices)
+        elif self.device_inverse:
             eng.fe_bind_coarse_inverse(self._pat[0][0], self._pat[0][1])
         # the residual and the Picard loop on the device as well - unless a
         # host-side coarse inverse needs the iterate on the host every
@@ -253,7 +300,7 @@ class DeviceProducer(object):
         # host's Galerkin pattern depends on the values it was built from;
         # the device product needs the structural pattern: re-create the
         # engine's level with it (values arrive with the first update)
-        if 0 < l < self.nlev - 1:
+        if 0 < l < self.nlev - 1 and not self.newton:
             ones = sp.csr_matrix((np.ones(indices_c.size), indices_c,
                                   indptr_c), shape=(Ps.shape[1],) * 2)
             K = sp.kron(ones, sp.identity(d), format="csr")
@@ -264,17 +311,46 @@ class DeviceProducer(object):
         self.eng.fe_set_level_galerkin(l, *plan[:6])
         self._pat[l] = (indptr_c, indices_c, Ps.shape[1])
 
+    def _set_newton(self, ksp0):
+        """Positions of the ``d x d`` blocks in every level's operator.  The
+        engine's intermediate levels are re-created on the structural pattern
+        ``(pattern of F_l) x ones(d, d)`` (host products drop entries that are
+        numerically zero at the first iterate); level 0 is the CSR the device
+        inverts; the finest level is the engine's A00."""
+        d, eng, mg = self.V.dim, self.eng, ksp0.pc.mg_data
+        top = self.nlev - 1
+        for l in range(self.nlev):
+            indptr, indices, n = self._pat[l]
+            if l == top:
+                patA = self.V._patterns(True)["A00"]
+                K = patA.matrix(np.ones(patA.nnz))
+            else:
+                K = coupled_pattern(indptr, indices, n, d)
+                if l > 0:
+                    eng.mg_set_level(c.KSP_A00, l, K, mg["chain"][l],
+                                     *mg["bounds"][l])
+            if l == 0:
+                self._K0 = K     # (a one-level hierarchy: the same pattern)
+            eng.fe_set_newton(l, block_positions(K, indptr, indices, d))
+
     def _bind_system(self):
         V, d = self.V, self.V.dim
         patS = V._patterns(False)["SS"]
-        patA = V._patterns(False)["A00"]
+        patA = V._patterns(self.newton)["A00"]
         lin_nnz = (patA.nnz, V._patterns(False)["A01"].nnz,
                    V._patterns(False)["A10"].nnz)
         mono = getattr(V, "_mono_%d_%d_%d" % lin_nnz)
         rows, cols = patS.rows.astype(np.int64), patS.indices.astype(np.int64)
-        pos = np.empty((d, patS.nnz), dtype=np.int64)
-        for k in range(d):
-            pos[k] = mono.inv[patA.locate(d * rows + k, d * cols + k)]
+        if self.newton:
+            pos = np.empty((d * d, patS.nnz), dtype=np.int64)
+            for i in range(d):
+                for j in range(d):
+                    pos[i * d + j] = mono.inv[patA.locate(d * rows + i,
+                                                          d * cols + j)]
+        else:
+            pos = np.empty((d, patS.nnz), dtype=np.int64)
+            for k in range(d):
+                pos[k] = mono.inv[patA.locate(d * rows + k, d * cols + k)]
         self.eng.fe_bind_system(pos)
 
     def _bind_kp(self, ksp1):
@@ -339,6 +415,7 @@ class DeviceProducer(object):
         if not self.device_inverse:
             self._refresh_coarsest()
         t3 = time.perf_counter()
+        # (Newton: ru already carries - N_unc d, see pcd_fe_update)
         Fu = ru + pb._A01_raw @ xp
         if pb.idt:
             Fu -= pb.idt * (pb._Mmass @ pb.u0)
@@ -367,10 +444,21 @@ class DeviceProducer(object):
 
     def level_matrix(self, l):
         """Velocity operator of FE level ``l`` as assembled on the device
-        (scipy CSR, F x I_d) - for tests and diagnostics."""
+        (scipy CSR, F x I_d [+ N]) - for tests and diagnostics."""
         d = self.V.dim
         F = self._scalar(l)
         K = sp.kron(F, sp.identity(d), format="csr")
+        if self.newton:
+            indptr, indices, n = self._pat[l]
+            Nv = self.eng.fe_newton_values(l, indices.size, d)
+            for i in range(d):
+                for j in range(d):
+                    E = np.zeros((d, d))
+                    E[i, j] = 1.0
+                    Nij = sp.csr_matrix((Nv[i * d + j], indices, indptr),
+                                        shape=(n, n))
+                    K = K + sp.kron(Nij, E, format="csr")
+            K = sp.csr_matrix(K)
         K.sort_indices()
         return K
 
@@ -380,7 +468,8 @@ class DeviceProducer(object):
 
 
 class DevicePicardSolver(object):
-    """Picard iteration with the device producer.  The first nonlinear step of
+    """Picard (or, with ``problem.nls == "newton"``, Newton) iteration with
+    the device producer.  The first nonlinear step of
     the first solve runs through the reference-shaped stack
     (``PCDNewtonSolver`` -> ``init_pcd`` -> host producer) and sets everything
     up; from then on operators never leave HBM.  Stopping rules, relaxation and
@@ -476,6 +565,10 @@ class DevicePicardSolver(object):
             converged = (r < prm["absolute_tolerance"]
                          or r / r0 < prm["relative_tolerance"])
         return it, converged
+
+
+#: the loop is the same for both linearisations
+DeviceNonlinearSolver = DevicePicardSolver
 
 
 def solve_steady_device(problem, **kw):

@@ -338,8 +338,21 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f,
 int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
                     const double* phi_mid, int nq_s, const double* qw_s,
                     const double* phi_s, const double* dphi_s);
+/* Newton linearisation (`--nls newton`: demo_navier-stokes-pcd.py:42,113-116,
+ * J = derivative(F, w)): the velocity block becomes F x I_d + N(w) with
+ * N_ij = (phi_b d_j w_i, phi_a), d*d scalar matrices on the pattern of F; the
+ * block lives on (pattern of F) x ones(d, d).  Call once per level after
+ * pcd_fe_set_level[_galerkin] and before pcd_fe_bind_system /
+ * pcd_fe_bind_coarse_inverse.  pos[(i*d+j)*nnz_f + k] = where block (i, j) of
+ * scalar entry k sits in the values of that level's operator: the multigrid
+ * level's CSR (0 < level < finest), PCD_MAT_A00 (finest), the CSR handed to
+ * pcd_fe_bind_coarse_inverse (level 0: then of d*n0 rows, inverted whole).
+ * The residual of pcd_fe_residual / pcd_fe_picard_solve stays that of the
+ * nonlinear problem; only the Jacobian changes (nonlinear_solvers.py:85-112). */
+int pcd_fe_set_newton(pcd_handle h, int level, const int32_t* pos);
 /* sys_pos[c*nnz_f + k] = position, in the value array given to
- * pcd_set_system, of entry k of the finest F for velocity component c        */
+ * pcd_set_system, of entry k of the finest F for velocity component c; after
+ * pcd_fe_set_newton: sys_pos[(i*d+j)*nnz_f + k] for every block (i, j)       */
 int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos);
 /* Kp = scale * (w . grad p, q) + kp_const on the pattern of PCD_MAT_KP
  * (same plan layout with nv x nv element matrices; kp_const may be NULL)     */
@@ -411,6 +424,8 @@ int pcd_fe_picard_solve(pcd_handle h, double* x, int mem, double r0,
                         int lin_max_it, int* n_it, int* lin_its,
                         double* res_hist, int* converged);
 int pcd_fe_get_level_values(pcd_handle h, int level, double* out);
+/* Newton term of one level as last assembled: d*d*nnz_f values [(i*d+j)][k]  */
+int pcd_fe_get_newton_values(pcd_handle h, int level, double* out);
 int pcd_fe_get_kp_values(pcd_handle h, double* out);
 int pcd_fe_get_bounds(pcd_handle h, int level, double* emin, double* emax);
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""End-to-end steady Picard solve: host producer vs device producer
-(time per nonlinear step, GMRES counts)."""
+"""End-to-end steady nonlinear solve: host producer vs device producer
+(time per nonlinear step, GMRES counts).
+usage: device_producer_timing.py [cavity|cube] [level] [newton_rtol]
+                                 [galerkin|rediscretised] [picard|newton]"""
 import json
 import os
 import sys
@@ -16,11 +18,12 @@ geometry = sys.argv[1] if len(sys.argv) > 1 else "cavity"
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 newton_rtol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-8
 galerkin = (sys.argv[4] if len(sys.argv) > 4 else "galerkin") == "galerkin"
+nls = sys.argv[5] if len(sys.argv) > 5 else "picard"
 
 
 def problem():
-    return Cavity(level, nu=0.01) if geometry == "cavity" \
-        else Cavity3D(level, nu=0.01, n0=4)
+    return Cavity(level, nu=0.01, nls=nls) if geometry == "cavity" \
+        else Cavity3D(level, nu=0.01, n0=4, nls=nls)
 
 
 res = {}
@@ -31,7 +34,7 @@ for name, fn in (("host", solve_steady), ("device", solve_steady_device)):
     t0 = time.time()
     out = fn(pb, max_newton=25, newton_rtol=newton_rtol)
     res[name] = {
-        "ndof": pb.space.ndof, "coarse_operators":
+        "ndof": pb.space.ndof, "nls": nls, "coarse_operators":
         "galerkin" if galerkin else "rediscretised",
         "newton_its": out["newton_its"],
         "converged": bool(out["converged"]),
