@@ -505,6 +505,7 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if world > 1:
+        eng.destroy()          # the engine's RCCL communicator, before torch's
         dist.destroy_process_group()
 
 

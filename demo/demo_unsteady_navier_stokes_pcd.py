@@ -42,6 +42,26 @@ p.add_argument("--dt", type=float, default=0.2)
 p.add_argument("--t_end", type=float, default=5.0)
 args = p.parse_args()
 
+# several GPUs: start it as the reference is started under `mpirun -np N`
+# (test/regression/test.py:186-195), here one process per GPU:
+#   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+#       --master-addr 127.0.0.1 demo/demo_unsteady_navier_stokes_pcd.py ...
+# torch.distributed only carries the RCCL unique id (fenapack_amd/parallel.py)
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+local = int(os.environ.get("LOCAL_RANK", "0"))
+solver_kw = {}
+if world > 1:
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from fenapack_amd.parallel import Comm
+    solver_kw = {"comm": Comm.world(), "device": local}
+    if rank:
+        sys.stdout = open(os.devnull, "w")      # rank 0 reports
+
 if args.mg_coarse is None:
     args.mg_coarse = "galerkin"
 pb = BackwardStep(args.level, nu=args.viscosity, variant=args.pcd_variant,
@@ -62,7 +82,7 @@ if args.producer == "device":
     from fenapack_amd.device_producer import solve_unsteady_device
     solve_unsteady = solve_unsteady_device
 out = solve_unsteady(pb, dt=args.dt, t_end=args.t_end, newton_rtol=1e-5,
-                     gmres_rtol=1e-6)
+                     gmres_rtol=1e-6, **solver_kw)
 tab = "{:^15} | {:^15} | {:^15} | {:^19} | {:^15}\n".format(
     "No. of DOF", "Steps", "Krylov its", "Krylov its (p.t.s.)", "Time (s)")
 tab += "{:>9}       | {:^15} | {:^15} | {:^19.1f} | {:^15.2f}\n".format(
@@ -74,3 +94,5 @@ print("Krylov iterations per time step:", out["krylov_per_step"])
 for k, (its, res) in enumerate(zip(out["krylov_per_newton"], out["residuals"])):
     print("step %2d  GMRES its per Picard iteration %s  |F| %s"
           % (k + 1, its, ["%.2e" % r for r in res]))
+if world > 1:
+    dist.destroy_process_group()

@@ -21,7 +21,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
     INFO_NUM_PCD_APPLY, INFO_NUM_FS_APPLY, INFO_GMRES_ITS, \
     INFO_GMRES_RNORM, INFO_N_U_LOCAL, INFO_N_P_LOCAL, INFO_A00_COMPONENTS, \
-    INFO_A00_ROWS_PER_WG = range(14)
+    INFO_A00_ROWS_PER_WG, INFO_RANKS = range(15)
 INFO_NNZ_BASE = 16
 
 KSP_TYPES = {"preonly": PREONLY, "richardson": RICHARDSON,
@@ -88,6 +88,7 @@ _HIP_ONLY = {
                               C.c_void_p],
     "fe_set_supg": [C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                     C.c_void_p, C.c_void_p, C.c_void_p],
+    "fe_bind_pattern": [C.c_int, C.c_int64, C.c_void_p, C.c_void_p],
     "fe_set_newton": [C.c_int, C.c_void_p],
     "fe_bind_system": [C.c_void_p],
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
@@ -463,6 +464,11 @@ class Engine(object):
                    _ptr(phi_mid), int(qw_s.size), _ptr(qw_s), _ptr(phi_s),
                    _ptr(dphi_s))
 
+    def fe_bind_pattern(self, level, indptr, indices):
+        ip, ix = _i32(indptr), _i32(indices)
+        self._call("fe_bind_pattern", int(level), int(ip.size - 1), _ptr(ip),
+                   _ptr(ix))
+
     def fe_set_newton(self, level, pos):
         pos = _i32(np.asarray(pos).ravel())
         self._call("fe_set_newton", int(level), _ptr(pos))
@@ -565,6 +571,7 @@ class Engine(object):
         return a.value, b.value
 
     def comm_init(self, rank, nranks, unique_id_bytes):
+        _map_torch_rccl()
         buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
         self._call("comm_init", int(rank), int(nranks), buf)
 
@@ -642,8 +649,23 @@ def dist_probe(A, rank, nranks, even_rows=False, even_cols=False):
                      for i in range(nrv)}}
 
 
+def _map_torch_rccl():
+    """PyTorch ships its own ``librccl.so`` (SONAME ``librccl.so.1``).  The
+    engine binds RCCL at run time and takes the copy that is already mapped;
+    if it loads ROCm's copy FIRST and torch is imported later, the loader does
+    not recognise the two as the same library, both end up in the process and
+    their static state is torn down twice at exit (``double free or
+    corruption``).  Importing torch before the first RCCL call keeps it at one
+    copy whenever torch is installed."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:                   # a host without torch: ROCm's copy
+        pass
+
+
 def comm_unique_id():
     """128-byte ncclUniqueId (rank 0 creates it, the host broadcasts it)."""
+    _map_torch_rccl()
     buf = C.create_string_buffer(128)
     lib = hip_library()
     rc = lib.comm_unique_id(buf)

@@ -217,12 +217,19 @@ struct RcclApi {
 
   bool load(std::string& err) {
     if (lib) return true;
-    // the copy torch already mapped wins (same SONAME), else the ROCm one
-    for (const char* name : {"librccl.so.1", "librccl.so",
-                             "/opt/rocm/lib/librccl.so.1"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // a copy that is already mapped wins (PyTorch ships its own librccl.so
+    // with the SONAME librccl.so.1: two copies in one process tear their
+    // static state down twice at exit), else the ROCm one
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
       if (lib) break;
     }
+    if (!lib)
+      for (const char* name : {"librccl.so.1", "librccl.so",
+                               "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+      }
     if (!lib) { err = std::string("dlopen librccl: ") + dlerror(); return false; }
 #define PCD_SYM(field, name)                                            \
     field = reinterpret_cast<decltype(field)>(dlsym(lib, name));        \

@@ -191,6 +191,8 @@ struct pcd_engine_s {
   std::vector<double> bc_val_host;
   DBuf<int> perm;                     // LOCAL split position -> caller's index
   DBuf<double> sysvals, psysvals;     // staging of the caller's value arrays
+  DBuf<double> valstage;              // staging of one operator's global values (several ranks)
+  std::vector<int32_t> perm_glob;     // split position -> caller's index, all rows
   // (1,0) and (1,1) blocks of the system (one GPU): w = A z is then applied
   // block-wise, so the velocity block goes through its F x I fast path
   DCsr a10, a11;
@@ -1413,9 +1415,11 @@ static int refresh_values(Engine* h, DCsr& A, const double* vals, int mem) {
   }
   const double* dv = vals;
   if (mem == PCD_MEM_HOST) {
-    CHK(h->sysvals.ensure(A.gnnz));
-    HIPCHK(hipMemcpyAsync(h->sysvals.p, vals, A.gnnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    dv = h->sysvals.p;
+    // (its own buffer: `sysvals` keeps the staged system values, which the
+    // device producer refreshes in place)
+    CHK(h->valstage.ensure(A.gnnz));
+    HIPCHK(hipMemcpyAsync(h->valstage.p, vals, A.gnnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    dv = h->valstage.p;
   }
   if (A.nnz)
     hipLaunchKernelGGL(k_gather_vals, dim3(grid1d(A.nnz, 4)), dim3(kBlock), 0,
@@ -1509,7 +1513,7 @@ int pcd_destroy(pcd_handle h) {
   for (auto& m : h->mat) m.release();
   for (auto& s : h->inner) s.release();
   h->bc_idx.release(); h->bc_val.release(); h->bc_slot.release(); h->perm.release();
-  h->sysvals.release(); h->psysvals.release();
+  h->sysvals.release(); h->psysvals.release(); h->valstage.release();
   h->w[0].release(); h->w[1].release(); h->wu.release();
   h->xs.release(); h->ys.release(); h->io_x.release(); h->io_y.release();
   h->V.release(); h->gz.release(); h->gw.release(); h->gparts.release();
@@ -1673,6 +1677,7 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   for (int64_t i = 0; i < n_u; ++i) mu[is_u[i]] = (int32_t)i;
   for (int64_t i = 0; i < n_p; ++i) mp[is_p[i]] = (int32_t)i;
   h->n_u = n_u; h->n_p = n_p; h->sys_nnz = rowptr[n];
+  h->perm_glob = perm;
   CHK(ensure_space(h, h->sp_u, n_u, true, "set_system"));
   CHK(ensure_space(h, h->sp_p, n_p, false, "set_system"));
   if (h->comm) h->sp_sys = Space::system(h->sp_u, h->sp_p);
@@ -2304,6 +2309,7 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_N_U_LOCAL: *out = (double)h->nu_loc; return 0;
     case PCD_INFO_N_P_LOCAL: *out = (double)h->np_loc; return 0;
     case PCD_INFO_A00_COMPONENTS: *out = (double)h->mat[PCD_MAT_A00].kron; return 0;
+    case PCD_INFO_RANKS: *out = h->comm ? (double)h->nranks : 0.0; return 0;
     case PCD_INFO_A00_ROWS_PER_WG:
       *out = (double)(h->mat[PCD_MAT_A00].kron ? h->mat[PCD_MAT_A00].rb2 : h->mat[PCD_MAT_A00].rb);
       return 0;
@@ -2413,7 +2419,11 @@ int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) {
 int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group) {
   if (!h || !group) return fail(PCD_ERR_ARG, "comm_init_threads: null argument");
   if (nranks < 2 || rank < 0 || rank >= nranks) return fail(PCD_ERR_ARG, "comm_init_threads: bad rank/size");
-  if (!*group) *group = new ThreadGroup(nranks);
+  {
+    static std::mutex mu;                 // the ranks may arrive concurrently
+    std::lock_guard<std::mutex> lk(mu);
+    if (!*group) *group = new ThreadGroup(nranks);
+  }
   ThreadBackend* b = new ThreadBackend();
   b->g = static_cast<ThreadGroup*>(*group);
   return comm_attach(h, b, rank, nranks);

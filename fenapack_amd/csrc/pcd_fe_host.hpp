@@ -26,10 +26,15 @@ struct FeLevel {
   // the values of this level's operator
   DBuf<double> N, cellsN, BN;
   DBuf<int> npos;
+  // several ranks: where entry (k, c) of F x I_d sits in the GLOBAL sorted CSR
+  // of the level (pcd_fe_bind_pattern), and the values expanded that way
+  DBuf<int> kpos;
+  DBuf<double> gvals;
   void release() {
     b_ptr.release(); c_ptr.release(); b_src.release(); c_src.release();
     b_w.release(); c_w.release(); B.release();
     N.release(); cellsN.release(); BN.release(); npos.release();
+    kpos.release(); gvals.release();
     cell_h.release(); cells_s.release(); Fa.release();
     dofs2.release(); f_ptr.release(); f_src.release(); diag_pos.release();
     inject.release(); gradlam.release(); measure.release(); f_const.release();
@@ -47,6 +52,11 @@ struct FeState {
   DBuf<double> Func;                 // unconstrained finest values (residual)
   bool newton = false;               // coupled block F x I + N (pcd_fe_set_newton)
   DBuf<double> Nunc, Jv, inv_vals, dvec, y2;
+  // several ranks: the nonlinear side is replicated (global vectors and
+  // operators on every rank), the linear solve is partitioned
+  DCsr Ku;                           // global F x I_d of the finest level
+  DBuf<int> gperm;                   // split position -> caller's index, all rows
+  DBuf<double> bloc, dxloc;          // this rank's slices for GMRES
   DBuf<int64_t> sys_pos; bool sys_bound = false; int sys_blocks = 0;
   int64_t nnz_kp = 0; double kp_scale = 1.0; bool kp_bound = false;
   DBuf<int> kp_ptr, kp_src;
@@ -75,6 +85,7 @@ struct FeState {
     lev.clear();
     qw.release(); phi.release(); dphi.release(); psi.release(); Func.release();
     Nunc.release(); Jv.release(); inv_vals.release(); dvec.release(); y2.release();
+    Ku.release(); gperm.release(); bloc.release(); dxloc.release();
     phic.release(); qw_s.release(); phi_s.release(); dphi_s.release();
     sys_pos.release(); kp_ptr.release(); kp_src.release(); kp_const.release();
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
@@ -186,6 +197,8 @@ static int fe_estimate_emax(Engine* h, FeState& fe, FeLevel& L, const DCsr& A,
   auto sqnorm_of_y = [&](const double* dinv, double* out) -> int {
     hipLaunchKernelGGL(k_fe_scale_sqnorm, dim3(g), dim3(kBlock), 0, h->stream, n, dinv, fe.y.p, fe.parts.p);
     hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, h->stream, fe.parts.p, g, 0, fe.slot.p);
+    if (h->comm && !A.replicated && h->comm->allreduce(fe.slot.p, 1, h->stream))
+      return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
     double s = 0.0;
     HIPCHK(hipMemcpyAsync(&s, fe.slot.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -289,7 +302,6 @@ int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
   if (dim != 2 && dim != 3) return fail(PCD_ERR_ARG, "fe_begin: dim must be 2 or 3");
   if (nlevels < 1 || nlevels > 32 || nq < 1 || !qw || !phi || !dphi || !psi)
     return fail(PCD_ERR_ARG, "fe_begin: bad arguments");
-  if (h->comm) return fail(PCD_ERR_STATE, "fe_begin: the device producer runs on one GPU");
   HIPCHK(hipSetDevice(h->device));
   fe_release(h);
   h->fe = new FeState();
@@ -400,6 +412,52 @@ int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
   CHK(fe_upload(fe.dphi_s, dphi_s, (size_t)nq_s * na * (fe.dim + 1)));
   fe.nq_s = nq_s;
   fe.nu = nu; fe.supg = true;
+  return 0;
+}
+
+// Several ranks (pcd_comm_init before pcd_fe_begin): the scalar CSR pattern of
+// a level (nn2 + 1 row pointers, nnz_f sorted column indices - the order of
+// pcd_fe_get_level_values).  The producer itself is REPLICATED - every rank
+// assembles every level from the replicated iterate, a few ms per nonlinear
+// step - and the engine cuts its rows out of the expanded values; this call
+// gives it the layout of the global F x I_d (sorted CSR, interleaved dofs).  On
+// the finest level it also creates the replicated operator the residual
+// applies.  Not needed on one GPU.
+int pcd_fe_bind_pattern(pcd_handle h, int level, int64_t nn2, const int32_t* rowptr,
+                        const int32_t* colidx) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_pattern: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev || !fe.lev[level].set || !rowptr || !colidx || nn2 < 1)
+    return fail(PCD_ERR_ARG, "fe_bind_pattern: level %d is not set / bad arguments", level);
+  FeLevel& L = fe.lev[level];
+  if (rowptr[nn2] != L.nnzf) return fail(PCD_ERR_ARG, "fe_bind_pattern: %lld entries, the level has %lld",
+                                        (long long)rowptr[nn2], (long long)L.nnzf);
+  const int d = fe.dim;
+  if ((int64_t)d * L.nnzf >= INT32_MAX) return fail(PCD_ERR_ARG, "fe_bind_pattern: values exceed int32 indexing");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<int32_t> kpos((size_t)d * L.nnzf);
+  for (int64_t a = 0; a < nn2; ++a) {
+    const int32_t b0 = rowptr[a], len = rowptr[a + 1] - b0;
+    for (int32_t k = b0; k < b0 + len; ++k)
+      for (int c = 0; c < d; ++c)
+        kpos[(size_t)c * L.nnzf + k] = d * b0 + c * len + (k - b0);
+  }
+  CHK(fe_upload(L.kpos, kpos.data(), kpos.size()));
+  CHK(L.gvals.ensure((size_t)d * L.nnzf));
+  if (level == fe.nlev - 1) {
+    std::vector<int32_t> rp((size_t)d * nn2 + 1), cc((size_t)d * L.nnzf);
+    rp[0] = 0;
+    for (int64_t a = 0; a < nn2; ++a) {
+      const int32_t b0 = rowptr[a], len = rowptr[a + 1] - b0;
+      for (int c = 0; c < d; ++c) {
+        rp[d * a + c + 1] = rp[d * a + c] + len;
+        for (int32_t k = 0; k < len; ++k) cc[(size_t)d * b0 + c * len + k] = d * colidx[b0 + k] + c;
+      }
+    }
+    CHK(upload_csr(h, fe.Ku, d * nn2, d * nn2, rp.data(), cc.data(), nullptr, nullptr));
+    fe.Ku.replicated = true;
+    HIPCHK(hipMemsetAsync(fe.Ku.val.p, 0, (size_t)fe.Ku.nnz * sizeof(double), h->stream));
+  }
   return 0;
 }
 
@@ -614,7 +672,18 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
       M.fused = false;                   // composed from the previous iterate
       const DCsr* A = &h->mat[kSlotMat[fe.mg_slot]];
       if (l < top) {
-        if (fe.newton) {
+        if (h->comm) {
+          // the level's operator is this rank's slice (or a replica) of the
+          // global F x I_d: expand the replicated scalar values into the
+          // global CSR order and let the ordinary value refresh cut it
+          if (fe.newton) return fail(PCD_ERR_STATE, "fe_update: the Newton block is assembled on one GPU");
+          if (!L.kpos.p) return fail(PCD_ERR_STATE, "fe_update: several ranks need pcd_fe_bind_pattern on every level");
+          if (!M.A.set || M.A.gnnz != (int64_t)fe.dim * L.nnzf)
+            return fail(PCD_ERR_STATE, "fe_update: multigrid level %d is not F x I_%d on the FE pattern", l, fe.dim);
+          hipLaunchKernelGGL(k_fe_scatter<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                             h->stream, L.nnzf, fe.dim, L.kpos.p, L.F.p, L.gvals.p);
+          CHK(refresh_values(h, M.A, L.gvals.p, PCD_MEM_DEVICE));
+        } else if (fe.newton) {
           if (!M.A.set || M.A.nnz != (int64_t)d2 * L.nnzf)
             return fail(PCD_ERR_STATE, "fe_update: multigrid level %d is not the coupled block on the FE pattern", l);
           hipLaunchKernelGGL(k_fe_scatter_blocks<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
@@ -658,7 +727,7 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
     }
     HIPCHK(hipGetLastError());
     if (h->mat[PCD_MAT_KP].set) {
-      if (h->mat[PCD_MAT_KP].nnz != fe.nnz_kp)
+      if ((h->comm ? h->mat[PCD_MAT_KP].gnnz : h->mat[PCD_MAT_KP].nnz) != fe.nnz_kp)
         return fail(PCD_ERR_STATE, "fe_update: Kp pattern differs from the FE pattern");
       CHK(pcd_update_values(h, PCD_MAT_KP, fe.kp_vals.p, PCD_MEM_DEVICE));
     }
@@ -698,9 +767,21 @@ static int fe_subtract_newton_defect(Engine* h, FeState& fe, const double* dxu, 
   return 0;
 }
 
+// several ranks: y = (S x I_d) v with the replicated global operator Ku
+static int fe_apply_global(Engine* h, FeState& fe, const double* S, const double* dv, double* dy) {
+  FeLevel& Lt = fe.lev[fe.nlev - 1];
+  if (!fe.Ku.set || !Lt.kpos.p)
+    return fail(PCD_ERR_STATE, "fe: several ranks need pcd_fe_bind_pattern on the finest level");
+  hipLaunchKernelGGL(k_fe_scatter<int>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                     h->stream, Lt.nnzf, fe.dim, Lt.kpos.p, S, fe.Ku.val.p);
+  CHK(refresh_kron(h, fe.Ku));
+  return spmv(h, fe.Ku, dv, dy);
+}
+
 static int fe_apply_unconstrained(Engine* h, FeState& fe, const double* dv, double* dy) {
   DCsr& A = h->mat[PCD_MAT_A00];
   FeLevel& Lt = fe.lev[fe.nlev - 1];
+  if (h->comm) return fe_apply_global(h, fe, fe.Func.p, dv, dy);
   if (fe.newton) return fe_apply_blocks(h, fe, fe.Func.p, nullptr, dv, dy);
   if (!A.set || A.kron != fe.dim || A.nnz2 != Lt.nnzf)
     return fail(PCD_ERR_STATE, "fe_update: A00 is not F x I_%d on the FE pattern", fe.dim);
@@ -757,7 +838,12 @@ static int fe_residual_dev(Engine* h, FeState& fe, const double* xd, double* bd,
   CHK(fe.xs.ensure(n)); CHK(fe.bs.ensure(n)); CHK(fe.vv.ensure(nu));
   CHK(h->gparts.ensure(2 * 512)); CHK(h->gh.ensure(4)); CHK(ensure_pinned(h, 8));
   const int g1 = grid1d(n, 1);
-  hipLaunchKernelGGL(k_gather, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, xd, fe.xs.p);
+  // several ranks: every rank evaluates the whole residual from the replicated
+  // iterate (one pass over the unconstrained operators: a fraction of a
+  // GMRES iteration), so perm is the global one and the norm needs no reduction
+  const int* perm = h->comm ? fe.gperm.p : h->perm.p;
+  if (h->comm && !perm) return fail(PCD_ERR_STATE, "fe_residual: bind the residual after pcd_comm_init");
+  hipLaunchKernelGGL(k_gather, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, perm, xd, fe.xs.p);
   const double *xu = fe.xs.p, *xp = fe.xs.p + nu;
   double *Fu = fe.bs.p, *Fp = fe.bs.p + nu;
   CHK(fe_refresh(h, fe, xu, true));
@@ -774,9 +860,16 @@ static int fe_residual_dev(Engine* h, FeState& fe, const double* xd, double* bd,
   if (fe.n_bc)
     hipLaunchKernelGGL(k_fe_bc_rows, dim3(grid1d(fe.n_bc)), dim3(kBlock), 0, h->stream,
                        (int)fe.n_bc, fe.bc_idx.p, fe.bc_g.p, fe.bc_mult.p, xu, Fu);
-  hipLaunchKernelGGL(k_scatter, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, h->perm.p, fe.bs.p, bd);
+  hipLaunchKernelGGL(k_scatter, dim3(g1), dim3(kBlock), 0, h->stream, (int)n, perm, fe.bs.p, bd);
   HIPCHK(hipGetLastError());
-  return dev_norm(h, n, fe.bs.p, norm);
+  if (!h->comm) return dev_norm(h, n, fe.bs.p, norm);
+  const int G = grid1d(n, 4, 512);
+  hipLaunchKernelGGL(k_mdot, dim3(G, 1), dim3(kBlock), 0, h->stream, n, fe.bs.p, (int64_t)0, 1, fe.bs.p, h->gparts.p, G);
+  hipLaunchKernelGGL(k_mdot_reduce, dim3(1), dim3(kBlock), 0, h->stream, h->gparts.p, G, h->gh.p);
+  HIPCHK(hipMemcpyAsync(h->pinned, h->gh.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *norm = std::sqrt(h->pinned[0]);
+  return 0;
 }
 
 extern "C" {
@@ -802,6 +895,11 @@ int pcd_fe_bind_residual(pcd_handle h, const int32_t* bt_rowptr, const int32_t* 
     if (bc_idx[i] < 0 || bc_idx[i] >= nu) return fail(PCD_ERR_ARG, "fe_bind_residual: bc index out of range");
   CHK(upload_csr(h, fe.A01raw, nu, np, bt_rowptr, bt_col, bt_val, nullptr));
   CHK(upload_csr(h, fe.A10raw, np, nu, b_rowptr, b_col, b_val, nullptr));
+  if (h->comm) {
+    fe.A01raw.replicated = fe.A10raw.replicated = true;
+    if ((int64_t)h->perm_glob.size() != nu + np) return fail(PCD_ERR_STATE, "fe_bind_residual: no system set");
+    CHK(fe_upload(fe.gperm, h->perm_glob.data(), h->perm_glob.size()));
+  }
   fe.n_bc = n_bc; fe.idt = idt;
   CHK(fe_upload(fe.bc_idx, bc_idx, (size_t)n_bc));
   CHK(fe_upload(fe.bc_mult, bc_mult, (size_t)n_bc));
@@ -837,7 +935,9 @@ int pcd_fe_set_previous(pcd_handle h, const double* u0, int mem) {
   HIPCHK(hipMemcpyAsync(fe.u0.p, u0, nu * sizeof(double),
                         mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
   DCsr& A = h->mat[PCD_MAT_A00];
-  if (fe.newton) {
+  if (h->comm) {
+    CHK(fe_apply_global(h, fe, fe.mass.p, fe.u0.p, fe.mu0.p));
+  } else if (fe.newton) {
     CHK(fe_apply_blocks(h, fe, fe.mass.p, nullptr, fe.u0.p, fe.mu0.p));
   } else {
     if (!A.set || A.kron != fe.dim || A.nnz2 != fe.lev[fe.nlev - 1].nnzf || !kron_ok(A, fe.u0.p, fe.mu0.p))
@@ -909,7 +1009,19 @@ int pcd_fe_picard_solve(pcd_handle h, double* x, int mem, double r0, double rtol
   while (!conv && it < max_it) {
     HIPCHK(hipMemsetAsync(fe.dxd.p, 0, n * sizeof(double), h->stream));
     int its = 0; double rn = 0.0;
-    CHK(pcd_gmres_solve(h, fe.bd.p, fe.dxd.p, PCD_MEM_DEVICE, lin_rtol, lin_atol, restart, lin_max_it, &its, &rn));
+    if (h->comm) {
+      // the linear solve is partitioned: hand GMRES this rank's rows of the
+      // replicated right-hand side, sum the slices of dx back into a replica
+      const int64_t nl = h->nu_loc + h->np_loc;
+      CHK(fe.bloc.ensure(nl)); CHK(fe.dxloc.ensure(nl));
+      hipLaunchKernelGGL(k_gather, dim3(grid1d(nl, 1)), dim3(kBlock), 0, h->stream, (int)nl, h->perm.p, fe.bd.p, fe.bloc.p);
+      CHK(pcd_gmres_solve(h, fe.bloc.p, fe.dxloc.p, PCD_MEM_DEVICE, lin_rtol, lin_atol, restart, lin_max_it, &its, &rn));
+      hipLaunchKernelGGL(k_scatter, dim3(grid1d(nl, 1)), dim3(kBlock), 0, h->stream, (int)nl, h->perm.p, fe.dxloc.p, fe.dxd.p);
+      if (h->comm->allreduce(fe.dxd.p, n, h->stream))
+        return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+    } else {
+      CHK(pcd_gmres_solve(h, fe.bd.p, fe.dxd.p, PCD_MEM_DEVICE, lin_rtol, lin_atol, restart, lin_max_it, &its, &rn));
+    }
     lin_its[it] = its;
     hipLaunchKernelGGL(k_axpby, dim3(grid1d(n, 4)), dim3(kBlock), 0, h->stream, (int)n, -relax, fe.dxd.p, 1.0, xd);
     ++it;

@@ -160,6 +160,12 @@ class DeviceProducer(object):
         pb, V = problem, problem.space
         self.newton = pb.nls == "newton"
         self.pb, self.V, self.ksp = pb, V, ksp
+        # 0: no communicator attached; >= 1: the engine's rows are partitioned
+        # (1 = a one-rank RCCL communicator, PCD_FORCE_COMM=1)
+        self.ranks = int(ksp.engine.info(c.INFO_RANKS))
+        if self.ranks and self.newton:
+            raise ValueError("device producer: the Newton block is assembled "
+                             "on one GPU")
         self.eng = eng = ksp.engine
         if not eng.L.hip:
             raise c.EngineError("device producer needs the HIP engine")
@@ -215,6 +221,11 @@ class DeviceProducer(object):
                 self._set_level(l, pl, injection_map(chain[lh + 1], d))
         if self.newton:
             self._set_newton(ksp0)
+        if self.ranks:
+            # replicated producer, partitioned solve: the engine needs the
+            # layout of every level's global F x I_d (pcd_fe_bind_pattern)
+            for l in range(nlev):
+                eng.fe_bind_pattern(l, self._pat[l][0], self._pat[l][1])
         self._bind_system()
         self._bind_kp(ksp1)
         a, b, cc, dd = ksp0.pc.mg_esteig
@@ -237,6 +248,10 @@ class DeviceProducer(object):
         # iteration
         self.device_loop = self.device_inverse \
             and os.environ.get("PCD_FE_HOST_LOOP") != "1"
+        if self.ranks and not self.device_loop:
+            raise ValueError("device producer: several ranks run the device "
+                             "loop (coarsest level <= 8192 rows, inverted on "
+                             "every rank)")
         if self.device_loop:
             mass = None
             if pb.idt:

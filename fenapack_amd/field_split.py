@@ -87,8 +87,14 @@ class PCDKSP(KSP):
         self.engine.set_velocity_block(getattr(V, "dim", 2))
         import os
         forced = os.environ.get("PCD_FORCE_COMM") == "1"   # 1-rank RCCL test
-        if self.comm is not None and (getattr(self.comm, "size", 1) > 1
-                                      or (forced and self.comm.unique_id())):
+        if self.comm is not None and getattr(self.comm, "thread_group",
+                                             None) is not None:
+            # R ranks as R threads of this process on one GPU (tests: RCCL
+            # refuses two ranks on one device)
+            self.engine.comm_init_threads(self.comm.rank, self.comm.size,
+                                          self.comm.thread_group)
+        elif self.comm is not None and (getattr(self.comm, "size", 1) > 1
+                                        or (forced and self.comm.unique_id())):
             # one process per GPU: rows are partitioned inside the engine,
             # RCCL carries the halos and the dot-product all-reduces
             self.engine.comm_init(self.comm.rank, self.comm.size,

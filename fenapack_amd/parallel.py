@@ -12,8 +12,11 @@ import os
 class Comm(object):
     """Rank/size of this process and the shared RCCL unique id."""
 
-    def __init__(self, rank=0, size=1, unique_id=None):
+    def __init__(self, rank=0, size=1, unique_id=None, thread_group=None):
         self.rank, self.size, self._id = int(rank), int(size), unique_id
+        #: ``ctypes.c_void_p`` shared by R engines of ONE process: the ranks
+        #: are threads on one GPU (``pcd_comm_init_threads``; tests only)
+        self.thread_group = thread_group
 
     def unique_id(self):
         return self._id

@@ -90,6 +90,7 @@ enum pcd_info {
    * multi-component kernels (2 / 3; 0 = scalar path) and rows (nodes) per
    * workgroup of its stream kernels (0 = CSR-vector fallback) */
   PCD_INFO_A00_COMPONENTS = 12, PCD_INFO_A00_ROWS_PER_WG = 13,
+  PCD_INFO_RANKS = 14,       /* ranks of the attached communicator (0: none) */
   PCD_INFO_NNZ_BASE = 16     /* + pcd_mat: stored nonzeros of that operator */
 };
 
@@ -338,6 +339,18 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f,
 int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
                     const double* phi_mid, int nq_s, const double* qw_s,
                     const double* phi_s, const double* dphi_s);
+/* Several ranks (pcd_comm_init before pcd_fe_begin; the reference's `mpirun
+ * -np N` over the same script, test/regression/test.py:186-195): the producer
+ * is REPLICATED - every rank assembles every level from the replicated iterate
+ * (a few ms per nonlinear step) and evaluates the whole residual, the linear
+ * solve is partitioned.  This call gives the engine the scalar CSR pattern of
+ * a level (nn2 + 1 row pointers, nnz_f sorted columns - the order of
+ * pcd_fe_get_level_values) = the layout of the global F x I_d it cuts its rows
+ * from; on the finest level it also creates the replicated operator the
+ * residual applies.  Host-pointer vectors of the pcd_fe_* calls are GLOBAL and
+ * identical on every rank.  Not needed on one GPU; Picard form only.          */
+int pcd_fe_bind_pattern(pcd_handle h, int level, int64_t nn2,
+                        const int32_t* rowptr, const int32_t* colidx);
 /* Newton linearisation (`--nls newton`: demo_navier-stokes-pcd.py:42,113-116,
  * J = derivative(F, w)): the velocity block becomes F x I_d + N(w) with
  * N_ij = (phi_b d_j w_i, phi_a), d*d scalar matrices on the pattern of F; the

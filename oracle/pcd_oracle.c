@@ -865,7 +865,7 @@ int pcdo_get_info(pcdo_t *h, int key, double *out) {
     case 9: *out = h->gmres_rnorm; break;
     case 10: *out = (double)h->n_u; break;      /* one rank owns every row */
     case 11: *out = (double)h->n_p; break;
-    case 12: case 13: *out = 0.0; break;          /* no kernel paths on the CPU */
+    case 12: case 13: case 14: *out = 0.0; break; /* no kernel paths, no communicator on the CPU */
     default:
       if (key >= 16 && key < 16 + MAT_COUNT) {
         *out = (double)h->mat[key - 16].nnz; break;

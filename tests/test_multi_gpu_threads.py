@@ -174,3 +174,108 @@ def test_three_dimensional_problem_partitioned(hip_lib):
         for x, its, nu_loc in run_ranks(hip_lib, R, "BRM1", work):
             assert its == ir and relerr(x, xr) < 1e-7
             assert nu_loc % 3 == 0
+
+
+@pytest.mark.parametrize("R,galerkin,dt", [(2, True, None), (3, False, None),
+                                           (2, True, 0.2)])
+def test_device_producer_on_several_ranks(hip_lib, R, galerkin, dt):
+    """Config 4 shape without the host producer: the nonlinear side
+    (assembly of every level, residual) replicated on every rank, the linear
+    solve partitioned; R ranks = R threads on this one GPU.  Compared with
+    the one-GPU device solve."""
+    from fenapack_amd import PETScOptions
+    from fenapack_amd.device_producer import (solve_steady_device,
+                                              solve_unsteady_device)
+    from fenapack_amd.driver import multigrid_inner_options
+    from fenapack_amd.fem import BackwardStep, Cavity
+    from fenapack_amd.parallel import Comm
+
+    def problem():
+        if dt:
+            return BackwardStep(3, nu=0.02, dt=dt)
+        return Cavity(5, nu=0.01)
+
+    def solve(comm):
+        pb = problem()
+        if dt:
+            out = solve_unsteady_device(pb, dt=dt, t_end=3 * dt,
+                                        newton_rtol=1e-5, comm=comm)
+            return out["newton_its"], out["krylov_per_newton"], \
+                out["w"].vector().copy()
+        out = solve_steady_device(pb, max_newton=8, comm=comm)
+        assert out["converged"]
+        eng = out["solver"].linear_solver().ksp().engine
+        rows.append((eng.info(c.INFO_N_U_LOCAL), pb.space.n_u,
+                     out["producer"].ranks))
+        return out["newton_its"], [out["krylov_per_step"]], \
+            out["w"].vector().copy()
+
+    rows = []
+    PETScOptions.clear()
+    multigrid_inner_options(dim=2, galerkin_u=galerkin)
+    PETScOptions.set("fieldsplit_u_pc_mg_coarse_eq_limit", 300)
+    # both kinds of coarse level: replicated below 300 rows (the coarsest one,
+    # which every rank inverts), partitioned above
+    import os
+    os.environ["PCD_REPLICATE_BELOW"] = "300"
+    try:
+        ref = solve(None)
+        group = ctypes.c_void_p()
+        comms = [Comm(r, R, thread_group=group) for r in range(R)]
+        out, errs = [None] * R, []
+
+        def body(r):
+            try:
+                out[r] = solve(comms[r])
+            except Exception as ex:            # pragma: no cover
+                errs.append((r, repr(ex)))
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not any(t.is_alive() for t in threads), "ranks deadlocked"
+        assert not errs, errs
+    finally:
+        del os.environ["PCD_REPLICATE_BELOW"]
+    for its, krylov, x in out:
+        assert its == ref[0]
+        for a, b in zip(krylov, ref[1]):
+            assert len(a) == len(b)
+            for i, j in zip(a, b):
+                assert abs(i - j) <= max(1, 0.05 * j), (krylov, ref[1])
+        assert relerr(x, ref[2]) < 1e-5
+    if not dt:
+        # the ranks really owned row blocks (rows[0] is the one-GPU run)
+        assert rows[0][0] == rows[0][1] and rows[0][2] == 0
+        assert sum(r[0] for r in rows[1:]) == rows[0][1]
+        assert all(0 < r[0] < r[1] and r[2] == R for r in rows[1:])
+    # every rank holds the same replicated iterate
+    for its, krylov, x in out[1:]:
+        assert relerr(x, out[0][2]) < 1e-12
+
+
+def test_device_producer_over_rccl_single_rank(hip_lib, monkeypatch):
+    """The same replicated-producer path over the RCCL backend itself, with
+    the one-rank communicator this box allows (all-reduces of whole vectors,
+    slices through the rank-local permutation)."""
+    from fenapack_amd import PETScOptions
+    from fenapack_amd.device_producer import solve_steady_device
+    from fenapack_amd.driver import multigrid_inner_options
+    from fenapack_amd.fem import Cavity
+    from fenapack_amd.parallel import Comm
+    PETScOptions.clear()
+    multigrid_inner_options(dim=2)
+    ref = solve_steady_device(Cavity(4, nu=0.01), max_newton=8)
+    monkeypatch.setenv("PCD_FORCE_COMM", "1")
+    out = solve_steady_device(Cavity(4, nu=0.01), max_newton=8,
+                              comm=Comm.world())
+    # (an RCCL communicator left to interpreter shutdown after another one
+    # has come and gone aborts in the library's own teardown: free it here)
+    out["solver"].linear_solver().ksp().engine.destroy()
+    assert out["producer"].ranks == 1 and ref["producer"].ranks == 0
+    assert out["converged"] and out["newton_its"] == ref["newton_its"]
+    for i, j in zip(out["krylov_per_step"], ref["krylov_per_step"]):
+        assert abs(i - j) <= max(1, 0.05 * j)
+    assert relerr(out["w"].vector(), ref["w"].vector()) < 1e-5
