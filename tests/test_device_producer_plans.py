@@ -80,3 +80,65 @@ def test_injection_map_picks_coincident_nodes(make, d):
     assert np.allclose(fine.node_coords[inj], coarse.node_coords, atol=1e-12)
     with pytest.raises(ValueError):
         injection_map(sp.csr_matrix(chain[-1]) * 0.5, d)
+
+
+@pytest.mark.parametrize("make", [lambda: Cavity(2, nls="newton"),
+                                  lambda: Cavity3D(1, n0=2, nls="newton")])
+def test_block_positions_rebuild_the_newton_block(make):
+    """pcd_fe_set_newton's position lists: scattering delta_ij F + N_ij
+    through them (what k_fe_scatter_blocks does) reproduces the host's
+    coupled velocity block; the structural pattern is (pattern of F) x
+    ones(d, d)."""
+    from fenapack_amd.device_producer import block_positions, coupled_pattern
+    pb = make()
+    V, d = pb.space, pb.space.dim
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((V.nn, d))
+    ref = V.assemble_A00(pb.nu, U, newton=True)              # host, no BCs
+    patS, patA = V._patterns(False)["SS"], V._patterns(True)["A00"]
+    K = coupled_pattern(patS.indptr, patS.indices, V.nn, d)
+    assert K.nnz == patA.nnz == d * d * patS.nnz
+    assert np.array_equal(K.indptr, patA.indptr)
+    assert np.array_equal(K.indices, patA.indices)
+    pos = block_positions(K, patS.indptr, patS.indices, d)
+    assert np.array_equal(np.sort(pos.ravel()), np.arange(K.nnz))
+    # scalar pieces on the pattern of F
+    w, gw = V.wind_at_qp(U)
+    S = pb.nu * V.p2_stiffness_cells() + V.p2_convection_cells(w)
+    F = np.bincount(patS.inv, weights=S.ravel(), minlength=patS.nnz)
+    Ncells = np.einsum('cq,qa,qb,cqkd->kdcab', V.wq, V.phi, V.phi, gw)
+    vals = np.zeros(K.nnz)
+    for i in range(d):
+        for j in range(d):
+            Nij = np.bincount(patS.inv, weights=Ncells[i, j].ravel(),
+                              minlength=patS.nnz)
+            vals[pos[i * d + j]] = (F if i == j else 0.0) + Nij
+    assert np.allclose(vals, ref.data, rtol=1e-12, atol=1e-12)
+    # an operator that lacks entries of the coupled pattern is refused
+    with pytest.raises(ValueError):
+        block_positions(V._patterns(False)["A00"].matrix(
+            np.ones(V._patterns(False)["A00"].nnz)), patS.indptr,
+            patS.indices, d)
+
+
+def test_kron_layout_of_a_level_matches_scipy():
+    """pcd_fe_bind_pattern's closed form: entry k of row a of F, component
+    c, sits at d*rowptr[a] + c*len_a + (k - rowptr[a]) of the sorted CSR of
+    F x I_d on interleaved dofs."""
+    pb = Cavity(2)
+    V, d = pb.space, 2
+    pat = V._patterns(False)["SS"]
+    rng = np.random.default_rng(2)
+    F = rng.standard_normal(pat.nnz)
+    K = sp.kron(pat.matrix(F), sp.identity(d), format="csr")
+    K.sort_indices()
+    rows = np.repeat(np.arange(V.nn), np.diff(pat.indptr))
+    b0 = pat.indptr[rows].astype(np.int64)
+    ln = np.diff(pat.indptr)[rows]
+    k = np.arange(pat.nnz)
+    got = np.zeros(K.nnz)
+    for c in range(d):
+        got[d * b0 + c * ln + (k - b0)] = F
+    # scipy keeps the structural zeros of kron(F, I)? it does not store them:
+    assert K.nnz == d * pat.nnz
+    assert np.array_equal(got, K.data)
