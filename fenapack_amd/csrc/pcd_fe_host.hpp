@@ -55,6 +55,7 @@ struct FeState {
   // several ranks: the nonlinear side is replicated (global vectors and
   // operators on every rank), the linear solve is partitioned
   DCsr Ku;                           // global F x I_d of the finest level
+  DCsr Ju;                           // ... and the global coupled block (Newton)
   DBuf<int> gperm;                   // split position -> caller's index, all rows
   DBuf<double> bloc, dxloc;          // this rank's slices for GMRES
   DBuf<int64_t> sys_pos; bool sys_bound = false; int sys_blocks = 0;
@@ -85,7 +86,7 @@ struct FeState {
     lev.clear();
     qw.release(); phi.release(); dphi.release(); psi.release(); Func.release();
     Nunc.release(); Jv.release(); inv_vals.release(); dvec.release(); y2.release();
-    Ku.release(); gperm.release(); bloc.release(); dxloc.release();
+    Ku.release(); Ju.release(); gperm.release(); bloc.release(); dxloc.release();
     phic.release(); qw_s.release(); phi_s.release(); dphi_s.release();
     sys_pos.release(); kp_ptr.release(); kp_src.release(); kp_const.release();
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
@@ -457,6 +458,25 @@ int pcd_fe_bind_pattern(pcd_handle h, int level, int64_t nn2, const int32_t* row
     CHK(upload_csr(h, fe.Ku, d * nn2, d * nn2, rp.data(), cc.data(), nullptr, nullptr));
     fe.Ku.replicated = true;
     HIPCHK(hipMemsetAsync(fe.Ku.val.p, 0, (size_t)fe.Ku.nnz * sizeof(double), h->stream));
+    if (fe.newton) {
+      // (pattern of F) x ones(d, d), sorted: row d a + i holds, for every
+      // entry b of row a, the columns d b .. d b + d - 1
+      if ((int64_t)d * d * L.nnzf >= INT32_MAX) return fail(PCD_ERR_ARG, "fe_bind_pattern: coupled block exceeds int32 indexing");
+      std::vector<int32_t> jp((size_t)d * nn2 + 1), jc((size_t)d * d * L.nnzf);
+      jp[0] = 0;
+      for (int64_t a = 0; a < nn2; ++a) {
+        const int32_t b0 = rowptr[a], len = rowptr[a + 1] - b0;
+        for (int i = 0; i < d; ++i) {
+          const int64_t base = (int64_t)d * d * b0 + (int64_t)i * d * len;
+          jp[d * a + i + 1] = (int32_t)(base + (int64_t)d * len);
+          for (int32_t k = 0; k < len; ++k)
+            for (int j = 0; j < d; ++j) jc[base + (int64_t)k * d + j] = d * colidx[b0 + k] + j;
+        }
+      }
+      CHK(upload_csr(h, fe.Ju, d * nn2, d * nn2, jp.data(), jc.data(), nullptr, nullptr));
+      fe.Ju.replicated = true;
+      HIPCHK(hipMemsetAsync(fe.Ju.val.p, 0, (size_t)fe.Ju.nnz * sizeof(double), h->stream));
+    }
   }
   return 0;
 }
@@ -676,12 +696,17 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
           // the level's operator is this rank's slice (or a replica) of the
           // global F x I_d: expand the replicated scalar values into the
           // global CSR order and let the ordinary value refresh cut it
-          if (fe.newton) return fail(PCD_ERR_STATE, "fe_update: the Newton block is assembled on one GPU");
           if (!L.kpos.p) return fail(PCD_ERR_STATE, "fe_update: several ranks need pcd_fe_bind_pattern on every level");
-          if (!M.A.set || M.A.gnnz != (int64_t)fe.dim * L.nnzf)
-            return fail(PCD_ERR_STATE, "fe_update: multigrid level %d is not F x I_%d on the FE pattern", l, fe.dim);
-          hipLaunchKernelGGL(k_fe_scatter<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
-                             h->stream, L.nnzf, fe.dim, L.kpos.p, L.F.p, L.gvals.p);
+          const int nb = fe.newton ? d2 : fe.dim;
+          if (!M.A.set || M.A.gnnz != (int64_t)nb * L.nnzf)
+            return fail(PCD_ERR_STATE, "fe_update: multigrid level %d does not have the FE pattern", l);
+          CHK(L.gvals.ensure((size_t)nb * L.nnzf));
+          if (fe.newton)        // npos = positions in the global coupled CSR
+            hipLaunchKernelGGL(k_fe_scatter_blocks<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                               h->stream, L.nnzf, fe.dim, L.npos.p, L.F.p, L.N.p, L.gvals.p);
+          else
+            hipLaunchKernelGGL(k_fe_scatter<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                               h->stream, L.nnzf, fe.dim, L.kpos.p, L.F.p, L.gvals.p);
           CHK(refresh_values(h, M.A, L.gvals.p, PCD_MEM_DEVICE));
         } else if (fe.newton) {
           if (!M.A.set || M.A.nnz != (int64_t)d2 * L.nnzf)
@@ -741,8 +766,14 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
 // are scattered into a scratch array that stands in for A00's own
 static int fe_apply_blocks(Engine* h, FeState& fe, const double* S, const double* Nb,
                            const double* dv, double* dy) {
-  DCsr& A = h->mat[PCD_MAT_A00];
   FeLevel& Lt = fe.lev[fe.nlev - 1];
+  if (h->comm) {                         // replicated global operator
+    if (!fe.Ju.set) return fail(PCD_ERR_STATE, "fe: several ranks need pcd_fe_bind_pattern after pcd_fe_set_newton");
+    hipLaunchKernelGGL(k_fe_scatter_blocks<int>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                       h->stream, Lt.nnzf, fe.dim, Lt.npos.p, S, Nb, fe.Ju.val.p);
+    return spmv(h, fe.Ju, dv, dy);
+  }
+  DCsr& A = h->mat[PCD_MAT_A00];
   if (!A.set || A.kron || A.nnz != (int64_t)fe.dim * fe.dim * Lt.nnzf)
     return fail(PCD_ERR_STATE, "fe_update: A00 is not the coupled block on the FE pattern");
   CHK(fe.Jv.ensure((size_t)A.nnz));

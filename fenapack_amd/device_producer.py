@@ -163,9 +163,6 @@ class DeviceProducer(object):
         # 0: no communicator attached; >= 1: the engine's rows are partitioned
         # (1 = a one-rank RCCL communicator, PCD_FORCE_COMM=1)
         self.ranks = int(ksp.engine.info(c.INFO_RANKS))
-        if self.ranks and self.newton:
-            raise ValueError("device producer: the Newton block is assembled "
-                             "on one GPU")
         self.eng = eng = ksp.engine
         if not eng.L.hip:
             raise c.EngineError("device producer needs the HIP engine")

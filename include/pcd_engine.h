@@ -348,7 +348,9 @@ int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
  * pcd_fe_get_level_values) = the layout of the global F x I_d it cuts its rows
  * from; on the finest level it also creates the replicated operator the
  * residual applies.  Host-pointer vectors of the pcd_fe_* calls are GLOBAL and
- * identical on every rank.  Not needed on one GPU; Picard form only.          */
+ * identical on every rank.  Not needed on one GPU.  With the Newton block
+ * call it AFTER pcd_fe_set_newton (the finest level then also gets the
+ * replicated coupled operator of the residual's boundary-defect term).        */
 int pcd_fe_bind_pattern(pcd_handle h, int level, int64_t nn2,
                         const int32_t* rowptr, const int32_t* colidx);
 /* Newton linearisation (`--nls newton`: demo_navier-stokes-pcd.py:42,113-116,

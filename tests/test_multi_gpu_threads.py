@@ -176,9 +176,11 @@ def test_three_dimensional_problem_partitioned(hip_lib):
             assert nu_loc % 3 == 0
 
 
-@pytest.mark.parametrize("R,galerkin,dt", [(2, True, None), (3, False, None),
-                                           (2, True, 0.2)])
-def test_device_producer_on_several_ranks(hip_lib, R, galerkin, dt):
+@pytest.mark.parametrize("R,galerkin,dt,nls", [
+    (2, True, None, "picard"), (3, False, None, "picard"),
+    (2, True, 0.2, "picard"), (2, True, None, "newton"),
+    (3, False, 0.2, "newton")])
+def test_device_producer_on_several_ranks(hip_lib, R, galerkin, dt, nls):
     """Config 4 shape without the host producer: the nonlinear side
     (assembly of every level, residual) replicated on every rank, the linear
     solve partitioned; R ranks = R threads on this one GPU.  Compared with
@@ -192,8 +194,8 @@ def test_device_producer_on_several_ranks(hip_lib, R, galerkin, dt):
 
     def problem():
         if dt:
-            return BackwardStep(3, nu=0.02, dt=dt)
-        return Cavity(5, nu=0.01)
+            return BackwardStep(3, nu=0.02, dt=dt, nls=nls)
+        return Cavity(5, nu=0.01, nls=nls)
 
     def solve(comm):
         pb = problem()
