@@ -144,3 +144,31 @@ def test_unsteady_anchor_against_the_published_table(pcdr, published, cycles,
     if cycles >= 8:
         # the published averages: 126.3 / 4 = 31.6 and 67.4 / 4 = 16.9
         assert max(per_picard) <= (19 if pcdr else 33), per_picard
+
+
+def test_cavity_level6_newton_block_on_the_device():
+    """`--nls newton` at the headline size: the coupled velocity block
+    F x I + N assembled on the DEVICE (pcd_fe_set_newton), as matrix and as
+    the engine applies it, against the HOST producer at the same iterate."""
+    from fenapack_amd.device_producer import solve_steady_device
+    PETScOptions.clear()
+    multigrid_inner_options(dim=2)
+    pb = Cavity(6, nu=0.01, nls="newton")
+    out = solve_steady_device(pb, max_newton=3, newton_rtol=0.0)
+    PETScOptions.clear()
+    assert out["krylov_per_step"] == [11, 39, 39]
+    prod, V = out["producer"], pb.space
+    assert prod.newton
+    # the host producer at the device's final iterate
+    x = out["w"].vector()
+    lin = pb.linearise(x[V.is_u], x[V.is_p])
+    import scipy.sparse.linalg as spla
+    A00 = prod.level_matrix(prod.nlev - 1)
+    assert abs(A00[0::2, 1::2]).max() > 1e-5                     # coupled
+    assert spla.norm(A00 - lin["A00"]) < 1e-12 * spla.norm(lin["A00"])
+    eng = out["solver"].linear_solver().ksp().engine
+    rng = np.random.default_rng(1)
+    xu = rng.standard_normal(V.n_u)
+    assert relerr(eng.spmv_np(c.MAT_A00, xu, V.n_u), lin["A00"] @ xu) < 1e-12
+    # (the GMRES counts are those of the host-driven Newton solve at these
+    # settings: profiles/r02_ac_newton_level6_host_vs_device.json)
