@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""BASELINE config 5's shape (3-D lid-driven cavity, three velocity components,
+row-partitioned over 8 ranks) on ONE GPU: the ranks are threads of this
+process (pcd_comm_init_threads), each with its own engine, partition, halo
+plans and device producer.  Steady Picard solve; prints one JSON line per R.
+Parity of the partitioned code path (Krylov counts, solution), NOT a timing.
+
+usage: steady_thread_ranks.py [cube|cavity] [level] [R ...=1 8]"""
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fenapack_amd import PETScOptions                                  # noqa
+from fenapack_amd.device_producer import solve_steady_device           # noqa
+from fenapack_amd.driver import multigrid_inner_options                # noqa
+from fenapack_amd.fem import Cavity, Cavity3D                          # noqa
+from fenapack_amd.parallel import Comm                                 # noqa
+
+geometry = sys.argv[1] if len(sys.argv) > 1 else "cube"
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+ranks = [int(a) for a in sys.argv[3:]] or [1, 8]
+dim = 3 if geometry == "cube" else 2
+# the two finest levels partitioned, the rest replicated (default limit:
+# 60000 rows; lowered so that small runs exercise both kinds of level)
+os.environ.setdefault("PCD_REPLICATE_BELOW", "20000")
+PETScOptions.clear()
+multigrid_inner_options(dim=dim)
+
+
+def solve(comm):
+    pb = Cavity3D(level, nu=0.01, n0=4) if geometry == "cube" \
+        else Cavity(level, nu=0.01)
+    out = solve_steady_device(pb, max_newton=10, comm=comm)
+    eng = out["solver"].linear_solver().ksp().engine
+    from fenapack_amd import _cabi as c
+    return {"ndof": pb.space.ndof, "picard_its": out["newton_its"],
+            "converged": bool(out["converged"]),
+            "krylov_per_step": out["krylov_per_step"],
+            "final_residual": out["residuals"][-1],
+            "rows_u_of_this_rank": int(eng.info(c.INFO_N_U_LOCAL)),
+            "checksum": float(abs(out["w"].vector()).sum())}
+
+
+for R in ranks:
+    t0 = time.time()
+    if R == 1:
+        res = [solve(None)]
+    else:
+        group = ctypes.c_void_p()
+        res, errs = [None] * R, []
+
+        def body(r):
+            try:
+                res[r] = solve(Comm(r, R, thread_group=group))
+            except Exception as ex:
+                errs.append((r, repr(ex)))
+
+        th = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            print(json.dumps({"ranks": R, "errors": errs}))
+            sys.exit(1)
+    same = all(r["krylov_per_step"] == res[0]["krylov_per_step"]
+               and abs(r["checksum"] - res[0]["checksum"])
+               <= 1e-10 * res[0]["checksum"] for r in res)
+    line = dict(res[0], ranks=R, geometry=geometry, level=level,
+                rows_u_per_rank=[r["rows_u_of_this_rank"] for r in res],
+                replicas_agree=same, wall_seconds=round(time.time() - t0, 2),
+                backend="threads on one GPU" if R > 1 else "one GPU")
+    line.pop("rows_u_of_this_rank")
+    print(json.dumps(line), flush=True)
