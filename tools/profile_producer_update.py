@@ -28,3 +28,12 @@ for _ in range(10):
     prod.update(x[V.is_u], x[V.is_p])
 print("10 updates: %.1f ms each (host pieces included)"
       % (100 * (time.perf_counter() - t0)))
+# the device-resident form of the same step: refresh + residual in one call
+prod.set_time_level()
+xm = np.ascontiguousarray(x)
+prod.residual(xm)
+t0 = time.perf_counter()
+for _ in range(10):
+    prod.residual(xm)
+print("10 device residual calls (refresh of every level + residual): "
+      "%.2f ms each" % (100 * (time.perf_counter() - t0)))
