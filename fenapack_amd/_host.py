@@ -1,0 +1,236 @@
+"""ctypes binding of ``libpcd_host.so`` (``include/pcd_host.h``): the native
+(OpenMP) integer work of problem set-up - sparsity patterns, element -> entry
+contribution lists, Galerkin gather plans, symbolic products.
+
+The library has no HIP dependency, so the producer uses it on every box.  It
+is part of the product build (``__graft_entry__.build()``); when it is missing
+the producer fails loudly - there is no silent numpy fallback.  The numpy
+implementations it replaced are kept as the *checker* of this library
+(``FENAPACK_AMD_NUMPY_PRODUCER=1`` selects them; ``tests/test_host_native.py``
+compares both on the same inputs)."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIBRARY_PATH = os.path.join(HERE, "lib", "libpcd_host.so")
+
+_I64P = ctypes.POINTER(ctypes.c_int64)
+_I32P = ctypes.POINTER(ctypes.c_int32)
+_F64P = ctypes.POINTER(ctypes.c_double)
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def use_numpy():
+    """The numpy restatement of the helpers (the checker), on request."""
+    return os.environ.get("FENAPACK_AMD_NUMPY_PRODUCER", "0") == "1"
+
+
+_lib = None
+
+
+def library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(HOST_LIBRARY_PATH):
+        raise HostError("%s is missing: run `python -c 'import "
+                        "__graft_entry__ as g; g.build()'` (g++ -fopenmp)"
+                        % HOST_LIBRARY_PATH)
+    L = ctypes.CDLL(HOST_LIBRARY_PATH)
+    L.pcdh_last_error.restype = ctypes.c_char_p
+    L.pcdh_group_nnz.restype = ctypes.c_int64
+    L.pcdh_group_kept.restype = ctypes.c_int64
+    L.pcdh_group_nnz.argtypes = [ctypes.c_void_p]
+    L.pcdh_group_kept.argtypes = [ctypes.c_void_p]
+    L.pcdh_group_free.argtypes = [ctypes.c_void_p]
+    L.pcdh_group_free.restype = None
+    L.pcdh_group_pairs.argtypes = [ctypes.c_int64, _I64P, _I64P,
+                                   ctypes.c_int64, ctypes.c_int64,
+                                   ctypes.c_int64,
+                                   ctypes.POINTER(ctypes.c_void_p)]
+    L.pcdh_pattern_cells.argtypes = [ctypes.c_int64, ctypes.c_int, _I64P,
+                                     ctypes.c_int, _I64P, ctypes.c_int64,
+                                     ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.POINTER(ctypes.c_void_p)]
+    L.pcdh_group_export.argtypes = [ctypes.c_void_p, _I64P, _I64P, _I64P,
+                                    _I64P, _I64P]
+    L.pcdh_extract_count.argtypes = [ctypes.c_int64, _I32P, _I32P, _I32P,
+                                     _I32P, _I32P]
+    L.pcdh_extract_fill.argtypes = [ctypes.c_int64, _I32P, _I32P, _I32P,
+                                    _I32P, _I32P, _I32P, _I64P]
+    L.pcdh_transpose.argtypes = [ctypes.c_int64, ctypes.c_int64, _I32P, _I32P,
+                                 _F64P, _I32P, _I32P, _F64P]
+    L.pcdh_spgemm_count.argtypes = [ctypes.c_int64, ctypes.c_int64,
+                                    ctypes.c_int64, _I32P, _I32P, _I32P,
+                                    _I32P, _I64P]
+    L.pcdh_spgemm_fill.argtypes = [ctypes.c_int64, ctypes.c_int64,
+                                   ctypes.c_int64, _I32P, _I32P, _F64P, _I32P,
+                                   _I32P, _F64P, _I64P, _I32P, _F64P]
+    L.pcdh_set_threads.argtypes = [ctypes.c_int]
+    _lib = L
+    nt = os.environ.get("FENAPACK_AMD_HOST_THREADS")
+    if nt:
+        L.pcdh_set_threads(int(nt))
+    return L
+
+
+def _chk(rc):
+    if rc:
+        raise HostError(library().pcdh_last_error().decode())
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Group(object):
+    """Result of a grouping: ``indptr`` (rows kept + 1), ``ucols`` (column of
+    every group), and on demand ``inv`` (group of every input pair),
+    ``ptr`` / ``order`` (members of every group in ascending input order)."""
+
+    def __init__(self, handle, n, nrows_kept):
+        self._h = handle
+        self.n, self.nrows = n, nrows_kept
+        L = library()
+        self.nnz = int(L.pcdh_group_nnz(handle))
+        self.kept = int(L.pcdh_group_kept(handle))
+        self.indptr = np.empty(nrows_kept + 1, dtype=np.int64)
+        self.ucols = np.empty(self.nnz, dtype=np.int64)
+        _chk(L.pcdh_group_export(handle, _p(self.indptr, _I64P),
+                                 _p(self.ucols, _I64P), None, None, None))
+        self._inv = self._ptr = self._order = None
+
+    @property
+    def inv(self):
+        if self._inv is None:
+            self._inv = np.empty(self.n, dtype=np.int64)
+            _chk(library().pcdh_group_export(self._h, None, None,
+                                             _p(self._inv, _I64P), None, None))
+        return self._inv
+
+    def members(self):
+        if self._ptr is None:
+            self._ptr = np.empty(self.nnz + 1, dtype=np.int64)
+            self._order = np.empty(self.kept, dtype=np.int64)
+            _chk(library().pcdh_group_export(self._h, None, None, None,
+                                             _p(self._ptr, _I64P),
+                                             _p(self._order, _I64P)))
+        return self._ptr, self._order
+
+    def release(self):
+        """Drop the native copy (the exported numpy arrays stay)."""
+        if self._h:
+            library().pcdh_group_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def group_pairs(rows, cols, nrows, row0=0, row1=None):
+    """Group ``(rows[i], cols[i])``: see ``pcdh_group_pairs``."""
+    rows = _i64(np.asarray(rows).ravel())
+    cols = None if cols is None else _i64(np.asarray(cols).ravel())
+    row1 = nrows if row1 is None else row1
+    h = ctypes.c_void_p()
+    _chk(library().pcdh_group_pairs(rows.size, _p(rows, _I64P),
+                                    _p(cols, _I64P), nrows, row0, row1,
+                                    ctypes.byref(h)))
+    return Group(h, rows.size, row1 - row0)
+
+
+def pattern_cells(rdofs, cdofs, nrows, row0=0, row1=None):
+    """Pattern of a form from cell dof tables ``rdofs`` (ncell, nr) x
+    ``cdofs`` (ncell, nc); element entries are (cell, a, b), b fastest."""
+    rdofs, cdofs = _i64(rdofs), _i64(cdofs)
+    ncell, nr = rdofs.shape
+    nc = cdofs.shape[1]
+    assert cdofs.shape[0] == ncell
+    row1 = nrows if row1 is None else row1
+    h = ctypes.c_void_p()
+    _chk(library().pcdh_pattern_cells(ncell, nr, _p(rdofs, _I64P), nc,
+                                      _p(cdofs, _I64P), nrows, row0, row1,
+                                      ctypes.byref(h)))
+    return Group(h, ncell * nr * nc, row1 - row0)
+
+
+def extract_block(rows, rowptr, col, colmap):
+    """Sub-matrix (rows, columns renumbered by ``colmap``; -1 drops) with
+    value provenance: returns (rowptr, col, src)."""
+    rows, rowptr, col, colmap = _i32(rows), _i32(rowptr), _i32(col), \
+        _i32(colmap)
+    L = library()
+    orp = np.empty(rows.size + 1, dtype=np.int32)
+    _chk(L.pcdh_extract_count(rows.size, _p(rows, _I32P), _p(rowptr, _I32P),
+                              _p(col, _I32P), _p(colmap, _I32P),
+                              _p(orp, _I32P)))
+    oc = np.empty(int(orp[-1]), dtype=np.int32)
+    osrc = np.empty(int(orp[-1]), dtype=np.int64)
+    _chk(L.pcdh_extract_fill(rows.size, _p(rows, _I32P), _p(rowptr, _I32P),
+                             _p(col, _I32P), _p(colmap, _I32P),
+                             _p(orp, _I32P), _p(oc, _I32P), _p(osrc, _I64P)))
+    return orp, oc, osrc
+
+
+def spgemm(A, B, row0=0, row1=None):
+    """Rows ``[row0, row1)`` of ``A @ B`` (scipy CSR in, scipy CSR out) with a
+    STRUCTURAL pattern: entries that cancel to zero are kept, columns
+    sorted."""
+    import scipy.sparse as sp
+    A, B = sp.csr_matrix(A), sp.csr_matrix(B)
+    assert A.shape[1] == B.shape[0]
+    row1 = A.shape[0] if row1 is None else row1
+    arp, ac, av = _i32(A.indptr), _i32(A.indices), \
+        np.ascontiguousarray(A.data, dtype=np.float64)
+    brp, bc, bv = _i32(B.indptr), _i32(B.indices), \
+        np.ascontiguousarray(B.data, dtype=np.float64)
+    L = library()
+    crp = np.empty(row1 - row0 + 1, dtype=np.int64)
+    _chk(L.pcdh_spgemm_count(row0, row1, B.shape[1], _p(arp, _I32P),
+                             _p(ac, _I32P), _p(brp, _I32P), _p(bc, _I32P),
+                             _p(crp, _I64P)))
+    nnz = int(crp[-1])
+    cc = np.empty(nnz, dtype=np.int32)
+    cv = np.empty(nnz, dtype=np.float64)
+    _chk(L.pcdh_spgemm_fill(row0, row1, B.shape[1], _p(arp, _I32P),
+                            _p(ac, _I32P), _p(av, _F64P), _p(brp, _I32P),
+                            _p(bc, _I32P), _p(bv, _F64P), _p(crp, _I64P),
+                            _p(cc, _I32P), _p(cv, _F64P)))
+    idx = crp.astype(np.int32) if nnz < 2 ** 31 else crp
+    C = sp.csr_matrix((cv, cc, idx), shape=(row1 - row0, B.shape[1]))
+    C.has_sorted_indices = True
+    return C
+
+
+def transpose(A):
+    """CSR transpose with sorted columns (counting sort by column)."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A)
+    nr, nc = A.shape
+    rp, ci = _i32(A.indptr), _i32(A.indices)
+    va = np.ascontiguousarray(A.data, dtype=np.float64)
+    trp = np.empty(nc + 1, dtype=np.int32)
+    tc = np.empty(A.nnz, dtype=np.int32)
+    tv = np.empty(A.nnz, dtype=np.float64)
+    _chk(library().pcdh_transpose(nr, nc, _p(rp, _I32P), _p(ci, _I32P),
+                                  _p(va, _F64P), _p(trp, _I32P),
+                                  _p(tc, _I32P), _p(tv, _F64P)))
+    T = sp.csr_matrix((tv, tc, trp), shape=(nc, nr))
+    T.has_sorted_indices = True
+    return T

@@ -1,0 +1,380 @@
+// pcd_host.cpp - libpcd_host.so: host-side (OpenMP) set-up helpers of the PCD
+// engine; C ABI in include/pcd_host.h.  Integer work only (patterns,
+// contribution lists, sub-matrix extraction, symbolic products); no HIP.
+//
+// Build: g++ -O3 -fopenmp -std=c++17 -shared -fPIC pcd_host.cpp -o libpcd_host.so
+#include "../../include/pcd_host.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <utility>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+static int g_threads = 0;
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static int nthreads() {
+  int t = g_threads > 0 ? g_threads : omp_get_max_threads();
+  return std::max(1, std::min(t, 256));
+}
+
+// ---------------------------------------------------------------- grouping
+struct pcdh_group_s {
+  int64_t n = 0, nrows_kept = 0, row0 = 0, nnz = 0, kept = 0;
+  std::vector<int64_t> indptr;   // nrows_kept + 1
+  std::vector<int64_t> ucols;    // nnz
+  std::vector<int64_t> ptr;      // nnz + 1
+  std::vector<int64_t> order;    // kept
+};
+
+// Stable grouping of items 0..n-1 by (row(i), col(i)); rows outside
+// [row0, row1) are dropped.  Two-level counting sort: items are first
+// partitioned (stably) into B contiguous row chunks with per-thread
+// histograms of size B, then every chunk is counting-sorted by row and each
+// row's short segment is sorted by column - all passes parallel, O(n) memory.
+template <class RowF, class ColF>
+static int group_impl(int64_t n, RowF row, ColF col, int64_t nrows, int64_t row0,
+                      int64_t row1, pcdh_group_s* g) {
+  const int T = nthreads();
+  const int64_t nk = row1 - row0;
+  g->n = n; g->nrows_kept = nk; g->row0 = row0;
+  g->indptr.assign(nk + 1, 0);
+  if (nk <= 0 || n <= 0) { g->ptr.assign(1, 0); return 0; }
+  const int64_t B = std::max<int64_t>(1, std::min<int64_t>(nk, (int64_t)T * 8));
+  const int64_t W = (nk + B - 1) / B;
+  // pass 1: per-thread histograms over the chunks
+  std::vector<int64_t> hist((size_t)T * B, 0);
+  int bad = 0;
+#pragma omp parallel num_threads(T)
+  {
+    const int t = omp_get_thread_num();
+    const int64_t i0 = n * t / T, i1 = n * (t + 1) / T;
+    int64_t* h = hist.data() + (size_t)t * B;
+    for (int64_t i = i0; i < i1; ++i) {
+      const int64_t r = row(i);
+      if (r < 0 || r >= nrows) { bad = 1; continue; }
+      if (r < row0 || r >= row1) continue;
+      ++h[(r - row0) / W];
+    }
+  }
+  if (bad) return fail(PCDH_ERR_ARG, "group: row index outside [0, %lld)", (long long)nrows);
+  // offsets: chunk-major, thread-minor (keeps ascending input position)
+  std::vector<int64_t> chunk_off(B + 1, 0);
+  {
+    int64_t run = 0;
+    for (int64_t b = 0; b < B; ++b) {
+      chunk_off[b] = run;
+      for (int t = 0; t < T; ++t) {
+        const int64_t c = hist[(size_t)t * B + b];
+        hist[(size_t)t * B + b] = run;
+        run += c;
+      }
+    }
+    chunk_off[B] = run;
+  }
+  const int64_t kept = chunk_off[B];
+  g->kept = kept;
+  std::vector<int64_t> part(kept), sorted(kept);
+#pragma omp parallel num_threads(T)
+  {
+    const int t = omp_get_thread_num();
+    const int64_t i0 = n * t / T, i1 = n * (t + 1) / T;
+    int64_t* h = hist.data() + (size_t)t * B;
+    for (int64_t i = i0; i < i1; ++i) {
+      const int64_t r = row(i);
+      if (r < row0 || r >= row1) continue;
+      part[h[(r - row0) / W]++] = i;
+    }
+  }
+  // pass 2: per chunk, counting sort by row, then sort each row by column
+  std::vector<int64_t> rowlen(nk, 0);            // groups per row
+  std::vector<std::vector<int64_t>> c_ucols(B), c_gsize(B);
+#pragma omp parallel num_threads(T)
+  {
+    std::vector<int64_t> cnt;
+    std::vector<std::pair<int64_t, int64_t>> seg;
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t b = 0; b < B; ++b) {
+      const int64_t r_lo = b * W, r_hi = std::min<int64_t>(nk, r_lo + W);
+      if (r_lo >= r_hi) continue;
+      const int64_t p0 = chunk_off[b], p1 = chunk_off[b + 1];
+      cnt.assign(r_hi - r_lo + 1, 0);
+      for (int64_t p = p0; p < p1; ++p) ++cnt[row(part[p]) - row0 - r_lo + 1];
+      for (int64_t r = 0; r < r_hi - r_lo; ++r) cnt[r + 1] += cnt[r];
+      {
+        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+        for (int64_t p = p0; p < p1; ++p) {
+          const int64_t i = part[p];
+          sorted[p0 + cur[row(i) - row0 - r_lo]++] = i;
+        }
+      }
+      auto& uc = c_ucols[b];
+      auto& gs = c_gsize[b];
+      for (int64_t r = 0; r < r_hi - r_lo; ++r) {
+        const int64_t s0 = p0 + cnt[r], s1 = p0 + cnt[r + 1];
+        if (s0 == s1) continue;
+        seg.resize(s1 - s0);
+        for (int64_t p = s0; p < s1; ++p) seg[p - s0] = {col(sorted[p]), sorted[p]};
+        // (col, position): positions are distinct, so this IS the stable order
+        std::sort(seg.begin(), seg.end());
+        int64_t groups = 0;
+        for (int64_t p = s0; p < s1; ++p) {
+          sorted[p] = seg[p - s0].second;
+          if (p == s0 || seg[p - s0].first != seg[p - s0 - 1].first) {
+            uc.push_back(seg[p - s0].first); gs.push_back(0); ++groups;
+          }
+          ++gs.back();
+        }
+        rowlen[r_lo + r] = groups;
+      }
+    }
+  }
+  for (int64_t r = 0; r < nk; ++r) g->indptr[r + 1] = g->indptr[r] + rowlen[r];
+  const int64_t nnz = g->indptr[nk];
+  g->nnz = nnz;
+  g->ucols.resize(nnz);
+  g->ptr.resize(nnz + 1);
+  std::vector<int64_t> goff(B + 1, 0);
+  for (int64_t b = 0; b < B; ++b) goff[b + 1] = goff[b] + (int64_t)c_ucols[b].size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(T)
+  for (int64_t b = 0; b < B; ++b) {
+    int64_t run = chunk_off[b];
+    for (size_t k = 0; k < c_ucols[b].size(); ++k) {
+      g->ucols[goff[b] + k] = c_ucols[b][k];
+      g->ptr[goff[b] + k] = run;
+      run += c_gsize[b][k];
+    }
+  }
+  g->ptr[nnz] = kept;
+  g->order.swap(sorted);
+  return 0;
+}
+
+extern "C" {
+
+const char* pcdh_last_error(void) { return g_err; }
+
+int pcdh_set_threads(int n) {
+  if (n < 0) return fail(PCDH_ERR_ARG, "set_threads: negative count");
+  g_threads = n;
+  return 0;
+}
+int pcdh_get_threads(void) { return nthreads(); }
+
+int pcdh_group_pairs(int64_t n, const int64_t* rows, const int64_t* cols,
+                     int64_t nrows, int64_t row0, int64_t row1, pcdh_group* out) {
+  if (!out || n < 0 || (n && !rows) || nrows < 0 || row0 < 0 || row1 > nrows || row0 > row1)
+    return fail(PCDH_ERR_ARG, "group_pairs: bad arguments");
+  pcdh_group_s* g = new (std::nothrow) pcdh_group_s();
+  if (!g) return fail(PCDH_ERR_NOMEM, "group_pairs: out of memory");
+  int rc;
+  try {
+    if (cols)
+      rc = group_impl(n, [rows](int64_t i) { return rows[i]; },
+                      [cols](int64_t i) { return cols[i]; }, nrows, row0, row1, g);
+    else
+      rc = group_impl(n, [rows](int64_t i) { return rows[i]; },
+                      [](int64_t) { return (int64_t)0; }, nrows, row0, row1, g);
+  } catch (const std::bad_alloc&) {
+    rc = fail(PCDH_ERR_NOMEM, "group_pairs: out of memory");
+  }
+  if (rc) { delete g; return rc; }
+  *out = g;
+  return 0;
+}
+
+int pcdh_pattern_cells(int64_t ncell, int nr, const int64_t* rdofs, int nc,
+                       const int64_t* cdofs, int64_t nrows, int64_t row0,
+                       int64_t row1, pcdh_group* out) {
+  if (!out || ncell < 0 || nr < 1 || nc < 1 || (ncell && (!rdofs || !cdofs)) ||
+      nrows < 0 || row0 < 0 || row1 > nrows || row0 > row1)
+    return fail(PCDH_ERR_ARG, "pattern_cells: bad arguments");
+  pcdh_group_s* g = new (std::nothrow) pcdh_group_s();
+  if (!g) return fail(PCDH_ERR_NOMEM, "pattern_cells: out of memory");
+  const int64_t per = (int64_t)nr * nc;
+  int rc;
+  try {
+    rc = group_impl(
+        ncell * per,
+        [=](int64_t i) { const int64_t c = i / per; return rdofs[c * nr + (i - c * per) / nc]; },
+        [=](int64_t i) { const int64_t c = i / per; return cdofs[c * nc + (i - c * per) % nc]; },
+        nrows, row0, row1, g);
+  } catch (const std::bad_alloc&) {
+    rc = fail(PCDH_ERR_NOMEM, "pattern_cells: out of memory");
+  }
+  if (rc) { delete g; return rc; }
+  *out = g;
+  return 0;
+}
+
+int64_t pcdh_group_nnz(pcdh_group g) { return g ? g->nnz : -1; }
+int64_t pcdh_group_kept(pcdh_group g) { return g ? g->kept : -1; }
+
+int pcdh_group_export(pcdh_group g, int64_t* indptr, int64_t* ucols, int64_t* inv,
+                      int64_t* ptr, int64_t* order) {
+  if (!g) return fail(PCDH_ERR_ARG, "group_export: null group");
+  const int T = nthreads();
+  if (indptr) std::copy(g->indptr.begin(), g->indptr.end(), indptr);
+  if (ucols) std::copy(g->ucols.begin(), g->ucols.end(), ucols);
+  if (ptr) std::copy(g->ptr.begin(), g->ptr.end(), ptr);
+  if (order) std::copy(g->order.begin(), g->order.end(), order);
+  if (inv) {
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int64_t i = 0; i < g->n; ++i) inv[i] = -1;
+#pragma omp parallel for schedule(static, 1024) num_threads(T)
+    for (int64_t k = 0; k < g->nnz; ++k)
+      for (int64_t p = g->ptr[k]; p < g->ptr[k + 1]; ++p) inv[g->order[p]] = k;
+  }
+  return 0;
+}
+
+void pcdh_group_free(pcdh_group g) { delete g; }
+
+// ------------------------------------------------------ sub-matrix extraction
+int pcdh_extract_count(int64_t nr, const int32_t* rows, const int32_t* rowptr,
+                       const int32_t* col, const int32_t* colmap, int32_t* orp) {
+  if (nr < 0 || !rows || !rowptr || !col || !colmap || !orp)
+    return fail(PCDH_ERR_ARG, "extract_count: bad arguments");
+  const int T = nthreads();
+  orp[0] = 0;
+#pragma omp parallel for schedule(static, 4096) num_threads(T)
+  for (int64_t i = 0; i < nr; ++i) {
+    int32_t c = 0;
+    for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k) c += colmap[col[k]] >= 0;
+    orp[i + 1] = c;
+  }
+  int64_t run = 0;
+  for (int64_t i = 0; i < nr; ++i) {
+    run += orp[i + 1];
+    if (run > INT32_MAX) return fail(PCDH_ERR_ARG, "extract_count: block exceeds int32 indexing");
+    orp[i + 1] = (int32_t)run;
+  }
+  return 0;
+}
+
+int pcdh_extract_fill(int64_t nr, const int32_t* rows, const int32_t* rowptr,
+                      const int32_t* col, const int32_t* colmap, const int32_t* orp,
+                      int32_t* oc, int64_t* osrc) {
+  if (nr < 0 || !rows || !rowptr || !col || !colmap || !orp || (orp[nr] && (!oc || !osrc)))
+    return fail(PCDH_ERR_ARG, "extract_fill: bad arguments");
+  const int T = nthreads();
+#pragma omp parallel num_threads(T)
+  {
+    std::vector<std::pair<int32_t, int64_t>> tmp;
+#pragma omp for schedule(static, 4096)
+    for (int64_t i = 0; i < nr; ++i) {
+      tmp.clear();
+      bool sorted = true;
+      for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k) {
+        const int32_t c = colmap[col[k]];
+        if (c < 0) continue;
+        if (!tmp.empty() && c < tmp.back().first) sorted = false;
+        tmp.emplace_back(c, (int64_t)k);
+      }
+      if (!sorted) std::sort(tmp.begin(), tmp.end());
+      int64_t q = orp[i];
+      for (auto& t : tmp) { oc[q] = t.first; osrc[q] = t.second; ++q; }
+    }
+  }
+  return 0;
+}
+
+// -------------------------------------------------------------------- transpose
+int pcdh_transpose(int64_t nr, int64_t nc, const int32_t* rp, const int32_t* ci,
+                   const double* va, int32_t* trp, int32_t* tc, double* tv) {
+  if (nr < 0 || nc < 0 || !rp || !trp || (rp[nr] && (!ci || !tc)))
+    return fail(PCDH_ERR_ARG, "transpose: bad arguments");
+  const int64_t nnz = rp[nr];
+  for (int64_t c = 0; c <= nc; ++c) trp[c] = 0;
+  for (int64_t k = 0; k < nnz; ++k) {
+    if (ci[k] < 0 || ci[k] >= nc) return fail(PCDH_ERR_ARG, "transpose: column outside [0, %lld)", (long long)nc);
+    ++trp[ci[k] + 1];
+  }
+  for (int64_t c = 0; c < nc; ++c) trp[c + 1] += trp[c];
+  std::vector<int32_t> fill(trp, trp + nc);
+  for (int64_t i = 0; i < nr; ++i)
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+      const int32_t q = fill[ci[k]]++;
+      tc[q] = (int32_t)i;
+      if (va && tv) tv[q] = va[k];
+    }
+  return 0;
+}
+
+// ----------------------------------------------------------------------- SpGEMM
+int pcdh_spgemm_count(int64_t row0, int64_t row1, int64_t b_cols,
+                      const int32_t* arp, const int32_t* ac, const int32_t* brp,
+                      const int32_t* bc, int64_t* crp) {
+  if (row0 < 0 || row1 < row0 || b_cols < 0 || !arp || !brp || !crp)
+    return fail(PCDH_ERR_ARG, "spgemm_count: bad arguments");
+  const int T = nthreads();
+  crp[0] = 0;
+#pragma omp parallel num_threads(T)
+  {
+    std::vector<int32_t> mark(b_cols, -1);
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = row0; i < row1; ++i) {
+      int64_t cnt = 0;
+      for (int32_t k = arp[i]; k < arp[i + 1]; ++k) {
+        const int32_t j = ac[k];
+        for (int32_t q = brp[j]; q < brp[j + 1]; ++q)
+          if (mark[bc[q]] != (int32_t)(i - row0)) { mark[bc[q]] = (int32_t)(i - row0); ++cnt; }
+      }
+      crp[i - row0 + 1] = cnt;
+    }
+  }
+  for (int64_t i = 0; i < row1 - row0; ++i) crp[i + 1] += crp[i];
+  return 0;
+}
+
+int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols, const int32_t* arp,
+                     const int32_t* ac, const double* av, const int32_t* brp,
+                     const int32_t* bc, const double* bv, const int64_t* crp,
+                     int32_t* cc, double* cv) {
+  if (row0 < 0 || row1 < row0 || !arp || !brp || !crp || (crp[row1 - row0] && (!cc || !cv)))
+    return fail(PCDH_ERR_ARG, "spgemm_fill: bad arguments");
+  const int T = nthreads();
+#pragma omp parallel num_threads(T)
+  {
+    std::vector<int64_t> where(b_cols, -1);     // column -> slot of the current row
+    std::vector<std::pair<int32_t, double>> rowbuf;
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = row0; i < row1; ++i) {
+      const int64_t base = crp[i - row0];
+      int64_t fillp = base;
+      for (int32_t k = arp[i]; k < arp[i + 1]; ++k) {
+        const int32_t j = ac[k];
+        const double a = av ? av[k] : 1.0;
+        for (int32_t q = brp[j]; q < brp[j + 1]; ++q) {
+          const int32_t c = bc[q];
+          const double v = a * (bv ? bv[q] : 1.0);
+          if (where[c] < base) { where[c] = fillp; cc[fillp] = c; cv[fillp] = v; ++fillp; }
+          else cv[where[c]] += v;
+        }
+      }
+      // sort the row by column (accumulation order per entry stays k-major)
+      const int64_t len = fillp - base;
+      rowbuf.resize(len);
+      for (int64_t p = 0; p < len; ++p) rowbuf[p] = {cc[base + p], cv[base + p]};
+      std::sort(rowbuf.begin(), rowbuf.end(),
+                [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) { return x.first < y.first; });
+      for (int64_t p = 0; p < len; ++p) { cc[base + p] = rowbuf[p].first; cv[base + p] = rowbuf[p].second; where[rowbuf[p].first] = -1; }
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

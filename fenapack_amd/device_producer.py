@@ -41,10 +41,17 @@ def _contribution_plan(inv, ncells, nloc2, nnz):
     values ``f_src[f_ptr[k]:f_ptr[k+1]]``; element storage is component-major
     (``ab * ncells + cell``), contributions in ascending cell order (the order
     ``numpy.bincount`` adds them on the host)."""
+    from . import _host
     inv = np.asarray(inv).ravel()
-    order = np.argsort(inv, kind="stable")
-    ptr = np.zeros(nnz + 1, dtype=np.int64)
-    np.cumsum(np.bincount(inv, minlength=nnz), out=ptr[1:])
+    if _host.use_numpy():
+        order = np.argsort(inv, kind="stable")
+        ptr = np.zeros(nnz + 1, dtype=np.int64)
+        np.cumsum(np.bincount(inv, minlength=nnz), out=ptr[1:])
+    else:
+        g = _host.group_pairs(inv, None, nnz)      # stable counting sort
+        gptr, order = g.members()
+        ptr = gptr[g.indptr]                       # (slots without members: empty)
+        g.release()
     cell, ab = np.divmod(order, nloc2)
     src = ab * ncells + cell
     assert src.size < 2 ** 31
@@ -62,14 +69,23 @@ def _expand_by_rows(P, row_of):
     return rep, P.indptr[row_of[rep]].astype(np.int64) + off
 
 
-def _group(key, nkeys_hint=None):
-    """Unique sorted keys + CSR-of-members (stable: members keep input order)."""
-    ukey, inv = np.unique(key, return_inverse=True)
-    inv = inv.ravel()
-    order = np.argsort(inv, kind="stable")
-    ptr = np.zeros(ukey.size + 1, dtype=np.int64)
-    np.cumsum(np.bincount(inv, minlength=ukey.size), out=ptr[1:])
-    return ukey, ptr, order
+def _group(rows, cols, nrows, ncols):
+    """Distinct (row, col) pairs in CSR order + CSR-of-members (stable:
+    members keep input order).  Returns (urows, ucols, ptr, order)."""
+    from . import _host
+    if _host.use_numpy():
+        ukey, inv = np.unique(rows * ncols + cols, return_inverse=True)
+        inv = inv.ravel()
+        order = np.argsort(inv, kind="stable")
+        ptr = np.zeros(ukey.size + 1, dtype=np.int64)
+        np.cumsum(np.bincount(inv, minlength=ukey.size), out=ptr[1:])
+        return ukey // ncols, ukey % ncols, ptr, order
+    g = _host.group_pairs(rows, cols, nrows)
+    ptr, order = g.members()
+    urows = np.repeat(np.arange(nrows, dtype=np.int64), np.diff(g.indptr))
+    ucols = g.ucols
+    g.release()
+    return urows, ucols, ptr, order
 
 
 def block_positions(A, indptr_f, indices_f, d):
@@ -131,23 +147,21 @@ def galerkin_plan(rows_f, cols_f, P):
                          "-pc_mg_galerkin none" % est)
     # B = F P: entry (i, J) collects F[i, j] * P[j, J]
     k_rep, pidx = _expand_by_rows(P, cols_f)
-    key = rows_f[k_rep] * ncoarse + P.indices[pidx]
-    ukey, b_ptr, order = _group(key)
+    rows_b, cols_b, b_ptr, order = _group(
+        rows_f[k_rep], P.indices[pidx].astype(np.int64), P.shape[0], ncoarse)
     b_src, b_w = k_rep[order], P.data[pidx][order]
-    rows_b, cols_b = ukey // ncoarse, ukey % ncoarse
-    del key, k_rep, pidx, order
+    del k_rep, pidx, order
     # F_c = P^T B: entry (I, J) collects P[i, I] * B[i, J]
     e_rep, pidx = _expand_by_rows(P, rows_b)
     if e_rep.size > MAX_GALERKIN_PAIRS:
         raise ValueError("Galerkin plan of %d pairs exceeds the limit; use "
                          "-pc_mg_galerkin none" % e_rep.size)
-    key = P.indices[pidx].astype(np.int64) * ncoarse + cols_b[e_rep]
-    ukey, c_ptr, order = _group(key)
+    rows_c, cols_c, c_ptr, order = _group(
+        P.indices[pidx].astype(np.int64), cols_b[e_rep], ncoarse, ncoarse)
     c_src, c_w = e_rep[order], P.data[pidx][order]
-    rows_c, cols_c = ukey // ncoarse, ukey % ncoarse
     indptr = np.zeros(ncoarse + 1, dtype=np.int64)
     np.cumsum(np.bincount(rows_c, minlength=ncoarse), out=indptr[1:])
-    assert b_src.size < 2 ** 31 and ukey.size < 2 ** 31
+    assert b_src.size < 2 ** 31 and cols_c.size < 2 ** 31
     return (b_ptr, b_src.astype(np.int32), b_w, c_ptr, c_src.astype(np.int32),
             c_w, indptr.astype(np.int32), cols_c.astype(np.int32))
 
@@ -388,7 +402,8 @@ class DeviceProducer(object):
             cols = np.repeat(pd[:, None, :], 2, axis=1).ravel()
             where = pat.locate(rows, cols)           # (e, i, j) -> Kp entry
             e_idx, ij = np.divmod(np.arange(where.size), 4)
-            aff_pos, aff_ptr, order = _group(where)
+            aff_pos, _, aff_ptr, order = _group(
+                where, np.zeros_like(where), pat.nnz, 1)
             self.eng.fe_bind_robin(pl["nodes"].T, pl["normal"].T,
                                    pl["length"], aff_pos, aff_ptr,
                                    (ij * nb + e_idx)[order],

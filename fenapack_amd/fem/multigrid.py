@@ -76,13 +76,30 @@ class CubeHierarchy(MeshHierarchy):
 
 
 def _unique_entries(rows, cols, vals, shape):
-    key = rows.ravel().astype(np.int64) * shape[1] + cols.ravel()
-    u, idx = np.unique(key, return_index=True)
-    v = vals.ravel()[idx]
+    """CSR of the distinct (row, col) entries; the value of the FIRST
+    occurrence is kept (every occurrence of a prolongation weight carries the
+    same number), entries below 1e-14 are dropped."""
+    from .. import _host
+    if _host.use_numpy():
+        key = rows.ravel().astype(np.int64) * shape[1] + cols.ravel()
+        u, idx = np.unique(key, return_index=True)
+        v = vals.ravel()[idx]
+        keep = np.abs(v) > 1e-14
+        P = sp.csr_matrix((v[keep], (u[keep] // shape[1], u[keep] % shape[1])),
+                          shape=shape)
+        P.sort_indices()
+        return P
+    g = _host.group_pairs(rows, cols, shape[0])
+    ptr, order = g.members()
+    v = vals.ravel()[order[ptr[:-1]]]
     keep = np.abs(v) > 1e-14
-    P = sp.csr_matrix((v[keep], (u[keep] // shape[1], u[keep] % shape[1])),
+    urow = np.repeat(np.arange(shape[0], dtype=np.int64), np.diff(g.indptr))
+    indptr = np.zeros(shape[0] + 1, dtype=np.int32)
+    np.cumsum(np.bincount(urow[keep], minlength=shape[0]), out=indptr[1:])
+    P = sp.csr_matrix((v[keep], g.ucols[keep].astype(np.int32), indptr),
                       shape=shape)
-    P.sort_indices()
+    P.has_sorted_indices = True
+    g.release()
     return P
 
 

@@ -104,48 +104,120 @@ def _p2_basis(lam, edges=((1, 2), (2, 0), (0, 1))):
 
 
 class FixedPattern(object):
-    """CSR sparsity pattern assembled once; values refreshed by ``bincount``."""
+    """CSR sparsity pattern assembled once; values refreshed by ``bincount``.
+
+    The grouping of the element entries is native (``libpcd_host.so``,
+    ``pcdh_group_pairs`` / ``pcdh_pattern_cells``); the numpy route
+    (``numpy.unique``) is its checker (``FENAPACK_AMD_NUMPY_PRODUCER=1``)."""
 
     def __init__(self, rows, cols, shape):
+        from .. import _host
         rows = np.asarray(rows, dtype=np.int64).ravel()
         cols = np.asarray(cols, dtype=np.int64).ravel()
-        key = rows * shape[1] + cols
-        ukey, inv = np.unique(key, return_inverse=True)
         self.shape = shape
+        if _host.use_numpy():
+            key = rows * shape[1] + cols
+            ukey, inv = np.unique(key, return_inverse=True)
+            self.inv = inv.ravel()
+            self.nnz = ukey.size
+            urow = ukey // shape[1]
+            self.indices = (ukey % shape[1]).astype(np.int32)
+            self.indptr = np.zeros(shape[0] + 1, dtype=np.int32)
+            np.cumsum(np.bincount(urow, minlength=shape[0]),
+                      out=self.indptr[1:])
+            return
+        g = _host.group_pairs(rows, cols, shape[0])
+        self._from_group(g)
+
+    def _from_group(self, g):
+        self.nnz = g.nnz
+        self.indices = g.ucols.astype(np.int32)
+        self.indptr = g.indptr.astype(np.int32)
+        self.inv = g.inv
+        self._members = g.members()
+        g.release()
+
+    @classmethod
+    def from_cells(cls, rdofs, cdofs, shape):
+        """Pattern of a form from cell dof tables (ncell, nr) x (ncell, nc);
+        ``inv`` is laid out (cell, a, b)."""
+        from .. import _host
+        if _host.use_numpy():
+            nr, nc = rdofs.shape[1], cdofs.shape[1]
+            return cls(np.repeat(rdofs[:, :, None], nc, axis=2),
+                       np.repeat(cdofs[:, None, :], nr, axis=1), shape)
+        self = cls.__new__(cls)
+        self.shape = shape
+        self._from_group(_host.pattern_cells(rdofs, cdofs, shape[0]))
+        return self
+
+    @classmethod
+    def from_csr(cls, indptr, indices, inv, shape):
+        self = cls.__new__(cls)
+        self.shape = shape
+        self.indptr = np.asarray(indptr, dtype=np.int32)
+        self.indices = np.asarray(indices, dtype=np.int32)
+        self.nnz = self.indices.size
         self.inv = inv
-        self.nnz = ukey.size
-        self.keys = ukey
-        urow = ukey // shape[1]
-        self.indices = (ukey % shape[1]).astype(np.int32)
-        self.indptr = np.zeros(shape[0] + 1, dtype=np.int32)
-        np.cumsum(np.bincount(urow, minlength=shape[0]), out=self.indptr[1:])
-        self.rows = urow.astype(np.int32)
+        return self
+
+    @property
+    def rows(self):
+        if not hasattr(self, "_rows"):
+            self._rows = np.repeat(np.arange(self.shape[0], dtype=np.int32),
+                                   np.diff(self.indptr))
+        return self._rows
+
+    @property
+    def keys(self):
+        if not hasattr(self, "_keys"):
+            self._keys = self.rows.astype(np.int64) * self.shape[1] \
+                + self.indices
+        return self._keys
+
+    def members(self):
+        """(ptr, order): element entries of CSR slot k are
+        ``order[ptr[k]:ptr[k+1]]`` in ascending position (= the stable argsort
+        of ``inv``)."""
+        if getattr(self, "_members", None) is None:
+            inv = np.asarray(self.inv).ravel()
+            order = np.argsort(inv, kind="stable")
+            ptr = np.zeros(self.nnz + 1, dtype=np.int64)
+            np.cumsum(np.bincount(inv, minlength=self.nnz), out=ptr[1:])
+            self._members = (ptr, order)
+        return self._members
 
     @classmethod
     def from_unique(cls, rows, cols, shape):
-        """Pattern of entries known to be pairwise distinct: a counting sort
-        through scipy's COO -> CSR conversion instead of ``numpy.unique`` on
-        the keys (several times faster at 10^7 entries)."""
+        """Pattern of entries known to be pairwise distinct; ``order`` maps
+        CSR slot -> input position (assembly is a pure permutation)."""
+        from .. import _host
         rows = np.asarray(rows).ravel()
         cols = np.asarray(cols).ravel()
         n = rows.size
-        tag = sp.coo_matrix((np.arange(1, n + 1, dtype=np.float64),
-                             (rows, cols)), shape=shape).tocsr()
-        tag.sort_indices()
-        if tag.nnz != n:
-            raise ValueError("from_unique: duplicate entries")
         self = cls.__new__(cls)
         self.shape = shape
         self.nnz = n
-        order = tag.data.astype(np.int64) - 1          # CSR slot -> input
+        if _host.use_numpy():
+            tag = sp.coo_matrix((np.arange(1, n + 1, dtype=np.float64),
+                                 (rows, cols)), shape=shape).tocsr()
+            tag.sort_indices()
+            if tag.nnz != n:
+                raise ValueError("from_unique: duplicate entries")
+            order = tag.data.astype(np.int64) - 1      # CSR slot -> input
+            self.indices = tag.indices.astype(np.int32)
+            self.indptr = tag.indptr.astype(np.int32)
+        else:
+            g = _host.group_pairs(rows, cols, shape[0])
+            if g.nnz != n:
+                raise ValueError("from_unique: duplicate entries")
+            order = g.members()[1]
+            self.indices = g.ucols.astype(np.int32)
+            self.indptr = g.indptr.astype(np.int32)
+            g.release()
         self.inv = np.empty(n, dtype=np.int64)
         self.inv[order] = np.arange(n)
         self.order = order
-        self.indices = tag.indices.astype(np.int32)
-        self.indptr = tag.indptr.astype(np.int32)
-        self.rows = np.repeat(np.arange(shape[0], dtype=np.int32),
-                              np.diff(self.indptr))
-        self.keys = self.rows.astype(np.int64) * shape[1] + self.indices
         return self
 
     def assemble(self, vals):
@@ -165,6 +237,17 @@ class FixedPattern(object):
         pos = np.searchsorted(self.keys, key)
         assert np.all(self.keys[pos] == key), "entry outside the pattern"
         return pos
+
+
+def _kron_rows(S, d, per_row):
+    """Row pointer of the pattern whose row ``d*i + k`` holds ``per_row``
+    entries for every entry of row ``i`` of the scalar pattern ``S``; also
+    returns (row length, row start) of ``S`` per scalar entry's row."""
+    ip = S.indptr.astype(np.int64)
+    ln = np.diff(ip)
+    indptr = np.zeros(d * ln.size + 1, dtype=np.int64)
+    np.cumsum(np.repeat(ln * per_row, d), out=indptr[1:])
+    return indptr, ln, ip
 
 
 class TaylorHood(object):
@@ -227,14 +310,13 @@ class TaylorHood(object):
             qp, qw = _QP2, _QW2
         else:
             qp, qw = _tet_rule(3)
-        self.phi, dphi = _p2_basis(qp, self.local_edges)       # (nq, na)
-        self.gphi = np.einsum('qak,ckd->cqad', dphi, g)         # (nc,nq,na,d)
+        self.phi, self._dphi = _p2_basis(qp, self.local_edges)  # (nq, na)
+        self._qw = qw
         # the streamline-diffusion term with a P2 wind has degree 6 (FFC
         # would pick a degree-6 scheme for it): its own rule, exact to 7
         self.qp_s, self.qw_s = _conical_rule(d, 4)
         self.phi_s, self.dphi_s = _p2_basis(self.qp_s, self.local_edges)
         self.psi = qp                                           # (nq, d+1)
-        self.wq = qw[None, :] * self.area[:, None]              # (nc, nq)
         edges = [np.linalg.norm(p[:, i] - p[:, j], axis=1)
                  for i in range(d + 1) for j in range(i)]
         self.cell_hmax = np.maximum.reduce(edges)
@@ -244,12 +326,137 @@ class TaylorHood(object):
         else:
             self.cell_h = self.cell_hmax
 
+    @property
+    def gphi(self):
+        """Physical basis gradients at the quadrature points, (nc, nq, na, d).
+        Large (20 GB at 3 M tetrahedra): the operators below are assembled
+        from reference tensors instead; this array is built on demand for the
+        terms that still integrate point by point (SUPG, Newton, tests)."""
+        if not hasattr(self, "_gphi"):
+            self._gphi = np.einsum('qak,ckd->cqad', self._dphi, self.gradlam)
+        return self._gphi
+
+    @property
+    def wq(self):
+        """Quadrature weights times cell measure, (nc, nq)."""
+        return self._qw[None, :] * self.area[:, None]
+
+    def _ref(self):
+        """Reference-cell tensors of the fixed forms.  On an affine simplex
+        every element matrix of this module is a contraction of a few
+        geometric numbers per cell (``grad lam_k . grad lam_l``,
+        ``U_m . grad lam_k``) with one of these constant tensors - one GEMM
+        per operator instead of a loop over quadrature points.  They are
+        integrated with the same rules as the point-wise forms (exact for
+        these polynomial degrees), so both routes agree to round-off."""
+        if hasattr(self, "_ref_cache"):
+            return self._ref_cache
+        qw, phi, dphi, psi = self._qw, self.phi, self._dphi, self.psi
+        R = {
+            # M[a,b] = int phi_a phi_b
+            "M": np.einsum('q,qa,qb->ab', qw, phi, phi),
+            # K[k,l,a,b] = int d_k phi_a d_l phi_b
+            "K": np.einsum('q,qak,qbl->klab', qw, dphi, dphi),
+            # C[m,k,a,b] = int phi_m phi_a d_k phi_b
+            "C": np.einsum('q,qm,qa,qbk->mkab', qw, phi, phi, dphi),
+            # B[l,a,j] = int psi_j d_l phi_a
+            "B": np.einsum('q,qj,qal->laj', qw, psi, dphi),
+            # P[i,j] = int psi_i psi_j ; S[m,i] = int phi_m psi_i
+            "P": np.einsum('q,qi,qj->ij', qw, psi, psi),
+            "S": np.einsum('q,qm,qi->mi', qw, phi, psi),
+        }
+        self._ref_cache = R
+        return R
+
     # ------------------------------------------------------------- patterns
     def _patterns(self, coupled):
-        """Fixed sparsity patterns in fieldsplit-local numbering."""
+        """Fixed sparsity patterns in fieldsplit-local numbering.
+
+        Only the SCALAR patterns are grouped (P2 x P2, P2 x P1, P1 x P2,
+        P1 x P1: ``pcdh_pattern_cells`` on the cell dof tables); the velocity
+        patterns are their Kronecker expansions - row ``d*i + k`` of the
+        block copies row ``i`` of the scalar pattern - so the element -> entry
+        maps follow by arithmetic instead of a sort of ``d`` (or ``d^2``)
+        times as many keys."""
         key = "_pat_%d" % int(coupled)
         if hasattr(self, key):
             return getattr(self, key)
+        from .. import _host
+        if _host.use_numpy():
+            pat = self._patterns_numpy(coupled)
+            setattr(self, key, pat)
+            return pat
+        d, na, nvl = self.dim, self.na, self.nvl
+        d2, d1 = self.cell_dofs2, self.cell_dofs1
+        other = getattr(self, "_pat_%d" % int(not coupled), None)
+        pat = {}
+        if other is not None:
+            for k in ("A01", "A10", "PP", "SS"):
+                pat[k] = other[k]
+        else:
+            pat["SS"] = FixedPattern.from_cells(d2, d2, (self.nn, self.nn))
+            pat["PP"] = FixedPattern.from_cells(d1, d1, (self.n_p, self.n_p))
+        SS = pat["SS"]
+        comp = np.arange(d, dtype=np.int64)
+        invS = SS.inv.reshape(-1, na, na)
+        rowS = SS.rows[invS].astype(np.int64)              # scalar row
+        if coupled:
+            # row d*i+k: entries (j, e) sorted by d*j + e
+            indptr, ln, ip = _kron_rows(SS, d, d)
+            base = d * d * ip[rowS] + d * (invS - ip[rowS])
+            inv = (base[..., None, None]
+                   + (comp[:, None] * d) * ln[rowS][..., None, None]
+                   + comp[None, :])
+            idx = (d * SS.indices.astype(np.int64)[:, None] + comp).ravel()
+            # indices of row d*i+k = d*cols(i) + e, identical for every k
+            seg = np.repeat(np.arange(ln.size, dtype=np.int64), d)
+            starts = d * ip[seg]
+            lens = d * ln[seg]
+            off = np.arange(indptr[-1], dtype=np.int64) \
+                - np.repeat(indptr[:-1], lens)
+            indices = idx[np.repeat(starts, lens) + off]
+        else:
+            indptr, ln, ip = _kron_rows(SS, d, 1)
+            inv = (invS + (d - 1) * ip[rowS])[..., None] \
+                + comp * ln[rowS][..., None]
+            seg = np.repeat(np.arange(ln.size, dtype=np.int64), d)
+            lens = ln[seg]
+            off = np.arange(indptr[-1], dtype=np.int64) \
+                - np.repeat(indptr[:-1], lens)
+            src = np.repeat(ip[seg], lens) + off
+            kk = np.repeat(np.tile(comp, ln.size), lens)
+            indices = d * SS.indices.astype(np.int64)[src] + kk
+        pat["A00"] = FixedPattern.from_csr(indptr, indices, inv.ravel(),
+                                           (self.n_u, self.n_u))
+        if other is None:
+            # A01: rows (a, k) -> d*node + k, cols j; inv laid out (c, a, j, k)
+            G = FixedPattern.from_cells(d2, d1, (self.nn, self.n_p))
+            indptr, ln, ip = _kron_rows(G, d, 1)
+            invG = G.inv.reshape(-1, na, nvl)
+            rowG = G.rows[invG].astype(np.int64)
+            inv = (invG + (d - 1) * ip[rowG])[..., None] \
+                + comp * ln[rowG][..., None]
+            seg = np.repeat(np.arange(ln.size, dtype=np.int64), d)
+            lens = ln[seg]
+            off = np.arange(indptr[-1], dtype=np.int64) \
+                - np.repeat(indptr[:-1], lens)
+            indices = G.indices[np.repeat(ip[seg], lens) + off]
+            pat["A01"] = FixedPattern.from_csr(indptr, indices, inv.ravel(),
+                                               (self.n_u, self.n_p))
+            # A10: rows j, cols d*node + k; inv laid out (c, a, j, k) as well
+            Gt = FixedPattern.from_cells(d1, d2, (self.n_p, self.nn))
+            invT = Gt.inv.reshape(-1, nvl, na).transpose(0, 2, 1)
+            inv = d * invT[..., None] + comp
+            indices = (d * Gt.indices.astype(np.int64)[:, None] + comp).ravel()
+            pat["A10"] = FixedPattern.from_csr(
+                d * Gt.indptr.astype(np.int64), indices,
+                np.ascontiguousarray(inv).ravel(), (self.n_p, self.n_u))
+        setattr(self, key, pat)
+        return pat
+
+    def _patterns_numpy(self, coupled):
+        """The numpy route (checker of the native one): every pattern from
+        the explicit (row, col) pairs of its element entries."""
         d, na, nvl = self.dim, self.na, self.nvl
         d2, d1 = self.cell_dofs2, self.cell_dofs1
         r2 = np.repeat(d2[:, :, None], na, axis=2)    # (nc,na,na) row = a
@@ -276,7 +483,6 @@ class TaylorHood(object):
         c1 = np.repeat(d1[:, None, :], nvl, axis=1)
         pat["PP"] = FixedPattern(r1, c1, (self.n_p, self.n_p))
         pat["SS"] = FixedPattern(r2, c2, (self.nn, self.nn))
-        setattr(self, key, pat)
         return pat
 
     # ----------------------------------------------------- scalar P2 pieces
@@ -289,14 +495,35 @@ class TaylorHood(object):
         return w, gw
 
     def p2_stiffness_cells(self):
-        return np.einsum('cq,cqad,cqbd->cab', self.wq, self.gphi, self.gphi)
+        g, na, nvl = self.gradlam, self.na, self.nvl
+        gg = np.einsum('ckd,cld->ckl', g, g) * self.area[:, None, None]
+        K = gg.reshape(-1, nvl * nvl) @ self._ref()["K"].reshape(nvl * nvl, -1)
+        return K.reshape(-1, na, na)
 
     def p2_mass_cells(self):
-        return np.einsum('cq,qa,qb->cab', self.wq, self.phi, self.phi)
+        return self.area[:, None, None] * self._ref()["M"][None]
 
     def p2_convection_cells(self, w):
+        """((w.grad) phi_b, phi_a) from the wind at the quadrature points
+        (point-wise route; the assembler uses ``p2_convection_nodal``)."""
         wg = np.einsum('cqd,cqbd->cqb', w, self.gphi)           # w.grad phi_b
         return np.einsum('cq,qa,cqb->cab', self.wq, self.phi, wg)
+
+    def p2_convection_nodal(self, U):
+        """The same element matrices from the nodal P2 wind ``U`` (nn, d):
+        ``C_c = sum_{m,k} |T| (U_m . grad lam_k) Chat[m,k]``."""
+        na, nvl = self.na, self.nvl
+        ug = np.einsum('cmd,ckd->cmk', U[self.cell_dofs2], self.gradlam)
+        ug *= self.area[:, None, None]
+        C = ug.reshape(-1, na * nvl) @ self._ref()["C"].reshape(na * nvl, -1)
+        return C.reshape(-1, na, na)
+
+    def _a01_cells(self):
+        """vals[c, a, j, comp] = -int psi_j d_comp phi_a."""
+        B = self._ref()["B"]                                    # (l, a, j)
+        v = np.einsum('cld,laj->cajd', self.gradlam, B)
+        v *= -self.area[:, None, None, None]
+        return v
 
     def p2_supg_cells(self, U, delta):
         """delta * (w.grad u, w.grad v): streamline diffusion added to the
@@ -319,8 +546,7 @@ class TaylorHood(object):
         if idt:
             S = S + idt * self.p2_mass_cells()
         if U is not None:
-            w, gw = self.wind_at_qp(U)
-            S = S + self.p2_convection_cells(w)
+            S = S + self.p2_convection_nodal(U)
             if delta is not None:
                 S = S + self.p2_supg_cells(U, delta)
         if not newton:
@@ -331,6 +557,7 @@ class TaylorHood(object):
             vals[..., k, k] = S
         if U is not None:
             # N[(a,c),(b,e)] = int phi_a phi_b d_e w_c
+            _, gw = self.wind_at_qp(U)
             N = np.einsum('cq,qa,qb,cqkd->cabkd', self.wq, self.phi, self.phi,
                           gw)
             vals += N
@@ -346,20 +573,18 @@ class TaylorHood(object):
         """Discrete gradient block from ``-p div v`` (rows velocity)."""
         pat = self._patterns(False)["A01"]
         # vals[c, a, j, comp] = -int psi_j d_comp phi_a
-        vals = -np.einsum('cq,qj,cqak->cajk', self.wq, self.psi, self.gphi)
-        return pat.assemble(vals)
+        return pat.assemble(self._a01_cells())
 
     def assemble_A10(self):
         """Divergence block from ``-q div u`` (rows pressure) = A01^T."""
         pat = self._patterns(False)["A10"]
-        vals = -np.einsum('cq,qj,cqak->cajk', self.wq, self.psi, self.gphi)
-        return pat.assemble(vals)
+        return pat.assemble(self._a01_cells())
 
     # ------------------------------------------------------------- pressure
     def assemble_Mp(self, scale):
         pat = self._patterns(False)["PP"]
-        return pat.assemble(scale * np.einsum('cq,qi,qj->cij', self.wq,
-                                              self.psi, self.psi))
+        return pat.assemble((scale * self.area)[:, None, None]
+                            * self._ref()["P"][None])
 
     def assemble_Ap(self):
         pat = self._patterns(False)["PP"]
@@ -372,12 +597,13 @@ class TaylorHood(object):
         [- (1/nu) int_{robin_edges} (w.n) p q ds]  (BRM2 boundary term,
         demo_navier-stokes-pcd.py:131-135)."""
         pat = self._patterns(False)["PP"]
-        w, _ = self.wind_at_qp(U)
-        wg = np.einsum('cqd,cjd->cqj', w, self.gradlam)         # w.grad psi_j
-        vals = np.einsum('cq,qi,cqj->cij', self.wq, self.psi, wg) / nu
+        # vals[c,i,j] = |T| sum_m (U_m . grad lam_j) int psi_i phi_m / nu
+        ug = np.einsum('cmd,cjd->cmj', U[self.cell_dofs2], self.gradlam)
+        vals = np.einsum('mi,cmj->cij', self._ref()["S"], ug) \
+            * (self.area / nu)[:, None, None]
         if idt:
-            vals = vals + (idt / nu) * np.einsum('cq,qi,qj->cij', self.wq,
-                                                 self.psi, self.psi)
+            vals = vals + (idt / nu) * self.area[:, None, None] \
+                * self._ref()["P"][None]
         K = pat.assemble(vals)
         if robin_edges is not None and len(robin_edges):
             R = self._boundary_flux_mass(U, robin_edges)

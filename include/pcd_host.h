@@ -1,0 +1,121 @@
+/* pcd_host.h - C ABI of libpcd_host.so: the host-side (OpenMP) set-up helpers
+ * of the MI355X PCD engine.
+ *
+ * Everything here is INTEGER work of problem set-up: sparsity patterns,
+ * element -> entry contribution lists, prolongation patterns, Galerkin
+ * gather plans, the fieldsplit sub-matrix extraction.  The floating-point
+ * work of set-up runs on the device (pcd_fe_* in pcd_engine.h) or as GEMMs
+ * over reference tensors in the Python producer; the hot path never comes
+ * here.  No HIP dependency: the library loads and is tested on a box without
+ * a GPU.
+ *
+ * What it replaces in the reference: the reference delegates set-up to
+ * DOLFIN's SystemAssembler / PETSc's MatCreateSubMatrix / MatPtAP
+ * (fenapack/field_split_backend.py:230-263, 285-291, 311-342;
+ * fenapack/assembling.py:151-180); on the partitioned path every rank only
+ * ever touches its owned rows (fenapack/SubfieldBC.h:136-155) - the
+ * `row0/row1` arguments below are that restriction.
+ *
+ * All functions return 0 on success, a PCDH_ERR_* code otherwise;
+ * pcdh_last_error() gives the message.  Nothing throws across the ABI.
+ */
+#ifndef PCD_HOST_H
+#define PCD_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCDH_ERR_ARG 1
+#define PCDH_ERR_NOMEM 2
+#define PCDH_ERR_STATE 3
+
+const char* pcdh_last_error(void);
+/* OpenMP threads the helpers use (0: the runtime's default) */
+int pcdh_set_threads(int nthreads);
+int pcdh_get_threads(void);
+
+/* ---- grouping of (row, col) pairs -------------------------------------------
+ * The one primitive behind every pattern of the producer: n pairs with
+ * 0 <= rows[i] < nrows and cols[i] >= 0 are grouped by (row, col), groups
+ * ordered by row then col, members of a group in ascending input position
+ * (the order numpy.bincount adds element contributions on the host and the
+ * device gather kernels add them in HBM: bitwise reproducible assembly).
+ * Only rows in [row0, row1) are kept (rank-local set-up: owned rows only);
+ * pairs of other rows get inv = -1.
+ *
+ * Replaces numpy.unique(keys, return_inverse=True) + stable argsort in the
+ * Python producer (fem/taylor_hood.py FixedPattern, device_producer._group /
+ * _contribution_plan, fem/multigrid._unique_entries, fem/mesh edge tables).
+ */
+typedef struct pcdh_group_s* pcdh_group;
+
+int pcdh_group_pairs(int64_t n, const int64_t* rows, const int64_t* cols,
+                     int64_t nrows, int64_t row0, int64_t row1,
+                     pcdh_group* out);
+/* number of distinct (row, col) groups / of kept input pairs */
+int64_t pcdh_group_nnz(pcdh_group g);
+int64_t pcdh_group_kept(pcdh_group g);
+/* Any output may be NULL.  indptr[row1 - row0 + 1]: CSR row pointer of the
+ * kept rows; ucols[nnz]: column of every group; inv[n]: group of every input
+ * pair (-1: row outside [row0, row1)); ptr[nnz + 1], order[kept]: members of
+ * group k are order[ptr[k] .. ptr[k+1]) in ascending input position. */
+int pcdh_group_export(pcdh_group g, int64_t* indptr, int64_t* ucols,
+                      int64_t* inv, int64_t* ptr, int64_t* order);
+void pcdh_group_free(pcdh_group g);
+
+/* ---- element -> entry maps from cell dof tables ------------------------------
+ * Pattern of a bilinear form on a mesh: cell c couples its `nr` row dofs
+ * rdofs[c*nr + a] with its `nc` column dofs cdofs[c*nc + b].  Same outputs as
+ * pcdh_group_pairs on the ncell*nr*nc pairs (a-major, b-minor within a cell),
+ * without materialising them.
+ */
+int pcdh_pattern_cells(int64_t ncell, int nr, const int64_t* rdofs, int nc,
+                       const int64_t* cdofs, int64_t nrows, int64_t row0,
+                       int64_t row1, pcdh_group* out);
+
+/* ---- fieldsplit sub-matrix extraction -----------------------------------------
+ * [ext PETSc] MatCreateSubMatrix(A, isrow, iscol) with value provenance, the
+ * host half of pcd_set_system (field_split_backend.py:311-342): rows
+ * `rows[0..nr)` of the CSR (rowptr, col), columns renumbered through
+ * colmap[] (-1: dropped), entries of a row sorted by the new column;
+ * src[k] = position of entry k in the caller's value array.
+ * Two calls: counts (orp) first, then the fill.
+ */
+int pcdh_extract_count(int64_t nr, const int32_t* rows, const int32_t* rowptr,
+                       const int32_t* col, const int32_t* colmap,
+                       int32_t* out_rowptr /* nr + 1 */);
+int pcdh_extract_fill(int64_t nr, const int32_t* rows, const int32_t* rowptr,
+                      const int32_t* col, const int32_t* colmap,
+                      const int32_t* out_rowptr, int32_t* out_col,
+                      int64_t* out_src);
+
+/* ---- CSR transpose (restriction = prolongation^T) ---------------------------- */
+int pcdh_transpose(int64_t nr, int64_t nc, const int32_t* rowptr,
+                   const int32_t* col, const double* val, int32_t* t_rowptr,
+                   int32_t* t_col, double* t_val);
+
+/* ---- fixed-pattern sparse product C = A B ------------------------------------
+ * Symbolic + numeric row-wise SpGEMM (Gustavson, one dense marker per
+ * thread), columns of every output row sorted.  Two calls: counts, then fill.
+ * The Galerkin operators P^T (A P) of the multigrid hierarchies
+ * ([ext PETSc] MatPtAP; fem/multigrid.galerkin_chain).  Rows [row0, row1) of A
+ * only (rank-local set-up).  Entries that cancel to an exact zero are KEPT:
+ * the pattern is structural, so later value refreshes fit it.
+ */
+int pcdh_spgemm_count(int64_t row0, int64_t row1, int64_t b_cols,
+                      const int32_t* a_rowptr, const int32_t* a_col,
+                      const int32_t* b_rowptr, const int32_t* b_col,
+                      int64_t* c_rowptr /* row1 - row0 + 1 */);
+int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols,
+                     const int32_t* a_rowptr, const int32_t* a_col,
+                     const double* a_val, const int32_t* b_rowptr,
+                     const int32_t* b_col, const double* b_val,
+                     const int64_t* c_rowptr, int32_t* c_col, double* c_val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
