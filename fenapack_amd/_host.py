@@ -72,6 +72,11 @@ def library():
                                    ctypes.c_int64, _I32P, _I32P, _F64P, _I32P,
                                    _I32P, _F64P, _I64P, _I32P, _F64P]
     L.pcdh_set_threads.argtypes = [ctypes.c_int]
+    PP32 = ctypes.POINTER(_I32P)
+    L.pcdh_union_count.argtypes = [ctypes.c_int64, ctypes.c_int, _I64P, PP32,
+                                   PP32, _I64P]
+    L.pcdh_union_fill.argtypes = [ctypes.c_int64, ctypes.c_int, _I64P, PP32,
+                                  PP32, PP32, PP32, _I64P, _I64P, _I32P, _I64P]
     _lib = L
     nt = os.environ.get("FENAPACK_AMD_HOST_THREADS")
     if nt:
@@ -234,3 +239,32 @@ def transpose(A):
     T = sp.csr_matrix((tv, tc, trp), shape=(nc, nr))
     T.has_sorted_indices = True
     return T
+
+
+def union_blocks(n, blocks):
+    """Pattern of the union of index-mapped CSR blocks.  ``blocks``: list of
+    ``(rowmap, colmap, indptr, indices)``; returns ``(indptr, indices,
+    order)`` with ``order[k]`` = position of entry ``k`` in the concatenation
+    of the blocks' value arrays."""
+    nb = len(blocks)
+    keep = [[_i32(a) for a in blk] for blk in blocks]
+
+    def ptrs(j):
+        arr = (_I32P * nb)()
+        for b in range(nb):
+            arr[b] = _p(keep[b][j], _I32P)
+        return arr
+    nr = np.array([blk[0].size for blk in keep], dtype=np.int64)
+    off = np.zeros(nb, dtype=np.int64)
+    off[1:] = np.cumsum([blk[3].size for blk in keep])[:-1]
+    L = library()
+    indptr = np.empty(n + 1, dtype=np.int64)
+    rm, cm, ip, ix = ptrs(0), ptrs(1), ptrs(2), ptrs(3)
+    _chk(L.pcdh_union_count(n, nb, _p(nr, _I64P), rm, ip, _p(indptr, _I64P)))
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.int32)
+    order = np.empty(nnz, dtype=np.int64)
+    _chk(L.pcdh_union_fill(n, nb, _p(nr, _I64P), rm, cm, ip, ix,
+                           _p(off, _I64P), _p(indptr, _I64P),
+                           _p(indices, _I32P), _p(order, _I64P)))
+    return indptr, indices, order

@@ -20,6 +20,21 @@
 
 using namespace pcd;
 
+// Host-side set-up loops (sub-matrix extraction, structure detection) run on
+// a few threads: chunks [begin, end) of 0..n, one std::thread each.
+#include <atomic>
+#include <thread>
+template <class F>
+static void parallel_chunks(int64_t n, F f) {
+  int T = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
+  if (const char* e = getenv("PCD_SETUP_THREADS")) T = std::max(1, atoi(e));
+  T = (int)std::min<int64_t>(T, std::max<int64_t>(1, n / 4096));
+  if (T <= 1) { f((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back(f, n * t / T, n * (t + 1) / T);
+  for (auto& x : th) x.join();
+}
+
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[1024] = "";
 
@@ -254,6 +269,17 @@ static int choose_lpr(const DCsr& A) {
   return l;
 }
 
+// every row holds exactly columns 0, 1, ..., ncols-1 in this order
+static bool full_sorted_rows(int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                             const int32_t* col) {
+  for (int64_t r = 0; r < nrows; ++r) {
+    if (rowptr[r + 1] - rowptr[r] != ncols) return false;
+    const int32_t* c = col + rowptr[r];
+    for (int64_t k = 0; k < ncols; ++k) if (c[k] != k) return false;
+  }
+  return true;
+}
+
 // rows per workgroup for the CSR-stream kernels: the largest of 256/128/64
 // whose every row block fits the LDS tile; 0 = some row block is too long
 static int g_max_rb = 256;              // PCD_MAX_RB: A/B switch
@@ -293,6 +319,7 @@ static int choose_rb(int64_t nrows, const int32_t* rowptr) {
 }
 // workgroups for a stream kernel: one per row block (capped), multiple of 8
 static inline int grid_stream(int64_t nrows, int rb, int cap = 1 << 20) {
+  if (rb <= 0) rb = 32;                  // (callers check; never divide by zero)
   int64_t nrb = (nrows + rb - 1) / rb;
   int64_t g = std::min<int64_t>(std::max<int64_t>(nrb, 1), cap);
   return (int)((g + 7) / 8 * 8);
@@ -400,8 +427,13 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // the two-component kernels move 16-byte pairs; three components need no
 // more than the 8-byte alignment every double* has
 static inline bool kron_ok(const DCsr& A, const void* a, const void* b = nullptr,
-                           const void* c = nullptr, const void* d = nullptr) {
+                           const void* c = nullptr, const void* d = nullptr,
+                           bool need_tile = false) {
   if (!A.kron) return false;
+  // rb2 == 0: no row block of F fits the LDS tile - only the kernels that need
+  // no tile (dense, wave-per-row, workgroup-per-row SpMV) may take the
+  // multi-component path; the Chebyshev / first-step stream kernels may not
+  if (!A.rb2 && (need_tile || !(A.dense2 || A.wave_rows || A.long_rows))) return false;
   if (A.kron != 2) return true;
   return aligned16(a) && aligned16(b) && aligned16(c) && aligned16(d);
 }
@@ -445,7 +477,7 @@ static void launch_spmv_any(Engine* h, const DCsr& A, const double* x,
                             const double* add, double* y, const double* ghost,
                             int64_t ncols, bool kron) {
   const XVec xv{x, ghost, (int)ncols};
-  if (kron && A.dense2) {
+  if (kron && A.dense2 && ghost == A.ghost.p) {
     const int nn = (int)(A.nrows / A.kron), mm = (int)(A.ncols / A.kron);
     const int g = std::min(nn, 65535);
     if (A.kron == 2) hipLaunchKernelGGL((k_dense_c<MODE, 2>), dim3(g), dim3(kBlock), 0, h->stream, nn, mm, A.val2.p, x, add, y);
@@ -599,7 +631,7 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                             double* pn, double c0, double c1, double c2) {
   const int n = (int)A.nrows;
   CHK(halo_exchange(h, A, pk));
-  if (dinv && kron_ok(A, b, pm, pk, pn)) {
+  if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
@@ -617,13 +649,13 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
 // zero-guess start fused with the first step (single GPU, stream kernels):
 // p0 = s D^-1 b (also written to `p0` unless null), pn = c1 p0 + c2 D^-1(b - A p0)
 static bool can_fuse_first(const Engine* h, const DCsr& A, const double* dinv) {
-  return A.rb && !h->comm && dinv != nullptr;
+  return A.rb && !h->comm && dinv != nullptr && (!A.kron || A.rb2);
 }
 static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
                               const double* b, double* p0, double* pn, double s,
                               double c1, double c2) {
   const int n = (int)A.nrows;
-  if (kron_ok(A, b, p0, pn)) {
+  if (kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2s.p, dinv, b, p0, pn, s, c1, c2);
@@ -770,7 +802,8 @@ static int solve_cg_sr(Engine* h, const DCsr& A, Inner& s, const double* b,
 static int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
                       double* x, double out_scale = 1.0) {
   const int n = (int)A.nrows;
-  const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
+  // (PCD_PC_EXPLICIT: the step-by-step form of a stale factor chain)
+  const double* dinv = (s.pc == PCD_PC_JACOBI || s.pc == PCD_PC_EXPLICIT) ? A.dinv.p : nullptr;
   const double scale = 2.0 / (s.emax + s.emin);
   const double alpha = 1.0 - scale * s.emin;
   const double mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
@@ -1062,9 +1095,17 @@ static int inner_solve(Engine* h, int slot, const double* b, double* x,
     // by the caller rides on the last one
     const int m = (int)s.chain.size();
     if (m < 1) return fail(PCD_ERR_STATE, "pc explicit: no factors (pcd_set_inner_factor)");
-    if (s.chain_stale)
-      return fail(PCD_ERR_STATE, "pc explicit: the operator of slot %d was updated after its factors "
-                                 "were composed; hand over new factors (pcd_set_inner_factor)", slot);
+    if (s.chain_stale) {
+      // the operator changed after the factors were composed: run the
+      // recurrence they stand for - max_it Chebyshev-Jacobi steps with the
+      // bounds kept in emin / emax - until new factors arrive
+      if (!(s.emax > s.emin && s.emin > 0.0))
+        return fail(PCD_ERR_STATE, "pc explicit: the operator of slot %d was updated after its factors "
+                                   "were composed and no Chebyshev bounds were given to fall back on; "
+                                   "hand over new factors (pcd_set_inner_factor)", slot);
+      if (scaled) *scaled = true;
+      return solve_cheb(h, A, s, b, x, scaled ? out_scale : 1.0);
+    }
     for (const DCsr& F : s.chain)
       if (!F.set || F.nrows != A.nrows || F.ncols != A.ncols)
         return fail(PCD_ERR_STATE, "pc explicit: factors incomplete or of the wrong size");
@@ -1276,17 +1317,22 @@ static int refresh_kron(Engine* h, DCsr& A) {
 static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* rowptr,
                          const int32_t* col) {
   if (nrows < nc || nrows % nc || ncols % nc) return false;
-  for (int64_t s = 0; s < nrows / nc; ++s) {
-    const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a;
-    for (int c = 1; c < nc; ++c)
-      if (rowptr[nc * s + c + 1] - rowptr[nc * s + c] != len) return false;
-    for (int32_t k = 0; k < len; ++k) {
-      if (col[a + k] % nc) return false;
-      for (int c = 1; c < nc; ++c)
-        if (col[rowptr[nc * s + c] + k] != col[a + k] + c) return false;
+  std::atomic<bool> ok{true};
+  parallel_chunks(nrows / nc, [&](int64_t s0, int64_t s1) {
+    for (int64_t s = s0; s < s1 && ok.load(std::memory_order_relaxed); ++s) {
+      const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a;
+      bool good = true;
+      for (int c = 1; c < nc && good; ++c)
+        if (rowptr[nc * s + c + 1] - rowptr[nc * s + c] != len) good = false;
+      for (int32_t k = 0; k < len && good; ++k) {
+        if (col[a + k] % nc) good = false;
+        for (int c = 1; c < nc && good; ++c)
+          if (col[rowptr[nc * s + c] + k] != col[a + k] + c) good = false;
+      }
+      if (!good) ok.store(false, std::memory_order_relaxed);
     }
-  }
-  return true;
+  });
+  return ok.load();
 }
 
 // detect the structure (the velocity block size first) + compressed arrays
@@ -1300,18 +1346,22 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     if (kron_pattern(cand, nrows, ncols, rowptr, col)) { nc = cand; break; }
   if (!nc) return 0;
   const int64_t nn = nrows / nc;
-  std::vector<int32_t> rpc(nn + 1, 0), cc;
-  std::vector<std::vector<int32_t>> pos(nc);
-  for (int64_t s = 0; s < nn; ++s) {
-    const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a;
-    for (int32_t k = 0; k < len; ++k) {
-      cc.push_back(col[a + k] / nc);
-      for (int c = 0; c < nc; ++c) pos[c].push_back(rowptr[nc * s + c] + k);
+  std::vector<int32_t> rpc(nn + 1, 0);
+  for (int64_t s = 0; s < nn; ++s) rpc[s + 1] = rpc[s] + (rowptr[nc * s + 1] - rowptr[nc * s]);
+  std::vector<int32_t> cc(rpc[nn]);
+  std::vector<std::vector<int32_t>> pos(nc, std::vector<int32_t>(rpc[nn]));
+  parallel_chunks(nn, [&](int64_t s0, int64_t s1) {
+    for (int64_t s = s0; s < s1; ++s) {
+      const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a, o = rpc[s];
+      for (int32_t k = 0; k < len; ++k) {
+        cc[o + k] = col[a + k] / nc;
+        for (int c = 0; c < nc; ++c) pos[c][o + k] = rowptr[nc * s + c] + k;
+      }
     }
-    rpc[s + 1] = (int32_t)cc.size();
-  }
+  });
   const int rb2 = rb_for(nn, rpc.data(), nc == 3 ? tile_c<3>() : tile_c<2>());
-  const bool dense2 = nn >= 64 && (int64_t)cc.size() == nn * (ncols / nc);
+  const bool dense2 = nn >= 64 && (int64_t)cc.size() == nn * (ncols / nc) &&
+                      full_sorted_rows(nn, ncols / nc, rpc.data(), cc.data());
   if (!rb2 && !g_want_wave && !dense2) return 0;   // (wave-per-row / dense kernels need no tile)
   A.dense2 = dense2;
   A.nnz2 = (int64_t)cc.size();
@@ -1347,7 +1397,9 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.lpr = choose_lpr(A);
   A.rb = g_force_vector ? 0 : choose_rb(nrows, rowptr);
   A.long_rows = A.rb == 0 && nrows > 0 && nnz / nrows >= 256;
-  A.dense = nrows >= 64 && nnz == nrows * ncols;
+  // the dense kernels read `val` as a row-major matrix and ignore `col`: only
+  // valid when every row stores columns 0..ncols-1 in ascending order
+  A.dense = nrows >= 64 && nnz == nrows * ncols && full_sorted_rows(nrows, ncols, rowptr, col);
   // measured (profiles/r02_f_timeline.txt): a wave per row wins on the few,
   // very long rows of a residual-restriction product (150-300 entries: 7 us
   // against 13-38 us for the stream kernel's serialised tile passes) and
@@ -1598,18 +1650,31 @@ static void extract_block(int64_t nr, const int32_t* rows, const int32_t* rowptr
                           std::vector<int32_t>& orp, std::vector<int32_t>& oc,
                           std::vector<int64_t>& osrc) {
   orp.assign(nr + 1, 0);
-  oc.clear(); osrc.clear();
-  std::vector<std::pair<int32_t, int64_t>> tmp;
-  for (int64_t i = 0; i < nr; ++i) {
-    tmp.clear();
-    for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k) {
-      const int32_t c = colmap[col[k]];
-      if (c >= 0) tmp.emplace_back(c, (int64_t)k);
+  parallel_chunks(nr, [&](int64_t i0, int64_t i1) {
+    for (int64_t i = i0; i < i1; ++i) {
+      int32_t c = 0;
+      for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k) c += colmap[col[k]] >= 0;
+      orp[i + 1] = c;
     }
-    std::sort(tmp.begin(), tmp.end());
-    for (auto& t : tmp) { oc.push_back(t.first); osrc.push_back(t.second); }
-    orp[i + 1] = (int32_t)oc.size();
-  }
+  });
+  for (int64_t i = 0; i < nr; ++i) orp[i + 1] += orp[i];
+  oc.resize(orp[nr]); osrc.resize(orp[nr]);
+  parallel_chunks(nr, [&](int64_t i0, int64_t i1) {
+    std::vector<std::pair<int32_t, int64_t>> tmp;
+    for (int64_t i = i0; i < i1; ++i) {
+      tmp.clear();
+      bool sorted = true;
+      for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k) {
+        const int32_t c = colmap[col[k]];
+        if (c < 0) continue;
+        if (!tmp.empty() && c < tmp.back().first) sorted = false;
+        tmp.emplace_back(c, (int64_t)k);
+      }
+      if (!sorted) std::sort(tmp.begin(), tmp.end());
+      int64_t q = orp[i];
+      for (auto& t : tmp) { oc[q] = t.first; osrc[q] = t.second; ++q; }
+    }
+  });
 }
 
 static int gather_block_values(Engine* h, DCsr& A, const double* dvals) {
@@ -2126,7 +2191,7 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
   const int G = grid1d(n, 4, 512);
   CHK(h->gz.ensure(n)); CHK(h->gw.ensure(n)); CHK(h->gxs.ensure(n)); CHK(h->gbs.ensure(n));
   CHK(h->gparts.ensure((size_t)(m + 2) * 512)); CHK(h->gh.ensure(m + 2)); CHK(h->gy.ensure(m + 2));
-  CHK(ensure_pinned(h, (size_t)m + 8));
+  CHK(ensure_pinned(h, (size_t)m + 24));
   IoMap io;
   if (local_io) { io.h = h; io.mem = mem; io.dx = b; io.dy = x; }
   else CHK(io_begin(h, io, b, nglob, x, nglob, mem));
@@ -2148,7 +2213,9 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
   CHK(h->gH.ensure((size_t)(m + 1) * m)); CHK(h->gcs.ensure(m)); CHK(h->gsn.ensure(m));
   CHK(h->gg.ensure(m + 1)); CHK(h->gstat.ensure(1));
   for (auto& e : h->gev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  GmresStatus* pst = reinterpret_cast<GmresStatus*>(h->pinned);   // 2 slots
+  // (pinned[0..7] carry the inner solvers' convergence flag and dev_norm's
+  // result: the two status slots live behind them)
+  GmresStatus* pst = reinterpret_cast<GmresStatus*>(h->pinned + 8);   // 2 slots
   static_assert(sizeof(GmresStatus) == 24 || sizeof(GmresStatus) == 32, "status layout");
   int it = 0;
   double res = bnorm;
@@ -2297,6 +2364,10 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
         CgState st;
         HIPCHK(hipMemcpyAsync(&st, s.state.p + s.state_idx, sizeof st, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (st.its < 0)
+          return fail(PCD_ERR_BREAKDOWN, "cg (single reduction): p.Ap <= 0 at iteration %d - the "
+                                         "operator of slot %d is not positive definite",
+                      -st.its - 1, key - PCD_INFO_ITS_AP);
         s.last_its = st.its;
       }
       *out = (double)s.last_its;

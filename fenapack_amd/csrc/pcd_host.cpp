@@ -377,4 +377,57 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols, const int32_t* 
   return 0;
 }
 
+// ------------------------------------------------------- union of mapped blocks
+int pcdh_union_count(int64_t n, int nb, const int64_t* nr, const int32_t* const* rowmap,
+                     const int32_t* const* indptr, int64_t* out) {
+  if (n < 0 || nb < 1 || !nr || !rowmap || !indptr || !out)
+    return fail(PCDH_ERR_ARG, "union_count: bad arguments");
+  for (int64_t i = 0; i <= n; ++i) out[i] = 0;
+  for (int b = 0; b < nb; ++b)
+    for (int64_t i = 0; i < nr[b]; ++i) {
+      const int32_t g = rowmap[b][i];
+      if (g < 0 || g >= n) return fail(PCDH_ERR_ARG, "union_count: row map of block %d leaves [0, %lld)", b, (long long)n);
+      out[g + 1] += indptr[b][i + 1] - indptr[b][i];
+    }
+  for (int64_t i = 0; i < n; ++i) out[i + 1] += out[i];
+  return 0;
+}
+
+int pcdh_union_fill(int64_t n, int nb, const int64_t* nr, const int32_t* const* rowmap,
+                    const int32_t* const* colmap, const int32_t* const* indptr,
+                    const int32_t* const* indices, const int64_t* data_off,
+                    const int64_t* out_indptr, int32_t* out_indices, int64_t* out_order) {
+  if (n < 0 || nb < 1 || !nr || !rowmap || !colmap || !indptr || !indices || !data_off ||
+      !out_indptr || !out_indices || !out_order)
+    return fail(PCDH_ERR_ARG, "union_fill: bad arguments");
+  const int T = nthreads();
+  // global row -> (block, block row) lists: a row may appear in several blocks
+  std::vector<int32_t> inv((size_t)nb * n, -1);
+  for (int b = 0; b < nb; ++b)
+    for (int64_t i = 0; i < nr[b]; ++i) inv[(size_t)b * n + rowmap[b][i]] = (int32_t)i;
+  int dup = 0;
+#pragma omp parallel num_threads(T)
+  {
+    std::vector<std::pair<int32_t, int64_t>> tmp;
+#pragma omp for schedule(static, 2048)
+    for (int64_t g = 0; g < n; ++g) {
+      tmp.clear();
+      for (int b = 0; b < nb; ++b) {
+        const int32_t i = inv[(size_t)b * n + g];
+        if (i < 0) continue;
+        for (int32_t k = indptr[b][i]; k < indptr[b][i + 1]; ++k)
+          tmp.emplace_back(colmap[b][indices[b][k]], data_off[b] + k);
+      }
+      std::sort(tmp.begin(), tmp.end());
+      int64_t q = out_indptr[g];
+      for (size_t t = 0; t < tmp.size(); ++t) {
+        if (t && tmp[t].first == tmp[t - 1].first) dup = 1;
+        out_indices[q] = tmp[t].first; out_order[q] = tmp[t].second; ++q;
+      }
+    }
+  }
+  if (dup) return fail(PCDH_ERR_ARG, "union_fill: the blocks overlap");
+  return 0;
+}
+
 }  // extern "C"

@@ -300,6 +300,15 @@ __global__ __launch_bounds__(kBlock) void k_cgsr_update(
     bb = beta / bo;
     dpi = delta - beta * beta * st_in->dpiold / (bo * bo);
   }
+  // indefinite / singular operator or cancellation in the recurrence: p.Ap <= 0
+  // (PETSc: KSP_DIVERGED_INDEFINITE_MAT).  Stop with the iterate reached so
+  // far instead of writing Inf / NaN; its = -(it + 1) tells the host.
+  if (!(dpi > 0.0) || !isfinite(dpi)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *st_out = *st_in; st_out->rz0 = beta0; st_out->its = -(it + 1); st_out->done = 1;
+    }
+    return;
+  }
   const double a = beta / dpi;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const double pi = it > 0 ? z[i] + bb * p[i] : z[i];

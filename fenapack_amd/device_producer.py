@@ -36,14 +36,16 @@ __all__ = ["DeviceProducer", "DevicePicardSolver", "DeviceNonlinearSolver",
            "solve_steady_device", "solve_unsteady_device"]
 
 
-def _contribution_plan(inv, ncells, nloc2, nnz):
+def _contribution_plan(inv, ncells, nloc2, nnz, pattern=None):
     """CSR-of-contributions for a FixedPattern: entry k sums the element
     values ``f_src[f_ptr[k]:f_ptr[k+1]]``; element storage is component-major
     (``ab * ncells + cell``), contributions in ascending cell order (the order
     ``numpy.bincount`` adds them on the host)."""
     from . import _host
     inv = np.asarray(inv).ravel()
-    if _host.use_numpy():
+    if pattern is not None and not _host.use_numpy():
+        ptr, order = pattern.members()     # grouped once, with the pattern
+    elif _host.use_numpy():
         order = np.argsort(inv, kind="stable")
         ptr = np.zeros(nnz + 1, dtype=np.int64)
         np.cumsum(np.bincount(inv, minlength=nnz), out=ptr[1:])
@@ -287,7 +289,7 @@ class DeviceProducer(object):
         V, d = pl.space, pl.space.dim
         nc, na = V.mesh.num_cells, V.na
         pat = V._patterns(False)["SS"]
-        ptr, src = _contribution_plan(pat.inv, nc, na * na, pat.nnz)
+        ptr, src = _contribution_plan(pat.inv, nc, na * na, pat.nnz, pat)
         S0 = pl.nu * V.p2_stiffness_cells()
         if pl.idt:
             S0 = S0 + pl.idt * V.p2_mass_cells()
@@ -383,7 +385,7 @@ class DeviceProducer(object):
         pb, V = self.pb, self.V
         nvl, nc = V.nvl, V.mesh.num_cells
         pat = V._patterns(False)["PP"]
-        ptr, src = _contribution_plan(pat.inv, nc, nvl * nvl, pat.nnz)
+        ptr, src = _contribution_plan(pat.inv, nc, nvl * nvl, pat.nnz, pat)
         cst = None
         idt = 0.0 if pb.pcdr else pb.idt
         if idt:

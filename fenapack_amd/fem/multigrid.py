@@ -200,10 +200,32 @@ def dense_csr(C):
                           np.arange(n + 1, dtype=np.int32) * m), shape=(n, m))
 
 
-def coarse_inverse(A0):
+def _kron_factor(A0, block):
+    """``F`` if ``A0 == F (x) I_block`` on interleaved dofs, else ``None``."""
+    n = A0.shape[0]
+    if block < 2 or n % block:
+        return None
+    A0 = sp.csr_matrix(A0)
+    F = A0[::block, ::block]
+    if sp.kron(F, sp.identity(block), format="csr").nnz < A0.nnz or \
+            abs(sp.kron(F, sp.identity(block), format="csr") - A0).max() != 0:
+        return None
+    return F
+
+
+def coarse_inverse(A0, block=1):
     """Explicit inverse of the coarsest operator (LU); a pseudo-inverse when
     the operator is singular (enclosed-flow ``R_p``: constants in the
-    kernel)."""
+    kernel).  ``block`` > 1: if the operator is ``F (x) I_block`` only the
+    scalar factor is inverted (``inv(F (x) I) = inv(F) (x) I``)."""
+    F = _kron_factor(A0, block)
+    if F is not None:
+        Ci = coarse_inverse(F, 1).toarray()
+        n = Ci.shape[0]
+        C = np.zeros((n, block, n, block))
+        for k in range(block):
+            C[:, k, :, k] = Ci
+        return dense_csr(C.reshape(n * block, n * block))
     D = A0.toarray()
     try:
         C = np.linalg.inv(D)

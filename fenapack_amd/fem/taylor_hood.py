@@ -134,8 +134,7 @@ class FixedPattern(object):
         self.indices = g.ucols.astype(np.int32)
         self.indptr = g.indptr.astype(np.int32)
         self.inv = g.inv
-        self._members = g.members()
-        g.release()
+        self._group = g            # members() are fetched on demand
 
     @classmethod
     def from_cells(cls, rdofs, cdofs, shape):
@@ -179,6 +178,11 @@ class FixedPattern(object):
         """(ptr, order): element entries of CSR slot k are
         ``order[ptr[k]:ptr[k+1]]`` in ascending position (= the stable argsort
         of ``inv``)."""
+        if getattr(self, "_members", None) is None and \
+                getattr(self, "_group", None) is not None:
+            self._members = self._group.members()
+            self._group.release()
+            self._group = None
         if getattr(self, "_members", None) is None:
             inv = np.asarray(self.inv).ravel()
             order = np.argsort(inv, kind="stable")
@@ -521,20 +525,35 @@ class TaylorHood(object):
     def _a01_cells(self):
         """vals[c, a, j, comp] = -int psi_j d_comp phi_a."""
         B = self._ref()["B"]                                    # (l, a, j)
-        v = np.einsum('cld,laj->cajd', self.gradlam, B)
-        v *= -self.area[:, None, None, None]
-        return v
+        na, nvl = self.na, self.nvl
+        # v[c, d, (a, j)] = sum_l grad lam_l[c, d] B[l, (a, j)]
+        v = np.matmul(self.gradlam.transpose(0, 2, 1),
+                      B.reshape(nvl, na * nvl)[None])
+        v *= -self.area[:, None, None]
+        return np.ascontiguousarray(
+            v.reshape(-1, self.dim, na, nvl).transpose(0, 2, 3, 1))
 
     def p2_supg_cells(self, U, delta):
         """delta * (w.grad u, w.grad v): streamline diffusion added to the
         preconditioner's 00-block (demo_navier-stokes-pcd.py:122-125);
         ``U`` (nn, d) nodal wind, integrated with the degree-7 rule."""
         Uc = U[self.cell_dofs2]                                 # (nc,na,d)
-        w = np.einsum('qa,cak->cqk', self.phi_s, Uc)
-        wl = np.einsum('cqd,ckd->cqk', w, self.gradlam)         # w.grad lam_k
-        wg = np.einsum('qbk,cqk->cqb', self.dphi_s, wl)         # w.grad phi_b
-        return np.einsum('c,c,q,cqa,cqb->cab', delta, self.area, self.qw_s,
-                         wg, wg)
+        nc = Uc.shape[0]
+        out = np.empty((nc, self.na, self.na))
+        sq = np.sqrt(self.qw_s)
+        # chunks bound the (cells, points, basis) temporaries
+        step = max(1, 4_000_000 // (self.qw_s.size * self.na))
+        for c0 in range(0, nc, step):
+            c1 = min(nc, c0 + step)
+            # U_m . grad lam_k per cell, then w . grad lam_k at the points
+            ug = np.matmul(Uc[c0:c1], self.gradlam[c0:c1].transpose(0, 2, 1))
+            wl = np.matmul(self.phi_s[None], ug)                # (c, q, k)
+            # w . grad phi_b = sum_k dphi_s[q, b, k] wl[c, q, k]
+            wg = np.einsum('qbk,cqk->cqb', self.dphi_s, wl, optimize=True)
+            wg *= sq[None, :, None]
+            out[c0:c1] = np.matmul(wg.transpose(0, 2, 1), wg)
+        out *= (delta * self.area)[:, None, None]
+        return out
 
     # ------------------------------------------------------------- velocity
     def assemble_A00(self, nu, U=None, idt=0.0, newton=False, delta=None):
@@ -557,10 +576,19 @@ class TaylorHood(object):
             vals[..., k, k] = S
         if U is not None:
             # N[(a,c),(b,e)] = int phi_a phi_b d_e w_c
-            _, gw = self.wind_at_qp(U)
-            N = np.einsum('cq,qa,qb,cqkd->cabkd', self.wq, self.phi, self.phi,
-                          gw)
-            vals += N
+            # = |T| sum_{m,l} U[m,c] (grad lam_l)_e  int d_l phi_m phi_a phi_b
+            R = self._ref()
+            if "N" not in R:
+                R["N"] = np.einsum('q,qml,qa,qb->mlab', self._qw, self._dphi,
+                                   self.phi, self.phi)
+            T = R["N"].reshape(self.na * self.nvl, -1)
+            Uc = U[self.cell_dofs2]                             # (nc,na,d)
+            for k in range(d):
+                for e in range(d):
+                    ug = Uc[:, :, k, None] * self.gradlam[:, None, :, e]
+                    ug *= self.area[:, None, None]
+                    vals[..., k, e] += (ug.reshape(-1, self.na * self.nvl)
+                                        @ T).reshape(S.shape)
         return pat.assemble(vals)
 
     def assemble_Mu(self, scale=1.0):
@@ -692,20 +720,35 @@ class TaylorHood(object):
         """Scatter the 2x2 blocks into the node-major mixed numbering on a
         fixed pattern (explicit zero diagonal kept on the pressure rows, as
         DOLFIN's ``keep_diagonal`` would)."""
+        from .. import _host
         key = "_mono_%d_%d_%d" % (A00.nnz, A01.nnz, A10.nnz)
         iu, ip = self.is_u, self.is_p
         if not hasattr(self, key):
-            def rc(M, ri, ci):
-                rows = np.repeat(np.arange(M.shape[0]), np.diff(M.indptr))
-                return ri[rows], ci[M.indices]
-            r0, c0 = rc(A00, iu, iu)
-            r1, c1 = rc(A01, iu, ip)
-            r2, c2 = rc(A10, ip, iu)
-            rows = np.concatenate([r0, r1, r2, ip])
-            cols = np.concatenate([c0, c1, c2, ip])
-            # every (row, col) of the blocks is unique: assembly is a pure
-            # permutation (pat.order), gathered instead of summed
-            pat = FixedPattern.from_unique(rows, cols, (self.ndof, self.ndof))
+            if _host.use_numpy():
+                def rc(M, ri, ci):
+                    rows = np.repeat(np.arange(M.shape[0]), np.diff(M.indptr))
+                    return ri[rows], ci[M.indices]
+                r0, c0 = rc(A00, iu, iu)
+                r1, c1 = rc(A01, iu, ip)
+                r2, c2 = rc(A10, ip, iu)
+                rows = np.concatenate([r0, r1, r2, ip])
+                cols = np.concatenate([c0, c1, c2, ip])
+                # every (row, col) of the blocks is unique: assembly is a pure
+                # permutation (pat.order), gathered instead of summed
+                pat = FixedPattern.from_unique(rows, cols,
+                                               (self.ndof, self.ndof))
+            else:
+                eye = np.arange(self.n_p + 1, dtype=np.int32)
+                indptr, indices, order = _host.union_blocks(self.ndof, [
+                    (iu, iu, A00.indptr, A00.indices),
+                    (iu, ip, A01.indptr, A01.indices),
+                    (ip, iu, A10.indptr, A10.indices),
+                    (ip, ip, eye, eye[:-1])])
+                inv = np.empty(order.size, dtype=np.int64)
+                inv[order] = np.arange(order.size)
+                pat = FixedPattern.from_csr(indptr, indices, inv,
+                                            (self.ndof, self.ndof))
+                pat.order = order
             setattr(self, key, pat)
         pat = getattr(self, key)
         vals = np.concatenate([A00.data, A01.data, A10.data,

@@ -597,7 +597,8 @@ class KSP(object):
             emax = estimate_emax(ops[l], iters=12,
                                  warm=pc._mg_warm.setdefault(l, {}))
             bounds.append((b * emax, d * emax))
-        C = coarse_inverse(ops[0])
+        C = coarse_inverse(ops[0], getattr(self.engine, "velocity_block", 2)
+                           if self.slot == c.KSP_A00 else 1)
         eng, slot, L = self.engine, self.slot, len(ops)
         # kept for statistics (roofline bytes) and for the CPU baseline
         nu_pre = pc.mg_smooth_its if pc.mg_smooth_down is None \

@@ -190,8 +190,10 @@ int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
  *   Any later update of that level's values or smoother bounds drops it too.
  * pcd_set_inner_factor: factor k of nfactors of x = W_{nfactors-1} ... W_0 b
  *   for pc_type PCD_PC_EXPLICIT (e.g. Chebyshev(5)+Jacobi on the constant
- *   M_p as two factors).  Updating the slot's operator afterwards makes the
- *   solve fail until new factors arrive. */
+ *   M_p as two factors).  After an update of the slot's operator the factors
+ *   are stale: the solve then runs the recurrence they stand for (max_it
+ *   Chebyshev-Jacobi steps with the emin / emax given to pcd_set_inner) until
+ *   new factors arrive; without valid bounds it fails (PCD_ERR_STATE). */
 int pcd_mg_set_fused(pcd_handle h, int slot, int level,
                      int64_t wd_rows, int64_t wd_cols, const int32_t* wd_rowptr,
                      const int32_t* wd_col, const double* wd_val,

@@ -115,6 +115,24 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols,
                      const int32_t* b_col, const double* b_val,
                      const int64_t* c_rowptr, int32_t* c_col, double* c_val);
 
+/* ---- union of index-mapped blocks -------------------------------------------
+ * The monolithic pattern of a block system in the caller's mixed numbering
+ * (what DOLFIN's SystemAssembler produces directly, assembling.py:151-155):
+ * block b contributes its CSR rows i -> global row rowmap[b][i], columns
+ * c -> colmap[b][c].  Blocks must not overlap.  Output: CSR with sorted
+ * columns and, per entry, its position in the concatenation of the blocks'
+ * value arrays (data_off[b] + k): assembling values is one gather.
+ * Two calls: counts, then fill.
+ */
+int pcdh_union_count(int64_t n, int nb, const int64_t* nr,
+                     const int32_t* const* rowmap, const int32_t* const* indptr,
+                     int64_t* out_indptr /* n + 1 */);
+int pcdh_union_fill(int64_t n, int nb, const int64_t* nr,
+                    const int32_t* const* rowmap, const int32_t* const* colmap,
+                    const int32_t* const* indptr, const int32_t* const* indices,
+                    const int64_t* data_off, const int64_t* out_indptr,
+                    int32_t* out_indices, int64_t* out_order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,3 +122,69 @@ def test_smoother_and_cg_on_random_spd(hip_lib, n):
         tol = 1e-7 if cfg[3] else 1e-10
         assert relerr(e.inner_solve_np(c.KSP_AP, b),
                       o.inner_solve_np(c.KSP_AP, b)) < tol, cfg
+
+
+def _full_unsorted(rng, M):
+    """CSR that stores EVERY entry of the dense ``M`` with the columns of each
+    row in a random order (what a scipy product can return)."""
+    n, m = M.shape
+    cols = np.concatenate([rng.permutation(m) for _ in range(n)])
+    rows = np.repeat(np.arange(n), m)
+    A = sp.csr_matrix((M[rows, cols], cols, np.arange(n + 1) * m),
+                      shape=(n, m))
+    assert not A.has_sorted_indices
+    return A
+
+
+@pytest.mark.parametrize("n", [64, 130])
+def test_full_pattern_with_unsorted_columns(hip_lib, n):
+    """A full-pattern CSR whose column indices are not 0..n-1 in order must
+    not take the row-major dense kernel (it ignores ``col``): scalar operator
+    and the F (x) I_2 form."""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    A = _full_unsorted(rng, M)
+    e = c.Engine(hip_lib, "BRM1", 0)
+    e.set_csr(c.MAT_KP, A)
+    x = rng.standard_normal(n)
+    assert relerr(e.spmv_np(c.MAT_KP, x, n), M @ x) < 1e-12
+    # two components per node, every block stored, columns shuffled per row
+    K = sp.kron(sp.csr_matrix(M), sp.identity(2), format="csr")
+    Kd = K.toarray()
+    rows, cols = [], []
+    for i in range(2 * n):
+        cc = np.nonzero(Kd[i])[0]
+        cols.append(rng.permutation(cc))
+        rows.append(len(cc))
+    cols = np.concatenate(cols)
+    indptr = np.concatenate([[0], np.cumsum(rows)])
+    r = np.repeat(np.arange(2 * n), rows)
+    K2 = sp.csr_matrix((Kd[r, cols], cols, indptr), shape=K.shape)
+    e.set_csr(c.MAT_A01, K2)
+    x2 = rng.standard_normal(2 * n)
+    assert relerr(e.spmv_np(c.MAT_A01, x2, 2 * n), Kd @ x2) < 1e-12
+
+
+@pytest.mark.parametrize("nc", [2, 3])
+def test_smoother_on_a_fully_dense_multi_component_level(hip_lib, nc):
+    """F (x) I_nc with a FULL F of 64+ nodes (a small Galerkin / gamg level):
+    its row blocks may fit no LDS tile (rb2 == 0), the SpMV still takes the
+    dense multi-component kernel and the smoother must fall back to the
+    general kernels instead of launching a tile kernel with rb2 = 0."""
+    nodes = 600                      # 600 entries per node row: > one 32-row tile
+    rng = np.random.default_rng(nc)
+    B = rng.standard_normal((nodes, nodes)) / np.sqrt(nodes)
+    F = B @ B.T + 2.0 * np.eye(nodes)
+    A = sp.kron(sp.csr_matrix(F), sp.identity(nc), format="csr")
+    A.sort_indices()
+    b = rng.standard_normal(nc * nodes)
+    e, o = c.Engine(hip_lib, "BRM1", 0), oracle.Engine("BRM1")
+    for eng in (e, o):
+        eng.set_csr(c.MAT_AP, A)
+    assert relerr(e.spmv_np(c.MAT_AP, b, nc * nodes), A @ b) < 1e-12
+    for cfg in (("chebyshev", "jacobi", 4, 0.0, 0.3, 1.8),
+                ("richardson", "jacobi", 3, 0.0)):
+        e.set_inner(c.KSP_AP, *cfg)
+        o.set_inner(c.KSP_AP, *cfg)
+        assert relerr(e.inner_solve_np(c.KSP_AP, b),
+                      o.inner_solve_np(c.KSP_AP, b)) < 1e-11, cfg

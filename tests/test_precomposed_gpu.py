@@ -123,10 +123,10 @@ def test_chebyshev_as_explicit_factors(hip_lib, its, nf):
     for eng in (g, o2):
         eng.setup()
     assert relerr(g.apply_np(xp), o2.apply_np(xp)) < 1e-11
-    # stale factors fail loudly; new factors repair
+    # stale factors are never applied: the step-by-step recurrence they stand
+    # for takes over (bounds from set_inner) until new factors arrive
     f.update_values(c.MAT_MP, 2.0 * pb.Mp.data)
-    with pytest.raises(c.EngineError, match="factors"):
-        f.inner_solve_np(c.KSP_MP, b)
+    assert relerr(f.inner_solve_np(c.KSP_MP, b), 0.5 * yo) < 1e-12
     f.set_inner_factors(c.KSP_MP, chebyshev_factors(2.0 * pb.Mp, 0.5, 2.0,
                                                     its, max_factors=nf))
     assert relerr(f.inner_solve_np(c.KSP_MP, b), 0.5 * yo) < 1e-12
