@@ -64,6 +64,10 @@ _SIGNATURES = {
 }
 # entry points only the HIP library has
 _HIP_ONLY = {
+    # rank-local hand-over (partitioned runs)
+    "set_csr_local": [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                      C.c_void_p, C.c_void_p],
+    "row_range": [C.c_int, C.c_int64, C.c_void_p, C.c_void_p],
     "set_stream": [C.c_void_p],
     "comm_init": [C.c_int, C.c_int, C.c_void_p],
     "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
@@ -269,6 +273,22 @@ class Engine(object):
         self._call("set_csr", which, A.shape[0], A.shape[1], _ptr(ip),
                    _ptr(ix), _ptr(dv))
 
+    def row_range(self, n_global, velocity=False):
+        """Rows ``[r0, r1)`` of a field this rank owns."""
+        r0, r1 = C.c_int64(), C.c_int64()
+        self._call("row_range", int(bool(velocity)), int(n_global),
+                   C.byref(r0), C.byref(r1))
+        return int(r0.value), int(r1.value)
+
+    def set_csr_local(self, which, A_rows, shape):
+        """Rank-local hand-over: ``A_rows`` = this rank's rows (scipy CSR,
+        GLOBAL column ids), ``shape`` = global shape."""
+        ip, ix, dv = _i32(A_rows.indptr), _i32(A_rows.indices), \
+            _f64(A_rows.data)
+        self.shapes[which] = tuple(shape)
+        self._call("set_csr_local", which, shape[0], shape[1],
+                   A_rows.shape[0], _ptr(ip), _ptr(ix), _ptr(dv))
+
     def update_values(self, which, vals, mem=MEM_HOST):
         if mem == MEM_HOST:
             vals = _f64(vals)
@@ -420,9 +440,11 @@ class Engine(object):
         self._call("graph_enable", int(bool(on)))
 
     def bandwidth_probe(self, kind="triad", nbytes=1 << 30, reps=5):
-        """GB/s (reads + writes) of a streaming copy / triad kernel."""
+        """GB/s (reads + writes) of a streaming kernel of the library: copy,
+        triad, read-only sweep, read-mostly (6 % writes)."""
         out = C.c_double(0.0)
-        self._call("bandwidth_probe", {"copy": 0, "triad": 1}[kind],
+        self._call("bandwidth_probe",
+                   {"copy": 0, "triad": 1, "read": 2, "read_mostly": 3}[kind],
                    int(nbytes), int(reps), C.byref(out))
         return out.value
 

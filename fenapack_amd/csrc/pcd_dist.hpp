@@ -199,6 +199,131 @@ struct CommBackend {
                        const std::vector<Msg>& recvs, hipStream_t s) = 0;
 };
 
+// Rank-local localisation: the rows this rank OWNS are all it looks at (the
+// owned-rows-only construction of SubfieldBC.h:136-155).  `span(i)` gives the
+// entry range of local row i in `col` / `val` (GLOBAL column ids) - a view of
+// a global CSR or arrays that hold this rank's rows only.  What the other
+// ranks need from this one cannot be read off its own rows (rectangular and
+// non-symmetric operators): it arrives in a set-up handshake over the
+// communicator - one all-reduce of the R x R request counts, one neighbour
+// exchange of the requested column ids (carried as doubles: exact below
+// 2^53).  Collective: every rank calls it for every operator in the same
+// order.  The ghost numbering (by owner, then global id) and the send lists
+// (ascending global id per peer) equal those of `localize`.
+template <class Span>
+inline int localize_owned(const Space& rs, const Space& cs, int me, int R,
+                          int64_t nrow_loc, Span span, const int32_t* col,
+                          const double* val, const int64_t* src_in,
+                          CommBackend* comm, hipStream_t stream,
+                          std::vector<int32_t>& orp, std::vector<int32_t>& oc,
+                          std::vector<double>& ov, std::vector<int64_t>& osrc,
+                          HaloPlan& plan, std::string& err) {
+  const int64_t ncol_loc = cs.nloc(me);
+  std::vector<int64_t> my_ghosts;
+  for (int64_t i = 0; i < nrow_loc; ++i) {
+    const auto be = span(i);
+    for (int64_t k = be.first; k < be.second; ++k)
+      if (cs.owner(col[k]) != me) my_ghosts.push_back(col[k]);
+  }
+  std::sort(my_ghosts.begin(), my_ghosts.end());
+  my_ghosts.erase(std::unique(my_ghosts.begin(), my_ghosts.end()), my_ghosts.end());
+  std::stable_sort(my_ghosts.begin(), my_ghosts.end(),
+                   [&](int64_t a, int64_t b) { return cs.owner(a) < cs.owner(b); });
+  plan = HaloPlan();
+  plan.nghost = (int)my_ghosts.size();
+  plan.recv_off.push_back(0);
+  for (size_t i = 0; i < my_ghosts.size();) {
+    const int o = cs.owner(my_ghosts[i]);
+    size_t j = i;
+    while (j < my_ghosts.size() && cs.owner(my_ghosts[j]) == o) ++j;
+    plan.peers_recv.push_back(o);
+    plan.recv_off.push_back((int)j);
+    i = j;
+  }
+  // ---- handshake: who needs what from me
+  {
+    auto hip_fail = [&](hipError_t e, const char* what) {
+      if (e == hipSuccess) return false;
+      err = std::string(what) + ": " + hipGetErrorString(e);
+      return true;
+    };
+    std::vector<double> cnt((size_t)R * R, 0.0);
+    for (size_t p = 0; p < plan.peers_recv.size(); ++p)
+      cnt[(size_t)me * R + plan.peers_recv[p]] = (double)(plan.recv_off[p + 1] - plan.recv_off[p]);
+    double* dcnt = nullptr;
+    if (hip_fail(hipMalloc((void**)&dcnt, cnt.size() * sizeof(double)), "hipMalloc")) return 1;
+    bool bad = hip_fail(hipMemcpyAsync(dcnt, cnt.data(), cnt.size() * sizeof(double), hipMemcpyHostToDevice, stream), "memcpy");
+    if (!bad && comm->allreduce(dcnt, cnt.size(), stream)) { err = comm->err; bad = true; }
+    if (!bad) bad = hip_fail(hipMemcpyAsync(cnt.data(), dcnt, cnt.size() * sizeof(double), hipMemcpyDeviceToHost, stream), "memcpy");
+    if (!bad) bad = hip_fail(hipStreamSynchronize(stream), "sync");
+    (void)hipFree(dcnt);
+    if (bad) return 1;
+    // requests: my ghost ids go to their owners, theirs come to me
+    size_t nsend = my_ghosts.size(), nrecv = 0;
+    std::vector<int> req_peers; std::vector<size_t> req_off(1, 0);
+    for (int q = 0; q < R; ++q) {
+      const size_t c = (size_t)cnt[(size_t)q * R + me];
+      if (q == me || !c) continue;
+      req_peers.push_back(q); nrecv += c; req_off.push_back(nrecv);
+    }
+    double *dsend = nullptr, *drecv = nullptr;
+    if (hip_fail(hipMalloc((void**)&dsend, std::max<size_t>(nsend, 1) * sizeof(double)), "hipMalloc")) return 1;
+    if (hip_fail(hipMalloc((void**)&drecv, std::max<size_t>(nrecv, 1) * sizeof(double)), "hipMalloc")) { (void)hipFree(dsend); return 1; }
+    std::vector<double> ids(my_ghosts.begin(), my_ghosts.end()), got(nrecv);
+    if (nsend) bad = hip_fail(hipMemcpyAsync(dsend, ids.data(), nsend * sizeof(double), hipMemcpyHostToDevice, stream), "memcpy");
+    std::vector<Msg> sends, recvs;
+    for (size_t p = 0; p < plan.peers_recv.size(); ++p)
+      sends.push_back(Msg{plan.peers_recv[p], dsend + plan.recv_off[p], (size_t)(plan.recv_off[p + 1] - plan.recv_off[p])});
+    for (size_t p = 0; p < req_peers.size(); ++p)
+      recvs.push_back(Msg{req_peers[p], drecv + req_off[p], req_off[p + 1] - req_off[p]});
+    if (!bad && comm->exchange(sends, recvs, stream)) { err = comm->err; bad = true; }
+    if (!bad && nrecv) bad = hip_fail(hipMemcpyAsync(got.data(), drecv, nrecv * sizeof(double), hipMemcpyDeviceToHost, stream), "memcpy");
+    if (!bad) bad = hip_fail(hipStreamSynchronize(stream), "sync");
+    (void)hipFree(dsend); (void)hipFree(drecv);
+    if (bad) return 1;
+    plan.send_off.push_back(0);
+    for (size_t p = 0; p < req_peers.size(); ++p) {
+      plan.peers_send.push_back(req_peers[p]);
+      for (size_t k = req_off[p]; k < req_off[p + 1]; ++k) {
+        const int64_t g = (int64_t)got[k];
+        if (cs.owner(g) != me) { err = "set-up handshake: asked for a column this rank does not own"; return 1; }
+        plan.send_idx.push_back((int32_t)cs.local(g, me));
+      }
+      plan.send_off.push_back((int)plan.send_idx.size());
+    }
+  }
+  // ---- local matrix (columns: owned -> local, ghosts -> ncol_loc + slot)
+  orp.assign(nrow_loc + 1, 0);
+  oc.clear(); ov.clear(); osrc.clear();
+  std::vector<std::pair<int32_t, int64_t>> tmp;
+  for (int64_t i = 0; i < nrow_loc; ++i) {
+    const auto be = span(i);
+    tmp.clear();
+    for (int64_t k = be.first; k < be.second; ++k) {
+      const int64_t cg = col[k];
+      int32_t lc;
+      const int o = cs.owner(cg);
+      if (o == me) lc = (int32_t)cs.local(cg, me);
+      else {
+        size_t pi = 0;
+        while (plan.peers_recv[pi] != o) ++pi;
+        auto b = my_ghosts.begin() + plan.recv_off[pi];
+        auto e = my_ghosts.begin() + plan.recv_off[pi + 1];
+        lc = (int32_t)(ncol_loc + (std::lower_bound(b, e, cg) - my_ghosts.begin()));
+      }
+      tmp.emplace_back(lc, k);
+    }
+    std::sort(tmp.begin(), tmp.end());
+    for (auto& t : tmp) {
+      oc.push_back(t.first);
+      if (val) ov.push_back(val[t.second]);
+      osrc.push_back(src_in ? src_in[t.second] : t.second);
+    }
+    orp[i + 1] = (int32_t)oc.size();
+  }
+  return 0;
+}
+
 // RCCL, bound at run time so that the library loads without it
 struct RcclApi {
   void* lib = nullptr;

@@ -101,6 +101,7 @@ struct DCsr {
   int kron = 0;
   int kron_pat = 0;       // components the PATTERN admits (kron: values agree too)
   int rb2 = 0;
+  bool pipe2 = false;     // every rb2-row block of F fits ONE pass through the tile: pipelined kernels
   int64_t nnz2 = 0;
   DBuf<int> rowptr2, col2, kron_pos;
   DBuf<double> val2;
@@ -117,7 +118,7 @@ struct DCsr {
     vals.release(); val2s.release();
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); kron_pos.release();
-    val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
+    val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0; pipe2 = false;
     plan = HaloPlan(); replicated = false;
     set = false; nrows = ncols = nnz = 0; has_src = false;
   }
@@ -325,6 +326,23 @@ static inline int grid_stream(int64_t nrows, int rb, int cap = 1 << 20) {
   return (int)((g + 7) / 8 * 8);
 }
 static bool g_force_vector = false;   // PCD_FORCE_CSR_VECTOR=1: A/B switch
+// Software-pipelined persistent stream kernels (k_*_scp): PCD_PIPE=0 switches
+// them off (A/B), PCD_PIPE_WGS = resident workgroups per CU they are sized for
+// (default: what the LDS tile admits - 5 with 32 KiB, 4 with 36 KiB).
+static bool g_pipe = true;
+static int g_pipe_wgs = 0;
+static int g_num_cus = 256;
+// persistent grid: as many workgroups as stay resident, every one walking the
+// same number of row blocks (a multiple of 8 for the XCD-aware ranges)
+static inline int grid_pipe(int64_t nrows, int rb, int lds_bytes) {
+  if (rb <= 0) rb = 32;
+  const int64_t nrb = std::max<int64_t>((nrows + rb - 1) / rb, 1);
+  const int per_cu = g_pipe_wgs > 0 ? g_pipe_wgs : std::max(1, std::min(8, (160 * 1024) / lds_bytes));
+  const int64_t slots = (int64_t)g_num_cus * per_cu;
+  const int64_t per = (nrb + slots - 1) / slots;          // row blocks per workgroup
+  const int64_t g = (nrb + per - 1) / per;
+  return (int)((g + 7) / 8 * 8);
+}
 
 static int ensure_pinned(Engine* h, size_t n) {
   if (n <= h->pinned_n) return 0;
@@ -457,6 +475,20 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
     const int gw = (int)std::min<int64_t>((nn + 3) / 4, 1 << 16);
     hipLaunchKernelGGL((k_spmv_wc<MODE, NC>), dim3(gw), dim3(kBlock), 0, h->stream,
                        nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y);
+    return;
+  }
+  if (A.pipe2 && g_pipe) {
+    const int gp = grid_pipe(nn, A.rb2, (int)(tile_c<NC>() * sizeof(VecC<NC>)));
+    switch (A.rb2) {
+      case 256: hipLaunchKernelGGL((k_spmv_scp<256, MODE, NC>), dim3(gp), dim3(kBlock), 0, h->stream,
+                                   nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
+      case 128: hipLaunchKernelGGL((k_spmv_scp<128, MODE, NC>), dim3(gp), dim3(kBlock), 0, h->stream,
+                                   nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
+      case 64: hipLaunchKernelGGL((k_spmv_scp<64, MODE, NC>), dim3(gp), dim3(kBlock), 0, h->stream,
+                                  nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
+      default: hipLaunchKernelGGL((k_spmv_scp<32, MODE, NC>), dim3(gp), dim3(kBlock), 0, h->stream,
+                                  nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
+    }
     return;
   }
   const int g = grid_stream(nn, A.rb2);
@@ -633,6 +665,12 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
   CHK(halo_exchange(h, A, pk));
   if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
+    if (A.pipe2 && g_pipe) {
+      const int lds = A.kron == 2 ? (int)(tile_c<2>() * sizeof(VecC<2>)) : (int)(tile_c<3>() * sizeof(VecC<3>));
+      LAUNCH_RBC(A, k_cheb_step_scp, grid_pipe(nn, A.rb2, lds), nn, A.rowptr2.p, A.col2.p,
+                 A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
+                 (int)(A.ncols / A.kron));
+    } else
     LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
                (int)(A.ncols / A.kron));
@@ -657,6 +695,12 @@ static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
   const int n = (int)A.nrows;
   if (kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;
+    if (A.pipe2 && g_pipe) {
+      const int lds = A.kron == 2 ? (int)(tile_c<2>() * sizeof(VecC<2>)) : (int)(tile_c<3>() * sizeof(VecC<3>));
+      LAUNCH_RBC(A, k_cheb_first_scp, grid_pipe(nn, A.rb2, lds), nn, A.rowptr2.p, A.col2.p,
+                 A.val2s.p, dinv, b, p0, pn, s, c1, c2);
+      return;
+    }
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2s.p, dinv, b, p0, pn, s, c1, c2);
     return;
@@ -1373,6 +1417,14 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     HIPCHK(hipMemcpy(A.kron_pos.p + c * A.nnz2, pos[c].data(), A.nnz2 * sizeof(int),
                      hipMemcpyHostToDevice));
   A.kron = A.kron_pat = nc; A.rb2 = rb2;
+  A.pipe2 = false;
+  if (rb2) {
+    const int tile = nc == 3 ? tile_c<3>() : tile_c<2>();
+    bool one_pass = tile % kBlock == 0;
+    for (int64_t r = 0; r < nn && one_pass; r += rb2)
+      if (rpc[std::min<int64_t>(r + rb2, nn)] - rpc[r] > tile) one_pass = false;
+    A.pipe2 = one_pass;
+  }
   if (have_vals) CHK(refresh_kron(h, A));
   return 0;
 }
@@ -1427,6 +1479,11 @@ static int ensure_space(Engine* h, Space& sp, int64_t n, bool velocity, const ch
   return 0;
 }
 
+template <class Span>
+static int upload_owned(Engine* h, DCsr& A, const Space* rs, const Space* cs,
+                        int64_t nrow_loc, Span span, const int32_t* col,
+                        const double* val, const int64_t* src);
+
 // Hand over a GLOBAL CSR.  One GPU: uploaded as is.  Several ranks: this
 // rank's row block with localised columns and the halo plan (pcd_dist.hpp);
 // the provenance array then maps local entries to the caller's value array.
@@ -1439,12 +1496,32 @@ static int upload_global(Engine* h, DCsr& A, const Space* rs, const Space* cs,
     A.plan = HaloPlan();
     return upload_csr(h, A, nrows, ncols, rowptr, col, val, src);
   }
+  // this rank's rows only (a view of the global arrays); what the others need
+  // from it arrives in the set-up handshake (pcd_dist.hpp: localize_owned)
+  const int me = h->rank;
+  auto span = [&](int64_t i) {
+    const int64_t g = rs->global(i, me);
+    return std::pair<int64_t, int64_t>(rowptr[g], rowptr[g + 1]);
+  };
+  return upload_owned(h, A, rs, cs, rs->nloc(me), span, col, val, src);
+}
+
+// hand-over of this rank's rows (`span(i)`: entries of local row i, GLOBAL
+// column ids): localisation, halo plan by handshake, upload
+template <class Span>
+static int upload_owned(Engine* h, DCsr& A, const Space* rs, const Space* cs,
+                        int64_t nrow_loc, Span span, const int32_t* col,
+                        const double* val, const int64_t* src) {
   std::vector<int32_t> orp, oc;
   std::vector<double> ov;
   std::vector<int64_t> osrc;
   HaloPlan plan;
-  localize(*rs, *cs, h->rank, h->nranks, rowptr, col, val, src, orp, oc, ov, osrc, plan);
-  CHK(upload_csr(h, A, rs->nloc(h->rank), cs->nloc(h->rank), orp.data(), oc.data(),
+  std::string err;
+  HIPCHK(hipSetDevice(h->device));
+  if (localize_owned(*rs, *cs, h->rank, h->nranks, nrow_loc, span, col, val, src,
+                     h->comm, h->stream, orp, oc, ov, osrc, plan, err))
+    return fail(PCD_ERR_COMM, "set-up handshake: %s", err.c_str());
+  CHK(upload_csr(h, A, nrow_loc, cs->nloc(h->rank), orp.data(), oc.data(),
                  val ? ov.data() : nullptr, osrc.data()));
   A.plan = plan;
   CHK(A.ghost.ensure(plan.nghost));
@@ -1536,6 +1613,11 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
   { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
   { const char* e = getenv("PCD_MAX_CHUNKS"); if (e && atoi(e) >= 1) g_max_chunks = atoi(e); }
+  { const char* e = getenv("PCD_PIPE"); g_pipe = !(e && e[0] == '0'); }
+  { const char* e = getenv("PCD_PIPE_WGS"); g_pipe_wgs = e ? atoi(e) : 0; }
+  { hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      g_num_cus = prop.multiProcessorCount; }
   // measured (profiles/r02_l_*): every cross-stream event join costs 6-12 us
   // on this stack, in eager launches and under graph replay alike - more than
   // the 5 us kernel it takes off the critical path (0.324 -> 0.368 ms per
@@ -1624,6 +1706,61 @@ int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
     }
   }
   CHK(upload_global(h, A, rs, cs, nrows, ncols, rowptr, colidx, vals, nullptr));
+  CHK(refresh_dinv(h, A));
+  values_changed(h, which);
+  h->ready = false; ++h->gen;
+  return 0;
+}
+
+int pcd_row_range(pcd_handle h, int velocity, int64_t n_global, int64_t* r0, int64_t* r1) {
+  if (!h || !r0 || !r1 || n_global < 0) return fail(PCD_ERR_ARG, "row_range: bad arguments");
+  if (!h->comm) { *r0 = 0; *r1 = n_global; return 0; }
+  Space& sp = velocity ? h->sp_u : h->sp_p;
+  CHK(ensure_space(h, sp, n_global, velocity != 0, "row_range"));
+  *r0 = sp.bounds[0][h->rank]; *r1 = sp.bounds[0][h->rank + 1];
+  return 0;
+}
+
+int pcd_set_csr_local(pcd_handle h, int which, int64_t nrows_global, int64_t ncols_global,
+                      int64_t nrows_local, const int32_t* rowptr, const int32_t* colidx,
+                      const double* vals) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (which < 0 || which >= PCD_MAT_A)
+    return fail(PCD_ERR_ARG, "set_csr_local: operator %d cannot be set directly", which);
+  if (!rowptr || nrows_local < 0 || (!colidx && rowptr[nrows_local]) || nrows_global < 0 || ncols_global < 0)
+    return fail(PCD_ERR_ARG, "set_csr_local: bad arrays");
+  if (nrows_global >= INT32_MAX || ncols_global >= INT32_MAX)
+    return fail(PCD_ERR_ARG, "set_csr_local: dimensions exceed int32 indexing");
+  if (!h->comm) {
+    if (nrows_local != nrows_global)
+      return fail(PCD_ERR_ARG, "set_csr_local: one rank owns every row (%lld), got %lld",
+                  (long long)nrows_global, (long long)nrows_local);
+    return pcd_set_csr(h, which, nrows_global, ncols_global, rowptr, colidx, vals);
+  }
+  HIPCHK(hipSetDevice(h->device));
+  DCsr& A = h->mat[which];
+  const Space *rs = nullptr, *cs = nullptr;
+  if (which == PCD_MAT_A00) {
+    CHK(ensure_space(h, h->sp_u, nrows_global, true, "set_csr_local"));
+    rs = cs = &h->sp_u;
+  } else if (which == PCD_MAT_A01) {
+    CHK(ensure_space(h, h->sp_u, nrows_global, true, "set_csr_local"));
+    CHK(ensure_space(h, h->sp_p, ncols_global, false, "set_csr_local"));
+    rs = &h->sp_u; cs = &h->sp_p;
+  } else {
+    CHK(ensure_space(h, h->sp_p, nrows_global, false, "set_csr_local"));
+    rs = cs = &h->sp_p;
+  }
+  if (cs->total() != ncols_global) return fail(PCD_ERR_ARG, "set_csr_local: column count does not match the partitioned space");
+  if (rs->nloc(h->rank) != nrows_local)
+    return fail(PCD_ERR_ARG, "set_csr_local: this rank owns %lld rows (pcd_row_range), got %lld",
+                (long long)rs->nloc(h->rank), (long long)nrows_local);
+  for (int64_t k = 0; k < rowptr[nrows_local]; ++k)
+    if (colidx[k] < 0 || colidx[k] >= ncols_global)
+      return fail(PCD_ERR_ARG, "set_csr_local: column id %d outside [0, %lld)", colidx[k], (long long)ncols_global);
+  auto span = [&](int64_t i) { return std::pair<int64_t, int64_t>(rowptr[i], rowptr[i + 1]); };
+  A.gnnz = rowptr[nrows_local];            // value updates carry this rank's entries
+  CHK(upload_owned(h, A, rs, cs, nrows_local, span, colidx, vals, nullptr));
   CHK(refresh_dinv(h, A));
   values_changed(h, which);
   h->ready = false; ++h->gen;
@@ -2403,12 +2540,13 @@ int pcd_set_velocity_block(pcd_handle h, int ncomp) {
 }
 
 // Streaming bandwidth of this GPU as a kernel of this library sees it:
-// kind 0 copy, 1 triad, on arrays of `bytes` each (>= 256 MiB: beyond the
+// kind 0 copy, 1 triad, 2 read-only, 3 read-mostly (6 % writes), on arrays of
+// `bytes` each (>= 256 MiB: beyond the
 // Infinity Cache), best of `reps` launches, timed with events on the engine's
 // stream.  *gbs = bytes moved (reads + writes) per second / 1e9.
 int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double* gbs) {
   if (!h || !gbs) return fail(PCD_ERR_ARG, "bandwidth_probe: null argument");
-  if (kind < 0 || kind > 1 || bytes < 1024 || reps < 1) return fail(PCD_ERR_ARG, "bandwidth_probe: bad arguments");
+  if (kind < 0 || kind > 3 || bytes < 1024 || reps < 1) return fail(PCD_ERR_ARG, "bandwidth_probe: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   const int64_t n2 = bytes / 16;
   DBuf<double> a, b, c;
@@ -2429,7 +2567,9 @@ int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double*
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    const double moved = (kind == 1 ? 3.0 : 2.0) * 16.0 * (double)n2;
+    // bytes moved: copy 1 read + 1 write, triad 2 + 1, read-only 1 (+ one store
+    // per thread), read-mostly 1 + 1/16 (one store per sixteen loads of a lane)
+    const double moved = (kind == 1 ? 3.0 : kind == 0 ? 2.0 : kind == 3 ? 1.0 + 1.0 / 16.0 : 1.0) * 16.0 * (double)n2;
     if (r > 0 && ms > 0.f) best = std::max(best, moved / (ms * 1e-3) / 1e9);
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -860,6 +860,210 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
   }
 }
 
+// ---- software-pipelined form (persistent workgroups) ------------------------
+// The kernels above walk one row block in three dependent memory round trips
+// (row pointers -> entries -> gathered vector) and keep 5 workgroups per CU
+// (LDS): counters show the waves waiting on memory two thirds of their cycles
+// (DESIGN.md 4).  Here a workgroup owns a CONTIGUOUS range of row blocks and
+// keeps the NEXT block's matrix entries in flight (registers) while it reduces
+// the current one out of LDS:
+//   * consecutive blocks are adjacent in val/col, so the next block starts at
+//     this block's end - its loads need no row-pointer round trip;
+//   * the row pointers of a block (row bounds, block end) and the end of the
+//     block after it are fetched at the top of an iteration and first used
+//     after the gather phase - their latency hides under it.
+// In steady state one block costs: gather (mostly L1 / L2 hits) -> LDS ->
+// barrier -> reduce -> store; the HBM stream of the matrix runs underneath.
+// Requirement (host): every row block fits ONE pass through the tile and
+// tile == U * kBlock entries (U loads per lane).
+template <int RB, int NC, int U, class XF, class Pre, class Epi>
+__device__ __forceinline__ void stream_blocks_pipelined(
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const XF& xf, int nrows, int rb0, int rb1,
+    VecC<NC>* lds, Pre pre, Epi epi) {
+  if (rb0 >= rb1) return;
+  constexpr int TPR = kBlock / RB;
+  const int tid = threadIdx.x;
+  const int sub = tid % TPR;
+  double* planes = reinterpret_cast<double*>(lds);
+  constexpr int kTileC = U * kBlock;
+  int c[U];
+  double v[U];
+  // prologue: bounds of the first block, then its entries
+  int k0 = rowptr[rb0 * RB];
+  int k1 = rowptr[min((rb0 + 1) * RB, nrows)];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = k0 + u * kBlock + tid;
+    const bool in = k < k1;
+    c[u] = in ? PCD_STREAM_LOAD(col + k) : -1;
+    v[u] = in ? PCD_STREAM_LOAD(val + k) : 0.0;
+  }
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const int r1 = min(r0 + RB, nrows);
+    const int row = r0 + tid / TPR;
+    const bool mine = row < r1;
+    // row bounds of THIS block and the end of the NEXT one: used after the
+    // gather phase / the barrier
+    const int ra = mine ? rowptr[row] : 0;
+    const int rbnd = mine ? rowptr[row + 1] : 0;
+    const int k2 = (rb + 1 < rb1) ? rowptr[min(r1 + RB, nrows)] : k1;
+    auto ops = pre(row, mine && sub == 0);
+    VecC<NC> xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : vzero<NC>();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = u * kBlock + tid;
+      if (c[u] >= 0) {
+        if (PCD_LDS_SOA && NC == 3) {
+#pragma unroll
+          for (int i = 0; i < NC; ++i) planes[i * kTileC + j] = v[u] * xv[u].c[i];
+        } else {
+          VecC<NC> t;
+#pragma unroll
+          for (int i = 0; i < NC; ++i) t.c[i] = v[u] * xv[u].c[i];
+          lds[j] = t;
+        }
+      }
+    }
+    __syncthreads();
+    // next block's entries: in flight during the reduction below
+    if (rb + 1 < rb1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k1 + u * kBlock + tid;
+        const bool in = k < k2;
+        c[u] = in ? PCD_STREAM_LOAD(col + k) : -1;
+        v[u] = in ? PCD_STREAM_LOAD(val + k) : 0.0;
+      }
+    }
+    VecC<NC> s = vzero<NC>();
+    for (int j = ra - k0 + sub; j < rbnd - k0; j += TPR) {
+      if (PCD_LDS_SOA && NC == 3) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) s.c[i] += planes[i * kTileC + j];
+      } else {
+        const VecC<NC> t = lds[j];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) s.c[i] += t.c[i];
+      }
+    }
+#pragma unroll
+    for (int m = TPR / 2; m > 0; m >>= 1) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += __shfl_xor(s.c[i], m);
+    }
+    if (mine && sub == 0) epi(row, s, ops);
+    __syncthreads();                        // the tile is reused by the next block
+    k0 = k1; k1 = k2;
+  }
+}
+
+template <int NC> struct ChebOps { VecC<NC> bi, d, xk, xm; };
+template <int NC> struct FirstOps { VecC<NC> d, bi; };
+template <int NC> struct AddOps { VecC<NC> a; };
+
+template <int RB, int NC>
+__global__ __launch_bounds__(kBlock) void k_cheb_step_scp(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* __restrict__ dinv_,
+    const double* b_, const double* pm_, const double* pk_, double* pn_,
+    double c0, double c1, double c2, const double* ghost, int nloc) {
+  constexpr int U = tile_c<NC>() / kBlock;
+  __shared__ VecC<NC> lds[U * kBlock];
+  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_), *pm = vc<NC>(pm_),
+               *pk = vc<NC>(pk_);
+  VecC<NC>* pn = vc<NC>(pn_);
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, RB, rb0, rb1);
+  const XVecC<NC> xf{pk, vc<NC>(ghost), nloc};
+  stream_blocks_pipelined<RB, NC, U>(
+      rowptr, col, val, xf, nrows, rb0, rb1, lds,
+      [&](int row, bool lead) {
+        ChebOps<NC> o;
+        o.bi = o.d = o.xk = o.xm = vzero<NC>();
+        if (lead) {
+          o.bi = b[row]; o.d = dinv[row]; o.xk = pk[row];
+          if (c0 != 0.0) o.xm = pm[row];
+        }
+        return o;
+      },
+      [&](int row, const VecC<NC>& s, const ChebOps<NC>& o) {
+        VecC<NC> r;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          r.c[i] = c0 * o.xm.c[i] + c1 * o.xk.c[i] + c2 * o.d.c[i] * (o.bi.c[i] - s.c[i]);
+        pn[row] = r;
+      });
+}
+
+template <int RB, int NC>
+__global__ __launch_bounds__(kBlock) void k_cheb_first_scp(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ vals, const double* __restrict__ dinv_,
+    const double* b_, double* p0_, double* pn_, double s, double c1, double c2) {
+  constexpr int U = tile_c<NC>() / kBlock;
+  __shared__ VecC<NC> lds[U * kBlock];
+  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
+  VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, RB, rb0, rb1);
+  const XVecC<NC> xf{b, b, nrows};
+  stream_blocks_pipelined<RB, NC, U>(
+      rowptr, col, vals, xf, nrows, rb0, rb1, lds,
+      [&](int row, bool lead) {
+        FirstOps<NC> o;
+        o.d = o.bi = vzero<NC>();
+        if (lead) { o.d = dinv[row]; o.bi = b[row]; }
+        return o;
+      },
+      [&](int row, const VecC<NC>& sum, const FirstOps<NC>& o) {
+        VecC<NC> x0, r;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          x0.c[i] = s * o.d.c[i] * o.bi.c[i];
+          r.c[i] = c1 * x0.c[i] + c2 * o.d.c[i] * (o.bi.c[i] - s * sum.c[i]);
+        }
+        if (p0) p0[row] = x0;
+        pn[row] = r;
+      });
+}
+
+template <int RB, int MODE, int NC>
+__global__ __launch_bounds__(kBlock) void k_spmv_scp(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const double* x, const double* ghost,
+    int nloc, const double* add_, double* y_) {
+  constexpr int U = tile_c<NC>() / kBlock;
+  __shared__ VecC<NC> lds[U * kBlock];
+  const XVecC<NC> xf{vc<NC>(x), vc<NC>(ghost), nloc};
+  const VecC<NC>* add = vc<NC>(add_);
+  VecC<NC>* y = vc<NC>(y_);
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, RB, rb0, rb1);
+  stream_blocks_pipelined<RB, NC, U>(
+      rowptr, col, val, xf, nrows, rb0, rb1, lds,
+      [&](int row, bool lead) {
+        AddOps<NC> o;
+        o.a = vzero<NC>();
+        if ((MODE == 1 || MODE == 2) && lead) o.a = add[row];
+        return o;
+      },
+      [&](int row, const VecC<NC>& s, const AddOps<NC>& o) {
+        VecC<NC> r;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          r.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? o.a.c[i] + s.c[i]
+                                          : (MODE == 2 ? o.a.c[i] - s.c[i] : -s.c[i]));
+        y[row] = r;
+      });
+}
+
 // valc[k] = val[pos[k]]; *mismatch |= (val[pos[c*nnzc + k]] differs, c >= 1):
 // pos holds, component-major, where the entry k of F sits in each component's
 // rows of the full matrix
@@ -1213,10 +1417,31 @@ __global__ __launch_bounds__(kBlock) void k_dense_c(
 // this engine can reach on this box ("confirm with a device-to-
 // device copy/triad microbench on the box and report THAT as the practical
 // roof").  kind 0: a = b (16 B/entry-pair moved: 1 read + 1 write);
-// kind 1: a = b + s c (triad: 2 reads + 1 write).
+// kind 1: a = b + s c (triad: 2 reads + 1 write); kind 2: read-only sweep;
+// kind 3: read-mostly (6 % writes, the mix of the dominant kernel).
 __global__ __launch_bounds__(kBlock) void k_bw_probe(
     int kind, int64_t n2, const double2* __restrict__ b,
     const double2* __restrict__ c, double s, double2* __restrict__ a) {
+  if (kind >= 2) {
+    // kind 2: read-only stream (sum kept in registers, one 16-byte store per
+    // thread at the end); kind 3: the read / write mix of the fused
+    // Chebyshev step (one 16-byte store per sixteen 16-byte loads: 6 % writes).
+    // Four independent loads in flight per lane.
+    double2 acc0 = {0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int trip = 0;
+    for (; i + 3 * stride < n2; i += 4 * stride, ++trip) {
+      const double2 v0 = b[i], v1 = b[i + stride], v2 = b[i + 2 * stride], v3 = b[i + 3 * stride];
+      acc0.x += v0.x; acc0.y += v0.y; acc1.x += v1.x; acc1.y += v1.y;
+      acc2.x += v2.x; acc2.y += v2.y; acc3.x += v3.x; acc3.y += v3.y;
+      if (kind == 3 && (trip & 3) == 0) a[i >> 4] = acc0;   // 1 store per 16 loads
+    }
+    for (; i < n2; i += stride) { const double2 v = b[i]; acc0.x += v.x; acc0.y += v.y; }
+    acc0.x += acc1.x + acc2.x + acc3.x; acc0.y += acc1.y + acc2.y + acc3.y;
+    a[(int64_t)blockIdx.x * kBlock + threadIdx.x] = acc0;
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
        i += (int64_t)gridDim.x * kBlock) {
     double2 v = b[i];

@@ -113,6 +113,23 @@ int pcd_set_stream(pcd_handle h, void* hip_stream);
 int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
                 const int32_t* rowptr, const int32_t* colidx,
                 const double* vals);
+/* Rank-local hand-over (several ranks): the caller passes ONLY the rows this
+ * rank owns - rows [r0, r1) of pcd_row_range - with GLOBAL column ids, the way
+ * a partitioned assembly produces them (owned-rows-only construction,
+ * SubfieldBC.h:136-155; PETSc MPIAIJ row blocks).  Nobody walks the global
+ * matrix: ghost columns and the halo plan follow from the owned rows plus a
+ * set-up handshake over the communicator (collective: every rank calls it for
+ * the same operator in the same order).  pcd_update_values then carries this
+ * rank's values only, in the order of the arrays handed over here.
+ * `which`: Ap / Mp / Kp / Rp / A00 / A01. */
+int pcd_set_csr_local(pcd_handle h, int which, int64_t nrows_global,
+                      int64_t ncols_global, int64_t nrows_local,
+                      const int32_t* rowptr_local, const int32_t* colidx_global,
+                      const double* vals_local);
+/* rows [*r0, *r1) of a field of `n_global` rows that this rank owns
+ * (`velocity` != 0: cuts fall on node boundaries); one GPU: [0, n). */
+int pcd_row_range(pcd_handle h, int velocity, int64_t n_global, int64_t* r0,
+                  int64_t* r1);
 /* non-constant forms are re-assembled into the existing submatrix every outer
  * iteration (field_split_backend.py:82-83,285-291; assembling.py:103-104):
  * same pattern, new values, Jacobi diagonals re-derived. */
@@ -244,7 +261,9 @@ int pcd_synchronize(pcd_handle h);
  * (launch-bound at the 2D sizes: SURVEY 7, hard part 3); 0 = eager launches */
 int pcd_graph_enable(pcd_handle h, int on);
 /* Streaming bandwidth of this GPU measured by a kernel of this library
- * (16 B per lane, unit stride): kind 0 copy, 1 triad, arrays of `bytes` each.
+ * (16 B per lane, unit stride): kind 0 copy, 1 triad, 2 read-only sweep,
+ * 3 read-mostly (6 % writes: the mix of the dominant kernel); arrays of
+ * `bytes` each.
  * The practical roof the roofline numbers are quoted next to. */
 int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps,
                         double* gbs);

@@ -281,3 +281,67 @@ def test_device_producer_over_rccl_single_rank(hip_lib, monkeypatch):
     for i, j in zip(out["krylov_per_step"], ref["krylov_per_step"]):
         assert abs(i - j) <= max(1, 0.05 * j)
     assert relerr(out["w"].vector(), ref["w"].vector()) < 1e-5
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_rank_local_handover_equals_global_handover(hip_lib, R):
+    """pcd_set_csr_local: every rank hands over ONLY its own rows (global
+    column ids); ghost columns and send lists come from the set-up handshake.
+    Same results as the hand-over of the global matrices, and value updates
+    carry the rank's entries only."""
+    import scipy.sparse as sp
+    st = flow_state("lshape", 3, dt=0.2)
+    pb, V = st["pb"], st["V"]
+    L = st["L"]
+    rng = np.random.default_rng(31)
+    xp, xu = rng.standard_normal(V.n_p), rng.standard_normal(V.n_u)
+    mats_p = {c.MAT_AP: pb.Ap, c.MAT_MP: pb.Mp, c.MAT_KP: st["Kp"],
+              c.MAT_RP: st["Rp"]}
+
+    def work(local):
+        def body(e, rank):
+            e.set_velocity_block(V.dim)
+            if local:
+                p0, p1 = e.row_range(V.n_p)
+                u0, u1 = e.row_range(V.n_u, velocity=True)
+                assert u0 % V.dim == 0
+                # (a hand-over that is not this rank's block is refused)
+                with pytest.raises(c.EngineError, match="owns"):
+                    e.set_csr_local(c.MAT_AP, sp.csr_matrix(pb.Ap)[p0:p1 - 1]
+                                    if p1 - p0 > 1 else
+                                    sp.csr_matrix(pb.Ap)[p0:p0], pb.Ap.shape)
+                for which, M in mats_p.items():
+                    e.set_csr_local(which, sp.csr_matrix(M)[p0:p1], M.shape)
+                e.set_csr_local(c.MAT_A00, sp.csr_matrix(L["A00"])[u0:u1],
+                                L["A00"].shape)
+                e.set_csr_local(c.MAT_A01, sp.csr_matrix(L["A01"])[u0:u1],
+                                L["A01"].shape)
+            else:
+                for which, M in mats_p.items():
+                    e.set_csr(which, M)
+                e.set_csr(c.MAT_A00, L["A00"])
+                e.set_csr(c.MAT_A01, L["A01"])
+            e.set_bc(pb.bc_p_idx, pb.bc_p_val)
+            set_iter_cfg(e)
+            e.setup()
+            res = {"Kp": e.spmv_np(c.MAT_KP, xp, V.n_p),
+                   "A00": e.spmv_np(c.MAT_A00, xu, V.n_u),
+                   "A01": e.spmv_np(c.MAT_A01, xp, V.n_u),
+                   "pcd": e.apply_np(xp)}
+            # new values: the rank's own entries (local) / everything (global)
+            K2 = sp.csr_matrix(st["Kp"]) * 1.5
+            if local:
+                p0, p1 = e.row_range(V.n_p)
+                e.update_values(c.MAT_KP, K2[p0:p1].data)
+            else:
+                e.update_values(c.MAT_KP, K2.data)
+            res["Kp2"] = e.spmv_np(c.MAT_KP, xp, V.n_p)
+            return res
+        return body
+
+    glob = run_ranks(hip_lib, R, "RBRM1", work(False))
+    loc = run_ranks(hip_lib, R, "RBRM1", work(True))
+    for r in range(R):
+        for k in glob[r]:
+            assert np.array_equal(loc[r][k], glob[r][k]), (r, k)
+    assert relerr(loc[0]["Kp2"], 1.5 * (st["Kp"] @ xp)) < 1e-13
