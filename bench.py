@@ -59,6 +59,10 @@ def parse():
     p.add_argument("--skip-u", default="", help="pc_mg_skip_levels of the "
                    "velocity multigrid (experiment)")
     p.add_argument("--skip-p", default="", help="same for Ap")
+    p.add_argument("--coarse-u", type=int, default=None,
+                   help="fieldsplit_u_pc_mg_coarse_eq_limit: the coarsest "
+                        "velocity level is the largest one of at most this "
+                        "many rows (its inverse is kept explicitly)")
     p.add_argument("--no-producer", action="store_true",
                    help="skip the end-to-end Picard-step timing at the end")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -249,6 +253,8 @@ def main():
         PETScOptions.set("fieldsplit_u_pc_mg_smoothdown", args.smooth_down)
     if args.smooth_up is not None:
         PETScOptions.set("fieldsplit_u_pc_mg_smoothup", args.smooth_up)
+    if args.coarse_u is not None:
+        PETScOptions.set("fieldsplit_u_pc_mg_coarse_eq_limit", args.coarse_u)
     if args.skip_u:
         PETScOptions.set("fieldsplit_u_pc_mg_skip_levels", args.skip_u)
     if args.skip_p:

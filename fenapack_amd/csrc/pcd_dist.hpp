@@ -6,8 +6,10 @@
 // owns of every operator; a column it does not own becomes a *ghost* column
 // whose value arrives in a halo exchange before the SpMV (the MPIAIJ picture
 // PETSc gives the reference, restated for RCCL over xGMI).  Every rank is
-// handed the same global matrices at set-up and cuts its slice out itself, so
-// set-up needs no communication at all; the hot path needs two primitives:
+// handed the same global matrices at set-up (or its own rows only:
+// pcd_set_csr_local) and looks at the rows it owns; what the other ranks need
+// from it arrives in a set-up handshake (localize_owned).  Set-up and the hot
+// path need the same two primitives:
 //   exchange()  - neighbour halo: grouped ncclSend/ncclRecv
 //   allreduce() - dot products / norms: ncclAllReduce(sum, fp64) in place
 // A second backend with the same two primitives runs R "ranks" as R threads of
@@ -449,9 +451,15 @@ struct ThreadBackend : CommBackend {
     if (fail(hipStreamSynchronize(s), "sync")) return 1;
     g->sends[rank] = sends;
     g->barrier();
+    // several messages between one pair of ranks (grouped halos of several
+    // operators) match in posting order, as grouped ncclSend / ncclRecv do
+    std::vector<int> taken(nranks, 0);
     for (const Msg& m : recvs) {
       const Msg* src = nullptr;
-      for (const Msg& q : g->sends[m.peer]) if (q.peer == rank) src = &q;
+      int seen = 0;
+      for (const Msg& q : g->sends[m.peer])
+        if (q.peer == rank && seen++ == taken[m.peer]) { src = &q; break; }
+      ++taken[m.peer];
       if (!src || src->count != m.count) { err = "halo mismatch"; return 1; }
       if (fail(hipMemcpy(m.ptr, src->ptr, m.count * sizeof(double),
                          hipMemcpyDeviceToDevice), "memcpy")) return 1;

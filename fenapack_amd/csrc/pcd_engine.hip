@@ -389,20 +389,36 @@ static inline XVec xvec(const DCsr& A, const double* x) {
 // Neighbour halo exchange of an SpMV input vector (multi-GPU): pack the owned
 // entries other ranks read, grouped send/recv into the ghost buffer.  Every
 // rank calls it for every SpMV (the threaded test backend synchronises there).
-static int halo_exchange(Engine* h, const DCsr& A, const double* x) {
-  if (!h->comm || A.replicated) return 0;
+static void halo_collect(Engine* h, const DCsr& A, const double* x,
+                         std::vector<Msg>& sends, std::vector<Msg>& recvs) {
   const HaloPlan& pl = A.plan;
   const int ns = (int)pl.send_idx.size();
   if (ns)
     hipLaunchKernelGGL(k_pack, dim3(grid1d(ns, 1)), dim3(kBlock), 0, h->stream,
                        ns, A.send_idx.p, x, A.sendbuf.p);
-  std::vector<Msg> sends, recvs;
   for (size_t i = 0; i < pl.peers_send.size(); ++i)
     sends.push_back(Msg{pl.peers_send[i], A.sendbuf.p + pl.send_off[i],
                         (size_t)(pl.send_off[i + 1] - pl.send_off[i])});
   for (size_t i = 0; i < pl.peers_recv.size(); ++i)
     recvs.push_back(Msg{pl.peers_recv[i], A.ghost.p + pl.recv_off[i],
                         (size_t)(pl.recv_off[i + 1] - pl.recv_off[i])});
+}
+static int halo_exchange(Engine* h, const DCsr& A, const double* x) {
+  if (!h->comm || A.replicated) return 0;
+  std::vector<Msg> sends, recvs;
+  halo_collect(h, A, x, sends, recvs);
+  if (h->comm->exchange(sends, recvs, h->stream))
+    return fail(PCD_ERR_COMM, "halo exchange: %s", h->comm->err.c_str());
+  return 0;
+}
+// the halos of several operators in ONE grouped exchange (one latency instead
+// of one per operator); each operator keeps its own ghost buffer
+struct HaloItem { const DCsr* A; const double* x; };
+static int halo_exchange_group(Engine* h, std::initializer_list<HaloItem> items) {
+  if (!h->comm) return 0;
+  std::vector<Msg> sends, recvs;
+  for (const HaloItem& it : items)
+    if (it.A->set && !it.A->replicated) halo_collect(h, *it.A, it.x, sends, recvs);
   if (h->comm->exchange(sends, recvs, h->stream))
     return fail(PCD_ERR_COMM, "halo exchange: %s", h->comm->err.c_str());
   return 0;
@@ -562,7 +578,8 @@ static void launch_spmv_any(Engine* h, const DCsr& A, const double* x,
 // functor carries the second piece, so no extra kernel is needed.
 static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
                 int mode = 0, const double* add = nullptr,
-                const double* x2 = nullptr, int64_t n1 = 0) {
+                const double* x2 = nullptr, int64_t n1 = 0,
+                bool halo_done = false) {
   if (!A.set) return fail(PCD_ERR_STATE, "spmv: operator not set");
   const double* ghost = A.ghost.p;
   int64_t ncols = A.ncols;
@@ -571,7 +588,7 @@ static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
       return fail(PCD_ERR_STATE, "spmv: two-piece input on an operator with a halo");
     if (A.kron && n1 % A.kron) return fail(PCD_ERR_ARG, "spmv: piece boundary splits a node");
     ghost = x2; ncols = n1;
-  } else {
+  } else if (!halo_done) {
     CHK(halo_exchange(h, A, x));
   }
   const bool kron = kron_ok(A, x, y, add, x2);
@@ -1897,12 +1914,15 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   extract_block(n_u, is_u, rowptr, colidx, mp, rp, cc, src);
   CHK(upload_global(h, h->mat[PCD_MAT_A01], &h->sp_u, &h->sp_p, n_u, n_p, rp.data(), cc.data(), nullptr, src.data()));
   h->a10.release(); h->a11.release(); h->a11_src_host.clear();
-  if (!h->comm) {
+  {
+    // (1,0) and (1,1) blocks: w = A z is applied block-wise (velocity block
+    // through its F x I fast path) - with several ranks too, the halos of the
+    // blocks travelling in one grouped exchange (apply_system)
     extract_block(n_p, is_p, rowptr, colidx, mu, rp, cc, src);
-    CHK(upload_csr(h, h->a10, n_p, n_u, rp.data(), cc.data(), nullptr, src.data()));
+    CHK(upload_global(h, h->a10, &h->sp_p, &h->sp_u, n_p, n_u, rp.data(), cc.data(), nullptr, src.data()));
     extract_block(n_p, is_p, rowptr, colidx, mp, rp, cc, src);
-    CHK(upload_csr(h, h->a11, n_p, n_p, rp.data(), cc.data(), nullptr, src.data()));
-    h->a11_src_host = src;
+    CHK(upload_global(h, h->a11, &h->sp_p, &h->sp_p, n_p, n_p, rp.data(), cc.data(), nullptr, src.data()));
+    h->a11_src_host = src;               // (positions in the caller's values, all rows)
   }
   extract_block(n, perm.data(), rowptr, colidx, ma, rp, cc, src);
   CHK(upload_global(h, h->mat[PCD_MAT_A], &h->sp_sys, &h->sp_sys, n, n, rp.data(), cc.data(), nullptr, src.data()));
@@ -2299,13 +2319,21 @@ static int dev_norm(Engine* h, int64_t n, const double* v, double* out) {
 // A00 (F x I fast path), A01, A10 (and A11 if it is not zero) - about half
 // the bytes of the monolithic CSR; otherwise the monolithic operator.
 static int apply_system(Engine* h, const double* z, double* w) {
-  if (h->comm || !h->p_is_a || !h->a10.set || !h->mat[PCD_MAT_A00].set || !h->mat[PCD_MAT_A01].set)
+  static const bool mono = [] { const char* e = getenv("PCD_SYSTEM_MONOLITHIC"); return e && e[0] == '1'; }();
+  if (mono || !h->p_is_a || !h->a10.set || !h->mat[PCD_MAT_A00].set || !h->mat[PCD_MAT_A01].set)
     return spmv(h, h->mat[PCD_MAT_A], z, w);
-  const int64_t nu = h->n_u;
-  CHK(spmv(h, h->mat[PCD_MAT_A00], z, w));
-  CHK(spmv(h, h->mat[PCD_MAT_A01], z + nu, w, 1, w));
-  CHK(spmv(h, h->a10, z, w + nu));
-  if (!h->a11_zero) CHK(spmv(h, h->a11, z + nu, w + nu, 1, w + nu));
+  const int64_t nu = h->nu_loc;
+  const DCsr &A00 = h->mat[PCD_MAT_A00], &A01 = h->mat[PCD_MAT_A01];
+  const bool with11 = !h->a11_zero;
+  if (h->comm) {
+    // one grouped exchange carries the ghosts of every block
+    if (with11) CHK(halo_exchange_group(h, {{&A00, z}, {&A01, z + nu}, {&h->a10, z}, {&h->a11, z + nu}}));
+    else CHK(halo_exchange_group(h, {{&A00, z}, {&A01, z + nu}, {&h->a10, z}}));
+  }
+  CHK(spmv(h, A00, z, w, 0, nullptr, nullptr, 0, true));
+  CHK(spmv(h, A01, z + nu, w, 1, w, nullptr, 0, true));
+  CHK(spmv(h, h->a10, z, w + nu, 0, nullptr, nullptr, 0, true));
+  if (with11) CHK(spmv(h, h->a11, z + nu, w + nu, 1, w + nu, nullptr, 0, true));
   return 0;
 }
 

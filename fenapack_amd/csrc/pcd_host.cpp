@@ -26,9 +26,15 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-static int nthreads() {
-  int t = g_threads > 0 ? g_threads : omp_get_max_threads();
-  return std::max(1, std::min(t, 256));
+// Threads for a job of `work` items: one per 32 k items, at most 32 (or what
+// pcdh_set_threads asked for).  Small set-ups - the test suite builds
+// thousands of tiny patterns - stay serial: waking a 256-thread team for a few
+// thousand entries costs more than the work, and idle OpenMP workers spinning
+// next to the other runtimes of the process (BLAS, torch) slow everything.
+static int nthreads(int64_t work = INT64_MAX) {
+  int cap = g_threads > 0 ? g_threads : std::min(omp_get_max_threads(), 32);
+  int64_t t = std::min<int64_t>(cap, work / 32768);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(t, 256));
 }
 
 // ---------------------------------------------------------------- grouping
@@ -48,7 +54,7 @@ struct pcdh_group_s {
 template <class RowF, class ColF>
 static int group_impl(int64_t n, RowF row, ColF col, int64_t nrows, int64_t row0,
                       int64_t row1, pcdh_group_s* g) {
-  const int T = nthreads();
+  const int T = nthreads(n);
   const int64_t nk = row1 - row0;
   g->n = n; g->nrows_kept = nk; g->row0 = row0;
   g->indptr.assign(nk + 1, 0);
@@ -226,7 +232,7 @@ int64_t pcdh_group_kept(pcdh_group g) { return g ? g->kept : -1; }
 int pcdh_group_export(pcdh_group g, int64_t* indptr, int64_t* ucols, int64_t* inv,
                       int64_t* ptr, int64_t* order) {
   if (!g) return fail(PCDH_ERR_ARG, "group_export: null group");
-  const int T = nthreads();
+  const int T = nthreads(g->n);
   if (indptr) std::copy(g->indptr.begin(), g->indptr.end(), indptr);
   if (ucols) std::copy(g->ucols.begin(), g->ucols.end(), ucols);
   if (ptr) std::copy(g->ptr.begin(), g->ptr.end(), ptr);
@@ -248,7 +254,7 @@ int pcdh_extract_count(int64_t nr, const int32_t* rows, const int32_t* rowptr,
                        const int32_t* col, const int32_t* colmap, int32_t* orp) {
   if (nr < 0 || !rows || !rowptr || !col || !colmap || !orp)
     return fail(PCDH_ERR_ARG, "extract_count: bad arguments");
-  const int T = nthreads();
+  const int T = nthreads(nr * 8);
   orp[0] = 0;
 #pragma omp parallel for schedule(static, 4096) num_threads(T)
   for (int64_t i = 0; i < nr; ++i) {
@@ -270,7 +276,7 @@ int pcdh_extract_fill(int64_t nr, const int32_t* rows, const int32_t* rowptr,
                       int32_t* oc, int64_t* osrc) {
   if (nr < 0 || !rows || !rowptr || !col || !colmap || !orp || (orp[nr] && (!oc || !osrc)))
     return fail(PCDH_ERR_ARG, "extract_fill: bad arguments");
-  const int T = nthreads();
+  const int T = nthreads(nr * 8);
 #pragma omp parallel num_threads(T)
   {
     std::vector<std::pair<int32_t, int64_t>> tmp;
@@ -320,7 +326,7 @@ int pcdh_spgemm_count(int64_t row0, int64_t row1, int64_t b_cols,
                       const int32_t* bc, int64_t* crp) {
   if (row0 < 0 || row1 < row0 || b_cols < 0 || !arp || !brp || !crp)
     return fail(PCDH_ERR_ARG, "spgemm_count: bad arguments");
-  const int T = nthreads();
+  const int T = nthreads((row1 - row0) * 64);
   crp[0] = 0;
 #pragma omp parallel num_threads(T)
   {
@@ -346,7 +352,7 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols, const int32_t* 
                      int32_t* cc, double* cv) {
   if (row0 < 0 || row1 < row0 || !arp || !brp || !crp || (crp[row1 - row0] && (!cc || !cv)))
     return fail(PCDH_ERR_ARG, "spgemm_fill: bad arguments");
-  const int T = nthreads();
+  const int T = nthreads((row1 - row0) * 64);
 #pragma omp parallel num_threads(T)
   {
     std::vector<int64_t> where(b_cols, -1);     // column -> slot of the current row
@@ -400,7 +406,7 @@ int pcdh_union_fill(int64_t n, int nb, const int64_t* nr, const int32_t* const* 
   if (n < 0 || nb < 1 || !nr || !rowmap || !colmap || !indptr || !indices || !data_off ||
       !out_indptr || !out_indices || !out_order)
     return fail(PCDH_ERR_ARG, "union_fill: bad arguments");
-  const int T = nthreads();
+  const int T = nthreads(n * 16);
   // global row -> (block, block row) lists: a row may appear in several blocks
   std::vector<int32_t> inv((size_t)nb * n, -1);
   for (int b = 0; b < nb; ++b)
