@@ -452,6 +452,7 @@ def main():
         "copy": eng.bandwidth_probe("copy", 1 << 30, 5),
         "read": eng.bandwidth_probe("read", 1 << 30, 5),
         "read_mostly": eng.bandwidth_probe("read_mostly", 1 << 30, 5),
+        "read_nontemporal": eng.bandwidth_probe("read_nt", 1 << 30, 5),
         "read_cache_resident_96MiB": eng.bandwidth_probe("read", 96 << 20, 20),
         "read_mostly_cache_resident_96MiB":
             eng.bandwidth_probe("read_mostly", 96 << 20, 20),

@@ -444,7 +444,8 @@ class Engine(object):
         triad, read-only sweep, read-mostly (6 % writes)."""
         out = C.c_double(0.0)
         self._call("bandwidth_probe",
-                   {"copy": 0, "triad": 1, "read": 2, "read_mostly": 3}[kind],
+                   {"copy": 0, "triad": 1, "read": 2, "read_mostly": 3,
+                    "read_nt": 4}[kind],
                    int(nbytes), int(reps), C.byref(out))
         return out.value
 

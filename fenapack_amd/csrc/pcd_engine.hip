@@ -101,7 +101,7 @@ struct DCsr {
   int kron = 0;
   int kron_pat = 0;       // components the PATTERN admits (kron: values agree too)
   int rb2 = 0;
-  bool pipe2 = false;     // every rb2-row block of F fits ONE pass through the tile: pipelined kernels
+  bool nt2 = false;       // F (x) I launches move more than the Infinity Cache holds: stream val/col non-temporally
   int64_t nnz2 = 0;
   DBuf<int> rowptr2, col2, kron_pos;
   DBuf<double> val2;
@@ -118,7 +118,7 @@ struct DCsr {
     vals.release(); val2s.release();
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); kron_pos.release();
-    val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0; pipe2 = false;
+    val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
     plan = HaloPlan(); replicated = false;
     set = false; nrows = ncols = nnz = 0; has_src = false;
   }
@@ -229,14 +229,6 @@ struct pcd_engine_s {
   double* pinned = nullptr;           // host-pinned scratch
   size_t pinned_n = 0;
   long num_pcd = 0, num_fs = 0;
-  // Side stream: work that is off the critical path of a cycle (the
-  // pre-smoothing of a pre-composed level is needed only on the way up) runs
-  // beside it; fork / join through events, which a stream capture turns into
-  // parallel branches of the graph.  One GPU only.
-  hipStream_t side = nullptr;
-  hipEvent_t sev[32] = {};
-  int sev_next = 0;
-  bool side_on = false;               // PCD_SIDE_STREAM=1: A/B switch (off: see DESIGN.md 4)
   // hipGraph replay of the fixed-iteration fieldsplit apply
   bool graph_on = false;
   hipGraphExec_t gexec = nullptr;
@@ -326,24 +318,10 @@ static inline int grid_stream(int64_t nrows, int rb, int cap = 1 << 20) {
   return (int)((g + 7) / 8 * 8);
 }
 static bool g_force_vector = false;   // PCD_FORCE_CSR_VECTOR=1: A/B switch
-// Software-pipelined persistent stream kernels (k_*_scp): PCD_PIPE=0 switches
-// them off (A/B), PCD_PIPE_WGS = resident workgroups per CU they are sized for
-// (default: what the LDS tile admits - 5 with 32 KiB, 4 with 36 KiB).
-static bool g_pipe = true;
-static int g_pipe_wgs = 0;
+// operators whose launches move more than this stream their matrix arrays with
+// non-temporal loads (PCD_NT_BYTES; -1: never): beyond the 256 MiB Infinity Cache
+static long long g_nt_bytes = 256ll << 20;
 static int g_num_cus = 256;
-// persistent grid: as many workgroups as stay resident, every one walking the
-// same number of row blocks (a multiple of 8 for the XCD-aware ranges)
-static inline int grid_pipe(int64_t nrows, int rb, int lds_bytes) {
-  if (rb <= 0) rb = 32;
-  const int64_t nrb = std::max<int64_t>((nrows + rb - 1) / rb, 1);
-  const int per_cu = g_pipe_wgs > 0 ? g_pipe_wgs : std::max(1, std::min(8, (160 * 1024) / lds_bytes));
-  const int64_t slots = (int64_t)g_num_cus * per_cu;
-  const int64_t per = (nrb + slots - 1) / slots;          // row blocks per workgroup
-  const int64_t g = (nrb + per - 1) / per;
-  return (int)((g + 7) / 8 * 8);
-}
-
 static int ensure_pinned(Engine* h, size_t n) {
   if (n <= h->pinned_n) return 0;
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -438,18 +416,23 @@ static int reduce_global(Engine* h, double* parts, int nparts, double* slot,
   return 0;
 }
 
-#define LAUNCH_RBC_(NC, A, KERNEL, GRID, ...)                                   \
+#define LAUNCH_RBC__(NC, NT, A, KERNEL, GRID, ...)                              \
   do {                                                                          \
     switch ((A).rb2) {                                                          \
-      case 256: hipLaunchKernelGGL((KERNEL<256, NC>), dim3(GRID), dim3(kBlock), \
+      case 256: hipLaunchKernelGGL((KERNEL<256, NC, NT>), dim3(GRID), dim3(kBlock), \
                                    0, h->stream, __VA_ARGS__); break;           \
-      case 128: hipLaunchKernelGGL((KERNEL<128, NC>), dim3(GRID), dim3(kBlock), \
+      case 128: hipLaunchKernelGGL((KERNEL<128, NC, NT>), dim3(GRID), dim3(kBlock), \
                                    0, h->stream, __VA_ARGS__); break;           \
-      case 64: hipLaunchKernelGGL((KERNEL<64, NC>), dim3(GRID), dim3(kBlock),   \
+      case 64: hipLaunchKernelGGL((KERNEL<64, NC, NT>), dim3(GRID), dim3(kBlock),   \
                                   0, h->stream, __VA_ARGS__); break;            \
-      default: hipLaunchKernelGGL((KERNEL<32, NC>), dim3(GRID), dim3(kBlock),   \
+      default: hipLaunchKernelGGL((KERNEL<32, NC, NT>), dim3(GRID), dim3(kBlock),   \
                                   0, h->stream, __VA_ARGS__); break;            \
     }                                                                           \
+  } while (0)
+#define LAUNCH_RBC_(NC, A, KERNEL, GRID, ...)                                   \
+  do {                                                                          \
+    if ((A).nt2) LAUNCH_RBC__(NC, true, A, KERNEL, GRID, __VA_ARGS__);          \
+    else LAUNCH_RBC__(NC, false, A, KERNEL, GRID, __VA_ARGS__);                 \
   } while (0)
 #define LAUNCH_RBC(A, KERNEL, GRID, ...)                                        \
   do {                                                                          \
@@ -493,31 +476,26 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
                        nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y);
     return;
   }
-  if (A.pipe2 && g_pipe) {
-    const int gp = grid_pipe(nn, A.rb2, (int)(tile_c<NC>() * sizeof(VecC<NC>)));
-    switch (A.rb2) {
-      case 256: hipLaunchKernelGGL((k_spmv_scp<256, MODE, NC>), dim3(gp), dim3(kBlock), 0, h->stream,
-                                   nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
-      case 128: hipLaunchKernelGGL((k_spmv_scp<128, MODE, NC>), dim3(gp), dim3(kBlock), 0, h->stream,
-                                   nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
-      case 64: hipLaunchKernelGGL((k_spmv_scp<64, MODE, NC>), dim3(gp), dim3(kBlock), 0, h->stream,
-                                  nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
-      default: hipLaunchKernelGGL((k_spmv_scp<32, MODE, NC>), dim3(gp), dim3(kBlock), 0, h->stream,
-                                  nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
-    }
-    return;
-  }
   const int g = grid_stream(nn, A.rb2);
-  switch (A.rb2) {
-    case 256: hipLaunchKernelGGL((k_spmv_sc<256, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
-    case 128: hipLaunchKernelGGL((k_spmv_sc<128, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                 nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
-    case 64: hipLaunchKernelGGL((k_spmv_sc<64, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
-    default: hipLaunchKernelGGL((k_spmv_sc<32, MODE, NC>), dim3(g), dim3(kBlock), 0, h->stream,
-                                nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y); break;
+#define PCD_SPMV_SC(RB, NT)                                                               \
+  hipLaunchKernelGGL((k_spmv_sc<RB, MODE, NC, NT>), dim3(g), dim3(kBlock), 0, h->stream, \
+                     nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y)
+  if (A.nt2) {
+    switch (A.rb2) {
+      case 256: PCD_SPMV_SC(256, true); break;
+      case 128: PCD_SPMV_SC(128, true); break;
+      case 64: PCD_SPMV_SC(64, true); break;
+      default: PCD_SPMV_SC(32, true); break;
+    }
+  } else {
+    switch (A.rb2) {
+      case 256: PCD_SPMV_SC(256, false); break;
+      case 128: PCD_SPMV_SC(128, false); break;
+      case 64: PCD_SPMV_SC(64, false); break;
+      default: PCD_SPMV_SC(32, false); break;
+    }
   }
+#undef PCD_SPMV_SC
 }
 
 template <int MODE>
@@ -682,12 +660,6 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
   CHK(halo_exchange(h, A, pk));
   if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
-    if (A.pipe2 && g_pipe) {
-      const int lds = A.kron == 2 ? (int)(tile_c<2>() * sizeof(VecC<2>)) : (int)(tile_c<3>() * sizeof(VecC<3>));
-      LAUNCH_RBC(A, k_cheb_step_scp, grid_pipe(nn, A.rb2, lds), nn, A.rowptr2.p, A.col2.p,
-                 A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
-                 (int)(A.ncols / A.kron));
-    } else
     LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
                (int)(A.ncols / A.kron));
@@ -712,12 +684,6 @@ static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
   const int n = (int)A.nrows;
   if (kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;
-    if (A.pipe2 && g_pipe) {
-      const int lds = A.kron == 2 ? (int)(tile_c<2>() * sizeof(VecC<2>)) : (int)(tile_c<3>() * sizeof(VecC<3>));
-      LAUNCH_RBC(A, k_cheb_first_scp, grid_pipe(nn, A.rb2, lds), nn, A.rowptr2.p, A.col2.p,
-                 A.val2s.p, dinv, b, p0, pn, s, c1, c2);
-      return;
-    }
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2s.p, dinv, b, p0, pn, s, c1, c2);
     return;
@@ -922,48 +888,6 @@ static int solve_rich(Engine* h, const DCsr& A, Inner& s, const double* b,
   return 0;
 }
 
-// ---- fork / join on the side stream ------------------------------------------
-static int side_event(Engine* h, hipEvent_t* ev) {
-  hipEvent_t& e = h->sev[h->sev_next];
-  h->sev_next = (h->sev_next + 1) % 32;
-  if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  *ev = e;
-  return 0;
-}
-static bool side_usable(Engine* h) { return h->side_on && !h->comm; }
-// stream and events exist before anything is captured (object creation inside
-// a stream capture is not something to rely on)
-static int side_prepare(Engine* h) {
-  if (!side_usable(h)) return 0;
-  if (!h->side) HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  for (auto& e : h->sev)
-    if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  return 0;
-}
-// from here on launches go to the side stream, ordered after everything the
-// main stream has been given so far; *main_stream remembers where to return
-static int side_fork(Engine* h, hipStream_t* main_stream) {
-  if (!h->side) HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  hipEvent_t ev;
-  CHK(side_event(h, &ev));
-  HIPCHK(hipEventRecord(ev, h->stream));
-  HIPCHK(hipStreamWaitEvent(h->side, ev, 0));
-  *main_stream = h->stream;
-  h->stream = h->side;
-  return 0;
-}
-// back to the main stream; *done fires when the side work has finished
-static int side_return(Engine* h, hipStream_t main_stream, hipEvent_t* done) {
-  CHK(side_event(h, done));
-  HIPCHK(hipEventRecord(*done, h->side));
-  h->stream = main_stream;
-  return 0;
-}
-static int side_join(Engine* h, hipEvent_t done) {
-  HIPCHK(hipStreamWaitEvent(h->stream, done, 0));
-  return 0;
-}
-
 // ---- [ext PETSc] PCMG: multiplicative V-cycle on the device -----------------
 // Chebyshev-Jacobi smoothing; every step is one fused k_cheb_step launch.
 // Iterates rotate through bufs[0..2]; with a nonzero guess the guess sits in
@@ -1035,31 +959,21 @@ static int mg_vcycle(Engine* h, const DCsr& Afine, Inner& s, int l,
     // x = Wu [T | b]
     const int64_t n = A.nrows, nc = L.P.ncols;
     double* T = L.T.p;
-    // x1 = pre-smoothing of b is needed only by the up-sweep: it runs on the
-    // side stream while the main one goes down (r_c = Wd b reads b alone)
-    const bool fork = side_usable(h);
-    hipStream_t main_stream = nullptr;
-    hipEvent_t x1_ready = nullptr;
-    if (fork) CHK(side_fork(h, &main_stream));
     {
       // ring arranged so that the smoothed vector lands in T[0, n)
       const int last = (s.nu_pre - 1) % 3;
       double* ring[3];
       ring[last] = T; ring[(last + 1) % 3] = L.t0.p; ring[(last + 2) % 3] = L.t1.p;
       double* px = nullptr;
-      int rc = mg_smooth(h, A, L.emin, L.emax, s.nu_pre, b, ring, true, &px);
-      if (!rc && px != T &&
-          hipMemcpyAsync(T, px, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
-        rc = fail(PCD_ERR_HIP, "fused level: copy of the smoothed vector failed");
-      if (fork) { const int r2 = side_return(h, main_stream, &x1_ready); if (!rc) rc = r2; }
-      CHK(rc);
+      CHK(mg_smooth(h, A, L.emin, L.emax, s.nu_pre, b, ring, true, &px));
+      if (px != T)
+        HIPCHK(hipMemcpyAsync(T, px, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
     CHK(spmv(h, L.Wd, b, T + n));
     double* pe = nullptr;
     CHK(mg_vcycle(h, Afine, s, l - 1, T + n, &pe, T + n + nc));
     if (pe != T + n + nc)
       HIPCHK(hipMemcpyAsync(T + n + nc, pe, nc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    if (fork) CHK(side_join(h, x1_ready));
     double* dst = target ? target : L.x.p;
     CHK(spmv(h, L.Wu, T, dst, 0, nullptr, b, n + 2 * nc));
     *out = dst;
@@ -1284,9 +1198,7 @@ static int fs_apply_split(Engine* h, const double* x, double* y) {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     if (!h->cap_stream)
       HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-    CHK(side_prepare(h));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->side) HIPCHK(hipStreamSynchronize(h->side));
     hipStream_t saved = h->stream;
     h->stream = h->cap_stream;
     hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
@@ -1434,14 +1346,8 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
     HIPCHK(hipMemcpy(A.kron_pos.p + c * A.nnz2, pos[c].data(), A.nnz2 * sizeof(int),
                      hipMemcpyHostToDevice));
   A.kron = A.kron_pat = nc; A.rb2 = rb2;
-  A.pipe2 = false;
-  if (rb2) {
-    const int tile = nc == 3 ? tile_c<3>() : tile_c<2>();
-    bool one_pass = tile % kBlock == 0;
-    for (int64_t r = 0; r < nn && one_pass; r += rb2)
-      if (rpc[std::min<int64_t>(r + rb2, nn)] - rpc[r] > tile) one_pass = false;
-    A.pipe2 = one_pass;
-  }
+  // bytes one fused step moves: F (12 B / entry) + five vector streams
+  A.nt2 = g_nt_bytes >= 0 && 12.0 * (double)A.nnz2 + 40.0 * (double)nrows > (double)g_nt_bytes;
   if (have_vals) CHK(refresh_kron(h, A));
   return 0;
 }
@@ -1630,17 +1536,10 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
   { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
   { const char* e = getenv("PCD_MAX_CHUNKS"); if (e && atoi(e) >= 1) g_max_chunks = atoi(e); }
-  { const char* e = getenv("PCD_PIPE"); g_pipe = !(e && e[0] == '0'); }
-  { const char* e = getenv("PCD_PIPE_WGS"); g_pipe_wgs = e ? atoi(e) : 0; }
+  { const char* e = getenv("PCD_NT_BYTES"); if (e) g_nt_bytes = atoll(e); }
   { hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       g_num_cus = prop.multiProcessorCount; }
-  // measured (profiles/r02_l_*): every cross-stream event join costs 6-12 us
-  // on this stack, in eager launches and under graph replay alike - more than
-  // the 5 us kernel it takes off the critical path (0.324 -> 0.368 ms per
-  // PCApply).  The fork/join code stays as an experiment switch.
-  bool want_side = false;
-  { const char* e = getenv("PCD_SIDE_STREAM"); want_side = e && e[0] == '1'; }
   { const char* e = getenv("PCD_NO_XCD_REMAP");
     if (e && e[0] == '1') {
       const int none = 0;
@@ -1649,7 +1548,6 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   Engine* h = new (std::nothrow) Engine();
   if (!h) return fail(PCD_ERR_NOMEM, "create: out of host memory");
   h->variant = variant; h->device = device;
-  h->side_on = want_side;
   *out = h;
   return 0;
 }
@@ -1658,7 +1556,6 @@ int pcd_destroy(pcd_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  if (h->side) (void)hipStreamSynchronize(h->side);
   fe_release(h);
   h->a10.release(); h->a11.release();
   for (auto& m : h->mat) m.release();
@@ -1676,8 +1573,6 @@ int pcd_destroy(pcd_handle h) {
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-  if (h->side) (void)hipStreamDestroy(h->side);
-  for (auto& e : h->sev) if (e) (void)hipEventDestroy(e);
   delete h;
   return 0;
 }
@@ -2233,7 +2128,6 @@ int pcd_setup(pcd_handle h) {
   }
   CHK(h->w[0].ensure(np)); CHK(h->w[1].ensure(np));
   for (int s = 0; s < PCD_KSP_COUNT; ++s) CHK(inner_prepare(h, s));
-  CHK(side_prepare(h));
   h->ready = true; ++h->gen;
   return 0;
 }
@@ -2568,38 +2462,45 @@ int pcd_set_velocity_block(pcd_handle h, int ncomp) {
 }
 
 // Streaming bandwidth of this GPU as a kernel of this library sees it:
-// kind 0 copy, 1 triad, 2 read-only, 3 read-mostly (6 % writes), on arrays of
+// kind 0 copy, 1 triad, 2 read-only, 3 read-mostly (6 % writes), 4 read-only
+// with non-temporal loads, on arrays of
 // `bytes` each (>= 256 MiB: beyond the
 // Infinity Cache), best of `reps` launches, timed with events on the engine's
 // stream.  *gbs = bytes moved (reads + writes) per second / 1e9.
 int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double* gbs) {
   if (!h || !gbs) return fail(PCD_ERR_ARG, "bandwidth_probe: null argument");
-  if (kind < 0 || kind > 3 || bytes < 1024 || reps < 1) return fail(PCD_ERR_ARG, "bandwidth_probe: bad arguments");
+  if (kind < 0 || kind > 4 || bytes < 4096 || reps < 1) return fail(PCD_ERR_ARG, "bandwidth_probe: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   const int64_t n2 = bytes / 16;
   DBuf<double> a, b, c;
-  CHK(a.ensure(2 * n2)); CHK(b.ensure(2 * n2));
+  // (read kinds write n2/16 + one 16-byte word per thread into `a`)
+  CHK(a.ensure(kind >= 2 ? 2 * (n2 / 16 + (int64_t)g_num_cus * 8 * kBlock + 16) : 2 * n2));
+  CHK(b.ensure(2 * n2));
   if (kind == 1) CHK(c.ensure(2 * n2));
   HIPCHK(hipMemsetAsync(b.p, 0, 16 * n2, h->stream));
   if (kind == 1) HIPCHK(hipMemsetAsync(c.p, 0, 16 * n2, h->stream));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  const int grid = 256 * 8 * 4;              // 32 workgroups per CU
+  // copy / triad: grid-stride, 32 workgroups per CU; read sweeps: one chunk per
+  // workgroup, best of 2, 4 and 8 workgroups per CU
+  const int grids_rw[1] = {g_num_cus * 32};
+  const int grids_rd[3] = {g_num_cus * 2, g_num_cus * 4, g_num_cus * 8};
+  const int* grids = kind >= 2 ? grids_rd : grids_rw;
+  const int ngrids = kind >= 2 ? 3 : 1;
+  const double moved = (kind == 1 ? 3.0 : kind == 0 ? 2.0 : kind == 3 ? 1.0 + 1.0 / 16.0 : 1.0) * 16.0 * (double)n2;
   double best = 0.0;
-  for (int r = 0; r < reps + 1; ++r) {
-    HIPCHK(hipEventRecord(e0, h->stream));
-    hipLaunchKernelGGL(k_bw_probe, dim3(grid), dim3(kBlock), 0, h->stream, kind, n2,
-                       reinterpret_cast<const double2*>(b.p), reinterpret_cast<const double2*>(c.p),
-                       3.0, reinterpret_cast<double2*>(a.p));
-    HIPCHK(hipEventRecord(e1, h->stream));
-    HIPCHK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    // bytes moved: copy 1 read + 1 write, triad 2 + 1, read-only 1 (+ one store
-    // per thread), read-mostly 1 + 1/16 (one store per sixteen loads of a lane)
-    const double moved = (kind == 1 ? 3.0 : kind == 0 ? 2.0 : kind == 3 ? 1.0 + 1.0 / 16.0 : 1.0) * 16.0 * (double)n2;
-    if (r > 0 && ms > 0.f) best = std::max(best, moved / (ms * 1e-3) / 1e9);
-  }
+  for (int gi = 0; gi < ngrids; ++gi)
+    for (int r = 0; r < reps + 1; ++r) {
+      HIPCHK(hipEventRecord(e0, h->stream));
+      hipLaunchKernelGGL(k_bw_probe, dim3(grids[gi]), dim3(kBlock), 0, h->stream, kind, n2,
+                         reinterpret_cast<const double2*>(b.p), reinterpret_cast<const double2*>(c.p),
+                         3.0, reinterpret_cast<double2*>(a.p));
+      HIPCHK(hipEventRecord(e1, h->stream));
+      HIPCHK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0 && ms > 0.f) best = std::max(best, moved / (ms * 1e-3) / 1e9);
+    }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   a.release(); b.release(); c.release();
   *gbs = best;

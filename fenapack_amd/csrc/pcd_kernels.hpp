@@ -374,21 +374,23 @@ __device__ __forceinline__ void row_block_range(int nrb, int rb_rows, int& begin
 constexpr int kUnroll = PCD_UNROLL;
 
 // The matrix arrays are read exactly once per launch; the gathered vector is
-// what should stay in L2.  -DPCD_NT_LOADS=1 marks the matrix stream
-// non-temporal (A/B switch: tools/nt_sweep.sh).
-#ifndef PCD_NT_LOADS
-#define PCD_NT_LOADS 0
-#endif
+// what should stay in cache.  Operators whose launch moves more than the
+// 256 MiB Infinity Cache holds stream val/col NON-TEMPORALLY (template flag NT
+// of the multi-component kernels, chosen per operator by the host): measured
+// on the finest A00 of cavity level 7 (439 MB per launch) 75.9 -> 69.5 us; on
+// level 6 (91 MB, cache-resident between launches) the same hint costs 12 %
+// (profiles/r03_g_pipelined_kernels_negative_result.txt, lib = -DPCD_NT_LOADS).
 // products of three-component operators parked in LDS as three planes of
 // doubles instead of 24-byte records (A/B switch)
 #ifndef PCD_LDS_SOA
 #define PCD_LDS_SOA 1
 #endif
-#if PCD_NT_LOADS
-#define PCD_STREAM_LOAD(p) __builtin_nontemporal_load(p)
-#else
 #define PCD_STREAM_LOAD(p) (*(p))
-#endif
+template <bool NT, class T>
+__device__ __forceinline__ T stream_load(const T* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
 
 template <int RB, class XF>
 __device__ __forceinline__ double stream_row_block(
@@ -400,19 +402,10 @@ __device__ __forceinline__ double stream_row_block(
   const int row = r0 + threadIdx.x / TPR;
   const int sub = threadIdx.x % TPR;
   const bool mine = row < r1;
-#ifdef PCD_FAKE_ROWLEN
-  // TIMING EXPERIMENT ONLY (wrong results): row bounds computed instead of
-  // loaded - what a storage format without the row-pointer round trip
-  // would save per launch (tools/time_small_solve.py)
-  const int k0 = r0 * PCD_FAKE_ROWLEN, k1 = r1 * PCD_FAKE_ROWLEN;
-  const int ra = mine ? (row - r0) * PCD_FAKE_ROWLEN : 0;
-  const int rb = mine ? (row + 1 - r0) * PCD_FAKE_ROWLEN : 0;
-#else
   const int k0 = rowptr[r0], k1 = rowptr[r1];
   // this lane's own row bounds, fetched up front (used after the barrier)
   const int ra = mine ? rowptr[row] - k0 : 0;
   const int rb = mine ? rowptr[row + 1] - k0 : 0;
-#endif
   double s = 0.0;
   // the block's entries pass through the LDS tile in chunks (normally one;
   // the host admits a few more for operators with long rows)
@@ -683,7 +676,7 @@ struct XScaledC {
   }
 };
 
-template <int RB, int NC, class XF>
+template <int RB, int NC, bool NT, class XF>
 __device__ __forceinline__ VecC<NC> stream_row_block_c(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const XF& xf, int r0, int nrows,
@@ -709,8 +702,8 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
       for (int u = 0; u < kUnroll; ++u) {
         const int k = base + u * kBlock + threadIdx.x;
         const bool in = k < k0 + c1;
-        c[u] = in ? PCD_STREAM_LOAD(col + k) : -1;
-        v[u] = in ? PCD_STREAM_LOAD(val + k) : 0.0;
+        c[u] = in ? stream_load<NT>(col + k) : -1;
+        v[u] = in ? stream_load<NT>(val + k) : 0.0;
       }
       VecC<NC> xv[kUnroll];
 #pragma unroll
@@ -759,7 +752,7 @@ __device__ __forceinline__ VecC<NC> stream_row_block_c(
 }
 
 // vectors arrive as plain double* (node-interleaved) and are viewed as VecC
-template <int RB, int MODE, int NC>
+template <int RB, int MODE, int NC, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* x, const double* ghost,
@@ -777,7 +770,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
     const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     VecC<NC> a = vzero<NC>();
     if ((MODE == 1 || MODE == 2) && mine) a = add[row];   // early: hides under phase 1
-    const VecC<NC> s = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
+    const VecC<NC> s = stream_row_block_c<RB, NC, NT>(rowptr, col, val, xf, r0, nrows, lds);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -790,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
   }
 }
 
-template <int RB, int NC>
+template <int RB, int NC, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const double* __restrict__ dinv_,
@@ -815,7 +808,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
       bi = b[row]; d = dinv[row]; xk = pk[row];
       if (c0 != 0.0) xm = pm[row];
     }
-    const VecC<NC> s = stream_row_block_c<RB, NC>(rowptr, col, val, xf, r0, nrows, lds);
+    const VecC<NC> s = stream_row_block_c<RB, NC, NT>(rowptr, col, val, xf, r0, nrows, lds);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -827,7 +820,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
   }
 }
 
-template <int RB, int NC>
+template <int RB, int NC, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ dinv_,
@@ -845,7 +838,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
     const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     VecC<NC> d = vzero<NC>(), bi = d;
     if (mine) { d = dinv[row]; bi = b[row]; }
-    const VecC<NC> sum = stream_row_block_c<RB, NC>(rowptr, col, vals, xf, r0, nrows, lds);
+    const VecC<NC> sum = stream_row_block_c<RB, NC, NT>(rowptr, col, vals, xf, r0, nrows, lds);
     if (mine) {
       VecC<NC> x0, o;
 #pragma unroll
@@ -858,210 +851,6 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
     }
     __syncthreads();
   }
-}
-
-// ---- software-pipelined form (persistent workgroups) ------------------------
-// The kernels above walk one row block in three dependent memory round trips
-// (row pointers -> entries -> gathered vector) and keep 5 workgroups per CU
-// (LDS): counters show the waves waiting on memory two thirds of their cycles
-// (DESIGN.md 4).  Here a workgroup owns a CONTIGUOUS range of row blocks and
-// keeps the NEXT block's matrix entries in flight (registers) while it reduces
-// the current one out of LDS:
-//   * consecutive blocks are adjacent in val/col, so the next block starts at
-//     this block's end - its loads need no row-pointer round trip;
-//   * the row pointers of a block (row bounds, block end) and the end of the
-//     block after it are fetched at the top of an iteration and first used
-//     after the gather phase - their latency hides under it.
-// In steady state one block costs: gather (mostly L1 / L2 hits) -> LDS ->
-// barrier -> reduce -> store; the HBM stream of the matrix runs underneath.
-// Requirement (host): every row block fits ONE pass through the tile and
-// tile == U * kBlock entries (U loads per lane).
-template <int RB, int NC, int U, class XF, class Pre, class Epi>
-__device__ __forceinline__ void stream_blocks_pipelined(
-    const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const XF& xf, int nrows, int rb0, int rb1,
-    VecC<NC>* lds, Pre pre, Epi epi) {
-  if (rb0 >= rb1) return;
-  constexpr int TPR = kBlock / RB;
-  const int tid = threadIdx.x;
-  const int sub = tid % TPR;
-  double* planes = reinterpret_cast<double*>(lds);
-  constexpr int kTileC = U * kBlock;
-  int c[U];
-  double v[U];
-  // prologue: bounds of the first block, then its entries
-  int k0 = rowptr[rb0 * RB];
-  int k1 = rowptr[min((rb0 + 1) * RB, nrows)];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int k = k0 + u * kBlock + tid;
-    const bool in = k < k1;
-    c[u] = in ? PCD_STREAM_LOAD(col + k) : -1;
-    v[u] = in ? PCD_STREAM_LOAD(val + k) : 0.0;
-  }
-  for (int rb = rb0; rb < rb1; ++rb) {
-    const int r0 = rb * RB;
-    const int r1 = min(r0 + RB, nrows);
-    const int row = r0 + tid / TPR;
-    const bool mine = row < r1;
-    // row bounds of THIS block and the end of the NEXT one: used after the
-    // gather phase / the barrier
-    const int ra = mine ? rowptr[row] : 0;
-    const int rbnd = mine ? rowptr[row + 1] : 0;
-    const int k2 = (rb + 1 < rb1) ? rowptr[min(r1 + RB, nrows)] : k1;
-    auto ops = pre(row, mine && sub == 0);
-    VecC<NC> xv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : vzero<NC>();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = u * kBlock + tid;
-      if (c[u] >= 0) {
-        if (PCD_LDS_SOA && NC == 3) {
-#pragma unroll
-          for (int i = 0; i < NC; ++i) planes[i * kTileC + j] = v[u] * xv[u].c[i];
-        } else {
-          VecC<NC> t;
-#pragma unroll
-          for (int i = 0; i < NC; ++i) t.c[i] = v[u] * xv[u].c[i];
-          lds[j] = t;
-        }
-      }
-    }
-    __syncthreads();
-    // next block's entries: in flight during the reduction below
-    if (rb + 1 < rb1) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = k1 + u * kBlock + tid;
-        const bool in = k < k2;
-        c[u] = in ? PCD_STREAM_LOAD(col + k) : -1;
-        v[u] = in ? PCD_STREAM_LOAD(val + k) : 0.0;
-      }
-    }
-    VecC<NC> s = vzero<NC>();
-    for (int j = ra - k0 + sub; j < rbnd - k0; j += TPR) {
-      if (PCD_LDS_SOA && NC == 3) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) s.c[i] += planes[i * kTileC + j];
-      } else {
-        const VecC<NC> t = lds[j];
-#pragma unroll
-        for (int i = 0; i < NC; ++i) s.c[i] += t.c[i];
-      }
-    }
-#pragma unroll
-    for (int m = TPR / 2; m > 0; m >>= 1) {
-#pragma unroll
-      for (int i = 0; i < NC; ++i) s.c[i] += __shfl_xor(s.c[i], m);
-    }
-    if (mine && sub == 0) epi(row, s, ops);
-    __syncthreads();                        // the tile is reused by the next block
-    k0 = k1; k1 = k2;
-  }
-}
-
-template <int NC> struct ChebOps { VecC<NC> bi, d, xk, xm; };
-template <int NC> struct FirstOps { VecC<NC> d, bi; };
-template <int NC> struct AddOps { VecC<NC> a; };
-
-template <int RB, int NC>
-__global__ __launch_bounds__(kBlock) void k_cheb_step_scp(
-    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double* __restrict__ dinv_,
-    const double* b_, const double* pm_, const double* pk_, double* pn_,
-    double c0, double c1, double c2, const double* ghost, int nloc) {
-  constexpr int U = tile_c<NC>() / kBlock;
-  __shared__ VecC<NC> lds[U * kBlock];
-  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_), *pm = vc<NC>(pm_),
-               *pk = vc<NC>(pk_);
-  VecC<NC>* pn = vc<NC>(pn_);
-  const int nrb = (nrows + RB - 1) / RB;
-  int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1);
-  const XVecC<NC> xf{pk, vc<NC>(ghost), nloc};
-  stream_blocks_pipelined<RB, NC, U>(
-      rowptr, col, val, xf, nrows, rb0, rb1, lds,
-      [&](int row, bool lead) {
-        ChebOps<NC> o;
-        o.bi = o.d = o.xk = o.xm = vzero<NC>();
-        if (lead) {
-          o.bi = b[row]; o.d = dinv[row]; o.xk = pk[row];
-          if (c0 != 0.0) o.xm = pm[row];
-        }
-        return o;
-      },
-      [&](int row, const VecC<NC>& s, const ChebOps<NC>& o) {
-        VecC<NC> r;
-#pragma unroll
-        for (int i = 0; i < NC; ++i)
-          r.c[i] = c0 * o.xm.c[i] + c1 * o.xk.c[i] + c2 * o.d.c[i] * (o.bi.c[i] - s.c[i]);
-        pn[row] = r;
-      });
-}
-
-template <int RB, int NC>
-__global__ __launch_bounds__(kBlock) void k_cheb_first_scp(
-    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ vals, const double* __restrict__ dinv_,
-    const double* b_, double* p0_, double* pn_, double s, double c1, double c2) {
-  constexpr int U = tile_c<NC>() / kBlock;
-  __shared__ VecC<NC> lds[U * kBlock];
-  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
-  VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
-  const int nrb = (nrows + RB - 1) / RB;
-  int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1);
-  const XVecC<NC> xf{b, b, nrows};
-  stream_blocks_pipelined<RB, NC, U>(
-      rowptr, col, vals, xf, nrows, rb0, rb1, lds,
-      [&](int row, bool lead) {
-        FirstOps<NC> o;
-        o.d = o.bi = vzero<NC>();
-        if (lead) { o.d = dinv[row]; o.bi = b[row]; }
-        return o;
-      },
-      [&](int row, const VecC<NC>& sum, const FirstOps<NC>& o) {
-        VecC<NC> x0, r;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-          x0.c[i] = s * o.d.c[i] * o.bi.c[i];
-          r.c[i] = c1 * x0.c[i] + c2 * o.d.c[i] * (o.bi.c[i] - s * sum.c[i]);
-        }
-        if (p0) p0[row] = x0;
-        pn[row] = r;
-      });
-}
-
-template <int RB, int MODE, int NC>
-__global__ __launch_bounds__(kBlock) void k_spmv_scp(
-    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double* x, const double* ghost,
-    int nloc, const double* add_, double* y_) {
-  constexpr int U = tile_c<NC>() / kBlock;
-  __shared__ VecC<NC> lds[U * kBlock];
-  const XVecC<NC> xf{vc<NC>(x), vc<NC>(ghost), nloc};
-  const VecC<NC>* add = vc<NC>(add_);
-  VecC<NC>* y = vc<NC>(y_);
-  const int nrb = (nrows + RB - 1) / RB;
-  int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1);
-  stream_blocks_pipelined<RB, NC, U>(
-      rowptr, col, val, xf, nrows, rb0, rb1, lds,
-      [&](int row, bool lead) {
-        AddOps<NC> o;
-        o.a = vzero<NC>();
-        if ((MODE == 1 || MODE == 2) && lead) o.a = add[row];
-        return o;
-      },
-      [&](int row, const VecC<NC>& s, const AddOps<NC>& o) {
-        VecC<NC> r;
-#pragma unroll
-        for (int i = 0; i < NC; ++i)
-          r.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? o.a.c[i] + s.c[i]
-                                          : (MODE == 2 ? o.a.c[i] - s.c[i] : -s.c[i]));
-        y[row] = r;
-      });
 }
 
 // valc[k] = val[pos[k]]; *mismatch |= (val[pos[c*nnzc + k]] differs, c >= 1):
@@ -1135,17 +924,31 @@ __global__ __launch_bounds__(kBlock) void k_bc_set(
 }
 
 // fieldsplit scatter: out[i] = in[perm[i]]  /  out[perm[i]] = in[i]
+// (four independent index -> value chains per thread in flight)
 __global__ __launch_bounds__(kBlock) void k_gather(
     int n, const int* __restrict__ perm, const double* in, double* out) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
-       i += gridDim.x * kBlock)
-    out[i] = in[perm[i]];
+  const int stride = gridDim.x * kBlock;
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const int p0 = perm[i], p1 = perm[i + stride], p2 = perm[i + 2 * stride],
+              p3 = perm[i + 3 * stride];
+    const double v0 = in[p0], v1 = in[p1], v2 = in[p2], v3 = in[p3];
+    out[i] = v0; out[i + stride] = v1; out[i + 2 * stride] = v2; out[i + 3 * stride] = v3;
+  }
+  for (; i < n; i += stride) out[i] = in[perm[i]];
 }
 __global__ __launch_bounds__(kBlock) void k_scatter(
     int n, const int* __restrict__ perm, const double* in, double* out) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
-       i += gridDim.x * kBlock)
-    out[perm[i]] = in[i];
+  const int stride = gridDim.x * kBlock;
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const int p0 = perm[i], p1 = perm[i + stride], p2 = perm[i + 2 * stride],
+              p3 = perm[i + 3 * stride];
+    const double v0 = in[i], v1 = in[i + stride], v2 = in[i + 2 * stride],
+                 v3 = in[i + 3 * stride];
+    out[p0] = v0; out[p1] = v1; out[p2] = v2; out[p3] = v3;
+  }
+  for (; i < n; i += stride) out[perm[i]] = in[i];
 }
 
 // block values from the caller's monolithic value array
@@ -1418,28 +1221,42 @@ __global__ __launch_bounds__(kBlock) void k_dense_c(
 // device copy/triad microbench on the box and report THAT as the practical
 // roof").  kind 0: a = b (16 B/entry-pair moved: 1 read + 1 write);
 // kind 1: a = b + s c (triad: 2 reads + 1 write); kind 2: read-only sweep;
-// kind 3: read-mostly (6 % writes, the mix of the dominant kernel).
+// kind 3: read-mostly (6 % writes, the mix of the dominant kernel); kind 4:
+// read-only with non-temporal loads.
 __global__ __launch_bounds__(kBlock) void k_bw_probe(
     int kind, int64_t n2, const double2* __restrict__ b,
     const double2* __restrict__ c, double s, double2* __restrict__ a) {
   if (kind >= 2) {
-    // kind 2: read-only stream (sum kept in registers, one 16-byte store per
-    // thread at the end); kind 3: the read / write mix of the fused
-    // Chebyshev step (one 16-byte store per sixteen 16-byte loads: 6 % writes).
-    // Four independent loads in flight per lane.
-    double2 acc0 = {0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    // read sweeps: one contiguous chunk per workgroup, eight independent
+    // 16-byte loads per lane in flight - the shape that reads fastest on this
+    // GPU with FEW workgroups per CU (profiles/r03_f_read_bandwidth_sweep.txt:
+    // 6.1-6.5 TB/s at 2-4 per CU against 5.3 at 32; non-temporal 7.1).
+    // kind 2: read-only; kind 3: read-mostly (one 16-byte store per sixteen
+    // loads of a lane: the 6 % writes of the fused Chebyshev step);
+    // kind 4: read-only, non-temporal.
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    const dv2* bb = reinterpret_cast<const dv2*>(b);
+    dv2* aa = reinterpret_cast<dv2*>(a);
+    const int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+    int64_t i = (int64_t)blockIdx.x * per + threadIdx.x;
+    const int64_t end = min(n2, (int64_t)(blockIdx.x + 1) * per);
+    dv2 acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = dv2(0.0);
     int trip = 0;
-    for (; i + 3 * stride < n2; i += 4 * stride, ++trip) {
-      const double2 v0 = b[i], v1 = b[i + stride], v2 = b[i + 2 * stride], v3 = b[i + 3 * stride];
-      acc0.x += v0.x; acc0.y += v0.y; acc1.x += v1.x; acc1.y += v1.y;
-      acc2.x += v2.x; acc2.y += v2.y; acc3.x += v3.x; acc3.y += v3.y;
-      if (kind == 3 && (trip & 3) == 0) a[i >> 4] = acc0;   // 1 store per 16 loads
+    for (; i + 7 * kBlock < end; i += 8 * kBlock, ++trip) {
+      dv2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = kind == 4 ? __builtin_nontemporal_load(bb + i + u * kBlock) : bb[i + u * kBlock];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += v[u];
+      if (kind == 3 && (trip & 1) == 0) aa[i >> 4] = acc[0];   // 1 store per 16 loads
     }
-    for (; i < n2; i += stride) { const double2 v = b[i]; acc0.x += v.x; acc0.y += v.y; }
-    acc0.x += acc1.x + acc2.x + acc3.x; acc0.y += acc1.y + acc2.y + acc3.y;
-    a[(int64_t)blockIdx.x * kBlock + threadIdx.x] = acc0;
+    for (; i < end; i += kBlock) acc[0] += bb[i];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) acc[0] += acc[u];
+    aa[n2 / 16 + (int64_t)blockIdx.x * kBlock + threadIdx.x] = acc[0];
     return;
   }
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;

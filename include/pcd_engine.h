@@ -262,8 +262,8 @@ int pcd_synchronize(pcd_handle h);
 int pcd_graph_enable(pcd_handle h, int on);
 /* Streaming bandwidth of this GPU measured by a kernel of this library
  * (16 B per lane, unit stride): kind 0 copy, 1 triad, 2 read-only sweep,
- * 3 read-mostly (6 % writes: the mix of the dominant kernel); arrays of
- * `bytes` each.
+ * 3 read-mostly (6 % writes: the mix of the dominant kernel), 4 read-only
+ * with non-temporal loads; arrays of `bytes` each.
  * The practical roof the roofline numbers are quoted next to. */
 int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps,
                         double* gbs);

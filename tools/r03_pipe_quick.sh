@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the PCD_PIPE kernels this script A/B-ed were in the tree at commit 82fcaca only (negative result: profiles/r03_g_pipelined_kernels_negative_result.txt)
 # quick GPU check: a slice of the suite with timings + pipelined-kernel A/B
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()"
