@@ -22,7 +22,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
-#include <condition_variable>
+#include <atomic>
+#include <thread>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -402,69 +403,106 @@ struct RcclBackend : CommBackend {
   }
 };
 
-// In-process stand-in: R threads, one engine each, one GPU.  Correct but slow
-// (host barriers); used by the tests only.
+// In-process stand-in: R threads, one engine each, one GPU.  Used by the tests
+// only (RCCL refuses two ranks on one device).  Nothing synchronises a stream:
+// the ranks meet at host barriers to publish pointers, and the ordering of the
+// device work across their streams is carried by events - a rank's copy of a
+// peer's send buffer waits for the event the peer recorded after packing it,
+// and the peer's next pack waits for the event recorded after that copy.
 struct ThreadGroup {
   int nranks;
-  std::mutex mu;
-  std::condition_variable cv;
-  int arrived = 0;
-  uint64_t phase = 0;
+  std::atomic<int> arrived{0};
+  std::atomic<uint64_t> phase{0};
   std::vector<double*> ar_buf;                       // allreduce operands
   std::vector<std::vector<Msg>> sends;               // posted sends per rank
-  std::vector<double> scratch;
-  explicit ThreadGroup(int n) : nranks(n), ar_buf(n, nullptr), sends(n) {}
+  std::vector<hipEvent_t> ev_ready, ev_done;         // per rank
+  explicit ThreadGroup(int n)
+      : nranks(n), ar_buf(n, nullptr), sends(n), ev_ready(n, nullptr), ev_done(n, nullptr) {}
+  // sense-reversing spin barrier: the ranks meet hundreds of thousands of
+  // times in a test run, a condition variable costs tens of microseconds each
   void barrier() {
-    std::unique_lock<std::mutex> lk(mu);
-    const uint64_t ph = phase;
-    if (++arrived == nranks) { arrived = 0; ++phase; cv.notify_all(); }
-    else cv.wait(lk, [&] { return phase != ph; });
+    const uint64_t ph = phase.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nranks) {
+      arrived.store(0, std::memory_order_relaxed);
+      phase.store(ph + 1, std::memory_order_release);
+    } else {
+      int spins = 0;
+      while (phase.load(std::memory_order_acquire) == ph)
+        if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
+    }
   }
 };
 
 struct ThreadBackend : CommBackend {
   ThreadGroup* g = nullptr;
+  double* tmp = nullptr;
+  size_t tmp_n = 0;
+  ~ThreadBackend() override { if (tmp) (void)hipFree(tmp); }
   int fail(hipError_t e, const char* what) {
     if (e == hipSuccess) return 0;
     err = std::string(what) + ": " + hipGetErrorString(e);
     return 1;
   }
-  int allreduce(double* dbuf, size_t count, hipStream_t s) override {
-    if (fail(hipStreamSynchronize(s), "sync")) return 1;
-    g->ar_buf[rank] = dbuf;
-    g->barrier();
-    // every rank sums all operands in rank order: identical results
-    std::vector<double> acc(count, 0.0), tmp(count);
-    for (int r = 0; r < nranks; ++r) {
-      if (fail(hipMemcpy(tmp.data(), g->ar_buf[r], count * sizeof(double),
-                         hipMemcpyDeviceToHost), "memcpy")) return 1;
-      for (size_t i = 0; i < count; ++i) acc[i] += tmp[i];
-    }
-    g->barrier();                                    // all have read
-    if (fail(hipMemcpy(dbuf, acc.data(), count * sizeof(double),
-                       hipMemcpyHostToDevice), "memcpy")) return 1;
-    g->barrier();
+  int events() {
+    if (!g->ev_ready[rank] &&
+        fail(hipEventCreateWithFlags(&g->ev_ready[rank], hipEventDisableTiming), "event")) return 1;
+    if (!g->ev_done[rank] &&
+        fail(hipEventCreateWithFlags(&g->ev_done[rank], hipEventDisableTiming), "event")) return 1;
     return 0;
+  }
+  int allreduce(double* dbuf, size_t count, hipStream_t s) override {
+    if (nranks > 16) { err = "thread backend: at most 16 ranks"; return 1; }
+    if (events()) return 1;
+    if (tmp_n < count) {
+      if (tmp) (void)hipFree(tmp);
+      tmp = nullptr; tmp_n = 0;
+      if (fail(hipMalloc((void**)&tmp, count * sizeof(double)), "hipMalloc")) return 1;
+      tmp_n = count;
+    }
+    g->ar_buf[rank] = dbuf;
+    if (fail(hipEventRecord(g->ev_ready[rank], s), "record")) return 1;
+    g->barrier();                                    // operands published
+    RankBufs bufs;
+    bufs.n = nranks;
+    for (int r = 0; r < nranks; ++r) {
+      bufs.p[r] = g->ar_buf[r];
+      if (r != rank && fail(hipStreamWaitEvent(s, g->ev_ready[r], 0), "wait")) return 1;
+    }
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
+    hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, s, bufs, (int64_t)count, tmp);
+    if (fail(hipEventRecord(g->ev_done[rank], s), "record")) return 1;
+    g->barrier();                                    // every rank has read every operand
+    for (int r = 0; r < nranks; ++r)
+      if (r != rank && fail(hipStreamWaitEvent(s, g->ev_done[r], 0), "wait")) return 1;
+    return fail(hipMemcpyAsync(dbuf, tmp, count * sizeof(double), hipMemcpyDeviceToDevice, s), "memcpy");
   }
   int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs,
                hipStream_t s) override {
-    if (fail(hipStreamSynchronize(s), "sync")) return 1;
+    if (events()) return 1;
     g->sends[rank] = sends;
-    g->barrier();
+    if (fail(hipEventRecord(g->ev_ready[rank], s), "record")) return 1;
+    g->barrier();                                    // send buffers published
     // several messages between one pair of ranks (grouped halos of several
     // operators) match in posting order, as grouped ncclSend / ncclRecv do
     std::vector<int> taken(nranks, 0);
+    int bad = 0;
     for (const Msg& m : recvs) {
       const Msg* src = nullptr;
       int seen = 0;
       for (const Msg& q : g->sends[m.peer])
         if (q.peer == rank && seen++ == taken[m.peer]) { src = &q; break; }
       ++taken[m.peer];
-      if (!src || src->count != m.count) { err = "halo mismatch"; return 1; }
-      if (fail(hipMemcpy(m.ptr, src->ptr, m.count * sizeof(double),
-                         hipMemcpyDeviceToDevice), "memcpy")) return 1;
+      if (!src || src->count != m.count) { err = "halo mismatch"; bad = 1; break; }
+      if (fail(hipStreamWaitEvent(s, g->ev_ready[m.peer], 0), "wait") ||
+          fail(hipMemcpyAsync(m.ptr, src->ptr, m.count * sizeof(double),
+                              hipMemcpyDeviceToDevice, s), "memcpy")) { bad = 1; break; }
     }
-    g->barrier();
+    if (!bad && fail(hipEventRecord(g->ev_done[rank], s), "record")) bad = 1;
+    g->barrier();                                    // all copies are enqueued
+    if (bad) return 1;
+    // my send buffers may be packed again only after my readers' copies
+    for (const Msg& m : sends)
+      if (fail(hipStreamWaitEvent(s, g->ev_done[m.peer], 0), "wait")) return 1;
     return 0;
   }
 };

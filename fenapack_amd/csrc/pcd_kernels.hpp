@@ -903,6 +903,19 @@ __global__ __launch_bounds__(kBlock) void k_sum_parts(const double* parts,
   if (threadIdx.x == 0) slot[blockIdx.x] = s;
 }
 
+// in-process test backend (ranks = threads on one GPU): out = sum over ranks
+// of their operands, added in rank order on every rank (identical results)
+struct RankBufs { const double* p[16]; int n; };
+__global__ __launch_bounds__(kBlock) void k_sum_ranks(RankBufs bufs, int64_t count,
+                                                       double* out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * kBlock) {
+    double s = 0.0;
+    for (int r = 0; r < bufs.n; ++r) s += bufs.p[r][i];
+    out[i] = s;
+  }
+}
+
 // z = x with the subfield BC values inserted (copy + VecSetValues fused):
 // slot[i] = position in val[] of row i's BC value, or -1
 __global__ __launch_bounds__(kBlock) void k_copy_bc(

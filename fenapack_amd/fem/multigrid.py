@@ -117,7 +117,7 @@ def prolongations(Vc, Vf, parent):
     l1d = np.einsum('cij,cnj->cni', Tinv, pts - pc[:, None, 0, :])
     lam = np.concatenate([1.0 - l1d.sum(axis=2, keepdims=True), l1d], axis=2)
     na, nvl = Vf.na, Vf.nvl
-    phi, _ = _p2_basis(lam.reshape(-1, nvl), Vc.local_edges)
+    phi, _ = _p2_basis(lam.reshape(-1, nvl), Vc.local_edges, grad=False)
     phi = phi.reshape(lam.shape[0], na, na)
     rows = np.repeat(Vf.cell_dofs2[:, :, None], na, axis=2)
     cols = np.repeat(Vc.cell_dofs2[parent][:, None, :], na, axis=1)

@@ -83,23 +83,27 @@ def _conical_rule(d, n):
     return np.array(pts), wts / wts.sum()
 
 
-def _p2_basis(lam, edges=((1, 2), (2, 0), (0, 1))):
+def _p2_basis(lam, edges=((1, 2), (2, 0), (0, 1)), grad=True):
     """P2 basis at barycentric points ``lam`` (nq, d+1).
 
     Local dofs: the d+1 vertices, then one per local edge (i, j) in the order
-    of ``edges``.  Returns (phi (nq, na), dphi/dlam (nq, na, d+1)).
+    of ``edges``.  Returns (phi (nq, na), dphi/dlam (nq, na, d+1)); with
+    ``grad=False`` the second item is ``None`` (millions of points: the
+    prolongation weights need the values only).
     """
     nq, nvl = lam.shape
     na = nvl + len(edges)
     phi = np.empty((nq, na))
-    dphi = np.zeros((nq, na, nvl))
+    dphi = np.zeros((nq, na, nvl)) if grad else None
     for i in range(nvl):
         phi[:, i] = lam[:, i] * (2 * lam[:, i] - 1)
-        dphi[:, i, i] = 4 * lam[:, i] - 1
+        if grad:
+            dphi[:, i, i] = 4 * lam[:, i] - 1
     for k, (i, j) in enumerate(edges):
         phi[:, nvl + k] = 4 * lam[:, i] * lam[:, j]
-        dphi[:, nvl + k, i] = 4 * lam[:, j]
-        dphi[:, nvl + k, j] = 4 * lam[:, i]
+        if grad:
+            dphi[:, nvl + k, i] = 4 * lam[:, j]
+            dphi[:, nvl + k, j] = 4 * lam[:, i]
     return phi, dphi
 
 
@@ -161,6 +165,19 @@ class FixedPattern(object):
         return self
 
     @property
+    def inv(self):
+        """Element entry -> CSR slot.  Patterns built as a permutation
+        (``order``: slot -> input position) derive it on first use."""
+        if getattr(self, "_inv", None) is None and hasattr(self, "order"):
+            self._inv = np.empty(self.order.size, dtype=np.int64)
+            self._inv[self.order] = np.arange(self.order.size)
+        return self._inv
+
+    @inv.setter
+    def inv(self, value):
+        self._inv = value
+
+    @property
     def rows(self):
         if not hasattr(self, "_rows"):
             self._rows = np.repeat(np.arange(self.shape[0], dtype=np.int32),
@@ -219,9 +236,8 @@ class FixedPattern(object):
             self.indices = g.ucols.astype(np.int32)
             self.indptr = g.indptr.astype(np.int32)
             g.release()
-        self.inv = np.empty(n, dtype=np.int64)
-        self.inv[order] = np.arange(n)
         self.order = order
+        self.inv = None                      # derived from `order` on demand
         return self
 
     def assemble(self, vals):
@@ -252,6 +268,58 @@ def _kron_rows(S, d, per_row):
     indptr = np.zeros(d * ln.size + 1, dtype=np.int64)
     np.cumsum(np.repeat(ln * per_row, d), out=indptr[1:])
     return indptr, ln, ip
+
+
+class BlockPattern(FixedPattern):
+    """Pattern of a block operator whose components repeat a SCALAR pattern
+    (velocity blocks: ``F (x) I_d``, ``F (x) ones(d, d)``; gradient /
+    divergence blocks).  ``pos[c]`` gives, per scalar entry, its slot in the
+    block CSR for component ``c``; assembly is one scalar ``bincount`` per
+    component plus a scatter - no element-level map of the block (that one,
+    ``inv``, is derived on demand for the few callers that ask)."""
+
+    def __init__(self, scalar, pos, indptr, indices, shape, cell_axes):
+        self.shape = shape
+        self.scalar = scalar
+        self.pos = pos                          # list of int64 arrays (nnz_s,)
+        self.indptr = np.asarray(indptr, dtype=np.int32)
+        self.indices = np.asarray(indices, dtype=np.int32)
+        self.nnz = self.indices.size
+        # how the scalar element map is laid out inside a cell of `vals`:
+        # axes of the scalar (cell, row, col) entries in the vals array
+        self._cell_axes = cell_axes
+
+    @property
+    def inv(self):
+        if getattr(self, "_inv", None) is None:
+            si = self.scalar.inv
+            if self._cell_axes == "T":           # scalar map is (c, j, a)
+                nc = self.scalar_cells
+                si = si.reshape(nc[0], nc[1], nc[2]).transpose(0, 2, 1)
+            self._inv = np.stack([p[si] for p in self.pos], axis=-1).ravel()
+        return self._inv
+
+    def assemble_components(self, comps):
+        """``comps[c]``: element values of component ``c`` laid out like the
+        scalar pattern's element entries."""
+        data = np.zeros(self.nnz)
+        for p, v in zip(self.pos, comps):
+            if v is None:
+                continue
+            data[p] = np.bincount(self.scalar.inv, weights=np.asarray(v).ravel(),
+                                  minlength=self.scalar.nnz)
+        return self.matrix(data)
+
+    def assemble(self, vals):
+        """``vals`` (cells, ..., ncomp): the last axis runs over ``pos``."""
+        vals = np.asarray(vals)
+        ncomp = len(self.pos)
+        v = vals.reshape(-1, ncomp)
+        if self._cell_axes == "T":
+            nc = self.scalar_cells
+            v = vals.reshape(nc[0], nc[2], nc[1], ncomp).transpose(0, 2, 1, 3)
+            v = v.reshape(-1, ncomp)
+        return self.assemble_components([v[:, c] for c in range(ncomp)])
 
 
 class TaylorHood(object):
@@ -402,59 +470,57 @@ class TaylorHood(object):
             pat["PP"] = FixedPattern.from_cells(d1, d1, (self.n_p, self.n_p))
         SS = pat["SS"]
         comp = np.arange(d, dtype=np.int64)
-        invS = SS.inv.reshape(-1, na, na)
-        rowS = SS.rows[invS].astype(np.int64)              # scalar row
+
+        def rows_of(S):
+            return S.rows.astype(np.int64), S.indptr.astype(np.int64)
+
+        rS, ipS = rows_of(SS)
+        lnS = np.diff(ipS)
+        offS = np.arange(SS.nnz, dtype=np.int64) - ipS[rS]   # position in its row
+        colS = SS.indices.astype(np.int64)
         if coupled:
-            # row d*i+k: entries (j, e) sorted by d*j + e
-            indptr, ln, ip = _kron_rows(SS, d, d)
-            base = d * d * ip[rowS] + d * (invS - ip[rowS])
-            inv = (base[..., None, None]
-                   + (comp[:, None] * d) * ln[rowS][..., None, None]
-                   + comp[None, :])
-            idx = (d * SS.indices.astype(np.int64)[:, None] + comp).ravel()
-            # indices of row d*i+k = d*cols(i) + e, identical for every k
-            seg = np.repeat(np.arange(ln.size, dtype=np.int64), d)
-            starts = d * ip[seg]
-            lens = d * ln[seg]
-            off = np.arange(indptr[-1], dtype=np.int64) \
-                - np.repeat(indptr[:-1], lens)
-            indices = idx[np.repeat(starts, lens) + off]
+            # row d*i+k holds (j, e) sorted by d*j + e: d*len_i entries
+            indptr = np.zeros(d * lnS.size + 1, dtype=np.int64)
+            np.cumsum(np.repeat(d * lnS, d), out=indptr[1:])
+            pos = [indptr[d * rS + k] + d * offS + e
+                   for k in range(d) for e in range(d)]
+            indices = np.empty(indptr[-1], dtype=np.int32)
+            for k in range(d):
+                for e in range(d):
+                    indices[pos[k * d + e]] = d * colS + e
         else:
-            indptr, ln, ip = _kron_rows(SS, d, 1)
-            inv = (invS + (d - 1) * ip[rowS])[..., None] \
-                + comp * ln[rowS][..., None]
-            seg = np.repeat(np.arange(ln.size, dtype=np.int64), d)
-            lens = ln[seg]
-            off = np.arange(indptr[-1], dtype=np.int64) \
-                - np.repeat(indptr[:-1], lens)
-            src = np.repeat(ip[seg], lens) + off
-            kk = np.repeat(np.tile(comp, ln.size), lens)
-            indices = d * SS.indices.astype(np.int64)[src] + kk
-        pat["A00"] = FixedPattern.from_csr(indptr, indices, inv.ravel(),
-                                           (self.n_u, self.n_u))
+            indptr = np.zeros(d * lnS.size + 1, dtype=np.int64)
+            np.cumsum(np.repeat(lnS, d), out=indptr[1:])
+            pos = [indptr[d * rS + k] + offS for k in range(d)]
+            indices = np.empty(indptr[-1], dtype=np.int32)
+            for k in range(d):
+                indices[pos[k]] = d * colS + k
+        pat["A00"] = BlockPattern(SS, pos, indptr, indices,
+                                  (self.n_u, self.n_u), "N")
         if other is None:
-            # A01: rows (a, k) -> d*node + k, cols j; inv laid out (c, a, j, k)
+            # A01: rows (a, k) -> d*node + k, cols j; vals laid out (c, a, j, k)
             G = FixedPattern.from_cells(d2, d1, (self.nn, self.n_p))
-            indptr, ln, ip = _kron_rows(G, d, 1)
-            invG = G.inv.reshape(-1, na, nvl)
-            rowG = G.rows[invG].astype(np.int64)
-            inv = (invG + (d - 1) * ip[rowG])[..., None] \
-                + comp * ln[rowG][..., None]
-            seg = np.repeat(np.arange(ln.size, dtype=np.int64), d)
-            lens = ln[seg]
-            off = np.arange(indptr[-1], dtype=np.int64) \
-                - np.repeat(indptr[:-1], lens)
-            indices = G.indices[np.repeat(ip[seg], lens) + off]
-            pat["A01"] = FixedPattern.from_csr(indptr, indices, inv.ravel(),
-                                               (self.n_u, self.n_p))
-            # A10: rows j, cols d*node + k; inv laid out (c, a, j, k) as well
+            rG, ipG = rows_of(G)
+            lnG = np.diff(ipG)
+            offG = np.arange(G.nnz, dtype=np.int64) - ipG[rG]
+            indptr = np.zeros(d * lnG.size + 1, dtype=np.int64)
+            np.cumsum(np.repeat(lnG, d), out=indptr[1:])
+            pos = [indptr[d * rG + k] + offG for k in range(d)]
+            indices = np.empty(indptr[-1], dtype=np.int32)
+            for k in range(d):
+                indices[pos[k]] = G.indices
+            pat["A01"] = BlockPattern(G, pos, indptr, indices,
+                                      (self.n_u, self.n_p), "N")
+            # A10: rows j, cols d*node + k; vals laid out (c, a, j, k) as well,
+            # the scalar element map (c, j, a)
             Gt = FixedPattern.from_cells(d1, d2, (self.n_p, self.nn))
-            invT = Gt.inv.reshape(-1, nvl, na).transpose(0, 2, 1)
-            inv = d * invT[..., None] + comp
+            slot = np.arange(Gt.nnz, dtype=np.int64)
+            pos = [d * slot + k for k in range(d)]
             indices = (d * Gt.indices.astype(np.int64)[:, None] + comp).ravel()
-            pat["A10"] = FixedPattern.from_csr(
-                d * Gt.indptr.astype(np.int64), indices,
-                np.ascontiguousarray(inv).ravel(), (self.n_p, self.n_u))
+            bp = BlockPattern(Gt, pos, d * Gt.indptr.astype(np.int64), indices,
+                              (self.n_p, self.n_u), "T")
+            bp.scalar_cells = (d1.shape[0], nvl, na)
+            pat["A10"] = bp
         setattr(self, key, pat)
         return pat
 
@@ -549,8 +615,11 @@ class TaylorHood(object):
             ug = np.matmul(Uc[c0:c1], self.gradlam[c0:c1].transpose(0, 2, 1))
             wl = np.matmul(self.phi_s[None], ug)                # (c, q, k)
             # w . grad phi_b = sum_k dphi_s[q, b, k] wl[c, q, k]
-            wg = np.einsum('qbk,cqk->cqb', self.dphi_s, wl, optimize=True)
-            wg *= sq[None, :, None]
+            # (batched over the points: (q, c, k) @ (q, k, b) -> (q, c, b))
+            wg = np.matmul(wl.transpose(1, 0, 2),
+                           self.dphi_s.transpose(0, 2, 1))
+            wg *= sq[:, None, None]
+            wg = np.ascontiguousarray(wg.transpose(1, 0, 2))    # (c, q, b)
             out[c0:c1] = np.matmul(wg.transpose(0, 2, 1), wg)
         out *= (delta * self.area)[:, None, None]
         return out
@@ -569,6 +638,8 @@ class TaylorHood(object):
             if delta is not None:
                 S = S + self.p2_supg_cells(U, delta)
         if not newton:
+            if isinstance(pat, BlockPattern):
+                return pat.assemble_components([S] * d)
             vals = np.repeat(S[..., None], d, axis=3)           # (nc,na,na,d)
             return pat.assemble(vals)
         vals = np.zeros(S.shape + (d, d))
@@ -595,6 +666,8 @@ class TaylorHood(object):
         """Velocity mass matrix scale*(u, v) on the decoupled pattern."""
         pat = self._patterns(False)["A00"]
         M = scale * self.p2_mass_cells()
+        if isinstance(pat, BlockPattern):
+            return pat.assemble_components([M] * self.dim)
         return pat.assemble(np.repeat(M[..., None], self.dim, axis=3))
 
     def assemble_A01(self):
@@ -744,11 +817,9 @@ class TaylorHood(object):
                     (iu, ip, A01.indptr, A01.indices),
                     (ip, iu, A10.indptr, A10.indices),
                     (ip, ip, eye, eye[:-1])])
-                inv = np.empty(order.size, dtype=np.int64)
-                inv[order] = np.arange(order.size)
-                pat = FixedPattern.from_csr(indptr, indices, inv,
+                pat = FixedPattern.from_csr(indptr, indices, None,
                                             (self.ndof, self.ndof))
-                pat.order = order
+                pat.order = order            # (inv follows on demand)
             setattr(self, key, pat)
         pat = getattr(self, key)
         vals = np.concatenate([A00.data, A01.data, A10.data,
