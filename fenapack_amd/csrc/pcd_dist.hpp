@@ -416,8 +416,16 @@ struct ThreadGroup {
   std::vector<double*> ar_buf;                       // allreduce operands
   std::vector<std::vector<Msg>> sends;               // posted sends per rank
   std::vector<hipEvent_t> ev_ready, ev_done;         // per rank
+  std::vector<hipStream_t> stream;                   // the stream each rank enqueues on
   explicit ThreadGroup(int n)
-      : nranks(n), ar_buf(n, nullptr), sends(n), ev_ready(n, nullptr), ev_done(n, nullptr) {}
+      : nranks(n), ar_buf(n, nullptr), sends(n), ev_ready(n, nullptr), ev_done(n, nullptr),
+        stream(n, nullptr) {}
+  // all ranks on ONE in-order stream (the tests' default: the null stream):
+  // enqueue order is execution order, the host barriers alone order the work
+  bool one_stream() const {
+    for (int r = 1; r < nranks; ++r) if (stream[r] != stream[0]) return false;
+    return true;
+  }
   // sense-reversing spin barrier: the ranks meet hundreds of thousands of
   // times in a test run, a condition variable costs tens of microseconds each
   void barrier() {
@@ -460,28 +468,39 @@ struct ThreadBackend : CommBackend {
       tmp_n = count;
     }
     g->ar_buf[rank] = dbuf;
-    if (fail(hipEventRecord(g->ev_ready[rank], s), "record")) return 1;
-    g->barrier();                                    // operands published
+    g->stream[rank] = s;
+    g->barrier();                                    // operands + streams published
+    const bool ordered = g->one_stream();            // (same answer on every rank)
+    if (!ordered) {
+      if (fail(hipEventRecord(g->ev_ready[rank], s), "record")) return 1;
+      g->barrier();                                  // every event recorded
+    }
     RankBufs bufs;
     bufs.n = nranks;
     for (int r = 0; r < nranks; ++r) {
       bufs.p[r] = g->ar_buf[r];
-      if (r != rank && fail(hipStreamWaitEvent(s, g->ev_ready[r], 0), "wait")) return 1;
+      if (!ordered && r != rank && fail(hipStreamWaitEvent(s, g->ev_ready[r], 0), "wait")) return 1;
     }
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
     hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, s, bufs, (int64_t)count, tmp);
-    if (fail(hipEventRecord(g->ev_done[rank], s), "record")) return 1;
-    g->barrier();                                    // every rank has read every operand
-    for (int r = 0; r < nranks; ++r)
-      if (r != rank && fail(hipStreamWaitEvent(s, g->ev_done[r], 0), "wait")) return 1;
+    if (!ordered && fail(hipEventRecord(g->ev_done[rank], s), "record")) return 1;
+    g->barrier();                                    // every rank has (enqueued its) read of every operand
+    if (!ordered)
+      for (int r = 0; r < nranks; ++r)
+        if (r != rank && fail(hipStreamWaitEvent(s, g->ev_done[r], 0), "wait")) return 1;
     return fail(hipMemcpyAsync(dbuf, tmp, count * sizeof(double), hipMemcpyDeviceToDevice, s), "memcpy");
   }
   int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs,
                hipStream_t s) override {
     if (events()) return 1;
     g->sends[rank] = sends;
-    if (fail(hipEventRecord(g->ev_ready[rank], s), "record")) return 1;
-    g->barrier();                                    // send buffers published
+    g->stream[rank] = s;
+    g->barrier();                                    // send buffers + streams published
+    const bool ordered = g->one_stream();
+    if (!ordered) {
+      if (fail(hipEventRecord(g->ev_ready[rank], s), "record")) return 1;
+      g->barrier();                                  // every event recorded
+    }
     // several messages between one pair of ranks (grouped halos of several
     // operators) match in posting order, as grouped ncclSend / ncclRecv do
     std::vector<int> taken(nranks, 0);
@@ -493,16 +512,17 @@ struct ThreadBackend : CommBackend {
         if (q.peer == rank && seen++ == taken[m.peer]) { src = &q; break; }
       ++taken[m.peer];
       if (!src || src->count != m.count) { err = "halo mismatch"; bad = 1; break; }
-      if (fail(hipStreamWaitEvent(s, g->ev_ready[m.peer], 0), "wait") ||
+      if ((!ordered && fail(hipStreamWaitEvent(s, g->ev_ready[m.peer], 0), "wait")) ||
           fail(hipMemcpyAsync(m.ptr, src->ptr, m.count * sizeof(double),
                               hipMemcpyDeviceToDevice, s), "memcpy")) { bad = 1; break; }
     }
-    if (!bad && fail(hipEventRecord(g->ev_done[rank], s), "record")) bad = 1;
+    if (!ordered && !bad && fail(hipEventRecord(g->ev_done[rank], s), "record")) bad = 1;
     g->barrier();                                    // all copies are enqueued
     if (bad) return 1;
     // my send buffers may be packed again only after my readers' copies
-    for (const Msg& m : sends)
-      if (fail(hipStreamWaitEvent(s, g->ev_done[m.peer], 0), "wait")) return 1;
+    if (!ordered)
+      for (const Msg& m : sends)
+        if (fail(hipStreamWaitEvent(s, g->ev_done[m.peer], 0), "wait")) return 1;
     return 0;
   }
 };

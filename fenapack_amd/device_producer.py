@@ -389,7 +389,7 @@ class DeviceProducer(object):
         cst = None
         idt = 0.0 if pb.pcdr else pb.idt
         if idt:
-            M = np.einsum('cq,qi,qj->cij', V.wq, V.psi, V.psi) * (idt / pb.nu)
+            M = V.area[:, None, None] * V._ref()["P"][None] * (idt / pb.nu)
             cst = np.bincount(pat.inv, weights=M.ravel(), minlength=pat.nnz)
         self.eng.fe_bind_kp(ptr, src, cst, 1.0 / pb.nu)
         self.nnz_kp = pat.nnz

@@ -114,7 +114,7 @@ def prolongations(Vc, Vf, parent):
     pts = np.concatenate([pf, mids], axis=1)           # P2 nodes of the cell
     T = np.stack([pc[:, k + 1] - pc[:, 0] for k in range(d)], axis=2)
     Tinv = np.linalg.inv(T)                            # (nf, d, d)
-    l1d = np.einsum('cij,cnj->cni', Tinv, pts - pc[:, None, 0, :])
+    l1d = np.matmul(pts - pc[:, None, 0, :], Tinv.transpose(0, 2, 1))
     lam = np.concatenate([1.0 - l1d.sum(axis=2, keepdims=True), l1d], axis=2)
     na, nvl = Vf.na, Vf.nvl
     phi, _ = _p2_basis(lam.reshape(-1, nvl), Vc.local_edges, grad=False)

@@ -303,11 +303,15 @@ class BlockPattern(FixedPattern):
         """``comps[c]``: element values of component ``c`` laid out like the
         scalar pattern's element entries."""
         data = np.zeros(self.nnz)
+        done = {}                       # components that ARE the same array
         for p, v in zip(self.pos, comps):
             if v is None:
                 continue
-            data[p] = np.bincount(self.scalar.inv, weights=np.asarray(v).ravel(),
-                                  minlength=self.scalar.nnz)
+            if id(v) not in done:
+                done[id(v)] = np.bincount(self.scalar.inv,
+                                          weights=np.asarray(v).ravel(),
+                                          minlength=self.scalar.nnz)
+            data[p] = done[id(v)]
         return self.matrix(data)
 
     def assemble(self, vals):
@@ -566,7 +570,7 @@ class TaylorHood(object):
 
     def p2_stiffness_cells(self):
         g, na, nvl = self.gradlam, self.na, self.nvl
-        gg = np.einsum('ckd,cld->ckl', g, g) * self.area[:, None, None]
+        gg = np.matmul(g, g.transpose(0, 2, 1)) * self.area[:, None, None]
         K = gg.reshape(-1, nvl * nvl) @ self._ref()["K"].reshape(nvl * nvl, -1)
         return K.reshape(-1, na, na)
 
@@ -583,7 +587,7 @@ class TaylorHood(object):
         """The same element matrices from the nodal P2 wind ``U`` (nn, d):
         ``C_c = sum_{m,k} |T| (U_m . grad lam_k) Chat[m,k]``."""
         na, nvl = self.na, self.nvl
-        ug = np.einsum('cmd,ckd->cmk', U[self.cell_dofs2], self.gradlam)
+        ug = np.matmul(U[self.cell_dofs2], self.gradlam.transpose(0, 2, 1))
         ug *= self.area[:, None, None]
         C = ug.reshape(-1, na * nvl) @ self._ref()["C"].reshape(na * nvl, -1)
         return C.reshape(-1, na, na)
@@ -691,7 +695,7 @@ class TaylorHood(object):
         pat = self._patterns(False)["PP"]
         g = self.gradlam
         return pat.assemble(self.area[:, None, None]
-                            * np.einsum('cid,cjd->cij', g, g))
+                            * np.matmul(g, g.transpose(0, 2, 1)))
 
     def assemble_Kp(self, nu, U, idt=0.0, robin_edges=None):
         """(1/nu) * (w.grad p, q) [+ (idt/nu) (p, q)]
@@ -699,8 +703,8 @@ class TaylorHood(object):
         demo_navier-stokes-pcd.py:131-135)."""
         pat = self._patterns(False)["PP"]
         # vals[c,i,j] = |T| sum_m (U_m . grad lam_j) int psi_i phi_m / nu
-        ug = np.einsum('cmd,cjd->cmj', U[self.cell_dofs2], self.gradlam)
-        vals = np.einsum('mi,cmj->cij', self._ref()["S"], ug) \
+        ug = np.matmul(U[self.cell_dofs2], self.gradlam.transpose(0, 2, 1))
+        vals = np.matmul(self._ref()["S"].T[None], ug) \
             * (self.area / nu)[:, None, None]
         if idt:
             vals = vals + (idt / nu) * self.area[:, None, None] \
@@ -774,7 +778,7 @@ class TaylorHood(object):
         ``Pe = 0.5*|w|*h*rho/nu; delta = Pe>1 ? 0.5*h*(1-1/Pe)/|w| : 0``."""
         lam = np.full((1, self.nvl), 1.0 / self.nvl)
         phi, _ = _p2_basis(lam, self.local_edges)
-        wmid = np.einsum('a,cak->ck', phi[0], U[self.cell_dofs2])
+        wmid = np.tensordot(U[self.cell_dofs2], phi[0], axes=([1], [0]))
         wnorm = np.linalg.norm(wmid, axis=1)
         h = self.cell_h
         with np.errstate(divide='ignore', invalid='ignore'):

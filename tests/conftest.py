@@ -18,23 +18,20 @@ def _gpus():
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """On a GPU box the suite runs on a few worker processes (pytest-xdist):
-    its time is host set-up of the problems (numpy / scipy / the OpenMP
-    helpers), which parallelises across tests, while the kernels of several
-    processes share the one GPU.  `python -m pytest tests -m gpu` stays the
-    command; `-n 0`, `-p no:xdist` or FENAPACK_AMD_TEST_WORKERS=0 give the
-    serial run.  Without xdist, without a GPU, or with an explicit `-n`
-    nothing changes."""
+    """FENAPACK_AMD_TEST_WORKERS=N spreads the GPU suite over N pytest-xdist
+    workers.  OFF by default: measured on an MI355X box (round 3,
+    gpurun_out/r03_m_*) four workers sharing the one GPU made every test 3-10x
+    slower - the kernels of this path are latency-bound, and processes
+    time-slice the device - for a net 332 s against ~390 s serial.  The suite
+    is kept short by making set-up fast, not by running it in parallel."""
     opt = config.option
     if not hasattr(opt, "numprocesses") or opt.numprocesses is not None:
         return None
     if os.environ.get("PYTEST_XDIST_WORKER") or _gpus() < 1:
         return None
-    want = os.environ.get("FENAPACK_AMD_TEST_WORKERS")
-    n = int(want) if want is not None else min(4, max(1, (os.cpu_count() or 1) // 8))
+    n = int(os.environ.get("FENAPACK_AMD_TEST_WORKERS", "0"))
     if n > 1:
         opt.numprocesses = n
-        # a worker's OpenMP helpers take their share of the cores
         os.environ.setdefault("FENAPACK_AMD_HOST_THREADS",
                               str(max(2, min(32, (os.cpu_count() or 8) // (2 * n)))))
     return None
