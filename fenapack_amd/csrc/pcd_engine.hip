@@ -17,6 +17,7 @@
 #include "pcd_kernels.hpp"
 #include "pcd_fe.hpp"
 #include "pcd_dist.hpp"
+#include "pcd_reorder.hpp"
 
 using namespace pcd;
 
@@ -89,6 +90,9 @@ struct DCsr {
   DBuf<double> vals, val2s;   // column-scaled copies val .* dinv[col] (zero-guess first step)
   DBuf<int64_t> src;      // provenance in the caller's monolithic values
   bool has_src = false;
+  // value refreshes arrive in the CALLER's entry order and go through `src`
+  // (localised row block and / or engine renumbering): staged gather
+  bool val_src = false;
   bool set = false;
   int lpr = 8;
   int rb = 0;             // rows per workgroup of the CSR-stream kernels (0: n/a)
@@ -120,8 +124,20 @@ struct DCsr {
     rowptr2.release(); col2.release(); kron_pos.release();
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
     plan = HaloPlan(); replicated = false;
-    set = false; nrows = ncols = nnz = 0; has_src = false;
+    set = false; nrows = ncols = nnz = 0; has_src = false; val_src = false;
   }
+};
+
+// Engine renumbering of one index space (pcd_reorder.hpp): n2o[new] = caller's
+// index, o2n its inverse; empty = identity.  d_n2o: device copy for the
+// gather / scatter of field vectors that cross the ABI in caller numbering.
+struct Reorder {
+  std::vector<int32_t> n2o, o2n;
+  DBuf<int> d_n2o;
+  bool active() const { return !n2o.empty(); }
+  const int32_t* rows() const { return n2o.empty() ? nullptr : n2o.data(); }
+  const int32_t* cols() const { return o2n.empty() ? nullptr : o2n.data(); }
+  void clear() { n2o.clear(); o2n.clear(); d_n2o.release(); }
 };
 
 // one level of the geometric multigrid hierarchy (level 0 = coarsest)
@@ -169,6 +185,8 @@ struct Inner {
   DBuf<double> slots;                // rank-reduced scalars (multi-GPU)
   DBuf<CgState> state;
   std::vector<Space> mg_space;       // multi-GPU: row space of every level
+  std::vector<Reorder> mg_r;         // engine renumbering of every level
+  std::vector<char> mg_r_known;      // ... decided (identity counts)
   int last_its = 0;
   bool its_on_device = false;
   int state_idx = 0;                 // which of the two state records is final
@@ -202,6 +220,11 @@ struct pcd_engine_s {
   CommBackend* comm = nullptr;
   int rank = 0, nranks = 1;
   int vel_block = 2;                  // velocity components per node
+  // engine renumbering of the velocity / pressure dofs (decided at
+  // pcd_set_system; PCD_REORDER = none | auto | always, default auto)
+  Reorder ru, rp, rs;                  // velocity, pressure, [u; p] system vectors
+  int reorder_mode = 1;
+  DBuf<double> px_s, py_s;            // staging of renumbered field vectors
   Space sp_u, sp_p, sp_sys;
   DBuf<double> loc_x, loc_y;          // local slices for host-pointer calls
   std::vector<double> bc_val_host;
@@ -1415,6 +1438,7 @@ static int upload_global(Engine* h, DCsr& A, const Space* rs, const Space* cs,
                          const int32_t* col, const double* val,
                          const int64_t* src) {
   A.gnnz = rowptr[nrows];
+  A.val_src = false;
   if (!h->comm) {
     A.plan = HaloPlan();
     return upload_csr(h, A, nrows, ncols, rowptr, col, val, src);
@@ -1446,6 +1470,7 @@ static int upload_owned(Engine* h, DCsr& A, const Space* rs, const Space* cs,
     return fail(PCD_ERR_COMM, "set-up handshake: %s", err.c_str());
   CHK(upload_csr(h, A, nrow_loc, cs->nloc(h->rank), orp.data(), oc.data(),
                  val ? ov.data() : nullptr, osrc.data()));
+  A.val_src = true;
   A.plan = plan;
   CHK(A.ghost.ensure(plan.nghost));
   CHK(A.sendbuf.ensure(plan.send_idx.size()));
@@ -1456,10 +1481,41 @@ static int upload_owned(Engine* h, DCsr& A, const Space* rs, const Space* cs,
   return 0;
 }
 
+// Hand over a GLOBAL CSR in the caller's numbering with the engine renumbering
+// of its row / column space applied first (either may be the identity)
+static int upload_global_r(Engine* h, DCsr& A, const Space* rs, const Space* cs,
+                           int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                           const int32_t* col, const double* val, const int64_t* src,
+                           const Reorder* rr, const Reorder* rc) {
+  const bool pr = rr && rr->active(), pc = rc && rc->active();
+  if (!pr && !pc) return upload_global(h, A, rs, cs, nrows, ncols, rowptr, col, val, src);
+  if ((pr && (int64_t)rr->n2o.size() != nrows) || (pc && (int64_t)rc->o2n.size() != ncols))
+    return fail(PCD_ERR_ARG, "operator %lld x %lld does not match the renumbered space",
+                (long long)nrows, (long long)ncols);
+  PermCsr B;
+  permute_csr(nrows, rowptr, col, pr ? rr->rows() : nullptr, pc ? rc->cols() : nullptr, B);
+  std::vector<double> bv;
+  if (val) { bv.resize(B.src.size()); for (size_t k = 0; k < bv.size(); ++k) bv[k] = val[B.src[k]]; }
+  if (src) for (auto& q : B.src) q = src[q];
+  const int64_t gnnz = rowptr[nrows];
+  CHK(upload_global(h, A, rs, cs, nrows, ncols, B.rp.data(), B.ci.data(),
+                    val ? bv.data() : nullptr, B.src.data()));
+  A.gnnz = gnnz;
+  A.val_src = true;                      // refreshes arrive in the caller's entry order
+  return 0;
+}
+
+static int upload_perm(Engine* h, Reorder& r) {
+  if (!r.active()) return 0;
+  CHK(r.d_n2o.ensure(r.n2o.size()));
+  HIPCHK(hipMemcpy(r.d_n2o.p, r.n2o.data(), r.n2o.size() * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
 // new values of a handed-over operator: one GPU copies, several ranks stage
 // the caller's global array and gather their entries
 static int refresh_values(Engine* h, DCsr& A, const double* vals, int mem) {
-  if (!h->comm || A.replicated) {
+  if (!A.val_src) {
     HIPCHK(hipMemcpyAsync(A.val.p, vals, A.nnz * sizeof(double),
                           mem == PCD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           h->stream));
@@ -1617,7 +1673,11 @@ int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
       rs = cs = &h->sp_p;
     }
   }
-  CHK(upload_global(h, A, rs, cs, nrows, ncols, rowptr, colidx, vals, nullptr));
+  // operators handed over one by one arrive in the caller's FIELD numbering:
+  // the engine renumbering decided at pcd_set_system applies to them as well
+  const Reorder* rr = (which == PCD_MAT_A00 || which == PCD_MAT_A01) ? &h->ru : &h->rp;
+  const Reorder* rc = (which == PCD_MAT_A00) ? &h->ru : &h->rp;
+  CHK(upload_global_r(h, A, rs, cs, nrows, ncols, rowptr, colidx, vals, nullptr, rr, rc));
   CHK(refresh_dinv(h, A));
   values_changed(h, which);
   h->ready = false; ++h->gen;
@@ -1643,6 +1703,9 @@ int pcd_set_csr_local(pcd_handle h, int which, int64_t nrows_global, int64_t nco
     return fail(PCD_ERR_ARG, "set_csr_local: bad arrays");
   if (nrows_global >= INT32_MAX || ncols_global >= INT32_MAX)
     return fail(PCD_ERR_ARG, "set_csr_local: dimensions exceed int32 indexing");
+  if (h->ru.active() || h->rp.active())
+    return fail(PCD_ERR_STATE, "set_csr_local: the engine renumbered the dofs at pcd_set_system "
+                               "(PCD_REORDER); rank-local hand-over needs PCD_REORDER=none");
   if (!h->comm) {
     if (nrows_local != nrows_global)
       return fail(PCD_ERR_ARG, "set_csr_local: one rank owns every row (%lld), got %lld",
@@ -1734,6 +1797,76 @@ static int gather_block_values(Engine* h, DCsr& A, const double* dvals) {
   return 0;
 }
 
+// Engine renumbering (pcd_reorder.hpp), decided once per pattern at
+// pcd_set_system: the velocity nodes by reverse Cuthill-McKee on the node graph
+// of A00 when the caller's numbering is not local ("auto": mean |row - col| / n
+// above 0.1; a geometric numbering gives a few per cent, a random one 0.33),
+// the pressure dofs by the first velocity node they couple to.  Outputs the
+// renumbered index sets (empty: unchanged).  Operators handed over BEFORE this
+// call stay in the numbering they came in: then only the velocity is renumbered.
+static int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const int32_t* colidx,
+                             int64_t n_u, const int32_t* is_u, int64_t n_p, const int32_t* is_p,
+                             std::vector<int32_t>& isu_r, std::vector<int32_t>& isp_r) {
+  { const char* e = getenv("PCD_REORDER");
+    if (e) h->reorder_mode = !strcmp(e, "none") ? 0 : !strcmp(e, "always") ? 2 : 1; }
+  if ((int64_t)h->ru.n2o.size() == n_u && (!h->rp.active() || (int64_t)h->rp.n2o.size() == n_p)) {
+    // same spaces as before (new pattern of the same problem): keep the numbering
+  } else {
+    h->ru.clear(); h->rp.clear(); h->rs.clear();
+    bool u_ops = h->mat[PCD_MAT_A00].set || h->mat[PCD_MAT_A01].set;
+    if (h->reorder_mode && !u_ops && n_u > 0) {
+      std::vector<int32_t> mu(n, -1), rp, cc; std::vector<int64_t> src;
+      for (int64_t i = 0; i < n_u; ++i) {
+        if (is_u[i] < 0 || is_u[i] >= n) return fail(PCD_ERR_ARG, "set_system: index sets do not partition 0..n-1");
+        mu[is_u[i]] = (int32_t)i;
+      }
+      extract_block(n_u, is_u, rowptr, colidx, mu, rp, cc, src);
+      // node graph when the block has the interleaved-component pattern
+      int nc = 1;
+      for (int cand : {h->vel_block, 2, 3})
+        if (cand > 1 && kron_pattern(cand, n_u, n_u, rp.data(), cc.data())) { nc = cand; break; }
+      std::vector<int32_t> grp, gcc;
+      const int32_t *gp = rp.data(), *gc = cc.data();
+      const int64_t nn = n_u / nc;
+      if (nc > 1) {
+        grp.assign(nn + 1, 0);
+        for (int64_t s2 = 0; s2 < nn; ++s2) grp[s2 + 1] = grp[s2] + (rp[nc * s2 + 1] - rp[nc * s2]);
+        gcc.resize(grp[nn]);
+        for (int64_t s2 = 0; s2 < nn; ++s2)
+          for (int32_t k = 0; k < grp[s2 + 1] - grp[s2]; ++k) gcc[grp[s2] + k] = cc[rp[nc * s2] + k] / nc;
+        gp = grp.data(); gc = gcc.data();
+      }
+      const double m = locality_metric(nn, gp, gc);
+      if (h->reorder_mode == 2 || m > 0.1) {
+        std::vector<int32_t> nodes = rcm_order(nn, gp, gc);
+        h->ru.n2o = nc > 1 ? expand_nodes(nodes, nc) : nodes;
+        h->ru.o2n = invert_perm(h->ru.n2o);
+        // pressure: by the first (renumbered) velocity dof it couples to - only
+        // if no pressure operator was handed over in the caller's numbering yet
+        bool p_ops = h->mat[PCD_MAT_AP].set || h->mat[PCD_MAT_MP].set || h->mat[PCD_MAT_KP].set ||
+                     h->mat[PCD_MAT_RP].set;
+        for (int sl : {PCD_KSP_AP, PCD_KSP_MP, PCD_KSP_RP}) if (!h->inner[sl].mg.empty()) p_ops = true;
+        if (!p_ops && n_p > 0) {
+          std::vector<int32_t> mp(n, -1);
+          for (int64_t i = 0; i < n_p; ++i) mp[is_p[i]] = (int32_t)i;
+          extract_block(n_u, is_u, rowptr, colidx, mp, rp, cc, src);     // A01 pattern
+          h->rp.n2o = induced_order(n_u, n_p, rp.data(), cc.data(), h->ru.o2n.data());
+          h->rp.o2n = invert_perm(h->rp.n2o);
+        }
+        h->rs.n2o.resize(n);
+        for (int64_t i = 0; i < n_u; ++i) h->rs.n2o[i] = h->ru.n2o[i];
+        for (int64_t j = 0; j < n_p; ++j)
+          h->rs.n2o[n_u + j] = (int32_t)(n_u + (h->rp.active() ? h->rp.n2o[j] : j));
+        h->rs.o2n = invert_perm(h->rs.n2o);
+        CHK(upload_perm(h, h->ru)); CHK(upload_perm(h, h->rp)); CHK(upload_perm(h, h->rs));
+      }
+    }
+  }
+  if (h->ru.active()) { isu_r.resize(n_u); for (int64_t i = 0; i < n_u; ++i) isu_r[i] = is_u[h->ru.n2o[i]]; }
+  if (h->rp.active()) { isp_r.resize(n_p); for (int64_t i = 0; i < n_p; ++i) isp_r[i] = is_p[h->rp.n2o[i]]; }
+  return 0;
+}
+
 int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
                       int mem) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
@@ -1780,6 +1913,10 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   if (n_u + n_p != n) return fail(PCD_ERR_ARG, "set_system: n_u + n_p != n");
   if (n >= INT32_MAX) return fail(PCD_ERR_ARG, "set_system: n exceeds int32 indexing");
   HIPCHK(hipSetDevice(h->device));
+  std::vector<int32_t> isu_r, isp_r;       // index sets in engine numbering
+  CHK(decide_reordering(h, n, rowptr, colidx, n_u, is_u, n_p, is_p, isu_r, isp_r));
+  if (!isu_r.empty()) is_u = isu_r.data();
+  if (!isp_r.empty()) is_p = isp_r.data();
   std::vector<int32_t> perm(n), mu(n, -1), mp(n, -1), ma(n, -1);
   for (int64_t i = 0; i < n_u; ++i) perm[i] = is_u[i];
   for (int64_t i = 0; i < n_p; ++i) perm[n_u + i] = is_p[i];
@@ -2109,8 +2246,9 @@ int pcd_setup(pcd_handle h) {
     const int64_t p0 = h->comm ? h->sp_p.bounds[0][h->rank] : 0;
     std::vector<int32_t> li; std::vector<double> lv;
     for (size_t k = 0; k < h->bc_host.size(); ++k) {
-      const int64_t g = h->bc_host[k];
+      int64_t g = h->bc_host[k];
       if (g < 0 || g >= np_glob) return fail(PCD_ERR_ARG, "setup: bc index %lld outside [0,%lld)", (long long)g, (long long)np_glob);
+      if (h->rp.active()) g = h->rp.o2n[g];                     // engine numbering
       if (g >= p0 && g < p0 + np) { li.push_back((int32_t)(g - p0)); lv.push_back(h->bc_val_host[k]); }
     }
     h->n_bc = (int64_t)li.size();
@@ -2139,29 +2277,64 @@ int pcd_setup(pcd_handle h) {
 struct FieldIo {
   Engine* h; IoMap io; const Space* sp; int64_t nglob, nloc;
   const double* lx = nullptr; double* ly = nullptr;
+  const Reorder* ry = nullptr;         // renumbering of the output space (or null)
+  double* y_caller = nullptr;          // where the caller-numbered result goes
+  double* y_engine = nullptr;          // the global vector in engine numbering
 };
 
+// Field vectors cross the ABI in the CALLER's numbering (global vectors); the
+// engine renumbering of their space (rx / ry, may be null) is applied here.
+// Device-pointer calls of a partitioned engine carry the rank's slice in the
+// engine's own order and pass through untouched.
 static int fio_begin(FieldIo& f, Engine* h, const Space* spx, int64_t nx_glob, int64_t nx_loc,
                      const Space* spy, int64_t ny_glob, int64_t ny_loc,
-                     const double* x, double* y, int mem, bool y_in = false) {
+                     const double* x, double* y, int mem, bool y_in = false,
+                     const Reorder* rx = nullptr, const Reorder* ry = nullptr) {
   f.h = h; f.sp = spy; f.nglob = ny_glob; f.nloc = ny_loc;
-  if (!h->comm || mem == PCD_MEM_DEVICE) {
+  if (rx && !rx->active()) rx = nullptr;
+  if (ry && !ry->active()) ry = nullptr;
+  if (h->comm && mem == PCD_MEM_DEVICE) {         // local slices, engine order
     CHK(io_begin(h, f.io, x, nx_glob, y, ny_glob, mem, y_in));
-    if (h->comm) { f.io.dx = x; f.io.dy = y; }
+    f.io.dx = x; f.io.dy = y;
     f.lx = f.io.dx; f.ly = f.io.dy;
     return 0;
   }
   CHK(io_begin(h, f.io, x, nx_glob, y, ny_glob, mem, y_in));
+  const double* gx = f.io.dx;                     // global, caller numbering
+  double* gy = f.io.dy;
+  if (rx && x) {
+    CHK(h->px_s.ensure(nx_glob));
+    hipLaunchKernelGGL(k_gather, dim3(grid1d(nx_glob, 4)), dim3(kBlock), 0, h->stream,
+                       (int)nx_glob, rx->d_n2o.p, gx, h->px_s.p);
+    gx = h->px_s.p;
+  }
+  if (ry && y) {
+    CHK(h->py_s.ensure(ny_glob));
+    if (y_in)
+      hipLaunchKernelGGL(k_gather, dim3(grid1d(ny_glob, 4)), dim3(kBlock), 0, h->stream,
+                         (int)ny_glob, ry->d_n2o.p, gy, h->py_s.p);
+    f.ry = ry; f.y_caller = gy; f.y_engine = h->py_s.p;
+    gy = h->py_s.p;
+  }
+  HIPCHK(hipGetLastError());
+  if (!h->comm) { f.lx = gx; f.ly = gy; return 0; }
   CHK(h->loc_x.ensure(nx_loc)); CHK(h->loc_y.ensure(ny_loc));
-  if (x) CHK(slice_in(h, *spx, f.io.dx, h->loc_x.p));
-  if (y_in) CHK(slice_in(h, *spy, f.io.dy, h->loc_y.p));
+  if (x) CHK(slice_in(h, *spx, gx, h->loc_x.p));
+  if (y_in) CHK(slice_in(h, *spy, gy, h->loc_y.p));
   f.lx = h->loc_x.p; f.ly = h->loc_y.p;
+  if (!f.ry) f.y_engine = gy;
   return 0;
 }
 
 static int fio_end(FieldIo& f) {
   Engine* h = f.h;
-  if (h->comm && f.io.mem == PCD_MEM_HOST) CHK(slice_out(h, *f.sp, f.ly, f.io.dy));
+  if (h->comm && f.io.mem == PCD_MEM_HOST)
+    CHK(slice_out(h, *f.sp, f.ly, f.ry ? f.y_engine : f.io.dy));
+  if (f.ry && !(h->comm && f.io.mem == PCD_MEM_DEVICE)) {
+    hipLaunchKernelGGL(k_scatter, dim3(grid1d(f.nglob, 4)), dim3(kBlock), 0, h->stream,
+                       (int)f.nglob, f.ry->d_n2o.p, f.y_engine, f.y_caller);
+    HIPCHK(hipGetLastError());
+  }
   return io_end(f.io);
 }
 
@@ -2170,7 +2343,8 @@ int pcd_apply(pcd_handle h, const double* x, double* y, int mem) {
   if (!h->ready) return fail(PCD_ERR_STATE, "apply: call pcd_setup first");
   if (!x || !y || x == y) return fail(PCD_ERR_ARG, "apply: x and y must be distinct non-null vectors");
   FieldIo f;
-  CHK(fio_begin(f, h, &h->sp_p, h->n_p, h->np_loc, &h->sp_p, h->n_p, h->np_loc, x, y, mem));
+  CHK(fio_begin(f, h, &h->sp_p, h->n_p, h->np_loc, &h->sp_p, h->n_p, h->np_loc, x, y, mem, false,
+                &h->rp, &h->rp));
   CHK(pcd_apply_dev(h, f.lx, f.ly));
   return fio_end(f);
 }
@@ -2379,8 +2553,11 @@ int pcd_spmv(pcd_handle h, int which, const double* x, double* y, int mem) {
   const Space *rs, *cs;
   mat_spaces(h, which, &rs, &cs);
   FieldIo f;
+  const Reorder* rx = which == PCD_MAT_A00 ? &h->ru : which == PCD_MAT_A ? &h->rs : &h->rp;
+  const Reorder* ry = (which == PCD_MAT_A00 || which == PCD_MAT_A01) ? &h->ru
+                      : which == PCD_MAT_A ? &h->rs : &h->rp;
   CHK(fio_begin(f, h, cs, h->comm ? cs->total() : A.ncols, A.ncols,
-                rs, h->comm ? rs->total() : A.nrows, A.nrows, x, y, mem));
+                rs, h->comm ? rs->total() : A.nrows, A.nrows, x, y, mem, false, rx, ry));
   CHK(spmv(h, A, f.lx, f.ly));
   return fio_end(f);
 }
@@ -2396,7 +2573,8 @@ int pcd_inner_solve(pcd_handle h, int slot, const double* b, double* x, int mem)
   mat_spaces(h, kSlotMat[slot], &rs, &cs);
   const int64_t ng = h->comm ? rs->total() : A.nrows;
   FieldIo f;
-  CHK(fio_begin(f, h, rs, ng, A.nrows, rs, ng, A.nrows, b, x, mem));
+  const Reorder* rr = slot == PCD_KSP_A00 ? &h->ru : &h->rp;
+  CHK(fio_begin(f, h, rs, ng, A.nrows, rs, ng, A.nrows, b, x, mem, false, rr, rr));
   CHK(inner_solve(h, slot, f.lx, f.ly));
   return fio_end(f);
 }
@@ -2406,7 +2584,8 @@ int pcd_apply_bc(pcd_handle h, double* x, int mem) {
   if (!x) return fail(PCD_ERR_ARG, "apply_bc: null vector");
   if (!h->ready) return fail(PCD_ERR_STATE, "apply_bc: call pcd_setup first");
   FieldIo f;
-  CHK(fio_begin(f, h, &h->sp_p, h->n_p, h->np_loc, &h->sp_p, h->n_p, h->np_loc, nullptr, x, mem, true));
+  CHK(fio_begin(f, h, &h->sp_p, h->n_p, h->np_loc, &h->sp_p, h->n_p, h->np_loc, nullptr, x, mem, true,
+                nullptr, &h->rp));
   CHK(apply_bc_dev(h, f.ly));
   return fio_end(f);
 }
