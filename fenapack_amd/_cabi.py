@@ -64,6 +64,7 @@ _SIGNATURES = {
 }
 # entry points only the HIP library has
 _HIP_ONLY = {
+    "set_reorder": [C.c_int],
     # rank-local hand-over (partitioned runs)
     "set_csr_local": [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                       C.c_void_p, C.c_void_p],
@@ -272,6 +273,10 @@ class Engine(object):
         self.shapes[which] = A.shape
         self._call("set_csr", which, A.shape[0], A.shape[1], _ptr(ip),
                    _ptr(ix), _ptr(dv))
+
+    def set_reorder(self, mode):
+        """Engine renumbering: "none" | "auto" | "always" (before set_system)."""
+        self._call("set_reorder", {"none": 0, "auto": 1, "always": 2}[mode])
 
     def row_range(self, n_global, velocity=False):
         """Rows ``[r0, r1)`` of a field this rank owns."""

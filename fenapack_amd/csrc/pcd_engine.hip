@@ -1867,6 +1867,13 @@ static int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const 
   return 0;
 }
 
+int pcd_set_reorder(pcd_handle h, int mode) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (mode < 0 || mode > 2) return fail(PCD_ERR_ARG, "set_reorder: mode 0 (never), 1 (auto) or 2 (always)");
+  h->reorder_mode = mode;
+  return 0;
+}
+
 int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
                       int mem) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
@@ -1983,6 +1990,8 @@ int pcd_mg_begin(pcd_handle h, int slot, int nlevels, int nu_pre, int nu_post) {
   for (auto& l : s.mg) l.release();
   s.mg.clear();
   s.mg.resize(nlevels);
+  s.mg_r.clear(); s.mg_r.resize(nlevels);
+  s.mg_r_known.assign(nlevels, 0);
   s.nu_pre = nu_pre; s.nu_post = nu_post;
   ++h->gen;
   return 0;
@@ -2006,6 +2015,61 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
     return fail(PCD_ERR_ARG, "mg_set_level: coarse levels need an operator");
   if (rowptr && (!colidx || !vals)) return fail(PCD_ERR_ARG, "mg_set_level: bad operator arrays");
   MgLevel& M = s.mg[level];
+  // Engine renumbering of the levels (pcd_reorder.hpp): the finest level takes
+  // the renumbering of its field; a coarser level inherits its order through
+  // the prolongation of the level above it - when the levels arrive finest
+  // first - and keeps the caller's numbering otherwise (the coarsest level,
+  // an explicit inverse, always does).  The arrays handed over are permuted
+  // here, once; everything below sees the engine numbering only.
+  PermCsr PA, PP;
+  std::vector<double> va_p, vp_p;
+  const int64_t* a_src = nullptr;
+  {
+    const int64_t nl0 = rowptr ? n : p_rows;
+    if ((int)s.mg_r.size() != L) { s.mg_r.clear(); s.mg_r.resize(L); s.mg_r_known.assign(L, 0); }
+    if (!s.mg_r_known[level]) {
+      if (level == L - 1) {
+        const Reorder& fr = slot == PCD_KSP_A00 ? h->ru : h->rp;
+        if (fr.active() && (int64_t)fr.n2o.size() == nl0) { s.mg_r[level].n2o = fr.n2o; s.mg_r[level].o2n = fr.o2n; }
+      }
+      s.mg_r_known[level] = 1;
+    }
+    Reorder& rl = s.mg_r[level];
+    if (level > 0 && !s.mg_r_known[level - 1]) {
+      if (level - 1 > 0 && rl.active() && prowptr && pcolidx) {
+        // velocity levels: order the NODES, keep a node's components together
+        const int nc = slot == PCD_KSP_A00 ? h->vel_block : 1;
+        if (nc > 1 && p_rows % nc == 0 && p_cols % nc == 0 && kron_pattern(nc, p_rows, p_cols, prowptr, pcolidx)) {
+          const int64_t nf = p_rows / nc, ncs = p_cols / nc;
+          std::vector<int32_t> grp(nf + 1, 0), gcc, fo2n(nf);
+          for (int64_t q = 0; q < nf; ++q) grp[q + 1] = grp[q] + (prowptr[nc * q + 1] - prowptr[nc * q]);
+          gcc.resize(grp[nf]);
+          for (int64_t q = 0; q < nf; ++q)
+            for (int32_t k = 0; k < grp[q + 1] - grp[q]; ++k) gcc[grp[q] + k] = pcolidx[prowptr[nc * q] + k] / nc;
+          for (int64_t q = 0; q < nf; ++q) fo2n[q] = rl.o2n[nc * q] / nc;
+          s.mg_r[level - 1].n2o = expand_nodes(induced_order(nf, ncs, grp.data(), gcc.data(), fo2n.data()), nc);
+        } else {
+          s.mg_r[level - 1].n2o = induced_order(p_rows, p_cols, prowptr, pcolidx, rl.o2n.data());
+        }
+        s.mg_r[level - 1].o2n = invert_perm(s.mg_r[level - 1].n2o);
+      }
+      s.mg_r_known[level - 1] = 1;
+    }
+    const Reorder* rc0 = level > 0 ? &s.mg_r[level - 1] : nullptr;
+    if (rowptr && rl.active()) {
+      if ((int64_t)rl.n2o.size() != n) return fail(PCD_ERR_ARG, "mg_set_level: level %d size does not match its renumbering", level);
+      permute_csr(n, rowptr, colidx, rl.rows(), rl.cols(), PA);
+      va_p.resize(PA.src.size());
+      for (size_t k = 0; k < va_p.size(); ++k) va_p[k] = vals[PA.src[k]];
+      rowptr = PA.rp.data(); colidx = PA.ci.data(); vals = va_p.data(); a_src = PA.src.data();
+    }
+    if (level > 0 && (rl.active() || (rc0 && rc0->active()))) {
+      permute_csr(p_rows, prowptr, pcolidx, rl.rows(), rc0 ? rc0->cols() : nullptr, PP);
+      vp_p.resize(PP.src.size());
+      for (size_t k = 0; k < vp_p.size(); ++k) vp_p[k] = pvals[PP.src[k]];
+      prowptr = PP.rp.data(); pcolidx = PP.ci.data(); pvals = vp_p.data();
+    }
+  }
   // multi-GPU: large levels are cut into contiguous row blocks like the finest
   // one (velocity levels keep the two components of a node together); levels
   // of at most PCD_REPLICATE_BELOW rows (default 60000) are replicated
@@ -2032,8 +2096,8 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
   }
   M.replicated = rep_l; M.transition = h->comm && !rep_l && rep_c; M.n_coarse = p_cols;
   if (rowptr) {
-    if (rep_l) { CHK(upload_csr(h, M.A, n, n, rowptr, colidx, vals, nullptr)); M.A.replicated = true; M.A.gnnz = rowptr[n]; }
-    else CHK(upload_global(h, M.A, sl, sl, n, n, rowptr, colidx, vals, nullptr));
+    if (rep_l) { CHK(upload_csr(h, M.A, n, n, rowptr, colidx, vals, a_src)); M.A.replicated = true; M.A.gnnz = rowptr[n]; M.A.val_src = a_src != nullptr; }
+    else { CHK(upload_global(h, M.A, sl, sl, n, n, rowptr, colidx, vals, a_src)); if (a_src) M.A.val_src = true; }
     CHK(refresh_dinv(h, M.A));
   }
   if (level > 0) {
@@ -2115,6 +2179,30 @@ int pcd_mg_set_fused(pcd_handle h, int slot, int level,
   if (s.nu_pre < 1 || s.nu_post < 1)
     return fail(PCD_ERR_STATE, "mg_set_fused: needs at least one pre- and one post-smoothing step");
   HIPCHK(hipStreamSynchronize(h->stream));
+  // engine renumbering of the two levels: Wd is (level-1) x (level); the
+  // columns of Wu run over [x1 (level) | r_c | e_c (level-1) | b (level)]
+  PermCsr PD, PU;
+  std::vector<double> vd_p, vu_p;
+  if ((int)s.mg_r.size() == L && (s.mg_r[level].active() || s.mg_r[level - 1].active())) {
+    const Reorder &rl = s.mg_r[level], &rcs = s.mg_r[level - 1];
+    permute_csr(wd_rows, wd_rowptr, wd_col, rcs.rows(), rl.cols(), PD);
+    vd_p.resize(PD.src.size());
+    for (size_t k = 0; k < vd_p.size(); ++k) vd_p[k] = wd_val[PD.src[k]];
+    std::vector<int32_t> cmap(2 * n + 2 * nc);
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t q = rl.active() ? rl.o2n[i] : (int32_t)i;
+      cmap[i] = q; cmap[n + 2 * nc + i] = (int32_t)(n + 2 * nc + q);
+    }
+    for (int64_t j = 0; j < nc; ++j) {
+      const int32_t q = rcs.active() ? rcs.o2n[j] : (int32_t)j;
+      cmap[n + j] = (int32_t)(n + q); cmap[n + nc + j] = (int32_t)(n + nc + q);
+    }
+    permute_csr(wu_rows, wu_rowptr, wu_col, rl.rows(), cmap.data(), PU);
+    vu_p.resize(PU.src.size());
+    for (size_t k = 0; k < vu_p.size(); ++k) vu_p[k] = wu_val[PU.src[k]];
+    wd_rowptr = PD.rp.data(); wd_col = PD.ci.data(); wd_val = vd_p.data();
+    wu_rowptr = PU.rp.data(); wu_col = PU.ci.data(); wu_val = vu_p.data();
+  }
   g_chunks_override = 64; g_want_wave = true;
   int rc_up = upload_csr(h, M.Wd, wd_rows, wd_cols, wd_rowptr, wd_col, wd_val, nullptr);
   if (!rc_up) rc_up = upload_csr(h, M.Wu, wu_rows, wu_cols, wu_rowptr, wu_col, wu_val, nullptr);
@@ -2154,7 +2242,8 @@ int pcd_set_inner_factor(pcd_handle h, int slot, int k, int nfactors, int64_t n,
   if (h->comm && sp->total() != n)
     return fail(PCD_ERR_ARG, "set_inner_factor: size %lld does not match the partitioned space", (long long)n);
   g_chunks_override = 64; g_want_wave = true;
-  const int rc_up = upload_global(h, s.chain[k], sp, sp, n, n, rowptr, colidx, vals, nullptr);
+  const Reorder* fr = slot == PCD_KSP_A00 ? &h->ru : &h->rp;
+  const int rc_up = upload_global_r(h, s.chain[k], sp, sp, n, n, rowptr, colidx, vals, nullptr, fr, fr);
   g_chunks_override = 0; g_want_wave = false;
   CHK(rc_up);
   if (s.chain[k].nrows != A.nrows)

@@ -301,6 +301,12 @@ int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
                  const double* phi, const double* dphi, const double* psi) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (dim != 2 && dim != 3) return fail(PCD_ERR_ARG, "fe_begin: dim must be 2 or 3");
+  // the producer's plans address operator entries in the numbering its caller
+  // handed over: it works on engines that kept that numbering
+  if (h->ru.active() || h->rp.active())
+    return fail(PCD_ERR_STATE, "fe_begin: the engine renumbered the dofs at pcd_set_system (the "
+                               "caller's numbering was not local); the device producer needs "
+                               "PCD_REORDER=none or a local numbering");
   if (nlevels < 1 || nlevels > 32 || nq < 1 || !qw || !phi || !dphi || !psi)
     return fail(PCD_ERR_ARG, "fe_begin: bad arguments");
   HIPCHK(hipSetDevice(h->device));

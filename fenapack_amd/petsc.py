@@ -610,10 +610,12 @@ class KSP(object):
         sig = (L, nu_pre, nu_post, tuple(o.nnz for o in ops))
         if pc._mg_pushed != sig:
             eng.mg_begin(slot, L, nu_pre, nu_post)
-            eng.mg_set_level(slot, 0, C)
-            for l in range(1, L):
+            # finest first: a level's engine numbering is inherited from the
+            # level above it through the prolongation (pcd_reorder.hpp)
+            for l in range(L - 1, 0, -1):
                 eng.mg_set_level(slot, l, ops[l] if l < L - 1 else None,
                                  chain[l], *bounds[l])
+            eng.mg_set_level(slot, 0, C)
             pc._mg_pushed = sig
         else:
             eng.mg_update_values(slot, 0, C.data)

@@ -146,6 +146,23 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
                    const double* pvals,
                    int64_t n_u, const int32_t* is_u,
                    int64_t n_p, const int32_t* is_p);
+/* Engine renumbering (csrc/pcd_reorder.hpp).  The index sets arrive as the
+ * caller's dofmap gives them (_field_split_utils.py:39-50: dofmap.dofs() as
+ * is); when that numbering is not local - mean |row - col| / n of the velocity
+ * block above 0.1; a geometric numbering gives a few per cent, a random one
+ * 0.33 - pcd_set_system renumbers the velocity nodes (reverse Cuthill-McKee
+ * on the node graph of A00, components of a node kept together) and the
+ * pressure dofs (by the velocity nodes they couple to), multigrid levels
+ * inherit their order through the prolongations when they are handed over
+ * finest first.  Invisible at this boundary: operators, BC indices and field
+ * vectors keep crossing it in the caller's numbering (at the price of one
+ * gather / scatter on the by-parts entry points; the fused fieldsplit / GMRES
+ * calls fold it into the split gather they perform anyway).
+ * mode 0: never, 1: auto (default), 2: always; the environment variable
+ * PCD_REORDER = none | auto | always overrides.  Call before pcd_set_system.
+ * Not available together with the device producer (pcd_fe_*) or
+ * pcd_set_csr_local, which address entries in the caller's numbering. */
+int pcd_set_reorder(pcd_handle h, int mode);
 /* in-place re-assembly of A (and P) between Newton steps, SURVEY 3.1 */
 int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
                       int mem);
