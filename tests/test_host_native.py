@@ -1,0 +1,169 @@
+"""CPU suite: the native set-up helpers (libpcd_host.so, include/pcd_host.h)
+against the numpy routes they replaced - which stay in the tree as their
+checker (FENAPACK_AMD_NUMPY_PRODUCER=1) - and the reference-tensor element
+matrices against point-wise quadrature."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from fenapack_amd import _host as H
+from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
+from fenapack_amd.fem.taylor_hood import TaylorHood
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_symbol_of_the_header():
+    text = open(os.path.join(ROOT, "include", "pcd_host.h")).read()
+    names = sorted(set(re.findall(r"\b(pcdh_[a-z_0-9]+)\s*\(", text)))
+    assert len(names) >= 14
+    lib = ctypes.CDLL(H.HOST_LIBRARY_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert H.library().pcdh_get_threads() >= 1
+
+
+def test_group_pairs_equals_numpy_unique_and_stable_argsort():
+    rng = np.random.default_rng(0)
+    n, nrows = 200_000, 9_000
+    rows = rng.integers(0, nrows, n)
+    cols = rng.integers(0, 40, n) + rows // 7
+    g = H.group_pairs(rows, cols, nrows)
+    key = rows * 10 ** 6 + cols
+    uk, inv = np.unique(key, return_inverse=True)
+    assert g.nnz == uk.size and np.array_equal(g.inv, inv.ravel())
+    assert np.array_equal(g.ucols, uk % 10 ** 6)
+    ptr, order = g.members()
+    assert np.array_equal(order, np.argsort(inv.ravel(), kind="stable"))
+    ip = np.zeros(nrows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(uk // 10 ** 6, minlength=nrows), out=ip[1:])
+    assert np.array_equal(ip, g.indptr)
+    # owned rows only (rank-local set-up)
+    r0, r1 = 2_000, 5_500
+    g2 = H.group_pairs(rows, cols, nrows, r0, r1)
+    sel = (rows >= r0) & (rows < r1)
+    assert np.array_equal(g2.inv[sel], inv.ravel()[sel] - inv.ravel()[sel].min())
+    assert np.all(g2.inv[~sel] == -1) and g2.indptr.size == r1 - r0 + 1
+    # bad input is refused, not read
+    with pytest.raises(H.HostError):
+        H.group_pairs(np.array([0, nrows]), np.array([0, 0]), nrows)
+    # no columns: a stable counting sort
+    g3 = H.group_pairs(rows, None, nrows)
+    assert np.array_equal(g3.members()[1], np.argsort(rows, kind="stable"))
+
+
+def test_pattern_products_extraction_union():
+    rng = np.random.default_rng(1)
+    nc = 20_000
+    rd, cd = rng.integers(0, 6_000, (nc, 6)), rng.integers(0, 1_800, (nc, 3))
+    g = H.pattern_cells(rd, cd, 6_000)
+    r = np.repeat(rd[:, :, None], 3, axis=2).ravel()
+    c = np.repeat(cd[:, None, :], 6, axis=1).ravel()
+    assert np.array_equal(g.inv, np.unique(r * 1_800 + c,
+                                           return_inverse=True)[1].ravel())
+    A = sp.random(2_000, 1_500, 0.004, format="csr", random_state=1)
+    B = sp.random(1_500, 1_200, 0.005, format="csr", random_state=2)
+    C, C2 = H.spgemm(A, B), (A @ B).tocsr()
+    assert abs(C - C2).max() < 1e-14 and C.nnz >= C2.nnz
+    assert C.has_sorted_indices
+    assert abs(H.spgemm(A, B, 500, 900) - C2[500:900]).max() < 1e-14
+    assert abs(H.transpose(A) - A.T.tocsr()).max() == 0
+    M = sp.random(1_500, 1_500, 0.01, format="csr", random_state=3)
+    M.sort_indices()
+    isr = rng.permutation(1_500)[:700]
+    isc = rng.permutation(1_500)[:800]
+    cm = np.full(1_500, -1, np.int32)
+    cm[isc] = np.arange(800)
+    orp, oc, osrc = H.extract_block(isr, M.indptr, M.indices, cm)
+    S = sp.csr_matrix((M.data[osrc], oc, orp), shape=(700, 800))
+    assert abs(S - M[isr][:, isc]).max() == 0
+    # union of index-mapped blocks = scipy's assembly of the same triplets
+    n = 900
+    iu, ip = rng.permutation(n)[:600], None
+    ip = np.setdiff1d(np.arange(n), iu)
+    B0 = sp.random(600, 600, 0.02, format="csr", random_state=4)
+    B1 = sp.random(600, 300, 0.02, format="csr", random_state=5)
+    for Bk in (B0, B1):
+        Bk.sort_indices()
+    indptr, indices, order = H.union_blocks(
+        n, [(iu, iu, B0.indptr, B0.indices), (iu, ip, B1.indptr, B1.indices)])
+    vals = np.concatenate([B0.data, B1.data])
+    U = sp.csr_matrix((vals[order], indices, indptr), shape=(n, n))
+    ref = sp.lil_matrix((n, n))
+    ref[np.ix_(iu, iu)] = B0
+    ref[np.ix_(iu, ip)] = B1
+    assert abs(U - ref.tocsr()).max() == 0
+    with pytest.raises(H.HostError, match="overlap"):
+        H.union_blocks(n, [(iu, iu, B0.indptr, B0.indices),
+                           (iu, iu, B0.indptr, B0.indices)])
+
+
+@pytest.mark.parametrize("make", [lambda: Cavity(2), lambda: Cavity3D(1, n0=2),
+                                  lambda: BackwardStep(1)])
+def test_native_producer_equals_the_numpy_route(make, monkeypatch):
+    monkeypatch.setenv("FENAPACK_AMD_NUMPY_PRODUCER", "0")
+    V = make().space
+    monkeypatch.setenv("FENAPACK_AMD_NUMPY_PRODUCER", "1")
+    W = TaylorHood(V.mesh)
+    U = np.random.default_rng(0).standard_normal((V.nn, V.dim))
+    for coupled in (False, True):
+        monkeypatch.setenv("FENAPACK_AMD_NUMPY_PRODUCER", "0")
+        pa = V._patterns(coupled)
+        mats = [V.assemble_A00(0.01, U, idt=2.0, newton=coupled),
+                V.assemble_A01(), V.assemble_A10(), V.assemble_Mu(2.0),
+                V.assemble_Kp(0.01, U, idt=2.0)]
+        mono = V.monolithic(mats[0], mats[1], mats[2])
+        monkeypatch.setenv("FENAPACK_AMD_NUMPY_PRODUCER", "1")
+        pb = W._patterns(coupled)
+        ref = [W.assemble_A00(0.01, U, idt=2.0, newton=coupled),
+               W.assemble_A01(), W.assemble_A10(), W.assemble_Mu(2.0),
+               W.assemble_Kp(0.01, U, idt=2.0)]
+        mono_ref = W.monolithic(ref[0], ref[1], ref[2])
+        for k in pa:
+            a, b = pa[k], pb[k]
+            assert a.nnz == b.nnz and np.array_equal(a.indptr, b.indptr), k
+            assert np.array_equal(a.indices, b.indices), k
+            assert np.array_equal(np.asarray(a.inv).ravel(),
+                                  np.asarray(b.inv).ravel()), (k, coupled)
+        for x, y in zip(mats + [mono], ref + [mono_ref]):
+            assert np.array_equal(x.indptr, y.indptr)
+            assert np.array_equal(x.indices, y.indices)
+            assert abs(x - y).max() <= 1e-14 * abs(y).max()
+
+
+@pytest.mark.parametrize("make", [lambda: Cavity(2), lambda: Cavity3D(1, n0=2)])
+def test_reference_tensor_element_matrices_equal_quadrature(make):
+    V = make().space
+    d = V.dim
+    rng = np.random.default_rng(3)
+    U = rng.standard_normal((V.nn, d))
+    w, gw = V.wind_at_qp(U)
+    tol = lambda ref: 1e-13 * np.abs(ref).max()
+    conv = V.p2_convection_cells(w)
+    assert np.abs(V.p2_convection_nodal(U) - conv).max() < tol(conv)
+    stiff = np.einsum('cq,cqad,cqbd->cab', V.wq, V.gphi, V.gphi)
+    assert np.abs(V.p2_stiffness_cells() - stiff).max() < tol(stiff)
+    mass = np.einsum('cq,qa,qb->cab', V.wq, V.phi, V.phi)
+    assert np.abs(V.p2_mass_cells() - mass).max() < tol(mass)
+    a01 = -np.einsum('cq,qj,cqak->cajk', V.wq, V.psi, V.gphi)
+    assert np.abs(V._a01_cells() - a01).max() < tol(a01)
+    # Newton block and SUPG term: whole matrices against the point-wise forms
+    N = np.einsum('cq,qa,qb,cqkd->cabkd', V.wq, V.phi, V.phi, gw)
+    S = 0.01 * stiff + conv
+    vals = np.zeros(S.shape + (d, d))
+    for k in range(d):
+        vals[..., k, k] = S
+    ref = V._patterns(True)["A00"].assemble(vals + N)
+    A = V.assemble_A00(0.01, U, newton=True)
+    assert abs(A - ref).max() < 1e-13 * abs(ref).max()
+    delta = np.abs(rng.standard_normal(V.mesh.num_cells))
+    Uc = U[V.cell_dofs2]
+    ww = np.einsum('qa,cak->cqk', V.phi_s, Uc)
+    wl = np.einsum('cqd,ckd->cqk', ww, V.gradlam)
+    wg = np.einsum('qbk,cqk->cqb', V.dphi_s, wl)
+    supg = np.einsum('c,c,q,cqa,cqb->cab', delta, V.area, V.qw_s, wg, wg)
+    assert np.abs(V.p2_supg_cells(U, delta) - supg).max() < tol(supg)
