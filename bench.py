@@ -59,6 +59,11 @@ def parse():
     p.add_argument("--skip-u", default="", help="pc_mg_skip_levels of the "
                    "velocity multigrid (experiment)")
     p.add_argument("--skip-p", default="", help="same for Ap")
+    p.add_argument("--algebraic", action="store_true",
+                   help="-pc_type gamg: hierarchies from the matrices alone "
+                        "(smoothed aggregation, fenapack_amd/amg.py) - for "
+                        "meshes without a nested hierarchy (e.g. --geometry "
+                        "cube --level 0 --n0 73 = BASELINE config 5's N)")
     p.add_argument("--coarse-u", type=int, default=None,
                    help="fieldsplit_u_pc_mg_coarse_eq_limit: the coarsest "
                         "velocity level is the largest one of at most this "
@@ -238,7 +243,7 @@ def main():
     if args.inner == "mg":
         multigrid_inner_options(cycles_u=args.cycles_u, cycles_p=args.cycles_p,
                                 smooth=args.smooth, mp_its=args.mp_its,
-                                dim=V.dim)
+                                dim=V.dim, algebraic=args.algebraic)
     else:
         default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
                               ap_rtol=args.ap_rtol, ap_its=args.ap_its,

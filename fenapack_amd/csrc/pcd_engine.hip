@@ -96,6 +96,7 @@ struct DCsr {
   bool set = false;
   int lpr = 8;
   int rb = 0;             // rows per workgroup of the CSR-stream kernels (0: n/a)
+  bool small_tile = false; // every rb-row block fits the half LDS tile (short rows): SpMV takes it
   bool long_rows = false; // >= 256 nonzeros per row on average: workgroup per row
   bool wave_rows = false; // composed operator with 24..255 entries per row: wave per row
   bool dense = false;     // every entry stored (explicit coarse inverse): val is row-major
@@ -341,6 +342,7 @@ static inline int grid_stream(int64_t nrows, int rb, int cap = 1 << 20) {
   return (int)((g + 7) / 8 * 8);
 }
 static bool g_force_vector = false;   // PCD_FORCE_CSR_VECTOR=1: A/B switch
+static bool g_no_small_tile = false;  // PCD_NO_SMALL_TILE=1: A/B switch
 // operators whose launches move more than this stream their matrix arrays with
 // non-temporal loads (PCD_NT_BYTES; -1: never): beyond the 256 MiB Infinity Cache
 static long long g_nt_bytes = 256ll << 20;
@@ -546,6 +548,18 @@ static void launch_spmv_any(Engine* h, const DCsr& A, const double* x,
     const int g = (int)std::min<int64_t>((A.nrows + 3) / 4, 1 << 16);
     hipLaunchKernelGGL((k_spmv_w<MODE>), dim3(g), dim3(kBlock), 0, h->stream,
                        (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y);
+  } else if (A.rb && A.small_tile) {
+    const int g = grid_stream(A.nrows, A.rb);
+    switch (A.rb) {
+      case 256: hipLaunchKernelGGL((k_spmv_s<256, MODE, kTileSmall>), dim3(g), dim3(kBlock), 0, h->stream,
+                                   (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      case 128: hipLaunchKernelGGL((k_spmv_s<128, MODE, kTileSmall>), dim3(g), dim3(kBlock), 0, h->stream,
+                                   (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      case 64: hipLaunchKernelGGL((k_spmv_s<64, MODE, kTileSmall>), dim3(g), dim3(kBlock), 0, h->stream,
+                                  (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+      default: hipLaunchKernelGGL((k_spmv_s<32, MODE, kTileSmall>), dim3(g), dim3(kBlock), 0, h->stream,
+                                  (int)A.nrows, A.rowptr.p, A.col.p, A.val.p, xv, add, y); break;
+    }
   } else if (A.rb) {
     const int g = grid_stream(A.nrows, A.rb);
     switch (A.rb) {
@@ -1394,6 +1408,13 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.set = true;
   A.lpr = choose_lpr(A);
   A.rb = g_force_vector ? 0 : choose_rb(nrows, rowptr);
+  A.small_tile = false;
+  if (A.rb && !g_no_small_tile) {
+    bool fits = true;
+    for (int64_t r = 0; r < nrows && fits; r += A.rb)
+      if (rowptr[std::min<int64_t>(r + A.rb, nrows)] - rowptr[r] > kTileSmall) fits = false;
+    A.small_tile = fits && nrows >= (int64_t)A.rb * 1280;   // (only when workgroups queue for CUs)
+  }
   A.long_rows = A.rb == 0 && nrows > 0 && nnz / nrows >= 256;
   // the dense kernels read `val` as a row-major matrix and ignore `col`: only
   // valid when every row stores columns 0..ncols-1 in ascending order
@@ -1593,6 +1614,7 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
   { const char* e = getenv("PCD_MAX_CHUNKS"); if (e && atoi(e) >= 1) g_max_chunks = atoi(e); }
   { const char* e = getenv("PCD_NT_BYTES"); if (e) g_nt_bytes = atoll(e); }
+  { const char* e = getenv("PCD_NO_SMALL_TILE"); g_no_small_tile = e && e[0] == '1'; }
   { hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       g_num_cus = prop.multiProcessorCount; }
@@ -2752,7 +2774,7 @@ int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double*
   // copy / triad: grid-stride, 32 workgroups per CU; read sweeps: one chunk per
   // workgroup, best of 2, 4 and 8 workgroups per CU
   const int grids_rw[1] = {g_num_cus * 32};
-  const int grids_rd[3] = {g_num_cus * 2, g_num_cus * 4, g_num_cus * 8};
+  const int grids_rd[3] = {g_num_cus * 2, g_num_cus * 4, g_num_cus * 8};   // (1 per CU never won the sweep)
   const int* grids = kind >= 2 ? grids_rd : grids_rw;
   const int ngrids = kind >= 2 ? 3 : 1;
   const double moved = (kind == 1 ? 3.0 : kind == 0 ? 2.0 : kind == 3 ? 1.0 + 1.0 / 16.0 : 1.0) * 16.0 * (double)n2;
@@ -2760,9 +2782,13 @@ int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double*
   for (int gi = 0; gi < ngrids; ++gi)
     for (int r = 0; r < reps + 1; ++r) {
       HIPCHK(hipEventRecord(e0, h->stream));
-      hipLaunchKernelGGL(k_bw_probe, dim3(grids[gi]), dim3(kBlock), 0, h->stream, kind, n2,
-                         reinterpret_cast<const double2*>(b.p), reinterpret_cast<const double2*>(c.p),
-                         3.0, reinterpret_cast<double2*>(a.p));
+      const double2* bp = reinterpret_cast<const double2*>(b.p);
+      double2* ap = reinterpret_cast<double2*>(a.p);
+      if (kind == 2) hipLaunchKernelGGL(k_bw_read<2>, dim3(grids[gi]), dim3(kBlock), 0, h->stream, n2, bp, ap);
+      else if (kind == 3) hipLaunchKernelGGL(k_bw_read<3>, dim3(grids[gi]), dim3(kBlock), 0, h->stream, n2, bp, ap);
+      else if (kind == 4) hipLaunchKernelGGL(k_bw_read<4>, dim3(grids[gi]), dim3(kBlock), 0, h->stream, n2, bp, ap);
+      else hipLaunchKernelGGL(k_bw_probe, dim3(grids[gi]), dim3(kBlock), 0, h->stream, kind, n2, bp,
+                              reinterpret_cast<const double2*>(c.p), 3.0, ap);
       HIPCHK(hipEventRecord(e1, h->stream));
       HIPCHK(hipEventSynchronize(e1));
       float ms = 0.f;

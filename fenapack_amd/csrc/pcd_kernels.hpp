@@ -392,7 +392,7 @@ __device__ __forceinline__ T stream_load(const T* p) {
   return *p;
 }
 
-template <int RB, class XF>
+template <int RB, class XF, int TILE = kTile>
 __device__ __forceinline__ double stream_row_block(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const XF& xf, int r0, int nrows,
@@ -409,8 +409,8 @@ __device__ __forceinline__ double stream_row_block(
   double s = 0.0;
   // the block's entries pass through the LDS tile in chunks (normally one;
   // the host admits a few more for operators with long rows)
-  for (int c0 = 0; c0 < k1 - k0; c0 += kTile) {
-    const int c1 = min(c0 + kTile, k1 - k0);
+  for (int c0 = 0; c0 < k1 - k0; c0 += TILE) {
+    const int c1 = min(c0 + TILE, k1 - k0);
     if (c0) __syncthreads();                // readers of the previous chunk
     for (int base = k0 + c0; base < k0 + c1; base += kUnroll * kBlock) {
       int c[kUnroll];
@@ -442,12 +442,16 @@ __device__ __forceinline__ double stream_row_block(
   return s;                                  // on every lane of the row
 }
 
-template <int RB, int MODE>
+// TILE: LDS doubles per workgroup.  Operators with short rows (A01: 4.75
+// entries per row; 256 rows fill 1 200 of the 4 096 slots) take the half
+// tile: 16 KiB leave room for 8 resident workgroups per CU instead of 5.
+constexpr int kTileSmall = 2048;
+template <int RB, int MODE, int TILE = kTile>
 __global__ __launch_bounds__(kBlock) void k_spmv_s(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, const XVec xf, const double* add,
     double* y) {
-  __shared__ double lds[kTile];
+  __shared__ double lds[TILE];
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, RB, rb0, rb1);
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_s(
     const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
     double a = 0.0;
     if ((MODE == 1 || MODE == 2) && mine) a = add[row];   // early: hides under phase 1
-    const double s = stream_row_block<RB>(rowptr, col, val, xf, r0, nrows, lds);
+    const double s = stream_row_block<RB, XVec, TILE>(rowptr, col, val, xf, r0, nrows, lds);
     if (mine) {
       if (MODE == 0) y[row] = s;
       if (MODE == 1) y[row] = a + s;
@@ -1236,42 +1240,44 @@ __global__ __launch_bounds__(kBlock) void k_dense_c(
 // kind 1: a = b + s c (triad: 2 reads + 1 write); kind 2: read-only sweep;
 // kind 3: read-mostly (6 % writes, the mix of the dominant kernel); kind 4:
 // read-only with non-temporal loads.
+// read sweeps: one contiguous chunk per workgroup, eight independent 16-byte
+// loads per lane in flight - the shape that reads fastest on this GPU with FEW
+// workgroups per CU (profiles/r03_f_read_bandwidth_sweep.txt: 6.1-6.5 TB/s at
+// 2-4 per CU against 5.3 at 32; non-temporal 7.1).  KIND 2: read-only; 3:
+// read-mostly (one 16-byte store per sixteen loads of a lane: the 6 % writes
+// of the fused Chebyshev step); 4: read-only, non-temporal.
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_bw_read(int64_t n2, const double2* __restrict__ b,
+                                                     double2* __restrict__ a) {
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  const dv2* bb = reinterpret_cast<const dv2*>(b);
+  dv2* aa = reinterpret_cast<dv2*>(a);
+  const int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  int64_t i = (int64_t)blockIdx.x * per + threadIdx.x;
+  const int64_t end = min(n2, (int64_t)(blockIdx.x + 1) * per);
+  dv2 acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = dv2(0.0);
+  int trip = 0;
+  for (; i + 7 * kBlock < end; i += 8 * kBlock, ++trip) {
+    dv2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = KIND == 4 ? __builtin_nontemporal_load(bb + i + u * kBlock) : bb[i + u * kBlock];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += v[u];
+    if (KIND == 3 && (trip & 1) == 0) aa[i >> 4] = acc[0];   // 1 store per 16 loads
+  }
+  for (; i < end; i += kBlock) acc[0] += bb[i];
+#pragma unroll
+  for (int u = 1; u < 8; ++u) acc[0] += acc[u];
+  aa[n2 / 16 + (int64_t)blockIdx.x * kBlock + threadIdx.x] = acc[0];
+}
+
+// copy (kind 0) / triad (kind 1), grid-stride
 __global__ __launch_bounds__(kBlock) void k_bw_probe(
     int kind, int64_t n2, const double2* __restrict__ b,
     const double2* __restrict__ c, double s, double2* __restrict__ a) {
-  if (kind >= 2) {
-    // read sweeps: one contiguous chunk per workgroup, eight independent
-    // 16-byte loads per lane in flight - the shape that reads fastest on this
-    // GPU with FEW workgroups per CU (profiles/r03_f_read_bandwidth_sweep.txt:
-    // 6.1-6.5 TB/s at 2-4 per CU against 5.3 at 32; non-temporal 7.1).
-    // kind 2: read-only; kind 3: read-mostly (one 16-byte store per sixteen
-    // loads of a lane: the 6 % writes of the fused Chebyshev step);
-    // kind 4: read-only, non-temporal.
-    typedef double dv2 __attribute__((ext_vector_type(2)));
-    const dv2* bb = reinterpret_cast<const dv2*>(b);
-    dv2* aa = reinterpret_cast<dv2*>(a);
-    const int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
-    int64_t i = (int64_t)blockIdx.x * per + threadIdx.x;
-    const int64_t end = min(n2, (int64_t)(blockIdx.x + 1) * per);
-    dv2 acc[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = dv2(0.0);
-    int trip = 0;
-    for (; i + 7 * kBlock < end; i += 8 * kBlock, ++trip) {
-      dv2 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        v[u] = kind == 4 ? __builtin_nontemporal_load(bb + i + u * kBlock) : bb[i + u * kBlock];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += v[u];
-      if (kind == 3 && (trip & 1) == 0) aa[i >> 4] = acc[0];   // 1 store per 16 loads
-    }
-    for (; i < end; i += kBlock) acc[0] += bb[i];
-#pragma unroll
-    for (int u = 1; u < 8; ++u) acc[0] += acc[u];
-    aa[n2 / 16 + (int64_t)blockIdx.x * kBlock + threadIdx.x] = acc[0];
-    return;
-  }
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
        i += (int64_t)gridDim.x * kBlock) {
     double2 v = b[i];

@@ -597,6 +597,15 @@ class KSP(object):
             emax = estimate_emax(ops[l], iters=12,
                                  warm=pc._mg_warm.setdefault(l, {}))
             bounds.append((b * emax, d * emax))
+        if ops[0].shape[0] > 30000:
+            # (an explicit inverse of that size is tens of GB - e.g. a smoothed-
+            # aggregation chain that stalled on a 3-D P2 operator)
+            raise ValueError(
+                "%spc_type %s: the coarsest level has %d rows - too large for "
+                "the explicit coarse inverse (limit 30000); the hierarchy "
+                "stalled or has too few levels"
+                % (self._prefix, "gamg" if pc.mg_algebraic else "mg",
+                   ops[0].shape[0]))
         C = coarse_inverse(ops[0], getattr(self.engine, "velocity_block", 2)
                            if self.slot == c.KSP_A00 else 1)
         eng, slot, L = self.engine, self.slot, len(ops)

@@ -25,8 +25,8 @@ def _gpus():
     return torch.cuda.device_count()      # (does not initialise the GPU)
 
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs")]
+pytestmark = pytest.mark.gpu
+needs2 = pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs")
 
 
 def _env():
@@ -37,14 +37,50 @@ def _env():
     return env
 
 
-def _launch(args, port, timeout):
+def _launch(args, port, timeout, nproc=2, extra_env=None):
+    env = _env()
+    env.update(extra_env or {})
     return subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(port)] + args, env=_env(), capture_output=True,
+         "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+         "--master-port", str(port)] + args, env=env, capture_output=True,
         text=True, timeout=timeout)
 
 
+@pytest.mark.timeout(600)
+def test_worker_on_one_rank_over_a_real_rccl_communicator(hip_lib, tmp_path):
+    """The worker of the two-GPU tests below, started by the same launcher
+    with ONE rank and the communicator forced on (PCD_FORCE_COMM): everything
+    of the multi-rank path except a second GPU - process group, unique id,
+    ncclCommInitRank, the set-up handshake, halos and all-reduces over RCCL -
+    runs on every box, so the script cannot be broken when two GPUs show up."""
+    out = str(tmp_path / "one.npz")
+    run = _launch([WORKER, "--out", out], 29639, 420, nproc=1,
+                  extra_env={"PCD_FORCE_COMM": "1"})
+    assert run.returncode == 0, run.stderr[-3000:]
+    one = np.load(out)
+    assert one["ranks"] == 1
+    st = flow_state("lshape", 3, dt=0.2)
+    V = st["V"]
+    e = c.Engine(hip_lib, "RBRM1", 0)
+    configure_engine(e, st)
+    set_iter_cfg(e)
+    e.set_inner(c.KSP_A00, "chebyshev", "jacobi", 4, 0.0, 0.2, 2.2)
+    e.setup()
+    rng = np.random.default_rng(20)
+    xp, xs = rng.standard_normal(V.n_p), rng.standard_normal(V.ndof)
+    assert relerr(one["A"], e.spmv_np(c.MAT_A, xs, V.ndof)) < 1e-13
+    assert relerr(one["fs"], e.fieldsplit_apply_np(xs)) < 1e-11
+    for s_ in (c.KSP_AP, c.KSP_MP, c.KSP_RP):
+        e.set_inner(s_, "cg", "jacobi", 3000, 1e-10)
+    e.set_inner(c.KSP_A00, "chebyshev", "jacobi", 40, 0.0, 0.02, 2.2)
+    x, its, _ = e.gmres_np(rng.standard_normal(V.ndof), rtol=1e-6,
+                           restart=150, max_it=600)
+    assert int(one["gmres_its"]) == its and its > 0
+    assert relerr(one["gmres_x"], x) < 1e-7
+
+
+@needs2
 @pytest.mark.timeout(900)
 def test_bench_on_two_gpus_over_rccl():
     """``bench.py --gpus 2`` as invoked (self-launched ranks, real RCCL): one
@@ -66,6 +102,7 @@ def test_bench_on_two_gpus_over_rccl():
         recs[1]["gmres_its_per_newton_step"]
 
 
+@needs2
 @pytest.mark.timeout(900)
 def test_two_processes_match_one_gpu(hip_lib, tmp_path):
     """Partitioned SpMV, PCD apply, fieldsplit PCApply and a full GMRES solve
@@ -92,11 +129,13 @@ def test_two_processes_match_one_gpu(hip_lib, tmp_path):
     for s in (c.KSP_AP, c.KSP_MP, c.KSP_RP):
         e.set_inner(s, "cg", "jacobi", 3000, 1e-10)
     e.set_inner(c.KSP_A00, "chebyshev", "jacobi", 40, 0.0, 0.02, 2.2)
-    x, its, _ = e.gmres_np(st["b"], rtol=1e-6, restart=150, max_it=600)
-    assert int(two["gmres_its"]) == its
+    x, its, _ = e.gmres_np(rng.standard_normal(V.ndof), rtol=1e-6,
+                           restart=150, max_it=600)
+    assert int(two["gmres_its"]) == its and its > 0
     assert relerr(two["gmres_x"], x) < 1e-7
 
 
+@needs2
 @pytest.mark.timeout(600)
 def test_failing_rank_does_not_hang_the_job(tmp_path):
     """One rank dies after set-up while the other waits inside an RCCL
