@@ -356,9 +356,14 @@ struct XCg {
 __constant__ int g_xcd_remap_max_rows = 1 << 20;
 
 // contiguous range of row blocks of this workgroup (gridDim.x multiple of 8)
-__device__ __forceinline__ void row_block_range(int nrb, int rb_rows, int& begin, int& end) {
+__device__ __forceinline__ void row_block_range(int nrb, int rb_rows, int& begin, int& end,
+                                                bool always = false) {
   const int G = gridDim.x;
-  const bool remap = (long long)nrb * rb_rows <= g_xcd_remap_max_rows;
+  // (`always`: kernels that stream the matrix non-temporally keep the mapping at
+  // every size - with the matrix out of the caches' way the gathered vector's
+  // slab is what the XCD's L2 holds: level 7 70.6 -> 68.8 us,
+  // profiles/r03_x_xcd_nt_level7.txt; with default-policy loads it costs 4 %)
+  const bool remap = always || (long long)nrb * rb_rows <= g_xcd_remap_max_rows;
   const int slot = remap ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8
                          : (int)blockIdx.x;
   begin = (int)((long long)slot * nrb / G);
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
   VecC<NC>* y = vc<NC>(y_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1);
+  row_block_range(nrb, RB, rb0, rb1, NT);
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x / (kBlock / RB);
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
   VecC<NC>* pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1);
+  row_block_range(nrb, RB, rb0, rb1, NT);
   const XVecC<NC> xf{pk, vc<NC>(ghost), nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1);
+  row_block_range(nrb, RB, rb0, rb1, NT);
   const XVecC<NC> xf{b, b, nrows};    // vals carry D^-1 (see k_cheb_first_s)
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
