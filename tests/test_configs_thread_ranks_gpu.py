@@ -60,6 +60,7 @@ def replicate_below(monkeypatch):
     return set_limit
 
 
+@pytest.mark.heavy(4)
 @pytest.mark.timeout(900)
 def test_config4_unsteady_100_steps_on_1_2_4_ranks(hip_lib, replicate_below):
     """100 steps on one rank (round 2's totals), the first 25 of them (the
@@ -107,6 +108,7 @@ def test_config4_unsteady_100_steps_on_1_2_4_ranks(hip_lib, replicate_below):
     PETScOptions.clear()
 
 
+@pytest.mark.heavy(3)
 @pytest.mark.timeout(900)
 def test_config5_shape_cube_n32_on_8_ranks(hip_lib, replicate_below):
     replicate_below(20000)

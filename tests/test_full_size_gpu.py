@@ -79,6 +79,7 @@ def test_cavity_level6_headline_workload(variant, its):
     assert np.array_equal(y0, y1) and np.array_equal(y1, y2)
 
 
+@pytest.mark.heavy(1)
 def test_cavity_level7_re1000_supg():
     """BASELINE configs[2]: 3 692 803 DOF, Re = 1000, SUPG-stabilised
     preconditioner matrix (stabilization.py), re-discretised coarse levels,
@@ -93,6 +94,7 @@ def test_cavity_level7_re1000_supg():
     compare_with_oracle(pb, ksp)
 
 
+@pytest.mark.heavy(5)
 def test_cube_n32_three_components():
     """Config 5's geometry at the size one host can assemble: N = 32,
     859 812 DOF, F (x) I_3 kernels."""
@@ -104,6 +106,7 @@ def test_cube_n32_three_components():
     compare_with_oracle(pb, ksp)
 
 
+@pytest.mark.heavy(2)
 def test_cube_n64_config5_size(monkeypatch):
     """BASELINE config 5's size class on ONE GPU: N = 64 per side, 6 714 692
     DOF (N = 73 - 9.9 M DOF - has no nested hierarchy; N = 64 and N = 80
@@ -170,6 +173,7 @@ def test_unsteady_anchor_against_the_published_table(pcdr, published, cycles,
         assert max(per_picard) <= (19 if pcdr else 33), per_picard
 
 
+@pytest.mark.heavy(6)
 def test_cavity_level6_newton_block_on_the_device():
     """`--nls newton` at the headline size: the coupled velocity block
     F x I + N assembled on the DEVICE (pcd_fe_set_newton), as matrix and as

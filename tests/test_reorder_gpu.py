@@ -140,6 +140,7 @@ def _time_applies(e, n, reps=30):
     return best
 
 
+@pytest.mark.heavy(7)
 @pytest.mark.parametrize("kind,level,kw", [("cavity", 5, {}),
                                            ("cube", 2, {"n0": 4})])
 def test_permuted_numbering_same_result_same_speed(hip_lib, monkeypatch, kind,
