@@ -1618,6 +1618,8 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       g_num_cus = prop.multiProcessorCount; }
+  { const char* e = getenv("PCD_XCD_REMAP_NT");            // A/B: mapping of the non-temporal kernels
+    if (e) { const int v = atoi(e); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pcd::g_xcd_remap_nt), &v, sizeof(int))); } }
   { const char* e = getenv("PCD_XCD_REMAP_MAX_ROWS");      // A/B: threshold of the XCD-aware mapping
     if (e) { const int v = atoi(e); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pcd::g_xcd_remap_max_rows), &v, sizeof(int))); } }
   { const char* e = getenv("PCD_NO_XCD_REMAP");

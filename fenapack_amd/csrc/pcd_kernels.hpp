@@ -354,6 +354,14 @@ struct XCg {
 // stream from HBM and do better with all XCDs walking one front (DESIGN.md
 // section 4 has the A/B).  PCD_NO_XCD_REMAP=1 sets it to 0.
 __constant__ int g_xcd_remap_max_rows = 1 << 20;
+// ... and at EVERY size by the two-component kernels that stream the matrix
+// non-temporally (bit 0: two-component kernels, bit 1: three-component ones;
+// PCD_XCD_REMAP_NT).  Measured: cavity level 7 70.6 -> 68.8 us and the counted
+// traffic 1.21 -> 0.99 x the kernel-model bytes; cube N = 64 the traffic falls
+// the same way (1.21 -> 1.02 x) but the launch gets 2 % SLOWER (262 -> 267 us:
+// the 3-D kernel is bound by its gather instructions, not by bytes), so bit 1
+// stays off (profiles/r03_x_xcd_nt_*.txt).
+__constant__ int g_xcd_remap_nt = 1;
 
 // contiguous range of row blocks of this workgroup (gridDim.x multiple of 8)
 __device__ __forceinline__ void row_block_range(int nrb, int rb_rows, int& begin, int& end,
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
   VecC<NC>* y = vc<NC>(y_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1, NT);
+  row_block_range(nrb, RB, rb0, rb1, NT && ((g_xcd_remap_nt >> (NC - 2)) & 1));
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x / (kBlock / RB);
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
   VecC<NC>* pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1, NT);
+  row_block_range(nrb, RB, rb0, rb1, NT && ((g_xcd_remap_nt >> (NC - 2)) & 1));
   const XVecC<NC> xf{pk, vc<NC>(ghost), nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1, NT);
+  row_block_range(nrb, RB, rb0, rb1, NT && ((g_xcd_remap_nt >> (NC - 2)) & 1));
   const XVecC<NC> xf{b, b, nrows};    // vals carry D^-1 (see k_cheb_first_s)
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
