@@ -677,6 +677,9 @@ __device__ __forceinline__ VecC<NC>* vc(double* p) {
 template <int NC>
 struct XVecC {
   const VecC<NC>* x; const VecC<NC>* ghost; int nloc;      // in node units
+  // (24-byte triples as one 16-byte + one 8-byte load instead of three 8-byte
+  // ones: no difference, 35.0 vs 35.1 us on the cube N = 32 -
+  // profiles/r03_t_triple_gather_ab_negative_result.txt)
   __device__ __forceinline__ VecC<NC> operator()(int c) const {
     return c < nloc ? x[c] : ghost[c - nloc];
   }
