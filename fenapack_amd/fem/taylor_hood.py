@@ -22,9 +22,13 @@ mixed dofmaps, so the fieldsplit index sets ``is_u`` / ``is_p`` are genuinely
 non-contiguous (``fenapack/field_split.py:71-73``).
 """
 
+import threading
+
 import numpy as np
 import scipy.sparse as sp
 from scipy.special import roots_jacobi
+
+_LAZY_LOCK = threading.RLock()
 
 # Dunavant 7-point rule, exact to degree 5 (enough for w(P2).grad u(P1) v(P2))
 _A1, _B1 = 0.059715871789770, 0.470142064105115
@@ -195,11 +199,12 @@ class FixedPattern(object):
         """(ptr, order): element entries of CSR slot k are
         ``order[ptr[k]:ptr[k+1]]`` in ascending position (= the stable argsort
         of ``inv``)."""
-        if getattr(self, "_members", None) is None and \
-                getattr(self, "_group", None) is not None:
-            self._members = self._group.members()
-            self._group.release()
-            self._group = None
+        with _LAZY_LOCK:        # (spaces may be shared by rank threads)
+            if getattr(self, "_members", None) is None and \
+                    getattr(self, "_group", None) is not None:
+                self._members = self._group.members()
+                self._group.release()
+                self._group = None
         if getattr(self, "_members", None) is None:
             inv = np.asarray(self.inv).ravel()
             order = np.argsort(inv, kind="stable")
