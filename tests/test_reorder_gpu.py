@@ -225,3 +225,83 @@ def test_permuted_numbering_same_result_same_speed(hip_lib, monkeypatch, kind,
         qw = np.ones(3) / 3
         e1.fe_begin(d, 1, qw, np.ones((3, V.na)), np.ones((3, V.na, d + 1)),
                     np.ones((3, d + 1)))
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_renumbering_on_several_ranks(hip_lib, monkeypatch, R):
+    """Renumbering happens BEFORE the rows are cut into rank blocks (it is what
+    makes the blocks geometric strips when the caller's numbering is not):
+    a randomly permuted problem on R thread ranks, host-pointer calls (global
+    vectors in the caller's numbering), against one engine on the
+    lexicographic input."""
+    import ctypes
+    import threading
+    monkeypatch.delenv("PCD_REORDER", raising=False)
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "300")
+    st = _state("cavity", 3)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    chain = pb.interpolations().chain("u", 3)
+    base = {"A": st["A"], "is_u": V.is_u, "is_p": V.is_p, "Ap": pb.Ap,
+            "Mp": pb.Mp, "Kp": st["Kp"], "bc_idx": pb.bc_p_idx}
+    perm = _permuted(st, 11)
+    rng = np.random.default_rng(12)
+    d = V.dim
+    sizes = [chain[1].shape[1]] + [P.shape[0] for P in chain[1:]]
+    lp = [perm["tu"] if l == len(sizes) - 1 else
+          (d * rng.permutation(n // d)[:, None] + np.arange(d)).ravel()
+          for l, n in enumerate(sizes)]
+    mg0 = _hierarchy(L["A00"], chain)
+    mg1 = _renumbered(mg0, lp)
+    e0 = _engine(hip_lib, st, base, mg0)
+    x, xp = rng.standard_normal(V.ndof), rng.standard_normal(V.n_p)
+    y0, yp0 = e0.fieldsplit_apply_np(x), e0.apply_np(xp)
+    b = rng.standard_normal(V.ndof)
+    x0, its0, _ = e0.gmres_np(b, rtol=1e-6, restart=150, max_it=300)
+    group = ctypes.c_void_p()
+    out, errs = [None] * R, []
+
+    def body(r):
+        try:
+            e = c.Engine(hip_lib, "BRM1", 0)
+            e.comm_init_threads(r, R, group)
+            e.set_velocity_block(d)
+            e.set_system(perm["A"], perm["is_u"], perm["is_p"])
+            for which, k in ((c.MAT_AP, "Ap"), (c.MAT_MP, "Mp"),
+                             (c.MAT_KP, "Kp")):
+                e.set_csr(which, perm[k])
+            e.set_bc(perm["bc_idx"], np.zeros(len(perm["bc_idx"])))
+            from fenapack_amd.fem.multigrid import dense_csr
+            ops, P, bounds, C = mg1
+            Lv = len(ops)
+            e.mg_begin(c.KSP_A00, Lv, 2, 2)
+            for l in range(Lv - 1, 0, -1):
+                e.mg_set_level(c.KSP_A00, l, ops[l] if l < Lv - 1 else None,
+                               P[l], *bounds[l])
+            e.mg_set_level(c.KSP_A00, 0, dense_csr(C))
+            e.set_inner(c.KSP_A00, "richardson", "mg", 1, 0.0)
+            emax_ap = 1.1 * estimate_emax(pb.Ap, iters=12)
+            e.set_inner(c.KSP_AP, "chebyshev", "jacobi", 12, 0.0,
+                        0.02 * emax_ap, emax_ap)
+            e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.5)
+            e.setup()
+            res = {"fs": e.fieldsplit_apply_np(x[perm["sig"]]),
+                   "pcd": e.apply_np(xp[perm["tp"]]),
+                   "nu_loc": e.info(c.INFO_N_U_LOCAL)}
+            res["x"], res["its"], _ = e.gmres_np(b[perm["sig"]], rtol=1e-6,
+                                                 restart=150, max_it=300)
+            out[r] = res
+        except Exception as ex:            # pragma: no cover
+            errs.append((r, repr(ex)))
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "ranks deadlocked"
+    assert not errs, errs
+    assert sum(int(o["nu_loc"]) for o in out) == V.n_u
+    for o in out:
+        assert relerr(o["fs"], y0[perm["sig"]]) < 1e-11
+        assert relerr(o["pcd"], yp0[perm["tp"]]) < 1e-11
+        assert abs(o["its"] - its0) <= max(2, its0 // 4)
