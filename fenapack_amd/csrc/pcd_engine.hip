@@ -1835,6 +1835,10 @@ static int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const 
                              std::vector<int32_t>& isu_r, std::vector<int32_t>& isp_r) {
   { const char* e = getenv("PCD_REORDER");
     if (e) h->reorder_mode = !strcmp(e, "none") ? 0 : !strcmp(e, "always") ? 2 : 1; }
+  for (int64_t i = 0; i < n_u; ++i)
+    if (is_u[i] < 0 || is_u[i] >= n) return fail(PCD_ERR_ARG, "set_system: index sets do not partition 0..n-1");
+  for (int64_t i = 0; i < n_p; ++i)
+    if (is_p[i] < 0 || is_p[i] >= n) return fail(PCD_ERR_ARG, "set_system: index sets do not partition 0..n-1");
   if ((int64_t)h->ru.n2o.size() == n_u && (!h->rp.active() || (int64_t)h->rp.n2o.size() == n_p)) {
     // same spaces as before (new pattern of the same problem): keep the numbering
   } else {
@@ -1842,10 +1846,7 @@ static int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const 
     bool u_ops = h->mat[PCD_MAT_A00].set || h->mat[PCD_MAT_A01].set;
     if (h->reorder_mode && !u_ops && n_u > 0) {
       std::vector<int32_t> mu(n, -1), rp, cc; std::vector<int64_t> src;
-      for (int64_t i = 0; i < n_u; ++i) {
-        if (is_u[i] < 0 || is_u[i] >= n) return fail(PCD_ERR_ARG, "set_system: index sets do not partition 0..n-1");
-        mu[is_u[i]] = (int32_t)i;
-      }
+      for (int64_t i = 0; i < n_u; ++i) mu[is_u[i]] = (int32_t)i;
       extract_block(n_u, is_u, rowptr, colidx, mu, rp, cc, src);
       // node graph when the block has the interleaved-component pattern
       int nc = 1;
@@ -2734,6 +2735,7 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_N_P_LOCAL: *out = (double)h->np_loc; return 0;
     case PCD_INFO_A00_COMPONENTS: *out = (double)h->mat[PCD_MAT_A00].kron; return 0;
     case PCD_INFO_RANKS: *out = h->comm ? (double)h->nranks : 0.0; return 0;
+    case PCD_INFO_REORDERED: *out = (h->ru.active() ? 1.0 : 0.0) + (h->rp.active() ? 2.0 : 0.0); return 0;
     case PCD_INFO_A00_ROWS_PER_WG:
       *out = (double)(h->mat[PCD_MAT_A00].kron ? h->mat[PCD_MAT_A00].rb2 : h->mat[PCD_MAT_A00].rb);
       return 0;

@@ -167,6 +167,9 @@ def test_permuted_numbering_same_result_same_speed(hip_lib, monkeypatch, kind,
     mg1 = _renumbered(mg0, lp)
     e0 = _engine(hip_lib, st, base, mg0)
     e1 = _engine(hip_lib, st, perm, mg1)
+    # the lexicographic input is left alone, the permuted one is renumbered
+    assert int(e0.info(c.INFO_REORDERED)) == 0
+    assert int(e1.info(c.INFO_REORDERED)) == 3
     x = rng.standard_normal(V.ndof)
     y0 = e0.fieldsplit_apply_np(x)
     y1 = e1.fieldsplit_apply_np(x[perm["sig"]])
@@ -211,6 +214,7 @@ def test_permuted_numbering_same_result_same_speed(hip_lib, monkeypatch, kind,
     t0, t1 = _time_applies(e0, V.ndof), _time_applies(e1, V.ndof)
     monkeypatch.setenv("PCD_REORDER", "none")
     e2 = _engine(hip_lib, st, perm, mg1)
+    assert int(e2.info(c.INFO_REORDERED)) == 0
     assert relerr(e2.fieldsplit_apply_np(x[perm["sig"]]), y0[perm["sig"]]) < 1e-11
     t2 = _time_applies(e2, V.ndof)
     print("\n%s level %d: %.3f ms lexicographic, %.3f ms permuted + engine "
