@@ -72,6 +72,8 @@ def library():
                                    ctypes.c_int64, _I32P, _I32P, _F64P, _I32P,
                                    _I32P, _F64P, _I64P, _I32P, _F64P]
     L.pcdh_set_threads.argtypes = [ctypes.c_int]
+    L.pcdh_spmv.argtypes = [ctypes.c_int64, _I32P, _I32P, _F64P, _F64P, _F64P,
+                            _F64P]
     PP32 = ctypes.POINTER(_I32P)
     L.pcdh_union_count.argtypes = [ctypes.c_int64, ctypes.c_int, _I64P, PP32,
                                    PP32, _I64P]
@@ -268,3 +270,26 @@ def union_blocks(n, blocks):
                            _p(off, _I64P), _p(indptr, _I64P),
                            _p(indices, _I32P), _p(order, _I64P)))
     return indptr, indices, order
+
+
+class SpMV(object):
+    """``y = scale .* (A x)`` with the arrays of ``A`` converted once (threaded;
+    bitwise scipy's ``csr_matvec`` row sums)."""
+
+    def __init__(self, A, scale=None):
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        self.n = A.shape[0]
+        self._rp, self._ci = _i32(A.indptr), _i32(A.indices)
+        self._va = np.ascontiguousarray(A.data, dtype=np.float64)
+        self._sc = None if scale is None else \
+            np.ascontiguousarray(scale, dtype=np.float64)
+
+    def __call__(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.n)
+        _chk(library().pcdh_spmv(self.n, _p(self._rp, _I32P),
+                                 _p(self._ci, _I32P), _p(self._va, _F64P),
+                                 _p(x, _F64P), _p(self._sc, _F64P),
+                                 _p(y, _F64P)))
+        return y

@@ -383,6 +383,21 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols, const int32_t* 
   return 0;
 }
 
+// ----------------------------------------------------------------------- SpMV
+int pcdh_spmv(int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
+              const double* x, const double* scale, double* y) {
+  if (nrows < 0 || !rowptr || (rowptr[nrows] && (!col || !val)) || !x || !y)
+    return fail(PCDH_ERR_ARG, "spmv: bad arguments");
+  const int T = nthreads((int64_t)rowptr[nrows]);
+#pragma omp parallel for schedule(static, 2048) num_threads(T)
+  for (int64_t i = 0; i < nrows; ++i) {
+    double s = 0.0;                        // (ascending k: scipy's csr_matvec order)
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * x[col[k]];
+    y[i] = scale ? scale[i] * s : s;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------- union of mapped blocks
 int pcdh_union_count(int64_t n, int nb, const int64_t* nr, const int32_t* const* rowmap,
                      const int32_t* const* indptr, int64_t* out) {

@@ -738,9 +738,18 @@ def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None):
     if not cold:
         iters = max(3, iters // 4)
     lam, best, it = 1.0, 0.0, 0
+    if A.nnz > 4000000:
+        # large operators: the threaded native SpMV (same row sums as scipy's)
+        from . import _host
+        if not _host.use_numpy():
+            apply = _host.SpMV(A, dinv)
+        else:
+            apply = lambda u: dinv * (A @ u)
+    else:
+        apply = lambda u: dinv * (A @ u)
     while it < iters:
         v = v / np.linalg.norm(v)
-        w = dinv * (A @ v)
+        w = apply(v)
         lam = np.linalg.norm(w)
         v = w
         it += 1

@@ -115,6 +115,15 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols,
                      const int32_t* b_col, const double* b_val,
                      const int64_t* c_rowptr, int32_t* c_col, double* c_val);
 
+/* ---- y = scale .* (A x) ------------------------------------------------------
+ * Threaded CSR SpMV (row sums in ascending entry order: bitwise what scipy's
+ * csr_matvec gives).  The host-side power iterations behind
+ * -ksp_chebyshev_esteig / the smoother bounds ([ext PETSc] KSPChebyshevEstEig)
+ * are a dozen of these per multigrid level; `scale` (may be NULL) is the
+ * Jacobi diagonal D^-1. */
+int pcdh_spmv(int64_t nrows, const int32_t* rowptr, const int32_t* col,
+              const double* val, const double* x, const double* scale, double* y);
+
 /* ---- union of index-mapped blocks -------------------------------------------
  * The monolithic pattern of a block system in the caller's mixed numbering
  * (what DOLFIN's SystemAssembler produces directly, assembling.py:151-155):
