@@ -74,6 +74,13 @@ def library():
     L.pcdh_set_threads.argtypes = [ctypes.c_int]
     L.pcdh_spmv.argtypes = [ctypes.c_int64, _I32P, _I32P, _F64P, _F64P, _F64P,
                             _F64P]
+    L.pcdh_spmm.argtypes = [ctypes.c_int64, _I32P, _I32P, _F64P, ctypes.c_int,
+                            _F64P, _F64P, _F64P]
+    L.pcdh_kron_factor.argtypes = [ctypes.c_int64, _I32P, _I32P, _F64P,
+                                   ctypes.c_int, _I32P, _I32P, _F64P]
+    L.pcdh_kron_expand.argtypes = [ctypes.c_int64, _I32P, _I32P, _F64P,
+                                   ctypes.c_int, _I32P, _I32P, _F64P]
+    L.pcdh_gather_sum.argtypes = [ctypes.c_int64, _I64P, _I64P, _F64P, _F64P]
     PP32 = ctypes.POINTER(_I32P)
     L.pcdh_union_count.argtypes = [ctypes.c_int64, ctypes.c_int, _I64P, PP32,
                                    PP32, _I64P]
@@ -274,12 +281,14 @@ def union_blocks(n, blocks):
 
 class SpMV(object):
     """``y = scale .* (A x)`` with the arrays of ``A`` converted once (threaded;
-    bitwise scipy's ``csr_matvec`` row sums)."""
+    bitwise scipy's ``csr_matvec`` row sums).  ``nvec`` > 1: ``A`` is the
+    scalar factor of ``A (x) I_nvec`` and ``x`` / ``scale`` / ``y`` are the
+    expanded operator's (node-interleaved) vectors."""
 
-    def __init__(self, A, scale=None):
+    def __init__(self, A, scale=None, nvec=1):
         import scipy.sparse as sp
         A = sp.csr_matrix(A)
-        self.n = A.shape[0]
+        self.n, self.nvec = A.shape[0], int(nvec)
         self._rp, self._ci = _i32(A.indptr), _i32(A.indices)
         self._va = np.ascontiguousarray(A.data, dtype=np.float64)
         self._sc = None if scale is None else \
@@ -287,9 +296,93 @@ class SpMV(object):
 
     def __call__(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
-        y = np.empty(self.n)
-        _chk(library().pcdh_spmv(self.n, _p(self._rp, _I32P),
-                                 _p(self._ci, _I32P), _p(self._va, _F64P),
-                                 _p(x, _F64P), _p(self._sc, _F64P),
-                                 _p(y, _F64P)))
+        y = np.empty(self.n * self.nvec)
+        if self.nvec == 1:
+            _chk(library().pcdh_spmv(self.n, _p(self._rp, _I32P),
+                                     _p(self._ci, _I32P), _p(self._va, _F64P),
+                                     _p(x, _F64P), _p(self._sc, _F64P),
+                                     _p(y, _F64P)))
+        else:
+            _chk(library().pcdh_spmm(self.n, _p(self._rp, _I32P),
+                                     _p(self._ci, _I32P), _p(self._va, _F64P),
+                                     self.nvec, _p(x, _F64P),
+                                     _p(self._sc, _F64P), _p(y, _F64P)))
         return y
+
+
+NOT_KRON = 100
+
+
+def kron_factor(A, nc):
+    """``F`` (scipy CSR) when ``A == F (x) I_nc`` exactly on node-interleaved
+    dofs - pattern AND values - else ``None``."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A)
+    n, m = A.shape
+    if nc < 2 or n % nc or m % nc or A.nnz % nc:
+        return None
+    if use_numpy():
+        F = sp.csr_matrix(A[::nc, ::nc])
+        E = sp.kron(F, sp.identity(nc), format="csr")
+        if E.nnz != A.nnz or abs(E - A).max() != 0:
+            return None
+        F.sort_indices()
+        return F
+    if not A.has_sorted_indices:
+        A = A.sorted_indices()
+    rp, ci = _i32(A.indptr), _i32(A.indices)
+    va = np.ascontiguousarray(A.data, dtype=np.float64)
+    frp = np.empty(n // nc + 1, dtype=np.int32)
+    fc = np.empty(A.nnz // nc, dtype=np.int32)
+    fv = np.empty(A.nnz // nc, dtype=np.float64)
+    rc = library().pcdh_kron_factor(n, _p(rp, _I32P), _p(ci, _I32P),
+                                    _p(va, _F64P), nc, _p(frp, _I32P),
+                                    _p(fc, _I32P), _p(fv, _F64P))
+    if rc == NOT_KRON:
+        return None
+    _chk(rc)
+    F = sp.csr_matrix((fv, fc, frp), shape=(n // nc, m // nc))
+    F.has_sorted_indices = True
+    return F
+
+
+def kron_expand(F, nc):
+    """``F (x) I_nc`` (node-interleaved, sorted columns); the result remembers
+    its factor (``.kron_scalar``, ``.kron_block``)."""
+    import scipy.sparse as sp
+    F = sp.csr_matrix(F)
+    if nc == 1:
+        return F
+    if use_numpy():
+        A = sp.kron(F, sp.identity(nc, format="csr"), format="csr")
+        A.sort_indices()
+    else:
+        if not F.has_sorted_indices:
+            F = F.sorted_indices()
+        ns, ms = F.shape
+        frp, fc = _i32(F.indptr), _i32(F.indices)
+        fv = np.ascontiguousarray(F.data, dtype=np.float64)
+        rp = np.empty(nc * ns + 1, dtype=np.int32)
+        ci = np.empty(nc * F.nnz, dtype=np.int32)
+        va = np.empty(nc * F.nnz, dtype=np.float64)
+        _chk(library().pcdh_kron_expand(ns, _p(frp, _I32P), _p(fc, _I32P),
+                                        _p(fv, _F64P), nc, _p(rp, _I32P),
+                                        _p(ci, _I32P), _p(va, _F64P)))
+        A = sp.csr_matrix((va, ci, rp), shape=(nc * ns, nc * ms))
+        A.has_sorted_indices = True
+    A.kron_scalar, A.kron_block = F, nc
+    return A
+
+
+def gather_sum(ptr, members, vals, out=None):
+    """``out[g] = sum(vals[members[ptr[g]:ptr[g+1]]])``, added in ascending
+    position (``numpy.bincount(inv, weights=vals)`` for the grouping whose
+    member lists these are)."""
+    ptr, members = _i64(ptr), _i64(members)
+    vals = np.ascontiguousarray(vals, dtype=np.float64).ravel()
+    ng = ptr.size - 1
+    if out is None:
+        out = np.empty(ng)
+    _chk(library().pcdh_gather_sum(ng, _p(ptr, _I64P), _p(members, _I64P),
+                                   _p(vals, _F64P), _p(out, _F64P)))
+    return out

@@ -1,6 +1,6 @@
 // pcd_host.cpp - libpcd_host.so: host-side (OpenMP) set-up helpers of the PCD
-// engine; C ABI in include/pcd_host.h.  Integer work only (patterns,
-// contribution lists, sub-matrix extraction, symbolic products); no HIP.
+// engine; C ABI in include/pcd_host.h.  Patterns, contribution lists, sub-matrix
+// extraction, sparse products, sums of element contributions; no HIP.
 //
 // Build: g++ -O3 -fopenmp -std=c++17 -shared -fPIC pcd_host.cpp -o libpcd_host.so
 #include "../../include/pcd_host.h"
@@ -394,6 +394,95 @@ int pcdh_spmv(int64_t nrows, const int32_t* rowptr, const int32_t* col, const do
     double s = 0.0;                        // (ascending k: scipy's csr_matvec order)
     for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * x[col[k]];
     y[i] = scale ? scale[i] * s : s;
+  }
+  return 0;
+}
+
+// y = scale .* (A X) for nvec interleaved vectors (X, Y: nrows x nvec row-major):
+// the power iteration of F (x) I_nvec without the expanded matrix; each of the
+// nvec row sums runs in ascending entry order (= the expanded operator's sums)
+int pcdh_spmm(int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
+              int nvec, const double* x, const double* scale, double* y) {
+  if (nrows < 0 || nvec < 1 || nvec > 8 || !rowptr || (rowptr[nrows] && (!col || !val)) || !x || !y)
+    return fail(PCDH_ERR_ARG, "spmm: bad arguments");
+  const int T = nthreads((int64_t)rowptr[nrows] * nvec);
+#pragma omp parallel for schedule(static, 2048) num_threads(T)
+  for (int64_t i = 0; i < nrows; ++i) {
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const double a = val[k];
+      const double* xr = x + (int64_t)col[k] * nvec;
+      for (int c = 0; c < nvec; ++c) s[c] += a * xr[c];
+    }
+    for (int c = 0; c < nvec; ++c) y[i * nvec + c] = scale ? scale[i * nvec + c] * s[c] : s[c];
+  }
+  return 0;
+}
+
+// ------------------------------------------------------- F (x) I_nc, both ways
+int pcdh_kron_factor(int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
+                     int nc, int32_t* f_rowptr, int32_t* f_col, double* f_val) {
+  if (nrows < 0 || nc < 2 || !rowptr || !f_rowptr) return fail(PCDH_ERR_ARG, "kron_factor: bad arguments");
+  if (nrows % nc || rowptr[nrows] % nc) return PCDH_NOT_KRON;
+  const int64_t ns = nrows / nc;
+  const int T = nthreads((int64_t)rowptr[nrows]);
+  int bad = 0;
+#pragma omp parallel for schedule(static, 2048) num_threads(T) reduction(| : bad)
+  for (int64_t s = 0; s < ns; ++s) {
+    const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a;
+    // component rows of one node are stored back to back: row c starts at a + c len
+    for (int c = 1; c < nc; ++c)
+      if (rowptr[nc * s + c] != a + c * len || rowptr[nc * s + c + 1] - rowptr[nc * s + c] != len) bad = 1;
+    if (bad) continue;
+    for (int32_t k = 0; k < len; ++k) {
+      if (col[a + k] % nc) { bad = 1; break; }
+      for (int c = 1; c < nc; ++c)
+        if (col[a + c * len + k] != col[a + k] + c || val[a + c * len + k] != val[a + k]) bad = 1;
+    }
+  }
+  if (bad) return PCDH_NOT_KRON;
+  for (int64_t s = 0; s <= ns; ++s) f_rowptr[s] = rowptr[s < ns ? nc * s : nrows] / nc;
+  if (!f_col || !f_val) return 0;
+#pragma omp parallel for schedule(static, 2048) num_threads(T)
+  for (int64_t s = 0; s < ns; ++s) {
+    const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a, o = f_rowptr[s];
+    for (int32_t k = 0; k < len; ++k) { f_col[o + k] = col[a + k] / nc; f_val[o + k] = val[a + k]; }
+  }
+  return 0;
+}
+
+int pcdh_kron_expand(int64_t ns, const int32_t* f_rowptr, const int32_t* f_col, const double* f_val,
+                     int nc, int32_t* rowptr, int32_t* col, double* val) {
+  if (ns < 0 || nc < 1 || !f_rowptr || !rowptr || (f_rowptr[ns] && (!f_col || !f_val || !col || !val)))
+    return fail(PCDH_ERR_ARG, "kron_expand: bad arguments");
+  if ((int64_t)f_rowptr[ns] * nc > INT32_MAX) return fail(PCDH_ERR_ARG, "kron_expand: more than 2^31 entries");
+  const int T = nthreads((int64_t)f_rowptr[ns] * nc);
+#pragma omp parallel for schedule(static, 2048) num_threads(T)
+  for (int64_t s = 0; s < ns; ++s) {
+    const int32_t o = f_rowptr[s], len = f_rowptr[s + 1] - o;
+    for (int c = 0; c < nc; ++c) {
+      const int32_t a = nc * o + c * len;
+      rowptr[nc * s + c] = a;
+      for (int32_t k = 0; k < len; ++k) { col[a + k] = nc * f_col[o + k] + c; val[a + k] = f_val[o + k]; }
+    }
+  }
+  rowptr[nc * ns] = nc * f_rowptr[ns];
+  return 0;
+}
+
+// ------------------------------------------------- sums of grouped contributions
+// out[g] = sum of vals[members[k]], k in [ptr[g], ptr[g+1]), added in ascending k
+// (members ascend within a group: numpy.bincount's order of additions)
+int pcdh_gather_sum(int64_t ngroups, const int64_t* ptr, const int64_t* members,
+                    const double* vals, double* out) {
+  if (ngroups < 0 || !ptr || (ptr[ngroups] && (!members || !vals)) || !out)
+    return fail(PCDH_ERR_ARG, "gather_sum: bad arguments");
+  const int T = nthreads(ptr[ngroups]);
+#pragma omp parallel for schedule(static, 4096) num_threads(T)
+  for (int64_t g = 0; g < ngroups; ++g) {
+    double s = 0.0;
+    for (int64_t k = ptr[g]; k < ptr[g + 1]; ++k) s += vals[members[k]];
+    out[g] = s;
   }
   return 0;
 }

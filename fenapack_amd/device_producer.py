@@ -269,8 +269,7 @@ class DeviceProducer(object):
             mass = None
             if pb.idt:
                 pat = V._patterns(False)["SS"]
-                mass = np.bincount(pat.inv, weights=V.p2_mass_cells().ravel(),
-                                   minlength=pat.nnz)
+                mass = pat.sum_entries(V.p2_mass_cells())
             eng.fe_bind_residual(sp.csr_matrix(pb._A01_raw),
                                  sp.csr_matrix(pb._A10_raw), pb.bc_u_idx,
                                  pb._bc_mult[pb.bc_u_idx], mass, pb.idt)
@@ -293,7 +292,7 @@ class DeviceProducer(object):
         S0 = pl.nu * V.p2_stiffness_cells()
         if pl.idt:
             S0 = S0 + pl.idt * V.p2_mass_cells()
-        f_const = np.bincount(pat.inv, weights=S0.ravel(), minlength=pat.nnz)
+        f_const = pat.sum_entries(S0)
         nodes = np.unique(pl.bc_u_idx // d)
         assert nodes.size * d == pl.bc_u_idx.size, \
             "device producer: Dirichlet data must constrain whole nodes"
@@ -390,7 +389,7 @@ class DeviceProducer(object):
         idt = 0.0 if pb.pcdr else pb.idt
         if idt:
             M = V.area[:, None, None] * V._ref()["P"][None] * (idt / pb.nu)
-            cst = np.bincount(pat.inv, weights=M.ravel(), minlength=pat.nnz)
+            cst = pat.sum_entries(M)
         self.eng.fe_bind_kp(ptr, src, cst, 1.0 / pb.nu)
         self.nnz_kp = pat.nnz
         # BRM2: - (1/nu) int_inflow (w.n) p q ds depends on the iterate too:

@@ -11,7 +11,8 @@ are Galerkin products ``P^T A P`` (host side, scipy)."""
 import numpy as np
 import scipy.sparse as sp
 
-from .taylor_hood import TaylorHood, _p2_basis
+from .. import _host
+from .taylor_hood import TaylorHood, _p2_basis, small_det_inv
 
 
 #: the numpy producer holds every element matrix of a level at once; beyond this
@@ -113,7 +114,7 @@ def prolongations(Vc, Vf, parent):
                     axis=1)
     pts = np.concatenate([pf, mids], axis=1)           # P2 nodes of the cell
     T = np.stack([pc[:, k + 1] - pc[:, 0] for k in range(d)], axis=2)
-    Tinv = np.linalg.inv(T)                            # (nf, d, d)
+    Tinv = small_det_inv(T)[1]                         # (nf, d, d)
     l1d = np.matmul(pts - pc[:, None, 0, :], Tinv.transpose(0, 2, 1))
     lam = np.concatenate([1.0 - l1d.sum(axis=2, keepdims=True), l1d], axis=2)
     na, nvl = Vf.na, Vf.nvl
@@ -129,10 +130,9 @@ def prolongations(Vc, Vf, parent):
 
 
 def interleave(P, d=2):
-    """Scalar P2 prolongation -> velocity prolongation (dofs d*node+comp)."""
-    P = sp.kron(P, sp.identity(d, format="csr"), format="csr")
-    P.sort_indices()
-    return P
+    """Scalar P2 prolongation -> velocity prolongation (dofs d*node+comp);
+    the result remembers its scalar factor (``.kron_scalar``)."""
+    return _host.kron_expand(P, d)
 
 
 interleave2 = interleave
@@ -162,13 +162,17 @@ class Interpolations(object):
 
 def galerkin_chain(A, chain):
     """Coarse operators ``A_{l-1} = P_l^T A_l P_l``; returns the list of
-    operators, coarsest first (``ops[-1] is A``)."""
+    operators, coarsest first (``ops[-1] is A``).  Large products run on the
+    threaded native SpGEMM (same sums in the same order as scipy's)."""
     ops = [None] * len(chain)
     ops[-1] = sp.csr_matrix(A)
     for l in range(len(chain) - 1, 0, -1):
         P = chain[l]
-        C = (P.T @ ops[l] @ P).tocsr()
-        C.sort_indices()
+        if ops[l].nnz > 400000 and not _host.use_numpy():
+            C = _host.spgemm(_host.spgemm(_host.transpose(P), ops[l]), P)
+        else:
+            C = (P.T @ ops[l] @ P).tocsr()
+            C.sort_indices()
         ops[l - 1] = C
     return ops
 
@@ -202,15 +206,11 @@ def dense_csr(C):
 
 def _kron_factor(A0, block):
     """``F`` if ``A0 == F (x) I_block`` on interleaved dofs, else ``None``."""
-    n = A0.shape[0]
-    if block < 2 or n % block:
+    if block < 2 or A0.shape[0] % block:
         return None
-    A0 = sp.csr_matrix(A0)
-    F = A0[::block, ::block]
-    if sp.kron(F, sp.identity(block), format="csr").nnz < A0.nnz or \
-            abs(sp.kron(F, sp.identity(block), format="csr") - A0).max() != 0:
-        return None
-    return F
+    if getattr(A0, "kron_block", 0) == block:
+        return A0.kron_scalar
+    return _host.kron_factor(A0, block)
 
 
 def coarse_inverse(A0, block=1):

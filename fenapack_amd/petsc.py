@@ -12,6 +12,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _cabi as c
+from . import _host
 
 
 # --------------------------------------------------------------- options DB
@@ -576,26 +577,58 @@ class KSP(object):
             if not 1 <= k < len(chain) - 1:
                 raise ValueError("%spc_mg_skip_levels %d: no such intermediate "
                                  "level" % (self._prefix, k))
-            merged = sp.csr_matrix(chain[k + 1] @ chain[k])
-            merged.sort_indices()
+            sa, sb = _scalar_of(chain[k + 1]), _scalar_of(chain[k])
+            if sa is not None and sb is not None and sa[1] == sb[1]:
+                merged = _host.kron_expand(sp.csr_matrix(sa[0] @ sb[0]), sa[1])
+            else:
+                merged = sp.csr_matrix(chain[k + 1] @ chain[k])
+                merged.sort_indices()
             chain = chain[:k] + [merged] + chain[k + 2:]
+        # The velocity block of the preconditioner matrix is F (x) I_d (the
+        # Picard operator couples no components) and so are its prolongations:
+        # products, bounds, the coarse inverse and the composed levels are
+        # computed on the scalar factor - the same numbers (row sums run in
+        # the same order) at 1/d of the work - and expanded for the hand-over.
+        blk = getattr(self.engine, "velocity_block", 2) \
+            if self.slot == c.KSP_A00 else 1
+        A = self._ops[1].A
+        chain_s = ops_s = None
+        if blk > 1:
+            facs = [_scalar_of(P) for P in chain[1:]]
+            if all(f is not None and f[1] == blk for f in facs):
+                F = _host.kron_factor(A, blk)
+                if F is not None:
+                    chain_s = [None] + [f[0] for f in facs]
         if pc.mg_galerkin:
-            ops = galerkin_chain(self._ops[1].A, chain)
+            if chain_s is not None:
+                ops_s = galerkin_chain(F, chain_s)
+                ops = [_host.kron_expand(o, blk) for o in ops_s[:-1]] \
+                    + [sp.csr_matrix(A)]
+            else:
+                ops = galerkin_chain(A, chain)
         else:
             if pc._mg_ops_cb is None:
                 raise RuntimeError("%spc_mg_galerkin none needs coarse "
                                    "operators (pc.setMGOperators)"
                                    % self._prefix)
             ops = [sp.csr_matrix(o) for o in pc._mg_ops_cb(len(chain))] \
-                + [sp.csr_matrix(self._ops[1].A)]
+                + [sp.csr_matrix(A)]
             assert len(ops) == len(chain)
+            if chain_s is not None:
+                ops_s = [_host.kron_factor(o, blk) for o in ops[:-1]] + [F]
+                if any(o is None for o in ops_s):
+                    chain_s = ops_s = None
         a, b, cc, d = pc.mg_esteig
         bounds = [None]
         if not hasattr(pc, "_mg_warm"):
             pc._mg_warm = {}
         for l in range(1, len(ops)):
-            emax = estimate_emax(ops[l], iters=12,
-                                 warm=pc._mg_warm.setdefault(l, {}))
+            if ops_s is not None:
+                emax = estimate_emax(ops_s[l], iters=12, block=blk,
+                                     warm=pc._mg_warm.setdefault(l, {}))
+            else:
+                emax = estimate_emax(ops[l], iters=12,
+                                     warm=pc._mg_warm.setdefault(l, {}))
             bounds.append((b * emax, d * emax))
         if ops[0].shape[0] > 30000:
             # (an explicit inverse of that size is tens of GB - e.g. a smoothed-
@@ -606,8 +639,7 @@ class KSP(object):
                 "stalled or has too few levels"
                 % (self._prefix, "gamg" if pc.mg_algebraic else "mg",
                    ops[0].shape[0]))
-        C = coarse_inverse(ops[0], getattr(self.engine, "velocity_block", 2)
-                           if self.slot == c.KSP_A00 else 1)
+        C = coarse_inverse(ops[0], blk)
         eng, slot, L = self.engine, self.slot, len(ops)
         # kept for statistics (roofline bytes) and for the CPU baseline
         nu_pre = pc.mg_smooth_its if pc.mg_smooth_down is None \
@@ -632,10 +664,12 @@ class KSP(object):
                 eng.mg_update_values(slot, l,
                                      ops[l].data if l < L - 1 else None,
                                      *bounds[l])
-        self._push_fused_levels(ops, chain, bounds)
+        self._push_fused_levels(ops, chain, bounds, ops_s, chain_s, blk)
 
-    def _push_fused_levels(self, ops, chain, bounds):
-        """Small levels of the cycle as pre-composed operators."""
+    def _push_fused_levels(self, ops, chain, bounds, ops_s=None, chain_s=None,
+                           blk=1):
+        """Small levels of the cycle as pre-composed operators (composed on
+        the scalar factors ``ops_s`` / ``chain_s`` when there are any)."""
         from .compose import vcycle_level
         pc, eng, slot = self.pc, self.engine, self.slot
         pc.mg_fused = []
@@ -643,9 +677,6 @@ class KSP(object):
         if not getattr(eng.L, "hip", False) or pc.mg_fuse_nnz <= 0 \
                 or nu_pre < 1 or nu_post < 1:
             return
-        blk = 1
-        if slot == c.KSP_A00:
-            blk = getattr(eng, "velocity_block", 2)
         for l in range(1, len(ops)):
             A = ops[l]
             grow = 3 if nu_post == 1 else 6     # nnz(W_u) / nnz(A), at least
@@ -653,14 +684,21 @@ class KSP(object):
                     or grow * (A.nnz // blk) > pc.mg_fuse_nnz:
                 break       # larger levels are bandwidth-bound: no point in
                 #             composing W_u just to measure it
-            Wd, Wu = vcycle_level(A, chain[l], bounds[l][0], bounds[l][1],
-                                  nu_pre, nu_post)
-            nnz_f, nodes = Wu.nnz // blk, A.shape[0] // blk
+            if ops_s is not None:
+                Wd, Wu = vcycle_level(ops_s[l], chain_s[l], bounds[l][0],
+                                      bounds[l][1], nu_pre, nu_post)
+                nnz_f, nodes = Wu.nnz, ops_s[l].shape[0]
+            else:
+                Wd, Wu = vcycle_level(A, chain[l], bounds[l][0], bounds[l][1],
+                                      nu_pre, nu_post)
+                nnz_f, nodes = Wu.nnz // blk, A.shape[0] // blk
             avg = nnz_f / float(max(nodes, 1))
             suits_stream = avg <= pc.mg_fuse_row_nnz
             suits_wave = nodes <= pc.mg_fuse_wave_nodes or avg >= 300.0
             if nnz_f > pc.mg_fuse_nnz or not (suits_stream or suits_wave):
                 break
+            if ops_s is not None:
+                Wd, Wu = _host.kron_expand(Wd, blk), _host.kron_expand(Wu, blk)
             eng.mg_set_fused(slot, l, Wd, Wu)
             pc.mg_fused.append((l, Wd.nnz, Wu.nnz))
 
@@ -721,30 +759,34 @@ class KSP(object):
         self.engine.inner_solve(self.slot, b.t, x.t, c.MEM_DEVICE)
 
 
-def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None):
+def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None, block=1):
     """Largest eigenvalue (modulus) of ``D^-1 A`` by power iteration on the
     host - the stand-in for PETSc's ``-ksp_chebyshev_esteig`` [ext PETSc].
     ``warm``: a dict that carries the iterate between calls (re-estimation
-    after a value refresh then needs only a few steps)."""
+    after a value refresh then needs only a few steps).  ``block`` > 1: ``A``
+    is the scalar factor of ``A (x) I_block``; the iteration is the expanded
+    operator's (same start vector, same sums) on ``block`` interleaved
+    vectors at once."""
     A = sp.csr_matrix(A)
+    n = A.shape[0] * block
     d = A.diagonal().copy()
     d[d == 0.0] = 1.0
     dinv = 1.0 / d if jacobi else np.ones_like(d)
+    if block > 1:
+        dinv = np.repeat(dinv, block)
     v = None if warm is None else warm.get("v")
-    cold = v is None or v.size != A.shape[0]
+    cold = v is None or v.size != n
     if cold:
-        v = np.random.default_rng(seed).standard_normal(A.shape[0])
+        v = np.random.default_rng(seed).standard_normal(n)
     full = iters
     if not cold:
         iters = max(3, iters // 4)
     lam, best, it = 1.0, 0.0, 0
-    if A.nnz > 4000000:
+    if A.nnz * block > 4000000 and not _host.use_numpy():
         # large operators: the threaded native SpMV (same row sums as scipy's)
-        from . import _host
-        if not _host.use_numpy():
-            apply = _host.SpMV(A, dinv)
-        else:
-            apply = lambda u: dinv * (A @ u)
+        apply = _host.SpMV(A, dinv, nvec=block)
+    elif block > 1:
+        apply = lambda u: dinv * (A @ u.reshape(-1, block)).ravel()
     else:
         apply = lambda u: dinv * (A @ u)
     while it < iters:
@@ -770,6 +812,13 @@ def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None):
         warm["v"] = v
         warm["lam"] = float(lam)
     return float(lam)
+
+
+def _scalar_of(P):
+    """``(F, block)`` when ``P`` was built as ``F (x) I_block``
+    (``_host.kron_expand``), else ``None``."""
+    F = getattr(P, "kron_scalar", None)
+    return None if F is None else (F, int(P.kron_block))
 
 
 class Sys(object):

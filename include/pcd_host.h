@@ -31,6 +31,7 @@ extern "C" {
 #define PCDH_ERR_ARG 1
 #define PCDH_ERR_NOMEM 2
 #define PCDH_ERR_STATE 3
+#define PCDH_NOT_KRON 100   /* pcdh_kron_factor: a valid answer, not an error */
 
 const char* pcdh_last_error(void);
 /* OpenMP threads the helpers use (0: the runtime's default) */
@@ -123,6 +124,39 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols,
  * Jacobi diagonal D^-1. */
 int pcdh_spmv(int64_t nrows, const int32_t* rowptr, const int32_t* col,
               const double* val, const double* x, const double* scale, double* y);
+
+/* The same for `nvec` (<= 8) interleaved vectors: X, Y are nrows x nvec row-major,
+ * scale has nrows * nvec entries.  With the scalar factor F of F (x) I_nvec this
+ * IS the expanded operator's SpMV (same sums, same order) at half / a third of
+ * the matrix traffic. */
+int pcdh_spmm(int64_t nrows, const int32_t* rowptr, const int32_t* col,
+              const double* val, int nvec, const double* x, const double* scale,
+              double* y);
+
+/* ---- F (x) I_nc <-> F ---------------------------------------------------------
+ * The velocity block of the preconditioner matrix is F (x) I_d on node-
+ * interleaved dofs (the Picard operator of demo_navier-stokes-pcd.py:101-106
+ * couples no components), and so are its prolongations: Galerkin products,
+ * smoother bounds and composed levels are computed on the scalar factor and
+ * expanded for the hand-over.
+ * pcdh_kron_factor: 0 and F (f_rowptr: nrows / nc + 1, f_col / f_val: nnz / nc;
+ * both may be NULL = test only) when A == F (x) I_nc EXACTLY (pattern and
+ * values), PCDH_NOT_KRON when it is not.
+ * pcdh_kron_expand: rowptr nc * ns + 1, col / val nc * nnz(F); sorted columns.
+ */
+int pcdh_kron_factor(int64_t nrows, const int32_t* rowptr, const int32_t* col,
+                     const double* val, int nc, int32_t* f_rowptr,
+                     int32_t* f_col, double* f_val);
+int pcdh_kron_expand(int64_t ns, const int32_t* f_rowptr, const int32_t* f_col,
+                     const double* f_val, int nc, int32_t* rowptr, int32_t* col,
+                     double* val);
+
+/* ---- out[g] = sum of vals[members[ptr[g] .. ptr[g+1])] ------------------------
+ * Element contributions summed per matrix entry (the scatter-add of assembly,
+ * assembling.py:151-155, as a threaded gather): additions in ascending
+ * position, the order of numpy.bincount and of the device's k_fe_gather. */
+int pcdh_gather_sum(int64_t ngroups, const int64_t* ptr, const int64_t* members,
+                    const double* vals, double* out);
 
 /* ---- union of index-mapped blocks -------------------------------------------
  * The monolithic pattern of a block system in the caller's mixed numbering

@@ -167,3 +167,74 @@ def test_reference_tensor_element_matrices_equal_quadrature(make):
     wg = np.einsum('qbk,cqk->cqb', V.dphi_s, wl)
     supg = np.einsum('c,c,q,cqa,cqb->cab', delta, V.area, V.qw_s, wg, wg)
     assert np.abs(V.p2_supg_cells(U, delta) - supg).max() < tol(supg)
+
+
+@pytest.mark.parametrize("nc", [2, 3])
+def test_kron_factor_expand_spmm_and_entry_sums(nc):
+    rng = np.random.default_rng(5)
+    F = sp.random(700, 500, density=0.01, format="csr", random_state=3)
+    F.sort_indices()
+    A = H.kron_expand(F, nc)
+    E = sp.kron(F, sp.identity(nc), format="csr")
+    E.sort_indices()
+    assert np.array_equal(A.indptr, E.indptr)
+    assert np.array_equal(A.indices, E.indices)
+    assert np.array_equal(A.data, E.data)
+    assert A.kron_block == nc and (A.kron_scalar != F).nnz == 0
+    G = H.kron_factor(A, nc)
+    assert G is not None and (G != F).nnz == 0
+    # a single differing value, a coupled pattern, a shape that does not divide
+    B = A.copy()
+    B.data[11] *= 1.0 + 1e-15 * 4
+    assert H.kron_factor(B, nc) is None
+    Cc = (A + sp.csr_matrix(([1.0], ([0], [1])), shape=A.shape)).tocsr()
+    Cc.sort_indices()
+    assert H.kron_factor(Cc, nc) is None
+    assert H.kron_factor(sp.identity(nc * 5 + 1, format="csr"), nc) is None
+    # nvec interleaved vectors on F = the expanded operator's SpMV, bitwise
+    x = rng.standard_normal(500 * nc)
+    sc = rng.standard_normal(700 * nc)
+    assert np.array_equal(H.SpMV(F, sc, nvec=nc)(x), sc * (A @ x))
+    assert np.array_equal(H.SpMV(F, None, nvec=nc)(x), A @ x)
+    # entry sums = bincount, bitwise
+    inv = rng.integers(0, 900, 40000)
+    w = rng.standard_normal(40000)
+    order = np.argsort(inv, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(inv, minlength=900))])
+    assert np.array_equal(H.gather_sum(ptr, order, w),
+                          np.bincount(inv, weights=w, minlength=900))
+
+
+def test_multigrid_pipeline_on_the_scalar_factor_equals_the_block_one():
+    """Galerkin chain, smoother bounds, coarse inverse and composed levels of
+    F (x) I_2 computed on F (petsc._push_multigrid) are bitwise those of the
+    expanded operators."""
+    from fenapack_amd.compose import vcycle_level
+    from fenapack_amd.fem.multigrid import coarse_inverse, galerkin_chain
+    from fenapack_amd.petsc import estimate_emax
+    pb = Cavity(3, nu=0.01, variant="BRM1")
+    V = pb.space
+    chain = pb.interpolations().velocity
+    A = V.assemble_A00(0.01, U=np.random.default_rng(0).standard_normal(
+        (V.nn, 2)))
+    F = H.kron_factor(A, 2)
+    assert F is not None
+    chain_s = [None] + [P.kron_scalar for P in chain[1:]]
+    ops, ops_s = galerkin_chain(A, chain), galerkin_chain(F, chain_s)
+    for o, s in zip(ops, ops_s):
+        e = H.kron_expand(s, 2)
+        assert np.array_equal(e.indices, o.indices)
+        assert np.array_equal(e.data, o.data)
+        assert estimate_emax(o, iters=12) == \
+            estimate_emax(s, iters=12, block=2)
+    assert abs(coarse_inverse(ops[0], 2)
+               - coarse_inverse(H.kron_expand(ops_s[0], 2), 2)).max() == 0
+    Wd, Wu = vcycle_level(ops[2], chain[2], 0.1, 1.1, 2, 2)
+    Wds, Wus = vcycle_level(ops_s[2], chain_s[2], 0.1, 1.1, 2, 2)
+    for W, Ws in ((Wd, Wds), (Wu, Wus)):
+        e = H.kron_expand(Ws, 2)
+        assert np.array_equal(e.indices, W.indices)
+        assert np.array_equal(e.data, W.data)
+    # the Newton block couples the components: no scalar factor
+    N = V.assemble_A00(0.01, U=np.ones((V.nn, 2)), newton=True)
+    assert H.kron_factor(N, 2) is None
