@@ -20,6 +20,11 @@ import os
 import sys
 import time
 
+# before numpy loads its BLAS: small dense calls of the host producer on a pool
+# of one thread per core cost ~100 x their work (level-6 set-up 4.8 -> 2.8 s,
+# profiles/r03_setup_by_blas_threads.txt)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -4,6 +4,11 @@ import time
 
 import pytest
 
+# Before numpy is imported anywhere: the host producer makes thousands of small
+# BLAS calls, and OpenBLAS's default pool (one thread per core of a 256-thread
+# host) costs each of them ~100 x its work (fenapack_amd.limit_blas_threads)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
