@@ -65,10 +65,22 @@ class Mesh(object):
         pairs = np.stack([c[:, [1, 2]], c[:, [2, 0]], c[:, [0, 1]]], axis=1)
         pairs = np.sort(pairs.reshape(-1, 2), axis=1)
         nv = self.num_vertices
-        key = pairs[:, 0] * nv + pairs[:, 1]
-        ukey, inv, counts = np.unique(key, return_inverse=True,
-                                      return_counts=True)
-        self.edges = np.stack([ukey // nv, ukey % nv], axis=1)
+        from .. import _host
+        if _host.use_numpy() or pairs.shape[0] < 50000:
+            key = pairs[:, 0] * nv + pairs[:, 1]
+            ukey, inv, counts = np.unique(key, return_inverse=True,
+                                          return_counts=True)
+            self.edges = np.stack([ukey // nv, ukey % nv], axis=1)
+        else:
+            # the same ordering (by first, then second vertex) from the native
+            # counting sort instead of a comparison sort of the keys
+            g = _host.group_pairs(pairs[:, 0], pairs[:, 1], nv)
+            inv = g.inv
+            counts = np.diff(g.members()[0])
+            first = np.repeat(np.arange(nv, dtype=np.int64),
+                              np.diff(g.indptr))
+            self.edges = np.stack([first, g.ucols], axis=1)
+            g.release()
         self.cell_edges = inv.reshape(-1, 3)
         self.boundary_edges = np.nonzero(counts == 1)[0]
         self.boundary_vertices = np.unique(self.edges[self.boundary_edges])
@@ -166,16 +178,35 @@ class TetMesh(object):
         nv = self.num_vertices
         pairs = np.stack([cells[:, list(e)] for e in _TET_EDGES], axis=1)
         pairs = np.sort(pairs.reshape(-1, 2), axis=1)
-        key = pairs[:, 0] * nv + pairs[:, 1]
-        ukey, inv = np.unique(key, return_inverse=True)
-        self.edges = np.stack([ukey // nv, ukey % nv], axis=1)
+        from .. import _host
+        native = not _host.use_numpy() and pairs.shape[0] >= 50000
+        if native:
+            # (counting sorts instead of comparison sorts of the keys; the
+            # orderings - by first, then second vertex - are numpy.unique's)
+            g = _host.group_pairs(pairs[:, 0], pairs[:, 1], nv)
+            inv = g.inv
+            e0 = np.repeat(np.arange(nv, dtype=np.int64), np.diff(g.indptr))
+            ukey = e0 * nv + g.ucols
+            self.edges = np.stack([e0, g.ucols], axis=1)
+            g.release()
+        else:
+            key = pairs[:, 0] * nv + pairs[:, 1]
+            ukey, inv = np.unique(key, return_inverse=True)
+            self.edges = np.stack([ukey // nv, ukey % nv], axis=1)
         self.cell_edges = inv.reshape(-1, 6)
         faces = np.stack([cells[:, [1, 2, 3]], cells[:, [0, 2, 3]],
                           cells[:, [0, 1, 3]], cells[:, [0, 1, 2]]], axis=1)
         faces = np.sort(faces.reshape(-1, 3), axis=1)
-        fkey = (faces[:, 0] * nv + faces[:, 1]) * nv + faces[:, 2]
-        uf, first, cnt = np.unique(fkey, return_index=True,
-                                   return_counts=True)
+        if native:
+            g = _host.group_pairs(faces[:, 0], faces[:, 1] * nv + faces[:, 2],
+                                  nv)
+            ptr, order = g.members()
+            first, cnt = order[ptr[:-1]], np.diff(ptr)
+            g.release()
+        else:
+            fkey = (faces[:, 0] * nv + faces[:, 1]) * nv + faces[:, 2]
+            uf, first, cnt = np.unique(fkey, return_index=True,
+                                       return_counts=True)
         bfaces = faces[first[cnt == 1]]
         self.boundary_vertices = np.unique(bfaces)
         bpairs = np.sort(np.concatenate([bfaces[:, [0, 1]], bfaces[:, [0, 2]],

@@ -607,10 +607,19 @@ class TaylorHood(object):
         return w, gw
 
     def p2_stiffness_cells(self):
+        """(grad phi_b, grad phi_a) per cell; geometry only, so it is kept
+        (read-only) between nonlinear steps while it is below 512 MB."""
+        K = getattr(self, "_stiff_cells", None)
+        if K is not None:
+            return K
         g, na, nvl = self.gradlam, self.na, self.nvl
         gg = np.matmul(g, g.transpose(0, 2, 1)) * self.area[:, None, None]
         K = gg.reshape(-1, nvl * nvl) @ self._ref()["K"].reshape(nvl * nvl, -1)
-        return K.reshape(-1, na, na)
+        K = K.reshape(-1, na, na)
+        if K.nbytes <= 512 << 20:
+            K.setflags(write=False)
+            self._stiff_cells = K
+        return K
 
     def p2_mass_cells(self):
         return self.area[:, None, None] * self._ref()["M"][None]
