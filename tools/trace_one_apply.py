@@ -13,11 +13,11 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pcd::", "")
          for r in rows]
-# an apply starts at a k_gather and ends at the following k_scatter
-ends = [i for i, n in enumerate(names) if n == "k_scatter"]
-starts = [i for i, n in enumerate(names) if n == "k_gather"]
-e = ends[-1]
-s = max(i for i in starts if i < e)
+# an apply starts at its entry permutation (k_gather, or - one rank - the
+# k_scatter by the inverse index set) and ends at the exit k_scatter
+io = [i for i, n in enumerate(names) if n in ("k_scatter", "k_gather")]
+e = io[-1]
+s = io[-2]
 t0 = int(rows[s]["Start_Timestamp"])
 busy = 0
 prev_end = t0
