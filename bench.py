@@ -69,6 +69,11 @@ def parse():
                         "(smoothed aggregation, fenapack_amd/amg.py) - for "
                         "meshes without a nested hierarchy (e.g. --geometry "
                         "cube --level 0 --n0 73 = BASELINE config 5's N)")
+    p.add_argument("--rediscretise-u", action="store_true",
+                   help="fieldsplit_u_pc_mg_galerkin none: coarse velocity "
+                        "operators assembled on the coarse meshes (PETSc's "
+                        "PCMG default) instead of Galerkin products, whose "
+                        "rows are ~2.5 x longer")
     p.add_argument("--coarse-u", type=int, default=None,
                    help="fieldsplit_u_pc_mg_coarse_eq_limit: the coarsest "
                         "velocity level is the largest one of at most this "
@@ -215,6 +220,11 @@ def main():
                          "run with --nproc-per-node N)" % (args.gpus, world))
     if args.stub_step:
         return stub_main(args, json_out, rank, world)
+    if world > 1:
+        # every rank hands the engine its own rows only (pcd_set_system_local,
+        # pcd_set_csr_local, pcd_mg_set_level_local) - what a partitioned
+        # assembly holds; FENAPACK_AMD_LOCAL_HANDOVER=0 is the A/B switch
+        os.environ.setdefault("FENAPACK_AMD_LOCAL_HANDOVER", "1")
     import torch
     import torch.distributed as dist
     if torch.cuda.device_count() < world:
@@ -248,7 +258,8 @@ def main():
     if args.inner == "mg":
         multigrid_inner_options(cycles_u=args.cycles_u, cycles_p=args.cycles_p,
                                 smooth=args.smooth, mp_its=args.mp_its,
-                                dim=V.dim, algebraic=args.algebraic)
+                                dim=V.dim, algebraic=args.algebraic,
+                                galerkin_u=not args.rediscretise_u)
     else:
         default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
                               ap_rtol=args.ap_rtol, ap_its=args.ap_its,

@@ -70,6 +70,13 @@ _HIP_ONLY = {
     "set_csr_local": [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                       C.c_void_p, C.c_void_p],
     "row_range": [C.c_int, C.c_int64, C.c_void_p, C.c_void_p],
+    "set_system_local": [C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                         C.c_void_p, C.c_void_p, C.c_void_p],
+    "mg_set_level_local": [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.c_double, C.c_double],
     "set_stream": [C.c_void_p],
     "comm_init": [C.c_int, C.c_int, C.c_void_p],
     "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
@@ -246,6 +253,9 @@ class Engine(object):
             raise EngineError("create failed (%d): %s" % (rc, library.error()))
         self.variant = v
         self.shapes = {}
+        #: set by ``set_system_local``: operators and multigrid levels are
+        #: handed over as this rank's rows (petsc.DeviceMat, _push_multigrid)
+        self.local_handover = False
 
     # -- plumbing -----------------------------------------------------------
     def _call(self, name, *args):
@@ -310,6 +320,25 @@ class Engine(object):
         self.n_u, self.n_p = iu.size, ipp.size
         self._call("set_system", A.shape[0], _ptr(ip), _ptr(ix), _ptr(dv),
                    _ptr(pv), iu.size, _ptr(iu), ipp.size, _ptr(ipp))
+        self.local_handover = False
+
+    def set_system_local(self, A_rows, rows, n, is_u, is_p, P_rows=None):
+        """Rank-local hand-over of the system: ``A_rows`` = this rank's rows
+        of the monolithic matrix (scipy CSR, the caller's GLOBAL column ids),
+        ``rows`` their global indices - velocity rows of ``row_range`` first,
+        then the pressure rows; the index sets whole."""
+        ip, ix, dv = _i32(A_rows.indptr), _i32(A_rows.indices), \
+            _f64(A_rows.data)
+        pv = None
+        if P_rows is not None:
+            assert P_rows.nnz == A_rows.nnz
+            pv = _f64(P_rows.data)
+        iu, ipp, rw = _i32(is_u), _i32(is_p), _i32(rows)
+        self.n_u, self.n_p = iu.size, ipp.size
+        self._call("set_system_local", int(n), iu.size, _ptr(iu), ipp.size,
+                   _ptr(ipp), rw.size, _ptr(rw), _ptr(ip), _ptr(ix), _ptr(dv),
+                   _ptr(pv))
+        self.local_handover = True
 
     def update_system(self, vals, pvals=None, mem=MEM_HOST):
         if mem == MEM_HOST:
@@ -346,6 +375,29 @@ class Engine(object):
             b = [P.shape[0], P.shape[1], _ptr(pp), _ptr(px), _ptr(pv)]
         self._call("mg_set_level", slot, int(level), *(a + b),
                    float(emin), float(emax))
+
+    def mg_set_level_local(self, slot, level, n, A_rows, P_rows, R_rows,
+                           emin, emax):
+        """Rank-local hand-over of a partitioned level: this rank's rows of
+        the operator (``None`` on the finest level), of the prolongation, and
+        of its transpose (``None`` when the level below is replicated)."""
+        a = [0, None, None, None]
+        keep = []
+        if A_rows is not None:
+            t = (_i32(A_rows.indptr), _i32(A_rows.indices), _f64(A_rows.data))
+            keep.append(t)
+            a = [A_rows.shape[0], _ptr(t[0]), _ptr(t[1]), _ptr(t[2])]
+        else:
+            a[0] = P_rows.shape[0]
+        pt = (_i32(P_rows.indptr), _i32(P_rows.indices), _f64(P_rows.data))
+        r = [0, None, None, None]
+        if R_rows is not None:
+            t = (_i32(R_rows.indptr), _i32(R_rows.indices), _f64(R_rows.data))
+            keep.append(t)
+            r = [R_rows.shape[0], _ptr(t[0]), _ptr(t[1]), _ptr(t[2])]
+        self._call("mg_set_level_local", slot, int(level), int(n), *(
+            a + [P_rows.shape[1], _ptr(pt[0]), _ptr(pt[1]), _ptr(pt[2])] + r
+            + [float(emin), float(emax)]))
 
     def mg_update_values(self, slot, level, vals, emin=0.0, emax=0.0,
                          mem=MEM_HOST):

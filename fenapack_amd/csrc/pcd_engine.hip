@@ -237,6 +237,8 @@ struct pcd_engine_s {
   // block-wise, so the velocity block goes through its F x I fast path
   DCsr a10, a11;
   std::vector<int64_t> a11_src_host;
+  bool sys_local = false;             // pcd_set_system_local: value arrays hold this rank's rows
+  DBuf<double> flagbuf;
   bool a11_zero = true, p_is_a = true;
   bool ready = false;
   DBuf<double> w[2];                  // pressure work vectors (get_work_vecs)
@@ -1713,9 +1715,10 @@ int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
 int pcd_row_range(pcd_handle h, int velocity, int64_t n_global, int64_t* r0, int64_t* r1) {
   if (!h || !r0 || !r1 || n_global < 0) return fail(PCD_ERR_ARG, "row_range: bad arguments");
   if (!h->comm) { *r0 = 0; *r1 = n_global; return 0; }
-  Space& sp = velocity ? h->sp_u : h->sp_p;
-  CHK(ensure_space(h, sp, n_global, velocity != 0, "row_range"));
-  *r0 = sp.bounds[0][h->rank]; *r1 = sp.bounds[0][h->rank + 1];
+  // the same rule for every space of the engine - the fields and the levels of
+  // their multigrid hierarchies: even cuts, on node boundaries for velocities
+  const std::vector<int64_t> b = Space::cut(n_global, h->nranks, velocity ? h->vel_block : 1);
+  *r0 = b[h->rank]; *r1 = b[h->rank + 1];
   return 0;
 }
 
@@ -1926,6 +1929,18 @@ int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
       h->a11_zero = true;
       for (int64_t k : h->a11_src_host)
         if (vals[k] != 0.0) { h->a11_zero = false; break; }
+      if (h->sys_local && h->comm) {
+        // every rank saw its own rows only; the ranks must agree on whether
+        // the (1,1) block takes part in the grouped halo exchange
+        double f = h->a11_zero ? 0.0 : 1.0;
+        CHK(h->flagbuf.ensure(1));
+        HIPCHK(hipMemcpyAsync(h->flagbuf.p, &f, sizeof f, hipMemcpyHostToDevice, h->stream));
+        if (h->comm->allreduce(h->flagbuf.p, 1, h->stream))
+          return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+        HIPCHK(hipMemcpyAsync(&f, h->flagbuf.p, sizeof f, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->a11_zero = f == 0.0;
+      }
     }
   }
   CHK(gather_block_values(h, h->mat[PCD_MAT_A], dv));
@@ -1962,6 +1977,7 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   for (int64_t i = 0; i < n_u; ++i) mu[is_u[i]] = (int32_t)i;
   for (int64_t i = 0; i < n_p; ++i) mp[is_p[i]] = (int32_t)i;
   h->n_u = n_u; h->n_p = n_p; h->sys_nnz = rowptr[n];
+  h->sys_local = false;
   h->perm_glob = perm;
   CHK(ensure_space(h, h->sp_u, n_u, true, "set_system"));
   CHK(ensure_space(h, h->sp_p, n_p, false, "set_system"));
@@ -1992,6 +2008,90 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   }
   extract_block(n, perm.data(), rowptr, colidx, ma, rp, cc, src);
   CHK(upload_global(h, h->mat[PCD_MAT_A], &h->sp_sys, &h->sp_sys, n, n, rp.data(), cc.data(), nullptr, src.data()));
+  h->ready = false; ++h->gen;
+  return pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
+}
+
+// Rank-local form of pcd_set_system: this rank's rows of the monolithic matrix
+// only.  `rows[i]` is the caller's (global) index of local row i: the rank's
+// velocity rows is_u[u0 .. u1) followed by its pressure rows is_p[p0 .. p1),
+// the ranges being pcd_row_range's; columns carry the caller's global indices.
+// The index sets are handed over whole (O(n) integers per rank - the matrix,
+// O(nnz / R), is what matters); who needs which of this rank's entries is
+// found in the set-up handshake (pcd_dist.hpp: localize_owned), so no rank
+// ever looks at a row it does not own.  The caller's dof order is kept
+// (renumbering needs the whole graph).  pcd_update_system then takes the
+// values of these rows, in this order.
+int pcd_set_system_local(pcd_handle h, int64_t n, int64_t n_u, const int32_t* is_u,
+                         int64_t n_p, const int32_t* is_p, int64_t nrows_local,
+                         const int32_t* rows, const int32_t* rowptr, const int32_t* colidx,
+                         const double* vals, const double* pvals) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (!rows || !rowptr || !vals || !is_u || !is_p || (!colidx && rowptr[nrows_local]))
+    return fail(PCD_ERR_ARG, "set_system_local: null argument");
+  if (n_u + n_p != n) return fail(PCD_ERR_ARG, "set_system_local: n_u + n_p != n");
+  if (n >= INT32_MAX) return fail(PCD_ERR_ARG, "set_system_local: n exceeds int32 indexing");
+  HIPCHK(hipSetDevice(h->device));
+  h->ru.clear(); h->rp.clear(); h->rs.clear();
+  std::vector<int32_t> perm(n), mu(n, -1), mp(n, -1), ma(n, -1);
+  for (int64_t i = 0; i < n_u; ++i) perm[i] = is_u[i];
+  for (int64_t i = 0; i < n_p; ++i) perm[n_u + i] = is_p[i];
+  for (int64_t i = 0; i < n; ++i) {
+    if (perm[i] < 0 || perm[i] >= n || ma[perm[i]] >= 0)
+      return fail(PCD_ERR_ARG, "set_system_local: index sets do not partition 0..n-1");
+    ma[perm[i]] = (int32_t)i;
+  }
+  for (int64_t i = 0; i < n_u; ++i) mu[is_u[i]] = (int32_t)i;
+  for (int64_t i = 0; i < n_p; ++i) mp[is_p[i]] = (int32_t)i;
+  h->n_u = n_u; h->n_p = n_p; h->sys_nnz = rowptr[nrows_local];
+  h->sys_local = true;
+  h->perm_glob = perm;
+  CHK(ensure_space(h, h->sp_u, n_u, true, "set_system_local"));
+  CHK(ensure_space(h, h->sp_p, n_p, false, "set_system_local"));
+  if (h->comm) h->sp_sys = Space::system(h->sp_u, h->sp_p);
+  const int me = h->rank;
+  const int64_t nul = h->comm ? h->sp_u.nloc(me) : n_u, npl = h->comm ? h->sp_p.nloc(me) : n_p;
+  if (nrows_local != nul + npl)
+    return fail(PCD_ERR_ARG, "set_system_local: this rank owns %lld + %lld rows (pcd_row_range), got %lld",
+                (long long)nul, (long long)npl, (long long)nrows_local);
+  std::vector<int32_t> pl(nrows_local);
+  for (int64_t i = 0; i < nrows_local; ++i) {
+    pl[i] = perm[h->comm ? h->sp_sys.global(i, me) : i];
+    if (rows[i] != pl[i])
+      return fail(PCD_ERR_ARG, "set_system_local: local row %lld is the caller's row %d, expected %d "
+                               "(velocity rows of pcd_row_range first, then the pressure rows)",
+                  (long long)i, rows[i], pl[i]);
+  }
+  for (int64_t k = 0; k < rowptr[nrows_local]; ++k)
+    if (colidx[k] < 0 || colidx[k] >= n)
+      return fail(PCD_ERR_ARG, "set_system_local: column id %d outside [0, %lld)", colidx[k], (long long)n);
+  CHK(h->perm.ensure(nrows_local));
+  if (nrows_local) HIPCHK(hipMemcpy(h->perm.p, pl.data(), nrows_local * sizeof(int), hipMemcpyHostToDevice));
+  // local row ids of the velocity / pressure rows in the arrays handed over
+  std::vector<int32_t> lu(nul), lp(npl), la(nrows_local);
+  for (int64_t i = 0; i < nul; ++i) lu[i] = (int32_t)i;
+  for (int64_t i = 0; i < npl; ++i) lp[i] = (int32_t)(nul + i);
+  for (int64_t i = 0; i < nrows_local; ++i) la[i] = (int32_t)i;
+  std::vector<int32_t> rp, cc; std::vector<int64_t> src;
+  auto hand_over = [&](DCsr& A, const Space* rs, const Space* cs, int64_t nr, const std::vector<int32_t>& lrows,
+                       const std::vector<int32_t>& colmap, int64_t ncols_glob) -> int {
+    extract_block(nr, lrows.data(), rowptr, colidx, colmap, rp, cc, src);
+    A.gnnz = rp[nr];
+    if (!h->comm) {
+      A.plan = HaloPlan();
+      A.val_src = false;
+      return upload_csr(h, A, nr, ncols_glob, rp.data(), cc.data(), nullptr, src.data());
+    }
+    auto span = [&](int64_t i) { return std::pair<int64_t, int64_t>(rp[i], rp[i + 1]); };
+    return upload_owned(h, A, rs, cs, nr, span, cc.data(), nullptr, src.data());
+  };
+  CHK(hand_over(h->mat[PCD_MAT_A00], &h->sp_u, &h->sp_u, nul, lu, mu, n_u));
+  CHK(hand_over(h->mat[PCD_MAT_A01], &h->sp_u, &h->sp_p, nul, lu, mp, n_p));
+  h->a10.release(); h->a11.release(); h->a11_src_host.clear();
+  CHK(hand_over(h->a10, &h->sp_p, &h->sp_u, npl, lp, mu, n_u));
+  CHK(hand_over(h->a11, &h->sp_p, &h->sp_p, npl, lp, mp, n_p));
+  h->a11_src_host = src;                 // (positions in this rank's values)
+  CHK(hand_over(h->mat[PCD_MAT_A], &h->sp_sys, &h->sp_sys, nrows_local, la, ma, n));
   h->ready = false; ++h->gen;
   return pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
 }
@@ -2168,6 +2268,111 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
   }
   M.emin = emin; M.emax = emax;
   M.fused = false;                       // composed from other values
+  ++h->gen;
+  if (h->ready) CHK(inner_prepare(h, slot));
+  return 0;
+}
+
+// Rank-local form of pcd_mg_set_level for a PARTITIONED level (more rows than
+// PCD_REPLICATE_BELOW; replicated levels are small by definition and keep the
+// global form): this rank's rows of the level operator (NULL on the finest
+// level, which is the field's own operator), its rows of the prolongation
+// (fine rows owned x global coarse columns) and - when the level below is
+// partitioned too - its rows of the restriction P^T (coarse rows owned x global
+// fine columns; [ext PETSc] MatTranspose of the distributed P).  Row ranges are
+// pcd_row_range's for a field of that many rows (velocity levels: whole nodes).
+int pcd_mg_set_level_local(pcd_handle h, int slot, int level, int64_t n, int64_t nrows_local,
+                           const int32_t* rowptr, const int32_t* colidx, const double* vals,
+                           int64_t p_cols, const int32_t* prowptr, const int32_t* pcolidx,
+                           const double* pvals, int64_t r_rows_local, const int32_t* rrowptr,
+                           const int32_t* rcolidx, const double* rvals, double emin, double emax) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_set_level_local: bad slot %d", slot);
+  Inner& s = h->inner[slot];
+  const int L = (int)s.mg.size();
+  if (level < 1 || level >= L)
+    return fail(PCD_ERR_ARG, "mg_set_level_local: level %d outside [1,%d) (the coarsest level is an explicit "
+                             "inverse: pcd_mg_set_level)", level, L);
+  if (!(emax > emin && emin > 0.0)) return fail(PCD_ERR_ARG, "mg_set_level_local: smoother needs 0 < emin < emax");
+  if (!prowptr || !pcolidx || !pvals) return fail(PCD_ERR_ARG, "mg_set_level_local: prolongation missing");
+  if (!rowptr && level != L - 1) return fail(PCD_ERR_ARG, "mg_set_level_local: coarse levels need an operator");
+  if (rowptr && (!colidx || !vals)) return fail(PCD_ERR_ARG, "mg_set_level_local: bad operator arrays");
+  if (!h->comm) return fail(PCD_ERR_STATE, "mg_set_level_local: no communicator (one GPU: pcd_mg_set_level)");
+  if (h->ru.active() || h->rp.active())
+    return fail(PCD_ERR_STATE, "mg_set_level_local: the engine renumbered the dofs (PCD_REORDER); "
+                               "rank-local hand-over needs PCD_REORDER=none");
+  HIPCHK(hipSetDevice(h->device));
+  MgLevel& M = s.mg[level];
+  if ((int)s.mg_r.size() != L) { s.mg_r.clear(); s.mg_r.resize(L); s.mg_r_known.assign(L, 0); }
+  s.mg_r_known[level] = s.mg_r_known[level - 1] = 1;      // the caller's numbering, as handed over
+  const int even = slot == PCD_KSP_A00 ? h->vel_block : 1;
+  const char* lim_env = getenv("PCD_REPLICATE_BELOW");
+  const int64_t limit = lim_env ? atoll(lim_env) : 60000LL;
+  if (level < L - 1 && n <= limit)
+    return fail(PCD_ERR_ARG, "mg_set_level_local: level %d (%lld rows) is replicated (PCD_REPLICATE_BELOW %lld): "
+                             "hand it over whole with pcd_mg_set_level", level, (long long)n, (long long)limit);
+  const bool rep_c = p_cols <= limit;
+  s.mg_space.resize(L);
+  if (s.mg_space[level].nf == 0) s.mg_space[level] = Space::field(n, h->nranks, even);
+  if (s.mg_space[level].total() != n) return fail(PCD_ERR_ARG, "mg_set_level_local: level %d size mismatch", level);
+  const Space* sl = &s.mg_space[level];
+  const Space* sc = nullptr;
+  if (!rep_c) {
+    if (s.mg_space[level - 1].nf == 0) s.mg_space[level - 1] = Space::field(p_cols, h->nranks, even);
+    if (s.mg_space[level - 1].total() != p_cols)
+      return fail(PCD_ERR_ARG, "mg_set_level_local: level %d prolongation width mismatch", level);
+    sc = &s.mg_space[level - 1];
+  }
+  const int me = h->rank;
+  if (sl->nloc(me) != nrows_local)
+    return fail(PCD_ERR_ARG, "mg_set_level_local: this rank owns %lld rows of level %d (pcd_row_range), got %lld",
+                (long long)sl->nloc(me), level, (long long)nrows_local);
+  auto check_cols = [&](const int32_t* rp, const int32_t* ci, int64_t nr, int64_t ncols, const char* what) -> int {
+    for (int64_t k = 0; k < rp[nr]; ++k)
+      if (ci[k] < 0 || ci[k] >= ncols)
+        return fail(PCD_ERR_ARG, "mg_set_level_local: %s column id %d outside [0, %lld)", what, ci[k], (long long)ncols);
+    return 0;
+  };
+  M.replicated = false; M.transition = rep_c; M.n_coarse = p_cols;
+  if (rowptr) {
+    CHK(check_cols(rowptr, colidx, nrows_local, n, "operator"));
+    auto span = [&](int64_t i) { return std::pair<int64_t, int64_t>(rowptr[i], rowptr[i + 1]); };
+    M.A.gnnz = rowptr[nrows_local];        // value updates carry this rank's entries
+    CHK(upload_owned(h, M.A, sl, sl, nrows_local, span, colidx, vals, nullptr));
+    CHK(refresh_dinv(h, M.A));
+  }
+  CHK(check_cols(prowptr, pcolidx, nrows_local, p_cols, "prolongation"));
+  if (rep_c) {
+    // my fine rows x ALL coarse columns; the transpose sums my contribution to
+    // every coarse row, the all-reduce in the cycle completes it
+    CHK(upload_csr(h, M.P, nrows_local, p_cols, prowptr, pcolidx, pvals, nullptr));
+    const int64_t nnz = prowptr[nrows_local];
+    std::vector<int32_t> trp(p_cols + 1, 0), tc(nnz); std::vector<double> tv(nnz);
+    for (int64_t k = 0; k < nnz; ++k) ++trp[pcolidx[k] + 1];
+    for (int64_t c = 0; c < p_cols; ++c) trp[c + 1] += trp[c];
+    std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
+    for (int64_t i = 0; i < nrows_local; ++i)
+      for (int32_t k = prowptr[i]; k < prowptr[i + 1]; ++k) {
+        const int32_t q = fill[pcolidx[k]]++;
+        tc[q] = (int32_t)i; tv[q] = pvals[k];
+      }
+    CHK(upload_csr(h, M.R, p_cols, nrows_local, trp.data(), tc.data(), tv.data(), nullptr));
+    M.P.replicated = M.R.replicated = true;       // no halo on either
+  } else {
+    if (!rrowptr || !rcolidx || !rvals)
+      return fail(PCD_ERR_ARG, "mg_set_level_local: the level below is partitioned too: this rank's rows of the "
+                               "restriction P^T are needed");
+    if (sc->nloc(me) != r_rows_local)
+      return fail(PCD_ERR_ARG, "mg_set_level_local: this rank owns %lld rows of level %d, the restriction has %lld",
+                  (long long)sc->nloc(me), level - 1, (long long)r_rows_local);
+    CHK(check_cols(rrowptr, rcolidx, r_rows_local, n, "restriction"));
+    auto pspan = [&](int64_t i) { return std::pair<int64_t, int64_t>(prowptr[i], prowptr[i + 1]); };
+    auto rspan = [&](int64_t i) { return std::pair<int64_t, int64_t>(rrowptr[i], rrowptr[i + 1]); };
+    CHK(upload_owned(h, M.P, sl, sc, nrows_local, pspan, pcolidx, pvals, nullptr));
+    CHK(upload_owned(h, M.R, sc, sl, r_rows_local, rspan, rcolidx, rvals, nullptr));
+  }
+  M.emin = emin; M.emax = emax;
+  M.fused = false;
   ++h->gen;
   if (h->ready) CHK(inner_prepare(h, slot));
   return 0;

@@ -303,6 +303,9 @@ int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
   if (dim != 2 && dim != 3) return fail(PCD_ERR_ARG, "fe_begin: dim must be 2 or 3");
   // the producer's plans address operator entries in the numbering its caller
   // handed over: it works on engines that kept that numbering
+  if (h->sys_local)
+    return fail(PCD_ERR_STATE, "fe_begin: the system was handed over rank-locally (pcd_set_system_local); the "
+                               "device producer addresses entries of the global value array");
   if (h->ru.active() || h->rp.active())
     return fail(PCD_ERR_STATE, "fe_begin: the engine renumbered the dofs at pcd_set_system (the "
                                "caller's numbering was not local); the device producer needs "

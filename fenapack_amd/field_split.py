@@ -93,12 +93,14 @@ class PCDKSP(KSP):
             # refuses two ranks on one device)
             self.engine.comm_init_threads(self.comm.rank, self.comm.size,
                                           self.comm.thread_group)
+            self._has_comm = True
         elif self.comm is not None and (getattr(self.comm, "size", 1) > 1
                                         or (forced and self.comm.unique_id())):
             # one process per GPU: rows are partitioned inside the engine,
             # RCCL carries the halos and the dot-product all-reduces
             self.engine.comm_init(self.comm.rank, self.comm.size,
                                   self.comm.unique_id())
+            self._has_comm = True
         A, P = self.getOperators()
         with Timer("FENaPack: {} setup".format(ksp0.getOptionsPrefix() or "")):
             self._upload_system(A, P, is0, is1, first=True)
@@ -136,11 +138,45 @@ class PCDKSP(KSP):
         M = P if (P is not None and P.isAssembled()) else A
         return M.A[is0.indices][:, is0.indices]
 
+    def _local_rows(self, A, is0, is1):
+        """This rank's rows of the monolithic matrix (velocity rows of the
+        engine's row range first, then the pressure rows) and the positions of
+        their entries in the matrix's value array."""
+        import numpy as np
+        eng = self.engine
+        u0, u1 = eng.row_range(is0.indices.size, velocity=True)
+        p0, p1 = eng.row_range(is1.indices.size)
+        rows = np.concatenate([np.asarray(is0.indices)[u0:u1],
+                               np.asarray(is1.indices)[p0:p1]])
+        ip = A.A.indptr
+        ln = (ip[rows + 1] - ip[rows]).astype(np.int64)
+        start = np.repeat(ip[rows].astype(np.int64) - np.concatenate(
+            [[0], np.cumsum(ln)[:-1]]), ln)
+        return rows, start + np.arange(int(ln.sum()), dtype=np.int64)
+
     def _upload_system(self, A, P, is0=None, is1=None, first=False):
+        import os
         pmat = None if (P is None or P is A or not P.isAssembled()) else P
         if first:
-            self.engine.set_system(A.A, is0.indices, is1.indices,
-                                   None if pmat is None else pmat.A)
+            local = os.environ.get("FENAPACK_AMD_LOCAL_HANDOVER") == "1" \
+                and getattr(self, "_has_comm", False)
+            if local:
+                # the engine sees this rank's rows only (pcd_set_system_local;
+                # the matrix a partitioned assembly would hold) - the host-
+                # driven path; the device producer needs the global hand-over
+                rows, pos = self._local_rows(A, is0, is1)
+                self._local_pos = pos
+                self.engine.set_system_local(
+                    A.A[rows], rows, A.A.shape[0], is0.indices, is1.indices,
+                    None if pmat is None else pmat.A[rows])
+            else:
+                self._local_pos = None
+                self.engine.set_system(A.A, is0.indices, is1.indices,
+                                       None if pmat is None else pmat.A)
+        elif getattr(self, "_local_pos", None) is not None:
+            pos = self._local_pos
+            self.engine.update_system(
+                A.A.data[pos], None if pmat is None else pmat.A.data[pos])
         else:
             self.engine.update_system(A.A.data,
                                       None if pmat is None else pmat.A.data)

@@ -234,11 +234,24 @@ class DeviceMat(Mat):
     def __init__(self, engine, which, A, comm=None):
         Mat.__init__(self, A, comm)
         self.engine, self.which = engine, which
-        engine.set_csr(which, self.A)
+        self._rows = None
+        if getattr(engine, "local_handover", False):
+            # this rank's rows only (pcd_set_csr_local); all of these live on
+            # the pressure space
+            self._rows = engine.row_range(self.A.shape[0])
+            r0, r1 = self._rows
+            engine.set_csr_local(which, self.A[r0:r1], self.A.shape)
+        else:
+            engine.set_csr(which, self.A)
 
     def update(self, A):
         self.set(A)
-        self.engine.update_values(self.which, self.A.data)
+        if self._rows is not None:
+            r0, r1 = self._rows
+            ip = self.A.indptr
+            self.engine.update_values(self.which, self.A.data[ip[r0]:ip[r1]])
+        else:
+            self.engine.update_values(self.which, self.A.data)
 
     def mult(self, x, y):
         self.engine.spmv(self.which, x.t, y.t, c.MEM_DEVICE)
@@ -649,21 +662,47 @@ class KSP(object):
         pc.mg_data = {"ops": ops, "chain": chain, "bounds": bounds, "C": C,
                       "nu": nu_pre, "nu_post": nu_post}
         sig = (L, nu_pre, nu_post, tuple(o.nnz for o in ops))
+        local = getattr(eng, "local_handover", False)
+        if local:
+            # partitioned levels go over as this rank's rows (the rule of
+            # pcd_mg_set_level: more than PCD_REPLICATE_BELOW rows, and the
+            # finest level always); replicated ones whole
+            import os
+            limit = int(os.environ.get("PCD_REPLICATE_BELOW", "60000"))
+            vel = slot == c.KSP_A00
+            part = [l == L - 1 or ops[l].shape[0] > limit for l in range(L)]
+            rng_ = [eng.row_range(ops[l].shape[0], velocity=vel)
+                    if part[l] else None for l in range(L)]
         if pc._mg_pushed != sig:
             eng.mg_begin(slot, L, nu_pre, nu_post)
             # finest first: a level's engine numbering is inherited from the
             # level above it through the prolongation (pcd_reorder.hpp)
             for l in range(L - 1, 0, -1):
-                eng.mg_set_level(slot, l, ops[l] if l < L - 1 else None,
-                                 chain[l], *bounds[l])
+                if local and part[l]:
+                    r0, r1 = rng_[l]
+                    P = sp.csr_matrix(chain[l])
+                    R_rows = None
+                    if ops[l - 1].shape[0] > limit:
+                        c0, c1 = eng.row_range(ops[l - 1].shape[0],
+                                               velocity=vel)
+                        R_rows = _host.transpose(P)[c0:c1]
+                    eng.mg_set_level_local(
+                        slot, l, ops[l].shape[0],
+                        sp.csr_matrix(ops[l])[r0:r1] if l < L - 1 else None,
+                        P[r0:r1], R_rows, *bounds[l])
+                else:
+                    eng.mg_set_level(slot, l, ops[l] if l < L - 1 else None,
+                                     chain[l], *bounds[l])
             eng.mg_set_level(slot, 0, C)
             pc._mg_pushed = sig
         else:
             eng.mg_update_values(slot, 0, C.data)
             for l in range(1, L):
-                eng.mg_update_values(slot, l,
-                                     ops[l].data if l < L - 1 else None,
-                                     *bounds[l])
+                vals = ops[l].data if l < L - 1 else None
+                if vals is not None and local and part[l]:
+                    ip = ops[l].indptr
+                    vals = vals[ip[rng_[l][0]]:ip[rng_[l][1]]]
+                eng.mg_update_values(slot, l, vals, *bounds[l])
         self._push_fused_levels(ops, chain, bounds, ops_s, chain_s, blk)
 
     def _push_fused_levels(self, ops, chain, bounds, ops_s=None, chain_s=None,

@@ -127,8 +127,9 @@ int pcd_set_csr_local(pcd_handle h, int which, int64_t nrows_global,
                       int64_t ncols_global, int64_t nrows_local,
                       const int32_t* rowptr_local, const int32_t* colidx_global,
                       const double* vals_local);
-/* rows [*r0, *r1) of a field of `n_global` rows that this rank owns
- * (`velocity` != 0: cuts fall on node boundaries); one GPU: [0, n). */
+/* rows [*r0, *r1) that this rank owns of a space of `n_global` rows - a field
+ * or a level of its multigrid hierarchy (`velocity` != 0: cuts fall on node
+ * boundaries; call pcd_set_velocity_block first in 3-D); one GPU: [0, n). */
 int pcd_row_range(pcd_handle h, int velocity, int64_t n_global, int64_t* r0,
                   int64_t* r1);
 /* non-constant forms are re-assembled into the existing submatrix every outer
@@ -147,6 +148,22 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
                    const double* pvals,
                    int64_t n_u, const int32_t* is_u,
                    int64_t n_p, const int32_t* is_p);
+/* Rank-local form (several ranks): this rank's rows of the monolithic matrix
+ * only - what a partitioned assembly holds (PETSc MPIAIJ row blocks; the
+ * reference never touches a row it does not own: SubfieldBC.h:136-155).
+ * `rows[i]` is the caller's global index of local row i: the rank's velocity
+ * rows is_u[u0 .. u1) followed by its pressure rows is_p[p0 .. p1), the ranges
+ * being pcd_row_range's; `colidx` holds the caller's global indices; the index
+ * sets are passed whole (O(n) integers - the matrix is what is O(nnz / R)).
+ * Collective.  Keeps the caller's dof order (PCD_REORDER needs the whole
+ * graph).  Afterwards pcd_update_system takes the values of THESE rows, in the
+ * order handed over here.  One GPU: the same call with every row. */
+int pcd_set_system_local(pcd_handle h, int64_t n, int64_t n_u,
+                         const int32_t* is_u, int64_t n_p, const int32_t* is_p,
+                         int64_t nrows_local, const int32_t* rows,
+                         const int32_t* rowptr_local,
+                         const int32_t* colidx_global, const double* vals,
+                         const double* pvals);
 /* Engine renumbering (csrc/pcd_reorder.hpp).  The index sets arrive as the
  * caller's dofmap gives them (_field_split_utils.py:39-50: dofmap.dofs() as
  * is); when that numbering is not local - mean |row - col| / n of the velocity
@@ -162,7 +179,8 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
  * mode 0: never, 1: auto (default), 2: always; the environment variable
  * PCD_REORDER = none | auto | always overrides.  Call before pcd_set_system.
  * Not available together with the device producer (pcd_fe_*) or
- * pcd_set_csr_local, which address entries in the caller's numbering. */
+ * pcd_set_csr_local / pcd_set_system_local / pcd_mg_set_level_local, which
+ * address entries in the caller's numbering. */
 int pcd_set_reorder(pcd_handle h, int mode);
 /* in-place re-assembly of A (and P) between Newton steps, SURVEY 3.1 */
 int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
@@ -201,6 +219,25 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
                      const double* vals, int64_t p_rows, int64_t p_cols,
                      const int32_t* prowptr, const int32_t* pcolidx,
                      const double* pvals, double emin, double emax);
+/* Rank-local form for a PARTITIONED level (several ranks; a level of more than
+ * PCD_REPLICATE_BELOW rows - smaller ones are replicated on every rank and keep
+ * the global form): this rank's rows of the level operator (n_global x
+ * n_global, GLOBAL column ids; rowptr == NULL on the finest level), its rows
+ * of the prolongation (fine rows owned x p_cols global coarse columns) and,
+ * when the level below is partitioned too, its rows of the restriction P^T
+ * (coarse rows owned x n_global fine columns - [ext PETSc] MatTranspose of the
+ * distributed P; NULL when the level below is replicated: the transpose of
+ * the local rows then sums this rank's contribution and an all-reduce in the
+ * cycle completes it).  Row ranges: pcd_row_range of a field of that many
+ * rows.  Collective.  pcd_mg_update_values then carries this rank's values. */
+int pcd_mg_set_level_local(pcd_handle h, int slot, int level, int64_t n_global,
+                           int64_t nrows_local, const int32_t* rowptr,
+                           const int32_t* colidx, const double* vals,
+                           int64_t p_cols, const int32_t* prowptr,
+                           const int32_t* pcolidx, const double* pvals,
+                           int64_t r_rows_local, const int32_t* rrowptr,
+                           const int32_t* rcolidx, const double* rvals,
+                           double emin, double emax);
 /* re-assembled operator of one level (same pattern) and refreshed bounds;
  * vals == NULL only refreshes the bounds (finest level) */
 int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,

@@ -138,3 +138,41 @@ def test_config5_shape_cube_n32_on_8_ranks(hip_lib, replicate_below):
     rows = [r["rows_u"] for r in eight]
     assert sum(rows) == one["rows_u"] and max(rows) - min(rows) <= 3
     PETScOptions.clear()
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_host_driven_solve_with_rank_local_handover(hip_lib, replicate_below,
+                                                    monkeypatch, R):
+    """FENAPACK_AMD_LOCAL_HANDOVER=1: every operator, the block system and
+    every partitioned multigrid level cross the C ABI as this rank's rows
+    only (pcd_set_csr_local / pcd_set_system_local / pcd_mg_set_level_local),
+    through the whole Python stack, value refreshes between the nonlinear
+    steps included.  Same Krylov history and the same solution as the global
+    hand-over on the same ranks."""
+    import numpy as np
+    from fenapack_amd.driver import solve_steady
+    from fenapack_amd.fem import Cavity
+    replicate_below(700)        # finest levels partitioned, the rest replicated
+
+    def run(local):
+        if local:
+            monkeypatch.setenv("FENAPACK_AMD_LOCAL_HANDOVER", "1")
+        else:
+            monkeypatch.delenv("FENAPACK_AMD_LOCAL_HANDOVER", raising=False)
+        PETScOptions.clear()
+        multigrid_inner_options()
+        pb = Cavity(3, nu=0.01)
+
+        def solve(comm):
+            out = solve_steady(pb, gmres_rtol=1e-6, max_newton=4, comm=comm)
+            eng = out["solver"].linear_solver().ksp().engine
+            assert eng.local_handover == local
+            return out["krylov_per_step"], np.array(out["w"].vector())
+        res = _on_ranks(R, solve)
+        PETScOptions.clear()
+        return res
+
+    glob, loc = run(False), run(True)
+    for (kg, xg), (kl, xl) in zip(glob, loc):
+        assert kl == kg and len(kg) == 4
+        assert np.abs(xl - xg).max() <= 1e-12 * np.abs(xg).max()

@@ -345,3 +345,105 @@ def test_rank_local_handover_equals_global_handover(hip_lib, R):
         for k in glob[r]:
             assert np.array_equal(loc[r][k], glob[r][k]), (r, k)
     assert relerr(loc[0]["Kp2"], 1.5 * (st["Kp"] @ xp)) < 1e-13
+
+
+def _push_multigrid_local(e, slot, A, chain, velocity, limit, nu=2, ratio=0.1):
+    """helpers.push_multigrid with every PARTITIONED level handed over as this
+    rank's rows only (pcd_mg_set_level_local); replicated levels - at most
+    ``limit`` rows - go over whole, as they live on every rank."""
+    import scipy.sparse as sp
+    from fenapack_amd.fem.multigrid import galerkin_chain, coarse_inverse
+    from fenapack_amd.petsc import estimate_emax
+    ops = galerkin_chain(A, chain)
+    L = len(ops)
+    e.mg_begin(slot, L, nu, nu)
+    e.mg_set_level(slot, 0, coarse_inverse(ops[0]))
+    n_local = 0
+    for l in range(1, L):
+        emax = 1.1 * estimate_emax(ops[l], iters=12)
+        n, nc = ops[l].shape[0], ops[l - 1].shape[0]
+        if l < L - 1 and n <= limit:
+            e.mg_set_level(slot, l, ops[l], chain[l], ratio * emax, emax)
+            continue
+        r0, r1 = e.row_range(n, velocity=velocity)
+        P = sp.csr_matrix(chain[l])
+        R_rows = None
+        if nc > limit:
+            c0, c1 = e.row_range(nc, velocity=velocity)
+            R_rows = sp.csr_matrix(P.T)[c0:c1]
+        e.mg_set_level_local(slot, l, n,
+                             sp.csr_matrix(ops[l])[r0:r1] if l < L - 1
+                             else None, P[r0:r1], R_rows, ratio * emax, emax)
+        n_local += 1
+    e.set_inner(slot, "richardson", "mg", 1, 0.0)
+    return n_local
+
+
+@pytest.mark.parametrize("R,replicate_below", [(2, "0"), (3, "700"),
+                                               (2, "60000")])
+def test_rank_local_system_and_multigrid_equal_the_global_handover(
+        hip_lib, monkeypatch, R, replicate_below):
+    """pcd_set_system_local / pcd_mg_set_level_local: a rank hands over its
+    own rows of the monolithic matrix and of every partitioned multigrid
+    level; nothing global but the index sets crosses the boundary.  Same
+    GMRES history and PCApply as the global hand-over, also after a value
+    refresh with the rank's own values."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", replicate_below)
+    limit = int(replicate_below)
+    st = flow_state("cavity", 3)
+    pb, V, Lz = st["pb"], st["V"], st["L"]
+    I = pb.interpolations()
+    A = sp.csr_matrix(st["A"])
+    n = A.shape[0]
+    A2 = A.copy()
+    A2.data = A2.data * (1.0 + 0.01 * np.sin(np.arange(A2.nnz)))
+    mats_p = {c.MAT_AP: pb.Ap, c.MAT_MP: pb.Mp, c.MAT_KP: st["Kp"]}
+
+    def work(local):
+        def body(e, rank):
+            e.set_velocity_block(V.dim)
+            if local:
+                p0, p1 = e.row_range(V.n_p)
+                u0, u1 = e.row_range(V.n_u, velocity=True)
+                for which, M in mats_p.items():
+                    e.set_csr_local(which, sp.csr_matrix(M)[p0:p1], M.shape)
+                e.set_bc(pb.bc_p_idx, pb.bc_p_val)
+                rows = np.concatenate([V.is_u[u0:u1], V.is_p[p0:p1]])
+                # (rows that are not this rank's blocks are refused)
+                with pytest.raises(c.EngineError, match="expected|owns"):
+                    e.set_system_local(A[rows[::-1]], rows[::-1], n, V.is_u,
+                                       V.is_p)
+                e.set_system_local(A[rows], rows, n, V.is_u, V.is_p)
+                nl = _push_multigrid_local(e, c.KSP_AP, pb.Ap, I.chain("p"),
+                                           False, limit)
+                nl += _push_multigrid_local(e, c.KSP_A00, Lz["A00"],
+                                            I.chain("u"), True, limit)
+                # (the finest level of a hierarchy is always partitioned)
+                assert nl >= 2 and (limit > 0 or nl > 2)
+            else:
+                configure_engine(e, st)
+                push_multigrid(e, c.KSP_AP, pb.Ap, I.chain("p"))
+                push_multigrid(e, c.KSP_A00, Lz["A00"], I.chain("u"))
+            e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+            e.setup()
+            x, its, rn = e.gmres_np(st["b"], rtol=1e-8, restart=60,
+                                    max_it=200)
+            y = e.fieldsplit_apply_np(st["b"])
+            if local:
+                e.update_system(A2[rows].data)
+            else:
+                e.update_system(A2.data)
+            x2, its2, _ = e.gmres_np(st["b"], rtol=1e-8, restart=60,
+                                     max_it=200)
+            return x, its, y, x2, its2
+        return body
+
+    glob = run_ranks(hip_lib, R, "BRM1", work(False))
+    loc = run_ranks(hip_lib, R, "BRM1", work(True))
+    for g, l in zip(glob, loc):
+        assert l[1] == g[1] and l[4] == g[4]
+        for a, b in ((l[0], g[0]), (l[2], g[2]), (l[3], g[3])):
+            assert np.array_equal(a, b)
+    assert relerr(A @ loc[0][0], st["b"]) < 1e-6
+    assert relerr(A2 @ loc[0][3], st["b"]) < 1e-6

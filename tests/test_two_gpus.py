@@ -47,15 +47,21 @@ def _launch(args, port, timeout, nproc=2, extra_env=None):
         text=True, timeout=timeout)
 
 
+@pytest.mark.parametrize("local", [False, True])
 @pytest.mark.timeout(600)
-def test_worker_on_one_rank_over_a_real_rccl_communicator(hip_lib, tmp_path):
+def test_worker_on_one_rank_over_a_real_rccl_communicator(hip_lib, tmp_path,
+                                                          local):
     """The worker of the two-GPU tests below, started by the same launcher
     with ONE rank and the communicator forced on (PCD_FORCE_COMM): everything
     of the multi-rank path except a second GPU - process group, unique id,
     ncclCommInitRank, the set-up handshake, halos and all-reduces over RCCL -
-    runs on every box, so the script cannot be broken when two GPUs show up."""
+    runs on every box, so the script cannot be broken when two GPUs show up.
+    ``local``: the rank-local hand-over (pcd_set_csr_local /
+    pcd_set_system_local)."""
     out = str(tmp_path / "one.npz")
-    run = _launch([WORKER, "--out", out], 29639, 420, nproc=1,
+    run = _launch([WORKER, "--out", out]
+                  + (["--handover=rows"] if local else []),
+                  29639 + int(local), 420, nproc=1,
                   extra_env={"PCD_FORCE_COMM": "1"})
     assert run.returncode == 0, run.stderr[-3000:]
     one = np.load(out)
@@ -103,12 +109,15 @@ def test_bench_on_two_gpus_over_rccl():
 
 
 @needs2
+@pytest.mark.parametrize("local", [False, True])
 @pytest.mark.timeout(900)
-def test_two_processes_match_one_gpu(hip_lib, tmp_path):
+def test_two_processes_match_one_gpu(hip_lib, tmp_path, local):
     """Partitioned SpMV, PCD apply, fieldsplit PCApply and a full GMRES solve
     on two RCCL ranks against one engine: 1e-11, identical iteration count."""
     out = str(tmp_path / "two.npz")
-    run = _launch([WORKER, "--out", out], 29641, 600)
+    run = _launch([WORKER, "--out", out]
+                  + (["--handover=rows"] if local else []),
+                  29641 + 6 * int(local), 600)
     assert run.returncode == 0, run.stderr[-3000:]
     two = np.load(out)
     assert two["ranks"] == 2 and 0 < two["nu_loc"] < 2 * 10 ** 9

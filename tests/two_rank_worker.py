@@ -20,6 +20,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 p = argparse.ArgumentParser()
 p.add_argument("--out", required=True)
 p.add_argument("--fail-rank", type=int, default=-1)
+p.add_argument("--handover", choices=("global", "rows"), default="global",
+               help="rows: every operator and the block system go over as "
+                    "this rank's rows only (pcd_set_csr_local, "
+                    "pcd_set_system_local)")
 a = p.parse_args()
 
 import torch                                                  # noqa: E402
@@ -44,7 +48,21 @@ if comm.unique_id() is None:
     raise SystemExit("two_rank_worker: no communicator (one rank needs "
                      "PCD_FORCE_COMM=1)")
 e.comm_init(comm.rank, comm.size, comm.unique_id())
-configure_engine(e, st)
+if a.handover == "rows":
+    import scipy.sparse as sp                                  # noqa: E402
+    pb = st["pb"]
+    e.set_velocity_block(V.dim)
+    p0, p1 = e.row_range(V.n_p)
+    u0, u1 = e.row_range(V.n_u, velocity=True)
+    for which, M in ((c.MAT_AP, pb.Ap), (c.MAT_MP, pb.Mp),
+                     (c.MAT_KP, st["Kp"]), (c.MAT_RP, st["Rp"])):
+        e.set_csr_local(which, sp.csr_matrix(M)[p0:p1], M.shape)
+    e.set_bc(pb.bc_p_idx, pb.bc_p_val)
+    rows = np.concatenate([V.is_u[u0:u1], V.is_p[p0:p1]])
+    e.set_system_local(sp.csr_matrix(st["A"])[rows], rows, V.ndof, V.is_u,
+                       V.is_p)
+else:
+    configure_engine(e, st)
 set_iter_cfg(e)
 e.set_inner(c.KSP_A00, "chebyshev", "jacobi", 4, 0.0, 0.2, 2.2)
 e.setup()
