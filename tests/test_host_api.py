@@ -386,3 +386,33 @@ def test_subfield_bc_arrays_merge_in_application_order():
     assert idx.dtype == np.int32 and val.dtype == np.float64
     assert np.array_equal(np.sort(idx), np.sort(pb.bc_p_idx))
     assert np.all(val == 0.0)
+
+
+def test_blas_pools_are_capped_but_never_resized_under_thread_binding(
+        monkeypatch):
+    """fenapack_amd.limit_blas_threads: the package caps the BLAS pools at
+    import (small dense calls on a pool of one thread per core cost ~100 x
+    their work); an explicit OPENBLAS_NUM_THREADS wins, and nothing is resized
+    when an OpenMP runtime binds threads (new BLAS threads would inherit the
+    bound main thread's one-core mask)."""
+    import fenapack_amd
+    threadpoolctl = pytest.importorskip("threadpoolctl")
+    monkeypatch.setenv("OPENBLAS_NUM_THREADS", "8")
+    assert fenapack_amd.limit_blas_threads() is None
+    monkeypatch.delenv("OPENBLAS_NUM_THREADS")
+    monkeypatch.setenv("OMP_PROC_BIND", "spread")
+    assert fenapack_amd.limit_blas_threads() is None
+    monkeypatch.delenv("OMP_PROC_BIND")
+    monkeypatch.setenv("FENAPACK_AMD_BLAS_THREADS", "0")
+    assert fenapack_amd.limit_blas_threads() is None
+    before = [d["num_threads"] for d in threadpoolctl.threadpool_info()
+              if d["user_api"] == "blas"]
+    lim = fenapack_amd.limit_blas_threads(1)
+    try:
+        assert all(d["num_threads"] == 1
+                   for d in threadpoolctl.threadpool_info()
+                   if d["user_api"] == "blas")
+    finally:
+        lim.restore_original_limits()
+    assert [d["num_threads"] for d in threadpoolctl.threadpool_info()
+            if d["user_api"] == "blas"] == before
