@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +36,20 @@ static void parallel_chunks(int64_t n, F f) {
   for (int t = 0; t < T; ++t) th.emplace_back(f, n * t / T, n * (t + 1) / T);
   for (auto& x : th) x.join();
 }
+
+// PCD_SETUP_TIMING=1: wall time of the set-up phases on stderr (diagnostics)
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PhaseTimer() : on([] { const char* e = getenv("PCD_SETUP_TIMING"); return e && e[0] == '1'; }()),
+                 t(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pcd set-up] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[1024] = "";
@@ -1962,8 +1977,10 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   if (n_u + n_p != n) return fail(PCD_ERR_ARG, "set_system: n_u + n_p != n");
   if (n >= INT32_MAX) return fail(PCD_ERR_ARG, "set_system: n exceeds int32 indexing");
   HIPCHK(hipSetDevice(h->device));
+  PhaseTimer pt;
   std::vector<int32_t> isu_r, isp_r;       // index sets in engine numbering
   CHK(decide_reordering(h, n, rowptr, colidx, n_u, is_u, n_p, is_p, isu_r, isp_r));
+  pt.lap("set_system: reordering");
   if (!isu_r.empty()) is_u = isu_r.data();
   if (!isp_r.empty()) is_p = isp_r.data();
   std::vector<int32_t> perm(n), mu(n, -1), mp(n, -1), ma(n, -1);
@@ -1990,11 +2007,15 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
     CHK(h->perm.ensure(nloc));
     if (nloc) HIPCHK(hipMemcpy(h->perm.p, pl.data(), nloc * sizeof(int), hipMemcpyHostToDevice));
   }
+  pt.lap("set_system: index maps");
   std::vector<int32_t> rp, cc; std::vector<int64_t> src;
   extract_block(n_u, is_u, rowptr, colidx, mu, rp, cc, src);
+  pt.lap("set_system: extract A00");
   CHK(upload_global(h, h->mat[PCD_MAT_A00], &h->sp_u, &h->sp_u, n_u, n_u, rp.data(), cc.data(), nullptr, src.data()));
+  pt.lap("set_system: upload A00");
   extract_block(n_u, is_u, rowptr, colidx, mp, rp, cc, src);
   CHK(upload_global(h, h->mat[PCD_MAT_A01], &h->sp_u, &h->sp_p, n_u, n_p, rp.data(), cc.data(), nullptr, src.data()));
+  pt.lap("set_system: A01");
   h->a10.release(); h->a11.release(); h->a11_src_host.clear();
   {
     // (1,0) and (1,1) blocks: w = A z is applied block-wise (velocity block
@@ -2006,10 +2027,15 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
     CHK(upload_global(h, h->a11, &h->sp_p, &h->sp_p, n_p, n_p, rp.data(), cc.data(), nullptr, src.data()));
     h->a11_src_host = src;               // (positions in the caller's values, all rows)
   }
+  pt.lap("set_system: A10, A11");
   extract_block(n, perm.data(), rowptr, colidx, ma, rp, cc, src);
+  pt.lap("set_system: extract A");
   CHK(upload_global(h, h->mat[PCD_MAT_A], &h->sp_sys, &h->sp_sys, n, n, rp.data(), cc.data(), nullptr, src.data()));
+  pt.lap("set_system: upload A");
   h->ready = false; ++h->gen;
-  return pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
+  const int rc = pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
+  pt.lap("set_system: values");
+  return rc;
 }
 
 // Rank-local form of pcd_set_system: this rank's rows of the monolithic matrix
