@@ -5,7 +5,12 @@ process (pcd_comm_init_threads), each with its own engine, partition, halo
 plans and device producer.  Steady Picard solve; prints one JSON line per R.
 Parity of the partitioned code path (Krylov counts, solution), NOT a timing.
 
-usage: steady_thread_ranks.py [cube|cavity] [level] [R ...=1 8]"""
+usage: steady_thread_ranks.py [--host] [cube|cavity] [level] [R ...=1 8]
+
+--host: the nonlinear steps driven from the host, as ``bench.py`` sets its
+workload up (two steps, exactly), instead of the device producer; with
+FENAPACK_AMD_LOCAL_HANDOVER=1 every rank hands over its own rows only - the
+shape of the driver's ``bench.py --gpus 8`` start-up minus RCCL."""
 import ctypes
 import json
 import os
@@ -20,9 +25,11 @@ from fenapack_amd.driver import multigrid_inner_options                # noqa
 from fenapack_amd.fem import Cavity, Cavity3D                          # noqa
 from fenapack_amd.parallel import Comm                                 # noqa
 
-geometry = sys.argv[1] if len(sys.argv) > 1 else "cube"
-level = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-ranks = [int(a) for a in sys.argv[3:]] or [1, 8]
+HOST = "--host" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--host"]
+geometry = argv[0] if len(argv) > 0 else "cube"
+level = int(argv[1]) if len(argv) > 1 else 2
+ranks = [int(a) for a in argv[2:]] or [1, 8]
 dim = 3 if geometry == "cube" else 2
 # the two finest levels partitioned, the rest replicated (default limit:
 # 60000 rows; lowered so that small runs exercise both kinds of level)
@@ -34,7 +41,12 @@ multigrid_inner_options(dim=dim)
 def solve(comm):
     pb = Cavity3D(level, nu=0.01, n0=4) if geometry == "cube" \
         else Cavity(level, nu=0.01)
-    out = solve_steady_device(pb, max_newton=10, comm=comm)
+    if HOST:
+        from fenapack_amd.driver import solve_steady
+        out = solve_steady(pb, gmres_rtol=1e-6, restart=150, newton_rtol=0.0,
+                           max_newton=2, comm=comm)
+    else:
+        out = solve_steady_device(pb, max_newton=10, comm=comm)
     eng = out["solver"].linear_solver().ksp().engine
     from fenapack_amd import _cabi as c
     return {"ndof": pb.space.ndof, "picard_its": out["newton_its"],
@@ -42,6 +54,7 @@ def solve(comm):
             "krylov_per_step": out["krylov_per_step"],
             "final_residual": out["residuals"][-1],
             "rows_u_of_this_rank": int(eng.info(c.INFO_N_U_LOCAL)),
+            "local_handover": bool(eng.local_handover),
             "checksum": float(abs(out["w"].vector()).sum())}
 
 
