@@ -79,16 +79,21 @@ def _mis(G, seed=0):
 def aggregate(S, seed=0):
     """MIS-2 aggregation of the strength graph ``S``: roots no closer than
     three edges, distance-1 vertices join their root, distance-2 vertices the
-    aggregate of their strongest aggregated neighbour; isolated vertices
-    (Dirichlet rows) are singletons collected into aggregates of their own.
-    Returns ``agg`` (n,) with values in ``[0, nagg)``."""
+    aggregate of their strongest aggregated neighbour.  Isolated vertices -
+    Dirichlet rows: nothing couples to them, one Jacobi step solves them - get
+    NO coarse representative (``agg = -1``, a zero row of the prolongator);
+    kept as singleton aggregates they would survive on every level (the 3-D
+    cavity has 6 N^2 of them: the hierarchy of cube N = 36 stalled at 58 k
+    rows, profiles/r03_u_gamg_cube_n36_stalled.txt).
+    Returns ``agg`` (n,) with values in ``[-1, nagg)``."""
     n = S.shape[0]
     pat = sp.csr_matrix((np.ones(S.nnz), S.indices, S.indptr), shape=S.shape)
     G2 = (pat @ pat + pat).tocsr()
     G2.setdiag(0)
     G2.eliminate_zeros()
     G2.sort_indices()
-    roots = _mis(G2, seed)
+    isolated = np.diff(S.indptr) == 0
+    roots = _mis(G2, seed) & ~isolated
     agg = np.full(n, -1, dtype=np.int64)
     ridx = np.nonzero(roots)[0]
     agg[ridx] = np.arange(ridx.size)
@@ -105,10 +110,12 @@ def aggregate(S, seed=0):
         new = agg.copy()
         new[r[last]] = agg[c[last]]
         agg = new
-    left = np.nonzero(agg < 0)[0]                 # isolated vertices
+    # connected vertices the two sweeps did not reach (farther than two edges
+    # from every root cannot happen for a maximal set; kept for safety)
+    left = np.nonzero((agg < 0) & ~isolated)[0]
     if left.size:
         agg[left] = ridx.size + np.arange(left.size)
-    return agg, int(agg.max()) + 1
+    return agg, int(agg.max()) + 1 if agg.size and agg.max() >= 0 else 0
 
 
 def _rho(A, iters=15, seed=0):
@@ -125,6 +132,15 @@ def _rho(A, iters=15, seed=0):
     return best
 
 
+def _tentative(agg, nagg):
+    """Piecewise-constant prolongator of the aggregates, columns normalised;
+    vertices without an aggregate (``agg < 0``) get a zero row."""
+    has = np.nonzero(agg >= 0)[0]
+    size = np.bincount(agg[has], minlength=nagg).astype(float)
+    return sp.csr_matrix((1.0 / np.sqrt(size[agg[has]]), (has, agg[has])),
+                         shape=(agg.size, nagg))
+
+
 def sa_prolongator(A, theta=0.02, omega=4.0 / 3.0, seed=0):
     """One smoothed-aggregation prolongator for the scalar operator ``A``:
     ``P = (I - omega/rho D^-1 A) T`` with the piecewise-constant tentative
@@ -132,9 +148,7 @@ def sa_prolongator(A, theta=0.02, omega=4.0 / 3.0, seed=0):
     A = sp.csr_matrix(A)
     n = A.shape[0]
     agg, nagg = aggregate(_strength(A, theta), seed)
-    size = np.bincount(agg, minlength=nagg).astype(float)
-    T = sp.csr_matrix((1.0 / np.sqrt(size[agg]), (np.arange(n), agg)),
-                      shape=(n, nagg))
+    T = _tentative(agg, nagg)
     d = A.diagonal().copy()
     d[d == 0.0] = 1.0
     rho = _rho(A)
@@ -192,12 +206,8 @@ def smoothed_aggregation_chain(A, block=1, coarse_rows=2000, max_levels=12,
             # the tentative prolongator with the true operator
             G = block_graph_operator(cur, block)
             agg, nagg = aggregate(_strength(G, theta), len(Ps))
-            n = cur.shape[0]
-            size = np.bincount(agg, minlength=nagg).astype(float)
-            rows = np.arange(n)
-            cols = block * agg[rows // block] + rows % block
-            T = sp.csr_matrix((1.0 / np.sqrt(size[agg[rows // block]]),
-                               (rows, cols)), shape=(n, block * nagg))
+            T = sp.kron(_tentative(agg, nagg), sp.identity(block),
+                        format="csr")
             d = cur.diagonal().copy()
             d[d == 0.0] = 1.0
             P = T - (4.0 / 3.0 / _rho(cur)) * (sp.diags(1.0 / d) @ (cur @ T))

@@ -288,8 +288,16 @@ def test_algebraic_hierarchy_from_the_matrix_alone():
     from fenapack_amd.fem.multigrid import galerkin_chain
     pb = Cavity(3, nu=0.01)
     Ap = sp.csr_matrix(pb.Ap)
-    agg, nagg = aggregate(_strength(Ap, 0.02))
-    assert agg.min() == 0 and agg.max() == nagg - 1 and nagg < Ap.shape[0] / 3
+    S = _strength(Ap, 0.02)
+    agg, nagg = aggregate(S)
+    assert agg.max() == nagg - 1 and nagg < Ap.shape[0] / 3
+    # Dirichlet rows - nothing couples to them - get no coarse representative
+    # (kept as singletons they would survive on every level: a 3-D cavity has
+    # 6 N^2 of them and its hierarchy stalled), everything else has one
+    isolated = np.diff(S.indptr) == 0
+    assert isolated.any() and np.all(agg[isolated] == -1)
+    assert np.all(agg[~isolated] >= 0)
+    assert set(np.unique(agg[~isolated])) == set(range(nagg))
     chain = smoothed_aggregation_chain(Ap, coarse_rows=300)
     assert chain[0] is None and chain[-1].shape[0] == Ap.shape[0]
     for a, b in zip(chain[1:-1], chain[2:]):
@@ -328,6 +336,15 @@ def test_algebraic_hierarchy_from_the_matrix_alone():
     ch = smoothed_aggregation_chain(A00, block=2, coarse_rows=500)
     for Pl in ch[1:]:
         assert scalar_stencil(sp.csr_matrix(Pl.T @ Pl), 2) is not None
+    # three components, enclosed flow: every boundary node is a Dirichlet row;
+    # the hierarchy reaches the coarse limit instead of stalling on them
+    from fenapack_amd.fem import Cavity3D
+    pb3 = Cavity3D(1, nu=0.01, n0=4)
+    A3 = sp.csr_matrix(pb3.linearise(*pb3.initial_guess())["A00"])
+    ch3 = smoothed_aggregation_chain(A3, block=3, coarse_rows=2000)
+    assert ch3[1].shape[1] <= 2000 and ch3[1].shape[1] % 3 == 0
+    zero_rows = np.diff(sp.csr_matrix(ch3[-1]).indptr) == 0
+    assert zero_rows.sum() >= 3 * 6 * 15 ** 2       # the boundary nodes
     # options: gamg and the reference's hypre spelling select it
     PETScOptions.clear()
     PETScOptions.set("x_pc_type", "hypre")
