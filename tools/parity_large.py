@@ -22,6 +22,9 @@ p = argparse.ArgumentParser()
 p.add_argument("--geometry", default="cube")
 p.add_argument("--level", type=int, default=4)
 p.add_argument("--n0", type=int, default=5)
+p.add_argument("--algebraic", action="store_true",
+               help="-pc_type gamg: hierarchy from the matrix (meshes without "
+                    "a nested one, e.g. --level 0 --n0 73)")
 a = p.parse_args()
 t0 = time.time()
 pb = {"cube": lambda: Cavity3D(a.level, nu=0.01, n0=a.n0),
@@ -29,7 +32,7 @@ pb = {"cube": lambda: Cavity3D(a.level, nu=0.01, n0=a.n0),
       "lshape": lambda: BackwardStep(a.level, nu=0.02)}[a.geometry]()
 V = pb.space
 PETScOptions.clear()
-multigrid_inner_options(dim=V.dim)
+multigrid_inner_options(dim=V.dim, algebraic=a.algebraic)
 w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150, newton_rtol=0.0,
                           max_newton=2)
 nls.parameters["absolute_tolerance"] = 0.0
@@ -48,7 +51,8 @@ t_oracle = time.time() - t0
 err = float(np.abs(yg - yo).max() / np.abs(yo).max())
 err_p = float(np.abs(yg[V.is_p] - yo[V.is_p]).max() / np.abs(yo[V.is_p]).max())
 print(json.dumps({
-    "workload": "%s level %d n0 %d" % (a.geometry, a.level, a.n0),
+    "workload": "%s level %d n0 %d%s" % (a.geometry, a.level, a.n0,
+                                        " gamg" if a.algebraic else ""),
     "ndof": int(V.ndof), "gmres_its_per_step": list(nls.krylov_history),
     "hip_vs_oracle_rel_err": err, "pressure_block_rel_err": err_p,
     "seconds": {"setup": t_setup, "mirror": t_mirror,
