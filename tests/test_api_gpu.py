@@ -192,3 +192,33 @@ def test_algebraic_multigrid_options_of_the_reference_demo(monkeypatch):
     assert max(gpu["krylov_per_step"]) < 120
     ksp0 = gpu["solver"].linear_solver().ksp().pc.getFieldSplitSubKSP()[0]
     assert ksp0.pc.mg_algebraic and len(ksp0.pc.mg_data["ops"]) >= 2
+
+
+def test_algebraic_hierarchy_in_three_dimensions(monkeypatch):
+    """-pc_type gamg on a 3-D operator (three components per node, every
+    boundary node a Dirichlet row - the rows that used to stall the
+    aggregation): the hierarchy goes below the coarse limit, the HIP engine
+    and the oracle count the same outer iterations.  Config 5's own mesh
+    (N = 73, no nested hierarchy) runs this path:
+    profiles/r03_gamg_cube_n73_config5_size.json."""
+    from fenapack_amd.driver import multigrid_inner_options
+    from fenapack_amd.fem import Cavity3D
+
+    def run(lib):
+        if lib is not None:
+            monkeypatch.setattr(c, "hip_library", lambda: lib)
+        PETScOptions.clear()
+        multigrid_inner_options(dim=3, algebraic=True)
+        out = solve_steady(Cavity3D(0, nu=0.01, n0=10), newton_rtol=0.0,
+                           max_newton=2, gmres_rtol=1e-6)
+        PETScOptions.clear()
+        return out
+    gpu = run(None)
+    cpu = run(oracle.library())
+    assert gpu["krylov_per_step"] == cpu["krylov_per_step"]
+    assert max(gpu["krylov_per_step"]) < 80
+    assert relerr(gpu["w"].vector(), cpu["w"].vector()) < 1e-6
+    ksp0 = gpu["solver"].linear_solver().ksp().pc.getFieldSplitSubKSP()[0]
+    ops = ksp0.pc.mg_data["ops"]
+    assert ksp0.pc.mg_algebraic and len(ops) >= 2
+    assert ops[0].shape[0] <= ksp0.pc.mg_coarse_eq_limit
