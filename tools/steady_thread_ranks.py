@@ -5,7 +5,7 @@ process (pcd_comm_init_threads), each with its own engine, partition, halo
 plans and device producer.  Steady Picard solve; prints one JSON line per R.
 Parity of the partitioned code path (Krylov counts, solution), NOT a timing.
 
-usage: steady_thread_ranks.py [--host] [cube|cavity] [level] [R ...=1 8]
+usage: steady_thread_ranks.py [--host] [--algebraic] [--n0=N] [cube|cavity] [level] [R ...=1 8]
 
 --host: the nonlinear steps driven from the host, as ``bench.py`` sets its
 workload up (two steps, exactly), instead of the device producer; with
@@ -26,7 +26,9 @@ from fenapack_amd.fem import Cavity, Cavity3D                          # noqa
 from fenapack_amd.parallel import Comm                                 # noqa
 
 HOST = "--host" in sys.argv
-argv = [a for a in sys.argv[1:] if a != "--host"]
+ALGEBRAIC = "--algebraic" in sys.argv        # -pc_type gamg: no nested hierarchy needed
+N0 = ([int(a[5:]) for a in sys.argv if a.startswith("--n0=")] or [4])[0]
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 geometry = argv[0] if len(argv) > 0 else "cube"
 level = int(argv[1]) if len(argv) > 1 else 2
 ranks = [int(a) for a in argv[2:]] or [1, 8]
@@ -35,11 +37,11 @@ dim = 3 if geometry == "cube" else 2
 # 60000 rows; lowered so that small runs exercise both kinds of level)
 os.environ.setdefault("PCD_REPLICATE_BELOW", "20000")
 PETScOptions.clear()
-multigrid_inner_options(dim=dim)
+multigrid_inner_options(dim=dim, algebraic=ALGEBRAIC)
 
 
 def solve(comm):
-    pb = Cavity3D(level, nu=0.01, n0=4) if geometry == "cube" \
+    pb = Cavity3D(level, nu=0.01, n0=N0) if geometry == "cube" \
         else Cavity(level, nu=0.01)
     if HOST:
         from fenapack_amd.driver import solve_steady
