@@ -76,7 +76,7 @@ def _mis(G, seed=0):
     return state == 1
 
 
-def aggregate(S, seed=0):
+def aggregate(S, seed=0, distance=2):
     """MIS-2 aggregation of the strength graph ``S``: roots no closer than
     three edges, distance-1 vertices join their root, distance-2 vertices the
     aggregate of their strongest aggregated neighbour.  Isolated vertices -
@@ -88,10 +88,13 @@ def aggregate(S, seed=0):
     Returns ``agg`` (n,) with values in ``[-1, nagg)``."""
     n = S.shape[0]
     pat = sp.csr_matrix((np.ones(S.nnz), S.indices, S.indptr), shape=S.shape)
-    G2 = (pat @ pat + pat).tocsr()
-    G2.setdiag(0)
-    G2.eliminate_zeros()
-    G2.sort_indices()
+    if distance >= 2:
+        G2 = (pat @ pat + pat).tocsr()
+        G2.setdiag(0)
+        G2.eliminate_zeros()
+        G2.sort_indices()
+    else:
+        G2 = pat          # MIS-1: roots two edges apart, aggregates = stars
     isolated = np.diff(S.indptr) == 0
     roots = _mis(G2, seed) & ~isolated
     agg = np.full(n, -1, dtype=np.int64)
@@ -141,13 +144,13 @@ def _tentative(agg, nagg):
                          shape=(agg.size, nagg))
 
 
-def sa_prolongator(A, theta=0.02, omega=4.0 / 3.0, seed=0):
+def sa_prolongator(A, theta=0.02, omega=4.0 / 3.0, seed=0, distance=2):
     """One smoothed-aggregation prolongator for the scalar operator ``A``:
     ``P = (I - omega/rho D^-1 A) T`` with the piecewise-constant tentative
     prolongator ``T`` of the aggregates (columns normalised)."""
     A = sp.csr_matrix(A)
     n = A.shape[0]
-    agg, nagg = aggregate(_strength(A, theta), seed)
+    agg, nagg = aggregate(_strength(A, theta), seed, distance)
     T = _tentative(agg, nagg)
     d = A.diagonal().copy()
     d[d == 0.0] = 1.0
@@ -187,7 +190,7 @@ def block_graph_operator(A, block):
 
 
 def smoothed_aggregation_chain(A, block=1, coarse_rows=2000, max_levels=12,
-                               theta=0.02, min_ratio=1.5):
+                               theta=0.02, min_ratio=1.5, distance=2):
     """Prolongation chain ``[None, P_1, ..., P_L]`` for the finest operator
     ``A`` (``P_l`` maps level ``l-1`` to ``l``; the format
     ``PC.setMGInterpolations`` takes).  Coarsening stops at ``coarse_rows``
@@ -198,14 +201,14 @@ def smoothed_aggregation_chain(A, block=1, coarse_rows=2000, max_levels=12,
     while cur.shape[0] > coarse_rows and len(Ps) < max_levels - 1:
         F = scalar_stencil(cur, block)
         if F is not None:
-            Pf = sa_prolongator(F, theta, seed=len(Ps))
+            Pf = sa_prolongator(F, theta, seed=len(Ps), distance=distance)
             P = sp.kron(Pf, sp.identity(block, format="csr"), format="csr") \
                 if block > 1 else Pf
         else:
             # coupled block: aggregate nodes on the block-norm graph, smooth
             # the tentative prolongator with the true operator
             G = block_graph_operator(cur, block)
-            agg, nagg = aggregate(_strength(G, theta), len(Ps))
+            agg, nagg = aggregate(_strength(G, theta), len(Ps), distance)
             T = sp.kron(_tentative(agg, nagg), sp.identity(block),
                         format="csr")
             d = cur.diagonal().copy()
