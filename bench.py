@@ -225,6 +225,10 @@ def main():
         # pcd_set_csr_local, pcd_mg_set_level_local) - what a partitioned
         # assembly holds; FENAPACK_AMD_LOCAL_HANDOVER=0 is the A/B switch
         os.environ.setdefault("FENAPACK_AMD_LOCAL_HANDOVER", "1")
+        # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; the
+        # native set-up helpers get their share of the host's cores anyway
+        os.environ.setdefault("FENAPACK_AMD_HOST_THREADS", str(
+            max(1, min(32, (os.cpu_count() or 8) // world))))
     import torch
     import torch.distributed as dist
     if torch.cuda.device_count() < world:
