@@ -363,6 +363,13 @@ def _push_multigrid_local(e, slot, A, chain, velocity, limit, nu=2, ratio=0.1):
         emax = 1.1 * estimate_emax(ops[l], iters=12)
         n, nc = ops[l].shape[0], ops[l - 1].shape[0]
         if l < L - 1 and n <= limit:
+            # (a replicated level lives whole on every rank: its rows alone
+            # are refused, before anything is exchanged)
+            r0, r1 = e.row_range(n, velocity=velocity)
+            with pytest.raises(c.EngineError, match="replicated"):
+                e.mg_set_level_local(slot, l, n, sp.csr_matrix(ops[l])[r0:r1],
+                                     sp.csr_matrix(chain[l])[r0:r1], None,
+                                     ratio * emax, emax)
             e.mg_set_level(slot, l, ops[l], chain[l], ratio * emax, emax)
             continue
         r0, r1 = e.row_range(n, velocity=velocity)
@@ -371,9 +378,19 @@ def _push_multigrid_local(e, slot, A, chain, velocity, limit, nu=2, ratio=0.1):
         if nc > limit:
             c0, c1 = e.row_range(nc, velocity=velocity)
             R_rows = sp.csr_matrix(P.T)[c0:c1]
-        e.mg_set_level_local(slot, l, n,
-                             sp.csr_matrix(ops[l])[r0:r1] if l < L - 1
-                             else None, P[r0:r1], R_rows, ratio * emax, emax)
+        A_rows = sp.csr_matrix(ops[l])[r0:r1] if l < L - 1 else None
+        if R_rows is not None:
+            # (the level below is partitioned too: its restriction rows are
+            # part of the hand-over; a block that is not this rank's is refused)
+            with pytest.raises(c.EngineError, match="restriction"):
+                e.mg_set_level_local(slot, l, n, A_rows, P[r0:r1], None,
+                                     ratio * emax, emax)
+        with pytest.raises(c.EngineError, match="owns"):
+            e.mg_set_level_local(slot, l, n, None if A_rows is None
+                                 else A_rows[:-1], P[r0:r1 - 1], R_rows,
+                                 ratio * emax, emax)
+        e.mg_set_level_local(slot, l, n, A_rows, P[r0:r1], R_rows,
+                             ratio * emax, emax)
         n_local += 1
     e.set_inner(slot, "richardson", "mg", 1, 0.0)
     return n_local
