@@ -33,6 +33,7 @@ p.add_argument("--level", type=int, default=6)
 p.add_argument("--geometry", default="cavity")
 p.add_argument("--variant", default="BRM1")
 p.add_argument("--n0", type=int, default=4)
+p.add_argument("--algebraic", action="store_true")
 a = p.parse_args()
 if a.geometry == "cavity":
     pb = Cavity(a.level, nu=0.01, variant=a.variant)
@@ -42,7 +43,7 @@ else:
     pb = BackwardStep(a.level, nu=0.02, variant=a.variant)
 V = pb.space
 PETScOptions.clear()
-multigrid_inner_options(dim=V.dim)
+multigrid_inner_options(dim=V.dim, algebraic=a.algebraic)
 w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150, newton_rtol=1e-5,
                           max_newton=2)
 nls.parameters["error_on_nonconvergence"] = False
