@@ -1637,6 +1637,8 @@ int pcd_create(pcd_handle* out, int variant, int device) {
       g_num_cus = prop.multiProcessorCount; }
   { const char* e = getenv("PCD_XCD_REMAP_NT");            // A/B: mapping of the non-temporal kernels
     if (e) { const int v = atoi(e); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pcd::g_xcd_remap_nt), &v, sizeof(int))); } }
+  { const char* e = getenv("PCD_XCD_REMAP_NT3_ROWS");      // node rows from which the 3-component kernels map too
+    if (e) { const int v = atoi(e); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pcd::g_xcd_remap_nt3_rows), &v, sizeof(int))); } }
   { const char* e = getenv("PCD_XCD_REMAP_MAX_ROWS");      // A/B: threshold of the XCD-aware mapping
     if (e) { const int v = atoi(e); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pcd::g_xcd_remap_max_rows), &v, sizeof(int))); } }
   { const char* e = getenv("PCD_NO_XCD_REMAP");
@@ -2359,6 +2361,17 @@ int pcd_mg_set_level_local(pcd_handle h, int slot, int level, int64_t n, int64_t
         return fail(PCD_ERR_ARG, "mg_set_level_local: %s column id %d outside [0, %lld)", what, ci[k], (long long)ncols);
     return 0;
   };
+  // (every refusal before anything is exchanged: the hand-over is collective)
+  if (!rep_c) {
+    if (!rrowptr || !rcolidx || !rvals)
+      return fail(PCD_ERR_ARG, "mg_set_level_local: the level below is partitioned too: this rank's rows of the "
+                               "restriction P^T are needed");
+    if (sc->nloc(me) != r_rows_local)
+      return fail(PCD_ERR_ARG, "mg_set_level_local: this rank owns %lld rows of level %d, the restriction has %lld",
+                  (long long)sc->nloc(me), level - 1, (long long)r_rows_local);
+    CHK(check_cols(rrowptr, rcolidx, r_rows_local, n, "restriction"));
+  }
+  CHK(check_cols(prowptr, pcolidx, nrows_local, p_cols, "prolongation"));
   M.replicated = false; M.transition = rep_c; M.n_coarse = p_cols;
   if (rowptr) {
     CHK(check_cols(rowptr, colidx, nrows_local, n, "operator"));
@@ -2367,7 +2380,6 @@ int pcd_mg_set_level_local(pcd_handle h, int slot, int level, int64_t n, int64_t
     CHK(upload_owned(h, M.A, sl, sl, nrows_local, span, colidx, vals, nullptr));
     CHK(refresh_dinv(h, M.A));
   }
-  CHK(check_cols(prowptr, pcolidx, nrows_local, p_cols, "prolongation"));
   if (rep_c) {
     // my fine rows x ALL coarse columns; the transpose sums my contribution to
     // every coarse row, the all-reduce in the cycle completes it
@@ -2385,13 +2397,6 @@ int pcd_mg_set_level_local(pcd_handle h, int slot, int level, int64_t n, int64_t
     CHK(upload_csr(h, M.R, p_cols, nrows_local, trp.data(), tc.data(), tv.data(), nullptr));
     M.P.replicated = M.R.replicated = true;       // no halo on either
   } else {
-    if (!rrowptr || !rcolidx || !rvals)
-      return fail(PCD_ERR_ARG, "mg_set_level_local: the level below is partitioned too: this rank's rows of the "
-                               "restriction P^T are needed");
-    if (sc->nloc(me) != r_rows_local)
-      return fail(PCD_ERR_ARG, "mg_set_level_local: this rank owns %lld rows of level %d, the restriction has %lld",
-                  (long long)sc->nloc(me), level - 1, (long long)r_rows_local);
-    CHK(check_cols(rrowptr, rcolidx, r_rows_local, n, "restriction"));
     auto pspan = [&](int64_t i) { return std::pair<int64_t, int64_t>(prowptr[i], prowptr[i + 1]); };
     auto rspan = [&](int64_t i) { return std::pair<int64_t, int64_t>(rrowptr[i], rrowptr[i + 1]); };
     CHK(upload_owned(h, M.P, sl, sc, nrows_local, pspan, pcolidx, pvals, nullptr));

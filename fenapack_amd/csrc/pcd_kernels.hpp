@@ -360,8 +360,18 @@ __constant__ int g_xcd_remap_max_rows = 1 << 20;
 // traffic 1.21 -> 0.99 x the kernel-model bytes; cube N = 64 the traffic falls
 // the same way (1.21 -> 1.02 x) but the launch gets 2 % SLOWER (262 -> 267 us:
 // the 3-D kernel is bound by its gather instructions, not by bytes), so bit 1
-// stays off (profiles/r03_x_xcd_nt_*.txt).
+// stays off (profiles/r03_x_xcd_nt_*.txt) ...
 __constant__ int g_xcd_remap_nt = 1;
+// ... below this many node rows.  Cube N = 73 (3.18 M node rows; config 5's own
+// mesh): counted traffic 1.32 x the kernel-model bytes, and the mapping wins:
+// 395.1 -> 376.5 us per launch, 2.913 -> 2.848 ms per PCApply
+// (profiles/r03_x_xcd_nt_cube73.txt; PCD_XCD_REMAP_NT3_ROWS).
+__constant__ int g_xcd_remap_nt3_rows = 2600000;
+
+template <int NC, bool NT>
+__device__ __forceinline__ bool xcd_remap_always(int nrows) {
+  return NT && (((g_xcd_remap_nt >> (NC - 2)) & 1) || (NC == 3 && nrows >= g_xcd_remap_nt3_rows));
+}
 
 // contiguous range of row blocks of this workgroup (gridDim.x multiple of 8)
 __device__ __forceinline__ void row_block_range(int nrb, int rb_rows, int& begin, int& end,
@@ -783,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
   VecC<NC>* y = vc<NC>(y_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1, NT && ((g_xcd_remap_nt >> (NC - 2)) & 1));
+  row_block_range(nrb, RB, rb0, rb1, xcd_remap_always<NC, NT>(nrows));
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x / (kBlock / RB);
@@ -815,7 +825,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
   VecC<NC>* pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1, NT && ((g_xcd_remap_nt >> (NC - 2)) & 1));
+  row_block_range(nrb, RB, rb0, rb1, xcd_remap_always<NC, NT>(nrows));
   const XVecC<NC> xf{pk, vc<NC>(ghost), nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
-  row_block_range(nrb, RB, rb0, rb1, NT && ((g_xcd_remap_nt >> (NC - 2)) & 1));
+  row_block_range(nrb, RB, rb0, rb1, xcd_remap_always<NC, NT>(nrows));
   const XVecC<NC> xf{b, b, nrows};    // vals carry D^-1 (see k_cheb_first_s)
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
