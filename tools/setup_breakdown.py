@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--n0", type=int, default=4)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--algebraic", action="store_true")
     ap.add_argument("--bind", action="store_true",
                     help="OMP_PROC_BIND=spread OMP_PLACES=cores, as bench.py")
     args = ap.parse_args()
@@ -60,7 +61,7 @@ def main():
         marks.append(("problem", time.time() - t0))
         t0 = time.time()
         PETScOptions.clear()
-        multigrid_inner_options(dim=pb.space.dim)
+        multigrid_inner_options(dim=pb.space.dim, algebraic=args.algebraic)
         w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150,
                                   newton_rtol=0.0, max_newton=args.steps,
                                   device=0)
