@@ -25,6 +25,8 @@ coarse level keeps the Kronecker structure the multi-component kernels use.
 import numpy as np
 import scipy.sparse as sp
 
+from . import _host
+
 
 def _strength(A, theta):
     """Symmetric strength graph: |a_ij| >= theta sqrt(|a_ii a_jj|), no
@@ -170,11 +172,20 @@ def scalar_stencil(A, block):
     A = sp.csr_matrix(A)
     if A.shape[0] % block:
         return None
-    F = A[0::block, 0::block].tocsr()
-    K = sp.kron(F, sp.identity(block, format="csr"), format="csr")
-    if K.nnz != A.nnz or abs(K - A).max() > 1e-14 * abs(A).max():
-        return None
-    return F
+    F = getattr(A, "kron_scalar", None)
+    if F is not None and getattr(A, "kron_block", 0) == block:
+        return F
+    return _host.kron_factor(A, block)
+
+
+def _galerkin(A, P):
+    """``P^T A P`` with sorted columns; large products on the threaded native
+    SpGEMM (the same sums in the same order as scipy's)."""
+    if A.nnz > 400000 and not _host.use_numpy():
+        return _host.spgemm(_host.spgemm(_host.transpose(P), A), P)
+    C = (P.T @ A @ P).tocsr()
+    C.sort_indices()
+    return C
 
 
 def block_graph_operator(A, block):
@@ -198,26 +209,36 @@ def smoothed_aggregation_chain(A, block=1, coarse_rows=2000, max_levels=12,
     A = sp.csr_matrix(A)
     Ps = []
     cur = A
+    curF = scalar_stencil(cur, block) if block > 1 else None
     while cur.shape[0] > coarse_rows and len(Ps) < max_levels - 1:
-        F = scalar_stencil(cur, block)
-        if F is not None:
+        if block == 1 or curF is not None:
+            # scalar operator, or F (x) I_d: everything on the scalar factor,
+            # expanded (with its factor attached) for the hand-over
+            F = cur if block == 1 else curF
             Pf = sa_prolongator(F, theta, seed=len(Ps), distance=distance)
-            P = sp.kron(Pf, sp.identity(block, format="csr"), format="csr") \
-                if block > 1 else Pf
-        else:
-            # coupled block: aggregate nodes on the block-norm graph, smooth
-            # the tentative prolongator with the true operator
-            G = block_graph_operator(cur, block)
-            agg, nagg = aggregate(_strength(G, theta), len(Ps), distance)
-            T = sp.kron(_tentative(agg, nagg), sp.identity(block),
-                        format="csr")
-            d = cur.diagonal().copy()
-            d[d == 0.0] = 1.0
-            P = T - (4.0 / 3.0 / _rho(cur)) * (sp.diags(1.0 / d) @ (cur @ T))
+            if Pf.shape[1] * min_ratio > Pf.shape[0]:
+                break                              # coarsening stalled
+            Fc = _galerkin(F, Pf)
+            if block == 1:
+                P, cur = Pf, Fc
+            else:
+                P = _host.kron_expand(Pf, block)
+                curF, cur = Fc, _host.kron_expand(Fc, block)
+            Ps.append(P)
+            continue
+        # coupled block: aggregate nodes on the block-norm graph, smooth
+        # the tentative prolongator with the true operator
+        G = block_graph_operator(cur, block)
+        agg, nagg = aggregate(_strength(G, theta), len(Ps), distance)
+        T = sp.kron(_tentative(agg, nagg), sp.identity(block),
+                    format="csr")
+        d = cur.diagonal().copy()
+        d[d == 0.0] = 1.0
+        P = T - (4.0 / 3.0 / _rho(cur)) * (sp.diags(1.0 / d) @ (cur @ T))
         P = sp.csr_matrix(P)
         P.sort_indices()
         if P.shape[1] * min_ratio > P.shape[0]:
             break                                  # coarsening stalled
         Ps.append(P)
-        cur = (P.T @ cur @ P).tocsr()
+        cur = _galerkin(cur, P)
     return [None] + Ps[::-1]
