@@ -23,13 +23,67 @@ from .taylor_hood import TaylorHood, _p2_basis, small_det_inv
 MAX_FINEST_CELLS = {2: 1_000_000, 3: 800_000}
 
 
+#: host memory the producer + solver set-up holds per cell of the finest level
+#: (measured: problem and one linearisation 12-16 KB per tetrahedron, the whole
+#: set-up with patterns, hierarchy and products about three times that)
+HOST_BYTES_PER_CELL = {2: 12_000, 3: 48_000}
+
+
+def host_memory_available():
+    """Bytes this process may still allocate: the smaller of the control
+    group's limit (a container usually owns a fraction of the machine that
+    ``free`` shows) and the kernel's MemAvailable; ``None`` when unknown."""
+    cands = []
+    for path in ("/sys/fs/cgroup/memory.max",
+                 "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(path).read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                used = 0
+                for u in ("/sys/fs/cgroup/memory.current",
+                          "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                    try:
+                        used = int(open(u).read().strip())
+                        break
+                    except (OSError, ValueError):
+                        pass
+                cands.append(int(v) - used)
+        except (OSError, ValueError):
+            pass
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                cands.append(int(line.split()[1]) * 1024)
+    except OSError:
+        pass
+    return min(cands) if cands else None
+
+
 def _check_size(cells, dim, what):
+    """A mistyped level, or R rank threads each building a 10 M-DOF problem,
+    must fail HERE, not take the machine down (it did, once: eight thread
+    ranks at cube N = 73 on a box whose container owned a fraction of the
+    memory ``free`` reported).  ``FENAPACK_AMD_CONCURRENT_BUILDS`` = how many
+    problems of this size the process builds at once (the thread-rank tools
+    set it); ``FENAPACK_AMD_IGNORE_MEMORY=1`` skips the estimate."""
     import os
     limit = int(os.environ.get("FENAPACK_AMD_MAX_CELLS", MAX_FINEST_CELLS[dim]))
     if cells > limit:
         raise ValueError("%s: %.3g cells on the finest level exceed the host "
                          "assembler's limit of %d (FENAPACK_AMD_MAX_CELLS)"
                          % (what, cells, limit))
+    if os.environ.get("FENAPACK_AMD_IGNORE_MEMORY") == "1":
+        return
+    builds = max(1, int(os.environ.get("FENAPACK_AMD_CONCURRENT_BUILDS", "1")))
+    need = float(cells) * HOST_BYTES_PER_CELL[dim] * builds
+    have = host_memory_available()
+    if have is not None and need > 0.5 * have:
+        raise MemoryError(
+            "%s: about %.0f GB of host memory for %d concurrent build(s) of "
+            "%.3g cells, %.0f GB available to this process (control group / "
+            "MemAvailable); refusing above half of it "
+            "(FENAPACK_AMD_IGNORE_MEMORY=1 overrides)"
+            % (what, need / 1e9, builds, cells, have / 1e9))
 
 
 class MeshHierarchy(object):

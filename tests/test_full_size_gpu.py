@@ -109,11 +109,16 @@ def test_cube_n32_three_components():
 @pytest.mark.heavy(2)
 def test_cube_n64_config5_size(monkeypatch):
     """BASELINE config 5's size class on ONE GPU: N = 64 per side, 6 714 692
-    DOF (N = 73 - 9.9 M DOF - has no nested hierarchy; N = 64 and N = 80
+    DOF (N = 73 - 9.9 M DOF - has no nested hierarchy: it runs through the
+    algebraic one, tools/parity_large.py --algebraic,
+    profiles/r03_parity_cube73_config5_size_gamg.json; N = 64 and N = 80
     bracket it, the latter - 13 M DOF - by tools/parity_large.py).  One
     fieldsplit PCApply and one PCD apply against the oracle."""
     monkeypatch.setenv("FENAPACK_AMD_MAX_CELLS", "2000000")
-    pb = Cavity3D(4, nu=0.01, n0=4)
+    try:
+        pb = Cavity3D(4, nu=0.01, n0=4)
+    except MemoryError as ex:     # (the producer's own estimate: ~75 GB host)
+        pytest.skip("host memory: %s" % ex)
     assert pb.space.ndof == 6714692
     # (one nonlinear step: the suite's time budget; the second, convective one
     # at this size is tools/parity_large.py's: profiles/r03_i_parity_cube64.json,

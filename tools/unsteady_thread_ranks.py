@@ -44,6 +44,9 @@ def solve(comm):
 
 
 for R in ranks:
+    # every rank thread builds the whole problem: the producer's memory check
+    # (fem/multigrid._check_size) must count all of them
+    os.environ["FENAPACK_AMD_CONCURRENT_BUILDS"] = str(R)
     t0 = time.time()
     if R == 1:
         res = [solve(None)]
