@@ -433,3 +433,28 @@ def test_blas_pools_are_capped_but_never_resized_under_thread_binding(
         lim.restore_original_limits()
     assert [d["num_threads"] for d in threadpoolctl.threadpool_info()
             if d["user_api"] == "blas"] == before
+
+
+def test_producer_refuses_builds_beyond_the_host_memory(monkeypatch):
+    """fem/multigrid._check_size: a mistyped level - or R rank threads each
+    building a 10 M-DOF problem - fails with a message instead of driving the
+    host out of memory."""
+    from fenapack_amd.fem import multigrid as mg
+    from fenapack_amd.fem import Cavity3D
+    have = mg.host_memory_available()
+    assert have is None or have > 0
+    monkeypatch.setattr(mg, "host_memory_available", lambda: 64e9)
+    monkeypatch.setenv("FENAPACK_AMD_MAX_CELLS", "3000000")
+    mg._check_size(6 * 36 ** 3, 3, "cube N = 36")              # 13 GB: fine
+    with pytest.raises(MemoryError, match="concurrent build"):
+        mg._check_size(6 * 73 ** 3, 3, "cube N = 73")          # 112 GB
+    monkeypatch.setenv("FENAPACK_AMD_CONCURRENT_BUILDS", "8")
+    with pytest.raises(MemoryError, match="8 concurrent"):
+        mg._check_size(6 * 36 ** 3, 3, "cube N = 36 on 8 rank threads")
+    monkeypatch.setenv("FENAPACK_AMD_IGNORE_MEMORY", "1")
+    mg._check_size(6 * 73 ** 3, 3, "cube N = 73")
+    monkeypatch.delenv("FENAPACK_AMD_IGNORE_MEMORY")
+    monkeypatch.delenv("FENAPACK_AMD_CONCURRENT_BUILDS")
+    monkeypatch.delenv("FENAPACK_AMD_MAX_CELLS")
+    with pytest.raises(ValueError, match="FENAPACK_AMD_MAX_CELLS"):
+        Cavity3D(5, nu=0.01, n0=4)                 # the cell limit comes first
