@@ -458,3 +458,58 @@ def test_producer_refuses_builds_beyond_the_host_memory(monkeypatch):
     monkeypatch.delenv("FENAPACK_AMD_MAX_CELLS")
     with pytest.raises(ValueError, match="FENAPACK_AMD_MAX_CELLS"):
         Cavity3D(5, nu=0.01, n0=4)                 # the cell limit comes first
+
+
+def test_rank_local_row_slices_of_the_python_mirror():
+    """field_split._local_rows / petsc.DeviceMat in the rank-local mode: the
+    rows, and the positions of their values in the caller's arrays, that go to
+    pcd_set_system_local / pcd_set_csr_local / pcd_update_*.  (The engine side
+    runs on thread ranks in -m gpu; this is the host logic alone.)"""
+    from fenapack_amd import _cabi as c
+    from fenapack_amd.field_split import PCDKSP as KSPcls
+    from fenapack_amd.petsc import DeviceMat
+    rng = np.random.default_rng(2)
+    nu, npr = 14, 5
+    n = nu + npr
+    perm = rng.permutation(n)
+    is_u, is_p = np.sort(perm[:nu]), np.sort(perm[nu:])
+    A = sp.random(n, n, density=0.4, format="csr", random_state=4)
+    A.sort_indices()
+
+    class FakeEngine(object):
+        local_handover = True
+
+        def __init__(self):
+            self.calls = []
+
+        def row_range(self, n_global, velocity=False):
+            return (4, 10) if velocity else (2, n_global)
+
+        def set_csr_local(self, which, rows, shape):
+            self.calls.append(("set_csr_local", which, rows.copy(), shape))
+
+        def update_values(self, which, vals):
+            self.calls.append(("update_values", which, np.array(vals)))
+
+    class IS_(object):
+        def __init__(self, idx):
+            self.indices = idx
+    ksp = KSPcls.__new__(KSPcls)
+    ksp.engine = FakeEngine()
+    rows, pos = ksp._local_rows(Mat(A), IS_(is_u), IS_(is_p))
+    assert np.array_equal(rows, np.concatenate([is_u[4:10], is_p[2:]]))
+    assert np.array_equal(A.data[pos], A[rows].data)
+    # a refresh reads the same positions of the re-assembled values
+    A2 = A.copy()
+    A2.data = A2.data * 3.0
+    assert np.array_equal(A2.data[pos], A2[rows].data)
+    # operators of the pressure space: rows [2, n_p) and their values
+    Mp = sp.random(npr, npr, density=0.6, format="csr", random_state=5)
+    Mp.sort_indices()
+    eng = FakeEngine()
+    M = DeviceMat(eng, c.MAT_MP, Mp)
+    name, which, got, shape = eng.calls[0]
+    assert name == "set_csr_local" and which == c.MAT_MP and shape == Mp.shape
+    assert (got != Mp[2:]).nnz == 0
+    M.update(Mp * 2.0)
+    assert np.array_equal(eng.calls[1][2], (Mp * 2.0).tocsr()[2:].data)
