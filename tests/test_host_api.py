@@ -513,3 +513,98 @@ def test_rank_local_row_slices_of_the_python_mirror():
     assert (got != Mp[2:]).nnz == 0
     M.update(Mp * 2.0)
     assert np.array_equal(eng.calls[1][2], (Mp * 2.0).tocsr()[2:].data)
+
+
+def test_rank_local_multigrid_push_of_the_python_mirror(monkeypatch):
+    """petsc._push_multigrid in the rank-local mode: partitioned levels go to
+    pcd_mg_set_level_local as this rank's rows of A, P and (when the level
+    below is partitioned too) P^T; levels of at most PCD_REPLICATE_BELOW rows
+    go over whole; value refreshes carry the rank's values."""
+    from fenapack_amd import _cabi as c
+    from fenapack_amd.fem import Cavity
+    from fenapack_amd.fem.multigrid import galerkin_chain
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "700")
+    pb = Cavity(3, nu=0.01)
+    V = pb.space
+    A00 = sp.csr_matrix(pb.linearise(*pb.initial_guess())["A00"])
+    chain = pb.interpolations().chain("u")
+    ops = galerkin_chain(A00, chain)
+
+    class Lib(object):
+        hip = False                              # (no composed levels here)
+
+    class FakeEngine(object):
+        local_handover = True
+        velocity_block = 2
+        L = Lib()
+
+        def __init__(self):
+            self.calls = []
+
+        def row_range(self, n_global, velocity=False):
+            cut = n_global // 2
+            cut -= cut % 2 if velocity else 0
+            return (cut, n_global)               # rank 1 of 2
+
+        def __getattr__(self, name):
+            def record(*a, **k):
+                self.calls.append((name,) + a)
+            return record
+    eng = FakeEngine()
+    PETScOptions.clear()
+    k = KSP()
+    k.setType("richardson")
+    k.pc.setType("mg")
+    k.setOperators(Mat(A00))
+    k.pc.setMGInterpolations(chain)
+    k.bind(eng, c.KSP_A00)
+    k.setUp()
+    # (the KSP cuts the chain at the largest level whose explicit inverse stays
+    # small: what it handed over is in pc.mg_data)
+    ops, chain = k.pc.mg_data["ops"], k.pc.mg_data["chain"]
+    sizes = [o.shape[0] for o in ops]
+    assert max(sizes[:-1]) > 700 or len(sizes) == 2
+    Lv = len(ops)
+    by = {}
+    for call in eng.calls:
+        by.setdefault(call[0], []).append(call[1:])
+    assert by["mg_begin"][0][:2] == (c.KSP_A00, Lv)
+    local = {a[1]: a for a in by["mg_set_level_local"]}
+    whole = {a[1]: a for a in by["mg_set_level"]}
+    for l in range(1, Lv):
+        n = sizes[l]
+        part = l == Lv - 1 or n > 700
+        assert (l in local) == part and (l in whole) == (not part)
+        if not part:
+            continue
+        slot, lev, ng, A_rows, P_rows, R_rows, emin, emax = local[l]
+        r0, r1 = eng.row_range(n, velocity=True)
+        assert ng == n and 0 < emin < emax
+        assert (A_rows is None) == (l == Lv - 1)
+        if A_rows is not None:
+            assert (A_rows != ops[l][r0:r1]).nnz == 0
+        assert (P_rows != sp.csr_matrix(chain[l])[r0:r1]).nnz == 0
+        if sizes[l - 1] > 700:
+            c0, c1 = eng.row_range(sizes[l - 1], velocity=True)
+            assert (R_rows != sp.csr_matrix(chain[l].T)[c0:c1]).nnz == 0
+        else:
+            assert R_rows is None
+    assert 0 in whole                            # the coarse inverse, whole
+    # a value refresh: same pattern, the rank's values of partitioned levels
+    eng.calls.clear()
+    A2 = A00.copy()
+    A2.data = A2.data * 2.0
+    k.setOperators(Mat(A2))
+    k.setUp()
+    ops2 = k.pc.mg_data["ops"]
+    upd = {a[1]: a for a in eng.calls if a[0] == "mg_update_values"
+           for a in [a[1:]]}
+    for l in range(1, Lv - 1):
+        vals = upd[l][2]
+        if sizes[l] > 700:
+            r0, r1 = eng.row_range(sizes[l], velocity=True)
+            assert np.array_equal(vals, ops2[l][r0:r1].data)
+        else:
+            assert np.array_equal(vals, ops2[l].data)
+    assert upd[Lv - 1][2] is None                # finest level: bounds only
+    PETScOptions.clear()
