@@ -238,3 +238,27 @@ def test_multigrid_pipeline_on_the_scalar_factor_equals_the_block_one():
     # the Newton block couples the components: no scalar factor
     N = V.assemble_A00(0.01, U=np.ones((V.nn, 2)), newton=True)
     assert H.kron_factor(N, 2) is None
+
+
+def test_new_helpers_validate_their_arguments():
+    F = sp.identity(6, format="csr")
+    with pytest.raises(H.HostError, match="spmm"):
+        H.SpMV(F, None, nvec=9)(np.zeros(54))          # at most 8 vectors
+    # unsorted column indices are sorted on the way in, the answer is the same
+    A = H.kron_expand(sp.random(40, 30, density=0.2, format="csr",
+                                random_state=7), 2)
+    B = sp.csr_matrix((A.data[::-1].copy(), A.indices[::-1].copy(),
+                       A.indptr), shape=A.shape)       # rows reversed inside
+    B2 = sp.csr_matrix(B)
+    B2.sort_indices()
+    G1, G2 = H.kron_factor(B, 2), H.kron_factor(B2, 2)
+    assert (G1 is None) == (G2 is None)
+    if G1 is not None:
+        assert (G1 != G2).nnz == 0
+    assert H.kron_expand(F, 1) is not None and H.kron_factor(F, 1) is None
+    # empty operators
+    E = sp.csr_matrix((4, 6))
+    assert H.kron_expand(E, 3).shape == (12, 18)
+    assert np.array_equal(H.gather_sum(np.zeros(1, dtype=np.int64),
+                                       np.zeros(0, dtype=np.int64),
+                                       np.zeros(0)), np.zeros(0))
