@@ -119,6 +119,9 @@ def launch_ranks(args):
     env.setdefault("MASTER_PORT", str(free_port()))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    # every child's producer guard (fem/multigrid._check_size) and resident-set
+    # watchdog (_guard) count N builds sharing this host's memory
+    env["FENAPACK_AMD_CONCURRENT_BUILDS"] = str(n)
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(n):
@@ -218,6 +221,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (start it as `python "
                          "bench.py --gpus N`, or through torch.distributed."
                          "run with --nproc-per-node N)" % (args.gpus, world))
+    # resident-set watchdog (native thread): this rank ends itself with status
+    # 97 above its share - 1 / LOCAL_WORLD_SIZE - of half the host memory
+    from fenapack_amd import _guard
+    os.environ.setdefault("FENAPACK_AMD_CONCURRENT_BUILDS", str(
+        int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    _guard.start_rss_watchdog(what="bench.py rank %d" % rank)
     if args.stub_step:
         return stub_main(args, json_out, rank, world)
     if world > 1:
@@ -545,6 +554,9 @@ def main():
             out["picard_step"] = picard_step_times(pb, w, nls, ksp, c)
         except Exception as exc:                  # never lose the bench line
             out["picard_step"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    out["host_peak_rss_gb"] = round(_guard.peak_rss_bytes() / 1e9, 2)
+    out["host_rss_watchdog_limit_gb"] = None if not _guard._WATCHDOG["limit"] \
+        else round(_guard._WATCHDOG["limit"] / 1e9, 1)
     if rank == 0:
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()

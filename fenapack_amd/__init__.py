@@ -19,7 +19,13 @@ from fenapack_amd.preconditioners import (PCDPC_BRM1, PCDPC_BRM2,
 from fenapack_amd.stabilization import StabilizationParameterSD
 from fenapack_amd.petsc import PETScOptions
 from fenapack_amd.timing import Timer, timed, timings, list_timings
+from fenapack_amd import _guard
 
+# bench.py, tools/*, demo/* and the test suite run under the resident-set
+# watchdog (a host application that imports this package does not, unless it
+# sets FENAPACK_AMD_WATCHDOG=1): two GPU boxes were lost to host allocations
+# of this repository's own scripts
+_guard.autostart()
 
 
 def limit_blas_threads(n=None):
@@ -32,7 +38,8 @@ def limit_blas_threads(n=None):
     them: measured on a 2 x 64-core EPYC 9575F, the level-6 bench set-up takes
     4.8 s at the default and 2.9 s with 8 (or 1) BLAS threads
     (``profiles/r03_setup_by_blas_threads.txt``).  Called once at import with
-    ``FENAPACK_AMD_BLAS_THREADS`` (default 8; 0 = leave the pools alone); an
+    ``FENAPACK_AMD_BLAS_THREADS`` (0 / unset in a host application = leave its
+    pools alone; the scripts of this repository default to 8); an
     ``OPENBLAS_NUM_THREADS`` the user set wins - and is the better route
     (``bench.py`` and ``tests/conftest.py`` set it before numpy is imported):
     resizing a pool at run time makes OpenBLAS start new threads, and threads
@@ -47,7 +54,10 @@ def limit_blas_threads(n=None):
                                            "GOMP_CPU_AFFINITY",
                                            "KMP_AFFINITY")):
             return None
-        n = int(os.environ.get("FENAPACK_AMD_BLAS_THREADS", "8"))
+        # opt-in for a host application (its BLAS pools are its own); the
+        # scripts of this repository (bench.py, tools/, demo/) get 8
+        n = int(os.environ.get("FENAPACK_AMD_BLAS_THREADS",
+                               "8" if _guard.main_script_is_ours() else "0"))
     if n <= 0:
         return None
     try:

@@ -1864,6 +1864,9 @@ static int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const 
   } else {
     h->ru.clear(); h->rp.clear(); h->rs.clear();
     bool u_ops = h->mat[PCD_MAT_A00].set || h->mat[PCD_MAT_A01].set;
+    // a velocity hierarchy pushed before the system (the finest level carries
+    // no operator, so A00 need not be set for it) is in the caller's numbering
+    if (!h->inner[PCD_KSP_A00].mg.empty()) u_ops = true;
     if (h->reorder_mode && !u_ops && n_u > 0) {
       std::vector<int32_t> mu(n, -1), rp, cc; std::vector<int64_t> src;
       for (int64_t i = 0; i < n_u; ++i) mu[is_u[i]] = (int32_t)i;
@@ -2055,6 +2058,8 @@ int pcd_set_system_local(pcd_handle h, int64_t n, int64_t n_u, const int32_t* is
                          const int32_t* rows, const int32_t* rowptr, const int32_t* colidx,
                          const double* vals, const double* pvals) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (nrows_local < 0 || nrows_local > n)
+    return fail(PCD_ERR_ARG, "set_system_local: nrows_local outside [0, n]");
   if (!rows || !rowptr || !vals || !is_u || !is_p || (!colidx && rowptr[nrows_local]))
     return fail(PCD_ERR_ARG, "set_system_local: null argument");
   if (n_u + n_p != n) return fail(PCD_ERR_ARG, "set_system_local: n_u + n_p != n");

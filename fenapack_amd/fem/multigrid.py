@@ -29,34 +29,7 @@ MAX_FINEST_CELLS = {2: 1_000_000, 3: 800_000}
 HOST_BYTES_PER_CELL = {2: 12_000, 3: 48_000}
 
 
-def host_memory_available():
-    """Bytes this process may still allocate: the smaller of the control
-    group's limit (a container usually owns a fraction of the machine that
-    ``free`` shows) and the kernel's MemAvailable; ``None`` when unknown."""
-    cands = []
-    for path in ("/sys/fs/cgroup/memory.max",
-                 "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
-        try:
-            v = open(path).read().strip()
-            if v != "max" and int(v) < (1 << 60):
-                used = 0
-                for u in ("/sys/fs/cgroup/memory.current",
-                          "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
-                    try:
-                        used = int(open(u).read().strip())
-                        break
-                    except (OSError, ValueError):
-                        pass
-                cands.append(int(v) - used)
-        except (OSError, ValueError):
-            pass
-    try:
-        for line in open("/proc/meminfo"):
-            if line.startswith("MemAvailable:"):
-                cands.append(int(line.split()[1]) * 1024)
-    except OSError:
-        pass
-    return min(cands) if cands else None
+from .._guard import host_memory_available, concurrent_builds  # noqa: E402,F401
 
 
 def _check_size(cells, dim, what):
@@ -74,7 +47,7 @@ def _check_size(cells, dim, what):
                          % (what, cells, limit))
     if os.environ.get("FENAPACK_AMD_IGNORE_MEMORY") == "1":
         return
-    builds = max(1, int(os.environ.get("FENAPACK_AMD_CONCURRENT_BUILDS", "1")))
+    builds = concurrent_builds()
     need = float(cells) * HOST_BYTES_PER_CELL[dim] * builds
     have = host_memory_available()
     if have is not None and need > 0.5 * have:

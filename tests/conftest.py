@@ -48,18 +48,42 @@ def pytest_configure(config):
         "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line(
         "markers", "heavy(order): a full-size GPU test (tens of seconds of "
-        "host set-up); runs after the light tests, in `order`, while the "
-        "suite's time budget lasts")
+        "host set-up); runs after the light tests, in `order`; FAILS if the "
+        "suite's time budget is already spent when it would start")
+    config.addinivalue_line(
+        "markers", "rss_gb(x): resident-set growth this test may cause "
+        "(default 8 GB); exceeding it fails the test")
 
 
-# The driver runs `pytest tests -x -q -m gpu` under a wall-clock limit on a box
-# whose host is about 3 x slower than the builder's at problem set-up; a suite
-# that is killed at the limit loses EVERY result.  The full-size tests are
-# therefore marked `heavy`, run after all the light ones in a fixed order of
-# importance, and are SKIPPED (visibly, with the reason) once the session has
-# used FENAPACK_AMD_SUITE_BUDGET_S seconds (default 900).  On the builder's
-# boxes the whole suite takes about 340 s and nothing is skipped.
+# The driver runs `pytest tests -x -q -m gpu` under a wall-clock limit (1200 s)
+# on a box whose host is about 3 x slower than the builder's at problem set-up.
+# The full-size tests are marked `heavy` and run after all the light ones in a
+# fixed order of importance.  Budgets are DECLARED and ENFORCED - a test over
+# budget FAILS, nothing is skipped for lack of time or memory:
+#   * time: a heavy test that would START after FENAPACK_AMD_SUITE_BUDGET_S
+#     (default 1000 s) of session time fails with the reason;
+#   * host memory: the whole session runs under the resident-set watchdog
+#     (fenapack_amd/_guard.py) with the limit FENAPACK_AMD_SUITE_RSS_GB
+#     (default 32 GB; the process ends with status 97 above it), and a test
+#     whose own resident-set growth exceeds its `rss_gb` budget fails.
+# Peak resident set and duration per test are printed as a table at the end
+# and written to $FENAPACK_AMD_RSS_TABLE (default gpurun_out/suite_rss.txt on a
+# GPU box) - the evidence kept under profiles/.
 _SESSION_T0 = time.time()
+_RSS_ROWS = []
+SUITE_RSS_GB = float(os.environ.get("FENAPACK_AMD_SUITE_RSS_GB", "32"))
+#: resident-set budget of one test unless it declares its own
+#: (`@pytest.mark.rss_gb(x)`)
+DEFAULT_TEST_RSS_GB = 8.0
+
+
+def pytest_sessionstart(session):
+    from fenapack_amd import _guard
+    have = _guard.host_memory_available()
+    limit = SUITE_RSS_GB * 1e9
+    if have is not None:
+        limit = min(limit, 0.5 * have)
+    _guard.start_rss_watchdog(limit_bytes=limit, what="pytest")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -70,15 +94,68 @@ def pytest_collection_modifyitems(config, items):
 
 
 @pytest.fixture(autouse=True)
-def _suite_time_budget(request):
-    if request.node.get_closest_marker("heavy") is not None:
-        limit = float(os.environ.get("FENAPACK_AMD_SUITE_BUDGET_S", "900"))
+def _suite_budgets(request):
+    from fenapack_amd import _guard
+    node = request.node
+    if node.get_closest_marker("heavy") is not None:
+        limit = float(os.environ.get("FENAPACK_AMD_SUITE_BUDGET_S", "1000"))
         used = time.time() - _SESSION_T0
         if used > limit:
-            pytest.skip("suite time budget: %.0f s of %.0f s used before this "
-                        "full-size test (run it alone, or raise "
-                        "FENAPACK_AMD_SUITE_BUDGET_S)" % (used, limit))
+            pytest.fail("suite time budget: %.0f s of %.0f s used before this "
+                        "full-size test could start (the suite must fit the "
+                        "driver's 1200 s: make set-up faster)" % (used, limit))
+    import gc
+    gc.collect()
+    r0, t0 = _guard.rss_bytes(), time.time()
+    hw0 = _guard.peak_rss_bytes()
     yield
+    hw1, r1 = _guard.peak_rss_bytes(), _guard.rss_bytes()
+    # the high-water mark is monotone: a test that did not raise it stayed
+    # below the earlier peak; its own growth is bounded by (hw1 - r0)
+    grew = max(0, hw1 - r0) if hw1 > hw0 else max(0, r1 - r0)
+    _RSS_ROWS.append((node.nodeid, time.time() - t0, r0, grew, hw1))
+    m = node.get_closest_marker("rss_gb")
+    budget = (m.args[0] if m is not None else DEFAULT_TEST_RSS_GB) * 1e9
+    if grew > budget:
+        pytest.fail("host-memory budget: this test raised the resident set by "
+                    "%.1f GB (budget %.1f GB, @pytest.mark.rss_gb)"
+                    % (grew / 1e9, budget / 1e9))
+
+
+def _rss_table():
+    lines = ["# peak resident set per test (fenapack_amd._guard; watchdog "
+             "limit %.0f GB)" % SUITE_RSS_GB,
+             "# %8s %9s %9s %9s  test" % ("seconds", "rss0_GB", "grew_GB",
+                                          "peak_GB")]
+    for nodeid, dt, r0, grew, hw in _RSS_ROWS:
+        lines.append("  %8.1f %9.2f %9.2f %9.2f  %s"
+                     % (dt, r0 / 1e9, grew / 1e9, hw / 1e9, nodeid))
+    if _RSS_ROWS:
+        lines.append("# session: %d tests, %.0f s, peak resident set %.2f GB"
+                     % (len(_RSS_ROWS), time.time() - _SESSION_T0,
+                        max(r[4] for r in _RSS_ROWS) / 1e9))
+    return lines
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not _RSS_ROWS or os.environ.get("PYTEST_XDIST_WORKER"):
+        return
+    lines = _rss_table()
+    path = os.environ.get("FENAPACK_AMD_RSS_TABLE")
+    if path is None and _gpus() > 0:
+        path = os.path.join(ROOT, "gpurun_out", "suite_rss.txt")
+    if path:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                f.write("\n".join(lines) + "\n")
+        except OSError:
+            pass
+    top = sorted(_RSS_ROWS, key=lambda r: -r[3])[:8]
+    terminalreporter.write_line(lines[-1])
+    for nodeid, dt, r0, grew, hw in top:
+        terminalreporter.write_line("#   +%.2f GB (peak %.2f GB, %.1f s) %s"
+                                    % (grew / 1e9, hw / 1e9, dt, nodeid))
 
 
 @pytest.fixture(scope="session")

@@ -18,6 +18,10 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fenapack_amd import _guard                                      # noqa: E402
+_guard.start_rss_watchdog()
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
