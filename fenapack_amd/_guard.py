@@ -127,20 +127,20 @@ def watchdog_limit_bytes(processes=1):
 
 
 def _native_watchdog(limit_bytes, interval):
-    """The poller as a native thread of libpcd_host.so (no GIL: a numpy call
+    """The poller as a native thread of libpcd_guard.so (no GIL: a numpy call
     that allocates while holding it cannot starve the watchdog).  False when
     the library is not built yet."""
     import ctypes
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
-                        "libpcd_host.so")
+                        "libpcd_guard.so")
     if not os.path.exists(path):
         return False
     try:
         L = ctypes.CDLL(path)
-        L.pcdh_watchdog_start.argtypes = [ctypes.c_int64, ctypes.c_int,
+        L.pcdg_watchdog_start.argtypes = [ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_int]
-        L.pcdh_watchdog_peak.restype = ctypes.c_int64
-        rc = L.pcdh_watchdog_start(int(limit_bytes),
+        L.pcdg_watchdog_peak.restype = ctypes.c_int64
+        rc = L.pcdg_watchdog_start(int(limit_bytes),
                                    max(1, int(interval * 1000)), WATCHDOG_EXIT)
     except (OSError, AttributeError):
         return False
@@ -154,7 +154,7 @@ def watchdog_peak_bytes():
     """Highest resident set the watchdog has seen (0: not started)."""
     L = _WATCHDOG.get("native")
     if L is not None:
-        return int(L.pcdh_watchdog_peak())
+        return int(L.pcdg_watchdog_peak())
     return max(_WATCHDOG["peak"], rss_bytes()) if _WATCHDOG["thread"] else 0
 
 
@@ -163,8 +163,8 @@ def start_rss_watchdog(limit_bytes=None, processes=None, interval=0.05,
     """Start (once per process) the thread that ends this process with status
     ``WATCHDOG_EXIT`` when its resident set exceeds ``limit_bytes`` (default:
     ``watchdog_limit_bytes``).  Returns the limit in force (None: unknown
-    host, no watchdog).  The thread is native (``pcdh_watchdog_start``) when
-    libpcd_host.so is built, a Python daemon thread otherwise."""
+    host, no watchdog).  The thread is native (``pcdg_watchdog_start``) when
+    libpcd_guard.so is built, a Python daemon thread otherwise."""
     if _WATCHDOG["thread"] is not None:
         return _WATCHDOG["limit"]
     if os.environ.get("FENAPACK_AMD_NO_WATCHDOG") == "1":

@@ -73,11 +73,23 @@ class FlowProblem(object):
 
     def __init__(self, hierarchy, nu, variant="BRM1", nls="picard", dt=None,
                  pcdr=False, stabilize=False, dirichlet_diag="unit",
-                 coarse_stabilize=False):
+                 coarse_stabilize=False, skeleton=False, local_of=None):
+        """``skeleton``: numbering and boundary classification only - no
+        operator is assembled (what every rank of a partitioned build holds
+        of the WHOLE problem).  ``local_of = (G, sub)``: the problem on the
+        sub-space ``sub`` (``partition.SubSpace``: the cells this rank
+        assembles) of the skeleton ``G``; its boundary sets are G's, mapped
+        to the local numbering (``fem/partition.py``)."""
         assert variant in ("BRM1", "BRM2")
         assert nls in ("picard", "newton")
         self.hierarchy = hierarchy
-        self.space = V = TaylorHood(hierarchy.finest)
+        self._init_kw = dict(nu=nu, variant=variant, nls=nls, dt=dt, pcdr=pcdr,
+                             stabilize=stabilize, dirichlet_diag=dirichlet_diag,
+                             coarse_stabilize=coarse_stabilize)
+        if local_of is not None:
+            self.space = V = local_of[1].V
+        else:
+            self.space = V = TaylorHood(hierarchy.finest)
         self.nu = float(nu)
         self.variant = variant
         self.nls = nls
@@ -98,7 +110,13 @@ class FlowProblem(object):
         mult = np.bincount(V.cell_dofs2.ravel(), minlength=V.nn).astype(float)
         self._bc_mult = np.repeat(mult, V.dim) \
             if dirichlet_diag == "multiplicity" else np.ones(V.n_u)
-        self._classify_boundary()
+        if local_of is not None:
+            self._localise_boundary(*local_of)
+        else:
+            self._classify_boundary()
+        self.u0 = np.zeros(V.n_u)
+        if skeleton:
+            return
         self.bc_u = _Dirichlet(V.n_u, self.bc_u_idx)
         self.bc_p = _Dirichlet(V.n_p, self.bc_p_idx)
         # constant operators (assembling.py:98-106: ap, mp, mu, gp constant)
@@ -111,8 +129,21 @@ class FlowProblem(object):
         self._Mmass = None
         if self.idt:
             self._Mmass = V.assemble_Mu(1.0)
-        self.u0 = np.zeros(V.n_u)
         V.interpolations = self.interpolations     # for pc_type mg
+
+    def _localise_boundary(self, G, sub):
+        """Boundary sets of the skeleton ``G`` in the numbering of the
+        sub-space (the sub-mesh's own boundary contains the artificial cut)."""
+        self._bc_nodes = sub.local_nodes(G._bc_nodes)
+        for name in ("_inlet_nodes",):
+            if hasattr(G, name):
+                setattr(self, name, sub.local_nodes(getattr(G, name)))
+        self.bc_u_idx = self._velocity_dofs(self._bc_nodes)
+        keep, self.bc_p_idx = sub.local_pdofs(G.bc_p_idx, with_mask=True)
+        self.bc_p_val = np.asarray(G.bc_p_val)[keep]
+        for name in ("robin_edges", "inlet_edges", "outlet_edges"):
+            if hasattr(G, name):
+                setattr(self, name, sub.local_edges(getattr(G, name)))
 
     def interpolations(self):
         """Prolongation chains for the multigrid inner solves (lazy)."""

@@ -369,7 +369,11 @@ class TaylorHood(object):
     """P2 velocity / P1 pressure spaces on a :class:`Mesh` (d = 2) or a
     :class:`TetMesh` (d = 3)."""
 
-    def __init__(self, mesh):
+    def __init__(self, mesh, axes=None):
+        """``axes``: sort order of the coordinate axes for the numbering
+        (default: longest extent first).  A sub-space of a partitioned build
+        passes the WHOLE domain's order, so that its numbering is the global
+        one restricted (``fem/partition.py``)."""
         self.mesh = mesh
         self.dim = d = mesh.dim
         self.local_edges = tuple(mesh.local_edges)
@@ -380,7 +384,9 @@ class TaylorHood(object):
         self.nn = nn = nv + ne                       # scalar P2 dofs
         coords = np.concatenate([mesh.vertices, mesh.edge_midpoints()])
         ext = coords.max(axis=0) - coords.min(axis=0)
-        axes = list(np.argsort(-ext, kind="stable"))  # longest axis first
+        if axes is None:
+            axes = list(np.argsort(-ext, kind="stable"))  # longest axis first
+        self.axes = axes = [int(a) for a in axes]
         # round so that nodes meant to share a coordinate compare equal
         # whatever sequence of midpoint averages produced them
         key = np.round(coords * 2.0 ** 30)

@@ -38,18 +38,6 @@ const char* pcdh_last_error(void);
 int pcdh_set_threads(int nthreads);
 int pcdh_get_threads(void);
 
-/* ---- resident-set watchdog ----------------------------------------------------
- * A detached native thread (no Python GIL involved: a numpy / scipy call that
- * allocates without releasing the GIL cannot starve it) polls
- * /proc/self/statm every `interval_ms` and ends the process with
- * _exit(exit_code) once the resident set exceeds `limit_bytes`, after one
- * line on stderr.  Started at most once per process; a second call only
- * lowers the limit.  pcdh_watchdog_peak(): highest resident set seen.
- * (fenapack_amd/_guard.py; the reason: profiles/README.md "two lost boxes") */
-int pcdh_watchdog_start(int64_t limit_bytes, int interval_ms, int exit_code);
-int64_t pcdh_watchdog_peak(void);
-int64_t pcdh_watchdog_limit(void);
-
 /* ---- grouping of (row, col) pairs -------------------------------------------
  * The one primitive behind every pattern of the producer: n pairs with
  * 0 <= rows[i] < nrows and cols[i] >= 0 are grouped by (row, col), groups

@@ -110,6 +110,15 @@ def _suite_budgets(request):
     hw0 = _guard.peak_rss_bytes()
     yield
     hw1, r1 = _guard.peak_rss_bytes(), _guard.rss_bytes()
+    if r1 - r0 > 1 << 30:
+        # give a large test's memory back to the system, so that the next
+        # one starts low and the session's peak is the largest TEST
+        gc.collect()
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6").malloc_trim(0)
+        except (OSError, AttributeError):
+            pass
     # the high-water mark is monotone: a test that did not raise it stayed
     # below the earlier peak; its own growth is bounded by (hw1 - r0)
     grew = max(0, hw1 - r0) if hw1 > hw0 else max(0, r1 - r0)

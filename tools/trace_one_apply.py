@@ -7,6 +7,10 @@ import glob
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fenapack_amd import _guard                                      # noqa: E402
+_guard.start_rss_watchdog()
+
 root = sys.argv[1]
 f = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
