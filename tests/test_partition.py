@@ -1,0 +1,197 @@
+"""CPU suite: the partitioned operator producer (fenapack_amd/fem/partition.py)
+against the global build - every rank assembles its rows only, and those rows
+are BITWISE the rows of the global build (same cells in the same order, same
+element matrices).  What the reference gets from DOLFIN's partitioned assembly
+(fenapack/_field_split_utils.py:39-50, fenapack/SubfieldBC.h:136-155)."""
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
+from fenapack_amd.fem import partition as pt
+
+CASES = {
+    "cube16": (Cavity3D, dict(level=2, nu=0.01, n0=4)),
+    "cavity4": (Cavity, dict(level=4, nu=0.01)),
+    "lshape3_brm2": (BackwardStep, dict(level=3, nu=0.02, variant="BRM2")),
+}
+_GLOBAL = {}
+
+
+def global_build(name):
+    if name not in _GLOBAL:
+        cls, kw = CASES[name]
+        kw = dict(kw)
+        pb = cls(kw.pop("level"), **kw)
+        rng = np.random.default_rng(3)
+        V = pb.space
+        xu = 0.1 * rng.standard_normal(V.n_u)
+        xp = 0.1 * rng.standard_normal(V.n_p)
+        lin = pb.linearise(xu, xp)
+        _GLOBAL[name] = dict(pb=pb, xu=xu, xp=xp, lin=lin, Kp=pb.Kp(xu),
+                             interp=pb.interpolations())
+    return _GLOBAL[name]
+
+
+def rows_equal(M_part, M_glob, own):
+    """Owned rows bitwise equal; every other row of the partitioned matrix
+    empty."""
+    A, B = sp.csr_matrix(M_part), sp.csr_matrix(M_glob)
+    assert A.shape == B.shape
+    r0, r1 = own
+    a, b = A[r0:r1], B[r0:r1]
+    assert np.array_equal(a.indptr, b.indptr)
+    assert np.array_equal(a.indices, b.indices)
+    assert np.array_equal(a.data, b.data)          # bitwise
+    assert A.nnz == a.nnz, "rows outside the owned range are populated"
+
+
+def test_cut_is_the_engine_s_rule():
+    # pcd_dist.hpp Space::cut
+    assert pt.cut(10, 3) == [0, 3, 6, 10]
+    assert pt.cut(14, 4, 2) == [0, 2, 6, 10, 14]
+    assert pt.cut(9529569, 8, 3)[1] % 3 == 0
+    for n, R, b in ((1000, 7, 3), (12, 8, 2), (5, 8, 1)):
+        c = pt.cut(n - n % b, R, b)
+        assert c[0] == 0 and c[-1] == n - n % b and sorted(c) == c
+
+
+@pytest.mark.parametrize("name,R", [("cube16", 2), ("cube16", 3),
+                                    ("cube16", 8), ("cavity4", 2),
+                                    ("cavity4", 3), ("cavity4", 8),
+                                    ("lshape3_brm2", 3)])
+def test_owned_rows_are_bitwise_the_global_build(name, R):
+    g = global_build(name)
+    pb, lin = g["pb"], g["lin"]
+    V = pb.space
+    cls, kw = CASES[name]
+    seen_u = np.zeros(V.n_u, dtype=int)
+    for r in range(R):
+        pp = pt.partitioned(cls, r, R, **kw)
+        f = pp.fine
+        assert pp.space.ndof == V.ndof
+        # the local space is a fraction of the mesh (slab + halo layer)
+        if R >= 3 and name != "lshape3_brm2":
+            assert f.sub.cells.size < 0.75 * V.mesh.num_cells
+        seen_u[f.own_u[0]:f.own_u[1]] += 1
+        L = pp.linearise(g["xu"], g["xp"])
+        rows_equal(L["A00"], lin["A00"], f.own_u)
+        rows_equal(L["A01"], lin["A01"], f.own_u)
+        rows_equal(L["A10"], lin["A10"], f.own_p)
+        rows_equal(pp.Ap, pb.Ap, f.own_p)
+        rows_equal(pp.Mp, pb.Mp, f.own_p)
+        rows_equal(pp.Kp(g["xu"]), g["Kp"], f.own_p)
+        for k, own in (("bu", f.own_u), ("bp", f.own_p)):
+            assert np.array_equal(L[k][own[0]:own[1]], lin[k][own[0]:own[1]])
+            rest = np.ones(L[k].size, bool)
+            rest[own[0]:own[1]] = False
+            assert not L[k][rest].any()
+        # boundary sets are the global ones
+        assert np.array_equal(pp.bc_u_idx, pb.bc_u_idx)
+        assert np.array_equal(pp.bc_p_idx, pb.bc_p_idx)
+        assert np.array_equal(pp.bc_u_values(0.0), pb.bc_u_values(0.0))
+        # the finest prolongation: owned rows bitwise, and the restriction
+        # rows of the owned coarse dofs complete
+        Pg_u, Pg_p = g["interp"].velocity[-1], g["interp"].pressure[-1]
+        I = pp.interpolations()
+        Pu, Pp = sp.csr_matrix(I.velocity[-1]), sp.csr_matrix(I.pressure[-1])
+        for P, Pg, own in ((Pu, Pg_u, f.own_u), (Pp, Pg_p, f.own_p)):
+            a, b = P[own[0]:own[1]], sp.csr_matrix(Pg)[own[0]:own[1]]
+            assert np.array_equal(a.indptr, b.indptr)
+            assert np.array_equal(a.indices, b.indices)
+            assert np.array_equal(a.data, b.data)
+        if Pg_u.shape[1] > pt.replicate_below():
+            c = pt.cut(Pg_u.shape[1], R, V.dim)
+            Rt = sp.csr_matrix(Pu.T)[c[r]:c[r + 1]]
+            Rg = sp.csr_matrix(Pg_u.T)[c[r]:c[r + 1]]
+            Rt.sort_indices(), Rg.sort_indices()
+            assert np.array_equal(Rt.indices, Rg.indices)
+            assert np.array_equal(Rt.data, Rg.data)
+        # the coarser prolongations are built whole
+        for l in range(1, len(I.velocity) - 1):
+            assert (sp.csr_matrix(I.velocity[l])
+                    != sp.csr_matrix(g["interp"].velocity[l])).nnz == 0
+    assert np.all(seen_u == 1)                 # the cuts partition the rows
+
+
+def test_restriction_rows_when_the_coarse_level_is_partitioned(monkeypatch):
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "500")
+    g = global_build("cavity4")
+    cls, kw = CASES["cavity4"]
+    V, R = g["pb"].space, 3
+    Pg_u = sp.csr_matrix(g["interp"].velocity[-1])
+    for r in range(R):
+        pp = pt.partitioned(cls, r, R, **kw)
+        Pu = sp.csr_matrix(pp.interpolations().velocity[-1])
+        c = pt.cut(Pg_u.shape[1], R, V.dim)
+        Rt, Rg = sp.csr_matrix(Pu.T)[c[r]:c[r + 1]], \
+            sp.csr_matrix(Pg_u.T)[c[r]:c[r + 1]]
+        Rt.sort_indices(), Rg.sort_indices()
+        assert np.array_equal(Rt.indptr, Rg.indptr)
+        assert np.array_equal(Rt.indices, Rg.indices)
+        assert np.array_equal(Rt.data, Rg.data)
+
+
+def test_rediscretised_coarse_operators_by_rows(monkeypatch):
+    """-pc_mg_galerkin none: every level assembled from the injected iterate,
+    partitioned levels as owned rows, small ones whole - no communication."""
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "2000")
+    g = global_build("cavity4")
+    pb, xu = g["pb"], g["xu"]
+    cls, kw = CASES["cavity4"]
+    ops_g = pb.coarse_velocity_operators(xu, 4)
+    R = 2
+    for r in range(R):
+        pp = pt.partitioned(cls, r, R, **kw)
+        ops = pp.coarse_velocity_operators(xu, 4)
+        assert len(ops) == len(ops_g) == 3
+        for A, Ag in zip(ops, ops_g):
+            n = Ag.shape[0]
+            if n > 2000:
+                c = pt.cut(n, R, 2)
+                rows_equal(A, Ag, (c[r], c[r + 1]))
+            else:
+                assert (sp.csr_matrix(A) != sp.csr_matrix(Ag)).nnz == 0
+
+
+def test_thread_host_comm_reductions():
+    R = 4
+    comms = pt.ThreadHostComm.group(R)
+    out = [None] * R
+
+    def body(r):
+        v = np.zeros(8)
+        v[2 * r:2 * r + 2] = r + 1.0
+        out[r] = (comms[r].allgather(r * r), comms[r].sum(v),
+                  comms[r].sum(float(r)), comms[r].max(r))
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+    [t.start() for t in th]
+    [t.join(60) for t in th]
+    for r in range(R):
+        assert out[r][0] == [0, 1, 4, 9]
+        assert np.array_equal(out[r][1], np.repeat([1.0, 2, 3, 4], 2))
+        assert out[r][2] == 6.0 and out[r][3] == 3
+    assert pt.HostComm().sum(2.5) == 2.5
+
+
+def test_partitioned_norm_is_the_global_norm():
+    g = global_build("cavity4")
+    cls, kw = CASES["cavity4"]
+    R = 3
+    comms = pt.ThreadHostComm.group(R)
+    b = g["lin"]["bu"]
+    got = [None] * R
+
+    def body(r):
+        pp = pt.partitioned(cls, r, R, host=comms[r], **kw)
+        L = pp.linearise(g["xu"], g["xp"])
+        got[r] = pp.norm(L["bu"])
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert len(set(got)) == 1
+    assert abs(got[0] - np.linalg.norm(b)) < 1e-12 * np.linalg.norm(b)
