@@ -86,6 +86,9 @@ def make_solver(problem, prefix="", gmres_rtol=1e-6, restart=150,
     w, forms = navier_stokes_forms(problem)
     assembler = PCDAssembler(**forms)
     nlp = PCDNonlinearProblem(assembler)
+    if getattr(problem, "partitioned", False):
+        # this rank's rows only (fem/partition.py): residual norms reduce
+        nlp.norm = problem.norm
     linear_solver = PCDKrylovSolver(comm=comm, device=device)
     if prefix:
         linear_solver.set_options_prefix(prefix)

@@ -187,10 +187,14 @@ class Interpolations(object):
         return [None] + full[len(full) - nlevels + 1:]
 
 
-def galerkin_chain(A, chain):
+def galerkin_chain(A, chain, reduce=None):
     """Coarse operators ``A_{l-1} = P_l^T A_l P_l``; returns the list of
     operators, coarsest first (``ops[-1] is A``).  Large products run on the
-    threaded native SpGEMM (same sums in the same order as scipy's)."""
+    threaded native SpGEMM (same sums in the same order as scipy's).
+    ``reduce``: ``A`` holds one rank's rows only (partitioned producer): every
+    product is that rank's contribution and ``reduce`` sums them over the
+    ranks (the coarse levels are then whole on every rank; the caller makes
+    sure they are small enough to be replicated)."""
     ops = [None] * len(chain)
     ops[-1] = sp.csr_matrix(A)
     for l in range(len(chain) - 1, 0, -1):
@@ -199,6 +203,11 @@ def galerkin_chain(A, chain):
             C = _host.spgemm(_host.spgemm(_host.transpose(P), ops[l]), P)
         else:
             C = (P.T @ ops[l] @ P).tocsr()
+            C.sort_indices()
+        if reduce is not None and l == len(chain) - 1:
+            # (only the finest operator is one rank's rows; what comes out of
+            # the reduction is whole, and so is everything below it)
+            C = sp.csr_matrix(reduce(C))
             C.sort_indices()
         ops[l - 1] = C
     return ops

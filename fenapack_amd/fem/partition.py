@@ -127,7 +127,7 @@ class TorchHostComm(HostComm):
         return out
 
     def sum(self, a):
-        if np.isscalar(a):
+        if not isinstance(a, np.ndarray):       # scalars, sparse matrices
             return HostComm.sum(self, a)
         import torch
         t = torch.from_numpy(np.ascontiguousarray(a).copy())
@@ -325,6 +325,7 @@ class PartitionedProblem(object):
         self.fine = self._make_level(G, partitioned=True)
         self._levels = {}
         V.interpolations = self.interpolations
+        V.partitioned_producer = self
 
     # -- levels --------------------------------------------------------------
     def _make_level(self, G, partitioned):

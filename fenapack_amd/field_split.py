@@ -101,6 +101,11 @@ class PCDKSP(KSP):
             self.engine.comm_init(self.comm.rank, self.comm.size,
                                   self.comm.unique_id())
             self._has_comm = True
+        # a partitioned producer (fem/partition.py): this rank's rows are all
+        # there is - rank-local hand-over, and the few host-side reductions of
+        # the set-up (smoother bounds, the coarse A_p) go through its HostComm
+        self._partitioned = bool(getattr(V, "partitioned_producer", None))
+        self.engine.producer = getattr(V, "partitioned_producer", None)
         A, P = self.getOperators()
         with Timer("FENaPack: {} setup".format(ksp0.getOptionsPrefix() or "")):
             self._upload_system(A, P, is0, is1, first=True)
@@ -158,8 +163,12 @@ class PCDKSP(KSP):
         import os
         pmat = None if (P is None or P is A or not P.isAssembled()) else P
         if first:
-            local = os.environ.get("FENAPACK_AMD_LOCAL_HANDOVER") == "1" \
+            local = (os.environ.get("FENAPACK_AMD_LOCAL_HANDOVER") == "1"
+                     or getattr(self, "_partitioned", False)) \
                 and getattr(self, "_has_comm", False)
+            if getattr(self, "_partitioned", False) and not local:
+                raise RuntimeError("a partitioned producer needs a "
+                                   "communicator (PCDKrylovSolver(comm=...))")
             if local:
                 # the engine sees this rank's rows only (pcd_set_system_local;
                 # the matrix a partitioned assembly would hold) - the host-

@@ -72,8 +72,11 @@ class PCDNewtonSolver(object):
         self.krylov_history, self.residual_history = [], []
         n = x.size
         b, dx = np.zeros(n), np.zeros(n)
+        # a partitioned producer fills the owned entries of b only: its norm
+        # reduces over the ranks (PETSc's VecNorm on a distributed Vec)
+        norm = getattr(problem, "norm", None) or np.linalg.norm
         problem.F(b, x)
-        r0 = r = float(np.linalg.norm(b))
+        r0 = r = float(norm(b))
         self.residual_history.append(r)
         # a zero first residual is a solved problem (never 0/0 below)
         it, converged = 0, (r < prm["absolute_tolerance"] or r == 0.0)
@@ -92,7 +95,7 @@ class PCDNewtonSolver(object):
             if not final_residual and it >= prm["maximum_iterations"]:
                 break
             problem.F(b, x)
-            r = float(np.linalg.norm(b))
+            r = float(norm(b))
             self.residual_history.append(r)
             converged = (r < prm["absolute_tolerance"] or r == 0.0
                          or r / r0 < prm["relative_tolerance"])

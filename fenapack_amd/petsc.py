@@ -8,6 +8,8 @@ protocol (``create/setFromOptions/setUp/apply``) and can be handed to
 ``pc.setPythonContext`` unchanged.
 """
 
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -550,8 +552,10 @@ class KSP(object):
         A = self._ops[1].A
         if not hasattr(self, "_cheb_warm"):
             self._cheb_warm = {}
+        prod = _producer(self.engine)
         emax = estimate_emax(A, jacobi=(self.pc.type == "jacobi"),
-                             warm=self._cheb_warm)
+                             warm=self._cheb_warm,
+                             reduce=None if prod is None else prod.host.sum)
         a, b, cc, d = self.cheb_esteig
         return (b * emax, d * emax)        # emin estimate taken as 0
 
@@ -606,6 +610,12 @@ class KSP(object):
             if self.slot == c.KSP_A00 else 1
         A = self._ops[1].A
         chain_s = ops_s = None
+        # partitioned producer: operators of partitioned levels hold this
+        # rank's rows only (fem/partition.py) - reductions through its HostComm
+        prod = _producer(self.engine)
+        rep_limit = int(os.environ.get("PCD_REPLICATE_BELOW", "60000"))
+        rowsparse = lambda l, n: prod is not None and (
+            l == len(chain) - 1 or n > rep_limit)
         if blk > 1:
             facs = [_scalar_of(P) for P in chain[1:]]
             if all(f is not None and f[1] == blk for f in facs):
@@ -613,7 +623,21 @@ class KSP(object):
                 if F is not None:
                     chain_s = [None] + [f[0] for f in facs]
         if pc.mg_galerkin:
-            if chain_s is not None:
+            red = None
+            if prod is not None:
+                if any(chain[l].shape[1] > rep_limit
+                       for l in range(1, len(chain))):
+                    raise RuntimeError(
+                        "%spc_type mg with a partitioned producer: a level "
+                        "below the finest one is partitioned too - Galerkin "
+                        "products of partitioned levels need rows of other "
+                        "ranks; use pc_mg_galerkin none (re-discretised coarse "
+                        "operators, PETSc's PCMG default)" % self._prefix)
+                red = prod.host.sum       # replicated coarse levels: the sum
+                #                           of the ranks' contributions P^T A_r P
+            if red is not None:
+                ops = galerkin_chain(A, chain, reduce=red)
+            elif chain_s is not None:
                 ops_s = galerkin_chain(F, chain_s)
                 ops = [_host.kron_expand(o, blk) for o in ops_s[:-1]] \
                     + [sp.csr_matrix(A)]
@@ -636,12 +660,15 @@ class KSP(object):
         if not hasattr(pc, "_mg_warm"):
             pc._mg_warm = {}
         for l in range(1, len(ops)):
+            red = prod.host.sum if rowsparse(l, ops[l].shape[0]) else None
             if ops_s is not None:
                 emax = estimate_emax(ops_s[l], iters=12, block=blk,
-                                     warm=pc._mg_warm.setdefault(l, {}))
+                                     warm=pc._mg_warm.setdefault(l, {}),
+                                     reduce=red)
             else:
                 emax = estimate_emax(ops[l], iters=12,
-                                     warm=pc._mg_warm.setdefault(l, {}))
+                                     warm=pc._mg_warm.setdefault(l, {}),
+                                     reduce=red)
             bounds.append((b * emax, d * emax))
         if ops[0].shape[0] > 30000:
             # (an explicit inverse of that size is tens of GB - e.g. a smoothed-
@@ -667,7 +694,6 @@ class KSP(object):
             # partitioned levels go over as this rank's rows (the rule of
             # pcd_mg_set_level: more than PCD_REPLICATE_BELOW rows, and the
             # finest level always); replicated ones whole
-            import os
             limit = int(os.environ.get("PCD_REPLICATE_BELOW", "60000"))
             vel = slot == c.KSP_A00
             part = [l == L - 1 or ops[l].shape[0] > limit for l in range(L)]
@@ -716,8 +742,13 @@ class KSP(object):
         if not getattr(eng.L, "hip", False) or pc.mg_fuse_nnz <= 0 \
                 or nu_pre < 1 or nu_post < 1:
             return
+        prod = _producer(eng)
+        rep_limit = int(os.environ.get("PCD_REPLICATE_BELOW", "60000"))
         for l in range(1, len(ops)):
             A = ops[l]
+            if prod is not None and (l == len(ops) - 1
+                                     or A.shape[0] > rep_limit):
+                break       # this rank's rows only: nothing to compose from
             grow = 3 if nu_post == 1 else 6     # nnz(W_u) / nnz(A), at least
             if A.shape[0] // blk > pc.mg_fuse_rows \
                     or grow * (A.nnz // blk) > pc.mg_fuse_nnz:
@@ -798,14 +829,18 @@ class KSP(object):
         self.engine.inner_solve(self.slot, b.t, x.t, c.MEM_DEVICE)
 
 
-def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None, block=1):
+def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None, block=1,
+                  reduce=None):
     """Largest eigenvalue (modulus) of ``D^-1 A`` by power iteration on the
     host - the stand-in for PETSc's ``-ksp_chebyshev_esteig`` [ext PETSc].
     ``warm``: a dict that carries the iterate between calls (re-estimation
     after a value refresh then needs only a few steps).  ``block`` > 1: ``A``
     is the scalar factor of ``A (x) I_block``; the iteration is the expanded
     operator's (same start vector, same sums) on ``block`` interleaved
-    vectors at once."""
+    vectors at once.  ``reduce``: ``A`` holds this rank's rows only (a
+    partitioned producer: global shape, other rows empty); the product is
+    completed by ``reduce`` (sum over ranks of vectors with disjoint
+    supports - exact), so every rank iterates on the same global vector."""
     A = sp.csr_matrix(A)
     n = A.shape[0] * block
     d = A.diagonal().copy()
@@ -828,6 +863,9 @@ def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None, block=1):
         apply = lambda u: dinv * (A @ u.reshape(-1, block)).ravel()
     else:
         apply = lambda u: dinv * (A @ u)
+    if reduce is not None:
+        apply_rows = apply
+        apply = lambda u: reduce(apply_rows(u))
     while it < iters:
         v = v / np.linalg.norm(v)
         w = apply(v)
@@ -851,6 +889,13 @@ def estimate_emax(A, jacobi=True, iters=20, seed=0, warm=None, block=1):
         warm["v"] = v
         warm["lam"] = float(lam)
     return float(lam)
+
+
+def _producer(engine):
+    """The partitioned producer (``fem/partition.PartitionedProblem``) whose
+    rows this engine received, or ``None`` (global hand-over)."""
+    prod = getattr(engine, "producer", None)
+    return prod if hasattr(prod, "host") and hasattr(prod, "fine") else None
 
 
 def _scalar_of(P):

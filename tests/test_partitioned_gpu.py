@@ -1,0 +1,95 @@
+"""GPU suite, part 9: the partitioned operator producer (fem/partition.py)
+through the whole Python stack, ranks as threads on the one GPU of this box.
+Every rank assembles its rows only, hands them over with the rank-local C ABI
+(pcd_set_system_local / pcd_set_csr_local / pcd_mg_set_level_local) and the
+result is the global hand-over's: identical Krylov history, same solution.
+What the reference gets from DOLFIN's partitioned assembly under
+``mpirun -np 3`` (test/regression/test.py:186-190)."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from fenapack_amd import PETScOptions
+from fenapack_amd.driver import multigrid_inner_options, solve_steady
+from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
+from fenapack_amd.fem import partition as pt
+from fenapack_amd.parallel import Comm
+
+pytestmark = pytest.mark.gpu
+
+
+def on_thread_ranks(R, body):
+    group = ctypes.c_void_p()
+    hosts = pt.ThreadHostComm.group(R)
+    res, errs = [None] * R, []
+
+    def run(r):
+        try:
+            comm = Comm(r, R, thread_group=group)
+            comm.host = hosts[r]
+            res[r] = body(r, comm, hosts[r])
+        except Exception as ex:                       # pragma: no cover
+            import traceback
+            errs.append((r, repr(ex), traceback.format_exc()))
+            try:
+                hosts[r]._sh.barrier.abort()          # release the others
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    assert not any(t.is_alive() for t in th), "ranks deadlocked"
+    assert not errs, errs
+    return res
+
+
+CASES = {
+    "cavity4": (Cavity, dict(level=4, nu=0.01), 2),
+    "cube16": (Cavity3D, dict(level=2, nu=0.01, n0=4), 3),
+    "lshape4": (BackwardStep, dict(level=4, nu=0.02), 2),
+}
+
+
+@pytest.mark.parametrize("name,R", [("cavity4", 2), ("cavity4", 3),
+                                    ("cube16", 2), ("cube16", 4),
+                                    ("lshape4", 3)])
+def test_partitioned_producer_equals_the_global_hand_over(hip_lib, monkeypatch,
+                                                          name, R):
+    cls, kw, dim = CASES[name]
+    # finest two levels partitioned, the rest replicated
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "1500")
+    PETScOptions.clear()
+    # re-discretised coarse velocity operators (-pc_mg_galerkin none, PETSc's
+    # PCMG default): what a partitioned producer assembles without
+    # communication; A_p: finest level + Galerkin coarse level (summed over
+    # the ranks)
+    multigrid_inner_options(dim=dim, galerkin_u=False)
+    kw1 = dict(kw)
+    one = solve_steady(cls(kw1.pop("level"), **kw1), max_newton=3,
+                       newton_rtol=0.0)
+    x1 = one["w"].vector().copy()
+
+    def body(r, comm, host):
+        pp = pt.partitioned(cls, r, R, host=host, **kw)
+        out = solve_steady(pp, max_newton=3, newton_rtol=0.0, comm=comm)
+        f = pp.fine
+        return {"its": out["krylov_per_step"], "x": out["w"].vector().copy(),
+                "res": out["residuals"], "cells": int(f.sub.cells.size),
+                "all_cells": int(pp.space.mesh.num_cells)}
+
+    runs = on_thread_ranks(R, body)
+    PETScOptions.clear()
+    for r in runs:
+        assert r["its"] == one["krylov_per_step"], (r["its"],
+                                                    one["krylov_per_step"])
+        assert np.abs(r["x"] - x1).max() <= 1e-9 * np.abs(x1).max()
+        assert np.allclose(r["res"], one["residuals"], rtol=1e-8, atol=1e-14)
+    assert all(np.array_equal(r["x"], runs[0]["x"]) for r in runs)
+    # every rank assembled a slab, not the mesh
+    if R >= 3:
+        assert max(r["cells"] for r in runs) < 0.75 * runs[0]["all_cells"]
