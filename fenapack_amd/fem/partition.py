@@ -344,19 +344,22 @@ class PartitionedProblem(object):
                                      **G._init_kw)
         return loc
 
-    def level(self, l):
-        """Level ``l`` of the hierarchy (finest = ``len(meshes) - 1``)."""
+    def level(self, l, whole=False):
+        """Level ``l`` of the hierarchy (finest = ``len(meshes) - 1``);
+        ``whole``: never partitioned (the coarsest level of a cycle: its
+        explicit inverse is replicated whatever its size)."""
         L = len(self.hierarchy.meshes) - 1
         if l == L:
             return self.fine
-        if l not in self._levels:
+        key = (l, bool(whole))
+        if key not in self._levels:
             Gl = self._factory(level=l, skeleton=True)
-            part = Gl.space.n_u > replicate_below()
+            part = Gl.space.n_u > replicate_below() and not whole
             lev = self._make_level(Gl, part)
             if not part:
                 lev.loc = self._factory(level=l)      # whole (small) problem
-            self._levels[l] = lev
-        return self._levels[l]
+            self._levels[key] = lev
+        return self._levels[key]
 
     # -- state ---------------------------------------------------------------
     @property
@@ -484,7 +487,7 @@ class PartitionedProblem(object):
         L = len(self.hierarchy.meshes) - 1
         ops = []
         for l in range(L - 1, L - nlev, -1):
-            lev = self.level(l)
+            lev = self.level(l, whole=(l == L - nlev + 1))
             self._sync(lev)
             x_l = self.injected_wind(xu, lev)
             lin = lev.loc.linearise(x_l, np.zeros(lev.loc.space.n_p))
