@@ -625,8 +625,9 @@ class KSP(object):
         if pc.mg_galerkin:
             red = None
             if prod is not None:
+                # (level 0 - an explicit inverse - is whole whatever its size)
                 if any(chain[l].shape[1] > rep_limit
-                       for l in range(1, len(chain))):
+                       for l in range(2, len(chain))):
                     raise RuntimeError(
                         "%spc_type mg with a partitioned producer: a level "
                         "below the finest one is partitioned too - Galerkin "
