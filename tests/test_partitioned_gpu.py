@@ -82,13 +82,31 @@ def test_partitioned_producer_equals_the_global_hand_over(hip_lib, monkeypatch,
                 "res": out["residuals"], "cells": int(f.sub.cells.size),
                 "all_cells": int(pp.space.mesh.num_cells)}
 
+    def body_global(r, comm, host):
+        # the same ranks fed by the GLOBAL producer (every rank builds the
+        # whole problem and slices its rows: pcd_set_system_local)
+        kw2 = dict(kw)
+        out = solve_steady(cls(kw2.pop("level"), **kw2), max_newton=3,
+                           newton_rtol=0.0, comm=comm)
+        return {"its": out["krylov_per_step"], "x": out["w"].vector().copy(),
+                "res": out["residuals"]}
+
     runs = on_thread_ranks(R, body)
+    monkeypatch.setenv("FENAPACK_AMD_LOCAL_HANDOVER", "1")
+    same_ranks = on_thread_ranks(R, body_global)[0]
     PETScOptions.clear()
+    xr = same_ranks["x"]
     for r in runs:
-        assert r["its"] == one["krylov_per_step"], (r["its"],
-                                                    one["krylov_per_step"])
-        assert np.abs(r["x"] - x1).max() <= 1e-9 * np.abs(x1).max()
-        assert np.allclose(r["res"], one["residuals"], rtol=1e-8, atol=1e-14)
+        # same ranks, the other producer: the same solve
+        assert r["its"] == same_ranks["its"], (r["its"], same_ranks["its"])
+        assert np.abs(r["x"] - xr).max() <= 1e-10 * np.abs(xr).max()
+        assert np.allclose(r["res"], same_ranks["res"], rtol=1e-9, atol=1e-14)
+        # one rank: the partitioned reductions change round-off, a count may
+        # move by one where a residual sits at the threshold
+        assert all(abs(a - b) <= 1 for a, b in
+                   zip(r["its"], one["krylov_per_step"])), (
+            r["its"], one["krylov_per_step"])
+        assert np.abs(r["x"] - x1).max() <= 1e-6 * np.abs(x1).max()
     assert all(np.array_equal(r["x"], runs[0]["x"]) for r in runs)
     # every rank assembled a slab, not the mesh
     if R >= 3:
