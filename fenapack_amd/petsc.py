@@ -799,6 +799,7 @@ class KSP(object):
         if self.type == "chebyshev" and pc == "jacobi" \
                 and self.cheb_precompose > 0 and 2 <= max_it <= 8 \
                 and getattr(self.engine.L, "hip", False) \
+                and _producer(self.engine) is None \
                 and self._ops[1].A is not None \
                 and self._ops[1].A.shape[0] <= self.cheb_precompose_rows:
             # a fixed number of Chebyshev-Jacobi steps from a zero guess is a
