@@ -73,6 +73,7 @@ _HIP_ONLY = {
     "set_system_local": [C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                          C.c_void_p, C.c_void_p, C.c_void_p],
+    "mg_set_level_cuts": [C.c_int, C.c_int, C.c_int64, C.c_void_p],
     "mg_set_level_local": [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -375,6 +376,12 @@ class Engine(object):
             b = [P.shape[0], P.shape[1], _ptr(pp), _ptr(px), _ptr(pv)]
         self._call("mg_set_level", slot, int(level), *(a + b),
                    float(emin), float(emax))
+
+    def mg_set_level_cuts(self, slot, level, n, bounds):
+        """Row cuts of a partitioned coarse level (``pcd_mg_set_level_cuts``):
+        ``bounds`` has one more entry than there are ranks."""
+        b = np.ascontiguousarray(bounds, dtype=np.int64)
+        self._call("mg_set_level_cuts", slot, int(level), int(n), _ptr(b))
 
     def mg_set_level_local(self, slot, level, n, A_rows, P_rows, R_rows,
                            emin, emax):

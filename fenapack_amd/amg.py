@@ -242,3 +242,226 @@ def smoothed_aggregation_chain(A, block=1, coarse_rows=2000, max_levels=12,
         Ps.append(P)
         cur = _galerkin(cur, P)
     return [None] + Ps[::-1]
+
+
+# --------------------------------------------------------------- partitioned
+class PartitionedSA(object):
+    """Smoothed-aggregation hierarchy built RANK BY RANK from an operator of
+    which every rank holds its rows only (``fem/partition.py``: global shape,
+    other rows empty) - [ext PETSc] PCGAMG on a distributed matrix.
+
+    * aggregation runs on the rank's diagonal block (couplings to other ranks'
+      rows are ignored when choosing aggregates), so aggregates never cross a
+      rank boundary and every rank OWNS the coarse dofs of its aggregates: the
+      coarse levels are cut where the aggregates fall
+      (``pcd_mg_set_level_cuts``), not evenly;
+    * the tentative prolongator is smoothed with the diagonal block as well
+      (``P = (I - omega/rho D^-1 A_rr) T``): ``P`` is block diagonal by rank,
+      its transpose needs no rows of other ranks;
+    * the Galerkin operator ``P^T A P`` couples across ranks through ``A``:
+      a rank needs the prolongator rows of its halo columns - exchanged once
+      (``HostComm.allgather`` of the boundary rows, kept while the pattern
+      stands);
+    * levels of at most ``replicate_rows`` dofs are gathered whole and the
+      rest of the chain is the replicated ``smoothed_aggregation_chain``.
+
+    The hierarchy therefore depends on the number of ranks (as PCGAMG's and
+    BoomerAMG's do); iteration counts are reported per rank count.
+    ``chain()`` / ``operators(F)`` give scalar prolongators / operators,
+    coarsest first, global-shaped with this rank's rows populated on the
+    partitioned levels; ``cuts[l]`` the row cuts of level ``l`` (scalar)."""
+
+    def __init__(self, F, own, host, block=1, theta=0.02, coarse_rows=2000,
+                 replicate_rows=60000, omega=4.0 / 3.0, distance=2,
+                 min_ratio=1.5, max_levels=12):
+        self.host, self.block = host, block
+        self.part = []                  # finest first: dicts of one coarsening
+        self.tail = [None]              # replicated chain below (coarsest first)
+        cur, cur_own = sp.csr_matrix(F), (int(own[0]), int(own[1]))
+        n = cur.shape[0]
+        self.n_fine, self.own_fine = n, cur_own
+        whole = None
+        while n * block > replicate_rows and n > coarse_rows \
+                and len(self.part) < max_levels - 1:
+            lev = self._coarsen(cur, cur_own, theta, omega, distance,
+                                seed=len(self.part))
+            if lev["nc"] * min_ratio > n:
+                break                                   # coarsening stalled
+            self.part.append(lev)
+            Ac = self._galerkin(cur, lev)
+            n = lev["nc"]
+            if n * block <= replicate_rows or n <= coarse_rows:
+                whole = self._gather(Ac, lev)
+                break
+            cur, cur_own = Ac, lev["own_c"]
+        if whole is None:
+            if self.part and n * block > replicate_rows:
+                raise ValueError(
+                    "partitioned gamg: coarsening stalled at %d rows, above "
+                    "the replication limit" % (n * block))
+            if not self.part:
+                raise ValueError("partitioned gamg: nothing to coarsen")
+        self._tail_A = whole
+        self.tail = smoothed_aggregation_chain(
+            whole, block=1, coarse_rows=coarse_rows, theta=theta,
+            distance=distance, max_levels=max_levels - len(self.part))
+
+    # one coarsening of the rows [r0, r1) of `A` (global shape)
+    def _coarsen(self, A, own, theta, omega, distance, seed):
+        host = self.host
+        r0, r1 = own
+        n = A.shape[0]
+        Arows = A[r0:r1]
+        Add = sp.csr_matrix(Arows[:, r0:r1])
+        agg, nagg = aggregate(_strength(Add, theta), seed, distance)
+        counts = host.allgather(int(nagg))
+        cuts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        off, nc = int(cuts[host.rank]), int(cuts[-1])
+        T = _tentative(agg, nagg)
+        d = Add.diagonal().copy()
+        d[d == 0.0] = 1.0
+        rho = self._rho(A, own, d)
+        Pl = T - (omega / rho) * (sp.diags(1.0 / d) @ (Add @ T))
+        Pl = sp.csr_matrix(Pl)
+        Pl.eliminate_zeros()
+        Pl.sort_indices()                    # (r1 - r0) x nagg, local columns
+        # halo rows of P: the columns of my rows owned by other ranks
+        cols = np.unique(Arows.indices)
+        halo = cols[(cols < r0) | (cols >= r1)]
+        bounds = host.allgather((r0, r1))
+        want = host.allgather(halo)
+        reply = {}
+        for q, need in enumerate(want):
+            if q == host.rank or need.size == 0:
+                continue
+            mine = need[(need >= r0) & (need < r1)]
+            if mine.size:
+                sub = Pl[mine - r0]
+                reply[q] = (mine, sub.indptr, sub.indices + off, sub.data)
+        got = host.allgather(reply)
+        rows_i, rows_p, rows_c, rows_v = [], [], [], []
+        for q, rep in enumerate(got):
+            if q == host.rank or host.rank not in rep:
+                continue
+            idx, ip, ci, cv = rep[host.rank]
+            rows_i.append(idx)
+            rows_p.append(np.diff(ip))
+            rows_c.append(ci)
+            rows_v.append(cv)
+        # P_ext: n x nc, my rows and the halo rows populated, global columns
+        own_len = np.diff(Pl.indptr)
+        idx = np.concatenate([np.arange(r0, r1)] + rows_i)
+        ln = np.concatenate([own_len] + rows_p)
+        ci = np.concatenate([Pl.indices + off] + rows_c)
+        cv = np.concatenate([Pl.data] + rows_v)
+        order = np.argsort(idx, kind="stable")
+        start = np.concatenate([[0], np.cumsum(ln)])[:-1]
+        take = np.concatenate([np.arange(start[k], start[k] + ln[k])
+                               for k in order]) if order.size else \
+            np.zeros(0, dtype=np.int64)
+        indptr = np.zeros(n + 1, dtype=np.int64)
+        indptr[idx[order] + 1] = ln[order]
+        np.cumsum(indptr, out=indptr)
+        Pext = sp.csr_matrix((cv[take], ci[take].astype(np.int64), indptr),
+                             shape=(n, nc))
+        # my rows only, global shape: what the hand-over slices
+        ip2 = np.zeros(n + 1, dtype=np.int64)
+        ip2[r0 + 1:r1 + 1] = own_len
+        np.cumsum(ip2, out=ip2)
+        Pown = sp.csr_matrix((Pl.data, (Pl.indices + off).astype(np.int64),
+                              ip2), shape=(n, nc))
+        return {"own": own, "own_c": (off, off + nagg), "nc": nc, "n": n,
+                "cuts": cuts, "Pl": Pl, "Pext": Pext, "Pown": Pown,
+                "bounds": bounds}
+
+    def _rho(self, A, own, d_own, iters=15, seed=0):
+        """Spectral radius estimate of D^-1 A for the whole operator: the
+        power iteration of ``_rho`` with the product completed over the
+        ranks."""
+        n = A.shape[0]
+        r0, r1 = own
+        Arows = A[r0:r1]
+        v = np.random.default_rng(seed).standard_normal(n)
+        best = 0.0
+        for k in range(iters):
+            v /= np.linalg.norm(v)
+            w = np.zeros(n)
+            w[r0:r1] = (Arows @ v) / d_own
+            v = self.host.sum(w)
+            if k >= 2:
+                best = max(best, float(np.linalg.norm(v)))
+        return best
+
+    def _galerkin(self, A, lev):
+        """My rows of ``P^T A P`` (the coarse dofs of my aggregates), global
+        shape."""
+        r0, r1 = lev["own"]
+        AP = sp.csr_matrix(A[r0:r1] @ lev["Pext"])       # nloc x nc
+        C = sp.csr_matrix(lev["Pl"].T @ AP)              # nagg x nc
+        C.sort_indices()
+        c0, c1 = lev["own_c"]
+        nc = lev["nc"]
+        ip = np.zeros(nc + 1, dtype=np.int64)
+        ip[c0 + 1:c1 + 1] = np.diff(C.indptr)
+        np.cumsum(ip, out=ip)
+        out = sp.csr_matrix((C.data, C.indices.astype(np.int64), ip),
+                            shape=(nc, nc))
+        out.has_sorted_indices = True
+        return out
+
+    def _gather(self, Ac, lev):
+        c0, c1 = lev["own_c"]
+        rows = sp.csr_matrix(Ac[c0:c1])
+        parts = self.host.allgather((rows.indptr, rows.indices, rows.data))
+        nc = lev["nc"]
+        mats = [sp.csr_matrix((dv, ix, ip), shape=(ip.size - 1, nc))
+                for ip, ix, dv in parts]
+        W = sp.vstack(mats, format="csr")
+        W.sort_indices()
+        return W
+
+    # -- what the solver stack reads ------------------------------------------
+    @property
+    def nlevels(self):
+        return len(self.part) + len(self.tail)
+
+    def chain(self):
+        """``[None, P_1, ..., P_L]`` (scalar), coarsest first."""
+        return list(self.tail) + [lev["Pown"] for lev in self.part[::-1]]
+
+    def level_cuts(self):
+        """``cuts[l]`` (scalar dofs) of every level, ``None`` where the level
+        is replicated or has the field's even cuts (the finest)."""
+        L = self.nlevels
+        cuts = [None] * L
+        for k, lev in enumerate(self.part):
+            l = L - 2 - k                       # level the coarsening produced
+            if k < len(self.part) - 1:          # (the last one was gathered)
+                cuts[l] = lev["cuts"]
+        return cuts
+
+    def partitioned_levels(self):
+        L = self.nlevels
+        flags = [False] * L
+        flags[L - 1] = True
+        for k in range(len(self.part) - 1):
+            flags[L - 2 - k] = True
+        return flags
+
+    def operators(self, F):
+        """Galerkin operators for the (re-assembled) finest operator ``F``
+        (my rows, global shape), coarsest first; partitioned levels as my
+        rows, replicated ones whole."""
+        from .fem.multigrid import galerkin_chain
+        ops_part = [sp.csr_matrix(F)]
+        cur = ops_part[0]
+        whole = None
+        for k, lev in enumerate(self.part):
+            Ac = self._galerkin(cur, lev)
+            if k == len(self.part) - 1:
+                whole = self._gather(Ac, lev)
+            else:
+                ops_part.append(Ac)
+                cur = Ac
+        tail_ops = galerkin_chain(whole, self.tail)     # coarsest first
+        return tail_ops + ops_part[::-1]

@@ -2152,8 +2152,33 @@ int pcd_mg_begin(pcd_handle h, int slot, int nlevels, int nu_pre, int nu_post) {
   s.mg.resize(nlevels);
   s.mg_r.clear(); s.mg_r.resize(nlevels);
   s.mg_r_known.assign(nlevels, 0);
+  s.mg_space.clear(); s.mg_space.resize(nlevels);     // (row cuts belong to a hierarchy)
   s.nu_pre = nu_pre; s.nu_post = nu_post;
   ++h->gen;
+  return 0;
+}
+
+int pcd_mg_set_level_cuts(pcd_handle h, int slot, int level, int64_t n, const int64_t* bounds) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_set_level_cuts: bad slot %d", slot);
+  Inner& s = h->inner[slot];
+  const int L = (int)s.mg.size();
+  if (level < 0 || level >= L - 1)
+    return fail(PCD_ERR_ARG, "mg_set_level_cuts: level %d outside [0,%d) (the finest level has the field's cuts)",
+                level, L - 1);
+  if (!bounds || n < 0) return fail(PCD_ERR_ARG, "mg_set_level_cuts: bad arguments");
+  if (!h->comm) return fail(PCD_ERR_STATE, "mg_set_level_cuts: no communicator");
+  const int even = slot == PCD_KSP_A00 ? h->vel_block : 1;
+  if (bounds[0] != 0 || bounds[h->nranks] != n)
+    return fail(PCD_ERR_ARG, "mg_set_level_cuts: cuts must run from 0 to n");
+  for (int r = 0; r < h->nranks; ++r)
+    if (bounds[r + 1] < bounds[r] || (even > 1 && bounds[r + 1] % even))
+      return fail(PCD_ERR_ARG, "mg_set_level_cuts: cuts must ascend%s", even > 1 ? " on node boundaries" : "");
+  if (s.mg[level].A.set || s.mg[level].P.set || (level + 1 < L && s.mg[level + 1].P.set))
+    return fail(PCD_ERR_STATE, "mg_set_level_cuts: level %d or its prolongation is set already", level);
+  if ((int)s.mg_space.size() != L) s.mg_space.resize(L);
+  Space sp; sp.nf = 1; sp.bounds[0].assign(bounds, bounds + h->nranks + 1);
+  s.mg_space[level] = sp;
   return 0;
 }
 

@@ -566,12 +566,36 @@ class KSP(object):
         from .fem.multigrid import galerkin_chain, coarse_inverse
         pc = self.pc
         if pc._mg_chain is None and pc.mg_algebraic:
-            from .amg import smoothed_aggregation_chain
+            from .amg import smoothed_aggregation_chain, PartitionedSA
             blk = getattr(self.engine, "velocity_block", 2) \
                 if self.slot == c.KSP_A00 else 1
-            pc.setMGInterpolations(smoothed_aggregation_chain(
-                self._ops[1].A, block=blk, coarse_rows=pc.mg_coarse_eq_limit,
-                theta=pc.mg_gamg_threshold))
+            prod0 = _producer(self.engine)
+            if prod0 is not None:
+                # this rank's rows only: aggregation rank by rank, coarse
+                # levels cut where the aggregates fall (amg.PartitionedSA)
+                A0 = sp.csr_matrix(self._ops[1].A)
+                F0 = A0 if blk == 1 else _host.kron_factor(A0, blk)
+                if F0 is None:
+                    raise RuntimeError(
+                        "%spc_type gamg with a partitioned producer needs the "
+                        "F (x) I_d velocity block (Picard)" % self._prefix)
+                r0, r1 = self.engine.row_range(A0.shape[0],
+                                               velocity=self.slot == c.KSP_A00)
+                psa = PartitionedSA(
+                    F0, (r0 // blk, r1 // blk), prod0.host, block=blk,
+                    theta=pc.mg_gamg_threshold,
+                    coarse_rows=pc.mg_coarse_eq_limit,
+                    replicate_rows=int(os.environ.get("PCD_REPLICATE_BELOW",
+                                                      "60000")))
+                pc._mg_psa = psa
+                pc.setMGInterpolations(
+                    [None] + [P if blk == 1 else _host.kron_expand(P, blk)
+                              for P in psa.chain()[1:]])
+            else:
+                pc.setMGInterpolations(smoothed_aggregation_chain(
+                    self._ops[1].A, block=blk,
+                    coarse_rows=pc.mg_coarse_eq_limit,
+                    theta=pc.mg_gamg_threshold))
         if pc._mg_chain is None:
             raise RuntimeError("%spc_type mg needs interpolations "
                                "(pc.setMGInterpolations)" % self._prefix)
@@ -585,8 +609,14 @@ class KSP(object):
             while nlev > 1 and chain[len(chain) - nlev + 1].shape[0] \
                     <= pc.mg_coarse_eq_limit:
                 nlev -= 1
+        psa = getattr(pc, "_mg_psa", None)
+        if psa is not None and pc.mg_levels is None:
+            # (the partitioned hierarchy replicates - and could invert - only
+            # what it gathered: never cut it above its first replicated level)
+            nlev = max(nlev, len(psa.part) + 1)
         if nlev < len(chain):
             chain = [None] + chain[len(chain) - nlev + 1:]
+        lvl_off = 0 if psa is None else psa.nlevels - len(chain)
         skip = range(1, len(chain) - 1) if pc.mg_skip_levels == "all" \
             else pc.mg_skip_levels
         for k in sorted(skip, reverse=True):
@@ -614,15 +644,32 @@ class KSP(object):
         # rank's rows only (fem/partition.py) - reductions through its HostComm
         prod = _producer(self.engine)
         rep_limit = int(os.environ.get("PCD_REPLICATE_BELOW", "60000"))
-        rowsparse = lambda l, n: prod is not None and (
-            l == len(chain) - 1 or n > rep_limit)
+        if psa is not None:
+            if pc.mg_skip_levels:
+                raise ValueError("%spc_mg_skip_levels with a partitioned "
+                                 "algebraic hierarchy" % self._prefix)
+            psa_part = psa.partitioned_levels()
+            rowsparse = lambda l, n: psa_part[l + lvl_off]
+        else:
+            rowsparse = lambda l, n: prod is not None and (
+                l == len(chain) - 1 or n > rep_limit)
         if blk > 1:
             facs = [_scalar_of(P) for P in chain[1:]]
             if all(f is not None and f[1] == blk for f in facs):
                 F = _host.kron_factor(A, blk)
                 if F is not None:
                     chain_s = [None] + [f[0] for f in facs]
-        if pc.mg_galerkin:
+        if pc.mg_galerkin and psa is not None:
+            F = A if blk == 1 else _host.kron_factor(A, blk)
+            ops_s = psa.operators(F)[lvl_off:]
+            chain_s = [None] + [P if blk == 1 else _scalar_of(P)[0]
+                                for P in chain[1:]]
+            ops = ops_s if blk == 1 else \
+                [_host.kron_expand(o, blk) for o in ops_s[:-1]] \
+                + [sp.csr_matrix(A)]
+            if blk == 1:
+                chain_s = ops_s = None
+        elif pc.mg_galerkin:
             red = None
             if prod is not None:
                 # (level 0 - an explicit inverse - is whole whatever its size)
@@ -697,11 +744,29 @@ class KSP(object):
             # finest level always); replicated ones whole
             limit = int(os.environ.get("PCD_REPLICATE_BELOW", "60000"))
             vel = slot == c.KSP_A00
-            part = [l == L - 1 or ops[l].shape[0] > limit for l in range(L)]
-            rng_ = [eng.row_range(ops[l].shape[0], velocity=vel)
-                    if part[l] else None for l in range(L)]
+            cuts = [None] * L
+            if psa is not None:
+                part = [psa_part[l + lvl_off] for l in range(L)]
+                part[0] = False
+                for l in range(L):
+                    cl = psa.level_cuts()[l + lvl_off]
+                    if part[l] and cl is not None:
+                        cuts[l] = np.asarray(cl, dtype=np.int64) * blk
+            else:
+                part = [l == L - 1 or ops[l].shape[0] > limit
+                        for l in range(L)]
+            me = getattr(prod, "rank", None)
+            rng_ = [None if not part[l] else
+                    (int(cuts[l][me]), int(cuts[l][me + 1]))
+                    if cuts[l] is not None else
+                    eng.row_range(ops[l].shape[0], velocity=vel)
+                    for l in range(L)]
         if pc._mg_pushed != sig:
             eng.mg_begin(slot, L, nu_pre, nu_post)
+            if local:
+                for l in range(L - 1):
+                    if cuts[l] is not None:
+                        eng.mg_set_level_cuts(slot, l, ops[l].shape[0], cuts[l])
             # finest first: a level's engine numbering is inherited from the
             # level above it through the prolongation (pcd_reorder.hpp)
             for l in range(L - 1, 0, -1):
@@ -709,9 +774,8 @@ class KSP(object):
                     r0, r1 = rng_[l]
                     P = sp.csr_matrix(chain[l])
                     R_rows = None
-                    if ops[l - 1].shape[0] > limit:
-                        c0, c1 = eng.row_range(ops[l - 1].shape[0],
-                                               velocity=vel)
+                    if part[l - 1]:
+                        c0, c1 = rng_[l - 1]
                         R_rows = _host.transpose(P)[c0:c1]
                     eng.mg_set_level_local(
                         slot, l, ops[l].shape[0],

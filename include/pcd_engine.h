@@ -238,6 +238,16 @@ int pcd_mg_set_level_local(pcd_handle h, int slot, int level, int64_t n_global,
                            int64_t r_rows_local, const int32_t* rrowptr,
                            const int32_t* rcolidx, const double* rvals,
                            double emin, double emax);
+/* Row cuts of a partitioned level other than the even ones of pcd_row_range:
+ * an ALGEBRAIC hierarchy built rank by rank gives every rank the aggregates of
+ * its own rows ([ext PETSc] PCGAMG's coarse ownership), so coarse levels are
+ * cut where the aggregates fall.  bounds[nranks + 1], from 0 to n, ascending,
+ * on node boundaries for PCD_KSP_A00; the same on every rank.  After
+ * pcd_mg_begin and before this level or the level above it is set
+ * (pcd_mg_set_level_local then checks the row counts against these cuts).
+ * The finest level always has the field's cuts. */
+int pcd_mg_set_level_cuts(pcd_handle h, int slot, int level, int64_t n,
+                          const int64_t* bounds);
 /* re-assembled operator of one level (same pattern) and refreshed bounds;
  * vals == NULL only refreshes the bounds (finest level) */
 int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,

@@ -111,3 +111,45 @@ def test_partitioned_producer_equals_the_global_hand_over(hip_lib, monkeypatch,
     # every rank assembled a slab, not the mesh
     if R >= 3:
         assert max(r["cells"] for r in runs) < 0.75 * runs[0]["all_cells"]
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_partitioned_algebraic_hierarchy(hip_lib, monkeypatch, R):
+    """-pc_type gamg from a partitioned producer (amg.PartitionedSA): every
+    rank aggregates its own rows, coarse levels are cut where the aggregates
+    fall (pcd_mg_set_level_cuts), Galerkin operators by rows.  The hierarchy
+    depends on the rank count (as PCGAMG's does): the Krylov counts stay in a
+    band around the one-rank hierarchy's, the solution is the same solve's."""
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "4000")
+    PETScOptions.clear()
+    multigrid_inner_options(dim=3, algebraic=True)
+    kw = dict(level=2, nu=0.01, n0=4)                    # cube N = 16
+    one = solve_steady(Cavity3D(2, nu=0.01, n0=4), max_newton=3,
+                       newton_rtol=0.0)
+    x1 = one["w"].vector().copy()
+
+    def body(r, comm, host):
+        pp = pt.partitioned(Cavity3D, r, R, host=host, **kw)
+        out = solve_steady(pp, max_newton=3, newton_rtol=0.0, comm=comm)
+        ksp = out["solver"].linear_solver().ksp()
+        ksp0 = ksp.pc.getFieldSplitSubKSP()[0]
+        psa = ksp0.pc._mg_psa
+        return {"its": out["krylov_per_step"], "x": out["w"].vector().copy(),
+                "levels": [o.shape[0] for o in ksp0.pc.mg_data["ops"]],
+                "part": psa.partitioned_levels(),
+                "cuts": [None if c is None else list(map(int, c))
+                         for c in psa.level_cuts()]}
+
+    runs = on_thread_ranks(R, body)
+    PETScOptions.clear()
+    r0 = runs[0]
+    # at least one coarse level is partitioned, with uneven (aggregate) cuts
+    assert sum(r0["part"]) >= 2, r0
+    assert any(c is not None for c in r0["cuts"])
+    for r in runs:
+        assert r["its"] == r0["its"] and r["levels"] == r0["levels"]
+        assert np.array_equal(r["x"], r0["x"])
+        assert all(b <= a + 4 for a, b in zip(one["krylov_per_step"],
+                                              r["its"])), (
+            r["its"], one["krylov_per_step"])
+        assert np.abs(r["x"] - x1).max() <= 2e-5 * np.abs(x1).max()
