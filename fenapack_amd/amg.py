@@ -281,8 +281,11 @@ class PartitionedSA(object):
         n = cur.shape[0]
         self.n_fine, self.own_fine = n, cur_own
         whole = None
-        while n * block > replicate_rows and n > coarse_rows \
-                and len(self.part) < max_levels - 1:
+        # (the engine's rule is by size alone: a level of more than
+        # PCD_REPLICATE_BELOW rows is partitioned - so coarsening goes on,
+        # rank by rank, until a level is below that limit, whatever
+        # `coarse_rows` says)
+        while n * block > replicate_rows and len(self.part) < max_levels - 1:
             lev = self._coarsen(cur, cur_own, theta, omega, distance,
                                 seed=len(self.part))
             if lev["nc"] * min_ratio > n:
@@ -290,7 +293,7 @@ class PartitionedSA(object):
             self.part.append(lev)
             Ac = self._galerkin(cur, lev)
             n = lev["nc"]
-            if n * block <= replicate_rows or n <= coarse_rows:
+            if n * block <= replicate_rows:
                 whole = self._gather(Ac, lev)
                 break
             cur, cur_own = Ac, lev["own_c"]

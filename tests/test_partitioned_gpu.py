@@ -120,7 +120,7 @@ def test_partitioned_algebraic_hierarchy(hip_lib, monkeypatch, R):
     fall (pcd_mg_set_level_cuts), Galerkin operators by rows.  The hierarchy
     depends on the rank count (as PCGAMG's does): the Krylov counts stay in a
     band around the one-rank hierarchy's, the solution is the same solve's."""
-    monkeypatch.setenv("PCD_REPLICATE_BELOW", "4000")
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "1000")
     PETScOptions.clear()
     multigrid_inner_options(dim=3, algebraic=True)
     kw = dict(level=2, nu=0.01, n0=4)                    # cube N = 16
