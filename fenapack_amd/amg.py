@@ -285,7 +285,10 @@ class PartitionedSA(object):
         # PCD_REPLICATE_BELOW rows is partitioned - so coarsening goes on,
         # rank by rank, until a level is below that limit, whatever
         # `coarse_rows` says)
-        while n * block > replicate_rows and len(self.part) < max_levels - 1:
+        # (the finest level is partitioned whatever its size: at least one
+        # coarsening runs rank by rank)
+        while (not self.part or n * block > replicate_rows) \
+                and len(self.part) < max_levels - 1:
             lev = self._coarsen(cur, cur_own, theta, omega, distance,
                                 seed=len(self.part))
             if lev["nc"] * min_ratio > n:
