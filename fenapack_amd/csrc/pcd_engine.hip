@@ -126,6 +126,13 @@ struct DCsr {
   DBuf<int> rowptr2, col2, kron_pos;
   DBuf<double> val2;
   DBuf<int> kron_flag;
+  // LDS-staged vector tiles of the F (x) I kernels (pcd_kernels.hpp k_*_tc):
+  // greedy row blocks, their column segments, 16-bit tile offsets per entry
+  bool vt = false;
+  int vt_blocks = 0;
+  DBuf<int> vt_start, vt_segptr;
+  DBuf<int2> vt_seg;
+  DBuf<unsigned short> vt_loc;
   // multi-GPU: nrows / ncols are LOCAL counts (ncols = owned columns); ghost
   // columns are numbered ncols .. ncols + nghost and live in `ghost`
   HaloPlan plan;
@@ -139,6 +146,7 @@ struct DCsr {
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); kron_pos.release();
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
+    vt = false; vt_blocks = 0; vt_start.release(); vt_segptr.release(); vt_seg.release(); vt_loc.release();
     plan = HaloPlan(); replicated = false;
     set = false; nrows = ncols = nnz = 0; has_src = false; val_src = false;
   }
@@ -518,6 +526,16 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
                        nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y);
     return;
   }
+  if (A.vt) {
+    const int gt = grid_stream(A.vt_blocks, 1);
+#define PCD_SPMV_TC(NT)                                                                       \
+    hipLaunchKernelGGL((k_spmv_tc<MODE, NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,       \
+                       A.vt_blocks, A.vt_start.p, A.rowptr2.p, A.val2.p, A.vt_loc.p,          \
+                       A.vt_segptr.p, A.vt_seg.p, x, ghost, nloc, add, y)
+    if (A.nt2) PCD_SPMV_TC(true); else PCD_SPMV_TC(false);
+#undef PCD_SPMV_TC
+    return;
+  }
   const int g = grid_stream(nn, A.rb2);
 #define PCD_SPMV_SC(RB, NT)                                                               \
   hipLaunchKernelGGL((k_spmv_sc<RB, MODE, NC, NT>), dim3(g), dim3(kBlock), 0, h->stream, \
@@ -712,7 +730,17 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                             double* pn, double c0, double c1, double c2) {
   const int n = (int)A.nrows;
   CHK(halo_exchange(h, A, pk));
-  if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
+  if (dinv && A.vt && kron_ok(A, b, pm, pk, pn, true)) {
+    const int gt = grid_stream(A.vt_blocks, 1);
+    const int nloc = (int)(A.ncols / A.kron);
+#define PCD_CHEB_TC(NC, NT)                                                                   \
+    hipLaunchKernelGGL((k_cheb_step_tc<NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,        \
+                       A.vt_blocks, A.vt_start.p, A.rowptr2.p, A.val2.p, A.vt_loc.p,          \
+                       A.vt_segptr.p, A.vt_seg.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
+    if (A.kron == 2) { if (A.nt2) PCD_CHEB_TC(2, true); else PCD_CHEB_TC(2, false); }
+    else { if (A.nt2) PCD_CHEB_TC(3, true); else PCD_CHEB_TC(3, false); }
+#undef PCD_CHEB_TC
+  } else if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
@@ -736,6 +764,18 @@ static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
                               const double* b, double* p0, double* pn, double s,
                               double c1, double c2) {
   const int n = (int)A.nrows;
+  if (A.vt && kron_ok(A, b, p0, pn, nullptr, true)) {
+    const int gt = grid_stream(A.vt_blocks, 1);
+    const int nn = n / A.kron;
+#define PCD_FIRST_TC(NC, NT)                                                                  \
+    hipLaunchKernelGGL((k_cheb_first_tc<NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,       \
+                       A.vt_blocks, A.vt_start.p, A.rowptr2.p, A.val2s.p, A.vt_loc.p,         \
+                       A.vt_segptr.p, A.vt_seg.p, dinv, b, p0, pn, s, c1, c2, nn)
+    if (A.kron == 2) { if (A.nt2) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
+    else { if (A.nt2) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
+#undef PCD_FIRST_TC
+    return;
+  }
   if (kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
@@ -1362,6 +1402,94 @@ static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* ro
   return ok.load();
 }
 
+// LDS-staged vector tiles (pcd_kernels.hpp): row blocks of the scalar stencil
+// F chosen greedily - rows are added while the block's distinct columns fit
+// the tile (kVtNodes), its entries the entry buffer (kVtEntries) and its rows
+// the workgroup (kVtRows) -, per block the maximal runs of consecutive columns
+// (never across the owned / ghost boundary `nloc`) and per entry the offset of
+// its column in the tile.  PCD_VEC_TILE: 0 off, 1 three-component operators
+// of at least PCD_VEC_TILE_ROWS node rows (default), 2 every F (x) I operator.
+static int g_vec_tile = 1;
+static long long g_vec_tile_rows = 200000;
+static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
+                          const std::vector<int32_t>& rpc, const std::vector<int32_t>& cc) {
+  A.vt = false; A.vt_blocks = 0;
+  { const char* e = getenv("PCD_VEC_TILE"); if (e) g_vec_tile = atoi(e); }
+  { const char* e = getenv("PCD_VEC_TILE_ROWS"); if (e) g_vec_tile_rows = atoll(e); }
+  if (!g_vec_tile || (g_vec_tile == 1 && (nc != 3 || nn < g_vec_tile_rows))) return 0;
+  if (nn < 1 || A.dense2 || A.long_rows || A.wave_rows) return 0;
+  // independent super-blocks of rows: block boundaries restart at multiples of
+  // kSuper rows, so the host threads need no hand-over and the result does not
+  // depend on their number
+  constexpr int64_t kSuper = 8192;
+  const int64_t nsup = (nn + kSuper - 1) / kSuper;
+  std::vector<std::vector<int32_t>> b_start(nsup);
+  std::vector<std::vector<int32_t>> b_nseg(nsup);           // segments (+ sentinel) per block
+  std::vector<std::vector<int2>> b_seg(nsup);
+  std::vector<unsigned short> loc(cc.size());
+  std::atomic<bool> ok{true};
+  parallel_chunks(nsup, [&](int64_t s0, int64_t s1) {
+    std::vector<int32_t> cols, uniq;
+    for (int64_t sb = s0; sb < s1 && ok.load(std::memory_order_relaxed); ++sb) {
+      const int64_t ra = sb * kSuper, rz = std::min<int64_t>(nn, ra + kSuper);
+      int64_t r = ra;
+      while (r < rz) {
+        // grow the block row by row
+        cols.clear();
+        int64_t r1 = r;
+        size_t kept = 0;
+        while (r1 < rz && r1 - r < kVtRows) {
+          const size_t before = cols.size();
+          cols.insert(cols.end(), cc.begin() + rpc[r1], cc.begin() + rpc[r1 + 1]);
+          if ((int64_t)cols.size() > kVtEntries) { cols.resize(before); break; }
+          uniq.assign(cols.begin(), cols.end());
+          std::sort(uniq.begin(), uniq.end());
+          uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+          if ((int64_t)uniq.size() > kVtNodes) { cols.resize(before); break; }
+          kept = cols.size();
+          ++r1;
+        }
+        if (r1 == r) { ok.store(false); return; }       // one row alone does not fit
+        cols.resize(kept);
+        uniq.assign(cols.begin(), cols.end());
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        // runs of consecutive columns
+        int nseg = 0;
+        for (size_t q = 0; q < uniq.size(); ++q)
+          if (q == 0 || uniq[q] != uniq[q - 1] + 1 || uniq[q] == (int32_t)nloc) {
+            b_seg[sb].push_back(int2{uniq[q], (int)q});
+            ++nseg;
+          }
+        b_seg[sb].push_back(int2{-1, (int)uniq.size()});   // sentinel: tile size
+        b_nseg[sb].push_back(nseg + 1);
+        b_start[sb].push_back((int32_t)r);
+        for (int32_t k = rpc[r]; k < rpc[r1]; ++k)
+          loc[k] = (unsigned short)(std::lower_bound(uniq.begin(), uniq.end(), cc[k]) - uniq.begin());
+        r = r1;
+      }
+    }
+  });
+  if (!ok.load()) return 0;
+  std::vector<int32_t> start, segptr(1, 0);
+  std::vector<int2> seg;
+  for (int64_t sb = 0; sb < nsup; ++sb) {
+    start.insert(start.end(), b_start[sb].begin(), b_start[sb].end());
+    for (int32_t c : b_nseg[sb]) segptr.push_back(segptr.back() + c);
+    seg.insert(seg.end(), b_seg[sb].begin(), b_seg[sb].end());
+  }
+  start.push_back((int32_t)nn);
+  A.vt_blocks = (int)start.size() - 1;
+  CHK(A.vt_start.ensure(start.size())); CHK(A.vt_segptr.ensure(segptr.size()));
+  CHK(A.vt_seg.ensure(seg.size())); CHK(A.vt_loc.ensure(loc.size()));
+  HIPCHK(hipMemcpy(A.vt_start.p, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(A.vt_segptr.p, segptr.data(), segptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(A.vt_seg.p, seg.data(), seg.size() * sizeof(int2), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(A.vt_loc.p, loc.data(), loc.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  A.vt = true;
+  return 0;
+}
+
 // detect the structure (the velocity block size first) + compressed arrays
 static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
                        const int32_t* rowptr, const int32_t* col, bool have_vals) {
@@ -1402,6 +1530,7 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.kron = A.kron_pat = nc; A.rb2 = rb2;
   // bytes one fused step moves: F (12 B / entry) + five vector streams
   A.nt2 = g_nt_bytes >= 0 && 12.0 * (double)A.nnz2 + 40.0 * (double)nrows > (double)g_nt_bytes;
+  if (rb2) CHK(build_vec_tile(h, A, nc, nn, ncols / nc, rpc, cc));
   if (have_vals) CHK(refresh_kron(h, A));
   return 0;
 }

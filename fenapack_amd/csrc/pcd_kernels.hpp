@@ -883,6 +883,183 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
   }
 }
 
+// ==========================================================================
+// LDS-staged VECTOR TILES for the multi-component operators (north-star:
+// "CSR SpMV ... with coalesced HBM row-pointer/col-index reads and LDS-staged
+// vector tiles").  The kernels above stage PRODUCTS in LDS and gather the
+// vector per entry from L1/L2: on a 3-D P2 stencil (29 entries per row, the
+// gathered nodes of a row in ~19 short runs) every wave-wide gather touches
+// ~30 cache lines for 1.5 KB of payload, and the texture-addresser, not HBM,
+// bounds the kernel (profiles/r02_s_*: TA busy 61 %).  Here the set-up gives
+// every row block the list of CONTIGUOUS column segments it touches
+// (pcd_engine.hip build_vec_tile): the workgroup loads those segments into
+// LDS with coalesced loads - every line once per block -, streams (value,
+// 16-bit tile offset) pairs into LDS as well, and the row sums read both from
+// LDS.  No product array, two barriers per block, 10 B instead of 12 B of
+// matrix stream per entry.
+//   blocks:  rows [rb_start[b], rb_start[b+1]) (<= kVtRows), chosen greedily
+//            so that the tile holds <= kVtNodes nodes and <= kVtEntries entries
+//   seg:     int2 (start node, tile offset) per segment + one sentinel per
+//            block (its tile offset = number of tile nodes); nodes >= nloc
+//            live in `ghost`
+//   loc:     tile offset of every entry's column (uint16)
+// ==========================================================================
+constexpr int kVtRows = 32;        // rows per block (8 lanes share a row)
+constexpr int kVtNodes = 768;      // tile nodes (x NC doubles)
+constexpr int kVtEntries = 1024;   // entries per block
+
+template <int NC, bool NT>
+__device__ __forceinline__ VecC<NC> tile_row_block(
+    int r0, int r1, const int* __restrict__ rowptr,
+    const double* __restrict__ val, const unsigned short* __restrict__ loc,
+    const int2* __restrict__ seg, int s0, int s1, const double* x,
+    const double* ghost, int nloc, double* tile, double* ev,
+    unsigned short* el) {
+  const int k0 = rowptr[r0], k1 = rowptr[r1];
+  constexpr int TPR = kBlock / kVtRows;
+  const int row = r0 + threadIdx.x / TPR;
+  const int sub = threadIdx.x % TPR;
+  const bool mine = row < r1;
+  const int ra = mine ? rowptr[row] - k0 : 0;
+  const int rb = mine ? rowptr[row + 1] - k0 : 0;
+  // A1: the block's column segments -> LDS planes (component-major), coalesced
+  for (int s = s0; s < s1 - 1; ++s) {
+    const int2 sg = seg[s];
+    const int len = seg[s + 1].y - sg.y;
+    const double* src = sg.x < nloc ? x + (size_t)NC * sg.x
+                                    : ghost + (size_t)NC * (sg.x - nloc);
+    for (int i = threadIdx.x; i < NC * len; i += kBlock)
+      tile[(i % NC) * kVtNodes + sg.y + i / NC] = src[i];
+  }
+  // A2: (value, tile offset) of every entry, streamed once
+  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+    ev[k - k0] = stream_load<NT>(val + k);
+    el[k - k0] = stream_load<NT>(loc + k);
+  }
+  __syncthreads();
+  VecC<NC> s = vzero<NC>();
+  for (int j = ra + sub; j < rb; j += TPR) {
+    const double v = ev[j];
+    const int o = el[j];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] += v * tile[i * kVtNodes + o];
+  }
+#pragma unroll
+  for (int m = TPR / 2; m > 0; m >>= 1) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] += __shfl_xor(s.c[i], m);
+  }
+  return s;
+}
+
+#define PCD_VT_SHARED(NC)                                   \
+  __shared__ double tile[NC * kVtNodes];                    \
+  __shared__ double ev[kVtEntries];                         \
+  __shared__ unsigned short el[kVtEntries]
+
+template <int MODE, int NC, bool NT>
+__global__ __launch_bounds__(kBlock) void k_spmv_tc(
+    int nblocks, const int* __restrict__ rb_start, const int* __restrict__ rowptr,
+    const double* __restrict__ val, const unsigned short* __restrict__ loc,
+    const int* __restrict__ segptr, const int2* __restrict__ seg,
+    const double* x, const double* ghost, int nloc, const double* add_,
+    double* y_) {
+  PCD_VT_SHARED(NC);
+  const VecC<NC>* add = vc<NC>(add_);
+  VecC<NC>* y = vc<NC>(y_);
+  int b0, b1;
+  row_block_range(nblocks, kVtRows, b0, b1, true);
+  for (int blk = b0; blk < b1; ++blk) {
+    const int r0 = rb_start[blk], r1 = rb_start[blk + 1];
+    const int row = r0 + threadIdx.x / (kBlock / kVtRows);
+    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && row < r1;
+    VecC<NC> a = vzero<NC>();
+    if ((MODE == 1 || MODE == 2) && mine) a = add[row];
+    const VecC<NC> s = tile_row_block<NC, NT>(r0, r1, rowptr, val, loc, seg, segptr[blk],
+                                              segptr[blk + 1], x, ghost, nloc, tile, ev, el);
+    if (mine) {
+      VecC<NC> o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i]
+                                        : (MODE == 2 ? a.c[i] - s.c[i] : -s.c[i]));
+      y[row] = o;
+    }
+    __syncthreads();
+  }
+}
+
+template <int NC, bool NT>
+__global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
+    int nblocks, const int* __restrict__ rb_start, const int* __restrict__ rowptr,
+    const double* __restrict__ val, const unsigned short* __restrict__ loc,
+    const int* __restrict__ segptr, const int2* __restrict__ seg,
+    const double* __restrict__ dinv_, const double* b_, const double* pm_,
+    const double* pk_, double* pn_, double c0, double c1, double c2,
+    const double* ghost, int nloc) {
+  PCD_VT_SHARED(NC);
+  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_), *pm = vc<NC>(pm_),
+               *pk = vc<NC>(pk_);
+  VecC<NC>* pn = vc<NC>(pn_);
+  int b0, b1;
+  row_block_range(nblocks, kVtRows, b0, b1, true);
+  for (int blk = b0; blk < b1; ++blk) {
+    const int r0 = rb_start[blk], r1 = rb_start[blk + 1];
+    const int row = r0 + threadIdx.x / (kBlock / kVtRows);
+    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && row < r1;
+    VecC<NC> bi = vzero<NC>(), d = bi, xk = bi, xm = bi;
+    if (mine) {
+      bi = b[row]; d = dinv[row]; xk = pk[row];
+      if (c0 != 0.0) xm = pm[row];
+    }
+    const VecC<NC> s = tile_row_block<NC, NT>(r0, r1, rowptr, val, loc, seg, segptr[blk],
+                                              segptr[blk + 1], pk_, ghost, nloc, tile, ev, el);
+    if (mine) {
+      VecC<NC> o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = c0 * xm.c[i] + c1 * xk.c[i] + c2 * d.c[i] * (bi.c[i] - s.c[i]);
+      pn[row] = o;
+    }
+    __syncthreads();
+  }
+}
+
+template <int NC, bool NT>
+__global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
+    int nblocks, const int* __restrict__ rb_start, const int* __restrict__ rowptr,
+    const double* __restrict__ vals, const unsigned short* __restrict__ loc,
+    const int* __restrict__ segptr, const int2* __restrict__ seg,
+    const double* __restrict__ dinv_, const double* b_, double* p0_, double* pn_,
+    double s, double c1, double c2, int nrows) {
+  PCD_VT_SHARED(NC);
+  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
+  VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
+  int b0, b1;
+  row_block_range(nblocks, kVtRows, b0, b1, true);
+  for (int blk = b0; blk < b1; ++blk) {
+    const int r0 = rb_start[blk], r1 = rb_start[blk + 1];
+    const int row = r0 + threadIdx.x / (kBlock / kVtRows);
+    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && row < r1;
+    VecC<NC> d = vzero<NC>(), bi = d;
+    if (mine) { d = dinv[row]; bi = b[row]; }
+    // (vals carry D^-1 by columns: the gathered vector is b alone; no halo)
+    const VecC<NC> sum = tile_row_block<NC, NT>(r0, r1, rowptr, vals, loc, seg, segptr[blk],
+                                                segptr[blk + 1], b_, b_, nrows, tile, ev, el);
+    if (mine) {
+      VecC<NC> x0, o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        x0.c[i] = s * d.c[i] * bi.c[i];
+        o.c[i] = c1 * x0.c[i] + c2 * d.c[i] * (bi.c[i] - s * sum.c[i]);
+      }
+      if (p0) p0[row] = x0;
+      pn[row] = o;
+    }
+    __syncthreads();
+  }
+}
+
 // valc[k] = val[pos[k]]; *mismatch |= (val[pos[c*nnzc + k]] differs, c >= 1):
 // pos holds, component-major, where the entry k of F sits in each component's
 // rows of the full matrix
