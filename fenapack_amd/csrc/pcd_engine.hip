@@ -130,9 +130,9 @@ struct DCsr {
   // greedy row blocks, their column segments, 16-bit tile offsets per entry
   bool vt = false;
   int vt_blocks = 0;
-  DBuf<int> vt_start, vt_segptr;
-  DBuf<int2> vt_seg;
-  DBuf<unsigned short> vt_loc;
+  DBuf<int4> vt_desc;
+  DBuf<int> vt_tsrc;
+  DBuf<unsigned short> vt_loc, vt_rowoff;
   // multi-GPU: nrows / ncols are LOCAL counts (ncols = owned columns); ghost
   // columns are numbered ncols .. ncols + nghost and live in `ghost`
   HaloPlan plan;
@@ -146,7 +146,7 @@ struct DCsr {
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); kron_pos.release();
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
-    vt = false; vt_blocks = 0; vt_start.release(); vt_segptr.release(); vt_seg.release(); vt_loc.release();
+    vt = false; vt_blocks = 0; vt_desc.release(); vt_rowoff.release(); vt_tsrc.release(); vt_loc.release();
     plan = HaloPlan(); replicated = false;
     set = false; nrows = ncols = nnz = 0; has_src = false; val_src = false;
   }
@@ -371,6 +371,11 @@ static bool g_no_small_tile = false;  // PCD_NO_SMALL_TILE=1: A/B switch
 // operators whose launches move more than this stream their matrix arrays with
 // non-temporal loads (PCD_NT_BYTES; -1: never): beyond the 256 MiB Infinity Cache
 static long long g_nt_bytes = 256ll << 20;
+// the tile kernels read a row's (value, offset) pairs with 8 lanes per row:
+// a cache line is touched by up to four consecutive load instructions of a
+// wave, so the loads keep the default cache policy (PCD_VT_NT=1: non-temporal
+// like the stream kernels - every touch then goes back to L2 / HBM)
+static int g_vt_nt = 0;
 static int g_num_cus = 256;
 static int ensure_pinned(Engine* h, size_t n) {
   if (n <= h->pinned_n) return 0;
@@ -530,9 +535,9 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
     const int gt = grid_stream(A.vt_blocks, 1);
 #define PCD_SPMV_TC(NT)                                                                       \
     hipLaunchKernelGGL((k_spmv_tc<MODE, NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,       \
-                       A.vt_blocks, A.vt_start.p, A.rowptr2.p, A.val2.p, A.vt_loc.p,          \
-                       A.vt_segptr.p, A.vt_seg.p, x, ghost, nloc, add, y)
-    if (A.nt2) PCD_SPMV_TC(true); else PCD_SPMV_TC(false);
+                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
+                       A.vt_loc.p, x, ghost, nloc, add, y)
+    if (A.nt2 && g_vt_nt) PCD_SPMV_TC(true); else PCD_SPMV_TC(false);
 #undef PCD_SPMV_TC
     return;
   }
@@ -735,10 +740,10 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
     const int nloc = (int)(A.ncols / A.kron);
 #define PCD_CHEB_TC(NC, NT)                                                                   \
     hipLaunchKernelGGL((k_cheb_step_tc<NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,        \
-                       A.vt_blocks, A.vt_start.p, A.rowptr2.p, A.val2.p, A.vt_loc.p,          \
-                       A.vt_segptr.p, A.vt_seg.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
-    if (A.kron == 2) { if (A.nt2) PCD_CHEB_TC(2, true); else PCD_CHEB_TC(2, false); }
-    else { if (A.nt2) PCD_CHEB_TC(3, true); else PCD_CHEB_TC(3, false); }
+                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
+                       A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
+    if (A.kron == 2) { if (A.nt2 && g_vt_nt) PCD_CHEB_TC(2, true); else PCD_CHEB_TC(2, false); }
+    else { if (A.nt2 && g_vt_nt) PCD_CHEB_TC(3, true); else PCD_CHEB_TC(3, false); }
 #undef PCD_CHEB_TC
   } else if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
@@ -769,10 +774,10 @@ static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
     const int nn = n / A.kron;
 #define PCD_FIRST_TC(NC, NT)                                                                  \
     hipLaunchKernelGGL((k_cheb_first_tc<NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,       \
-                       A.vt_blocks, A.vt_start.p, A.rowptr2.p, A.val2s.p, A.vt_loc.p,         \
-                       A.vt_segptr.p, A.vt_seg.p, dinv, b, p0, pn, s, c1, c2, nn)
-    if (A.kron == 2) { if (A.nt2) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
-    else { if (A.nt2) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
+                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2s.p,        \
+                       A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, nn)
+    if (A.kron == 2) { if (A.nt2 && g_vt_nt) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
+    else { if (A.nt2 && g_vt_nt) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
 #undef PCD_FIRST_TC
     return;
   }
@@ -1405,9 +1410,8 @@ static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* ro
 // LDS-staged vector tiles (pcd_kernels.hpp): row blocks of the scalar stencil
 // F chosen greedily - rows are added while the block's distinct columns fit
 // the tile (kVtNodes), its entries the entry buffer (kVtEntries) and its rows
-// the workgroup (kVtRows) -, per block the maximal runs of consecutive columns
-// (never across the owned / ghost boundary `nloc`) and per entry the offset of
-// its column in the tile.  PCD_VEC_TILE: 0 off, 1 three-component operators
+// the workgroup (kVtRows) -, per block its distinct columns in ascending order
+// (the tile's sources) and per entry the offset of its column in the tile.  PCD_VEC_TILE: 0 off, 1 three-component operators
 // of at least PCD_VEC_TILE_ROWS node rows (default), 2 every F (x) I operator.
 static int g_vec_tile = 1;
 static long long g_vec_tile_rows = 200000;
@@ -1416,16 +1420,24 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   A.vt = false; A.vt_blocks = 0;
   { const char* e = getenv("PCD_VEC_TILE"); if (e) g_vec_tile = atoi(e); }
   { const char* e = getenv("PCD_VEC_TILE_ROWS"); if (e) g_vec_tile_rows = atoll(e); }
-  if (!g_vec_tile || (g_vec_tile == 1 && (nc != 3 || nn < g_vec_tile_rows))) return 0;
+  { const char* e = getenv("PCD_VT_NT"); if (e) g_vt_nt = atoi(e); }
+  // default: three-component operators that are large enough to fill the chip
+  // AND whose launch stays inside the Infinity Cache (not nt2).  Measured,
+  // k_cheb_step on the finest A00 of the unit cube (profiles/r04_e_*, r04_f_*):
+  // N = 32 (90 MB per launch) 34.9 -> 31.8 us, texture-addresser stalls
+  // 2.3 M -> 0.12 M cycles; N = 48 (428 MB per launch, HBM-bound) 110.6 ->
+  // 116.7 us: there both kernels move the same bytes and the stream kernel's
+  // fully coalesced non-temporal loads win.
+  if (!g_vec_tile || (g_vec_tile == 1 && (nc != 3 || nn < g_vec_tile_rows || A.nt2))) return 0;
   if (nn < 1 || A.dense2 || A.long_rows || A.wave_rows) return 0;
   // independent super-blocks of rows: block boundaries restart at multiples of
   // kSuper rows, so the host threads need no hand-over and the result does not
   // depend on their number
   constexpr int64_t kSuper = 8192;
   const int64_t nsup = (nn + kSuper - 1) / kSuper;
-  std::vector<std::vector<int32_t>> b_start(nsup);
-  std::vector<std::vector<int32_t>> b_nseg(nsup);           // segments (+ sentinel) per block
-  std::vector<std::vector<int2>> b_seg(nsup);
+  struct Blk { int32_t r0, nr, k0, tn; };
+  std::vector<std::vector<Blk>> b_desc(nsup);
+  std::vector<std::vector<int32_t>> b_src(nsup);             // tile sources, block after block
   std::vector<unsigned short> loc(cc.size());
   std::atomic<bool> ok{true};
   parallel_chunks(nsup, [&](int64_t s0, int64_t s1) {
@@ -1441,7 +1453,7 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
         while (r1 < rz && r1 - r < kVtRows) {
           const size_t before = cols.size();
           cols.insert(cols.end(), cc.begin() + rpc[r1], cc.begin() + rpc[r1 + 1]);
-          if ((int64_t)cols.size() > kVtEntries) { cols.resize(before); break; }
+          if (cols.size() > 60000) { cols.resize(before); break; }      // (16-bit row offsets)
           uniq.assign(cols.begin(), cols.end());
           std::sort(uniq.begin(), uniq.end());
           uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
@@ -1454,16 +1466,8 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
         uniq.assign(cols.begin(), cols.end());
         std::sort(uniq.begin(), uniq.end());
         uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-        // runs of consecutive columns
-        int nseg = 0;
-        for (size_t q = 0; q < uniq.size(); ++q)
-          if (q == 0 || uniq[q] != uniq[q - 1] + 1 || uniq[q] == (int32_t)nloc) {
-            b_seg[sb].push_back(int2{uniq[q], (int)q});
-            ++nseg;
-          }
-        b_seg[sb].push_back(int2{-1, (int)uniq.size()});   // sentinel: tile size
-        b_nseg[sb].push_back(nseg + 1);
-        b_start[sb].push_back((int32_t)r);
+        b_src[sb].insert(b_src[sb].end(), uniq.begin(), uniq.end());
+        b_desc[sb].push_back(Blk{(int32_t)r, (int32_t)(r1 - r), rpc[r], (int32_t)uniq.size()});
         for (int32_t k = rpc[r]; k < rpc[r1]; ++k)
           loc[k] = (unsigned short)(std::lower_bound(uniq.begin(), uniq.end(), cc[k]) - uniq.begin());
         r = r1;
@@ -1471,20 +1475,41 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
     }
   });
   if (!ok.load()) return 0;
-  std::vector<int32_t> start, segptr(1, 0);
-  std::vector<int2> seg;
+  std::vector<int4> desc;
+  std::vector<int32_t> tsrc;
+  std::vector<unsigned short> rowoff;
   for (int64_t sb = 0; sb < nsup; ++sb) {
-    start.insert(start.end(), b_start[sb].begin(), b_start[sb].end());
-    for (int32_t c : b_nseg[sb]) segptr.push_back(segptr.back() + c);
-    seg.insert(seg.end(), b_seg[sb].begin(), b_seg[sb].end());
+    for (const Blk& b : b_desc[sb]) {
+      if (tsrc.size() + b.tn > (size_t)INT32_MAX) return 0;
+      desc.push_back(int4{b.r0, b.k0, (int)tsrc.size(), b.nr | (b.tn << 8)});
+      tsrc.resize(tsrc.size() + b.tn);
+      const size_t at = rowoff.size();
+      rowoff.resize(at + kVtRowOff, 0);
+      for (int i = 0; i <= b.nr; ++i) rowoff[at + i] = (unsigned short)(rpc[b.r0 + i] - b.k0);
+      for (int i = b.nr + 1; i < kVtRowOff; ++i) rowoff[at + i] = rowoff[at + b.nr];
+    }
   }
-  start.push_back((int32_t)nn);
-  A.vt_blocks = (int)start.size() - 1;
-  CHK(A.vt_start.ensure(start.size())); CHK(A.vt_segptr.ensure(segptr.size()));
-  CHK(A.vt_seg.ensure(seg.size())); CHK(A.vt_loc.ensure(loc.size()));
-  HIPCHK(hipMemcpy(A.vt_start.p, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(A.vt_segptr.p, segptr.data(), segptr.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(A.vt_seg.p, seg.data(), seg.size() * sizeof(int2), hipMemcpyHostToDevice));
+  {
+    size_t at = 0;
+    for (int64_t sb = 0; sb < nsup; ++sb) {
+      std::copy(b_src[sb].begin(), b_src[sb].end(), tsrc.begin() + at);
+      at += b_src[sb].size();
+    }
+  }
+  A.vt_blocks = (int)desc.size();
+  if (const char* e = getenv("PCD_VEC_TILE_STATS")) if (e[0] == '1') {
+    int full = 0;
+    for (const int4& d : desc) full += (d.w & 0xff) == kVtRows;
+    fprintf(stderr, "[pcd vec tile] %lld node rows x %d comps: %zu blocks, %.1f rows, %.0f tile nodes "
+                    "per block on average; %.0f %% of the blocks full (%d rows)\n",
+            (long long)nn, nc, desc.size(), (double)nn / desc.size(), (double)tsrc.size() / desc.size(),
+            100.0 * full / desc.size(), kVtRows);
+  }
+  CHK(A.vt_desc.ensure(desc.size())); CHK(A.vt_rowoff.ensure(rowoff.size()));
+  CHK(A.vt_tsrc.ensure(tsrc.size())); CHK(A.vt_loc.ensure(loc.size()));
+  HIPCHK(hipMemcpy(A.vt_desc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(A.vt_rowoff.p, rowoff.data(), rowoff.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(A.vt_tsrc.p, tsrc.data(), tsrc.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(A.vt_loc.p, loc.data(), loc.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   A.vt = true;
   return 0;

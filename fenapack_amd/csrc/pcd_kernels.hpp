@@ -893,56 +893,89 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
 // bounds the kernel (profiles/r02_s_*: TA busy 61 %).  Here the set-up gives
 // every row block the list of CONTIGUOUS column segments it touches
 // (pcd_engine.hip build_vec_tile): the workgroup loads those segments into
-// LDS with coalesced loads - every line once per block -, streams (value,
-// 16-bit tile offset) pairs into LDS as well, and the row sums read both from
-// LDS.  No product array, two barriers per block, 10 B instead of 12 B of
-// matrix stream per entry.
-//   blocks:  rows [rb_start[b], rb_start[b+1]) (<= kVtRows), chosen greedily
-//            so that the tile holds <= kVtNodes nodes and <= kVtEntries entries
-//   seg:     int2 (start node, tile offset) per segment + one sentinel per
-//            block (its tile offset = number of tile nodes); nodes >= nloc
-//            live in `ghost`
+// LDS with coalesced loads - every line once per block - and the row sums
+// gather from the tile with 16-bit offsets instead of from L1 / L2
+// LDS; (value, offset) pairs come straight from the matrix stream.  No product
+// array, 10 B instead of 12 B of matrix stream per entry.
+//   blocks:  <= kVtRows consecutive rows, chosen greedily so that the tile
+//            holds <= kVtNodes nodes
+//   tsrc:    vector node of every tile slot (ascending: runs of consecutive
+//            nodes); nodes >= nloc live in `ghost`
+//   rowoff:  entry offsets of the block's rows relative to its first entry
 //   loc:     tile offset of every entry's column (uint16)
 // ==========================================================================
 constexpr int kVtRows = 32;        // rows per block (8 lanes share a row)
 constexpr int kVtNodes = 768;      // tile nodes (x NC doubles)
-constexpr int kVtEntries = 1024;   // entries per block
-
+constexpr int kVtRowOff = 34;      // row offsets per block (kVtRows + 1, padded)
+static_assert(kVtNodes % kBlock == 0, "one lane per tile node, whole passes");
+// per block: x = first row, y = first entry, z = first slot in `tsrc`,
+// w = rows | tile nodes << 8.  tsrc[z + t] = vector node of tile slot t (the
+// block's distinct columns, ascending: runs of consecutive nodes, so a wave's
+// loads of the vector are coalesced).  A block costs two dependent memory
+// round trips after its descriptor: (row offsets, tile sources, epilogue
+// operands), then (vector tile, matrix entries).  Earlier forms: a loop over
+// segment descriptors serialised one load latency per segment (70 us per
+// launch at cube N = 32 against 35 for the gather kernel); a binary search of
+// the segments in LDS per tile slot (35 us: the LDS waits took the place of
+// the texture-addresser stalls, profiles/r04_f_*).
 template <int NC, bool NT>
 __device__ __forceinline__ VecC<NC> tile_row_block(
-    int r0, int r1, const int* __restrict__ rowptr,
-    const double* __restrict__ val, const unsigned short* __restrict__ loc,
-    const int2* __restrict__ seg, int s0, int s1, const double* x,
-    const double* ghost, int nloc, double* tile, double* ev,
-    unsigned short* el) {
-  const int k0 = rowptr[r0], k1 = rowptr[r1];
+    const int4 d, const unsigned short* __restrict__ rowoff, int blk,
+    const int* __restrict__ tsrc, const double* __restrict__ val,
+    const unsigned short* __restrict__ loc, const double* x,
+    const double* ghost, int nloc, double* tile) {
   constexpr int TPR = kBlock / kVtRows;
-  const int row = r0 + threadIdx.x / TPR;
-  const int sub = threadIdx.x % TPR;
-  const bool mine = row < r1;
-  const int ra = mine ? rowptr[row] - k0 : 0;
-  const int rb = mine ? rowptr[row + 1] - k0 : 0;
-  // A1: the block's column segments -> LDS planes (component-major), coalesced
-  for (int s = s0; s < s1 - 1; ++s) {
-    const int2 sg = seg[s];
-    const int len = seg[s + 1].y - sg.y;
-    const double* src = sg.x < nloc ? x + (size_t)NC * sg.x
-                                    : ghost + (size_t)NC * (sg.x - nloc);
-    for (int i = threadIdx.x; i < NC * len; i += kBlock)
-      tile[(i % NC) * kVtNodes + sg.y + i / NC] = src[i];
+  const int lr = threadIdx.x / TPR, sub = threadIdx.x % TPR;
+  const int k0 = d.y, nr = d.w & 0xff, tn = d.w >> 8;
+  const bool mine = lr < nr;
+  const int ra = mine ? rowoff[blk * kVtRowOff + lr] : 0;
+  const int rb = mine ? rowoff[blk * kVtRowOff + lr + 1] : 0;
+  int node[kVtNodes / kBlock];
+#pragma unroll
+  for (int u = 0; u < kVtNodes / kBlock; ++u) {
+    const int t = threadIdx.x + u * kBlock;
+    node[u] = t < tn ? tsrc[d.z + t] : -1;
   }
-  // A2: (value, tile offset) of every entry, streamed once
-  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
-    ev[k - k0] = stream_load<NT>(val + k);
-    el[k - k0] = stream_load<NT>(loc + k);
+  const double* src[kVtNodes / kBlock];
+#pragma unroll
+  for (int u = 0; u < kVtNodes / kBlock; ++u)
+    src[u] = node[u] < 0 ? nullptr
+             : (node[u] < nloc ? x + (size_t)NC * node[u] : ghost + (size_t)NC * (node[u] - nloc));
+  double tv[kVtNodes / kBlock][NC];
+#pragma unroll
+  for (int u = 0; u < kVtNodes / kBlock; ++u)
+#pragma unroll
+    for (int i = 0; i < NC; ++i) tv[u][i] = src[u] ? src[u][i] : 0.0;
+  // the first entries of my row: (value, tile offset), straight from the
+  // stream (8 lanes of a row read 64 + 16 contiguous bytes per step)
+  constexpr int U = 4;
+  double v[U];
+  int o[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int jj = ra + sub + u * TPR;
+    const bool in = jj < rb;
+    v[u] = in ? stream_load<NT>(val + k0 + jj) : 0.0;
+    o[u] = in ? (int)stream_load<NT>(loc + k0 + jj) : 0;
   }
+#pragma unroll
+  for (int u = 0; u < kVtNodes / kBlock; ++u)
+    if (src[u]) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
+    }
   __syncthreads();
   VecC<NC> s = vzero<NC>();
-  for (int j = ra + sub; j < rb; j += TPR) {
-    const double v = ev[j];
-    const int o = el[j];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) s.c[i] += v * tile[i * kVtNodes + o];
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] += v[u] * tile[i * kVtNodes + o[u]];
+  }
+  for (int jj = ra + sub + U * TPR; jj < rb; jj += TPR) {     // long rows
+    const double vv = stream_load<NT>(val + k0 + jj);
+    const int oo = stream_load<NT>(loc + k0 + jj);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
   }
 #pragma unroll
   for (int m = TPR / 2; m > 0; m >>= 1) {
@@ -952,17 +985,16 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   return s;
 }
 
-#define PCD_VT_SHARED(NC)                                   \
-  __shared__ double tile[NC * kVtNodes];                    \
-  __shared__ double ev[kVtEntries];                         \
-  __shared__ unsigned short el[kVtEntries]
+#define PCD_VT_SHARED(NC) __shared__ double tile[NC * kVtNodes]
+
+#define PCD_VT_ARGS                                                                   \
+  int nblocks, const int4* __restrict__ desc, const unsigned short* __restrict__ rowoff, \
+  const int* __restrict__ tsrc, const double* __restrict__ val,                        \
+  const unsigned short* __restrict__ loc
 
 template <int MODE, int NC, bool NT>
 __global__ __launch_bounds__(kBlock) void k_spmv_tc(
-    int nblocks, const int* __restrict__ rb_start, const int* __restrict__ rowptr,
-    const double* __restrict__ val, const unsigned short* __restrict__ loc,
-    const int* __restrict__ segptr, const int2* __restrict__ seg,
-    const double* x, const double* ghost, int nloc, const double* add_,
+    PCD_VT_ARGS, const double* x, const double* ghost, int nloc, const double* add_,
     double* y_) {
   PCD_VT_SHARED(NC);
   const VecC<NC>* add = vc<NC>(add_);
@@ -970,13 +1002,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tc(
   int b0, b1;
   row_block_range(nblocks, kVtRows, b0, b1, true);
   for (int blk = b0; blk < b1; ++blk) {
-    const int r0 = rb_start[blk], r1 = rb_start[blk + 1];
-    const int row = r0 + threadIdx.x / (kBlock / kVtRows);
-    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && row < r1;
+    const int4 d = desc[blk];
+    const int lr = threadIdx.x / (kBlock / kVtRows);
+    const int row = d.x + lr;
+    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && lr < (d.w & 0xff);
     VecC<NC> a = vzero<NC>();
     if ((MODE == 1 || MODE == 2) && mine) a = add[row];
-    const VecC<NC> s = tile_row_block<NC, NT>(r0, r1, rowptr, val, loc, seg, segptr[blk],
-                                              segptr[blk + 1], x, ghost, nloc, tile, ev, el);
+    const VecC<NC> s = tile_row_block<NC, NT>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -991,10 +1023,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tc(
 
 template <int NC, bool NT>
 __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
-    int nblocks, const int* __restrict__ rb_start, const int* __restrict__ rowptr,
-    const double* __restrict__ val, const unsigned short* __restrict__ loc,
-    const int* __restrict__ segptr, const int2* __restrict__ seg,
-    const double* __restrict__ dinv_, const double* b_, const double* pm_,
+    PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, const double* pm_,
     const double* pk_, double* pn_, double c0, double c1, double c2,
     const double* ghost, int nloc) {
   PCD_VT_SHARED(NC);
@@ -1004,16 +1033,16 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
   int b0, b1;
   row_block_range(nblocks, kVtRows, b0, b1, true);
   for (int blk = b0; blk < b1; ++blk) {
-    const int r0 = rb_start[blk], r1 = rb_start[blk + 1];
-    const int row = r0 + threadIdx.x / (kBlock / kVtRows);
-    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && row < r1;
+    const int4 d4 = desc[blk];
+    const int lr = threadIdx.x / (kBlock / kVtRows);
+    const int row = d4.x + lr;
+    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && lr < (d4.w & 0xff);
     VecC<NC> bi = vzero<NC>(), d = bi, xk = bi, xm = bi;
     if (mine) {
       bi = b[row]; d = dinv[row]; xk = pk[row];
       if (c0 != 0.0) xm = pm[row];
     }
-    const VecC<NC> s = tile_row_block<NC, NT>(r0, r1, rowptr, val, loc, seg, segptr[blk],
-                                              segptr[blk + 1], pk_, ghost, nloc, tile, ev, el);
+    const VecC<NC> s = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -1027,25 +1056,22 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
 
 template <int NC, bool NT>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
-    int nblocks, const int* __restrict__ rb_start, const int* __restrict__ rowptr,
-    const double* __restrict__ vals, const unsigned short* __restrict__ loc,
-    const int* __restrict__ segptr, const int2* __restrict__ seg,
-    const double* __restrict__ dinv_, const double* b_, double* p0_, double* pn_,
-    double s, double c1, double c2, int nrows) {
+    PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, double* p0_,
+    double* pn_, double s, double c1, double c2, int nrows) {
   PCD_VT_SHARED(NC);
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   int b0, b1;
   row_block_range(nblocks, kVtRows, b0, b1, true);
   for (int blk = b0; blk < b1; ++blk) {
-    const int r0 = rb_start[blk], r1 = rb_start[blk + 1];
-    const int row = r0 + threadIdx.x / (kBlock / kVtRows);
-    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && row < r1;
+    const int4 d4 = desc[blk];
+    const int lr = threadIdx.x / (kBlock / kVtRows);
+    const int row = d4.x + lr;
+    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && lr < (d4.w & 0xff);
     VecC<NC> d = vzero<NC>(), bi = d;
     if (mine) { d = dinv[row]; bi = b[row]; }
     // (vals carry D^-1 by columns: the gathered vector is b alone; no halo)
-    const VecC<NC> sum = tile_row_block<NC, NT>(r0, r1, rowptr, vals, loc, seg, segptr[blk],
-                                                segptr[blk + 1], b_, b_, nrows, tile, ev, el);
+    const VecC<NC> sum = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, b_, b_, nrows, tile);
     if (mine) {
       VecC<NC> x0, o;
 #pragma unroll
