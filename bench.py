@@ -364,9 +364,13 @@ def main():
     nnz_a00 = int(eng.info(c.INFO_NNZ_BASE + c.MAT_A00))
     ncomp = int(eng.info(c.INFO_A00_COMPONENTS))
     rows_wg = int(eng.info(c.INFO_A00_ROWS_PER_WG))
-    kernel_name = ("pcd::k_cheb_step_sc<%d, %d>" % (rows_wg, ncomp)) if ncomp \
-        else ("pcd::k_cheb_step_s<%d>" % rows_wg if rows_wg
-              else "pcd::k_cheb_step<LPR>")
+    if ncomp and rows_wg < 0:              # LDS-staged vector tiles
+        kernel_name = "pcd::k_cheb_step_tc<%d> (%d-row blocks)" % (ncomp,
+                                                                   -rows_wg)
+    else:
+        kernel_name = ("pcd::k_cheb_step_sc<%d, %d>" % (rows_wg, ncomp)) \
+            if ncomp else ("pcd::k_cheb_step_s<%d>" % rows_wg if rows_wg
+                           else "pcd::k_cheb_step<LPR>")
     kernel_name += " on the finest A00"
     b_kernel = rf.b_cheb(V.n_u, nnz_a00) / world      # per GPU
     achieved = b_kernel / t_kernel / 1e9

@@ -3158,6 +3158,7 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_REORDERED: *out = (h->ru.active() ? 1.0 : 0.0) + (h->rp.active() ? 2.0 : 0.0); return 0;
     case PCD_INFO_A00_ROWS_PER_WG:
       *out = (double)(h->mat[PCD_MAT_A00].kron ? h->mat[PCD_MAT_A00].rb2 : h->mat[PCD_MAT_A00].rb);
+      if (h->mat[PCD_MAT_A00].kron && h->mat[PCD_MAT_A00].vt) *out = -(double)kVtRows;
       return 0;
     default:
       if (key >= PCD_INFO_NNZ_BASE && key < PCD_INFO_NNZ_BASE + PCD_MAT_COUNT) {

@@ -88,7 +88,8 @@ enum pcd_info {
   PCD_INFO_N_U_LOCAL = 10, PCD_INFO_N_P_LOCAL = 11,  /* rows of this rank */
   /* kernel path of the velocity block: components carried together by the
    * multi-component kernels (2 / 3; 0 = scalar path) and rows (nodes) per
-   * workgroup of its stream kernels (0 = CSR-vector fallback) */
+   * workgroup of its stream kernels (0 = CSR-vector fallback; negative: rows
+   * per block of the LDS-staged vector-tile kernels k_*_tc) */
   PCD_INFO_A00_COMPONENTS = 12, PCD_INFO_A00_ROWS_PER_WG = 13,
   PCD_INFO_RANKS = 14,       /* ranks of the attached communicator (0: none) */
   PCD_INFO_REORDERED = 15,   /* engine renumbering active: +1 velocity, +2 pressure */
