@@ -81,6 +81,7 @@ _HIP_ONLY = {
     "set_stream": [C.c_void_p],
     "comm_init": [C.c_int, C.c_int, C.c_void_p],
     "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
+    "comm_init_host": [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "graph_enable": [C.c_int],
     "bandwidth_probe": [C.c_int, C.c_int64, C.c_int, _f64p],
     "set_velocity_block": [C.c_int],
@@ -667,6 +668,48 @@ class Engine(object):
         """Test backend; ``group`` is a ``ctypes.c_void_p`` shared by all."""
         self._call("comm_init_threads", int(rank), int(nranks),
                    C.byref(group))
+
+    def comm_init_host(self, rank, nranks, transport):
+        """Communicator over a host transport (``pcd_comm_init_host``):
+        ``transport.allreduce(array)`` sums a float64 array in place over the
+        ranks, ``transport.exchange(sends, recvs)`` with lists of ``(peer,
+        array)`` is one neighbour exchange (``parallel.TorchHostTransport``;
+        an mpi4py communicator wraps the same way)."""
+        def ar(ctx, buf, count):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(int(count),))
+                transport.allreduce(a)
+                return 0
+            except Exception:               # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def ex(ctx, ns, sp, sb, sc, nr, rp, rb, rc):
+            try:
+                sends = [(int(sp[i]), np.ctypeslib.as_array(
+                    sb[i], shape=(int(sc[i]),)) if sc[i] else np.zeros(0))
+                    for i in range(ns)]
+                recvs = [(int(rp[i]), np.ctypeslib.as_array(
+                    rb[i], shape=(int(rc[i]),)) if rc[i] else np.zeros(0))
+                    for i in range(nr)]
+                transport.exchange(sends, recvs)
+                return 0
+            except Exception:               # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        dp = C.POINTER(C.c_double)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, C.c_int64)
+        EX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                         C.POINTER(dp), C.POINTER(C.c_int64), C.c_int,
+                         C.POINTER(C.c_int), C.POINTER(dp),
+                         C.POINTER(C.c_int64))
+        # (the callbacks must outlive the communicator)
+        self._host_cbs = (AR(ar), EX(ex), transport)
+        self._call("comm_init_host", int(rank), int(nranks),
+                   C.cast(self._host_cbs[0], C.c_void_p),
+                   C.cast(self._host_cbs[1], C.c_void_p), None)
 
     # -- numpy conveniences used by tests ------------------------------------
     def apply_np(self, x):

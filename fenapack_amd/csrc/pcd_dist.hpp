@@ -195,6 +195,8 @@ struct CommBackend {
   int rank = 0, nranks = 1;
   std::string err;
   virtual ~CommBackend() {}
+  // one-shot peer-write halos / reductions available (pcd_peer.hpp)
+  virtual bool peer() const { return false; }
   // in-place sum over ranks of a device buffer, enqueued on `s`
   virtual int allreduce(double* dbuf, size_t count, hipStream_t s) = 0;
   // all sends and receives of one halo exchange, enqueued on `s`
@@ -403,6 +405,65 @@ struct RcclBackend : CommBackend {
   }
 };
 
+// Host transport supplied by the caller (pcd_comm_init_host): two callbacks on
+// HOST buffers - what an application that already owns an MPI communicator
+// (the reference: PETSc's, through mpi4py) or a torch.distributed process
+// group plugs in.  Device buffers are staged through the host, so this
+// backend alone is a slow path; its role is the BOOTSTRAP of the peer
+// protocol (pcd_peer.hpp), which then carries the hot path between the
+// processes of a node - including two processes that share ONE GPU, where
+// RCCL refuses to build a communicator.
+typedef int (*host_allreduce_fn)(void* ctx, double* buf, int64_t count);
+typedef int (*host_exchange_fn)(void* ctx, int nsend, const int* send_peers,
+                                double* const* send_bufs, const int64_t* send_counts,
+                                int nrecv, const int* recv_peers, double* const* recv_bufs,
+                                const int64_t* recv_counts);
+struct HostBackend : CommBackend {
+  host_allreduce_fn ar = nullptr;
+  host_exchange_fn ex = nullptr;
+  void* ctx = nullptr;
+  int fail(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+  }
+  int allreduce(double* dbuf, size_t count, hipStream_t s) override {
+    std::vector<double> hb(count);
+    if (fail(hipMemcpyAsync(hb.data(), dbuf, count * sizeof(double), hipMemcpyDeviceToHost, s), "memcpy") ||
+        fail(hipStreamSynchronize(s), "sync")) return 1;
+    if (ar(ctx, hb.data(), (int64_t)count)) { err = "host all-reduce callback failed"; return 1; }
+    if (fail(hipMemcpyAsync(dbuf, hb.data(), count * sizeof(double), hipMemcpyHostToDevice, s), "memcpy") ||
+        fail(hipStreamSynchronize(s), "sync")) return 1;
+    return 0;
+  }
+  int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs,
+               hipStream_t s) override {
+    std::vector<std::vector<double>> sb(sends.size()), rb(recvs.size());
+    std::vector<int> sp, rp;
+    std::vector<double*> sptr, rptr;
+    std::vector<int64_t> sc, rc;
+    for (size_t i = 0; i < sends.size(); ++i) {
+      sb[i].resize(sends[i].count);
+      if (sends[i].count &&
+          fail(hipMemcpyAsync(sb[i].data(), sends[i].ptr, sends[i].count * sizeof(double),
+                              hipMemcpyDeviceToHost, s), "memcpy")) return 1;
+      sp.push_back(sends[i].peer); sptr.push_back(sb[i].data()); sc.push_back((int64_t)sends[i].count);
+    }
+    for (size_t i = 0; i < recvs.size(); ++i) {
+      rb[i].resize(recvs[i].count);
+      rp.push_back(recvs[i].peer); rptr.push_back(rb[i].data()); rc.push_back((int64_t)recvs[i].count);
+    }
+    if (fail(hipStreamSynchronize(s), "sync")) return 1;
+    if (ex(ctx, (int)sends.size(), sp.data(), sptr.data(), sc.data(), (int)recvs.size(), rp.data(),
+           rptr.data(), rc.data())) { err = "host exchange callback failed"; return 1; }
+    for (size_t i = 0; i < recvs.size(); ++i)
+      if (recvs[i].count &&
+          fail(hipMemcpyAsync(recvs[i].ptr, rb[i].data(), recvs[i].count * sizeof(double),
+                              hipMemcpyHostToDevice, s), "memcpy")) return 1;
+    return fail(hipStreamSynchronize(s), "sync");
+  }
+};
+
 // In-process stand-in: R threads, one engine each, one GPU.  Used by the tests
 // only (RCCL refuses two ranks on one device).  Nothing synchronises a stream:
 // the ranks meet at host barriers to publish pointers, and the ordering of the
@@ -417,9 +478,10 @@ struct ThreadGroup {
   std::vector<std::vector<Msg>> sends;               // posted sends per rank
   std::vector<hipEvent_t> ev_ready, ev_done;         // per rank
   std::vector<hipStream_t> stream;                   // the stream each rank enqueues on
+  std::vector<char*> arenas;                         // peer protocol (pcd_peer.hpp): every rank's arena
   explicit ThreadGroup(int n)
       : nranks(n), ar_buf(n, nullptr), sends(n), ev_ready(n, nullptr), ev_done(n, nullptr),
-        stream(n, nullptr) {}
+        stream(n, nullptr), arenas(n, nullptr) {}
   // all ranks on ONE in-order stream (the tests' default: the null stream):
   // enqueue order is execution order, the host barriers alone order the work
   bool one_stream() const {

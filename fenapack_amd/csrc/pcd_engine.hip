@@ -18,6 +18,7 @@
 #include "pcd_kernels.hpp"
 #include "pcd_fe.hpp"
 #include "pcd_dist.hpp"
+#include "pcd_peer.hpp"
 #include "pcd_reorder.hpp"
 
 using namespace pcd;
@@ -140,6 +141,7 @@ struct DCsr {
   int64_t gnnz = 0;       // nonzeros of the GLOBAL matrix (value updates)
   DBuf<double> ghost, sendbuf;
   DBuf<int> send_idx;
+  PeerHalo ph;            // one-shot peer-write channel of this operator's halo (pcd_peer.hpp)
   void release() {
     rowptr.release(); col.release(); val.release(); dinv.release();
     vals.release(); val2s.release();
@@ -148,6 +150,8 @@ struct DCsr {
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
     vt = false; vt_blocks = 0; vt_desc.release(); vt_rowoff.release(); vt_tsrc.release(); vt_loc.release();
     plan = HaloPlan(); replicated = false;
+    if (ph.dev.seq) (void)hipFree(ph.dev.seq);
+    ph = PeerHalo();
     set = false; nrows = ncols = nnz = 0; has_src = false; val_src = false;
   }
 };
@@ -283,6 +287,12 @@ struct pcd_engine_s {
   hipGraphExec_t gexec = nullptr;
   hipStream_t cap_stream = nullptr;
   uint64_t gen = 1, ggen = 0;        // configuration generation / captured one
+  // several ranks: a PCApply is captured only when every exchange and
+  // reduction in it is a kernel of this stream (peer protocol, pcd_peer.hpp);
+  // the first apply of a configuration runs eagerly and counts the others
+  long boot_exchanges = 0;
+  uint64_t gcheck_gen = 0;
+  bool g_ok = false;
   int gmres_its = 0;
   double gmres_rnorm = 0.0;
 };
@@ -438,6 +448,13 @@ static void halo_collect(Engine* h, const DCsr& A, const double* x,
 }
 static int halo_exchange(Engine* h, const DCsr& A, const double* x) {
   if (!h->comm || A.replicated) return 0;
+  if (A.ph.ready && static_cast<PeerBackend*>(h->comm)->usable(h->stream)) {
+    // one kernel: pack, remote store, signal, wait, land
+    PeerBackend* pb = static_cast<PeerBackend*>(h->comm);
+    if (pb->halo(A.ph, x, h->stream)) return fail(PCD_ERR_COMM, "halo exchange: %s", pb->err.c_str());
+    return 0;
+  }
+  h->boot_exchanges++;
   std::vector<Msg> sends, recvs;
   halo_collect(h, A, x, sends, recvs);
   if (h->comm->exchange(sends, recvs, h->stream))
@@ -450,8 +467,18 @@ struct HaloItem { const DCsr* A; const double* x; };
 static int halo_exchange_group(Engine* h, std::initializer_list<HaloItem> items) {
   if (!h->comm) return 0;
   std::vector<Msg> sends, recvs;
-  for (const HaloItem& it : items)
-    if (it.A->set && !it.A->replicated) halo_collect(h, *it.A, it.x, sends, recvs);
+  bool any = false;
+  for (const HaloItem& it : items) {
+    if (!it.A->set || it.A->replicated) continue;
+    if (it.A->ph.ready && static_cast<PeerBackend*>(h->comm)->usable(h->stream)) {
+      CHK(halo_exchange(h, *it.A, it.x));
+      continue;
+    }
+    halo_collect(h, *it.A, it.x, sends, recvs);
+    any = true;
+  }
+  if (!any) return 0;
+  h->boot_exchanges++;
   if (h->comm->exchange(sends, recvs, h->stream))
     return fail(PCD_ERR_COMM, "halo exchange: %s", h->comm->err.c_str());
   return 0;
@@ -1291,7 +1318,19 @@ static bool graph_capturable(const Engine* h) {
 
 static int fs_apply_split(Engine* h, const double* x, double* y) {
   ++h->num_fs;
-  if (!h->graph_on || h->comm || !graph_capturable(h)) return fs_apply_eager(h, x, y);
+  if (!h->graph_on || !graph_capturable(h)) return fs_apply_eager(h, x, y);
+  if (h->comm) {
+    if (!h->comm->peer()) return fs_apply_eager(h, x, y);
+    PeerBackend* pb = static_cast<PeerBackend*>(h->comm);
+    if (h->gcheck_gen != h->gen) {
+      pb->boot_calls = 0; h->boot_exchanges = 0;
+      const int rc = fs_apply_eager(h, x, y);
+      h->gcheck_gen = h->gen;
+      h->g_ok = rc == 0 && pb->boot_calls == 0 && h->boot_exchanges == 0;
+      return rc;
+    }
+    if (!h->g_ok) return fs_apply_eager(h, x, y);
+  }
   const int n = (int)(h->nu_loc + h->np_loc);
   if (!h->gexec || h->ggen != h->gen) {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
@@ -1670,6 +1709,14 @@ static int upload_owned(Engine* h, DCsr& A, const Space* rs, const Space* cs,
   if (!plan.send_idx.empty())
     HIPCHK(hipMemcpy(A.send_idx.p, plan.send_idx.data(), plan.send_idx.size() * sizeof(int),
                      hipMemcpyHostToDevice));
+  if (A.ph.dev.seq) { (void)hipFree(A.ph.dev.seq); }
+  A.ph = PeerHalo();
+  if (h->comm->peer()) {
+    // collective: landing buffers and flags of this halo in the peers' arenas
+    PeerBackend* pb = static_cast<PeerBackend*>(h->comm);
+    if (pb->register_halo(A.plan, A.send_idx.p, A.ghost.p, A.ph, h->stream))
+      return fail(PCD_ERR_COMM, "peer halo registration: %s", pb->err.c_str());
+  }
   return 0;
 }
 
@@ -1840,10 +1887,19 @@ int pcd_set_stream(pcd_handle h, void* hip_stream) {
   return 0;
 }
 
+// several ranks, peer protocol: did a wait for a neighbour give up since the
+// last check?  (the kernels never hang: they set an error word and go on)
+static int peer_check(Engine* h) {
+  if (!h->comm || !h->comm->peer()) return 0;
+  PeerBackend* pb = static_cast<PeerBackend*>(h->comm);
+  if (pb->take_error(h->stream)) return fail(PCD_ERR_COMM, "%s", pb->err.c_str());
+  return 0;
+}
+
 int pcd_synchronize(pcd_handle h) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
+  return peer_check(h);
 }
 
 int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
@@ -3067,7 +3123,7 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
   h->gmres_its = it; h->gmres_rnorm = res;
   if (its) *its = it;
   if (rnorm) *rnorm = res;
-  return 0;
+  return peer_check(h);
 }
 
 // which -> (row space, column space) of a stored operator
@@ -3257,6 +3313,49 @@ static int comm_attach(Engine* h, CommBackend* c, int rank, int nranks) {
   return 0;
 }
 
+// Put the one-shot peer-write protocol (pcd_peer.hpp) in front of a bootstrap
+// backend.  PCD_COMM_PEER: "0" never, "1" always; default: on for one process
+// per GPU (RCCL bootstrap), off for the thread ranks of the single-GPU tests
+// (their ranks share the legacy stream unless the caller gives each one its
+// own - a kernel that waits for another rank's kernel must not sit in front
+// of it in one in-order stream).  If the arenas cannot be set up (no IPC
+// between the devices) every rank falls back to the bootstrap backend alone:
+// the decision is an all-reduce.
+static void thread_group_barrier(void* g) { static_cast<ThreadGroup*>(g)->barrier(); }
+static CommBackend* wrap_peer(Engine* h, CommBackend* boot, int rank, int nranks, ThreadGroup* tg,
+                              bool default_on) {
+  const char* e = getenv("PCD_COMM_PEER");
+  const bool want = e ? e[0] == '1' : default_on;
+  if (!want || nranks > kPeerMaxPeers) return boot;
+  size_t cap = 512ull << 20;
+  if (const char* m = getenv("PCD_PEER_ARENA_MB")) cap = (size_t)std::max(1ll, atoll(m)) << 20;
+  PeerBackend* pb = new PeerBackend();
+  pb->boot = boot; pb->rank = rank; pb->nranks = nranks;
+  boot->rank = rank; boot->nranks = nranks;
+  if (const char* t = getenv("PCD_PEER_TIMEOUT_S")) pb->spin_limit = (long long)(atof(t) * 4.0e6);
+  int bad = pb->init(cap, tg ? tg->arenas.data() : nullptr, thread_group_barrier, tg, h->stream);
+  // every rank must have its arena and its mappings, or nobody uses them
+  double flag = bad ? 1.0 : 0.0;
+  double* dflag = nullptr;
+  if (hipMalloc((void**)&dflag, sizeof(double)) == hipSuccess) {
+    (void)hipMemcpyAsync(dflag, &flag, sizeof flag, hipMemcpyHostToDevice, h->stream);
+    if (boot->allreduce(dflag, 1, h->stream) == 0) {
+      (void)hipMemcpyAsync(&flag, dflag, sizeof flag, hipMemcpyDeviceToHost, h->stream);
+      (void)hipStreamSynchronize(h->stream);
+    } else flag = 1.0;
+    (void)hipFree(dflag);
+  } else flag = 1.0;
+  if (flag != 0.0) {
+    if (getenv("PCD_COMM_VERBOSE"))
+      fprintf(stderr, "[pcd comm] rank %d: peer protocol unavailable (%s); bootstrap backend only\n",
+              rank, pb->err.c_str());
+    pb->boot = nullptr;                  // (keep the bootstrap backend alive)
+    delete pb;
+    return boot;
+  }
+  return pb;
+}
+
 int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(PCD_ERR_ARG, "comm_init: bad rank/size/id");
@@ -3272,7 +3371,20 @@ int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) {
   RcclBackend* b = new RcclBackend();
   ncclResult_t r = rccl_api().CommInitRank(&b->comm, nranks, uid, rank);
   if (r != ncclSuccess) { delete b; return fail(PCD_ERR_COMM, "ncclCommInitRank: %s", rccl_api().GetErrorString(r)); }
-  return comm_attach(h, b, rank, nranks);
+  for (auto& m : h->mat) if (m.set) { delete b; return fail(PCD_ERR_STATE, "comm_init: call before any operator is handed over"); }
+  return comm_attach(h, wrap_peer(h, b, rank, nranks, nullptr, true), rank, nranks);
+}
+
+int pcd_comm_init_host(pcd_handle h, int rank, int nranks, pcd_host_allreduce_fn allreduce,
+                       pcd_host_exchange_fn exchange, void* ctx) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (nranks < 2 || rank < 0 || rank >= nranks || !allreduce || !exchange)
+    return fail(PCD_ERR_ARG, "comm_init_host: bad rank / size / callbacks");
+  for (auto& m : h->mat) if (m.set) return fail(PCD_ERR_STATE, "comm_init: call before any operator is handed over");
+  HIPCHK(hipSetDevice(h->device));
+  HostBackend* b = new HostBackend();
+  b->ar = allreduce; b->ex = exchange; b->ctx = ctx;
+  return comm_attach(h, wrap_peer(h, b, rank, nranks, nullptr, true), rank, nranks);
 }
 
 // test-only backend: `nranks` engines of ONE process (one thread each) on one
@@ -3287,7 +3399,9 @@ int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group) {
   }
   ThreadBackend* b = new ThreadBackend();
   b->g = static_cast<ThreadGroup*>(*group);
-  return comm_attach(h, b, rank, nranks);
+  for (auto& m : h->mat) if (m.set) { delete b; return fail(PCD_ERR_STATE, "comm_init: call before any operator is handed over"); }
+  HIPCHK(hipSetDevice(h->device));
+  return comm_attach(h, wrap_peer(h, b, rank, nranks, b->g, false), rank, nranks);
 }
 
 // Host-only view of the partitioning (no device call): the row block, the

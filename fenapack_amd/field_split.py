@@ -87,8 +87,17 @@ class PCDKSP(KSP):
         self.engine.set_velocity_block(getattr(V, "dim", 2))
         import os
         forced = os.environ.get("PCD_FORCE_COMM") == "1"   # 1-rank RCCL test
-        if self.comm is not None and getattr(self.comm, "thread_group",
+        if self.comm is not None and getattr(self.comm, "stream", None):
+            self.engine.set_stream(self.comm.stream)
+        if self.comm is not None and getattr(self.comm, "host_transport",
                                              None) is not None:
+            # a host transport the caller owns (MPI / torch.distributed)
+            # bootstraps the peer-write protocol (pcd_comm_init_host)
+            self.engine.comm_init_host(self.comm.rank, self.comm.size,
+                                       self.comm.host_transport)
+            self._has_comm = True
+        elif self.comm is not None and getattr(self.comm, "thread_group",
+                                               None) is not None:
             # R ranks as R threads of this process on one GPU (tests: RCCL
             # refuses two ranks on one device)
             self.engine.comm_init_threads(self.comm.rank, self.comm.size,

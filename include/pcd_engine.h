@@ -357,6 +357,32 @@ int pcd_set_velocity_block(pcd_handle h, int ncomp);
 int pcd_comm_unique_id(void* out128);
 int pcd_comm_init(pcd_handle h, int rank, int nranks,
                   const void* nccl_unique_id);
+/* Communicator over a HOST transport the caller owns (the reference's ranks
+ * talk through PETSc's MPI communicator, PCDKSP(comm):
+ * fenapack/field_split.py:46-57): two callbacks on host buffers, collective
+ * like their MPI counterparts.
+ *   allreduce(ctx, buf, count): in-place sum of `count` doubles over all ranks
+ *   exchange(ctx, nsend, send_peers, send_bufs, send_counts,
+ *            nrecv, recv_peers, recv_bufs, recv_counts): one neighbour
+ *     exchange; several messages between one pair match in posting order
+ * (non-zero return = failure).  Device data is staged through the host for
+ * these calls, so they carry set-up traffic; the hot path between the
+ * processes of one node then runs on the one-shot peer-write protocol
+ * (csrc/pcd_peer.hpp: arenas shared through HIP IPC, halo exchange and dot
+ * products as single kernels of the engine's stream, capturable into a
+ * hipGraph) - also between two processes that share ONE GPU, where RCCL
+ * cannot build a communicator.  PCD_COMM_PEER=0 keeps everything on the
+ * transport given here (or on RCCL for pcd_comm_init). */
+typedef int (*pcd_host_allreduce_fn)(void* ctx, double* buf, int64_t count);
+typedef int (*pcd_host_exchange_fn)(void* ctx, int nsend, const int* send_peers,
+                                    double* const* send_bufs,
+                                    const int64_t* send_counts, int nrecv,
+                                    const int* recv_peers,
+                                    double* const* recv_bufs,
+                                    const int64_t* recv_counts);
+int pcd_comm_init_host(pcd_handle h, int rank, int nranks,
+                       pcd_host_allreduce_fn allreduce,
+                       pcd_host_exchange_fn exchange, void* ctx);
 /* TEST backend with the same two primitives (halo exchange, all-reduce):
  * `nranks` handles driven by `nranks` threads of ONE process on one GPU.
  * *group must be NULL for the first caller and is shared by the others.  It

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Worker of tests/test_peer_gpu.py: TWO PROCESSES on ONE GPU.  RCCL refuses
+two ranks on one device; the engine's peer-write protocol (csrc/pcd_peer.hpp)
+does not need it: the processes exchange the IPC handles of their arenas over
+a host transport (torch.distributed / gloo here, pcd_comm_init_host) and every
+halo exchange and dot product of the solve is then one kernel that stores
+into the other process's arena.  Rank 0 writes the results."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+p = argparse.ArgumentParser()
+p.add_argument("--out", required=True)
+p.add_argument("--level", type=int, default=4)
+p.add_argument("--fail-rank", type=int, default=-1)
+a = p.parse_args()
+
+import torch                                                  # noqa: E402
+import torch.distributed as dist                              # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                                      # the ONE GPU
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+dist.init_process_group("gloo")
+
+from fenapack_amd import PETScOptions, _cabi as c            # noqa: E402
+from fenapack_amd.driver import multigrid_inner_options, solve_steady  # noqa
+from fenapack_amd.fem import Cavity                          # noqa: E402
+from fenapack_amd.fem import partition as pt                 # noqa: E402
+from fenapack_amd.parallel import Comm, TorchHostTransport   # noqa: E402
+
+os.environ.setdefault("PCD_REPLICATE_BELOW", "1500")
+transport = TorchHostTransport()
+comm = Comm(rank, world, host_transport=transport)
+comm.host = pt.TorchHostComm()
+PETScOptions.clear()
+multigrid_inner_options(dim=2, galerkin_u=False)
+pp = pt.partitioned(Cavity, rank, world, host=comm.host, level=a.level, nu=0.01)
+out = solve_steady(pp, max_newton=3, newton_rtol=0.0, comm=comm)
+ksp = out["solver"].linear_solver().ksp()
+eng = ksp.engine
+res = {"its": np.array(out["krylov_per_step"]), "x": out["w"].vector().copy(),
+       "ranks": eng.info(c.INFO_RANKS)}
+if rank == a.fail_rank:
+    sys.stderr.write("peer_ipc_worker: rank %d leaves on purpose\n" % rank)
+    os._exit(3)
+# one PCApply eagerly and as a replayed hipGraph (the exchanges are kernels of
+# the engine's stream: they are captured with everything else)
+V = pp.space
+xg = np.random.default_rng(5).standard_normal(V.ndof)
+y0 = eng.fieldsplit_apply_np(xg)
+eng.graph_enable(True)
+y1 = eng.fieldsplit_apply_np(xg)          # first: eager, counts other traffic
+y2 = eng.fieldsplit_apply_np(xg)          # captured
+y3 = eng.fieldsplit_apply_np(xg)          # replayed
+t0 = time.perf_counter()
+for _ in range(50):
+    eng.fieldsplit_apply_np(xg)
+t_graph = (time.perf_counter() - t0) / 50
+eng.graph_enable(False)
+t0 = time.perf_counter()
+for _ in range(50):
+    eng.fieldsplit_apply_np(xg)
+t_eager = (time.perf_counter() - t0) / 50
+res.update({"y0": y0, "y1": y1, "y2": y2, "y3": y3,
+            "t_graph": t_graph, "t_eager": t_eager})
+if rank == 0:
+    np.savez(a.out, **res)
+eng.destroy()
+dist.barrier()
+dist.destroy_process_group()

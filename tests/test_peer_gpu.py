@@ -1,0 +1,165 @@
+"""GPU suite, part 10: the one-shot peer-write protocol (csrc/pcd_peer.hpp) -
+halo exchange and dot products as single kernels that store into the
+neighbour's arena, capturable into a hipGraph.
+
+* thread ranks, one stream each (PCD_COMM_PEER=1): the same solve as over the
+  host-barrier thread backend, and hipGraph replay with ranks;
+* TWO PROCESSES ON ONE GPU over HIP IPC, bootstrapped by a host transport
+  (torch.distributed / gloo, pcd_comm_init_host): RCCL cannot build a
+  communicator there - the reference's ``mpirun -np 2`` on one box
+  (test/regression/test.py:186-190) - against one engine."""
+import ctypes
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from fenapack_amd import PETScOptions
+from fenapack_amd.driver import multigrid_inner_options, solve_steady
+from fenapack_amd.fem import Cavity, Cavity3D
+from fenapack_amd.fem import partition as pt
+from fenapack_amd.parallel import Comm
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "peer_ipc_worker.py")
+
+
+def on_thread_ranks(R, body, own_streams):
+    group = ctypes.c_void_p()
+    hosts = pt.ThreadHostComm.group(R)
+    res, errs = [None] * R, []
+
+    def run(r):
+        try:
+            comm = Comm(r, R, thread_group=group)
+            comm.host = hosts[r]
+            if own_streams:
+                s = torch.cuda.Stream()
+                comm.stream = s.cuda_stream
+                with torch.cuda.stream(s):
+                    res[r] = body(r, comm, hosts[r])
+                    s.synchronize()
+            else:
+                res[r] = body(r, comm, hosts[r])
+        except Exception as ex:                       # pragma: no cover
+            import traceback
+            errs.append((r, repr(ex), traceback.format_exc()))
+            try:
+                hosts[r]._sh.barrier.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in th), "ranks deadlocked"
+    assert not errs, errs
+    return res
+
+
+@pytest.mark.parametrize("cls,kw,dim,R", [
+    (Cavity, dict(level=4, nu=0.01), 2, 2),
+    (Cavity, dict(level=4, nu=0.01), 2, 3),
+    (Cavity3D, dict(level=2, nu=0.01, n0=4), 3, 4)])
+def test_peer_protocol_on_thread_ranks(hip_lib, monkeypatch, cls, kw, dim, R):
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "1500")
+    monkeypatch.setenv("PCD_PEER_TIMEOUT_S", "20")
+    PETScOptions.clear()
+    multigrid_inner_options(dim=dim, galerkin_u=False)
+
+    def body(r, comm, host):
+        from fenapack_amd import _cabi as c
+        pp = pt.partitioned(cls, r, R, host=host, **kw)
+        out = solve_steady(pp, max_newton=3, newton_rtol=0.0, comm=comm)
+        eng = out["solver"].linear_solver().ksp().engine
+        V = pp.space
+        xg = np.random.default_rng(5).standard_normal(V.ndof)
+        y0 = eng.fieldsplit_apply_np(xg)
+        eng.graph_enable(True)
+        ys = [eng.fieldsplit_apply_np(xg) for _ in range(4)]
+        eng.graph_enable(False)
+        return {"its": out["krylov_per_step"], "x": out["w"].vector().copy(),
+                "y0": y0, "ys": ys}
+
+    monkeypatch.setenv("PCD_COMM_PEER", "0")
+    ref = on_thread_ranks(R, body, own_streams=False)[0]
+    monkeypatch.setenv("PCD_COMM_PEER", "1")
+    runs = on_thread_ranks(R, body, own_streams=True)
+    PETScOptions.clear()
+    for r in runs:
+        assert r["its"] == ref["its"], (r["its"], ref["its"])
+        # (the peer all-reduce adds in rank order, the thread backend too)
+        assert np.abs(r["x"] - ref["x"]).max() <= 1e-11 * np.abs(ref["x"]).max()
+        assert np.abs(r["y0"] - ref["y0"]).max() <= 1e-12 * np.abs(ref["y0"]).max()
+        # hipGraph replay with ranks: bitwise the eager result
+        for y in r["ys"]:
+            assert np.array_equal(y, r["y0"])
+    assert all(np.array_equal(r["x"], runs[0]["x"]) for r in runs)
+
+
+def _launch(args, port, timeout, nproc=2, extra_env=None):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.update(extra_env or {})
+    return subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+         "--master-port", str(port)] + args, env=env, capture_output=True,
+        text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(900)
+def test_two_processes_on_one_gpu_over_hip_ipc(hip_lib, tmp_path):
+    out = str(tmp_path / "two.npz")
+    run = _launch([WORKER, "--out", out], 29671, 600,
+                  extra_env={"PCD_COMM_PEER": "1", "PCD_PEER_TIMEOUT_S": "30",
+                             "PCD_COMM_VERBOSE": "1"})
+    assert run.returncode == 0, run.stderr[-4000:]
+    assert "peer protocol unavailable" not in run.stderr, run.stderr[-2000:]
+    two = np.load(out)
+    assert two["ranks"] == 2
+    # one engine, same options
+    os.environ["PCD_REPLICATE_BELOW"] = "1500"
+    try:
+        PETScOptions.clear()
+        multigrid_inner_options(dim=2, galerkin_u=False)
+        pb = Cavity(4, nu=0.01)
+        one = solve_steady(pb, max_newton=3, newton_rtol=0.0)
+        eng = one["solver"].linear_solver().ksp().engine
+        xg = np.random.default_rng(5).standard_normal(pb.space.ndof)
+        y = eng.fieldsplit_apply_np(xg)
+    finally:
+        os.environ.pop("PCD_REPLICATE_BELOW", None)
+        PETScOptions.clear()
+    assert list(two["its"]) == one["krylov_per_step"]
+    x1 = one["w"].vector()
+    assert np.abs(two["x"] - x1).max() <= 1e-9 * np.abs(x1).max()
+    assert np.abs(two["y0"] - y).max() <= 1e-11 * np.abs(y).max()
+    for k in ("y1", "y2", "y3"):                  # eager / captured / replayed
+        assert np.array_equal(two[k], two["y0"]), k
+    print("two processes on one GPU: PCApply %.3f ms eager, %.3f ms as a "
+          "replayed hipGraph" % (1e3 * two["t_eager"], 1e3 * two["t_graph"]))
+
+
+@pytest.mark.timeout(600)
+def test_a_process_that_leaves_does_not_hang_the_other(hip_lib, tmp_path):
+    """Rank 1 exits after set-up: rank 0's exchange kernels give up after
+    PCD_PEER_TIMEOUT_S, the engine reports PCD_ERR_COMM, the launcher ends
+    with a non-zero status - nothing hangs, the GPU stays usable."""
+    out = str(tmp_path / "gone.npz")
+    run = _launch([WORKER, "--out", out, "--fail-rank", "1"], 29673, 420,
+                  extra_env={"PCD_COMM_PEER": "1", "PCD_PEER_TIMEOUT_S": "3"})
+    assert run.returncode != 0
+    assert not os.path.exists(out)
+    # the GPU still works
+    t = torch.ones(1024, device="cuda")
+    assert float(t.sum().item()) == 1024.0
