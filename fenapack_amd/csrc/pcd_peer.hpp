@@ -87,7 +87,10 @@ __global__ __launch_bounds__(kBlock) void k_halo_xchg(PeerHaloDev d, const doubl
   }
   if ((int)threadIdx.x < d.nrp) {
     long long spins = 0;
+    // (sticky: once a wait gave up, later ones do not spin - one time-out per
+    // failure, not one per exchange)
     while (__hip_atomic_load(d.lflag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq_now) {
+      if (*(volatile int*)d.err) break;
       __builtin_amdgcn_s_sleep(8);
       if (++spins > spin_limit) { *d.err = 1; break; }
     }
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_peer_allreduce(PeerReduceDev d, doub
   if ((int)threadIdx.x < d.nranks) {
     long long spins = 0;
     while (__hip_atomic_load(&d.flag[d.rank][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq_now) {
+      if (*(volatile int*)d.err) break;
       __builtin_amdgcn_s_sleep(8);
       if (++spins > spin_limit) { *d.err = 1; break; }
     }
@@ -357,10 +361,9 @@ struct PeerBackend : CommBackend {
     int e = 0;
     if (hipMemcpyAsync(&e, derr, sizeof e, hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
-    if (e) {
-      (void)hipMemsetAsync(derr, 0, sizeof(int), s);
-      err = "peer exchange: a neighbour's data did not arrive (rank gone or out of step)";
-    }
+    // (not reset: the ranks' sequence numbers are out of step from here on -
+    // the communicator stays failed, every later call reports it at once)
+    if (e) err = "peer exchange: a neighbour's data did not arrive (rank gone or out of step)";
     return e;
   }
 };
