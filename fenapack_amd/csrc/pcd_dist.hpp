@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <cstdint>
 #include <cstring>
@@ -490,17 +491,39 @@ struct ThreadGroup {
   }
   // sense-reversing spin barrier: the ranks meet hundreds of thousands of
   // times in a test run, a condition variable costs tens of microseconds each
-  void barrier() {
+  // A rank that failed (or left) never arrives: the others give up after
+  // PCD_THREAD_BARRIER_TIMEOUT_S (default 120 s) and the group stays failed -
+  // every later barrier returns at once, every rank leaves with an error
+  // instead of spinning forever.
+  std::atomic<bool> failed{false};
+  bool barrier() {
+    if (failed.load(std::memory_order_acquire)) return false;
     const uint64_t ph = phase.load(std::memory_order_acquire);
     if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nranks) {
       arrived.store(0, std::memory_order_relaxed);
       phase.store(ph + 1, std::memory_order_release);
-    } else {
-      int spins = 0;
-      while (phase.load(std::memory_order_acquire) == ph)
-        if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
+      return true;
     }
+    static const double limit = [] {
+      const char* e = getenv("PCD_THREAD_BARRIER_TIMEOUT_S");
+      return e ? atof(e) : 120.0;
+    }();
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (phase.load(std::memory_order_acquire) == ph) {
+      if (failed.load(std::memory_order_acquire)) return false;
+      if (++spins > 2000) {
+        std::this_thread::yield();
+        spins = 0;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+          failed.store(true, std::memory_order_release);
+          return false;
+        }
+      }
+    }
+    return true;
   }
+  void fail_group() { failed.store(true, std::memory_order_release); }
 };
 
 struct ThreadBackend : CommBackend {
@@ -508,9 +531,16 @@ struct ThreadBackend : CommBackend {
   double* tmp = nullptr;
   size_t tmp_n = 0;
   ~ThreadBackend() override { if (tmp) (void)hipFree(tmp); }
+  // (a rank-local failure inside a collective fails the group at once: the
+  // others would otherwise wait for the barrier's time-out)
   int fail(hipError_t e, const char* what) {
     if (e == hipSuccess) return 0;
     err = std::string(what) + ": " + hipGetErrorString(e);
+    if (g) g->fail_group();
+    return 1;
+  }
+  int gone() {
+    err = "thread ranks: a rank failed or did not arrive at a collective";
     return 1;
   }
   int events() {
@@ -531,11 +561,11 @@ struct ThreadBackend : CommBackend {
     }
     g->ar_buf[rank] = dbuf;
     g->stream[rank] = s;
-    g->barrier();                                    // operands + streams published
+    if (!g->barrier()) return gone();                // operands + streams published
     const bool ordered = g->one_stream();            // (same answer on every rank)
     if (!ordered) {
       if (fail(hipEventRecord(g->ev_ready[rank], s), "record")) return 1;
-      g->barrier();                                  // every event recorded
+      if (!g->barrier()) return gone();              // every event recorded
     }
     RankBufs bufs;
     bufs.n = nranks;
@@ -546,7 +576,7 @@ struct ThreadBackend : CommBackend {
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
     hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, s, bufs, (int64_t)count, tmp);
     if (!ordered && fail(hipEventRecord(g->ev_done[rank], s), "record")) return 1;
-    g->barrier();                                    // every rank has (enqueued its) read of every operand
+    if (!g->barrier()) return gone();                // every rank has (enqueued its) read of every operand
     if (!ordered)
       for (int r = 0; r < nranks; ++r)
         if (r != rank && fail(hipStreamWaitEvent(s, g->ev_done[r], 0), "wait")) return 1;
@@ -557,11 +587,11 @@ struct ThreadBackend : CommBackend {
     if (events()) return 1;
     g->sends[rank] = sends;
     g->stream[rank] = s;
-    g->barrier();                                    // send buffers + streams published
+    if (!g->barrier()) return gone();                // send buffers + streams published
     const bool ordered = g->one_stream();
     if (!ordered) {
       if (fail(hipEventRecord(g->ev_ready[rank], s), "record")) return 1;
-      g->barrier();                                  // every event recorded
+      if (!g->barrier()) return gone();              // every event recorded
     }
     // several messages between one pair of ranks (grouped halos of several
     // operators) match in posting order, as grouped ncclSend / ncclRecv do
@@ -579,7 +609,7 @@ struct ThreadBackend : CommBackend {
                               hipMemcpyDeviceToDevice, s), "memcpy")) { bad = 1; break; }
     }
     if (!ordered && !bad && fail(hipEventRecord(g->ev_done[rank], s), "record")) bad = 1;
-    g->barrier();                                    // all copies are enqueued
+    if (!g->barrier()) return gone();                // all copies are enqueued
     if (bad) return 1;
     // my send buffers may be packed again only after my readers' copies
     if (!ordered)

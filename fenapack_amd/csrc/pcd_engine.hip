@@ -3321,7 +3321,7 @@ static int comm_attach(Engine* h, CommBackend* c, int rank, int nranks) {
 // of it in one in-order stream).  If the arenas cannot be set up (no IPC
 // between the devices) every rank falls back to the bootstrap backend alone:
 // the decision is an all-reduce.
-static void thread_group_barrier(void* g) { static_cast<ThreadGroup*>(g)->barrier(); }
+static void thread_group_barrier(void* g) { (void)static_cast<ThreadGroup*>(g)->barrier(); }
 static CommBackend* wrap_peer(Engine* h, CommBackend* boot, int rank, int nranks, ThreadGroup* tg,
                               bool default_on) {
   const char* e = getenv("PCD_COMM_PEER");
@@ -3332,7 +3332,7 @@ static CommBackend* wrap_peer(Engine* h, CommBackend* boot, int rank, int nranks
   PeerBackend* pb = new PeerBackend();
   pb->boot = boot; pb->rank = rank; pb->nranks = nranks;
   boot->rank = rank; boot->nranks = nranks;
-  if (const char* t = getenv("PCD_PEER_TIMEOUT_S")) pb->spin_limit = (long long)(atof(t) * 4.0e6);
+  if (const char* t = getenv("PCD_PEER_TIMEOUT_S")) pb->spin_limit = (long long)(atof(t) * 1.0e8);
   int bad = pb->init(cap, tg ? tg->arenas.data() : nullptr, thread_group_barrier, tg, h->stream);
   // every rank must have its arena and its mappings, or nobody uses them
   double flag = bad ? 1.0 : 0.0;

@@ -86,13 +86,14 @@ __global__ __launch_bounds__(kBlock) void k_halo_xchg(PeerHaloDev d, const doubl
     if (threadIdx.x == 0) d.ctr[0] = 0;
   }
   if ((int)threadIdx.x < d.nrp) {
-    long long spins = 0;
-    // (sticky: once a wait gave up, later ones do not spin - one time-out per
-    // failure, not one per exchange)
+    // bounded by the wall clock (s_memrealtime, 100 MHz); sticky: once a wait
+    // gave up, later ones do not spin - one time-out per failure, not one per
+    // exchange
+    const long long t0 = wall_clock64();
     while (__hip_atomic_load(d.lflag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq_now) {
       if (*(volatile int*)d.err) break;
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > spin_limit) { *d.err = 1; break; }
+      if (wall_clock64() - t0 > spin_limit) { *d.err = 1; break; }
     }
   }
   __syncthreads();
@@ -133,11 +134,11 @@ __global__ __launch_bounds__(kBlock) void k_peer_allreduce(PeerReduceDev d, doub
   if ((int)threadIdx.x < d.nranks)
     __hip_atomic_store(&d.flag[threadIdx.x][d.rank], seq_now, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if ((int)threadIdx.x < d.nranks) {
-    long long spins = 0;
+    const long long t0 = wall_clock64();
     while (__hip_atomic_load(&d.flag[d.rank][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq_now) {
       if (*(volatile int*)d.err) break;
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > spin_limit) { *d.err = 1; break; }
+      if (wall_clock64() - t0 > spin_limit) { *d.err = 1; break; }
     }
   }
   __syncthreads();
@@ -168,7 +169,7 @@ struct PeerBackend : CommBackend {
   PeerReduceDev red;
   unsigned long long* dseq = nullptr;       // counters of the all-reduce channel (ordinary memory)
   int* derr = nullptr;                      // error word read by the host at synchronisation points
-  long long spin_limit = 40000000;          // ~10 s of s_sleep(8)
+  long long spin_limit = 3000000000ll;      // 30 s of the 100 MHz wall clock
   bool process_mode = false;
   long boot_calls = 0;                      // hot-path calls that went to the bootstrap backend
 
