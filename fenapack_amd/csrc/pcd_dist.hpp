@@ -26,6 +26,7 @@
 #include <chrono>
 #include <thread>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -603,7 +604,14 @@ struct ThreadBackend : CommBackend {
       for (const Msg& q : g->sends[m.peer])
         if (q.peer == rank && seen++ == taken[m.peer]) { src = &q; break; }
       ++taken[m.peer];
-      if (!src || src->count != m.count) { err = "halo mismatch"; bad = 1; break; }
+      if (!src || src->count != m.count) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "halo mismatch: rank %d expects %zu doubles from rank %d as its message "
+                 "%d, found %s%zu (rank %d posted %zu sends, this rank %zu receives)", rank, m.count,
+                 m.peer, taken[m.peer] - 1, src ? "" : "none; ", src ? src->count : (size_t)0, m.peer,
+                 g->sends[m.peer].size(), recvs.size());
+        err = buf; bad = 1; break;
+      }
       if ((!ordered && fail(hipStreamWaitEvent(s, g->ev_ready[m.peer], 0), "wait")) ||
           fail(hipMemcpyAsync(m.ptr, src->ptr, m.count * sizeof(double),
                               hipMemcpyDeviceToDevice, s), "memcpy")) { bad = 1; break; }

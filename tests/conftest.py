@@ -8,6 +8,12 @@ import pytest
 # BLAS calls, and OpenBLAS's default pool (one thread per core of a 256-thread
 # host) costs each of them ~100 x its work (fenapack_amd.limit_blas_threads)
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
+# Thread ranks that use the peer-write protocol (tests/test_peer_gpu.py) run
+# kernels that wait for another rank's kernel: both must be in flight at once.
+# The streams of one process are multiplexed onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4), and two rank streams in one queue serialise.  Read by
+# the HIP runtime when it initialises, i.e. after this line.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -90,8 +90,12 @@ def test_peer_protocol_on_thread_ranks(hip_lib, monkeypatch, cls, kw, dim, R):
         eng.graph_enable(True)
         ys = [eng.fieldsplit_apply_np(xg) for _ in range(4)]
         eng.graph_enable(False)
-        return {"its": out["krylov_per_step"], "x": out["w"].vector().copy(),
-                "y0": y0, "ys": ys}
+        res = {"its": out["krylov_per_step"], "x": out["w"].vector().copy(),
+               "y0": y0, "ys": ys}
+        eng.synchronize()
+        host.allgather(0)                 # every rank is done with the others
+        eng.destroy()                     # streams / queues back before the next test
+        return res
 
     monkeypatch.setenv("PCD_COMM_PEER", "0")
     ref = on_thread_ranks(R, body, own_streams=False)[0]
