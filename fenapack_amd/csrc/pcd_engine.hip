@@ -692,18 +692,21 @@ static int refresh_dinv(Engine* h, DCsr& A) {
   hipLaunchKernelGGL(k_dinv, dim3(grid1d(A.nrows, 1, 1 << 30)), dim3(kBlock), 0,
                      h->stream, (int)A.nrows, A.rowptr.p, A.col.p, A.val.p,
                      A.dinv.p);
-  // column-scaled values for the fused zero-guess first step (single GPU:
-  // with a halo the first step is not fused, see can_fuse_first)
-  if (!h->comm && A.nnz) {
+  // column-scaled values for the fused zero-guess first step; with several
+  // ranks the reciprocal diagonal of the ghost columns arrives like any halo
+  // (collective: every rank refreshes every operator in the same order)
+  if (A.nnz) {
+    CHK(halo_exchange(h, A, A.dinv.p));
     if (A.kron && A.nnz2) {
       CHK(A.val2s.ensure(A.nnz2));
       hipLaunchKernelGGL(k_scale_cols, dim3(grid1d(A.nnz2, 4)), dim3(kBlock), 0, h->stream,
-                         A.nnz2, A.col2.p, A.val2.p, A.dinv.p, A.kron, A.val2s.p);
+                         A.nnz2, A.col2.p, A.val2.p, A.dinv.p, A.kron, A.val2s.p,
+                         A.ghost.p, (int)(A.ncols / A.kron));
     }
     if (A.rb) {
       CHK(A.vals.ensure(A.nnz));
       hipLaunchKernelGGL(k_scale_cols, dim3(grid1d(A.nnz, 4)), dim3(kBlock), 0, h->stream,
-                         A.nnz, A.col.p, A.val.p, A.dinv.p, 1, A.vals.p);
+                         A.nnz, A.col.p, A.val.p, A.dinv.p, 1, A.vals.p, A.ghost.p, (int)A.ncols);
     }
   }
   HIPCHK(hipGetLastError());
@@ -790,32 +793,36 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
 // zero-guess start fused with the first step (single GPU, stream kernels):
 // p0 = s D^-1 b (also written to `p0` unless null), pn = c1 p0 + c2 D^-1(b - A p0)
 static bool can_fuse_first(const Engine* h, const DCsr& A, const double* dinv) {
-  return A.rb && !h->comm && dinv != nullptr && (!A.kron || A.rb2);
+  (void)h;
+  return A.rb && dinv != nullptr && (!A.kron || A.rb2);
 }
-static void launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
-                              const double* b, double* p0, double* pn, double s,
-                              double c1, double c2) {
+static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
+                             const double* b, double* p0, double* pn, double s,
+                             double c1, double c2) {
   const int n = (int)A.nrows;
+  CHK(halo_exchange(h, A, b));           // (several ranks: the halo of b)
+  const double* ghost = (h->comm && !A.replicated) ? A.ghost.p : b;
   if (A.vt && kron_ok(A, b, p0, pn, nullptr, true)) {
     const int gt = grid_stream(A.vt_blocks, 1);
     const int nn = n / A.kron;
 #define PCD_FIRST_TC(NC, NT)                                                                  \
     hipLaunchKernelGGL((k_cheb_first_tc<NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,       \
                        A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2s.p,        \
-                       A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, nn)
+                       A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron))
     if (A.kron == 2) { if (A.nt2 && g_vt_nt) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
     else { if (A.nt2 && g_vt_nt) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
 #undef PCD_FIRST_TC
-    return;
+    return 0;
   }
   if (kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
-               A.val2s.p, dinv, b, p0, pn, s, c1, c2);
-    return;
+               A.val2s.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron));
+    return 0;
   }
   LAUNCH_RB(A, k_cheb_first_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
-            A.vals.p, dinv, b, p0, pn, s, c1, c2);
+            A.vals.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)A.ncols);
+  return 0;
 }
 
 // CG with the direction update fused into the SpMV: two launches per
@@ -978,8 +985,8 @@ static int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
     double* pn = ring[(it + 1) % 3];
     if (it == 0 && fuse) {
       // p_{-1} = 0: p1 = omega p0 + omega scale D^-1 (b - A p0)
-      launch_cheb_first(h, A, dinv, b, m >= 2 ? pk : nullptr, pn, scale,
-                        f * omega, f * omega * scale);
+      CHK(launch_cheb_first(h, A, dinv, b, m >= 2 ? pk : nullptr, pn, scale,
+                            f * omega, f * omega * scale));
     } else {
       // p_{-1} = 0 at the first step: coefficient forced to zero, never read
       double* pm = (it == 0) ? pk : ring[(it + 2) % 3];
@@ -1039,8 +1046,8 @@ static int mg_smooth(Engine* h, const DCsr& A, double emin, double emax, int nu,
     // needs it as p_{k-1}
     const double c_kp1 = 2.0 * mu * c_k - c_km1;
     const double omega = omegaprod * c_k / c_kp1;
-    launch_cheb_first(h, A, dinv, b, nu >= 3 ? bufs[0] : nullptr, bufs[1],
-                      scale, omega, omega * scale);
+    CHK(launch_cheb_first(h, A, dinv, b, nu >= 3 ? bufs[0] : nullptr, bufs[1],
+                          scale, omega, omega * scale));
     c_km1 = c_k; c_k = c_kp1;
     cur = 1; have_pm = true;
     --nu;                                  // one step already done

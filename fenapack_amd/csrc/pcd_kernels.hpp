@@ -535,12 +535,15 @@ template <int RB>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_s(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ dinv,
-    const double* b, double* p0, double* pn, double s, double c1, double c2) {
+    const double* b, double* p0, double* pn, double s, double c1, double c2,
+    const double* ghost, int nloc) {
   __shared__ double lds[kTile];
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, RB, rb0, rb1);
-  const XVec xf{b, b, nrows};   // (no halo: the ghost segment is never read)
+  // (one GPU: ghost == b, nloc == nrows - the ghost segment is never read;
+  // several ranks: the halo of b, exchanged before the launch)
+  const XVec xf{b, ghost, nloc};
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x / (kBlock / RB);
@@ -559,12 +562,18 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_s(
 
 // vals[k] = val[k] * dinv[col[k] * stride]   (stride = components per node
 // when `val` holds the scalar stencil F of an F (x) I operator)
+// (`ghost` / `nloc`: several ranks - the reciprocal diagonal of the ghost
+// columns, exchanged like any halo; one GPU: nloc = every column)
 __global__ __launch_bounds__(kBlock) void k_scale_cols(
     int64_t nnz, const int* __restrict__ col, const double* __restrict__ val,
-    const double* __restrict__ dinv, int stride, double* vals) {
+    const double* __restrict__ dinv, int stride, double* vals,
+    const double* __restrict__ ghost, int nloc) {
   for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
-       k += (int64_t)gridDim.x * kBlock)
-    vals[k] = val[k] * dinv[(int64_t)col[k] * stride];
+       k += (int64_t)gridDim.x * kBlock) {
+    const int c = col[k];
+    vals[k] = val[k] * (c < nloc ? dinv[(int64_t)c * stride]
+                                 : ghost[(int64_t)(c - nloc) * stride]);
+  }
 }
 
 // long rows (dense coarse inverse): one workgroup per row, 4 loads in flight
@@ -854,14 +863,15 @@ template <int RB, int NC, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ dinv_,
-    const double* b_, double* p0_, double* pn_, double s, double c1, double c2) {
+    const double* b_, double* p0_, double* pn_, double s, double c1, double c2,
+    const double* ghost, int nloc) {
   __shared__ VecC<NC> lds[tile_c<NC>()];
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   const int nrb = (nrows + RB - 1) / RB;
   int rb0, rb1;
   row_block_range(nrb, RB, rb0, rb1, xcd_remap_always<NC, NT>(nrows));
-  const XVecC<NC> xf{b, b, nrows};    // vals carry D^-1 (see k_cheb_first_s)
+  const XVecC<NC> xf{b, vc<NC>(ghost), nloc};    // vals carry D^-1 (see k_cheb_first_s)
   for (int rb = rb0; rb < rb1; ++rb) {
     const int r0 = rb * RB;
     const int row = r0 + threadIdx.x / (kBlock / RB);
@@ -1057,7 +1067,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
 template <int NC, bool NT>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, double* p0_,
-    double* pn_, double s, double c1, double c2, int nrows) {
+    double* pn_, double s, double c1, double c2, const double* ghost, int nloc) {
   PCD_VT_SHARED(NC);
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
@@ -1070,8 +1080,9 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
     const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && lr < (d4.w & 0xff);
     VecC<NC> d = vzero<NC>(), bi = d;
     if (mine) { d = dinv[row]; bi = b[row]; }
-    // (vals carry D^-1 by columns: the gathered vector is b alone; no halo)
-    const VecC<NC> sum = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, b_, b_, nrows, tile);
+    // (vals carry D^-1 by columns: the gathered vector is b alone, with its
+    // halo when there are several ranks)
+    const VecC<NC> sum = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile);
     if (mine) {
       VecC<NC> x0, o;
 #pragma unroll
