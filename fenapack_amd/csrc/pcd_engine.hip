@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/pcd_engine.h"
+#include "pcd_launch.hpp"
 #include "pcd_kernels.hpp"
 #include "pcd_fe.hpp"
 #include "pcd_dist.hpp"
@@ -3219,6 +3220,7 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_A00_COMPONENTS: *out = (double)h->mat[PCD_MAT_A00].kron; return 0;
     case PCD_INFO_RANKS: *out = h->comm ? (double)h->nranks : 0.0; return 0;
     case PCD_INFO_REORDERED: *out = (h->ru.active() ? 1.0 : 0.0) + (h->rp.active() ? 2.0 : 0.0); return 0;
+    case PCD_INFO_LAUNCHES: *out = (double)launch_count(); return 0;
     case PCD_INFO_A00_ROWS_PER_WG:
       *out = (double)(h->mat[PCD_MAT_A00].kron ? h->mat[PCD_MAT_A00].rb2 : h->mat[PCD_MAT_A00].rb);
       if (h->mat[PCD_MAT_A00].kron && h->mat[PCD_MAT_A00].vt) *out = -(double)kVtRows;

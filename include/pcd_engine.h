@@ -93,7 +93,9 @@ enum pcd_info {
   PCD_INFO_A00_COMPONENTS = 12, PCD_INFO_A00_ROWS_PER_WG = 13,
   PCD_INFO_RANKS = 14,       /* ranks of the attached communicator (0: none) */
   PCD_INFO_REORDERED = 15,   /* engine renumbering active: +1 velocity, +2 pressure */
-  PCD_INFO_NNZ_BASE = 16     /* + pcd_mat: stored nonzeros of that operator */
+  PCD_INFO_NNZ_BASE = 16,    /* + pcd_mat: stored nonzeros of that operator */
+  PCD_INFO_LAUNCHES = 64     /* kernel launches this host thread has issued so far (a
+                              * replayed hipGraph counts as none: it is one hipGraphLaunch) */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */

@@ -69,8 +69,37 @@ t0 = time.perf_counter()
 for _ in range(50):
     eng.fieldsplit_apply_np(xg)
 t_eager = (time.perf_counter() - t0) / 50
+# the same with vectors resident on the device (this rank's row block
+# [u_loc; p_loc]): what bench.py times; kernel launches per PCApply
+from fenapack_amd.petsc import Vec                            # noqa: E402
+nl = int(eng.info(c.INFO_N_U_LOCAL)) + int(eng.info(c.INFO_N_P_LOCAL))
+xd = Vec(xg[:nl].copy(), device="cuda:0")
+yd = xd.duplicate()
+
+
+def timed(n=200):
+    for _ in range(10):
+        eng.fieldsplit_apply(xd.t, yd.t, c.MEM_DEVICE)
+    torch.cuda.synchronize()
+    dist.barrier()
+    l0 = eng.info(c.INFO_LAUNCHES)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.fieldsplit_apply(xd.t, yd.t, c.MEM_DEVICE)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, (eng.info(c.INFO_LAUNCHES) - l0) / n
+
+
+td_eager, launches = timed()
+eng.graph_enable(True)
+td_graph, launches_graph = timed()
+eng.graph_enable(False)
 res.update({"y0": y0, "y1": y1, "y2": y2, "y3": y3,
-            "t_graph": t_graph, "t_eager": t_eager})
+            "t_graph": t_graph, "t_eager": t_eager,
+            "td_eager": td_eager, "td_graph": td_graph,
+            "launches_per_pcapply": launches,
+            "launches_per_pcapply_graph": launches_graph,
+            "peer": float(os.environ.get("PCD_COMM_PEER", "1") != "0")})
 if rank == 0:
     np.savez(a.out, **res)
 eng.destroy()
