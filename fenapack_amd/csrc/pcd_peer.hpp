@@ -45,7 +45,7 @@
 namespace pcd {
 
 constexpr int kPeerMaxPeers = 16;
-constexpr int kPeerMaxCount = 512;          // doubles per peer all-reduce
+constexpr int kPeerMaxCount = 65536;        // doubles per peer all-reduce (a replicated coarse level)
 constexpr int kPeerXchgGrid = 32;           // workgroups of one exchange kernel
 
 // one halo channel, device view (passed by value)
@@ -117,22 +117,32 @@ struct PeerReduceDev {
   double* slot[kPeerMaxPeers];              // rank r's slot array [2][nranks][kPeerMaxCount]
   unsigned long long* flag[kPeerMaxPeers];  // rank r's flags [nranks]
   unsigned long long* seq = nullptr;
+  unsigned* ctr = nullptr;                  // [0] arrived, [1] finished workgroups
   int* err = nullptr;
 };
 
 __global__ __launch_bounds__(kBlock) void k_peer_allreduce(PeerReduceDev d, double* buf, int count,
                                                             long long spin_limit) {
-  const unsigned long long seq_now = *d.seq + 1;
+  __shared__ int s_last;
+  const unsigned long long seq_now = *d.seq + 1;       // (advanced by the last finisher)
   const size_t p = (size_t)(seq_now & 1);
   const size_t mine = (p * d.nranks + d.rank) * kPeerMaxCount;
-  for (int i = threadIdx.x; i < count * d.nranks; i += kBlock) {
-    const int r = i / count, k = i % count;
+  const long long total = (long long)count * d.nranks;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kBlock) {
+    const int r = (int)(i / count), k = (int)(i % count);
     d.slot[r][mine + k] = buf[k];
   }
   __threadfence_system();
   __syncthreads();
-  if ((int)threadIdx.x < d.nranks)
-    __hip_atomic_store(&d.flag[threadIdx.x][d.rank], seq_now, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) s_last = atomicAdd(&d.ctr[0], 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (s_last) {
+    __threadfence_system();
+    if ((int)threadIdx.x < d.nranks)
+      __hip_atomic_store(&d.flag[threadIdx.x][d.rank], seq_now, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) d.ctr[0] = 0;
+  }
   if ((int)threadIdx.x < d.nranks) {
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(&d.flag[d.rank][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq_now) {
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_peer_allreduce(PeerReduceDev d, doub
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < count; k += kBlock) {
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
     double s = 0.0;
     for (int r = 0; r < d.nranks; ++r)
       s += __hip_atomic_load(&d.slot[d.rank][(p * d.nranks + r) * kPeerMaxCount + k], __ATOMIC_RELAXED,
@@ -150,7 +160,10 @@ __global__ __launch_bounds__(kBlock) void k_peer_allreduce(PeerReduceDev d, doub
     buf[k] = s;
   }
   __syncthreads();
-  if (threadIdx.x == 0) *d.seq = seq_now;
+  if (threadIdx.x == 0 && atomicAdd(&d.ctr[1], 1u) == gridDim.x - 1) {
+    d.ctr[1] = 0;
+    *d.seq = seq_now;
+  }
 }
 
 // host side of one halo channel
@@ -259,6 +272,7 @@ struct PeerBackend : CommBackend {
       red.flag[r] = reinterpret_cast<unsigned long long*>(peer_arena[r] + (flags - arena));
     }
     red.seq = dseq;
+    red.ctr = reinterpret_cast<unsigned*>(dseq + 2);
     red.err = derr;
     return 0;
   }
@@ -268,7 +282,12 @@ struct PeerBackend : CommBackend {
       ++boot_calls;
       return forward(boot->allreduce(dbuf, count, s));
     }
-    hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(kBlock), 0, s, red, dbuf, (int)count, spin_limit);
+    // (in place: a sum is written only after the flags of ALL ranks arrived,
+    // this rank's own among them - and that one is set after its last
+    // workgroup pushed its share of the operand)
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((count * nranks + kBlock - 1) / kBlock,
+                                                               (size_t)kPeerXchgGrid));
+    hipLaunchKernelGGL(k_peer_allreduce, dim3(grid), dim3(kBlock), 0, s, red, dbuf, (int)count, spin_limit);
     return fail(hipGetLastError(), "k_peer_allreduce");
   }
   int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs, hipStream_t s) override {
