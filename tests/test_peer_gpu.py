@@ -172,7 +172,7 @@ def test_two_processes_on_one_gpu_over_hip_ipc(hip_lib, tmp_path):
     for _ in range(10):
         eng.fieldsplit_apply(xd.t, yd.t, c.MEM_DEVICE)
     single = (eng.info(c.INFO_LAUNCHES) - l0) / 10
-    assert two["launches_per_pcapply_graph"] == 0.0
+    assert two["launches_per_pcapply_graph"] <= 2.0      # (copy in, copy out)
     print("two processes on one GPU over HIP IPC: %.0f launches per PCApply "
           "(one engine: %.0f), %.3f ms eager, %.3f ms as a replayed hipGraph"
           % (two["launches_per_pcapply"], single, 1e3 * two["td_eager"],
