@@ -24,6 +24,7 @@ INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
     INFO_A00_ROWS_PER_WG, INFO_RANKS = range(15)
 INFO_REORDERED = 15          # HIP engine only: +1 velocity, +2 pressure renumbered
 INFO_LAUNCHES = 64           # HIP engine only: kernel launches of this host thread
+INFO_PEER_CALLS, INFO_BOOT_CALLS = 65, 66   # exchanges / reductions: peer kernels, bootstrap
 INFO_NNZ_BASE = 16
 
 KSP_TYPES = {"preonly": PREONLY, "richardson": RICHARDSON,

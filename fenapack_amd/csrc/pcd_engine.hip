@@ -3221,6 +3221,13 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_RANKS: *out = h->comm ? (double)h->nranks : 0.0; return 0;
     case PCD_INFO_REORDERED: *out = (h->ru.active() ? 1.0 : 0.0) + (h->rp.active() ? 2.0 : 0.0); return 0;
     case PCD_INFO_LAUNCHES: *out = (double)launch_count(); return 0;
+    case PCD_INFO_PEER_CALLS:
+      *out = (h->comm && h->comm->peer()) ? (double)static_cast<PeerBackend*>(h->comm)->peer_calls : 0.0;
+      return 0;
+    case PCD_INFO_BOOT_CALLS:
+      *out = (double)h->boot_exchanges +
+             ((h->comm && h->comm->peer()) ? (double)static_cast<PeerBackend*>(h->comm)->boot_calls : 0.0);
+      return 0;
     case PCD_INFO_A00_ROWS_PER_WG:
       *out = (double)(h->mat[PCD_MAT_A00].kron ? h->mat[PCD_MAT_A00].rb2 : h->mat[PCD_MAT_A00].rb);
       if (h->mat[PCD_MAT_A00].kron && h->mat[PCD_MAT_A00].vt) *out = -(double)kVtRows;

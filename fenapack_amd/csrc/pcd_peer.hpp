@@ -185,6 +185,7 @@ struct PeerBackend : CommBackend {
   long long spin_limit = 3000000000ll;      // 30 s of the 100 MHz wall clock
   bool process_mode = false;
   long boot_calls = 0;                      // hot-path calls that went to the bootstrap backend
+  long peer_calls = 0;                      // exchanges / reductions issued as kernels of the stream
 
   ~PeerBackend() override {
     for (void* p : opened) (void)hipIpcCloseMemHandle(p);
@@ -287,6 +288,7 @@ struct PeerBackend : CommBackend {
     // workgroup pushed its share of the operand)
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((count * nranks + kBlock - 1) / kBlock,
                                                                (size_t)kPeerXchgGrid));
+    ++peer_calls;
     hipLaunchKernelGGL(k_peer_allreduce, dim3(grid), dim3(kBlock), 0, s, red, dbuf, (int)count, spin_limit);
     return fail(hipGetLastError(), "k_peer_allreduce");
   }
@@ -373,6 +375,7 @@ struct PeerBackend : CommBackend {
   // the bootstrap protocol unless every rank was given a stream of its own.
   bool usable(hipStream_t s) const { return process_mode || s != nullptr; }
   int halo(const PeerHalo& ph, const double* x, hipStream_t s) {
+    ++peer_calls;
     hipLaunchKernelGGL(k_halo_xchg, dim3(ph.grid), dim3(kBlock), 0, s, ph.dev, x, spin_limit);
     return fail(hipGetLastError(), "k_halo_xchg");
   }

@@ -94,8 +94,11 @@ enum pcd_info {
   PCD_INFO_RANKS = 14,       /* ranks of the attached communicator (0: none) */
   PCD_INFO_REORDERED = 15,   /* engine renumbering active: +1 velocity, +2 pressure */
   PCD_INFO_NNZ_BASE = 16,    /* + pcd_mat: stored nonzeros of that operator */
-  PCD_INFO_LAUNCHES = 64     /* kernel launches this host thread has issued so far (a
+  PCD_INFO_LAUNCHES = 64,    /* kernel launches this host thread has issued so far (a
                               * replayed hipGraph counts as none: it is one hipGraphLaunch) */
+  PCD_INFO_PEER_CALLS = 65,  /* halo exchanges / all-reduces issued as kernels of the
+                              * stream (peer protocol), so far */
+  PCD_INFO_BOOT_CALLS = 66   /* ... and those that went through RCCL / the host transport */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */

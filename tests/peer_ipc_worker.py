@@ -83,17 +83,23 @@ def timed(n=200):
     torch.cuda.synchronize()
     dist.barrier()
     l0 = eng.info(c.INFO_LAUNCHES)
+    p0 = eng.info(c.INFO_PEER_CALLS)
+    b0 = eng.info(c.INFO_BOOT_CALLS)
     t0 = time.perf_counter()
     for _ in range(n):
         eng.fieldsplit_apply(xd.t, yd.t, c.MEM_DEVICE)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n, (eng.info(c.INFO_LAUNCHES) - l0) / n
+    return ((time.perf_counter() - t0) / n,
+            (eng.info(c.INFO_LAUNCHES) - l0) / n,
+            (eng.info(c.INFO_PEER_CALLS) - p0) / n,
+            (eng.info(c.INFO_BOOT_CALLS) - b0) / n)
 
 
-td_eager, launches = timed()
+td_eager, launches, exchanges, boot = timed()
 eng.graph_enable(True)
-td_graph, launches_graph = timed()
+td_graph, launches_graph, _, _ = timed()
 eng.graph_enable(False)
+res.update({"exchanges_per_pcapply": exchanges, "boot_calls_per_pcapply": boot})
 res.update({"y0": y0, "y1": y1, "y2": y2, "y3": y3,
             "t_graph": t_graph, "t_eager": t_eager,
             "td_eager": td_eager, "td_graph": td_graph,

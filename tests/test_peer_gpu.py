@@ -173,12 +173,17 @@ def test_two_processes_on_one_gpu_over_hip_ipc(hip_lib, tmp_path):
         eng.fieldsplit_apply(xd.t, yd.t, c.MEM_DEVICE)
     single = (eng.info(c.INFO_LAUNCHES) - l0) / 10
     assert two["launches_per_pcapply_graph"] <= 2.0      # (copy in, copy out)
-    print("two processes on one GPU over HIP IPC: %.0f launches per PCApply "
-          "(one engine: %.0f), %.3f ms eager, %.3f ms as a replayed hipGraph"
-          % (two["launches_per_pcapply"], single, 1e3 * two["td_eager"],
-             1e3 * two["td_graph"]))
-    # (every level of this small problem exchanges: at most 2.2 x)
-    assert two["launches_per_pcapply"] <= 2.2 * single
+    print("two processes on one GPU over HIP IPC: %.0f launches per PCApply, "
+          "%.0f of them exchanges / reductions (one engine: %.0f launches), "
+          "%.3f ms eager, %.3f ms as a replayed hipGraph"
+          % (two["launches_per_pcapply"], two["exchanges_per_pcapply"], single,
+             1e3 * two["td_eager"], 1e3 * two["td_graph"]))
+    # every exchange / reduction is ONE kernel, nothing goes through the host
+    # transport; (with PCD_REPLICATE_BELOW lowered as here, levels that one
+    # engine composes into single operators stay step by step on ranks - the
+    # launch count at the default limit is in profiles/)
+    assert two["boot_calls_per_pcapply"] == 0.0
+    assert two["exchanges_per_pcapply"] >= 4
 
 
 @pytest.mark.timeout(300)
