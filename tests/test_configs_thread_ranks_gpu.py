@@ -62,12 +62,14 @@ def replicate_below(monkeypatch):
 
 @pytest.mark.heavy(4)
 @pytest.mark.timeout(900)
-def test_config4_unsteady_100_steps_on_1_2_4_ranks(hip_lib, replicate_below):
-    """100 steps on one rank (round 2's totals), the first 25 of them (the
-    length of the reference's own table) on two and on four ranks:
-    R thread ranks share ONE GPU, so a run costs R times the replicated device
-    work, and the suite has a time budget.  The full 100 steps on 2 and 4
-    ranks are a tools/ run, repeated every round
+def test_config4_unsteady_100_steps_on_1_and_2_ranks(hip_lib, replicate_below):
+    """BASELINE config 4 as it is stated: the unsteady demo, 100 time steps,
+    row-partitioned - the FULL 100 steps on one rank and on two thread ranks
+    (R thread ranks share ONE GPU: a run costs R times the replicated device
+    work).  Identical Picard counts, Krylov totals that agree to a handful of
+    iterations (round-off of the partitioned reductions), replicas identical.
+    Four ranks (the other half of config 4) run the same code path with more
+    neighbours: tools/unsteady_thread_ranks.py, repeated every round
     (profiles/r03_i_unsteady_level4_100steps_thread_ranks.jsonl: 13339 /
     13340 / 13340 Krylov iterations on 1 / 2 / 4 ranks)."""
     # partitioned finest levels, replicated coarse ones - as on real ranks; the
@@ -96,48 +98,77 @@ def test_config4_unsteady_100_steps_on_1_2_4_ranks(hip_lib, replicate_below):
     # round 2's totals (13339 Krylov / 421 Picard iterations); the producer's
     # element matrices changed by round-off since: a small band
     assert abs(one["krylov"] - 13339) <= 70 and abs(one["picard"] - 421) <= 2
-    for R, steps in ((2, 25), (4, 25)):
-        runs = _on_ranks(R, solver(steps))
-        ref_k = sum(one["per_step"][:steps])
-        ref_p = sum(one["picard_per_step"][:steps])
-        for r in runs:                          # every replica
-            assert r["steps"] == steps and r["picard"] == ref_p
-            assert abs(r["krylov"] - ref_k) <= 8, (R, r["krylov"], ref_k)
-        assert len({r["krylov"] for r in runs}) == 1
-        assert len({round(r["checksum"], 6) for r in runs}) == 1
+    runs = _on_ranks(2, solver(100))
+    for r in runs:                              # every replica
+        assert r["steps"] == 100 and r["picard"] == one["picard"]
+        assert abs(r["krylov"] - one["krylov"]) <= 20, (r["krylov"],
+                                                        one["krylov"])
+    assert len({r["krylov"] for r in runs}) == 1
+    assert len({round(r["checksum"], 6) for r in runs}) == 1
     PETScOptions.clear()
 
 
 @pytest.mark.heavy(3)
-@pytest.mark.rss_gb(26)
+@pytest.mark.rss_gb(12)
 @pytest.mark.timeout(900)
 def test_config5_shape_cube_n32_on_8_ranks(hip_lib, replicate_below):
+    """BASELINE config 5's shape - 3-D lid-driven cube, three components per
+    node, 8 ranks - with the PARTITIONED producer (fem/partition.py): every
+    rank assembles its slab only and hands its rows over; the finest levels
+    partitioned, the rest replicated; re-discretised coarse velocity operators
+    (-pc_mg_galerkin none).  Against one rank with the same options."""
+    from fenapack_amd.driver import solve_steady
+    from fenapack_amd.fem import partition as pt
     replicate_below(20000)
     PETScOptions.clear()
-    multigrid_inner_options(dim=3)
+    multigrid_inner_options(dim=3, galerkin_u=False)
+    kw = dict(level=3, nu=0.01, n0=4)                    # N = 32: 859 812 DOF
+    R = 8
+    one = solve_steady(Cavity3D(3, nu=0.01, n0=4), max_newton=2,
+                       newton_rtol=0.0)
+    x1 = one["w"].vector().copy()
+    assert one["w"].function_space().ndof == 859812
+    assert one["krylov_per_step"][0] <= 12 and one["krylov_per_step"][1] <= 55
+    hosts = pt.ThreadHostComm.group(R)
+    group = ctypes.c_void_p()
+    res, errs = [None] * R, []
 
-    # one problem object for all ranks (read-only here; its pattern caches are
-    # warm after the one-rank run): the R threads would otherwise build it R
-    # times under the interpreter lock
-    pb = Cavity3D(3, nu=0.01, n0=4)                      # N = 32: 859 812 DOF
+    def body(r):
+        try:
+            from fenapack_amd import _cabi as c
+            comm = Comm(r, R, thread_group=group)
+            comm.host = hosts[r]
+            pp = pt.partitioned(Cavity3D, r, R, host=hosts[r], **kw)
+            out = solve_steady(pp, max_newton=2, newton_rtol=0.0, comm=comm)
+            eng = out["solver"].linear_solver().ksp().engine
+            res[r] = {"its": out["krylov_per_step"],
+                      "x": out["w"].vector().copy(),
+                      "rows_u": int(eng.info(c.INFO_N_U_LOCAL)),
+                      "cells": int(pp.fine.sub.cells.size),
+                      "all_cells": int(pp.space.mesh.num_cells)}
+        except Exception as ex:            # pragma: no cover
+            import traceback
+            errs.append((r, repr(ex), traceback.format_exc()))
+            hosts[r]._sh.barrier.abort()
 
-    def solve(comm):
-        from fenapack_amd import _cabi as c
-        out = solve_steady_device(pb, max_newton=10, comm=comm)
-        eng = out["solver"].linear_solver().ksp().engine
-        return {"ndof": pb.space.ndof, "its": out["krylov_per_step"],
-                "rows_u": int(eng.info(c.INFO_N_U_LOCAL)),
-                "checksum": float(abs(out["w"].vector()).sum())}
-
-    one = _on_ranks(1, solve)[0]
-    eight = _on_ranks(8, solve)
-    assert one["ndof"] == 859812
-    assert one["its"][0] <= 12 and one["its"][1] <= 50
-    for r in eight:
-        assert r["its"] == one["its"]
-        assert abs(r["checksum"] - one["checksum"]) <= 1e-9 * one["checksum"]
-    rows = [r["rows_u"] for r in eight]
-    assert sum(rows) == one["rows_u"] and max(rows) - min(rows) <= 3
+    th = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    assert not any(t.is_alive() for t in th), "ranks deadlocked"
+    assert not errs, errs
+    import numpy as np
+    for r in res:
+        assert all(abs(a - b) <= 1 for a, b in zip(r["its"],
+                                                   one["krylov_per_step"])), (
+            r["its"], one["krylov_per_step"])
+        assert np.abs(r["x"] - x1).max() <= 1e-6 * np.abs(x1).max()
+        assert np.array_equal(r["x"], res[0]["x"])
+        assert r["cells"] < 0.3 * r["all_cells"]        # a slab, not the mesh
+    rows = [r["rows_u"] for r in res]
+    assert sum(rows) == one["w"].function_space().n_u
+    assert max(rows) - min(rows) <= 3
     PETScOptions.clear()
 
 
