@@ -128,7 +128,12 @@ def test_config5_shape_cube_n32_on_8_ranks(hip_lib, replicate_below):
                        newton_rtol=0.0)
     x1 = one["w"].vector().copy()
     assert one["w"].function_space().ndof == 859812
-    assert one["krylov_per_step"][0] <= 12 and one["krylov_per_step"][1] <= 55
+    # (re-discretised coarse levels - what a partitioned producer assembles
+    # without communication - cost iterations in 3-D against Galerkin ones:
+    # 10 / 44 there, DESIGN.md "Galerkin vs re-discretised")
+    assert one["krylov_per_step"][0] <= 30 and one["krylov_per_step"][1] <= 110, \
+        one["krylov_per_step"]
+    print("cube N = 32, re-discretised coarse levels: GMRES", one["krylov_per_step"])
     hosts = pt.ThreadHostComm.group(R)
     group = ctypes.c_void_p()
     res, errs = [None] * R, []
