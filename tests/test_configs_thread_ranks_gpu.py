@@ -109,7 +109,7 @@ def test_config4_unsteady_100_steps_on_1_and_2_ranks(hip_lib, replicate_below):
 
 
 @pytest.mark.heavy(3)
-@pytest.mark.rss_gb(12)
+@pytest.mark.rss_gb(16)
 @pytest.mark.timeout(900)
 def test_config5_shape_cube_n32_on_8_ranks(hip_lib, replicate_below):
     """BASELINE config 5's shape - 3-D lid-driven cube, three components per
