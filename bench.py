@@ -78,12 +78,26 @@ def parse():
                    help="fieldsplit_u_pc_mg_coarse_eq_limit: the coarsest "
                         "velocity level is the largest one of at most this "
                         "many rows (its inverse is kept explicitly)")
+    p.add_argument("--partitioned-producer", action="store_true",
+                   help="several ranks: every rank assembles ITS rows only "
+                        "(fenapack_amd/fem/partition.py) instead of building "
+                        "the whole problem and slicing; implies "
+                        "--rediscretise-u for nested hierarchies (coarse "
+                        "levels assembled without communication); default "
+                        "for the cube from one million cells on")
     p.add_argument("--no-producer", action="store_true",
                    help="skip the end-to-end Picard-step timing at the end")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--dist-backend", default=None,
                    help="torch.distributed backend of the bootstrap group "
                         "(default: nccl = RCCL on a GPU box, gloo without)")
+    p.add_argument("--share-gpu", action="store_true",
+                   help="TEST ONLY: all ranks on GPU 0 (a box with one GPU): "
+                        "torch.distributed over gloo bootstraps the engine's "
+                        "peer-write protocol over HIP IPC (RCCL refuses two "
+                        "ranks on one device); the ranks time-share the GPU, "
+                        "so the figure is a code-path check, not a scaling "
+                        "point")
     p.add_argument("--stub-step", action="store_true",
                    help="TEST ONLY: replace the engine workload by a no-op "
                         "step so that the launch / barrier / max-over-ranks "
@@ -171,6 +185,8 @@ def timed_steps(step, sync, args, dist, world, device):
     dt = time.perf_counter() - t0
     if world > 1:
         import torch
+        if dist.get_backend() == "gloo":
+            device = "cpu"
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -240,15 +256,21 @@ def main():
             max(1, min(32, (os.cpu_count() or 8) // world))))
     import torch
     import torch.distributed as dist
-    if torch.cuda.device_count() < world:
+    if args.share_gpu:
+        local = 0
+    elif torch.cuda.device_count() < world:
         raise SystemExit("--gpus %d but this node shows %d GPU(s): one "
                          "process drives one GPU (RCCL refuses two ranks on "
-                         "one device)" % (world, torch.cuda.device_count()))
+                         "one device; --share-gpu is the single-GPU test "
+                         "mode)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.dist_backend or "nccl",
-                                device_id=torch.device("cuda", local))
+        if args.share_gpu:
+            dist.init_process_group(args.dist_backend or "gloo")
+        else:
+            dist.init_process_group(args.dist_backend or "nccl",
+                                    device_id=torch.device("cuda", local))
 
     from fenapack_amd import PETScOptions
     from fenapack_amd import _cabi as c
@@ -260,12 +282,35 @@ def main():
     from fenapack_amd.petsc import Vec
 
     t_setup = time.time()
+    from fenapack_amd.parallel import Comm
+    comm = Comm.world()
+    if args.share_gpu and world > 1:
+        from fenapack_amd.parallel import TorchHostTransport
+        comm = Comm(rank, world, host_transport=TorchHostTransport())
     if args.geometry == "cavity":
-        pb = Cavity(args.level, nu=0.01, variant=args.variant)   # Re = 100
+        cls, kw = Cavity, dict(level=args.level, nu=0.01, variant=args.variant)
     elif args.geometry == "cube":                                # 3D, Re = 100
-        pb = Cavity3D(args.level, nu=0.01, n0=args.n0, variant=args.variant)
+        cls, kw = Cavity3D, dict(level=args.level, nu=0.01, n0=args.n0,
+                                 variant=args.variant)
     else:
-        pb = BackwardStep(args.level, nu=0.02, variant=args.variant)
+        cls, kw = BackwardStep, dict(level=args.level, nu=0.02,
+                                     variant=args.variant)
+    big_cube = args.geometry == "cube" and \
+        6 * (args.n0 * 2 ** args.level) ** 3 >= 1000000
+    partitioned = world > 1 and (args.partitioned_producer or big_cube)
+    if partitioned:
+        # every rank assembles its slab only; the few host-side reductions of
+        # the set-up travel over a gloo group beside the RCCL one
+        from fenapack_amd.fem import partition as pt
+        os.environ.setdefault("FENAPACK_AMD_MAX_CELLS", "4000000")
+        os.environ.setdefault("FENAPACK_AMD_IGNORE_MEMORY", "1")
+        comm.host = pt.TorchHostComm()
+        pb = pt.partitioned(cls, rank, world, host=comm.host, **kw)
+        if not args.algebraic:
+            args.rediscretise_u = True
+    else:
+        kw = dict(kw)
+        pb = cls(kw.pop("level"), **kw)
     V = pb.space
     PETScOptions.clear()
     if args.inner == "mg":
@@ -293,8 +338,6 @@ def main():
         PETScOptions.set("fieldsplit_u_pc_mg_skip_levels", args.skip_u)
     if args.skip_p:
         PETScOptions.set("fieldsplit_p_PCD_Ap_pc_mg_skip_levels", args.skip_p)
-    from fenapack_amd.parallel import Comm
-    comm = Comm.world()
     # tolerances 0: EXACTLY `picard_steps` nonlinear iterations, so that the
     # frozen operators always carry convection (on fine 3-D meshes the first,
     # Stokes-like step already meets the demo's 1e-5 residual reduction)
@@ -526,6 +569,8 @@ def main():
             "gmres": "restart 150, rtol 1e-6, right PC",
             "launch": "eager" if args.no_graph else "hipGraph replay",
             "parallelism": "row partition x%d" % world,
+            "producer": "partitioned (every rank assembles its rows)"
+                        if partitioned else "global",
         },
         "gmres_its_per_newton_step": gmres_per_step,
         "pcapply_ms_synchronised_p10_median_p90": [
