@@ -199,3 +199,32 @@ def test_a_process_that_leaves_does_not_hang_the_other(hip_lib, tmp_path):
     # the GPU still works
     t = torch.ones(1024, device="cuda")
     assert float(t.sum().item()) == 1024.0
+
+
+@pytest.mark.timeout(400)
+def test_bench_with_two_ranks_sharing_the_gpu(hip_lib):
+    """bench.py --gpus 2 through its own launcher, the ranks as two processes
+    on GPU 0 (--share-gpu: gloo bootstraps the peer protocol over HIP IPC):
+    the contract's multi-rank path - launcher, barrier-bracketed timed region,
+    max over ranks, ONE JSON line, hipGraph replay with ranks - on a box with
+    one GPU.  (Real GPUs: test_two_gpus.py.)"""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for extra in ([], ["--partitioned-producer"]):
+        run = subprocess.run(
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+             "--share-gpu", "--level", "4", "--steps", "10", "--warmup", "3",
+             "--no-cpu-baseline"] + extra,
+            env=env, capture_output=True, text=True, timeout=360)
+        assert run.returncode == 0, run.stderr[-3000:]
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, run.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 10 and d["value"] > 0
+        assert d["config"]["parallelism"] == "row partition x2"
+        assert d["config"]["launch"] == "hipGraph replay"
+        assert ("partitioned" in d["config"]["producer"]) == bool(extra)
+        assert len(d["gmres_its_per_newton_step"]) == 2
