@@ -896,6 +896,61 @@ int pcdo_get_info(pcdo_t *h, int key, double *out) {
  * ========================================================================== */
 #ifdef _OPENMP
 #define T_FOR _Pragma("omp for schedule(static)")
+/* Loops of the team: one static partition per loop LENGTH.  Long loops (>=
+ * t_big iterations) run on the whole team and end in the team's barrier; short
+ * ones - the coarse multigrid levels, a few hundred to a few thousand rows -
+ * run on the first t_sub threads only and end in a barrier of those threads:
+ * libgomp's barrier is centralised, its cost grows with the team (measured,
+ * round 3: 2.5 ms per PCApply on 16 threads, 12.8 ms on 128 - about 150
+ * barriers per apply at 0.5 us per thread each), and a 7-row share per thread
+ * is all overhead.  Before the next long loop (or `single`) the threads that
+ * sat the short ones out meet the others in one full barrier (t_sync). */
+static int t_big = 40000, t_sub = 8;
+static __thread int t_dirty = 0;            /* short loops since the last full barrier */
+static __thread int t_sense = 0;
+static volatile int t_sb_count = 0, t_sb_sense = 0;
+
+static inline void t_sync(void) {
+  if (t_dirty) {
+    _Pragma("omp barrier")
+    t_dirty = 0;
+  }
+}
+static inline void t_sub_barrier(int k) {
+  t_sense = !t_sense;
+  if (__atomic_add_fetch(&t_sb_count, 1, __ATOMIC_ACQ_REL) == k) {
+    __atomic_store_n(&t_sb_count, 0, __ATOMIC_RELAXED);
+    __atomic_store_n(&t_sb_sense, t_sense, __ATOMIC_RELEASE);
+  } else {
+    while (__atomic_load_n(&t_sb_sense, __ATOMIC_ACQUIRE) != t_sense) __builtin_ia32_pause();
+  }
+}
+static inline int t_width(int64_t n) {
+  const int nth = omp_get_num_threads();
+  return (n >= t_big || nth <= t_sub) ? nth : t_sub;
+}
+static inline int64_t t_lo(int64_t n) {
+  const int nth = omp_get_num_threads(), tid = omp_get_thread_num(), k = t_width(n);
+  if (k == nth) t_sync();
+  return tid < k ? n * tid / k : 0;
+}
+static inline int64_t t_hi(int64_t n) {
+  const int tid = omp_get_thread_num(), k = t_width(n);
+  return tid < k ? n * (tid + 1) / k : 0;
+}
+static inline void t_end(int64_t n) {
+  const int nth = omp_get_num_threads(), k = t_width(n);
+  if (k == nth) {
+    _Pragma("omp barrier")
+  } else {
+    if (omp_get_thread_num() < k) t_sub_barrier(k);
+    t_dirty = 1;
+  }
+}
+#define T_LOOP(i, n)                                                            \
+  for (int64_t i##_n = (n), i##_lo = t_lo(i##_n), i##_hi = t_hi(i##_n), i##_go = 1; \
+       i##_go; i##_go = 0, t_end(i##_n))                                        \
+    for (int64_t i = i##_lo; i < i##_hi; ++i)
 
 typedef struct {
   int levels, nu_pre, nu_post;
@@ -931,8 +986,7 @@ static void t_copy_csr(csr_t *d, const csr_t *s, int threads) {
   if (s->dinv) d->dinv = (double *)t_alloc(sizeof(double) * s->nrows);
 #pragma omp parallel num_threads(threads)
   {
-    T_FOR
-    for (int64_t i = 0; i < s->nrows; ++i) {
+    T_LOOP(i, s->nrows) {
       d->rowptr[i] = s->rowptr[i];
       for (int32_t k = s->rowptr[i]; k < s->rowptr[i + 1]; ++k) {
         d->col[k] = s->col[k]; d->val[k] = s->val[k];
@@ -947,8 +1001,7 @@ static double *t_vec(int64_t n, int threads) {
   double *v = (double *)t_alloc(sizeof(double) * n);
 #pragma omp parallel num_threads(threads)
   {
-    T_FOR
-    for (int64_t i = 0; i < n; ++i) v[i] = 0.0;
+    T_LOOP(i, n) v[i] = 0.0;
   }
   return v;
 }
@@ -957,8 +1010,7 @@ static double *t_vec(int64_t n, int threads) {
 /* mode 0: y = A x; 1: y = add + A x; 2: y = add - A x */
 static void t_spmv(const csr_t *A, const double *x, double *y, int mode,
                    const double *add) {
-  T_FOR
-  for (int64_t i = 0; i < A->nrows; ++i) {
+  T_LOOP(i, A->nrows) {
     double s = 0.0;
     for (int32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
       s += A->val[k] * x[A->col[k]];
@@ -970,8 +1022,7 @@ static void t_spmv(const csr_t *A, const double *x, double *y, int mode,
 static void t_cheb_step(const csr_t *A, const double *b, const double *pm,
                         const double *pk, double *pn, double c0, double c1,
                         double c2) {
-  T_FOR
-  for (int64_t i = 0; i < A->nrows; ++i) {
+  T_LOOP(i, A->nrows) {
     double s = 0.0;
     for (int32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
       s += A->val[k] * pk[A->col[k]];
@@ -982,8 +1033,7 @@ static void t_cheb_step(const csr_t *A, const double *b, const double *pm,
 }
 
 static void t_scale_dinv(const csr_t *A, const double *b, double s, double *x) {
-  T_FOR
-  for (int64_t i = 0; i < A->nrows; ++i) x[i] = s * (A->dinv[i] * b[i]);
+  T_LOOP(i, A->nrows) x[i] = s * (A->dinv[i] * b[i]);
 }
 
 /* nu Chebyshev-Jacobi steps; iterates rotate through bufs; returns the
@@ -1018,8 +1068,7 @@ static double *t_vcycle(team_mg_t *g, const csr_t *Afine, int l,
   double *bufs[3] = {g->x[l], g->t0[l], g->t1[l]};
   double *px = t_smooth(A, g->emin[l], g->emax[l], g->nu_pre, b, bufs, 1);
   if (g->nu_pre == 0) {
-    T_FOR
-    for (int64_t i = 0; i < A->nrows; ++i) px[i] = 0.0;
+    T_LOOP(i, A->nrows) px[i] = 0.0;
   }
   const double *r = b;
   if (g->nu_pre > 0) { t_spmv(A, px, g->r[l], 2, b); r = g->r[l]; }
@@ -1043,8 +1092,8 @@ static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) 
       const double *r = b;
       if (it > 0) { t_spmv(A, x, T->cw[slot][0], 2, b); r = T->cw[slot][0]; }
       double *z = t_vcycle(&T->mg[slot], A, T->mg[slot].levels - 1, r);
-      if (it == 0) { T_FOR for (int64_t i = 0; i < n; ++i) x[i] = z[i]; }
-      else { T_FOR for (int64_t i = 0; i < n; ++i) x[i] += z[i]; }
+      if (it == 0) { T_LOOP(i, n) x[i] = z[i]; }
+      else { T_LOOP(i, n) x[i] += z[i]; }
     }
     return;
   }
@@ -1053,7 +1102,7 @@ static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) 
     double scale = 2.0 / (s->emax + s->emin), alpha = 1.0 - scale * s->emin;
     double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, c_km1 = 1.0, c_k = mu;
     if (s->pc == PC_JACOBI) t_scale_dinv(A, b, scale, ring[0]);
-    else { T_FOR for (int64_t i = 0; i < n; ++i) ring[0][i] = scale * b[i]; }
+    else { T_LOOP(i, n) ring[0][i] = scale * b[i]; }
     for (int it = 0; it < s->max_it; ++it) {
       double c_kp1 = 2.0 * mu * c_k - c_km1, omega = omegaprod * c_k / c_kp1;
       double *pk = ring[it % 3], *pn = ring[(it + 1) % 3];
@@ -1062,8 +1111,7 @@ static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) 
       c_km1 = c_k; c_k = c_kp1;
     }
     const double *res = ring[s->max_it % 3];
-    T_FOR
-    for (int64_t i = 0; i < n; ++i) x[i] = res[i];
+    T_LOOP(i, n) x[i] = res[i];
     return;
   }
   if (s->ksp == KSP_PREONLY) { t_scale_dinv(A, b, 1.0, x); return; }
@@ -1071,8 +1119,7 @@ static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) 
     t_scale_dinv(A, b, 1.0, x);
     for (int it = 1; it < s->max_it; ++it) {
       t_cheb_step(A, b, x, x, T->cw[slot][0], 0.0, 1.0, 1.0);
-      T_FOR
-      for (int64_t i = 0; i < n; ++i) x[i] = T->cw[slot][0][i];
+      T_LOOP(i, n) x[i] = T->cw[slot][0][i];
     }
     return;
   }
@@ -1080,10 +1127,11 @@ static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) 
    * scalars, every thread takes the same decision */
   double *r = T->cw[slot][0], *z = T->cw[slot][1], *p = T->cw[slot][2];
   double *q = T->mg[slot].x[MG_MAX_LEVELS - 1];
-  T_FOR
-  for (int64_t i = 0; i < n; ++i) {
+  t_sync();
+  T_LOOP(i, n) {
     x[i] = 0.0; r[i] = b[i]; z[i] = A->dinv[i] * b[i]; p[i] = z[i];
   }
+  t_sync();
 #pragma omp single
   T->rz = 0.0;
   { double acc = 0.0;
@@ -1095,6 +1143,7 @@ static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) 
   for (int it = 0; it < s->max_it; ++it) {
     if (rz == 0.0) break;
     if (s->rtol > 0.0 && sqrt(fabs(rz)) <= s->rtol * sqrt(fabs(rz0))) break;
+  t_sync();
 #pragma omp single
     T->pq = 0.0;
     { double acc = 0.0;
@@ -1109,6 +1158,7 @@ static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) 
 #pragma omp barrier
     double alpha_ = rz / T->pq;
 #pragma omp barrier
+  t_sync();
 #pragma omp single
     T->rz = 0.0;
     { double acc = 0.0;
@@ -1122,8 +1172,7 @@ static void t_inner(pcdo_t *h, team_t *T, int slot, const double *b, double *x) 
 #pragma omp barrier
     double rz_new = T->rz, beta = rz_new / rz;
     rz = rz_new;
-    T_FOR
-    for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+    T_LOOP(i, n) p[i] = z[i] + beta * p[i];
   }
 }
 
@@ -1131,8 +1180,8 @@ static void t_pcd(pcdo_t *h, team_t *T, const double *x, double *y) {
   int64_t n = h->n_p;
   double *z = T->w0, *z1 = T->w1;
   if (h->variant == BRM1 || h->variant == RBRM1) {
-    T_FOR
-    for (int64_t i = 0; i < n; ++i) z[i] = x[i];
+    T_LOOP(i, n) z[i] = x[i];
+  t_sync();
 #pragma omp single
     for (int64_t i = 0; i < h->n_bc; ++i) z[h->bc_idx[i]] = h->bc_val[i];
     t_inner(h, T, SLOT_AP, z, y);
@@ -1140,19 +1189,20 @@ static void t_pcd(pcdo_t *h, team_t *T, const double *x, double *y) {
     t_inner(h, T, SLOT_MP, z1, y);
     if (h->variant == RBRM1) {
       t_inner(h, T, SLOT_RP, x, z);
-      T_FOR for (int64_t i = 0; i < n; ++i) y[i] = -(y[i] + z[i]);
-    } else { T_FOR for (int64_t i = 0; i < n; ++i) y[i] = -y[i]; }
+      T_LOOP(i, n) y[i] = -(y[i] + z[i]);
+    } else { T_LOOP(i, n) y[i] = -y[i]; }
   } else {
     t_inner(h, T, SLOT_MP, x, y);
     t_spmv(&T->mat[MAT_KP], y, z1, 0, NULL);
+  t_sync();
 #pragma omp single
     for (int64_t i = 0; i < h->n_bc; ++i) z1[h->bc_idx[i]] = h->bc_val[i];
     t_inner(h, T, SLOT_AP, z1, z);
     if (h->variant == RBRM2) {
-      T_FOR for (int64_t i = 0; i < n; ++i) y[i] += z[i];
+      T_LOOP(i, n) y[i] += z[i];
       t_inner(h, T, SLOT_RP, x, z);
     }
-    T_FOR for (int64_t i = 0; i < n; ++i) y[i] = -(y[i] + z[i]);
+    T_LOOP(i, n) y[i] = -(y[i] + z[i]);
   }
 }
 
@@ -1166,6 +1216,8 @@ int pcdo_team_prepare(pcdo_t *h, int threads) {
   if (!h->ready || !h->mat[MAT_A00].set)
     return fail(4, "team_prepare: system/setup missing");
   if (threads < 1) threads = omp_get_max_threads();
+  { const char *e = getenv("PCDO_TEAM_BIG"); if (e) t_big = atoi(e);
+    e = getenv("PCDO_TEAM_SUB"); if (e && atoi(e) > 0) t_sub = atoi(e); }
   int slot = team_slot(h);
   if (slot < 0) for (int i = 0; i < 64 && slot < 0; ++i) if (!g_team_owner[i]) slot = i;
   if (slot < 0) return fail(3, "team_prepare: too many engines");
@@ -1200,8 +1252,7 @@ int pcdo_team_prepare(pcdo_t *h, int threads) {
   T->perm = (int32_t *)t_alloc(sizeof(int32_t) * n);
 #pragma omp parallel num_threads(threads)
   {
-    T_FOR
-    for (int64_t i = 0; i < n; ++i) T->perm[i] = h->perm[i];
+    T_LOOP(i, n) T->perm[i] = h->perm[i];
   }
   g_team[slot] = T; g_team_owner[slot] = h;
   return 0;
@@ -1214,13 +1265,11 @@ int pcdo_team_fieldsplit_apply(pcdo_t *h, const double *x, double *y) {
   int64_t nu = h->n_u, n = h->n_u + h->n_p;
 #pragma omp parallel num_threads(T->threads)
   {
-    T_FOR
-    for (int64_t i = 0; i < n; ++i) T->xs[i] = x[T->perm[i]];
+    T_LOOP(i, n) T->xs[i] = x[T->perm[i]];
     t_pcd(h, T, T->xs + nu, T->ys + nu);                /* y_p = S^-1 x_p */
     t_spmv(&T->mat[MAT_A01], T->ys + nu, T->wu, 2, T->xs);   /* x_u - A01 y_p */
     t_inner(h, T, SLOT_A00, T->wu, T->ys);
-    T_FOR
-    for (int64_t i = 0; i < n; ++i) y[T->perm[i]] = T->ys[i];
+    T_LOOP(i, n) y[T->perm[i]] = T->ys[i];
   }
   ++h->num_fs;
   return 0;
@@ -1235,8 +1284,7 @@ double pcdo_stream_triad(int64_t n, int reps, int threads) {
     double t0 = omp_get_wtime();
 #pragma omp parallel num_threads(threads)
     {
-      T_FOR
-      for (int64_t i = 0; i < n; ++i) a[i] = b[i] + 3.0 * c[i];
+      T_LOOP(i, n) a[i] = b[i] + 3.0 * c[i];
     }
     double dt = omp_get_wtime() - t0;
     double gbs = 24.0 * (double)n / dt / 1e9;

@@ -265,13 +265,29 @@ def test_three_dimensional_producer_and_solver_chain():
     assert relerr(st["A"] @ x, st["b"]) < 1e-6
 
 
-@pytest.mark.parametrize("variant,mg", [("BRM1", True), ("BRM2", True),
-                                        ("RBRM1", False), ("BRM1", False)])
-def test_team_timing_port_equals_the_serial_oracle(variant, mg):
+@pytest.mark.parametrize("variant,mg,sub", [("BRM1", True, None),
+                                            ("BRM2", True, None),
+                                            ("RBRM1", False, None),
+                                            ("BRM1", False, None),
+                                            # short loops on a sub-team of two
+                                            ("BRM1", True, 2),
+                                            ("RBRM1", False, 2)])
+def test_team_timing_port_equals_the_serial_oracle(variant, mg, sub,
+                                                   monkeypatch):
     """bench.py's cpu_baseline times the OpenMP TEAM port (one parallel region
-    per PCApply, first-touch placement, fused loops); it must compute what
-    the serial parity oracle computes."""
+    per PCApply, first-touch placement, fused loops, short loops on a
+    sub-team); it must compute what the serial parity oracle computes."""
     from helpers import push_multigrid
+    if sub:
+        # (rows of the finest level here: 5 k velocity, 0.7 k pressure - the
+        # finest velocity loops stay on the whole team, everything else goes
+        # to the sub-team; the box's default would put ALL loops of this
+        # small problem on one side)
+        monkeypatch.setenv("PCDO_TEAM_SUB", str(sub))
+        monkeypatch.setenv("PCDO_TEAM_BIG", "3000")
+    else:
+        monkeypatch.setenv("PCDO_TEAM_SUB", "8")
+        monkeypatch.setenv("PCDO_TEAM_BIG", "40000")
     st = flow_state("lshape", 3, dt=0.2 if variant.startswith("R") else None)
     pb, V, L = st["pb"], st["V"], st["L"]
     par, _ = oracle.omp_engine(variant)
