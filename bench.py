@@ -848,8 +848,11 @@ def cpu_baseline(args, pb, ksp, eng, c, x, algorithmic_bytes=None):
         sweep_best = rN
         rN, nN, tN = n_done / el, n_done, el
         errN = float(np.abs(yh2 - yh).max() / np.abs(yh).max())
+        # the host's own roof by thread count: why more threads than the best
+        # count do not help (the triad stops growing where the sweep peaks)
         triad = {t: round(par.stream_triad(1 << 27, 2, t), 1)
-                 for t in sorted(set((nthreads, phys, navail)))}
+                 for t in sorted(set(t for t in (8, 16, 32, 64, nthreads, phys,
+                                                 navail) if 1 <= t <= navail))}
         out["all_cores"] = {
             "value": rN, "threads": nthreads, "threads_available": navail,
             "physical_cores": phys, "sweep": sweep,
@@ -858,9 +861,12 @@ def cpu_baseline(args, pb, ksp, eng, c, x, algorithmic_bytes=None):
             "host_stream_triad_gbs_by_threads": triad,
             "pcapply_gbs_at_best": rN * algorithmic_bytes / 1e9
             if algorithmic_bytes else None,
+            "frac_of_host_triad_at_best":
+                (rN * algorithmic_bytes / 1e9 / triad[nthreads])
+                if algorithmic_bytes and triad.get(nthreads) else None,
             "sample": "%d PCApply (%.1f s), OpenMP TEAM port: one parallel "
                       "region per apply, first-touch placement, fused "
-                      "loops" % (nN, tN)}
+                      "loops, short loops on a sub-team of 8" % (nN, tN)}
         if rN > r1:
             out["value"], out["cores"] = rN, nthreads
             out["sample"] = ("%d fieldsplit PCApply of the same workload and "
