@@ -130,7 +130,7 @@ def test_config5_shape_cube_n32_on_8_ranks(hip_lib, replicate_below):
     assert one["w"].function_space().ndof == 859812
     # (re-discretised coarse levels - what a partitioned producer assembles
     # without communication - cost iterations in 3-D against Galerkin ones:
-    # 10 / 44 there, DESIGN.md "Galerkin vs re-discretised")
+    # 10 / 44 there)
     assert one["krylov_per_step"][0] <= 30 and one["krylov_per_step"][1] <= 110, \
         one["krylov_per_step"]
     print("cube N = 32, re-discretised coarse levels: GMRES", one["krylov_per_step"])

@@ -84,7 +84,7 @@ def test_cavity_level6_headline_workload(variant, its):
 def test_cavity_level7_re1000_supg():
     """BASELINE configs[2]: 3 692 803 DOF, Re = 1000, SUPG-stabilised
     preconditioner matrix (stabilization.py), re-discretised coarse levels,
-    2 x V(3,3) per inner solve."""
+    2 x V(3,3) per inner solve (profiles/HISTORY_design_diary_rounds_1-3.md 9)."""
     pb = Cavity(7, nu=0.001, stabilize=True)
     assert pb.space.ndof == 3692803
     ksp, hist = frozen_state(pb, cycles_u=2, cycles_p=2, smooth=3,

@@ -322,3 +322,72 @@ def test_multigrid_push_from_a_partitioned_producer(monkeypatch, R):
         assert np.allclose(whole[0][3].toarray(), ref[0][3].toarray(),
                            rtol=1e-10, atol=1e-14)
     PETScOptions.clear()
+
+
+@pytest.mark.parametrize("R", [1, 3])
+def test_partitioned_smoothed_aggregation(R):
+    """amg.PartitionedSA on thread ranks: every rank aggregates its own rows,
+    owns the coarse dofs of its aggregates (uneven cuts), and the operators it
+    holds are rows of P^T A P of the hierarchy the ranks built together - the
+    Galerkin identity checked on the assembled whole.  One rank: the first
+    coarsening is the global builder's."""
+    from fenapack_amd import amg, _host
+    pb = Cavity3D(2, nu=0.01, n0=4)                       # cube N = 16
+    L = pb.linearise(*pb.initial_guess())
+    F = _host.kron_factor(sp.csr_matrix(L["A00"]), 3)
+    n = F.shape[0]
+    comms = pt.ThreadHostComm.group(R) if R > 1 else [pt.HostComm()]
+    cuts = pt.cut(n, R, 1)
+    res, errs = [None] * R, []
+
+    def body(r):
+        try:
+            r0, r1 = cuts[r], cuts[r + 1]
+            ip = np.zeros(n + 1, dtype=np.int64)
+            ip[r0 + 1:r1 + 1] = np.diff(F.indptr)[r0:r1]
+            np.cumsum(ip, out=ip)
+            Fr = sp.csr_matrix((F.data[F.indptr[r0]:F.indptr[r1]],
+                                F.indices[F.indptr[r0]:F.indptr[r1]], ip),
+                               shape=F.shape)
+            psa = amg.PartitionedSA(Fr, (r0, r1), comms[r], block=3,
+                                    replicate_rows=3000, coarse_rows=300)
+            res[r] = (psa, psa.operators(Fr))
+        except Exception:                               # pragma: no cover
+            import traceback
+            errs.append(traceback.format_exc())
+            if R > 1:
+                comms[r]._sh.barrier.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not errs, errs[0]
+    psa0 = res[0][0]
+    Lv = psa0.nlevels
+    flags = psa0.partitioned_levels()
+    assert flags[-1] and not flags[0] and Lv >= 3
+    cl = psa0.level_cuts()
+    if R > 1:
+        # (35 937 nodes -> ~1000 aggregates x 3 components = the one coarse
+        # level above the replication limit: partitioned, cut by aggregates)
+        assert sum(flags) == 2
+        cut1 = [c for c in cl if c is not None][0]
+        assert cut1[0] == 0 and len(cut1) == R + 1 and np.all(np.diff(cut1) > 0)
+    else:
+        ref = amg.smoothed_aggregation_chain(F, block=1, coarse_rows=300)
+        assert psa0.chain()[-1].shape == ref[-1].shape
+    chains = [res[r][0].chain() for r in range(R)]
+    opss = [res[r][1] for r in range(R)]
+    Pg = [None] + [sum(chains[r][l] for r in range(R)) if flags[l]
+                   else chains[0][l] for l in range(1, Lv)]
+    Og = [sum(opss[r][l] for r in range(R)) if flags[l] else opss[0][l]
+          for l in range(Lv)]
+    assert abs(Og[-1] - F).max() == 0.0               # the rows partition F
+    for l in range(Lv - 1, 0, -1):
+        C = (Pg[l].T @ Og[l] @ Pg[l]).tocsr()
+        assert abs(C - Og[l - 1]).max() <= 1e-12 * abs(Og[l - 1]).max(), l
+        # replicated levels are the same on every rank
+        if not flags[l - 1]:
+            for r in range(1, R):
+                assert (sp.csr_matrix(opss[r][l - 1])
+                        != sp.csr_matrix(opss[0][l - 1])).nnz == 0
