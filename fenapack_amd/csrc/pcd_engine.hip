@@ -3350,6 +3350,34 @@ static CommBackend* wrap_peer(Engine* h, CommBackend* boot, int rank, int nranks
   boot->rank = rank; boot->nranks = nranks;
   if (const char* t = getenv("PCD_PEER_TIMEOUT_S")) pb->spin_limit = (long long)(atof(t) * 1.0e8);
   int bad = pb->init(cap, tg ? tg->arenas.data() : nullptr, thread_group_barrier, tg, h->stream);
+  // self-test before anything depends on it: one peer all-reduce of a known
+  // vector with a short time-out - remote stores, flags and the mapped
+  // arenas of EVERY pair of ranks are exercised once; a platform where that
+  // does not work (no peer access between two devices, ...) falls back to
+  // the bootstrap backend on all ranks instead of failing in the first solve.
+  // (Thread ranks on the legacy stream cannot run it: their kernels would
+  // queue behind each other - they only use the protocol with own streams.)
+  if (!bad && pb->usable(h->stream)) {
+    const long long keep = pb->spin_limit;
+    pb->spin_limit = 500000000ll;                        // 5 s
+    double probe[2] = {(double)(rank + 1), 1.0};
+    double* dp = nullptr;
+    if (hipMalloc((void**)&dp, sizeof probe) != hipSuccess) bad = 1;
+    if (!bad) {
+      (void)hipMemcpyAsync(dp, probe, sizeof probe, hipMemcpyHostToDevice, h->stream);
+      if (pb->allreduce(dp, 2, h->stream)) bad = 1;
+      (void)hipMemcpyAsync(probe, dp, sizeof probe, hipMemcpyDeviceToHost, h->stream);
+      if (hipStreamSynchronize(h->stream) != hipSuccess) bad = 1;
+      if (pb->take_error(h->stream)) bad = 1;
+      if (probe[0] != 0.5 * nranks * (nranks + 1) || probe[1] != (double)nranks) {
+        bad = 1;
+        if (pb->err.empty()) pb->err = "peer self-test: wrong sum";
+      }
+      (void)hipFree(dp);
+    }
+    pb->spin_limit = keep;
+    pb->peer_calls = 0;
+  }
   // every rank must have its arena and its mappings, or nobody uses them
   double flag = bad ? 1.0 : 0.0;
   double* dflag = nullptr;
