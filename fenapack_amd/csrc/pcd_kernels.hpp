@@ -914,9 +914,18 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
 //   rowoff:  entry offsets of the block's rows relative to its first entry
 //   loc:     tile offset of every entry's column (uint16)
 // ==========================================================================
-constexpr int kVtRows = 32;        // rows per block (8 lanes share a row)
-constexpr int kVtNodes = 768;      // tile nodes (x NC doubles)
-constexpr int kVtRowOff = 34;      // row offsets per block (kVtRows + 1, padded)
+#ifndef PCD_VT_ROWS
+#define PCD_VT_ROWS 32
+#endif
+#ifndef PCD_VT_NODES
+#define PCD_VT_NODES 768
+#endif
+#ifndef PCD_VT_U
+#define PCD_VT_U 4
+#endif
+constexpr int kVtRows = PCD_VT_ROWS;        // rows per block (256 / rows lanes share a row)
+constexpr int kVtNodes = PCD_VT_NODES;      // tile nodes (x NC doubles)
+constexpr int kVtRowOff = PCD_VT_ROWS + 2;  // row offsets per block (rows + 1, padded)
 static_assert(kVtNodes % kBlock == 0, "one lane per tile node, whole passes");
 // per block: x = first row, y = first entry, z = first slot in `tsrc`,
 // w = rows | tile nodes << 8.  tsrc[z + t] = vector node of tile slot t (the
@@ -958,7 +967,7 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
     for (int i = 0; i < NC; ++i) tv[u][i] = src[u] ? src[u][i] : 0.0;
   // the first entries of my row: (value, tile offset), straight from the
   // stream (8 lanes of a row read 64 + 16 contiguous bytes per step)
-  constexpr int U = 4;
+  constexpr int U = PCD_VT_U;
   double v[U];
   int o[U];
 #pragma unroll

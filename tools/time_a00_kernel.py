@@ -12,15 +12,16 @@ from fenapack_amd import _cabi as c                       # noqa: E402
 from fenapack_amd.fem import Cavity, Cavity3D              # noqa: E402
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-cube = len(sys.argv) > 2 and sys.argv[2] == "cube"     # level = refinements of n0 = 4
-pb = Cavity3D(level, nu=0.01, n0=4) if cube else Cavity(level, nu=0.01)
+cube = len(sys.argv) > 2 and sys.argv[2] == "cube"     # level = refinements of n0 (default 4)
+n0 = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+pb = Cavity3D(level, nu=0.01, n0=n0) if cube else Cavity(level, nu=0.01)
 V = pb.space
 x, y = V.node_coords[:, 0], V.node_coords[:, 1]
 U = np.stack([np.sin(np.pi * x) ** 2 * np.sin(2 * np.pi * y),
               -np.sin(2 * np.pi * x) * np.sin(np.pi * y) ** 2]
              + ([0.1 * np.sin(np.pi * V.node_coords[:, 2])] if cube else []),
              axis=1)
-cache = "/tmp/a00_%s_%d.npz" % ("cube" if cube else "cavity", level)
+cache = "/tmp/a00_%s_%d_%d.npz" % ("cube" if cube else "cavity", level, n0)
 import scipy.sparse as sp                                  # noqa: E402
 if os.path.exists(cache):
     A00 = sp.load_npz(cache)
@@ -57,4 +58,5 @@ print("level %d n_u %d nnz %d: %.2f us per launch, %.0f GB/s algorithmic (%s)"
                   ("PCD_NO_XCD_REMAP", "PCD_NO_KRON2", "PCD_FORCE_CSR_VECTOR",
                    "PCD_MAX_RB", "PCD_MAX_CHUNKS", "PCD_MIN_WGS", "PCD_NO_COL16",
                    "PCD_XCD_REMAP_MAX_ROWS", "PCD_NT_BYTES", "PCD_XCD_REMAP_NT",
+                   "PCD_VEC_TILE", "PCD_VT_NT",
                    "FENAPACK_AMD_HIP_LIB") if k in os.environ) or "default"))
