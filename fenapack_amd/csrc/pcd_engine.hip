@@ -382,11 +382,10 @@ static bool g_no_small_tile = false;  // PCD_NO_SMALL_TILE=1: A/B switch
 // operators whose launches move more than this stream their matrix arrays with
 // non-temporal loads (PCD_NT_BYTES; -1: never): beyond the 256 MiB Infinity Cache
 static long long g_nt_bytes = 256ll << 20;
-// the tile kernels read a row's (value, offset) pairs with 8 lanes per row:
-// a cache line is touched by up to four consecutive load instructions of a
-// wave, so the loads keep the default cache policy (PCD_VT_NT=1: non-temporal
-// like the stream kernels - every touch then goes back to L2 / HBM)
-static int g_vt_nt = 0;
+// the tile kernels of operators streamed from HBM (nt2) take the STAGED form:
+// the block's (value, offset) pairs pass through LDS with coalesced
+// non-temporal loads; PCD_VT_NT=0 keeps the direct, default-policy form
+static int g_vt_nt = 1;
 static int g_num_cus = 256;
 static int ensure_pinned(Engine* h, size_t n) {
   if (n <= h->pinned_n) return 0;
@@ -1500,7 +1499,7 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
         while (r1 < rz && r1 - r < kVtRows) {
           const size_t before = cols.size();
           cols.insert(cols.end(), cc.begin() + rpc[r1], cc.begin() + rpc[r1 + 1]);
-          if (cols.size() > 60000) { cols.resize(before); break; }      // (16-bit row offsets)
+          if ((int64_t)cols.size() > kVtEntries) { cols.resize(before); break; }   // (staged form: LDS slots)
           uniq.assign(cols.begin(), cols.end());
           std::sort(uniq.begin(), uniq.end());
           uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());

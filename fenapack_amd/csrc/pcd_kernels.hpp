@@ -915,17 +915,18 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
 //   loc:     tile offset of every entry's column (uint16)
 // ==========================================================================
 #ifndef PCD_VT_ROWS
-#define PCD_VT_ROWS 32
+#define PCD_VT_ROWS 64
 #endif
 #ifndef PCD_VT_NODES
 #define PCD_VT_NODES 768
 #endif
 #ifndef PCD_VT_U
-#define PCD_VT_U 4
+#define PCD_VT_U 8
 #endif
 constexpr int kVtRows = PCD_VT_ROWS;        // rows per block (256 / rows lanes share a row)
 constexpr int kVtNodes = PCD_VT_NODES;      // tile nodes (x NC doubles)
 constexpr int kVtRowOff = PCD_VT_ROWS + 2;  // row offsets per block (rows + 1, padded)
+constexpr int kVtEntries = PCD_VT_ROWS * 32;  // entries per block (staged form: LDS slots)
 static_assert(kVtNodes % kBlock == 0, "one lane per tile node, whole passes");
 // per block: x = first row, y = first entry, z = first slot in `tsrc`,
 // w = rows | tile nodes << 8.  tsrc[z + t] = vector node of tile slot t (the
@@ -942,7 +943,7 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
     const int4 d, const unsigned short* __restrict__ rowoff, int blk,
     const int* __restrict__ tsrc, const double* __restrict__ val,
     const unsigned short* __restrict__ loc, const double* x,
-    const double* ghost, int nloc, double* tile) {
+    const double* ghost, int nloc, double* tile, double* ev, unsigned short* el) {
   constexpr int TPR = kBlock / kVtRows;
   const int lr = threadIdx.x / TPR, sub = threadIdx.x % TPR;
   const int k0 = d.y, nr = d.w & 0xff, tn = d.w >> 8;
@@ -965,36 +966,73 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   for (int u = 0; u < kVtNodes / kBlock; ++u)
 #pragma unroll
     for (int i = 0; i < NC; ++i) tv[u][i] = src[u] ? src[u][i] : 0.0;
-  // the first entries of my row: (value, tile offset), straight from the
-  // stream (8 lanes of a row read 64 + 16 contiguous bytes per step)
-  constexpr int U = PCD_VT_U;
-  double v[U];
-  int o[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int jj = ra + sub + u * TPR;
-    const bool in = jj < rb;
-    v[u] = in ? stream_load<NT>(val + k0 + jj) : 0.0;
-    o[u] = in ? (int)stream_load<NT>(loc + k0 + jj) : 0;
-  }
-#pragma unroll
-  for (int u = 0; u < kVtNodes / kBlock; ++u)
-    if (src[u]) {
-#pragma unroll
-      for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
-    }
-  __syncthreads();
   VecC<NC> s = vzero<NC>();
+  if (NT) {
+    // operators streamed from HBM: the block's (value, tile offset) pairs go
+    // through LDS with fully coalesced NON-TEMPORAL loads (lane t takes
+    // entries t, t + 256, ...) - read by rows they would touch every cache
+    // line from up to four load instructions, and a non-temporal line is
+    // fetched again each time (N = 48: 128 -> 157 us)
+    constexpr int UE = kVtEntries / kBlock;
+    const int ne = rowoff[blk * kVtRowOff + nr];
+    double ve[UE];
+    unsigned short le[UE];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UE; ++u) {
+      const int j = threadIdx.x + u * kBlock;
+      const bool in = j < ne;
+      ve[u] = in ? stream_load<true>(val + k0 + j) : 0.0;
+      le[u] = in ? stream_load<true>(loc + k0 + j) : (unsigned short)0;
+    }
 #pragma unroll
-    for (int i = 0; i < NC; ++i) s.c[i] += v[u] * tile[i * kVtNodes + o[u]];
-  }
-  for (int jj = ra + sub + U * TPR; jj < rb; jj += TPR) {     // long rows
-    const double vv = stream_load<NT>(val + k0 + jj);
-    const int oo = stream_load<NT>(loc + k0 + jj);
+    for (int u = 0; u < kVtNodes / kBlock; ++u)
+      if (src[u]) {
 #pragma unroll
-    for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
+        for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
+      }
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      const int j = threadIdx.x + u * kBlock;
+      if (j < ne) { ev[j] = ve[u]; el[j] = le[u]; }
+    }
+    __syncthreads();
+    for (int jj = ra + sub; jj < rb; jj += TPR) {
+      const double vv = ev[jj];
+      const int oo = el[jj];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
+    }
+  } else {
+    // cache-resident operators: the first entries of my row straight from
+    // the stream (the lanes of a row read contiguous bytes per step)
+    constexpr int U = PCD_VT_U;
+    double v[U];
+    int o[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int jj = ra + sub + u * TPR;
+      const bool in = jj < rb;
+      v[u] = in ? val[k0 + jj] : 0.0;
+      o[u] = in ? (int)loc[k0 + jj] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kVtNodes / kBlock; ++u)
+      if (src[u]) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += v[u] * tile[i * kVtNodes + o[u]];
+    }
+    for (int jj = ra + sub + U * TPR; jj < rb; jj += TPR) {     // long rows
+      const double vv = val[k0 + jj];
+      const int oo = loc[k0 + jj];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
+    }
   }
 #pragma unroll
   for (int m = TPR / 2; m > 0; m >>= 1) {
@@ -1004,7 +1042,10 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   return s;
 }
 
-#define PCD_VT_SHARED(NC) __shared__ double tile[NC * kVtNodes]
+#define PCD_VT_SHARED(NC)                                         \
+  __shared__ double tile[NC * kVtNodes];                          \
+  __shared__ double ev[NT ? kVtEntries : 1];                      \
+  __shared__ unsigned short el[NT ? kVtEntries : 1]
 
 #define PCD_VT_ARGS                                                                   \
   int nblocks, const int4* __restrict__ desc, const unsigned short* __restrict__ rowoff, \
@@ -1027,7 +1068,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tc(
     const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && lr < (d.w & 0xff);
     VecC<NC> a = vzero<NC>();
     if ((MODE == 1 || MODE == 2) && mine) a = add[row];
-    const VecC<NC> s = tile_row_block<NC, NT>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile);
+    const VecC<NC> s = tile_row_block<NC, NT>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile, ev, el);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -1061,7 +1102,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
       bi = b[row]; d = dinv[row]; xk = pk[row];
       if (c0 != 0.0) xm = pm[row];
     }
-    const VecC<NC> s = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile);
+    const VecC<NC> s = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile, ev, el);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -1091,7 +1132,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
     if (mine) { d = dinv[row]; bi = b[row]; }
     // (vals carry D^-1 by columns: the gathered vector is b alone, with its
     // halo when there are several ranks)
-    const VecC<NC> sum = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile);
+    const VecC<NC> sum = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, ev, el);
     if (mine) {
       VecC<NC> x0, o;
 #pragma unroll

@@ -8,7 +8,7 @@ SRC=fenapack_amd/csrc/pcd_engine.hip
 mkdir -p /tmp/pcdlibs
 for WL in "$@"; do
   PCD_VEC_TILE=0 python3 tools/time_a00_kernel.py $WL
-  for CFG in "32 4" "64 8" "64 4" "16 2"; do
+  for CFG in "64 8" "32 4" "32 8" "64 4"; do
     set -- $CFG
     LIB=/tmp/pcdlibs/vt_$1_$2.so
     [ -f $LIB ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -DPCD_VT_ROWS=$1 -DPCD_VT_U=$2 -o $LIB $SRC
