@@ -1467,14 +1467,14 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   { const char* e = getenv("PCD_VEC_TILE"); if (e) g_vec_tile = atoi(e); }
   { const char* e = getenv("PCD_VEC_TILE_ROWS"); if (e) g_vec_tile_rows = atoll(e); }
   { const char* e = getenv("PCD_VT_NT"); if (e) g_vt_nt = atoi(e); }
-  // default: three-component operators that are large enough to fill the chip
-  // AND whose launch stays inside the Infinity Cache (not nt2).  Measured,
-  // k_cheb_step on the finest A00 of the unit cube (profiles/r04_e_*, r04_f_*):
-  // N = 32 (90 MB per launch) 34.9 -> 31.8 us, texture-addresser stalls
-  // 2.3 M -> 0.12 M cycles; N = 48 (428 MB per launch, HBM-bound) 110.6 ->
-  // 116.7 us: there both kernels move the same bytes and the stream kernel's
-  // fully coalesced non-temporal loads win.
-  if (!g_vec_tile || (g_vec_tile == 1 && (nc != 3 || nn < g_vec_tile_rows || A.nt2))) return 0;
+  // default: three-component operators that are large enough to fill the chip.
+  // Measured, k_cheb_step on the finest A00 of the unit cube, us per launch
+  // (profiles/r04_q_vt_sweep*.txt, r04_e_*, r04_f_*): N = 32 (90 MB per
+  // launch, cache-resident) gather kernel 34.9, tile kernel 27.1-29.6;
+  // N = 48 (428 MB per launch, HBM-bound) 110.8 against 91.3 in the staged
+  // non-temporal form (123.9 with default-policy loads, 157 with
+  // non-temporal loads read by rows).
+  if (!g_vec_tile || (g_vec_tile == 1 && (nc != 3 || nn < g_vec_tile_rows))) return 0;
   if (nn < 1 || A.dense2 || A.long_rows || A.wave_rows) return 0;
   // independent super-blocks of rows: block boundaries restart at multiples of
   // kSuper rows, so the host threads need no hand-over and the result does not
