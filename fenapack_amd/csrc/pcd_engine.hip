@@ -131,7 +131,7 @@ struct DCsr {
   // LDS-staged vector tiles of the F (x) I kernels (pcd_kernels.hpp k_*_tc):
   // greedy row blocks, their column segments, 16-bit tile offsets per entry
   bool vt = false;
-  int vt_blocks = 0;
+  int vt_blocks = 0, vt_rows = 0;     // rows per block (template parameter of the kernels)
   DBuf<int4> vt_desc;
   DBuf<int> vt_tsrc;
   DBuf<unsigned short> vt_loc, vt_rowoff;
@@ -560,12 +560,14 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
   }
   if (A.vt) {
     const int gt = grid_stream(A.vt_blocks, 1);
-#define PCD_SPMV_TC(NT)                                                                       \
-    hipLaunchKernelGGL((k_spmv_tc<MODE, NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,       \
+#define PCD_SPMV_TC_(NT, ROWS)                                                                 \
+    hipLaunchKernelGGL((k_spmv_tc<MODE, NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream, \
                        A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
                        A.vt_loc.p, x, ghost, nloc, add, y)
+#define PCD_SPMV_TC(NT) do { if (A.vt_rows == 128) PCD_SPMV_TC_(NT, 128); else PCD_SPMV_TC_(NT, 64); } while (0)
     if (A.nt2 && g_vt_nt) PCD_SPMV_TC(true); else PCD_SPMV_TC(false);
 #undef PCD_SPMV_TC
+#undef PCD_SPMV_TC_
     return;
   }
   const int g = grid_stream(nn, A.rb2);
@@ -768,13 +770,15 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
   if (dinv && A.vt && kron_ok(A, b, pm, pk, pn, true)) {
     const int gt = grid_stream(A.vt_blocks, 1);
     const int nloc = (int)(A.ncols / A.kron);
-#define PCD_CHEB_TC(NC, NT)                                                                   \
-    hipLaunchKernelGGL((k_cheb_step_tc<NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,        \
+#define PCD_CHEB_TC_(NC, NT, ROWS)                                                             \
+    hipLaunchKernelGGL((k_cheb_step_tc<NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream,  \
                        A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
                        A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
+#define PCD_CHEB_TC(NC, NT) do { if (A.vt_rows == 128) PCD_CHEB_TC_(NC, NT, 128); else PCD_CHEB_TC_(NC, NT, 64); } while (0)
     if (A.kron == 2) { if (A.nt2 && g_vt_nt) PCD_CHEB_TC(2, true); else PCD_CHEB_TC(2, false); }
     else { if (A.nt2 && g_vt_nt) PCD_CHEB_TC(3, true); else PCD_CHEB_TC(3, false); }
 #undef PCD_CHEB_TC
+#undef PCD_CHEB_TC_
   } else if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
@@ -805,13 +809,15 @@ static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
   if (A.vt && kron_ok(A, b, p0, pn, nullptr, true)) {
     const int gt = grid_stream(A.vt_blocks, 1);
     const int nn = n / A.kron;
-#define PCD_FIRST_TC(NC, NT)                                                                  \
-    hipLaunchKernelGGL((k_cheb_first_tc<NC, NT>), dim3(gt), dim3(kBlock), 0, h->stream,       \
+#define PCD_FIRST_TC_(NC, NT, ROWS)                                                            \
+    hipLaunchKernelGGL((k_cheb_first_tc<NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream, \
                        A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2s.p,        \
                        A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron))
+#define PCD_FIRST_TC(NC, NT) do { if (A.vt_rows == 128) PCD_FIRST_TC_(NC, NT, 128); else PCD_FIRST_TC_(NC, NT, 64); } while (0)
     if (A.kron == 2) { if (A.nt2 && g_vt_nt) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
     else { if (A.nt2 && g_vt_nt) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
 #undef PCD_FIRST_TC
+#undef PCD_FIRST_TC_
     return 0;
   }
   if (kron_ok(A, b, p0, pn, nullptr, true)) {
@@ -1461,9 +1467,14 @@ static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* ro
 // of at least PCD_VEC_TILE_ROWS node rows (default), 2 every F (x) I operator.
 static int g_vec_tile = 1;
 static long long g_vec_tile_rows = 200000;
+static int g_vt_rows2 = 128, g_vt_rows3 = 64;
 static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
                           const std::vector<int32_t>& rpc, const std::vector<int32_t>& cc) {
   A.vt = false; A.vt_blocks = 0;
+  { const char* e = getenv("PCD_VT_ROWS2"); if (e && (atoi(e) == 64 || atoi(e) == 128)) g_vt_rows2 = atoi(e); }
+  const int kVtRows = nc == 2 ? g_vt_rows2 : g_vt_rows3;
+  const int kVtRowOff = vt_rowoff(kVtRows);
+  A.vt_rows = kVtRows;
   { const char* e = getenv("PCD_VEC_TILE"); if (e) g_vec_tile = atoi(e); }
   { const char* e = getenv("PCD_VEC_TILE_ROWS"); if (e) g_vec_tile_rows = atoll(e); }
   { const char* e = getenv("PCD_VT_NT"); if (e) g_vt_nt = atoi(e); }
@@ -3229,7 +3240,7 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
       return 0;
     case PCD_INFO_A00_ROWS_PER_WG:
       *out = (double)(h->mat[PCD_MAT_A00].kron ? h->mat[PCD_MAT_A00].rb2 : h->mat[PCD_MAT_A00].rb);
-      if (h->mat[PCD_MAT_A00].kron && h->mat[PCD_MAT_A00].vt) *out = -(double)kVtRows;
+      if (h->mat[PCD_MAT_A00].kron && h->mat[PCD_MAT_A00].vt) *out = -(double)h->mat[PCD_MAT_A00].vt_rows;
       return 0;
     default:
       if (key >= PCD_INFO_NNZ_BASE && key < PCD_INFO_NNZ_BASE + PCD_MAT_COUNT) {

@@ -907,26 +907,25 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
 // gather from the tile with 16-bit offsets instead of from L1 / L2
 // LDS; (value, offset) pairs come straight from the matrix stream.  No product
 // array, 10 B instead of 12 B of matrix stream per entry.
-//   blocks:  <= kVtRows consecutive rows, chosen greedily so that the tile
+//   blocks:  <= ROWS consecutive rows, chosen greedily so that the tile
 //            holds <= kVtNodes nodes
 //   tsrc:    vector node of every tile slot (ascending: runs of consecutive
 //            nodes); nodes >= nloc live in `ghost`
 //   rowoff:  entry offsets of the block's rows relative to its first entry
 //   loc:     tile offset of every entry's column (uint16)
 // ==========================================================================
-#ifndef PCD_VT_ROWS
-#define PCD_VT_ROWS 64
-#endif
 #ifndef PCD_VT_NODES
 #define PCD_VT_NODES 768
 #endif
 #ifndef PCD_VT_U
 #define PCD_VT_U 8
 #endif
-constexpr int kVtRows = PCD_VT_ROWS;        // rows per block (256 / rows lanes share a row)
+// rows per block = template parameter ROWS of the kernels (256 / ROWS lanes
+// share a row): 64 for three components (29 entries per row), 64 or 128 for
+// two (11.5 entries per row), chosen on the host per operator
 constexpr int kVtNodes = PCD_VT_NODES;      // tile nodes (x NC doubles)
-constexpr int kVtRowOff = PCD_VT_ROWS + 2;  // row offsets per block (rows + 1, padded)
-constexpr int kVtEntries = PCD_VT_ROWS * 32;  // entries per block (staged form: LDS slots)
+constexpr int vt_rowoff(int rows) { return rows + 2; }   // row offsets per block (rows + 1, padded)
+constexpr int kVtEntries = 2048;            // entries per block (staged form: LDS slots)
 static_assert(kVtNodes % kBlock == 0, "one lane per tile node, whole passes");
 // per block: x = first row, y = first entry, z = first slot in `tsrc`,
 // w = rows | tile nodes << 8.  tsrc[z + t] = vector node of tile slot t (the
@@ -938,13 +937,14 @@ static_assert(kVtNodes % kBlock == 0, "one lane per tile node, whole passes");
 // launch at cube N = 32 against 35 for the gather kernel); a binary search of
 // the segments in LDS per tile slot (35 us: the LDS waits took the place of
 // the texture-addresser stalls, profiles/r04_f_*).
-template <int NC, bool NT>
+template <int NC, bool NT, int ROWS>
 __device__ __forceinline__ VecC<NC> tile_row_block(
     const int4 d, const unsigned short* __restrict__ rowoff, int blk,
     const int* __restrict__ tsrc, const double* __restrict__ val,
     const unsigned short* __restrict__ loc, const double* x,
     const double* ghost, int nloc, double* tile, double* ev, unsigned short* el) {
-  constexpr int TPR = kBlock / kVtRows;
+  constexpr int TPR = kBlock / ROWS;
+  constexpr int kVtRowOff = vt_rowoff(ROWS);
   const int lr = threadIdx.x / TPR, sub = threadIdx.x % TPR;
   const int k0 = d.y, nr = d.w & 0xff, tn = d.w >> 8;
   const bool mine = lr < nr;
@@ -1052,7 +1052,7 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   const int* __restrict__ tsrc, const double* __restrict__ val,                        \
   const unsigned short* __restrict__ loc
 
-template <int MODE, int NC, bool NT>
+template <int MODE, int NC, bool NT, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_spmv_tc(
     PCD_VT_ARGS, const double* x, const double* ghost, int nloc, const double* add_,
     double* y_) {
@@ -1060,15 +1060,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tc(
   const VecC<NC>* add = vc<NC>(add_);
   VecC<NC>* y = vc<NC>(y_);
   int b0, b1;
-  row_block_range(nblocks, kVtRows, b0, b1, true);
+  row_block_range(nblocks, ROWS, b0, b1, true);
   for (int blk = b0; blk < b1; ++blk) {
     const int4 d = desc[blk];
-    const int lr = threadIdx.x / (kBlock / kVtRows);
+    const int lr = threadIdx.x / (kBlock / ROWS);
     const int row = d.x + lr;
-    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && lr < (d.w & 0xff);
+    const bool mine = threadIdx.x % (kBlock / ROWS) == 0 && lr < (d.w & 0xff);
     VecC<NC> a = vzero<NC>();
     if ((MODE == 1 || MODE == 2) && mine) a = add[row];
-    const VecC<NC> s = tile_row_block<NC, NT>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile, ev, el);
+    const VecC<NC> s = tile_row_block<NC, NT, ROWS>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile, ev, el);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tc(
   }
 }
 
-template <int NC, bool NT>
+template <int NC, bool NT, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, const double* pm_,
     const double* pk_, double* pn_, double c0, double c1, double c2,
@@ -1091,18 +1091,18 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
                *pk = vc<NC>(pk_);
   VecC<NC>* pn = vc<NC>(pn_);
   int b0, b1;
-  row_block_range(nblocks, kVtRows, b0, b1, true);
+  row_block_range(nblocks, ROWS, b0, b1, true);
   for (int blk = b0; blk < b1; ++blk) {
     const int4 d4 = desc[blk];
-    const int lr = threadIdx.x / (kBlock / kVtRows);
+    const int lr = threadIdx.x / (kBlock / ROWS);
     const int row = d4.x + lr;
-    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && lr < (d4.w & 0xff);
+    const bool mine = threadIdx.x % (kBlock / ROWS) == 0 && lr < (d4.w & 0xff);
     VecC<NC> bi = vzero<NC>(), d = bi, xk = bi, xm = bi;
     if (mine) {
       bi = b[row]; d = dinv[row]; xk = pk[row];
       if (c0 != 0.0) xm = pm[row];
     }
-    const VecC<NC> s = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile, ev, el);
+    const VecC<NC> s = tile_row_block<NC, NT, ROWS>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile, ev, el);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
   }
 }
 
-template <int NC, bool NT>
+template <int NC, bool NT, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, double* p0_,
     double* pn_, double s, double c1, double c2, const double* ghost, int nloc) {
@@ -1122,17 +1122,17 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   int b0, b1;
-  row_block_range(nblocks, kVtRows, b0, b1, true);
+  row_block_range(nblocks, ROWS, b0, b1, true);
   for (int blk = b0; blk < b1; ++blk) {
     const int4 d4 = desc[blk];
-    const int lr = threadIdx.x / (kBlock / kVtRows);
+    const int lr = threadIdx.x / (kBlock / ROWS);
     const int row = d4.x + lr;
-    const bool mine = threadIdx.x % (kBlock / kVtRows) == 0 && lr < (d4.w & 0xff);
+    const bool mine = threadIdx.x % (kBlock / ROWS) == 0 && lr < (d4.w & 0xff);
     VecC<NC> d = vzero<NC>(), bi = d;
     if (mine) { d = dinv[row]; bi = b[row]; }
     // (vals carry D^-1 by columns: the gathered vector is b alone, with its
     // halo when there are several ranks)
-    const VecC<NC> sum = tile_row_block<NC, NT>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, ev, el);
+    const VecC<NC> sum = tile_row_block<NC, NT, ROWS>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, ev, el);
     if (mine) {
       VecC<NC> x0, o;
 #pragma unroll
