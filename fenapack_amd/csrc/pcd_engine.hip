@@ -1467,25 +1467,32 @@ static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* ro
 // of at least PCD_VEC_TILE_ROWS node rows (default), 2 every F (x) I operator.
 static int g_vec_tile = 1;
 static long long g_vec_tile_rows = 200000;
-static int g_vt_rows2 = 128, g_vt_rows3 = 64;
+// rows per block: three components 64 (29 entries per row); two components
+// (11.5 entries per row) 64 in the direct form, 128 in the staged one -
+// measured on the finest A00 of the cavity (profiles/r04_r_vt_sweep_2d.txt):
+// level 6 (cache-resident) gather kernel 18.9 us, tile 15.5 (64 rows) / 17.7
+// (128); level 7 (HBM) 67.6 against 62.7 (128 rows, staged) / 91.8 (64)
+static int g_vt_rows2 = 0, g_vt_rows3 = 64;
 static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
                           const std::vector<int32_t>& rpc, const std::vector<int32_t>& cc) {
   A.vt = false; A.vt_blocks = 0;
   { const char* e = getenv("PCD_VT_ROWS2"); if (e && (atoi(e) == 64 || atoi(e) == 128)) g_vt_rows2 = atoi(e); }
-  const int kVtRows = nc == 2 ? g_vt_rows2 : g_vt_rows3;
+  const int kVtRows = nc == 2 ? (g_vt_rows2 ? g_vt_rows2 : ((A.nt2 && g_vt_nt) ? 128 : 64)) : g_vt_rows3;
   const int kVtRowOff = vt_rowoff(kVtRows);
   A.vt_rows = kVtRows;
   { const char* e = getenv("PCD_VEC_TILE"); if (e) g_vec_tile = atoi(e); }
   { const char* e = getenv("PCD_VEC_TILE_ROWS"); if (e) g_vec_tile_rows = atoll(e); }
   { const char* e = getenv("PCD_VT_NT"); if (e) g_vt_nt = atoi(e); }
-  // default: three-component operators that are large enough to fill the chip.
+  // default: F (x) I operators that are large enough to fill the chip (below
+  // ~2 10^5 node rows a launch is at its latency floor either way: cavity
+  // level 5, 103 k node rows, 5.9 us with both kernels).
   // Measured, k_cheb_step on the finest A00 of the unit cube, us per launch
   // (profiles/r04_q_vt_sweep*.txt, r04_e_*, r04_f_*): N = 32 (90 MB per
   // launch, cache-resident) gather kernel 34.9, tile kernel 27.1-29.6;
   // N = 48 (428 MB per launch, HBM-bound) 110.8 against 91.3 in the staged
   // non-temporal form (123.9 with default-policy loads, 157 with
   // non-temporal loads read by rows).
-  if (!g_vec_tile || (g_vec_tile == 1 && (nc != 3 || nn < g_vec_tile_rows))) return 0;
+  if (!g_vec_tile || (g_vec_tile == 1 && nn < g_vec_tile_rows)) return 0;
   if (nn < 1 || A.dense2 || A.long_rows || A.wave_rows) return 0;
   // independent super-blocks of rows: block boundaries restart at multiples of
   // kSuper rows, so the host threads need no hand-over and the result does not
