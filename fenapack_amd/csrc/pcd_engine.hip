@@ -1504,36 +1504,43 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   std::vector<std::vector<int32_t>> b_src(nsup);             // tile sources, block after block
   std::vector<unsigned short> loc(cc.size());
   std::atomic<bool> ok{true};
+  int32_t ncol_all = 0;
+  for (int32_t c : cc) ncol_all = std::max(ncol_all, c + 1);
   parallel_chunks(nsup, [&](int64_t s0, int64_t s1) {
-    std::vector<int32_t> cols, uniq;
+    std::vector<int32_t> uniq;
+    // distinct columns of the growing block are counted with a stamp per
+    // column (one pass over the entries; the columns are sorted once per
+    // block, not once per row)
+    std::vector<int32_t> stamp(ncol_all, -1), slot(ncol_all, 0);
+    int32_t tick = 0;
     for (int64_t sb = s0; sb < s1 && ok.load(std::memory_order_relaxed); ++sb) {
       const int64_t ra = sb * kSuper, rz = std::min<int64_t>(nn, ra + kSuper);
       int64_t r = ra;
       while (r < rz) {
-        // grow the block row by row
-        cols.clear();
+        ++tick;
         int64_t r1 = r;
-        size_t kept = 0;
+        int32_t nuniq = 0;
+        uniq.clear();
         while (r1 < rz && r1 - r < kVtRows) {
-          const size_t before = cols.size();
-          cols.insert(cols.end(), cc.begin() + rpc[r1], cc.begin() + rpc[r1 + 1]);
-          if ((int64_t)cols.size() > kVtEntries) { cols.resize(before); break; }   // (staged form: LDS slots)
-          uniq.assign(cols.begin(), cols.end());
-          std::sort(uniq.begin(), uniq.end());
-          uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-          if ((int64_t)uniq.size() > kVtNodes) { cols.resize(before); break; }
-          kept = cols.size();
+          if (rpc[r1 + 1] - rpc[r] > kVtEntries) break;               // (staged form: LDS slots)
+          int32_t add = 0;
+          const size_t before = uniq.size();
+          for (int32_t k = rpc[r1]; k < rpc[r1 + 1]; ++k)
+            if (stamp[cc[k]] != tick) { stamp[cc[k]] = tick; uniq.push_back(cc[k]); ++add; }
+          if (nuniq + add > kVtNodes) {
+            for (size_t q = before; q < uniq.size(); ++q) stamp[uniq[q]] = -1;     // undo the row
+            uniq.resize(before);
+            break;
+          }
+          nuniq += add;
           ++r1;
         }
         if (r1 == r) { ok.store(false); return; }       // one row alone does not fit
-        cols.resize(kept);
-        uniq.assign(cols.begin(), cols.end());
         std::sort(uniq.begin(), uniq.end());
-        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
         b_src[sb].insert(b_src[sb].end(), uniq.begin(), uniq.end());
         b_desc[sb].push_back(Blk{(int32_t)r, (int32_t)(r1 - r), rpc[r], (int32_t)uniq.size()});
-        for (int32_t k = rpc[r]; k < rpc[r1]; ++k)
-          loc[k] = (unsigned short)(std::lower_bound(uniq.begin(), uniq.end(), cc[k]) - uniq.begin());
+        for (size_t q = 0; q < uniq.size(); ++q) slot[uniq[q]] = (int32_t)q;
+        for (int32_t k = rpc[r]; k < rpc[r1]; ++k) loc[k] = (unsigned short)slot[cc[k]];
         r = r1;
       }
     }
