@@ -541,9 +541,9 @@ def main():
     # what the launched kernel must move by construction: F once (values +
     # column indices + row pointers) and five vector streams (b, D^-1, p_k,
     # p_{k-1} read, p_{k+1} written); the gathered p_k is served from cache
-    nn_k = V.n_u // ncomp if ncomp else V.n_u
-    b_model = (12 * (nnz_a00 // ncomp if ncomp else nnz_a00)
-               + 4 * (nn_k + 1) + 40 * V.n_u) / world
+    # (the engine knows the kernel in force: the vector-tile kernels stream
+    # 10 B per entry + their tile sources, the gather kernels 12 B + row pointers)
+    b_model = float(eng.info(c.INFO_A00_MODEL_BYTES))
     out = {
         "metric": "fieldsplit PCApply calls/sec (%s Re=100, P2/P1)"
                   % ("3D cavity" if args.geometry == "cube" else "2D cavity"),

@@ -132,6 +132,7 @@ struct DCsr {
   // greedy row blocks, their column segments, 16-bit tile offsets per entry
   bool vt = false;
   int vt_blocks = 0, vt_rows = 0;     // rows per block (template parameter of the kernels)
+  int64_t vt_nsrc = 0;                // tile slots of all blocks
   DBuf<int4> vt_desc;
   DBuf<int> vt_tsrc;
   DBuf<unsigned short> vt_loc, vt_rowoff;
@@ -1568,6 +1569,7 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
     }
   }
   A.vt_blocks = (int)desc.size();
+  A.vt_nsrc = (int64_t)tsrc.size();
   if (const char* e = getenv("PCD_VEC_TILE_STATS")) if (e[0] == '1') {
     int full = 0;
     for (const int4& d : desc) full += (d.w & 0xff) == kVtRows;
@@ -3245,6 +3247,19 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_RANKS: *out = h->comm ? (double)h->nranks : 0.0; return 0;
     case PCD_INFO_REORDERED: *out = (h->ru.active() ? 1.0 : 0.0) + (h->rp.active() ? 2.0 : 0.0); return 0;
     case PCD_INFO_LAUNCHES: *out = (double)launch_count(); return 0;
+    case PCD_INFO_A00_MODEL_BYTES: {
+      // what one launch of the fused Chebyshev step on A00 moves by construction
+      const DCsr& A = h->mat[PCD_MAT_A00];
+      const double vec = 40.0 * (double)A.nrows;        // b, D^-1, p_k, p_{k-1} read, p_{k+1} written
+      if (A.kron && A.vt)
+        *out = 10.0 * (double)A.nnz2 + 4.0 * (double)A.vt_nsrc +
+               (16.0 + 2.0 * (A.vt_rows + 2)) * (double)A.vt_blocks + vec;
+      else if (A.kron)
+        *out = 12.0 * (double)A.nnz2 + 4.0 * ((double)A.nrows / A.kron + 1.0) + vec;
+      else
+        *out = 12.0 * (double)A.nnz + 4.0 * ((double)A.nrows + 1.0) + vec;
+      return 0;
+    }
     case PCD_INFO_PEER_CALLS:
       *out = (h->comm && h->comm->peer()) ? (double)static_cast<PeerBackend*>(h->comm)->peer_calls : 0.0;
       return 0;

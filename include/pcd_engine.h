@@ -98,7 +98,11 @@ enum pcd_info {
                               * replayed hipGraph counts as none: it is one hipGraphLaunch) */
   PCD_INFO_PEER_CALLS = 65,  /* halo exchanges / all-reduces issued as kernels of the
                               * stream (peer protocol), so far */
-  PCD_INFO_BOOT_CALLS = 66   /* ... and those that went through RCCL / the host transport */
+  PCD_INFO_BOOT_CALLS = 66,  /* ... and those that went through RCCL / the host transport */
+  PCD_INFO_A00_MODEL_BYTES = 67  /* bytes one launch of the fused Chebyshev step on the velocity
+                                  * block moves BY CONSTRUCTION with the kernel in force (matrix
+                                  * stream + tile sources / row pointers + five vector streams);
+                                  * bench.py's `kernel_model_bytes_per_launch` */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */
