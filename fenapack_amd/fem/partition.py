@@ -83,6 +83,45 @@ class HostComm(object):
     def max(self, x):
         return max(self.allgather(x))
 
+    def sum_rows(self, M, cuts):
+        """Rows ``cuts[rank]:cuts[rank + 1]`` of the sum over ranks of the
+        global-shaped sparse matrices ``M`` (every rank's contribution to a
+        product like ``B^T B`` summed over its own rows of ``B``): each rank
+        sends the rows it holds for the others - the few beside its cut -
+        and keeps a global-shaped matrix with its own rows filled.  Summed
+        in rank order, so the bits do not depend on arrival."""
+        M = sp.csr_matrix(M)
+        if len(cuts) != self.size + 1 or cuts[-1] != M.shape[0]:
+            raise ValueError("sum_rows: %d cuts for %d ranks, %d rows"
+                             % (len(cuts), self.size, M.shape[0]))
+
+        def rows(q):
+            a, b = int(cuts[q]), int(cuts[q + 1])
+            lo, hi = int(M.indptr[a]), int(M.indptr[b])
+            if hi == lo:
+                return None
+            return (M.indptr[a:b + 1] - lo, M.indices[lo:hi], M.data[lo:hi])
+
+        got = self.allgather([None if q == self.rank else rows(q)
+                              for q in range(self.size)])
+        a, b = int(cuts[self.rank]), int(cuts[self.rank + 1])
+        out = None
+        for q in range(self.size):
+            piece = rows(q) if q == self.rank else got[q][self.rank]
+            if piece is None:
+                continue
+            ip, idx, val = piece
+            P = sp.csr_matrix((val, idx, ip), shape=(b - a, M.shape[1]))
+            out = P if out is None else out + P
+        if out is None:
+            out = sp.csr_matrix((b - a, M.shape[1]))
+        out = sp.csr_matrix(out)
+        out.sort_indices()
+        indptr = np.zeros(M.shape[0] + 1, dtype=np.int64)
+        indptr[a + 1:b + 1] = out.indptr[1:]
+        indptr[b + 1:] = out.indptr[-1]
+        return sp.csr_matrix((out.data, out.indices, indptr), shape=M.shape)
+
 
 class ThreadHostComm(HostComm):
     """R ranks as threads of one process (the thread-rank tests and tools)."""
@@ -312,10 +351,6 @@ class PartitionedProblem(object):
         for k in ("nu", "variant", "nls", "idt", "pcdr", "stabilize",
                   "coarse_stabilize"):
             setattr(self, k, getattr(G, k))
-        if self.pcdr:
-            raise NotImplementedError(
-                "partitioned producer: R_p = B diag(M_u)^-1 B^T needs a second "
-                "halo layer (PCDR runs through the global hand-over)")
         self.t = 0.0
         self._u0 = np.zeros(V.n_u)
         self.bc_u_idx, self.bc_p_idx = G.bc_u_idx, G.bc_p_idx
@@ -433,6 +468,22 @@ class PartitionedProblem(object):
 
     def Mu(self):
         return self._uu(self.fine, self.fine.loc.Mu(), "Mu")
+
+    def Rp(self):
+        """Owned rows of ``B diag(Mu)^-1 B^T`` (``FlowProblem.Rp``;
+        field_split_backend.py:142-166).  The product is a sum over velocity
+        rows: every rank forms the terms of ITS rows of ``B^T`` - they reach
+        pressure rows beside its cut too - and ``HostComm.sum_rows`` hands
+        each row's terms to its owner (what ``MatTransposeMatMult`` does on
+        an MPI matrix)."""
+        lev = self.fine
+        a, b = lev.own_u
+        d = self.Mu().diagonal()[a:b]
+        s = np.zeros(self.space.n_u)
+        s[a:b] = np.sqrt(np.abs(1.0 / d))
+        T = sp.diags(s) @ self.A01
+        return self.host.sum_rows((T.T @ T).tocsr(),
+                                  cut(self.space.n_p, self.size, 1))
 
     # -- one linearisation ---------------------------------------------------
     def _sync(self, lev, t=None):

@@ -142,7 +142,16 @@ class PCDInterface(object):
         diagMu.sqrtabs()
         Bt.copy(result=Ap)
         Ap.diagonalScale(L=diagMu)
-        return Ap.transposeMatMult(Ap)
+        R = Ap.transposeMatMult(Ap)
+        prod = getattr(self.engine, "producer", None)
+        if prod is not None and getattr(prod, "size", 1) > 1:
+            # rows of B^T by ranks: the product is this rank's TERMS of all
+            # rows; each row's terms go to its owner (MatTransposeMatMult on
+            # an MPI matrix does the same)
+            from .fem.partition import cut
+            n = R.A.shape[0]
+            R.set(prod.host.sum_rows(R.A, cut(n, prod.size, 1)))
+        return R
 
     def _give_interpolations(self, ksp):
         """pc_type mg on a pressure-space KSP: hand over the P1 chain."""

@@ -106,7 +106,10 @@ class Vec(object):
         self.t.mul_(alpha)
 
     def reciprocal(self):
-        self.t.reciprocal_()
+        # VecReciprocal: zero entries stay zero (rows a rank does not hold)
+        t = self.t
+        nz = t != 0
+        t[nz] = 1.0 / t[nz]
 
     def sqrtabs(self):
         self.t.abs_().sqrt_()

@@ -183,6 +183,76 @@ def test_thread_host_comm_reductions():
     assert pt.HostComm().sum(2.5) == 2.5
 
 
+def _threads(R, body):
+    errs = []
+
+    def run(r):
+        try:
+            body(r)
+        except Exception as ex:                       # pragma: no cover
+            import traceback
+            errs.append((r, repr(ex), traceback.format_exc()))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(R)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("R", [1, 2, 5])
+def test_sum_rows_gives_each_owner_its_rows_of_the_sum(R):
+    """``HostComm.sum_rows``: rank r contributes a global-shaped matrix with
+    entries anywhere; every rank gets the rows of the SUM that it owns."""
+    n = 23
+    rng = np.random.default_rng(5)
+    Ms = [sp.random(n, 9, density=0.3, random_state=rng.integers(1 << 30),
+                    format="csr") for _ in range(R)]
+    Ms[-1] = sp.csr_matrix((n, 9)) if R > 1 else Ms[-1]    # an empty term
+    total = sum(Ms[1:], Ms[0]).toarray()
+    cuts = pt.cut(n, R)
+    comms = pt.ThreadHostComm.group(R) if R > 1 else [pt.HostComm()]
+    got = [None] * R
+
+    def body(r):
+        got[r] = comms[r].sum_rows(Ms[r], cuts)
+
+    _threads(R, body)
+    for r in range(R):
+        a, b = cuts[r], cuts[r + 1]
+        G = got[r]
+        assert G.shape == (n, 9) and G.has_sorted_indices
+        assert np.abs(G[a:b].toarray() - total[a:b]).max() < 1e-15
+        assert G.nnz == G[a:b].nnz                 # own rows only
+    with pytest.raises(ValueError):
+        comms[0].sum_rows(Ms[0], [0, n + 1] if R == 1 else cuts[:-1])
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_reaction_laplacian_of_pcdr_by_rows(R):
+    """PCDR's ``R_p = B diag(M_u)^-1 B^T`` from a partitioned producer: the
+    product sums over VELOCITY rows, so every rank holds terms of pressure
+    rows beside its cut - they travel to the owner (``sum_rows``)."""
+    kw = dict(level=3, nu=0.02, dt=0.2, pcdr=True)
+    pb = BackwardStep(3, nu=0.02, dt=0.2, pcdr=True)
+    Rg = sp.csr_matrix(pb.Rp())
+    comms = pt.ThreadHostComm.group(R)
+    got = [None] * R
+
+    def body(r):
+        pp = pt.partitioned(BackwardStep, r, R, host=comms[r], **kw)
+        rows_equal(pp.Mu(), pb.Mu(), pp.fine.own_u)
+        got[r] = (pp.Rp(), pp.fine.own_p)
+
+    _threads(R, body)
+    scale = np.abs(Rg.data).max()
+    for Rr, (a, b) in got:
+        assert Rr.shape == Rg.shape and Rr.nnz == Rr[a:b].nnz
+        D = (Rr[a:b] - Rg[a:b]).tocsr()
+        # (terms summed in another order: round-off, not bits)
+        assert (np.abs(D.data).max() if D.nnz else 0.0) < 1e-14 * scale
+        # same pattern up to explicit zeros
+        assert np.array_equal((Rr[a:b] != 0).indices, (Rg[a:b] != 0).indices)
+
+
 def test_partitioned_norm_is_the_global_norm():
     g = global_build("cavity4")
     cls, kw = CASES["cavity4"]
