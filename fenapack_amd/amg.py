@@ -22,6 +22,8 @@ on the scalar stencil ``F`` and the prolongator is ``P_F (x) I_d``: every
 coarse level keeps the Kronecker structure the multi-component kernels use.
 """
 
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -255,13 +257,19 @@ class PartitionedSA(object):
       rank boundary and every rank OWNS the coarse dofs of its aggregates: the
       coarse levels are cut where the aggregates fall
       (``pcd_mg_set_level_cuts``), not evenly;
-    * the tentative prolongator is smoothed with the diagonal block as well
-      (``P = (I - omega/rho D^-1 A_rr) T``): ``P`` is block diagonal by rank,
-      its transpose needs no rows of other ranks;
-    * the Galerkin operator ``P^T A P`` couples across ranks through ``A``:
-      a rank needs the prolongator rows of its halo columns - exchanged once
-      (``HostComm.allgather`` of the boundary rows, kept while the pattern
-      stands);
+    * the tentative prolongator is smoothed with the TRUE rows of ``A``
+      (``P = (I - omega/rho D^-1 A) T``; the tentative rows of the halo nodes
+      are exchanged first), so ``P`` reaches into the neighbours' aggregates
+      like the one-rank prolongator does; ``smooth="block"`` (or
+      ``PCD_GAMG_SMOOTH=block``) smooths with the diagonal block only - ``P``
+      block diagonal by rank, one exchange less, more iterations at the cuts;
+    * the Galerkin operator ``P^T A P``: a rank needs the prolongator rows of
+      its halo columns (exchanged once per coarsening) and forms its rows'
+      TERMS of every coarse row; terms of other ranks' coarse rows travel to
+      their owners (``HostComm.sum_rows``).  The prolongator handed over
+      holds my rows AND the halo rows: the restriction rows of my coarse dofs
+      (``P^T`` by rows) need the neighbours' entries in my columns, and with
+      a structurally symmetric ``A`` those sit in my halo rows;
     * levels of at most ``replicate_rows`` dofs are gathered whole and the
       rest of the chain is the replicated ``smoothed_aggregation_chain``.
 
@@ -273,8 +281,15 @@ class PartitionedSA(object):
 
     def __init__(self, F, own, host, block=1, theta=0.02, coarse_rows=2000,
                  replicate_rows=60000, omega=4.0 / 3.0, distance=2,
-                 min_ratio=1.5, max_levels=12):
+                 min_ratio=1.5, max_levels=12, smooth=None):
         self.host, self.block = host, block
+        # "global": the tentative prolongator is smoothed with the true rows
+        # of A (halo rows of T exchanged); "block": with the rank's diagonal
+        # block only (P block diagonal by rank - cheaper set-up, more
+        # iterations at the cuts)
+        self.smooth = smooth or os.environ.get("PCD_GAMG_SMOOTH", "global")
+        if self.smooth not in ("global", "block"):
+            raise ValueError("PartitionedSA: smooth = %r" % (self.smooth,))
         self.part = []                  # finest first: dicts of one coarsening
         self.tail = [None]              # replicated chain below (coarsest first)
         cur, cur_own = sp.csr_matrix(F), (int(own[0]), int(own[1]))
@@ -317,33 +332,57 @@ class PartitionedSA(object):
         host = self.host
         r0, r1 = own
         n = A.shape[0]
-        Arows = A[r0:r1]
+        Arows = sp.csr_matrix(A[r0:r1])
         Add = sp.csr_matrix(Arows[:, r0:r1])
         agg, nagg = aggregate(_strength(Add, theta), seed, distance)
         counts = host.allgather(int(nagg))
         cuts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         off, nc = int(cuts[host.rank]), int(cuts[-1])
         T = _tentative(agg, nagg)
+        Tg = sp.csr_matrix((T.data, T.indices.astype(np.int64) + off,
+                            T.indptr), shape=(r1 - r0, nc))
         d = Add.diagonal().copy()
         d[d == 0.0] = 1.0
         rho = self._rho(A, own, d)
-        Pl = T - (omega / rho) * (sp.diags(1.0 / d) @ (Add @ T))
-        Pl = sp.csr_matrix(Pl)
-        Pl.eliminate_zeros()
-        Pl.sort_indices()                    # (r1 - r0) x nagg, local columns
-        # halo rows of P: the columns of my rows owned by other ranks
+        # halo: the columns of my rows owned by other ranks
         cols = np.unique(Arows.indices)
         halo = cols[(cols < r0) | (cols >= r1)]
         bounds = host.allgather((r0, r1))
         want = host.allgather(halo)
+        if self.smooth == "global":
+            # the true rows of A: tentative rows of the halo nodes first
+            AT = Arows @ self._with_halo_rows(Tg, own, n, want)
+        else:
+            AT = Add @ Tg
+        Pg = sp.csr_matrix(Tg - (omega / rho) * (sp.diags(1.0 / d) @ AT))
+        Pg.eliminate_zeros()
+        Pg.sort_indices()                    # (r1 - r0) x nc, global columns
+        # P_ext: n x nc, my rows and the halo rows populated
+        Pext = self._with_halo_rows(Pg, own, n, want)
+        # my rows only, global shape
+        ip2 = np.zeros(n + 1, dtype=np.int64)
+        ip2[r0 + 1:r1 + 1] = np.diff(Pg.indptr)
+        np.cumsum(ip2, out=ip2)
+        Pown = sp.csr_matrix((Pg.data, Pg.indices.astype(np.int64), ip2),
+                             shape=(n, nc))
+        return {"own": own, "own_c": (off, off + nagg), "nc": nc, "n": n,
+                "cuts": cuts, "Pg": Pg, "Pext": Pext, "Pown": Pown,
+                "bounds": bounds}
+
+    def _with_halo_rows(self, Mloc, own, n, want):
+        """``n x nc`` matrix holding my rows ``Mloc`` (global columns) and the
+        rows every ``want[q]`` asks of their owners (``want``: the halo lists
+        of all ranks, gathered once per coarsening)."""
+        host = self.host
+        r0, r1 = own
         reply = {}
         for q, need in enumerate(want):
             if q == host.rank or need.size == 0:
                 continue
             mine = need[(need >= r0) & (need < r1)]
             if mine.size:
-                sub = Pl[mine - r0]
-                reply[q] = (mine, sub.indptr, sub.indices + off, sub.data)
+                sub = Mloc[mine - r0]
+                reply[q] = (mine, sub.indptr, sub.indices, sub.data)
         got = host.allgather(reply)
         rows_i, rows_p, rows_c, rows_v = [], [], [], []
         for q, rep in enumerate(got):
@@ -354,31 +393,23 @@ class PartitionedSA(object):
             rows_p.append(np.diff(ip))
             rows_c.append(ci)
             rows_v.append(cv)
-        # P_ext: n x nc, my rows and the halo rows populated, global columns
-        own_len = np.diff(Pl.indptr)
+        own_len = np.diff(Mloc.indptr)
         idx = np.concatenate([np.arange(r0, r1)] + rows_i)
         ln = np.concatenate([own_len] + rows_p)
-        ci = np.concatenate([Pl.indices + off] + rows_c)
-        cv = np.concatenate([Pl.data] + rows_v)
+        ci = np.concatenate([Mloc.indices] + rows_c)
+        cv = np.concatenate([Mloc.data] + rows_v)
+        # (rows arrive rank by rank in ascending order and my block sits
+        # between them: a stable sort of the row ids orders the segments)
         order = np.argsort(idx, kind="stable")
-        start = np.concatenate([[0], np.cumsum(ln)])[:-1]
-        take = np.concatenate([np.arange(start[k], start[k] + ln[k])
-                               for k in order]) if order.size else \
-            np.zeros(0, dtype=np.int64)
+        lens = ln[order]
+        src0 = (np.cumsum(ln) - ln)[order]
+        dst0 = np.cumsum(lens) - lens
+        take = np.repeat(src0 - dst0, lens) + np.arange(int(lens.sum()))
         indptr = np.zeros(n + 1, dtype=np.int64)
         indptr[idx[order] + 1] = ln[order]
         np.cumsum(indptr, out=indptr)
-        Pext = sp.csr_matrix((cv[take], ci[take].astype(np.int64), indptr),
-                             shape=(n, nc))
-        # my rows only, global shape: what the hand-over slices
-        ip2 = np.zeros(n + 1, dtype=np.int64)
-        ip2[r0 + 1:r1 + 1] = own_len
-        np.cumsum(ip2, out=ip2)
-        Pown = sp.csr_matrix((Pl.data, (Pl.indices + off).astype(np.int64),
-                              ip2), shape=(n, nc))
-        return {"own": own, "own_c": (off, off + nagg), "nc": nc, "n": n,
-                "cuts": cuts, "Pl": Pl, "Pext": Pext, "Pown": Pown,
-                "bounds": bounds}
+        return sp.csr_matrix((cv[take], ci[take].astype(np.int64), indptr),
+                             shape=(n, Mloc.shape[1]))
 
     def _rho(self, A, own, d_own, iters=15, seed=0):
         """Spectral radius estimate of D^-1 A for the whole operator: the
@@ -400,20 +431,17 @@ class PartitionedSA(object):
 
     def _galerkin(self, A, lev):
         """My rows of ``P^T A P`` (the coarse dofs of my aggregates), global
-        shape."""
+        shape.  ``P^T`` sums over fine rows: my rows' terms of the coarse rows
+        of OTHER ranks (smoothing across the cut put entries there) travel to
+        their owners (``HostComm.sum_rows``)."""
         r0, r1 = lev["own"]
         AP = sp.csr_matrix(A[r0:r1] @ lev["Pext"])       # nloc x nc
-        C = sp.csr_matrix(lev["Pl"].T @ AP)              # nagg x nc
+        C = sp.csr_matrix(lev["Pg"].T @ AP)              # nc x nc, my terms
+        if self.smooth == "global":
+            C = self.host.sum_rows(C, lev["cuts"])
         C.sort_indices()
-        c0, c1 = lev["own_c"]
-        nc = lev["nc"]
-        ip = np.zeros(nc + 1, dtype=np.int64)
-        ip[c0 + 1:c1 + 1] = np.diff(C.indptr)
-        np.cumsum(ip, out=ip)
-        out = sp.csr_matrix((C.data, C.indices.astype(np.int64), ip),
-                            shape=(nc, nc))
-        out.has_sorted_indices = True
-        return out
+        C.has_sorted_indices = True
+        return C
 
     def _gather(self, Ac, lev):
         c0, c1 = lev["own_c"]
@@ -433,7 +461,8 @@ class PartitionedSA(object):
 
     def chain(self):
         """``[None, P_1, ..., P_L]`` (scalar), coarsest first."""
-        return list(self.tail) + [lev["Pown"] for lev in self.part[::-1]]
+        key = "Pext" if self.smooth == "global" else "Pown"
+        return list(self.tail) + [lev[key] for lev in self.part[::-1]]
 
     def level_cuts(self):
         """``cuts[l]`` (scalar dofs) of every level, ``None`` where the level

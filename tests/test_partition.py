@@ -448,8 +448,40 @@ def test_partitioned_smoothed_aggregation(R):
         assert psa0.chain()[-1].shape == ref[-1].shape
     chains = [res[r][0].chain() for r in range(R)]
     opss = [res[r][1] for r in range(R)]
-    Pg = [None] + [sum(chains[r][l] for r in range(R)) if flags[l]
+
+    def own_rows(r, l):
+        # the prolongator handed over holds my rows AND my halo rows (the
+        # restriction rows of my coarse dofs need the neighbours' entries)
+        lev = res[r][0].part[Lv - 1 - l]
+        a, b = lev["own"]
+        P = sp.csr_matrix(chains[r][l])
+        ip = np.zeros(P.shape[0] + 1, dtype=np.int64)
+        ip[a + 1:b + 1] = np.diff(P.indptr)[a:b]
+        np.cumsum(ip, out=ip)
+        lo, hi = P.indptr[a], P.indptr[b]
+        return sp.csr_matrix((P.data[lo:hi], P.indices[lo:hi], ip),
+                             shape=P.shape)
+
+    Pg = [None] + [sum(own_rows(r, l) for r in range(R)) if flags[l]
                    else chains[0][l] for l in range(1, Lv)]
+    for l in range(1, Lv):
+        if not flags[l]:
+            continue
+        for r in range(R):
+            lev = res[r][0].part[Lv - 1 - l]
+            a, b = lev["own"]
+            c0, c1 = lev["own_c"]
+            mine = sp.csr_matrix(chains[r][l])
+            # my rows, and every entry of the whole P in my coarse columns
+            assert abs(mine[a:b] - Pg[l][a:b]).max() == 0.0
+            assert abs(mine.T.tocsr()[c0:c1]
+                       - Pg[l].T.tocsr()[c0:c1]).max() == 0.0
+    if R > 1:
+        # smoothed across the cuts: P couples the ranks
+        a, b = res[0][0].part[0]["own"]
+        c0, c1 = res[0][0].part[0]["own_c"]
+        P0 = sp.csr_matrix(Pg[Lv - 1])[a:b].tocsc()
+        assert P0[:, c1:].nnz > 0
     Og = [sum(opss[r][l] for r in range(R)) if flags[l] else opss[0][l]
           for l in range(Lv)]
     assert abs(Og[-1] - F).max() == 0.0               # the rows partition F
