@@ -133,6 +133,7 @@ struct DCsr {
   bool vt = false;
   int vt_blocks = 0, vt_rows = 0;     // rows per block (template parameter of the kernels)
   int64_t vt_nsrc = 0;                // tile slots of all blocks
+  bool vt_staged = false;             // staged (non-temporal) form of the tile kernels
   DBuf<int4> vt_desc;
   DBuf<int> vt_tsrc;
   DBuf<unsigned short> vt_loc, vt_rowoff;
@@ -566,7 +567,7 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
                        A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
                        A.vt_loc.p, x, ghost, nloc, add, y)
 #define PCD_SPMV_TC(NT) do { if (A.vt_rows == 128) PCD_SPMV_TC_(NT, 128); else PCD_SPMV_TC_(NT, 64); } while (0)
-    if (A.nt2 && g_vt_nt) PCD_SPMV_TC(true); else PCD_SPMV_TC(false);
+    if (A.vt_staged) PCD_SPMV_TC(true); else PCD_SPMV_TC(false);
 #undef PCD_SPMV_TC
 #undef PCD_SPMV_TC_
     return;
@@ -776,8 +777,8 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                        A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
                        A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
 #define PCD_CHEB_TC(NC, NT) do { if (A.vt_rows == 128) PCD_CHEB_TC_(NC, NT, 128); else PCD_CHEB_TC_(NC, NT, 64); } while (0)
-    if (A.kron == 2) { if (A.nt2 && g_vt_nt) PCD_CHEB_TC(2, true); else PCD_CHEB_TC(2, false); }
-    else { if (A.nt2 && g_vt_nt) PCD_CHEB_TC(3, true); else PCD_CHEB_TC(3, false); }
+    if (A.kron == 2) { if (A.vt_staged) PCD_CHEB_TC(2, true); else PCD_CHEB_TC(2, false); }
+    else { if (A.vt_staged) PCD_CHEB_TC(3, true); else PCD_CHEB_TC(3, false); }
 #undef PCD_CHEB_TC
 #undef PCD_CHEB_TC_
   } else if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
@@ -815,8 +816,8 @@ static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
                        A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2s.p,        \
                        A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron))
 #define PCD_FIRST_TC(NC, NT) do { if (A.vt_rows == 128) PCD_FIRST_TC_(NC, NT, 128); else PCD_FIRST_TC_(NC, NT, 64); } while (0)
-    if (A.kron == 2) { if (A.nt2 && g_vt_nt) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
-    else { if (A.nt2 && g_vt_nt) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
+    if (A.kron == 2) { if (A.vt_staged) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
+    else { if (A.vt_staged) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
 #undef PCD_FIRST_TC
 #undef PCD_FIRST_TC_
     return 0;
@@ -1477,13 +1478,17 @@ static int g_vt_rows2 = 0, g_vt_rows3 = 64;
 static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
                           const std::vector<int32_t>& rpc, const std::vector<int32_t>& cc) {
   A.vt = false; A.vt_blocks = 0;
-  { const char* e = getenv("PCD_VT_ROWS2"); if (e && (atoi(e) == 64 || atoi(e) == 128)) g_vt_rows2 = atoi(e); }
-  const int kVtRows = nc == 2 ? (g_vt_rows2 ? g_vt_rows2 : ((A.nt2 && g_vt_nt) ? 128 : 64)) : g_vt_rows3;
+  // (read per operator, defaults restored when a variable is gone: the A/B
+  // tests of one process must not leak their switches into later engines)
+  { const char* e = getenv("PCD_VT_ROWS2"); g_vt_rows2 = (e && (atoi(e) == 64 || atoi(e) == 128)) ? atoi(e) : 0; }
+  { const char* e = getenv("PCD_VT_NT"); g_vt_nt = e ? atoi(e) : 1; }
+  A.vt_staged = A.nt2 && g_vt_nt;      // the form is fixed with the layout
+  const int kVtRows = nc == 2 ? (g_vt_rows2 ? g_vt_rows2 : (A.vt_staged ? 128 : 64)) : g_vt_rows3;
+  const int kEntries = vt_entries(nc);
   const int kVtRowOff = vt_rowoff(kVtRows);
   A.vt_rows = kVtRows;
-  { const char* e = getenv("PCD_VEC_TILE"); if (e) g_vec_tile = atoi(e); }
-  { const char* e = getenv("PCD_VEC_TILE_ROWS"); if (e) g_vec_tile_rows = atoll(e); }
-  { const char* e = getenv("PCD_VT_NT"); if (e) g_vt_nt = atoi(e); }
+  { const char* e = getenv("PCD_VEC_TILE"); g_vec_tile = e ? atoi(e) : 1; }
+  { const char* e = getenv("PCD_VEC_TILE_ROWS"); g_vec_tile_rows = e ? atoll(e) : 200000; }
   // default: F (x) I operators that are large enough to fill the chip (below
   // ~2 10^5 node rows a launch is at its latency floor either way: cavity
   // level 5, 103 k node rows, 5.9 us with both kernels).
@@ -1523,7 +1528,7 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
         int32_t nuniq = 0;
         uniq.clear();
         while (r1 < rz && r1 - r < kVtRows) {
-          if (rpc[r1 + 1] - rpc[r] > kVtEntries) break;               // (staged form: LDS slots)
+          if (rpc[r1 + 1] - rpc[r] > kEntries) break;                 // (staged form: LDS slots)
           int32_t add = 0;
           const size_t before = uniq.size();
           for (int32_t k = rpc[r1]; k < rpc[r1 + 1]; ++k)
@@ -1865,7 +1870,7 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   { const char* e = getenv("PCD_MAX_RB"); if (e && atoi(e) >= 32) g_max_rb = atoi(e); }
   { const char* e = getenv("PCD_MIN_WGS"); if (e) g_min_wgs = atoi(e); }
   { const char* e = getenv("PCD_MAX_CHUNKS"); if (e && atoi(e) >= 1) g_max_chunks = atoi(e); }
-  { const char* e = getenv("PCD_NT_BYTES"); if (e) g_nt_bytes = atoll(e); }
+  { const char* e = getenv("PCD_NT_BYTES"); g_nt_bytes = e ? atoll(e) : (256ll << 20); }
   { const char* e = getenv("PCD_NO_SMALL_TILE"); g_no_small_tile = e && e[0] == '1'; }
   { hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)

@@ -925,7 +925,17 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
 // two (11.5 entries per row), chosen on the host per operator
 constexpr int kVtNodes = PCD_VT_NODES;      // tile nodes (x NC doubles)
 constexpr int vt_rowoff(int rows) { return rows + 2; }   // row offsets per block (rows + 1, padded)
-constexpr int kVtEntries = 2048;            // entries per block (staged form: LDS slots)
+// entries per block (staged form: LDS slots).  LDS bounds the occupancy of the
+// staged form and its launch time follows T = a + b / W in the workgroups W
+// per CU (measured with LDS padding, cube N = 48: 142.6 / 108.1 / 91.2 us at
+// W = 2 / 3 / 4): two components fit FIVE workgroups per CU with 1792 slots
+// (12 KB tile + 17.5 KB entries; the 128-row blocks of a 2-D P2 stencil hold
+// ~1470 entries and stay full) - cavity level 7: 62.9 -> 56.8 us per launch;
+// three components would need a 512-node tile for that, and the blocks it
+// leaves (42 rows instead of 56) cost more than the occupancy brings
+// (N = 73: 363 -> 376 us; profiles/r04_j_*)
+constexpr int vt_entries(int nc) { return nc == 2 ? 1792 : 2048; }
+constexpr int kVtEntries = 2048;            // (largest)
 static_assert(kVtNodes % kBlock == 0, "one lane per tile node, whole passes");
 // per block: x = first row, y = first entry, z = first slot in `tsrc`,
 // w = rows | tile nodes << 8.  tsrc[z + t] = vector node of tile slot t (the
@@ -973,7 +983,7 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
     // entries t, t + 256, ...) - read by rows they would touch every cache
     // line from up to four load instructions, and a non-temporal line is
     // fetched again each time (N = 48: 128 -> 157 us)
-    constexpr int UE = kVtEntries / kBlock;
+    constexpr int UE = vt_entries(NC) / kBlock;
     const int ne = rowoff[blk * kVtRowOff + nr];
     double ve[UE];
     unsigned short le[UE];
@@ -1044,8 +1054,8 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
 
 #define PCD_VT_SHARED(NC)                                         \
   __shared__ double tile[NC * kVtNodes];                          \
-  __shared__ double ev[NT ? kVtEntries : 1];                      \
-  __shared__ unsigned short el[NT ? kVtEntries : 1]
+  __shared__ double ev[NT ? vt_entries(NC) : 1];                  \
+  __shared__ unsigned short el[NT ? vt_entries(NC) : 1]
 
 #define PCD_VT_ARGS                                                                   \
   int nblocks, const int4* __restrict__ desc, const unsigned short* __restrict__ rowoff, \

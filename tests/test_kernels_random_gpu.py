@@ -49,15 +49,23 @@ def test_spmv_random_shapes(hip_lib, n, m, avg, long_rows):
         assert relerr(e.spmv_np(c.MAT_KP, x, n), ref) < 1e-13
 
 
-@pytest.mark.parametrize("vec_tile", ["0", "2"])
+def _tile_form(monkeypatch, form):
+    """``0``: stream kernels; ``2``: the LDS-staged vector-tile kernels
+    (k_*_tc) on every F (x) I operator, whatever its size, direct form;
+    ``2staged``: their staged form (what operators beyond the Infinity Cache
+    get: matrix entries through LDS with non-temporal loads)."""
+    monkeypatch.setenv("PCD_VEC_TILE", form[0])
+    if form == "2staged":
+        monkeypatch.setenv("PCD_NT_BYTES", "0")
+
+
+@pytest.mark.parametrize("vec_tile", ["0", "2", "2staged"])
 @pytest.mark.parametrize("nc", [2, 3])
 @pytest.mark.parametrize("nodes,mnodes", [(1, 1), (33, 33), (500, 321),
                                           (4000, 4000)])
 def test_multi_component_operators_and_near_misses(hip_lib, monkeypatch, nodes,
                                                    mnodes, nc, vec_tile):
-    # PCD_VEC_TILE=2: the LDS-staged vector-tile kernels (k_*_tc) on every
-    # F (x) I operator, whatever its size
-    monkeypatch.setenv("PCD_VEC_TILE", vec_tile)
+    _tile_form(monkeypatch, vec_tile)
     rng = np.random.default_rng(nodes)
     F = _random_csr(rng, nodes, mnodes, 9, empty_frac=0.0)
     K = sp.kron(F, sp.identity(nc), format="csr")
@@ -82,15 +90,15 @@ def test_multi_component_operators_and_near_misses(hip_lib, monkeypatch, nodes,
         assert relerr(e.spmv_np(c.MAT_A01, x, M.shape[0]), M @ x) < 1e-13
 
 
-@pytest.mark.parametrize("vec_tile", ["0", "2"])
+@pytest.mark.parametrize("vec_tile", ["0", "2", "2staged"])
 @pytest.mark.parametrize("nc", [2, 3])
-@pytest.mark.parametrize("nodes", [1, 70, 2500])
+@pytest.mark.parametrize("nodes", [1, 70, 2500, 9000])
 def test_smoother_on_multi_component_spd(hip_lib, monkeypatch, nodes, nc,
                                          vec_tile):
     """F (x) I_nc with F SPD: the fused multi-component Chebyshev start/step
     (and their fall-back when one value breaks the structure); with the
     stream kernels and with the LDS-staged vector-tile kernels."""
-    monkeypatch.setenv("PCD_VEC_TILE", vec_tile)
+    _tile_form(monkeypatch, vec_tile)
     rng = np.random.default_rng(nodes + nc)
     B = _random_csr(rng, nodes, nodes, 6, empty_frac=0.0)
     F = (B @ B.T + sp.identity(nodes) * (1.0 + abs(B).sum(axis=1).max())).tocsr()
