@@ -1015,7 +1015,11 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   } else {
     // cache-resident operators: the first entries of my row straight from
     // the stream (the lanes of a row read contiguous bytes per step)
-    constexpr int U = PCD_VT_U;
+    // (entries in flight per lane; two components: 4 - with 4 lanes per row
+    // that covers the 2-D P2 rows, and 58 instead of 70 VGPRs are an eighth
+    // wave per SIMD: cavity level 6 15.54 -> 15.20 us; three components:
+    // 8 - N = 32 29.6, 30.9 with 4)
+    constexpr int U = NC == 2 ? PCD_VT_U / 2 : PCD_VT_U;
     double v[U];
     int o[U];
 #pragma unroll
