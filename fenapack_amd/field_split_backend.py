@@ -143,7 +143,7 @@ class PCDInterface(object):
         Bt.copy(result=Ap)
         Ap.diagonalScale(L=diagMu)
         R = Ap.transposeMatMult(Ap)
-        prod = getattr(self.engine, "producer", None)
+        prod = getattr(getattr(self, "engine", None), "producer", None)
         if prod is not None and getattr(prod, "size", 1) > 1:
             # rows of B^T by ranks: the product is this rank's TERMS of all
             # rows; each row's terms go to its owner (MatTransposeMatMult on
