@@ -359,6 +359,20 @@ class PartitionedSA(object):
         Pg.sort_indices()                    # (r1 - r0) x nc, global columns
         # P_ext: n x nc, my rows and the halo rows populated
         Pext = self._with_halo_rows(Pg, own, n, want)
+        if self.smooth == "global":
+            # the restriction rows of my coarse dofs are taken from P_ext (my
+            # rows + my halo rows): complete iff every row with an entry in my
+            # columns is one of them - true when the pattern of A is
+            # structurally symmetric; checked, because a silent miss would be
+            # a restriction that is not P^T
+            c0, c1 = off, off + nagg
+            mine = Pext.tocsc()[:, c0:c1].nnz
+            if host.sum(float(mine)) != host.sum(float(Pg.nnz)):
+                raise ValueError(
+                    "partitioned gamg: the operator's pattern is not "
+                    "structurally symmetric - prolongator entries in a rank's "
+                    "coarse columns lie outside its halo rows; use "
+                    "PCD_GAMG_SMOOTH=block")
         # my rows only, global shape
         ip2 = np.zeros(n + 1, dtype=np.int64)
         ip2[r0 + 1:r1 + 1] = np.diff(Pg.indptr)

@@ -493,3 +493,38 @@ def test_partitioned_smoothed_aggregation(R):
             for r in range(1, R):
                 assert (sp.csr_matrix(opss[r][l - 1])
                         != sp.csr_matrix(opss[0][l - 1])).nnz == 0
+
+
+def test_partitioned_sa_refuses_a_structurally_unsymmetric_pattern():
+    """Smoothing across the cuts takes the restriction rows of a rank's coarse
+    dofs from its halo rows of P - complete only for a structurally symmetric
+    operator.  A one-sided coupling across the cut must be refused (by every
+    rank), not restricted wrongly."""
+    from fenapack_amd import amg
+    n, R = 400, 2
+    T = sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(n, n)).tolil()
+    T[n // 2 - 3, n // 2 + 40] = -0.7           # rank 0 -> rank 1 only
+    F = sp.csr_matrix(T)
+    comms = pt.ThreadHostComm.group(R)
+    cuts = pt.cut(n, R)
+    seen = [None] * R
+
+    def body(r):
+        r0, r1 = cuts[r], cuts[r + 1]
+        ip = np.zeros(n + 1, dtype=np.int64)
+        ip[r0 + 1:r1 + 1] = np.diff(F.indptr)[r0:r1]
+        np.cumsum(ip, out=ip)
+        Fr = sp.csr_matrix((F.data[F.indptr[r0]:F.indptr[r1]],
+                            F.indices[F.indptr[r0]:F.indptr[r1]], ip),
+                           shape=F.shape)
+        try:
+            amg.PartitionedSA(Fr, (r0, r1), comms[r], replicate_rows=50,
+                              coarse_rows=20)
+        except ValueError as ex:
+            seen[r] = str(ex)
+        # block-diagonal smoothing does not need the symmetry
+        amg.PartitionedSA(Fr, (r0, r1), comms[r], replicate_rows=50,
+                          coarse_rows=20, smooth="block")
+
+    _threads(R, body)
+    assert all(s and "structurally symmetric" in s for s in seen), seen
