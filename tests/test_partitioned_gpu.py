@@ -154,7 +154,7 @@ def test_partitioned_algebraic_hierarchy(hip_lib, monkeypatch, R):
         assert np.abs(r["x"] - x1).max() <= 2e-5 * np.abs(x1).max()
 
 
-@pytest.mark.parametrize("variant,R", [("BRM1", 2), ("BRM2", 3)])
+@pytest.mark.parametrize("variant,R", [("BRM2", 3)])
 def test_unsteady_pcdr_from_a_partitioned_producer(hip_lib, monkeypatch,
                                                    variant, R):
     """The unsteady PCDR demo (demo_unsteady-navier-stokes-pcdr.py:137-208)
