@@ -1468,7 +1468,7 @@ static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* ro
 // (the tile's sources) and per entry the offset of its column in the tile.  PCD_VEC_TILE: 0 off, 1 three-component operators
 // of at least PCD_VEC_TILE_ROWS node rows (default), 2 every F (x) I operator.
 static int g_vec_tile = 1;
-static long long g_vec_tile_rows = 200000;
+static long long g_vec_tile_rows = 80000;
 // rows per block: three components 64 (29 entries per row); two components
 // (11.5 entries per row) 64 in the direct form, 128 in the staged one -
 // measured on the finest A00 of the cavity (profiles/r04_r_vt_sweep_2d.txt):
@@ -1488,10 +1488,14 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   const int kVtRowOff = vt_rowoff(kVtRows);
   A.vt_rows = kVtRows;
   { const char* e = getenv("PCD_VEC_TILE"); g_vec_tile = e ? atoi(e) : 1; }
-  { const char* e = getenv("PCD_VEC_TILE_ROWS"); g_vec_tile_rows = e ? atoll(e) : 200000; }
-  // default: F (x) I operators that are large enough to fill the chip (below
-  // ~2 10^5 node rows a launch is at its latency floor either way: cavity
-  // level 5, 103 k node rows, 5.9 us with both kernels).
+  { const char* e = getenv("PCD_VEC_TILE_ROWS"); g_vec_tile_rows = e ? atoll(e) : 80000; }
+  // default: F (x) I operators from 80 000 node rows.  Timed alone (launched
+  // back to back, operator warm in L2) cavity level 5 - 103 k node rows - runs
+  // 5.9 us with both kernels, the latency floor; INSIDE the cycle, where the
+  // finest level has pushed it out of L2, its five launches take 9-11 us with
+  // the gather kernels and the tile kernels' 10 instead of 12 bytes per entry
+  // count: level-6 PCApply 0.3093 -> 0.2989 ms with tiles on level 5 as well,
+  // 0.3014 with level 4 (26 k node rows) too (profiles/r04_k_*).
   // Measured, k_cheb_step on the finest A00 of the unit cube, us per launch
   // (profiles/r04_q_vt_sweep*.txt, r04_e_*, r04_f_*): N = 32 (90 MB per
   // launch, cache-resident) gather kernel 34.9, tile kernel 27.1-29.6;
