@@ -702,7 +702,7 @@ static int refresh_dinv(Engine* h, DCsr& A) {
   if (A.nnz) {
     CHK(halo_exchange(h, A, A.dinv.p));
     if (A.kron && A.nnz2) {
-      CHK(A.val2s.ensure(A.nnz2));
+      CHK(A.val2s.ensure(A.nnz2 + 2));
       hipLaunchKernelGGL(k_scale_cols, dim3(grid1d(A.nnz2, 4)), dim3(kBlock), 0, h->stream,
                          A.nnz2, A.col2.p, A.val2.p, A.dinv.p, A.kron, A.val2s.p,
                          A.ghost.p, (int)(A.ncols / A.kron));
@@ -1588,7 +1588,7 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
             100.0 * full / desc.size(), kVtRows);
   }
   CHK(A.vt_desc.ensure(desc.size())); CHK(A.vt_rowoff.ensure(rowoff.size()));
-  CHK(A.vt_tsrc.ensure(tsrc.size())); CHK(A.vt_loc.ensure(loc.size()));
+  CHK(A.vt_tsrc.ensure(tsrc.size())); CHK(A.vt_loc.ensure(loc.size() + 4));
   HIPCHK(hipMemcpy(A.vt_desc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(A.vt_rowoff.p, rowoff.data(), rowoff.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(A.vt_tsrc.p, tsrc.data(), tsrc.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1627,7 +1627,7 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   if (!rb2 && !g_want_wave && !dense2) return 0;   // (wave-per-row / dense kernels need no tile)
   A.dense2 = dense2;
   A.nnz2 = (int64_t)cc.size();
-  CHK(A.rowptr2.ensure(nn + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2));
+  CHK(A.rowptr2.ensure(nn + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2 + 2));
   CHK(A.kron_pos.ensure(nc * A.nnz2)); CHK(A.kron_flag.ensure(1));
   HIPCHK(hipMemcpy(A.rowptr2.p, rpc.data(), (nn + 1) * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(A.col2.p, cc.data(), A.nnz2 * sizeof(int), hipMemcpyHostToDevice));

@@ -920,6 +920,15 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
 #ifndef PCD_VT_U
 #define PCD_VT_U 8
 #endif
+#ifndef PCD_VT_WIDE
+#define PCD_VT_WIDE 1
+#endif
+#ifndef PCD_VT_PAIR
+#define PCD_VT_PAIR 1
+#endif
+#ifndef PCD_VT_U2
+#define PCD_VT_U2 (PCD_VT_U / 2)
+#endif
 // rows per block = template parameter ROWS of the kernels (256 / ROWS lanes
 // share a row): 64 for three components (29 entries per row), 64 or 128 for
 // two (11.5 entries per row), chosen on the host per operator
@@ -971,11 +980,15 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   for (int u = 0; u < kVtNodes / kBlock; ++u)
     src[u] = node[u] < 0 ? nullptr
              : (node[u] < nloc ? x + (size_t)NC * node[u] : ghost + (size_t)NC * (node[u] - nloc));
+  // (one node = one VecC: a 16-byte load for two components, 16 + 8 for three)
   double tv[kVtNodes / kBlock][NC];
 #pragma unroll
-  for (int u = 0; u < kVtNodes / kBlock; ++u)
+  for (int u = 0; u < kVtNodes / kBlock; ++u) {
+    VecC<NC> t = vzero<NC>();
+    if (src[u]) t = *vc<NC>(src[u]);
 #pragma unroll
-    for (int i = 0; i < NC; ++i) tv[u][i] = src[u] ? src[u][i] : 0.0;
+    for (int i = 0; i < NC; ++i) tv[u][i] = t.c[i];
+  }
   VecC<NC> s = vzero<NC>();
   if (NT) {
     // operators streamed from HBM: the block's (value, tile offset) pairs go
@@ -983,8 +996,61 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
     // entries t, t + 256, ...) - read by rows they would touch every cache
     // line from up to four load instructions, and a non-temporal line is
     // fetched again each time (N = 48: 128 -> 157 us)
-    constexpr int UE = vt_entries(NC) / kBlock;
     const int ne = rowoff[blk * kVtRowOff + nr];
+#if PCD_VT_WIDE
+    // 16-byte loads of the values (pairs) and 8-byte loads of the 16-bit
+    // offsets (quads) from bases aligned DOWN to the pair / quad the block's
+    // first entry sits in: 6-8 load and 6-8 LDS-write instructions per lane
+    // instead of 16 + 16; the LDS copies keep the shift (shv, shl)
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    typedef unsigned uv2 __attribute__((ext_vector_type(2)));
+    constexpr int E = vt_entries(NC);
+    constexpr int UV = (E / 2 + 1 + kBlock - 1) / kBlock, UL = (E / 4 + 1 + kBlock - 1) / kBlock;
+    const int shv = k0 & 1, shl = k0 & 3;
+    const dv2* vb = reinterpret_cast<const dv2*>(val + (k0 - shv));
+    const uv2* lb = reinterpret_cast<const uv2*>(loc + (k0 - shl));
+    dv2 ve[UV];
+    uv2 le[UL];
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int p = threadIdx.x + u * kBlock;
+      ve[u] = 2 * p < ne + shv ? __builtin_nontemporal_load(vb + p) : dv2(0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int q = threadIdx.x + u * kBlock;
+      le[u] = 4 * q < ne + shl ? __builtin_nontemporal_load(lb + q) : uv2(0u);
+    }
+#pragma unroll
+    for (int u = 0; u < kVtNodes / kBlock; ++u)
+      if (src[u]) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
+      }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int p = threadIdx.x + u * kBlock;
+      if (2 * p < ne + shv) reinterpret_cast<dv2*>(ev)[p] = ve[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int q = threadIdx.x + u * kBlock;
+      if (4 * q < ne + shl) reinterpret_cast<uv2*>(el)[q] = le[u];
+    }
+    __syncthreads();
+    // (one entry per trip: four per trip with the reads hoisted - to break the
+    // chain of two dependent LDS latencies per entry - is 9 % SLOWER, level 7
+    // 53.5 -> 58.8 us, cube N = 48 85.8 -> 93.7: the extra clamped reads of
+    // the last trip cost what they add in LDS operations, i.e. this phase is
+    // bound by LDS throughput, not by its latency)
+    for (int jj = ra + sub; jj < rb; jj += TPR) {
+      const double vv = ev[jj + shv];
+      const int oo = el[jj + shl];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
+    }
+#else
+    constexpr int UE = vt_entries(NC) / kBlock;
     double ve[UE];
     unsigned short le[UE];
 #pragma unroll
@@ -1012,6 +1078,7 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
 #pragma unroll
       for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
     }
+#endif
   } else {
     // cache-resident operators: the first entries of my row straight from
     // the stream (the lanes of a row read contiguous bytes per step)
@@ -1019,9 +1086,29 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
     // that covers the 2-D P2 rows, and 58 instead of 70 VGPRs are an eighth
     // wave per SIMD: cavity level 6 15.54 -> 15.20 us; three components:
     // 8 - N = 32 29.6, 30.9 with 4)
-    constexpr int U = NC == 2 ? PCD_VT_U / 2 : PCD_VT_U;
+    constexpr int U = NC == 2 ? PCD_VT_U2 : PCD_VT_U;
     double v[U];
     int o[U];
+#if PCD_VT_PAIR
+    // a lane takes PAIRS of consecutive entries: one 16-byte load of the
+    // values and one 4-byte load of the offsets per pair (8- and 2-byte
+    // aligned: the hardware's unaligned mode), half the load instructions
+    typedef double dv2u __attribute__((ext_vector_type(2), aligned(8)));
+    typedef unsigned short us2u __attribute__((ext_vector_type(2), aligned(2)));
+#pragma unroll
+    for (int u = 0; u < U / 2; ++u) {
+      const int jj = ra + 2 * sub + u * 2 * TPR;
+      const bool in = jj < rb, in2 = jj + 1 < rb;
+      dv2u vv = dv2u(0.0);
+      us2u ll = us2u((unsigned short)0);
+      if (in) {
+        vv = *reinterpret_cast<const dv2u*>(val + k0 + jj);
+        ll = *reinterpret_cast<const us2u*>(loc + k0 + jj);
+      }
+      v[2 * u] = vv.x; o[2 * u] = ll.x;
+      v[2 * u + 1] = in2 ? vv.y : 0.0; o[2 * u + 1] = in2 ? (int)ll.y : 0;
+    }
+#else
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int jj = ra + sub + u * TPR;
@@ -1029,6 +1116,7 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
       v[u] = in ? val[k0 + jj] : 0.0;
       o[u] = in ? (int)loc[k0 + jj] : 0;
     }
+#endif
 #pragma unroll
     for (int u = 0; u < kVtNodes / kBlock; ++u)
       if (src[u]) {
@@ -1058,8 +1146,8 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
 
 #define PCD_VT_SHARED(NC)                                         \
   __shared__ double tile[NC * kVtNodes];                          \
-  __shared__ double ev[NT ? vt_entries(NC) : 1];                  \
-  __shared__ unsigned short el[NT ? vt_entries(NC) : 1]
+  __shared__ __attribute__((aligned(16))) double ev[NT ? vt_entries(NC) + 2 * PCD_VT_WIDE : 1]; \
+  __shared__ __attribute__((aligned(16))) unsigned short el[NT ? vt_entries(NC) + 4 * PCD_VT_WIDE : 1]
 
 #define PCD_VT_ARGS                                                                   \
   int nblocks, const int4* __restrict__ desc, const unsigned short* __restrict__ rowoff, \
