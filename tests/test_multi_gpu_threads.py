@@ -176,6 +176,43 @@ def test_three_dimensional_problem_partitioned(hip_lib):
             assert nu_loc % 3 == 0
 
 
+@pytest.mark.parametrize("form", ["2", "2staged"])
+@pytest.mark.parametrize("kind,level,nu,R", [("cavity", 3, 0.01, 3),
+                                             ("cube", 1, 0.1, 2)])
+def test_tile_kernels_read_their_ghost_columns(hip_lib, monkeypatch, form,
+                                               kind, level, nu, R):
+    """The LDS-staged vector-tile kernels on row-partitioned operators: a
+    block's tile holds nodes of OTHER ranks (tile sources >= nloc live in the
+    ghost buffer).  By default the tile kernels start at 80 000 node rows per
+    rank - beyond the suite's multi-rank sizes - so they are forced here
+    (direct and staged form), every level distributed."""
+    monkeypatch.setenv("PCD_VEC_TILE", "2")
+    if form == "2staged":
+        monkeypatch.setenv("PCD_NT_BYTES", "0")
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "0")
+    st = flow_state(kind, level, nu=nu)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    I = pb.interpolations()
+    rng = np.random.default_rng(5)
+    xu = rng.standard_normal(V.n_u)
+
+    def work(e, rank):
+        configure_engine(e, st)
+        push_multigrid(e, c.KSP_AP, pb.Ap, I.chain("p"))
+        push_multigrid(e, c.KSP_A00, L["A00"], I.chain("u"))
+        e.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.3, 2.6)
+        e.setup()
+        x, its, _ = e.gmres_np(st["b"], rtol=1e-8, restart=80, max_it=200)
+        return (x, its, e.spmv_np(c.MAT_A00, xu, V.n_u),
+                e.inner_solve_np(c.KSP_A00, xu))
+
+    xr, ir, yr, zr = work(oracle.Engine("BRM1"), 0)
+    for x, its, y, z in run_ranks(hip_lib, R, "BRM1", work):
+        assert relerr(y, yr) < 1e-13
+        assert relerr(z, zr) < 1e-11
+        assert its == ir and relerr(x, xr) < 1e-7
+
+
 @pytest.mark.parametrize("R,galerkin,dt,nls", [
     (2, True, None, "picard"), (3, False, None, "picard"),
     (2, True, 0.2, "picard"), (2, True, None, "newton"),
