@@ -81,10 +81,8 @@ def parse():
     p.add_argument("--partitioned-producer", action="store_true",
                    help="several ranks: every rank assembles ITS rows only "
                         "(fenapack_amd/fem/partition.py) instead of building "
-                        "the whole problem and slicing; implies "
-                        "--rediscretise-u for nested hierarchies (coarse "
-                        "levels assembled without communication); default "
-                        "for the cube from one million cells on")
+                        "the whole problem and slicing; default for the "
+                        "cube from one million cells on")
     p.add_argument("--no-producer", action="store_true",
                    help="skip the end-to-end Picard-step timing at the end")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -306,8 +304,9 @@ def main():
         os.environ.setdefault("FENAPACK_AMD_IGNORE_MEMORY", "1")
         comm.host = pt.TorchHostComm()
         pb = pt.partitioned(cls, rank, world, host=comm.host, **kw)
-        if not args.algebraic:
-            args.rediscretise_u = True
+        # (Galerkin coarse operators as on one GPU: every rank forms its rows'
+        # terms, partitioned coarse levels through HostComm.sum_rows;
+        # --rediscretise-u assembles them on the coarse meshes instead)
     else:
         kw = dict(kw)
         pb = cls(kw.pop("level"), **kw)

@@ -187,16 +187,22 @@ class Interpolations(object):
         return [None] + full[len(full) - nlevels + 1:]
 
 
-def galerkin_chain(A, chain, reduce=None):
+def galerkin_chain(A, chain, reduce=None, reduce_level=None):
     """Coarse operators ``A_{l-1} = P_l^T A_l P_l``; returns the list of
     operators, coarsest first (``ops[-1] is A``).  Large products run on the
     threaded native SpGEMM (same sums in the same order as scipy's).
-    ``reduce``: ``A`` holds one rank's rows only (partitioned producer): every
-    product is that rank's contribution and ``reduce`` sums them over the
-    ranks (the coarse levels are then whole on every rank; the caller makes
-    sure they are small enough to be replicated)."""
+
+    Partitioned producer: ``A`` holds one rank's rows only, so every product
+    is that rank's TERMS of the coarse operator (``P^T`` sums over fine rows).
+    ``reduce(C)``: the coarse levels are whole on every rank - summed once,
+    below the finest level.  ``reduce_level(C, l) -> (C', rowsparse)``: level
+    ``l`` may be partitioned too - the caller hands every coarse row's terms
+    to its owner (``HostComm.sum_rows``) and says whether ``C'`` is again one
+    rank's rows; products go on being reduced until a level comes back
+    whole."""
     ops = [None] * len(chain)
     ops[-1] = sp.csr_matrix(A)
+    rowsparse = reduce is not None or reduce_level is not None
     for l in range(len(chain) - 1, 0, -1):
         P = chain[l]
         if ops[l].nnz > 400000 and not _host.use_numpy():
@@ -204,10 +210,14 @@ def galerkin_chain(A, chain, reduce=None):
         else:
             C = (P.T @ ops[l] @ P).tocsr()
             C.sort_indices()
-        if reduce is not None and l == len(chain) - 1:
-            # (only the finest operator is one rank's rows; what comes out of
-            # the reduction is whole, and so is everything below it)
-            C = sp.csr_matrix(reduce(C))
+        if rowsparse:
+            # (what comes out of a plain sum is whole, and so is everything
+            # below it)
+            if reduce_level is not None:
+                C, rowsparse = reduce_level(C, l - 1)
+            else:
+                C, rowsparse = reduce(C), False
+            C = sp.csr_matrix(C)
             C.sort_indices()
         ops[l - 1] = C
     return ops

@@ -675,19 +675,21 @@ class KSP(object):
         elif pc.mg_galerkin:
             red = None
             if prod is not None:
-                # (level 0 - an explicit inverse - is whole whatever its size)
-                if any(chain[l].shape[1] > rep_limit
-                       for l in range(2, len(chain))):
-                    raise RuntimeError(
-                        "%spc_type mg with a partitioned producer: a level "
-                        "below the finest one is partitioned too - Galerkin "
-                        "products of partitioned levels need rows of other "
-                        "ranks; use pc_mg_galerkin none (re-discretised coarse "
-                        "operators, PETSc's PCMG default)" % self._prefix)
-                red = prod.host.sum       # replicated coarse levels: the sum
-                #                           of the ranks' contributions P^T A_r P
+                # this rank's terms of every coarse operator: summed over the
+                # ranks where the level is replicated, handed to the rows'
+                # owners where it is partitioned (the engine's rule: more
+                # than PCD_REPLICATE_BELOW rows; level 0 - an explicit
+                # inverse - is whole whatever its size)
+                from .fem.partition import cut
+
+                def red(C, l):
+                    n = C.shape[0]
+                    if l >= 1 and n > rep_limit and prod.size > 1:
+                        return prod.host.sum_rows(
+                            C, cut(n, prod.size, blk)), True
+                    return prod.host.sum(C), False
             if red is not None:
-                ops = galerkin_chain(A, chain, reduce=red)
+                ops = galerkin_chain(A, chain, reduce_level=red)
             elif chain_s is not None:
                 ops_s = galerkin_chain(F, chain_s)
                 ops = [_host.kron_expand(o, blk) for o in ops_s[:-1]] \

@@ -528,3 +528,55 @@ def test_partitioned_sa_refuses_a_structurally_unsymmetric_pattern():
 
     _threads(R, body)
     assert all(s and "structurally symmetric" in s for s in seen), seen
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_galerkin_products_of_partitioned_levels(R):
+    """``galerkin_chain(reduce_level=...)``: every rank forms ITS rows' terms
+    of each coarse operator; a partitioned coarse level gets them through
+    ``HostComm.sum_rows`` (rows to their owners), a replicated one through a
+    plain sum - against the global products, level by level."""
+    from fenapack_amd.fem.multigrid import galerkin_chain
+    g = global_build("cavity4")
+    pb = g["pb"]
+    A = sp.csr_matrix(g["lin"]["A00"])
+    chain = pb.interpolations().chain("u", 4)
+    ref = galerkin_chain(A, chain)
+    d, limit = 2, 3000
+    comms = pt.ThreadHostComm.group(R)
+    got = [None] * R
+    n = A.shape[0]
+
+    def body(r):
+        cu = pt.cut(n, R, d)
+        ip = np.zeros(n + 1, dtype=np.int64)
+        ip[cu[r] + 1:cu[r + 1] + 1] = np.diff(A.indptr)[cu[r]:cu[r + 1]]
+        np.cumsum(ip, out=ip)
+        lo, hi = A.indptr[cu[r]], A.indptr[cu[r + 1]]
+        Ar = sp.csr_matrix((A.data[lo:hi], A.indices[lo:hi], ip), shape=A.shape)
+
+        def red(C, l):
+            m = C.shape[0]
+            if l >= 1 and m > limit:
+                return comms[r].sum_rows(C, pt.cut(m, R, d)), True
+            return comms[r].sum(C), False
+
+        got[r] = galerkin_chain(Ar, chain, reduce_level=red)
+
+    _threads(R, body)
+    kinds = []
+    for l in range(len(chain) - 1):
+        G = sp.csr_matrix(ref[l])
+        m = G.shape[0]
+        scale = abs(G).max()
+        part = l >= 1 and m > limit
+        kinds.append(part)
+        for r in range(R):
+            M = sp.csr_matrix(got[r][l])
+            if part:
+                a, b = pt.cut(m, R, d)[r], pt.cut(m, R, d)[r + 1]
+                assert M.nnz == M[a:b].nnz
+                assert abs(M[a:b] - G[a:b]).max() <= 1e-13 * scale
+            else:
+                assert abs(M - G).max() <= 1e-13 * scale
+    assert any(kinds) and not kinds[0]      # both kinds of level were there

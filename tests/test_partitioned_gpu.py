@@ -55,19 +55,21 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("name,R", [("cavity4", 3), ("cube16", 4),
-                                    ("lshape4", 2)])
+@pytest.mark.parametrize("name,R,galerkin", [
+    ("cavity4", 3, False), ("cube16", 4, False), ("lshape4", 2, False),
+    ("cavity4", 3, True), ("cube16", 2, True)])
 def test_partitioned_producer_equals_the_global_hand_over(hip_lib, monkeypatch,
-                                                          name, R):
+                                                          name, R, galerkin):
     cls, kw, dim = CASES[name]
     # finest two levels partitioned, the rest replicated
     monkeypatch.setenv("PCD_REPLICATE_BELOW", "1500")
     PETScOptions.clear()
-    # re-discretised coarse velocity operators (-pc_mg_galerkin none, PETSc's
-    # PCMG default): what a partitioned producer assembles without
-    # communication; A_p: finest level + Galerkin coarse level (summed over
-    # the ranks)
-    multigrid_inner_options(dim=dim, galerkin_u=False)
+    # galerkin False: re-discretised coarse velocity operators
+    # (-pc_mg_galerkin none, PETSc's PCMG default) - what a partitioned
+    # producer assembles without communication; True: Galerkin products, each
+    # rank its rows' terms, partitioned coarse levels by HostComm.sum_rows.
+    # A_p: finest level + Galerkin coarse level (summed over the ranks)
+    multigrid_inner_options(dim=dim, galerkin_u=galerkin)
     kw1 = dict(kw)
     one = solve_steady(cls(kw1.pop("level"), **kw1), max_newton=3,
                        newton_rtol=0.0)
