@@ -105,6 +105,7 @@ struct DCsr {
   DBuf<int> rowptr, col;
   DBuf<double> val, dinv;
   DBuf<double> vals, val2s;   // column-scaled copies val .* dinv[col] (zero-guess first step)
+  DBuf<double> dghost;        // tile kernels: reciprocal diagonal of the ghost columns (no val2s then)
   DBuf<int64_t> src;      // provenance in the caller's monolithic values
   bool has_src = false;
   // value refreshes arrive in the CALLER's entry order and go through `src`
@@ -147,7 +148,7 @@ struct DCsr {
   PeerHalo ph;            // one-shot peer-write channel of this operator's halo (pcd_peer.hpp)
   void release() {
     rowptr.release(); col.release(); val.release(); dinv.release();
-    vals.release(); val2s.release();
+    vals.release(); val2s.release(); dghost.release();
     src.release(); ghost.release(); sendbuf.release(); send_idx.release();
     rowptr2.release(); col2.release(); kron_pos.release();
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
@@ -701,7 +702,17 @@ static int refresh_dinv(Engine* h, DCsr& A) {
   // (collective: every rank refreshes every operator in the same order)
   if (A.nnz) {
     CHK(halo_exchange(h, A, A.dinv.p));
-    if (A.kron && A.nnz2) {
+    if (A.kron && A.nnz2 && A.vt) {
+      // tile kernels scale the gathered TILE instead (k_cheb_first_tc): no
+      // second copy of the values; the ghost columns' reciprocal diagonal is
+      // kept aside (the ghost buffer itself is every later exchange's)
+      A.val2s.release();
+      if (A.plan.nghost && h->comm && !A.replicated) {
+        CHK(A.dghost.ensure(A.plan.nghost));
+        HIPCHK(hipMemcpyAsync(A.dghost.p, A.ghost.p, (size_t)A.plan.nghost * sizeof(double),
+                              hipMemcpyDeviceToDevice, h->stream));
+      }
+    } else if (A.kron && A.nnz2) {
       CHK(A.val2s.ensure(A.nnz2 + 2));
       hipLaunchKernelGGL(k_scale_cols, dim3(grid1d(A.nnz2, 4)), dim3(kBlock), 0, h->stream,
                          A.nnz2, A.col2.p, A.val2.p, A.dinv.p, A.kron, A.val2s.p,
@@ -813,8 +824,9 @@ static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
     const int nn = n / A.kron;
 #define PCD_FIRST_TC_(NC, NT, ROWS)                                                            \
     hipLaunchKernelGGL((k_cheb_first_tc<NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream, \
-                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2s.p,        \
-                       A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron))
+                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
+                       A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron), \
+                       A.dghost.p ? A.dghost.p : dinv)
 #define PCD_FIRST_TC(NC, NT) do { if (A.vt_rows == 128) PCD_FIRST_TC_(NC, NT, 128); else PCD_FIRST_TC_(NC, NT, 64); } while (0)
     if (A.kron == 2) { if (A.vt_staged) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
     else { if (A.vt_staged) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }

@@ -961,7 +961,13 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
     const int4 d, const unsigned short* __restrict__ rowoff, int blk,
     const int* __restrict__ tsrc, const double* __restrict__ val,
     const unsigned short* __restrict__ loc, const double* x,
-    const double* ghost, int nloc, double* tile, double* ev, unsigned short* el) {
+    const double* ghost, int nloc, double* tile, double* ev, unsigned short* el,
+    const double* xscale = nullptr, const double* gscale = nullptr) {
+  // (xscale / gscale: the tile holds x .* xscale - one factor per NODE, its
+  // first component's, as the diagonal of F (x) I repeats: the zero-guess
+  // first step gathers D^-1 b with the unscaled operator instead of b with a
+  // column-scaled COPY of it, which would be a second 8 B / entry array
+  // streaming through the Infinity Cache once per cycle)
   constexpr int TPR = kBlock / ROWS;
   constexpr int kVtRowOff = vt_rowoff(ROWS);
   const int lr = threadIdx.x / TPR, sub = threadIdx.x % TPR;
@@ -985,7 +991,15 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
 #pragma unroll
   for (int u = 0; u < kVtNodes / kBlock; ++u) {
     VecC<NC> t = vzero<NC>();
-    if (src[u]) t = *vc<NC>(src[u]);
+    if (src[u]) {
+      t = *vc<NC>(src[u]);
+      if (xscale) {
+        const double dd = node[u] < nloc ? xscale[(size_t)NC * node[u]]
+                                         : gscale[(size_t)NC * (node[u] - nloc)];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) t.c[i] *= dd;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NC; ++i) tv[u][i] = t.c[i];
   }
@@ -1219,7 +1233,8 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
 template <int NC, bool NT, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, double* p0_,
-    double* pn_, double s, double c1, double c2, const double* ghost, int nloc) {
+    double* pn_, double s, double c1, double c2, const double* ghost, int nloc,
+    const double* __restrict__ dghost) {
   PCD_VT_SHARED(NC);
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
@@ -1232,9 +1247,10 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
     const bool mine = threadIdx.x % (kBlock / ROWS) == 0 && lr < (d4.w & 0xff);
     VecC<NC> d = vzero<NC>(), bi = d;
     if (mine) { d = dinv[row]; bi = b[row]; }
-    // (vals carry D^-1 by columns: the gathered vector is b alone, with its
-    // halo when there are several ranks)
-    const VecC<NC> sum = tile_row_block<NC, NT, ROWS>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, ev, el);
+    // (the tile holds D^-1 b - b with its halo when there are several ranks,
+    // the reciprocal diagonal of the ghost columns kept from its own exchange)
+    const VecC<NC> sum = tile_row_block<NC, NT, ROWS>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, ev, el,
+                                                      dinv_, dghost);
     if (mine) {
       VecC<NC> x0, o;
 #pragma unroll
