@@ -535,7 +535,8 @@ static inline bool kron_ok(const DCsr& A, const void* a, const void* b = nullptr
   // rb2 == 0: no row block of F fits the LDS tile - only the kernels that need
   // no tile (dense, wave-per-row, workgroup-per-row SpMV) may take the
   // multi-component path; the Chebyshev / first-step stream kernels may not
-  if (!A.rb2 && (need_tile || !(A.dense2 || A.wave_rows || A.long_rows))) return false;
+  // (the tile kernels choose their blocks greedily and need no such fit)
+  if (!A.rb2 && !A.vt && (need_tile || !(A.dense2 || A.wave_rows || A.long_rows))) return false;
   if (A.kron != 2) return true;
   return aligned16(a) && aligned16(b) && aligned16(c) && aligned16(d);
 }
@@ -792,7 +793,7 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
     else { if (A.vt_staged) PCD_CHEB_TC(3, true); else PCD_CHEB_TC(3, false); }
 #undef PCD_CHEB_TC
 #undef PCD_CHEB_TC_
-  } else if (dinv && kron_ok(A, b, pm, pk, pn, true)) {
+  } else if (dinv && A.rb2 && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p,
@@ -811,7 +812,9 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
 // p0 = s D^-1 b (also written to `p0` unless null), pn = c1 p0 + c2 D^-1(b - A p0)
 static bool can_fuse_first(const Engine* h, const DCsr& A, const double* dinv) {
   (void)h;
-  return A.rb && dinv != nullptr && (!A.kron || A.rb2);
+  // (a multi-component operator none of whose kernels takes the step falls
+  // through to the scalar stream kernel and its column-scaled values)
+  return A.rb && dinv != nullptr;
 }
 static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
                              const double* b, double* p0, double* pn, double s,
@@ -834,7 +837,7 @@ static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
 #undef PCD_FIRST_TC_
     return 0;
   }
-  if (kron_ok(A, b, p0, pn, nullptr, true)) {
+  if (A.rb2 && kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2s.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron));
@@ -1589,6 +1592,9 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
       at += b_src[sb].size();
     }
   }
+  // rows of hundreds of entries leave a handful of rows per block: most lanes
+  // of the row-sum phase idle and the tile is loaded for nothing
+  if ((double)nn < 8.0 * (double)desc.size()) return 0;
   A.vt_blocks = (int)desc.size();
   A.vt_nsrc = (int64_t)tsrc.size();
   if (const char* e = getenv("PCD_VEC_TILE_STATS")) if (e[0] == '1') {
@@ -1636,7 +1642,12 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   const int rb2 = rb_for(nn, rpc.data(), nc == 3 ? tile_c<3>() : tile_c<2>());
   const bool dense2 = nn >= 64 && (int64_t)cc.size() == nn * (ncols / nc) &&
                       full_sorted_rows(nn, ncols / nc, rpc.data(), cc.data());
-  if (!rb2 && !g_want_wave && !dense2) return 0;   // (wave-per-row / dense kernels need no tile)
+  // rb2 == 0: some row block of F does not fit the LDS tile of the gather
+  // kernels (a few fat rows are enough: the first smoothed-aggregation level
+  // of cube N = 73, 41 entries per row on average, fell back to the scalar
+  // kernels - three times the bytes - for that).  The wave-per-row / dense
+  // kernels need no tile, and the tile kernels choose their blocks greedily
+  // by entries and distinct columns: tried below, kept if they took it
   A.dense2 = dense2;
   A.nnz2 = (int64_t)cc.size();
   CHK(A.rowptr2.ensure(nn + 1)); CHK(A.col2.ensure(A.nnz2)); CHK(A.val2.ensure(A.nnz2 + 2));
@@ -1649,7 +1660,21 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.kron = A.kron_pat = nc; A.rb2 = rb2;
   // bytes one fused step moves: F (12 B / entry) + five vector streams
   A.nt2 = g_nt_bytes >= 0 && 12.0 * (double)A.nnz2 + 40.0 * (double)nrows > (double)g_nt_bytes;
-  if (rb2) CHK(build_vec_tile(h, A, nc, nn, ncols / nc, rpc, cc));
+  CHK(build_vec_tile(h, A, nc, nn, ncols / nc, rpc, cc));
+  // no row block fits the gather kernels' tile and the tile kernels declined
+  // (a handful of rows per block): rows of a hundred entries and more go to
+  // the wave-per-row kernel, F still read once for all components (the
+  // restriction of a smoothed-aggregation level in space, ~180 entries per
+  // row: cube N = 73 183 us with the scalar stream kernel)
+  if (!rb2 && !A.vt && !dense2 && !A.long_rows && !A.wave_rows && nn > 0 &&
+      (int64_t)cc.size() / nn >= 96)
+    A.wave_rows = true;
+  if (!rb2 && !A.vt && !g_want_wave && !dense2 && !A.wave_rows && !A.long_rows) {
+    // nobody can run it as F (x) I: the scalar kernels take the operator
+    A.kron = 0; A.kron_pat = 0; A.rb2 = 0; A.nnz2 = 0; A.dense2 = false;
+    A.rowptr2.release(); A.col2.release(); A.val2.release(); A.kron_pos.release();
+    return 0;
+  }
   if (have_vals) CHK(refresh_kron(h, A));
   return 0;
 }
