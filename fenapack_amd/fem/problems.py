@@ -22,7 +22,17 @@ from .mesh import _LSHAPE_VERTICES, _LSHAPE_CELLS
 from .multigrid import (MeshHierarchy, CubeHierarchy, Interpolations,
                         injection_map)
 from .taylor_hood import TaylorHood
+from .. import _host
 
+
+
+def _matvec(A, x):
+    """``A @ x``; large operators through the threaded native SpMV (bitwise
+    scipy's row sums) - scipy's own is one thread, and at config 5's size the
+    five products of a residual were ~1.5 of the 3.4 s of a linearisation."""
+    if A.nnz > 400000 and not _host.use_numpy():
+        return _host.SpMV(A)(x)
+    return A @ x
 
 class _Dirichlet(object):
     """Symmetric elimination of a dof set on fixed-pattern CSR blocks."""
@@ -229,10 +239,10 @@ class FlowProblem(object):
         V = self.space
         U = self.nodal_velocity(xu)
         A00p = V.assemble_A00(self.nu, U, idt=self.idt, newton=False)
-        Fu = A00p @ xu + self._A01_raw @ xp
+        Fu = _matvec(A00p, xu) + _matvec(self._A01_raw, xp)
         if self.idt:
-            Fu -= self.idt * (self._Mmass @ self.u0)
-        Fp = self._A10_raw @ xu
+            Fu -= self.idt * _matvec(self._Mmass, self.u0)
+        Fp = _matvec(self._A10_raw, xu)
         if self.nls == "newton":
             A00 = V.assemble_A00(self.nu, U, idt=self.idt, newton=True)
         else:
@@ -240,8 +250,8 @@ class FlowProblem(object):
         g = self.bc_u_values(self.t)
         d = np.zeros(V.n_u)
         d[self.bc_u_idx] = xu[self.bc_u_idx] - g
-        Fu = Fu - A00 @ d
-        Fp = Fp - self._A10_raw @ d
+        Fu = Fu - _matvec(A00, d)
+        Fp = Fp - _matvec(self._A10_raw, d)
         Fu[self.bc_u_idx] = self._bc_mult[self.bc_u_idx] * d[self.bc_u_idx]
         out = {"A00": self.bc_u.square(A00, self._bc_mult), "A01": self.A01,
                "A10": self.A10, "bu": Fu, "bp": Fp}
