@@ -72,6 +72,9 @@ def library():
                                    ctypes.c_int64, _I32P, _I32P, _F64P, _I32P,
                                    _I32P, _F64P, _I64P, _I32P, _F64P]
     L.pcdh_set_threads.argtypes = [ctypes.c_int]
+    L.pcdh_wind_gradlam.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, _I64P, _F64P, _F64P, _F64P,
+                                    _F64P]
     L.pcdh_spmv.argtypes = [ctypes.c_int64, _I32P, _I32P, _F64P, _F64P, _F64P,
                             _F64P]
     L.pcdh_spmm.argtypes = [ctypes.c_int64, _I32P, _I32P, _F64P, ctypes.c_int,
@@ -372,6 +375,22 @@ def kron_expand(F, nc):
         A.has_sorted_indices = True
     A.kron_scalar, A.kron_block = F, nc
     return A
+
+
+def wind_gradlam(cell_dofs, U, gradlam, area):
+    """``out[c, m, k] = area[c] * sum_d U[cell_dofs[c, m], d] * gradlam[c, k, d]``
+    (threaded, one pass; bitwise the elementwise numpy chain)."""
+    dofs = _i64(cell_dofs)
+    U = np.ascontiguousarray(U, dtype=np.float64)
+    g = np.ascontiguousarray(gradlam, dtype=np.float64)
+    a = np.ascontiguousarray(area, dtype=np.float64)
+    nc, na = dofs.shape
+    nvl, dim = g.shape[1], g.shape[2]
+    out = np.empty((nc, na, nvl))
+    _chk(library().pcdh_wind_gradlam(nc, na, nvl, dim, _p(dofs, _I64P),
+                                     _p(U, _F64P), _p(g, _F64P), _p(a, _F64P),
+                                     _p(out, _F64P)))
+    return out
 
 
 def gather_sum(ptr, members, vals, out=None):

@@ -489,6 +489,39 @@ int pcdh_gather_sum(int64_t ngroups, const int64_t* ptr, const int64_t* members,
   return 0;
 }
 
+// ------------------------------------------ wind x barycentric gradients per cell
+// out[c, m, k] = |T_c| * sum_d U[dofs[c, m], d] * gradlam[c, k, d], the sum in
+// ascending d with every product rounded before it is added (numpy's
+// elementwise chain, bitwise): the left factor of the convection element
+// matrices (taylor_hood.py p2_convection_nodal), one pass instead of eight
+int pcdh_wind_gradlam(int64_t ncell, int na, int nvl, int dim, const int64_t* dofs,
+                      const double* U, const double* gradlam, const double* area,
+                      double* out) {
+  if (ncell < 0 || na < 1 || nvl < 1 || dim < 1 || dim > 3 ||
+      (ncell && (!dofs || !U || !gradlam || !area || !out)))
+    return fail(PCDH_ERR_ARG, "wind_gradlam: bad arguments");
+  const int T = nthreads(ncell * na * nvl);
+#pragma omp parallel for schedule(static, 2048) num_threads(T)
+  for (int64_t c = 0; c < ncell; ++c) {
+    const double* g = gradlam + c * nvl * dim;
+    const double a = area[c];
+    for (int m = 0; m < na; ++m) {
+      const double* u = U + dofs[c * na + m] * dim;
+      double* o = out + (c * na + m) * nvl;
+      for (int k = 0; k < nvl; ++k) {
+        volatile double p = u[0] * g[k * dim];          // (volatile: no contraction
+        double s = p;                                   //  into a fused multiply-add)
+        for (int d = 1; d < dim; ++d) {
+          p = u[d] * g[k * dim + d];
+          s += p;
+        }
+        o[k] = s * a;
+      }
+    }
+  }
+  return 0;
+}
+
 // ------------------------------------------------------- union of mapped blocks
 int pcdh_union_count(int64_t n, int nb, const int64_t* nr, const int32_t* const* rowmap,
                      const int32_t* const* indptr, int64_t* out) {

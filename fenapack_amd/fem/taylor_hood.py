@@ -639,7 +639,13 @@ class TaylorHood(object):
     def p2_convection_nodal(self, U):
         """The same element matrices from the nodal P2 wind ``U`` (nn, d):
         ``C_c = sum_{m,k} |T| (U_m . grad lam_k) Chat[m,k]``."""
+        from .. import _host
         na, nvl = self.na, self.nvl
+        if self.cell_dofs2.shape[0] > 20000 and not _host.use_numpy():
+            # one threaded pass (bitwise the chain below)
+            ug = _host.wind_gradlam(self.cell_dofs2, U, self.gradlam, self.area)
+            C = ug.reshape(-1, na * nvl) @ self._ref()["C"].reshape(na * nvl, -1)
+            return C.reshape(-1, na, na)
         Uc, g = U[self.cell_dofs2], self.gradlam      # (nc,na,d), (nc,nvl,d)
         # (elementwise: a batched matmul of (na, d) x (d, nvl) blocks runs one
         # tiny GEMM per cell)

@@ -158,6 +158,14 @@ int pcdh_kron_expand(int64_t ns, const int32_t* f_rowptr, const int32_t* f_col,
 int pcdh_gather_sum(int64_t ngroups, const int64_t* ptr, const int64_t* members,
                     const double* vals, double* out);
 
+/* ---- out[c, m, k] = |T_c| sum_d U[dofs[c, m], d] gradlam[c, k, d] ------------
+ * The wind-dependent factor of the P2 convection element matrices (the form
+ * ((w.grad) u, v) of demo_navier-stokes-pcd.py:106-109 on nodal winds), in one
+ * threaded pass; bitwise the elementwise numpy chain it replaces. */
+int pcdh_wind_gradlam(int64_t ncell, int na, int nvl, int dim, const int64_t* dofs,
+                      const double* U, const double* gradlam, const double* area,
+                      double* out);
+
 /* ---- union of index-mapped blocks -------------------------------------------
  * The monolithic pattern of a block system in the caller's mixed numbering
  * (what DOLFIN's SystemAssembler produces directly, assembling.py:151-155):
