@@ -135,6 +135,12 @@ struct DCsr {
   int vt_blocks = 0, vt_rows = 0;     // rows per block (template parameter of the kernels)
   int64_t vt_nsrc = 0;                // tile slots of all blocks
   bool vt_staged = false;             // staged (non-temporal) form of the tile kernels
+  // lane-major form (operators streamed from HBM; pcd_kernels.hpp k_*_lm):
+  // values in lane-major order (refreshed from val2 through vt_pos), 8 per lane
+  bool vt_lm = false;
+  int64_t vt_slots = 0;               // entries incl. the padding to whole lanes
+  DBuf<double> vt_val;
+  DBuf<int> vt_pos;                   // entry of F (row-major) behind every slot, -1: padding
   DBuf<int4> vt_desc;
   DBuf<int> vt_tsrc;
   DBuf<unsigned short> vt_loc, vt_rowoff;
@@ -153,6 +159,7 @@ struct DCsr {
     rowptr2.release(); col2.release(); kron_pos.release();
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
     vt = false; vt_blocks = 0; vt_desc.release(); vt_rowoff.release(); vt_tsrc.release(); vt_loc.release();
+    vt_lm = false; vt_slots = 0; vt_val.release(); vt_pos.release();
     plan = HaloPlan(); replicated = false;
     if (ph.dev.seq) (void)hipFree(ph.dev.seq);
     ph = PeerHalo();
@@ -562,6 +569,12 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
                        nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y);
     return;
   }
+  if (A.vt && A.vt_lm) {
+    hipLaunchKernelGGL((k_spmv_lm<MODE, NC>), dim3(grid_stream(A.vt_blocks, 1)), dim3(kBlock), 0, h->stream,
+                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,
+                       A.vt_loc.p, x, ghost, nloc, add, y);
+    return;
+  }
   if (A.vt) {
     const int gt = grid_stream(A.vt_blocks, 1);
 #define PCD_SPMV_TC_(NT, ROWS)                                                                 \
@@ -690,6 +703,22 @@ static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
   return 0;
 }
 
+// y = (G (x) I) x for another value array G on F's pattern (row-major, like
+// val2); the lane-major copy of the tile kernels follows the values in force
+static int spmv_other_values(Engine* h, DCsr& A, double*& other, const double* x, double* y) {
+  auto lane_major = [&]() {
+    if (A.vt && A.vt_lm)
+      hipLaunchKernelGGL(k_lm_values, dim3(grid1d(A.vt_slots, 4)), dim3(kBlock), 0, h->stream,
+                         A.vt_slots, A.vt_pos.p, A.val2.p, A.vt_val.p);
+  };
+  std::swap(A.val2.p, other);
+  lane_major();
+  const int rc = spmv(h, A, x, y);
+  std::swap(A.val2.p, other);
+  lane_major();
+  return rc;
+}
+
 static int refresh_kron(Engine* h, DCsr& A);
 static int refresh_dinv(Engine* h, DCsr& A) {
   CHK(refresh_kron(h, A));
@@ -701,6 +730,10 @@ static int refresh_dinv(Engine* h, DCsr& A) {
   // column-scaled values for the fused zero-guess first step; with several
   // ranks the reciprocal diagonal of the ghost columns arrives like any halo
   // (collective: every rank refreshes every operator in the same order)
+  // (the exchange is collective: a rank that owns no rows of a partitioned
+  // level - pcd_mg_set_level_cuts accepts empty blocks - still takes part;
+  // only the launches on its own entries are skipped)
+  if (h->comm && !A.replicated && !A.nnz) CHK(halo_exchange(h, A, A.dinv.p));
   if (A.nnz) {
     CHK(halo_exchange(h, A, A.dinv.p));
     if (A.kron && A.nnz2 && A.vt) {
@@ -781,7 +814,16 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                             double* pn, double c0, double c1, double c2) {
   const int n = (int)A.nrows;
   CHK(halo_exchange(h, A, pk));
-  if (dinv && A.vt && kron_ok(A, b, pm, pk, pn, true)) {
+  if (dinv && A.vt && A.vt_lm && kron_ok(A, b, pm, pk, pn, true)) {
+    const int gt = grid_stream(A.vt_blocks, 1);
+    const int nloc = (int)(A.ncols / A.kron);
+#define PCD_CHEB_LM(NC)                                                                        \
+    hipLaunchKernelGGL((k_cheb_step_lm<NC>), dim3(gt), dim3(kBlock), 0, h->stream,            \
+                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,       \
+                       A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
+    if (A.kron == 2) PCD_CHEB_LM(2); else PCD_CHEB_LM(3);
+#undef PCD_CHEB_LM
+  } else if (dinv && A.vt && kron_ok(A, b, pm, pk, pn, true)) {
     const int gt = grid_stream(A.vt_blocks, 1);
     const int nloc = (int)(A.ncols / A.kron);
 #define PCD_CHEB_TC_(NC, NT, ROWS)                                                             \
@@ -822,6 +864,17 @@ static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
   const int n = (int)A.nrows;
   CHK(halo_exchange(h, A, b));           // (several ranks: the halo of b)
   const double* ghost = (h->comm && !A.replicated) ? A.ghost.p : b;
+  if (A.vt && A.vt_lm && kron_ok(A, b, p0, pn, nullptr, true)) {
+    const int gt = grid_stream(A.vt_blocks, 1);
+#define PCD_FIRST_LM(NC)                                                                       \
+    hipLaunchKernelGGL((k_cheb_first_lm<NC>), dim3(gt), dim3(kBlock), 0, h->stream,           \
+                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,       \
+                       A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron), \
+                       A.dghost.p ? A.dghost.p : dinv)
+    if (A.kron == 2) PCD_FIRST_LM(2); else PCD_FIRST_LM(3);
+#undef PCD_FIRST_LM
+    return 0;
+  }
   if (A.vt && kron_ok(A, b, p0, pn, nullptr, true)) {
     const int gt = grid_stream(A.vt_blocks, 1);
     const int nn = n / A.kron;
@@ -1449,6 +1502,9 @@ static int refresh_kron(Engine* h, DCsr& A) {
   // values differ between components: general path - until a later refresh
   // brings equal components back.  Either way the set of kernels a PCApply
   // launches changes, so a captured graph is stale.
+  if (A.vt && A.vt_lm)
+    hipLaunchKernelGGL(k_lm_values, dim3(grid1d(A.vt_slots, 4)), dim3(kBlock), 0, h->stream,
+                       A.vt_slots, A.vt_pos.p, A.val2.p, A.vt_val.p);
   const int now = flag ? 0 : A.kron_pat;
   if (now != A.kron) { A.kron = now; ++h->gen; }
   return 0;
@@ -1490,6 +1546,7 @@ static long long g_vec_tile_rows = 80000;
 // level 6 (cache-resident) gather kernel 18.9 us, tile 15.5 (64 rows) / 17.7
 // (128); level 7 (HBM) 67.6 against 62.7 (128 rows, staged) / 91.8 (64)
 static int g_vt_rows2 = 0, g_vt_rows3 = 64;
+static int g_vt_lm = 1;
 static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
                           const std::vector<int32_t>& rpc, const std::vector<int32_t>& cc) {
   A.vt = false; A.vt_blocks = 0;
@@ -1498,8 +1555,14 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   { const char* e = getenv("PCD_VT_ROWS2"); g_vt_rows2 = (e && (atoi(e) == 64 || atoi(e) == 128)) ? atoi(e) : 0; }
   { const char* e = getenv("PCD_VT_NT"); g_vt_nt = e ? atoi(e) : 1; }
   A.vt_staged = A.nt2 && g_vt_nt;      // the form is fixed with the layout
-  const int kVtRows = nc == 2 ? (g_vt_rows2 ? g_vt_rows2 : (A.vt_staged ? 128 : 64)) : g_vt_rows3;
-  const int kEntries = vt_entries(nc);
+  // operators streamed from HBM: lane-major entries, straight to registers
+  // (k_*_lm; PCD_VT_LM=0 keeps the form that stages the entries in LDS)
+  { const char* e = getenv("PCD_VT_LM"); g_vt_lm = e ? atoi(e) : 1; }
+  A.vt_lm = A.vt_staged && g_vt_lm;
+  const int kVtRows = A.vt_lm ? lm_rows(nc)
+                      : nc == 2 ? (g_vt_rows2 ? g_vt_rows2 : (A.vt_staged ? 128 : 64)) : g_vt_rows3;
+  const int kEntries = A.vt_lm ? kLmEntries : vt_entries(nc);
+  const int kNodes = A.vt_lm ? lm_nodes(nc) : kVtNodes;
   const int kVtRowOff = vt_rowoff(kVtRows);
   A.vt_rows = kVtRows;
   { const char* e = getenv("PCD_VEC_TILE"); g_vec_tile = e ? atoi(e) : 1; }
@@ -1552,7 +1615,7 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
           const size_t before = uniq.size();
           for (int32_t k = rpc[r1]; k < rpc[r1 + 1]; ++k)
             if (stamp[cc[k]] != tick) { stamp[cc[k]] = tick; uniq.push_back(cc[k]); ++add; }
-          if (nuniq + add > kVtNodes) {
+          if (nuniq + add > kNodes) {
             for (size_t q = before; q < uniq.size(); ++q) stamp[uniq[q]] = -1;     // undo the row
             uniq.resize(before);
             break;
@@ -1574,9 +1637,20 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   std::vector<int4> desc;
   std::vector<int32_t> tsrc;
   std::vector<unsigned short> rowoff;
+  int64_t lm_lanes = 0;
+  std::vector<int32_t> lm_k0;
+  bool lm_empty_row = false;
   for (int64_t sb = 0; sb < nsup; ++sb) {
     for (const Blk& b : b_desc[sb]) {
       if (tsrc.size() + b.tn > (size_t)INT32_MAX) return 0;
+      if (A.vt_lm) {
+        // y = lanes of all blocks before this one, w = rows | tile nodes << 9 | lanes << 20
+        const int ne = rpc[b.r0 + b.nr] - b.k0, L = (ne + kLmE - 1) / kLmE;
+        desc.push_back(int4{b.r0, (int)lm_lanes, (int)tsrc.size(), b.nr | (b.tn << 9) | (L << 20)});
+        lm_k0.push_back(b.k0);
+        lm_lanes += L;
+        for (int i = 0; i < b.nr; ++i) lm_empty_row |= rpc[b.r0 + i + 1] == rpc[b.r0 + i];
+      } else
       desc.push_back(int4{b.r0, b.k0, (int)tsrc.size(), b.nr | (b.tn << 8)});
       tsrc.resize(tsrc.size() + b.tn);
       const size_t at = rowoff.size();
@@ -1605,8 +1679,44 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
             (long long)nn, nc, desc.size(), (double)nn / desc.size(), (double)tsrc.size() / desc.size(),
             100.0 * full / desc.size(), kVtRows);
   }
+  if (A.vt_lm) {
+    // (the lanes find their rows by counting row ends: no empty rows; 32-bit slots)
+    if (lm_empty_row || lm_lanes * kLmE > (int64_t)INT32_MAX - kLmE) { A.vt_blocks = 0; A.vt_lm = false; return 0; }
+    A.vt_slots = lm_lanes * kLmE;
+    std::vector<unsigned short> lloc((size_t)A.vt_slots, 0);
+    std::vector<int32_t> lpos((size_t)A.vt_slots, -1);
+    parallel_chunks((int64_t)desc.size(), [&](int64_t j0, int64_t j1) {
+      for (int64_t j = j0; j < j1; ++j) {
+        const int4 d = desc[j];
+        const int nr = d.w & 0x1ff, L = (d.w >> 20) & 0x1ff, k0 = lm_k0[j];
+        const int ne = rpc[d.x + nr] - k0;
+        const size_t base = (size_t)d.y * kLmE;
+        int row = 0;                                   // block row of entry e
+        for (int e = 0; e < ne; ++e) {
+          while (rpc[d.x + row + 1] - k0 <= e) ++row;
+          const int t = e / kLmE, u = e % kLmE;
+          unsigned short w = loc[k0 + e];              // (< 2048: 11 bits)
+          if (e + 1 == rpc[d.x + row + 1] - k0) w |= 0x8000u;
+          if (u == 0) w |= (unsigned short)((row & 0xf) << 11);
+          lloc[base + (size_t)t * kLmE + u] = w;
+          lpos[base + ((size_t)(u / 2) * L + t) * 2 + (u % 2)] = k0 + e;
+        }
+        // (the high nibble of a lane's first row travels with its entry 1,
+        // which may be padding)
+        for (int t = 0; t < L; ++t) {
+          const int e = t * kLmE;
+          int r = 0;
+          while (rpc[d.x + r + 1] - k0 <= e) ++r;
+          lloc[base + (size_t)t * kLmE + 1] |= (unsigned short)(((r >> 4) & 0xf) << 11);
+        }
+      }
+    });
+    loc.swap(lloc);
+    CHK(A.vt_pos.ensure(lpos.size())); CHK(A.vt_val.ensure(lpos.size()));
+    HIPCHK(hipMemcpy(A.vt_pos.p, lpos.data(), lpos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   CHK(A.vt_desc.ensure(desc.size())); CHK(A.vt_rowoff.ensure(rowoff.size()));
-  CHK(A.vt_tsrc.ensure(tsrc.size())); CHK(A.vt_loc.ensure(loc.size() + 4));
+  CHK(A.vt_tsrc.ensure(tsrc.size())); CHK(A.vt_loc.ensure(loc.size() + 8));
   HIPCHK(hipMemcpy(A.vt_desc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(A.vt_rowoff.p, rowoff.data(), rowoff.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(A.vt_tsrc.p, tsrc.data(), tsrc.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -3297,7 +3407,10 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
       // what one launch of the fused Chebyshev step on A00 moves by construction
       const DCsr& A = h->mat[PCD_MAT_A00];
       const double vec = 40.0 * (double)A.nrows;        // b, D^-1, p_k, p_{k-1} read, p_{k+1} written
-      if (A.kron && A.vt)
+      if (A.kron && A.vt && A.vt_lm)
+        *out = 10.0 * (double)A.vt_slots + 4.0 * (double)A.vt_nsrc +
+               (16.0 + 2.0 * (A.vt_rows + 2)) * (double)A.vt_blocks + vec;
+      else if (A.kron && A.vt)
         *out = 10.0 * (double)A.nnz2 + 4.0 * (double)A.vt_nsrc +
                (16.0 + 2.0 * (A.vt_rows + 2)) * (double)A.vt_blocks + vec;
       else if (A.kron)

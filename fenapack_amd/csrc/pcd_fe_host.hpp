@@ -827,10 +827,7 @@ static int fe_apply_unconstrained(Engine* h, FeState& fe, const double* dv, doub
     return fail(PCD_ERR_STATE, "fe_update: A00 is not F x I_%d on the FE pattern", fe.dim);
   if (!kron_ok(A, dv, dy))
     return fail(PCD_ERR_ARG, "fe_update: v / ru must be 16-byte aligned for the two-component SpMV");
-  std::swap(A.val2.p, fe.Func.p);        // same pattern, unmasked values
-  const int rc = spmv(h, A, dv, dy);
-  std::swap(A.val2.p, fe.Func.p);
-  return rc;
+  return spmv_other_values(h, A, fe.Func.p, dv, dy);   // same pattern, unmasked values
 }
 
 extern "C" {
@@ -982,10 +979,7 @@ int pcd_fe_set_previous(pcd_handle h, const double* u0, int mem) {
   } else {
     if (!A.set || A.kron != fe.dim || A.nnz2 != fe.lev[fe.nlev - 1].nnzf || !kron_ok(A, fe.u0.p, fe.mu0.p))
       return fail(PCD_ERR_STATE, "fe_set_previous: A00 is not F x I_%d on the FE pattern", fe.dim);
-    std::swap(A.val2.p, fe.mass.p);        // (M x I) u0 on the pattern of F
-    const int rc = spmv(h, A, fe.u0.p, fe.mu0.p);
-    std::swap(A.val2.p, fe.mass.p);
-    if (rc) return rc;
+    CHK(spmv_other_values(h, A, fe.mass.p, fe.u0.p, fe.mu0.p));   // (M x I) u0 on the pattern of F
   }
   hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, fe.idt, fe.mu0.p, 0.0, fe.mu0.p);
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -1265,6 +1265,236 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
   }
 }
 
+// ==========================================================================
+// LANE-MAJOR form of the vector-tile kernels (operators streamed from HBM).
+// The staged form above passes every (value, offset) pair through LDS: 10 B
+// written + 10 B + 8 NC B read per entry, and the entry buffers are half of
+// the workgroup's LDS, i.e. they decide how many workgroups a CU holds - which
+// is what the launch time follows (profiles/r04_j_*: T = a + b / W).  Here the
+// set-up stores each block's entries LANE-MAJOR: lane t owns the kLmE = 8
+// CONSECUTIVE entries 8 t .. 8 t + 7 of the block's row-major stream (blocks
+// are padded to whole lanes with zero entries: < 0.4 % of the stream); the
+// values of the pair (2 k, 2 k + 1) of all L active lanes sit side by side
+// (16-byte non-temporal loads, fully coalesced), a lane's eight 16-bit offsets
+// are one 16-byte load.  Entries go straight to REGISTERS; LDS holds the
+// vector tile, one partial sum per lane and one sum per row:
+//   loc:   bits 0-10 tile slot of the entry's column, bit 15 = last entry of
+//          its row; bits 11-14 of a lane's entries 0 / 1 = low / high nibble
+//          of the block row its first entry belongs to
+//   lane:  s += v * tile[slot]; at a row end R[row] = s, next row, s = 0;
+//          after its entries T[lane] = s (the part of a row that goes on in
+//          the next lane)
+//   row r (one lane per row, epilogue operands coalesced): entries [ra, rb)
+//          live in lanes la = ra / 8 .. lb = (rb - 1) / 8:
+//          sum = T[la] + ... + T[lb - 1] + R[r]   - a fixed order: reproducible
+// Two barriers per block, LDS per entry 8 NC B read.
+// ==========================================================================
+#ifndef PCD_LM_NODES3
+#define PCD_LM_NODES3 768
+#endif
+#ifndef PCD_LM_NODES2
+#define PCD_LM_NODES2 768
+#endif
+#ifndef PCD_LM_ROWS3
+#define PCD_LM_ROWS3 64
+#endif
+#ifndef PCD_LM_ROWS2
+#define PCD_LM_ROWS2 128
+#endif
+constexpr int kLmE = 8;                              // entries per lane
+constexpr int kLmEntries = kLmE * kBlock;            // entries per block
+constexpr int lm_nodes(int nc) { return nc == 3 ? PCD_LM_NODES3 : PCD_LM_NODES2; }
+constexpr int lm_rows(int nc) { return nc == 3 ? PCD_LM_ROWS3 : PCD_LM_ROWS2; }
+static_assert(lm_nodes(2) % kBlock == 0 && lm_nodes(3) % kBlock == 0, "one lane per tile node, whole passes");
+static_assert(lm_nodes(2) <= 2048 && lm_nodes(3) <= 2048, "11-bit tile slots");
+static_assert(lm_rows(2) <= 256 && lm_rows(3) <= 256, "one lane per row, 8-bit first rows");
+// descriptor: x = first row, y = lanes of all blocks before this one (its
+// values start at 8 y doubles, its offsets at 8 y shorts), z = first slot in
+// `tsrc`, w = rows | tile nodes << 9 | active lanes << 20
+
+#define PCD_LM_SHARED(NC)                                   \
+  __shared__ double tile[NC * lm_nodes(NC)];                \
+  __shared__ double lmR[NC * lm_rows(NC)];                  \
+  __shared__ double lmT[NC * kBlock]
+
+template <int NC>
+__device__ __forceinline__ VecC<NC> lm_row_block(
+    const int4 d, const unsigned short* __restrict__ rowoff, int blk,
+    const int* __restrict__ tsrc, const double* __restrict__ val,
+    const unsigned short* __restrict__ loc, const double* x,
+    const double* ghost, int nloc, double* tile, double* lmR, double* lmT,
+    const double* xscale = nullptr, const double* gscale = nullptr) {
+  constexpr int TN = lm_nodes(NC), RM = lm_rows(NC), RO = vt_rowoff(RM);
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+  const int t = threadIdx.x;
+  const int nr = d.w & 0x1ff, tn = (d.w >> 9) & 0x7ff, L = (d.w >> 20) & 0x1ff;
+  // the matrix stream: addresses known with the descriptor
+  const bool act = t < L;
+  const dv2* vb = reinterpret_cast<const dv2*>(val) + (size_t)d.y * (kLmE / 2);
+  dv2 ve[kLmE / 2];
+#pragma unroll
+  for (int k = 0; k < kLmE / 2; ++k)
+    ve[k] = act ? __builtin_nontemporal_load(vb + k * L + t) : dv2(0.0);
+  uv4 le = uv4(0u);
+  if (act) le = __builtin_nontemporal_load(reinterpret_cast<const uv4*>(loc) + d.y + t);
+  // entries [ra, rb) of the row whose sum this lane completes
+  const bool mine = t < nr;
+  const int ra = mine ? rowoff[blk * RO + t] : 0;
+  const int rb = mine ? rowoff[blk * RO + t + 1] : 0;
+  int node[TN / kBlock];
+#pragma unroll
+  for (int u = 0; u < TN / kBlock; ++u) {
+    const int q = t + u * kBlock;
+    node[u] = q < tn ? tsrc[d.z + q] : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < TN / kBlock; ++u) {
+    if (node[u] < 0) continue;
+    const bool own = node[u] < nloc;
+    const double* src = own ? x + (size_t)NC * node[u] : ghost + (size_t)NC * (node[u] - nloc);
+    VecC<NC> v = *vc<NC>(src);
+    if (xscale) {
+      const double dd = own ? xscale[(size_t)NC * node[u]] : gscale[(size_t)NC * (node[u] - nloc)];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) v.c[i] *= dd;
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) tile[i * TN + t + u * kBlock] = v.c[i];
+  }
+  __syncthreads();
+  if (act) {
+    int cur = ((le.x >> 11) & 0xf) | (((le.x >> 27) & 0xf) << 4);
+    VecC<NC> s = vzero<NC>();
+#pragma unroll
+    for (int u = 0; u < kLmE; ++u) {
+      const unsigned w = u & 1 ? le[u >> 1] >> 16 : le[u >> 1] & 0xffffu;
+      const double vv = u & 1 ? ve[u >> 1].y : ve[u >> 1].x;
+      const int oo = w & 0x7ff;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * TN + oo];
+      if (w & 0x8000u) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { lmR[i * RM + cur] = s.c[i]; s.c[i] = 0.0; }
+        ++cur;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) lmT[i * kBlock + t] = s.c[i];
+  }
+  __syncthreads();
+  VecC<NC> sum = vzero<NC>();
+  if (mine && rb > ra) {
+    const int la = ra / kLmE, lb = (rb - 1) / kLmE;
+    for (int q = la; q < lb; ++q) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) sum.c[i] += lmT[i * kBlock + q];
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) sum.c[i] += lmR[i * RM + t];
+  }
+  return sum;
+}
+
+template <int MODE, int NC>
+__global__ __launch_bounds__(kBlock) void k_spmv_lm(
+    PCD_VT_ARGS, const double* x, const double* ghost, int nloc, const double* add_,
+    double* y_) {
+  PCD_LM_SHARED(NC);
+  const VecC<NC>* add = vc<NC>(add_);
+  VecC<NC>* y = vc<NC>(y_);
+  int b0, b1;
+  row_block_range(nblocks, lm_rows(NC), b0, b1, true);
+  for (int blk = b0; blk < b1; ++blk) {
+    const int4 d = desc[blk];
+    const int row = d.x + threadIdx.x;
+    const bool mine = (int)threadIdx.x < (d.w & 0x1ff);
+    VecC<NC> a = vzero<NC>();
+    if ((MODE == 1 || MODE == 2) && mine) a = add[row];
+    const VecC<NC> s = lm_row_block<NC>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile, lmR, lmT);
+    if (mine) {
+      VecC<NC> o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i]
+                                        : (MODE == 2 ? a.c[i] - s.c[i] : -s.c[i]));
+      y[row] = o;
+    }
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(kBlock) void k_cheb_step_lm(
+    PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, const double* pm_,
+    const double* pk_, double* pn_, double c0, double c1, double c2,
+    const double* ghost, int nloc) {
+  PCD_LM_SHARED(NC);
+  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_), *pm = vc<NC>(pm_),
+               *pk = vc<NC>(pk_);
+  VecC<NC>* pn = vc<NC>(pn_);
+  int b0, b1;
+  row_block_range(nblocks, lm_rows(NC), b0, b1, true);
+  for (int blk = b0; blk < b1; ++blk) {
+    const int4 d4 = desc[blk];
+    const int row = d4.x + threadIdx.x;
+    const bool mine = (int)threadIdx.x < (d4.w & 0x1ff);
+    VecC<NC> bi = vzero<NC>(), d = bi, xk = bi, xm = bi;
+    if (mine) {
+      bi = b[row]; d = dinv[row]; xk = pk[row];
+      if (c0 != 0.0) xm = pm[row];
+    }
+    const VecC<NC> s = lm_row_block<NC>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile, lmR, lmT);
+    if (mine) {
+      VecC<NC> o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = c0 * xm.c[i] + c1 * xk.c[i] + c2 * d.c[i] * (bi.c[i] - s.c[i]);
+      pn[row] = o;
+    }
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(kBlock) void k_cheb_first_lm(
+    PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, double* p0_,
+    double* pn_, double s, double c1, double c2, const double* ghost, int nloc,
+    const double* __restrict__ dghost) {
+  PCD_LM_SHARED(NC);
+  const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_);
+  VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
+  int b0, b1;
+  row_block_range(nblocks, lm_rows(NC), b0, b1, true);
+  for (int blk = b0; blk < b1; ++blk) {
+    const int4 d4 = desc[blk];
+    const int row = d4.x + threadIdx.x;
+    const bool mine = (int)threadIdx.x < (d4.w & 0x1ff);
+    VecC<NC> d = vzero<NC>(), bi = d;
+    if (mine) { d = dinv[row]; bi = b[row]; }
+    const VecC<NC> sum = lm_row_block<NC>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, lmR, lmT,
+                                          dinv_, dghost);
+    if (mine) {
+      VecC<NC> x0, o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        x0.c[i] = s * d.c[i] * bi.c[i];
+        o.c[i] = c1 * x0.c[i] + c2 * d.c[i] * (bi.c[i] - s * sum.c[i]);
+      }
+      if (p0) p0[row] = x0;
+      pn[row] = o;
+    }
+  }
+}
+
+// lane-major values from F's row-major ones: out[s] = pos[s] < 0 ? 0 : valc[pos[s]]
+__global__ __launch_bounds__(kBlock) void k_lm_values(
+    int64_t nslots, const int* __restrict__ pos, const double* valc, double* out) {
+  for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots;
+       s += (int64_t)gridDim.x * kBlock) {
+    const int p = pos[s];
+    out[s] = p < 0 ? 0.0 : valc[p];
+  }
+}
+
 // valc[k] = val[pos[k]]; *mismatch |= (val[pos[c*nnzc + k]] differs, c >= 1):
 // pos holds, component-major, where the entry k of F sits in each component's
 // rows of the full matrix

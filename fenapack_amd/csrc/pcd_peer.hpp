@@ -306,6 +306,27 @@ struct PeerBackend : CommBackend {
   int register_halo(const HaloPlan& pl, const int* d_send_idx, double* ghost, PeerHalo& ph,
                     hipStream_t s) {
     ph = PeerHalo();
+    // The double-buffered landing areas are safe because a sender's exchange
+    // n + 2 follows ITS wait for the receiver's exchange n + 1, which the
+    // receiver issues after its consumers of n - true only if every receiver
+    // of a halo also sends to that peer on the same channel.  One-directional
+    // halos (restrictions, algebraic prolongators) get the missing direction
+    // as an EMPTY message: a flag and no data.  The rule is its own mirror
+    // image (q in recv \ send here <=> this rank in send \ recv there), so
+    // the ranks agree without talking.
+    HaloPlan sym = pl;
+    for (int q : pl.peers_recv)
+      if (std::find(pl.peers_send.begin(), pl.peers_send.end(), q) == pl.peers_send.end()) {
+        sym.peers_send.push_back(q); sym.send_off.push_back(sym.send_off.back());
+      }
+    for (int q : pl.peers_send)
+      if (std::find(pl.peers_recv.begin(), pl.peers_recv.end(), q) == pl.peers_recv.end()) {
+        sym.peers_recv.push_back(q); sym.recv_off.push_back(sym.recv_off.back());
+      }
+    return register_halo_sym(sym, d_send_idx, ghost, ph, s);
+  }
+  int register_halo_sym(const HaloPlan& pl, const int* d_send_idx, double* ghost, PeerHalo& ph,
+                        hipStream_t s) {
     const int nsp = (int)pl.peers_send.size(), nrp = (int)pl.peers_recv.size();
     bool fits = nsp <= kPeerMaxPeers && nrp <= kPeerMaxPeers;
     std::vector<size_t> land_off(nrp, 0), flag_off(nrp, 0);

@@ -910,6 +910,17 @@ static __thread int t_dirty = 0;            /* short loops since the last full b
 static __thread int t_sense = 0;
 static volatile int t_sb_count = 0, t_sb_sense = 0;
 
+/* Every parallel region starts from a known barrier state: t_dirty / t_sense
+ * live in the pool threads and would otherwise survive a region that ended on
+ * a short loop (the next, larger team would then take t_sync()'s barrier with
+ * some of its threads only).  t_region() runs on the encountering thread
+ * before the fork, t_begin() is the first statement of every team thread. */
+static inline void t_region(void) {
+  __atomic_store_n(&t_sb_count, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&t_sb_sense, 0, __ATOMIC_RELEASE);
+}
+static inline void t_begin(void) { t_dirty = 0; t_sense = 0; }
+
 static inline void t_sync(void) {
   if (t_dirty) {
     _Pragma("omp barrier")
@@ -984,8 +995,10 @@ static void t_copy_csr(csr_t *d, const csr_t *s, int threads) {
   d->col = (int32_t *)t_alloc(sizeof(int32_t) * s->nnz);
   d->val = (double *)t_alloc(sizeof(double) * s->nnz);
   if (s->dinv) d->dinv = (double *)t_alloc(sizeof(double) * s->nrows);
+  t_region();
 #pragma omp parallel num_threads(threads)
   {
+    t_begin();
     T_LOOP(i, s->nrows) {
       d->rowptr[i] = s->rowptr[i];
       for (int32_t k = s->rowptr[i]; k < s->rowptr[i + 1]; ++k) {
@@ -999,8 +1012,10 @@ static void t_copy_csr(csr_t *d, const csr_t *s, int threads) {
 
 static double *t_vec(int64_t n, int threads) {
   double *v = (double *)t_alloc(sizeof(double) * n);
+  t_region();
 #pragma omp parallel num_threads(threads)
   {
+    t_begin();
     T_LOOP(i, n) v[i] = 0.0;
   }
   return v;
@@ -1250,8 +1265,10 @@ int pcdo_team_prepare(pcdo_t *h, int threads) {
   T->wu = t_vec(h->n_u, threads);
   T->xs = t_vec(n, threads); T->ys = t_vec(n, threads);
   T->perm = (int32_t *)t_alloc(sizeof(int32_t) * n);
+  t_region();
 #pragma omp parallel num_threads(threads)
   {
+    t_begin();
     T_LOOP(i, n) T->perm[i] = h->perm[i];
   }
   g_team[slot] = T; g_team_owner[slot] = h;
@@ -1263,8 +1280,10 @@ int pcdo_team_fieldsplit_apply(pcdo_t *h, const double *x, double *y) {
   if (slot < 0) return fail(4, "team_fieldsplit_apply: call pcdo_team_prepare first");
   team_t *T = g_team[slot];
   int64_t nu = h->n_u, n = h->n_u + h->n_p;
+  t_region();
 #pragma omp parallel num_threads(T->threads)
   {
+    t_begin();
     T_LOOP(i, n) T->xs[i] = x[T->perm[i]];
     t_pcd(h, T, T->xs + nu, T->ys + nu);                /* y_p = S^-1 x_p */
     t_spmv(&T->mat[MAT_A01], T->ys + nu, T->wu, 2, T->xs);   /* x_u - A01 y_p */
@@ -1282,8 +1301,10 @@ double pcdo_stream_triad(int64_t n, int reps, int threads) {
   double best = 0.0;
   for (int r = 0; r < reps + 1; ++r) {
     double t0 = omp_get_wtime();
+  t_region();
 #pragma omp parallel num_threads(threads)
     {
+      t_begin();
       T_LOOP(i, n) a[i] = b[i] + 3.0 * c[i];
     }
     double dt = omp_get_wtime() - t0;

@@ -316,6 +316,42 @@ def test_team_timing_port_equals_the_serial_oracle(variant, mg, sub,
     assert par.stream_triad(1 << 20, 2, 2) > 0.0
 
 
+@pytest.mark.timeout(300)
+def test_team_barrier_state_does_not_survive_a_region(monkeypatch):
+    """Regions that END on a short loop (every loop short here) followed by a
+    LARGER team: the sub-team barrier's per-thread state must start afresh in
+    every parallel region - pool threads keep their thread-local flags, and a
+    new team would otherwise enter the full barrier with some of its threads
+    only (a hang of the CPU baseline)."""
+    from helpers import push_multigrid
+    monkeypatch.setenv("PCDO_TEAM_SUB", "2")
+    monkeypatch.setenv("PCDO_TEAM_BIG", str(10 ** 9))
+    st = flow_state("lshape", 2)
+    pb, V, L = st["pb"], st["V"], st["L"]
+    par, _ = oracle.omp_engine("BRM1")
+    ser = oracle.Engine("BRM1")
+    for eng in (ser, par):
+        configure_engine(eng, st)
+        I = pb.interpolations()
+        push_multigrid(eng, c.KSP_AP, pb.Ap, I.chain("p"), cycles=2)
+        push_multigrid(eng, c.KSP_A00, L["A00"], I.chain("u"), nu=2)
+        eng.set_inner(c.KSP_MP, "chebyshev", "jacobi", 5, 0.0, 0.5, 2.0)
+        eng.setup()
+    x = np.random.default_rng(4).standard_normal(V.ndof)
+    ref = ser.fieldsplit_apply_np(x)
+    for threads in (3, 4, 6, 3, 8):
+        par.team_prepare(threads)
+        y = np.empty_like(x)
+        par.team_fieldsplit_apply(x, y)
+        assert relerr(y, ref) < 1e-11, threads
+        # the next region's first loop is long: whole team, full barrier
+        monkeypatch.setenv("PCDO_TEAM_BIG", "1")
+        par.team_prepare(threads + 1)
+        par.team_fieldsplit_apply(x, y)
+        assert relerr(y, ref) < 1e-11, threads
+        monkeypatch.setenv("PCDO_TEAM_BIG", str(10 ** 9))
+
+
 def test_single_reduction_cg_is_cg():
     """[ext PETSc] -ksp_cg_single_reduction (Chronopoulos-Gear recurrence):
     the same Krylov iterates as standard CG in exact arithmetic."""
