@@ -399,6 +399,12 @@ def main():
     t_hi = min(time_a00(m_hi) for _ in range(3))
     t_lo = min(time_a00(m_lo) for _ in range(3))
     t_kernel = (t_hi - t_lo) / (m_hi - m_lo)
+    # ... which is the kernel with the caches as ITS OWN previous launch left
+    # them (the operator warm in L2 / the Infinity Cache as far as it fits).
+    # The same kernel where it runs - inside the multigrid cycle, after the
+    # coarser levels have used the caches - is timed below with an event pair
+    # per launch (pcd_probe_a00_step), once the bench settings are back
+    in_cycle = None
     if args.inner == "mg":                     # restore the bench settings
         eng.set_inner(c.KSP_A00, "richardson", "mg", args.cycles_u, 0.0)
     else:
@@ -422,6 +428,11 @@ def main():
         eng.fieldsplit_apply(x.t, y.t, c.MEM_DEVICE)
 
     dt = timed_steps(step, torch.cuda.synchronize, args, dist, world, "cuda")
+    try:
+        us_c, n_c = eng.probe_a00_step(x.t, y.t, 3)
+        in_cycle = {"us_per_launch": us_c, "launches_timed": n_c}
+    except Exception as exc:                       # never lose the bench line
+        in_cycle = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     # SURVEY 8(d) extras, outside the timed region, rank-local:
     #  * per-call latency distribution (each call synchronised: includes the
@@ -581,7 +592,8 @@ def main():
         "pcapply_hbm_gbs": bytes_pc * args.steps / dt / 1e9,
         "roofline": roofline_block(
             kernel_name, b_kernel, t_kernel, traffic, b_model, probes,
-            copy_gbs, pmc, rf.HBM_PEAK_GBS, resident_bytes=b_model),
+            copy_gbs, pmc, rf.HBM_PEAK_GBS, resident_bytes=b_model,
+            in_cycle=in_cycle),
         # the same three numbers for the WHOLE PCApply (all its launches)
         "pcapply_roofline": roofline_block(
             "all %s launches of one fieldsplit PCApply"
@@ -698,7 +710,7 @@ def pmc_measurement(n_u, world):
 
 def roofline_block(kernel, b_alg, t, traffic, b_model, probes,
                    torch_copy_gbs, pmc, peak, resident_bytes=None,
-                   whole_apply=False):
+                   whole_apply=False, in_cycle=None):
     """The physical readings first - PMC traffic (`frac_traffic`) and the
     bytes the kernel must move by construction (`frac_kernel_model`), each
     over the measured time against the 8 TB/s spec and against the best
@@ -748,6 +760,23 @@ def roofline_block(kernel, b_alg, t, traffic, b_model, probes,
     if b_model is not None:
         out["kernel_model_bytes_per_launch"] = int(b_model)
         out["frac_kernel_model"] = gbs(b_model) / peak
+    if not whole_apply:
+        # which cache state `us_per_launch` is: 65 launches back to back on ONE
+        # operator (warm as far as the operator fits the caches); next to it
+        # the same kernel inside eager PCApplies, where the coarser levels of
+        # the cycle have used the caches in between (an event pair per launch
+        # adds about a microsecond)
+        out["us_per_launch_cache_state"] = (
+            "back-to-back loop on one operator (cache-warm as far as %.0f MB "
+            "fit L2 / the 256 MiB Infinity Cache)" % ((b_model or b_alg) / 1e6))
+        out["in_cycle"] = in_cycle
+        if in_cycle and in_cycle.get("us_per_launch"):
+            tc = in_cycle["us_per_launch"] * 1e-6
+            phys_c = traffic if traffic is not None else b_model
+            in_cycle["achieved"] = b_alg / tc / 1e9
+            in_cycle["frac"] = b_alg / tc / 1e9 / peak
+            if phys_c is not None:
+                in_cycle["frac_physical"] = phys_c / tc / 1e9 / peak
     return out
 
 

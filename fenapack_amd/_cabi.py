@@ -25,6 +25,7 @@ INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
 INFO_REORDERED = 15          # HIP engine only: +1 velocity, +2 pressure renumbered
 INFO_LAUNCHES = 64           # HIP engine only: kernel launches of this host thread
 INFO_PEER_CALLS, INFO_BOOT_CALLS = 65, 66   # exchanges / reductions: peer kernels, bootstrap
+INFO_PEER_DECLINED = 68      # halo channels that did not fit the peer arena (bootstrap path)
 INFO_A00_MODEL_BYTES = 67    # bytes one Chebyshev step on A00 moves by construction
 INFO_NNZ_BASE = 16
 
@@ -86,6 +87,8 @@ _HIP_ONLY = {
     "comm_init_threads": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "comm_init_host": [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "graph_enable": [C.c_int],
+    "probe_a00_step": [C.c_void_p, C.c_void_p, C.c_int, _f64p,
+                       C.POINTER(C.c_int)],
     "bandwidth_probe": [C.c_int, C.c_int64, C.c_int, _f64p],
     "set_velocity_block": [C.c_int],
     # pre-composed inner solves
@@ -505,6 +508,15 @@ class Engine(object):
         if self.L.hip:
             self._call("set_velocity_block", int(ncomp))
 
+    def probe_a00_step(self, x, y, reps=3):
+        """(us per launch, launches timed) of the fused Chebyshev step on the
+        finest velocity operator INSIDE eager fieldsplit applies (device
+        vectors)."""
+        us, cnt = C.c_double(0.0), C.c_int(0)
+        self._call("probe_a00_step", _ptr(x), _ptr(y), int(reps),
+                   C.byref(us), C.byref(cnt))
+        return us.value, cnt.value
+
     def graph_enable(self, on=True):
         self._call("graph_enable", int(bool(on)))
 
@@ -581,7 +593,8 @@ class Engine(object):
 
     def fe_bind_robin(self, nodes, normals, lengths, aff_pos, aff_ptr,
                       aff_src, aff_w):
-        """``nodes`` (3, nb), ``normals`` (2, nb): component-major."""
+        """``nodes`` (3, nb), ``normals`` (2, nb): component-major (3-D:
+        (6, nb) and (3, nb), ``lengths`` = areas of the boundary faces)."""
         nodes, aff_pos, aff_src = _i32(nodes), _i32(aff_pos), _i32(aff_src)
         normals, lengths, aff_w = _f64(normals), _f64(lengths), _f64(aff_w)
         aff_ptr = np.ascontiguousarray(aff_ptr, dtype=np.int64)

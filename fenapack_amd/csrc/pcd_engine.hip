@@ -129,6 +129,14 @@ struct DCsr {
   DBuf<int> rowptr2, col2, kron_pos;
   DBuf<double> val2;
   DBuf<int> kron_flag;
+  // ROW-blocked structure (the discrete gradient A01): the rk rows of a node
+  // share one column pattern - kept once per node, values node-entry-major
+  // (pcd_kernels.hpp k_spmv_rk); refreshed from `val` through rk_pos
+  int rk = 0, rk_rb = 0;
+  bool rk_nt = false;
+  int64_t rk_nnz = 0;                 // node-entries
+  DBuf<int> rk_rowptr, rk_col, rk_pos;
+  DBuf<double> rk_val;
   // LDS-staged vector tiles of the F (x) I kernels (pcd_kernels.hpp k_*_tc):
   // greedy row blocks, their column segments, 16-bit tile offsets per entry
   bool vt = false;
@@ -141,6 +149,11 @@ struct DCsr {
   int64_t vt_slots = 0;               // entries incl. the padding to whole lanes
   DBuf<double> vt_val;
   DBuf<int> vt_pos;                   // entry of F (row-major) behind every slot, -1: padding
+  // several ranks, PCD_OVERLAP=1: the blocks that read no ghost column
+  // (vt_nint of them, first in vt_list) run while the halo travels, the
+  // vt_nbnd others after it has landed
+  DBuf<int> vt_list;
+  int vt_nint = 0, vt_nbnd = 0;
   DBuf<int4> vt_desc;
   DBuf<int> vt_tsrc;
   DBuf<unsigned short> vt_loc, vt_rowoff;
@@ -160,8 +173,17 @@ struct DCsr {
     val2.release(); kron_flag.release(); kron = 0; kron_pat = 0; rb2 = 0; nnz2 = 0;
     vt = false; vt_blocks = 0; vt_desc.release(); vt_rowoff.release(); vt_tsrc.release(); vt_loc.release();
     vt_lm = false; vt_slots = 0; vt_val.release(); vt_pos.release();
+    vt_list.release(); vt_nint = vt_nbnd = 0;
+    rk = 0; rk_rb = 0; rk_nnz = 0; rk_rowptr.release(); rk_col.release(); rk_pos.release(); rk_val.release();
     plan = HaloPlan(); replicated = false;
     if (ph.dev.seq) (void)hipFree(ph.dev.seq);
+    if (ph.owner) {
+      // the channel's landing buffers and flags go back to the arena's free
+      // list (a gamg hierarchy pushed again every Picard step would otherwise
+      // fill the arena and fall back to the bootstrap path without a word)
+      std::lock_guard<std::mutex> lk(peer_live_mu());
+      if (peer_live().count(ph.owner)) ph.owner->give_back(ph);
+    }
     ph = PeerHalo();
     set = false; nrows = ncols = nnz = 0; has_src = false; val_src = false;
   }
@@ -306,6 +328,13 @@ struct pcd_engine_s {
   bool g_ok = false;
   int gmres_its = 0;
   double gmres_rnorm = 0.0;
+  // pcd_probe_a00_step: event pairs around every fused Chebyshev step on the
+  // finest velocity operator of an EAGER fieldsplit apply
+  bool probe_on = false;
+  std::vector<hipEvent_t> probe_ev;
+  // interior / boundary split of a tile-kernel launch (PCD_OVERLAP=1):
+  // 0 all blocks, 1 the blocks without ghost columns, 2 the others
+  int ov_phase = 0;
 };
 
 typedef pcd_engine_s Engine;
@@ -471,6 +500,38 @@ static int halo_exchange(Engine* h, const DCsr& A, const double* x) {
     return fail(PCD_ERR_COMM, "halo exchange: %s", h->comm->err.c_str());
   return 0;
 }
+// SpMV overlaps the halo transfer with the rows that need no ghost column
+// (what PETSc's MPIAIJ MatMult does with its diag / offd blocks
+// under the reference's mpirun -np 3, test/regression/test.py:186-190).  With
+// the peer protocol the exchange is one ~4 us kernel; split, it is a send
+// kernel, the interior blocks, a wait-and-land kernel, the boundary blocks:
+// two launches more per SpMV, the neighbours' latency hidden behind the
+// interior blocks.  Only real peers can price it (two processes on one GPU
+// time-share it), so it sits behind a switch: PCD_OVERLAP=1.  Blocks are
+// computed exactly as without the split: bitwise the same result.
+static int g_overlap = [] { const char* e = getenv("PCD_OVERLAP"); return e ? atoi(e) : 0; }();
+static bool overlap_ok(Engine* h, const DCsr& A) {
+  return g_overlap && h->comm && !A.replicated && A.vt && A.vt_nbnd > 0 && A.ph.ready &&
+         static_cast<PeerBackend*>(h->comm)->usable(h->stream);
+}
+static int halo_send(Engine* h, const DCsr& A, const double* x) {
+  PeerBackend* pb = static_cast<PeerBackend*>(h->comm);
+  if (pb->halo_send(A.ph, x, h->stream)) return fail(PCD_ERR_COMM, "halo exchange: %s", pb->err.c_str());
+  return 0;
+}
+static int halo_wait(Engine* h, const DCsr& A) {
+  PeerBackend* pb = static_cast<PeerBackend*>(h->comm);
+  if (pb->halo_wait(A.ph, h->stream)) return fail(PCD_ERR_COMM, "halo exchange: %s", pb->err.c_str());
+  return 0;
+}
+// the blocks of a tile-kernel launch in the current phase
+struct VtBlocks { int n; const int* list; };
+static inline VtBlocks vt_blocks_now(const Engine* h, const DCsr& A) {
+  if (h->ov_phase == 1) return VtBlocks{A.vt_nint, A.vt_list.p};
+  if (h->ov_phase == 2) return VtBlocks{A.vt_nbnd, A.vt_list.p + A.vt_nint};
+  return VtBlocks{A.vt_blocks, nullptr};
+}
+
 // the halos of several operators in ONE grouped exchange (one latency instead
 // of one per operator); each operator keeps its own ghost buffer
 struct HaloItem { const DCsr* A; const double* x; };
@@ -569,17 +630,19 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
                        nn, A.rowptr2.p, A.col2.p, A.val2.p, x, ghost, nloc, add, y);
     return;
   }
+  const VtBlocks vb = vt_blocks_now(h, A);
+  if (A.vt && vb.n == 0) return;
   if (A.vt && A.vt_lm) {
-    hipLaunchKernelGGL((k_spmv_lm<MODE, NC>), dim3(grid_stream(A.vt_blocks, 1)), dim3(kBlock), 0, h->stream,
-                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,
+    hipLaunchKernelGGL((k_spmv_lm<MODE, NC>), dim3(grid_stream(vb.n, 1)), dim3(kBlock), 0, h->stream,
+                       vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,
                        A.vt_loc.p, x, ghost, nloc, add, y);
     return;
   }
   if (A.vt) {
-    const int gt = grid_stream(A.vt_blocks, 1);
+    const int gt = grid_stream(vb.n, 1);
 #define PCD_SPMV_TC_(NT, ROWS)                                                                 \
     hipLaunchKernelGGL((k_spmv_tc<MODE, NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream, \
-                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
+                       vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,       \
                        A.vt_loc.p, x, ghost, nloc, add, y)
 #define PCD_SPMV_TC(NT) do { if (A.vt_rows == 128) PCD_SPMV_TC_(NT, 128); else PCD_SPMV_TC_(NT, 64); } while (0)
     if (A.vt_staged) PCD_SPMV_TC(true); else PCD_SPMV_TC(false);
@@ -622,6 +685,24 @@ static void launch_spmv_any(Engine* h, const DCsr& A, const double* x,
   } else if (kron) {
     if (A.kron == 2) launch_spmv_kron_nc<MODE, 2>(h, A, x, add, y, ghost, ncols);
     else launch_spmv_kron_nc<MODE, 3>(h, A, x, add, y, ghost, ncols);
+  } else if (A.rk && A.rk_rb && (A.rk == 3 || (aligned16(y) && aligned16(add)))) {
+    // the rows of a node share their columns: one index per node-entry
+    const int nn = (int)(A.nrows / A.rk);
+    const int g = grid_stream(nn, A.rk_rb);
+#define PCD_SPMV_RK_(RB, NC, NT)                                                          \
+    hipLaunchKernelGGL((k_spmv_rk<RB, MODE, NC, NT>), dim3(g), dim3(kBlock), 0, h->stream, \
+                       nn, A.rk_rowptr.p, A.rk_col.p, A.rk_val.p, xv, add, y)
+#define PCD_SPMV_RK(NC, NT)                                                               \
+    switch (A.rk_rb) {                                                                    \
+      case 256: PCD_SPMV_RK_(256, NC, NT); break;                                         \
+      case 128: PCD_SPMV_RK_(128, NC, NT); break;                                         \
+      case 64: PCD_SPMV_RK_(64, NC, NT); break;                                           \
+      default: PCD_SPMV_RK_(32, NC, NT); break;                                           \
+    }
+    if (A.rk == 2) { if (A.rk_nt) { PCD_SPMV_RK(2, true) } else { PCD_SPMV_RK(2, false) } }
+    else { if (A.rk_nt) { PCD_SPMV_RK(3, true) } else { PCD_SPMV_RK(3, false) } }
+#undef PCD_SPMV_RK
+#undef PCD_SPMV_RK_
   } else if (A.dense && ghost == A.ghost.p) {
     const int g = (int)std::min<int64_t>(A.nrows, 65535);
     hipLaunchKernelGGL((k_dense_c<MODE, 1>), dim3(g), dim3(kBlock), 0, h->stream,
@@ -689,15 +770,27 @@ static int spmv(Engine* h, const DCsr& A, const double* x, double* y,
       return fail(PCD_ERR_STATE, "spmv: two-piece input on an operator with a halo");
     if (A.kron && n1 % A.kron) return fail(PCD_ERR_ARG, "spmv: piece boundary splits a node");
     ghost = x2; ncols = n1;
-  } else if (!halo_done) {
-    CHK(halo_exchange(h, A, x));
   }
   const bool kron = kron_ok(A, x, y, add, x2);
-  switch (mode) {
-    case 0: launch_spmv_any<0>(h, A, x, add, y, ghost, ncols, kron); break;
-    case 1: launch_spmv_any<1>(h, A, x, add, y, ghost, ncols, kron); break;
-    case 2: launch_spmv_any<2>(h, A, x, add, y, ghost, ncols, kron); break;
-    default: launch_spmv_any<3>(h, A, x, add, y, ghost, ncols, kron); break;
+  auto run = [&]() {
+    switch (mode) {
+      case 0: launch_spmv_any<0>(h, A, x, add, y, ghost, ncols, kron); break;
+      case 1: launch_spmv_any<1>(h, A, x, add, y, ghost, ncols, kron); break;
+      case 2: launch_spmv_any<2>(h, A, x, add, y, ghost, ncols, kron); break;
+      default: launch_spmv_any<3>(h, A, x, add, y, ghost, ncols, kron); break;
+    }
+  };
+  if (!x2 && !halo_done && kron && overlap_ok(h, A)) {
+    // interior blocks while the halo travels, boundary blocks after it landed
+    CHK(halo_send(h, A, x));
+    h->ov_phase = 1; run();
+    h->ov_phase = 0;
+    CHK(halo_wait(h, A));
+    h->ov_phase = 2; run();
+    h->ov_phase = 0;
+  } else {
+    if (!x2 && !halo_done) CHK(halo_exchange(h, A, x));
+    run();
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -813,22 +906,39 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                             const double* b, const double* pm, const double* pk,
                             double* pn, double c0, double c1, double c2) {
   const int n = (int)A.nrows;
-  CHK(halo_exchange(h, A, pk));
-  if (dinv && A.vt && A.vt_lm && kron_ok(A, b, pm, pk, pn, true)) {
-    const int gt = grid_stream(A.vt_blocks, 1);
+  const bool probe = h->probe_on && &A == &h->mat[PCD_MAT_A00];
+  struct Probe {                 // (every return path below records the closing event)
+    Engine* h; bool on;
+    Probe(Engine* h_, bool on_) : h(h_), on(on_) { if (on) mark(); }
+    ~Probe() { if (on) mark(); }
+    void mark() {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, h->stream) == hipSuccess) h->probe_ev.push_back(e);
+    }
+  } probe_guard(h, probe);
+  const bool tile = dinv && A.vt && kron_ok(A, b, pm, pk, pn, true);
+  auto run = [&]() {
+  if (tile && A.vt_lm) {
+    const VtBlocks vb = vt_blocks_now(h, A);
+    if (!vb.n) return;
+    const int gt = grid_stream(vb.n, 1);
     const int nloc = (int)(A.ncols / A.kron);
 #define PCD_CHEB_LM(NC)                                                                        \
     hipLaunchKernelGGL((k_cheb_step_lm<NC>), dim3(gt), dim3(kBlock), 0, h->stream,            \
-                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,       \
-                       A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
+                       vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,     \
+                       A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc, epi_nt)
+    // (the step's five vectors beyond the Infinity Cache: streamed past it)
+    const int epi_nt = g_nt_bytes >= 0 && 40.0 * (double)A.nrows > (double)g_nt_bytes;
     if (A.kron == 2) PCD_CHEB_LM(2); else PCD_CHEB_LM(3);
 #undef PCD_CHEB_LM
-  } else if (dinv && A.vt && kron_ok(A, b, pm, pk, pn, true)) {
-    const int gt = grid_stream(A.vt_blocks, 1);
+  } else if (tile) {
+    const VtBlocks vb = vt_blocks_now(h, A);
+    if (!vb.n) return;
+    const int gt = grid_stream(vb.n, 1);
     const int nloc = (int)(A.ncols / A.kron);
 #define PCD_CHEB_TC_(NC, NT, ROWS)                                                             \
     hipLaunchKernelGGL((k_cheb_step_tc<NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream,  \
-                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
+                       vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,       \
                        A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
 #define PCD_CHEB_TC(NC, NT) do { if (A.vt_rows == 128) PCD_CHEB_TC_(NC, NT, 128); else PCD_CHEB_TC_(NC, NT, 64); } while (0)
     if (A.kron == 2) { if (A.vt_staged) PCD_CHEB_TC(2, true); else PCD_CHEB_TC(2, false); }
@@ -847,6 +957,18 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
     LAUNCH_LPR(A, k_cheb_step, grid_rows(n, A.lpr), n, A.rowptr.p, A.col.p,
                A.val.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, (int)A.ncols);
   }
+  };
+  if (tile && overlap_ok(h, A)) {
+    CHK(halo_send(h, A, pk));
+    h->ov_phase = 1; run();
+    h->ov_phase = 0;
+    CHK(halo_wait(h, A));
+    h->ov_phase = 2; run();
+    h->ov_phase = 0;
+  } else {
+    CHK(halo_exchange(h, A, pk));
+    run();
+  }
   return 0;
 }
 
@@ -862,25 +984,27 @@ static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
                              const double* b, double* p0, double* pn, double s,
                              double c1, double c2) {
   const int n = (int)A.nrows;
-  CHK(halo_exchange(h, A, b));           // (several ranks: the halo of b)
   const double* ghost = (h->comm && !A.replicated) ? A.ghost.p : b;
-  if (A.vt && A.vt_lm && kron_ok(A, b, p0, pn, nullptr, true)) {
-    const int gt = grid_stream(A.vt_blocks, 1);
+  const bool tile = A.vt && kron_ok(A, b, p0, pn, nullptr, true);
+  auto run = [&]() {
+  if (tile && A.vt_lm) {
+    const VtBlocks vb = vt_blocks_now(h, A);
+    if (!vb.n) return;
+    const int gt = grid_stream(vb.n, 1);
 #define PCD_FIRST_LM(NC)                                                                       \
     hipLaunchKernelGGL((k_cheb_first_lm<NC>), dim3(gt), dim3(kBlock), 0, h->stream,           \
-                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,       \
+                       vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,     \
                        A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron), \
                        A.dghost.p ? A.dghost.p : dinv)
     if (A.kron == 2) PCD_FIRST_LM(2); else PCD_FIRST_LM(3);
 #undef PCD_FIRST_LM
-    return 0;
-  }
-  if (A.vt && kron_ok(A, b, p0, pn, nullptr, true)) {
-    const int gt = grid_stream(A.vt_blocks, 1);
-    const int nn = n / A.kron;
+  } else if (tile) {
+    const VtBlocks vb = vt_blocks_now(h, A);
+    if (!vb.n) return;
+    const int gt = grid_stream(vb.n, 1);
 #define PCD_FIRST_TC_(NC, NT, ROWS)                                                            \
     hipLaunchKernelGGL((k_cheb_first_tc<NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream, \
-                       A.vt_blocks, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,         \
+                       vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,       \
                        A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron), \
                        A.dghost.p ? A.dghost.p : dinv)
 #define PCD_FIRST_TC(NC, NT) do { if (A.vt_rows == 128) PCD_FIRST_TC_(NC, NT, 128); else PCD_FIRST_TC_(NC, NT, 64); } while (0)
@@ -888,16 +1012,26 @@ static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
     else { if (A.vt_staged) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
 #undef PCD_FIRST_TC
 #undef PCD_FIRST_TC_
-    return 0;
-  }
-  if (A.rb2 && kron_ok(A, b, p0, pn, nullptr, true)) {
+  } else if (A.rb2 && kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
                A.val2s.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron));
-    return 0;
+  } else {
+    LAUNCH_RB(A, k_cheb_first_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
+              A.vals.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)A.ncols);
   }
-  LAUNCH_RB(A, k_cheb_first_s, grid_stream(n, A.rb), n, A.rowptr.p, A.col.p,
-            A.vals.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)A.ncols);
+  };
+  if (tile && overlap_ok(h, A)) {
+    CHK(halo_send(h, A, b));               // (several ranks: the halo of b)
+    h->ov_phase = 1; run();
+    h->ov_phase = 0;
+    CHK(halo_wait(h, A));
+    h->ov_phase = 2; run();
+    h->ov_phase = 0;
+  } else {
+    CHK(halo_exchange(h, A, b));
+    run();
+  }
   return 0;
 }
 
@@ -1491,6 +1625,9 @@ static bool g_no_kron = false;         // PCD_NO_KRON2=1: A/B switch
 // After new values arrived: refresh F's values and verify that all
 // components still carry the same numbers; otherwise drop to the general path.
 static int refresh_kron(Engine* h, DCsr& A) {
+  if (A.rk && A.rk_nnz)          // row-blocked values follow `val`
+    hipLaunchKernelGGL(k_lm_values, dim3(grid1d(A.rk_nnz * A.rk, 4)), dim3(kBlock), 0, h->stream,
+                       A.rk_nnz * A.rk, A.rk_pos.p, A.val.p, A.rk_val.p);
   if (!A.kron_pat || !A.nnz2) return 0;
   HIPCHK(hipMemsetAsync(A.kron_flag.p, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(k_kron_gather, dim3(grid1d(A.nnz2, 4)), dim3(kBlock), 0,
@@ -1715,6 +1852,22 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
     CHK(A.vt_pos.ensure(lpos.size())); CHK(A.vt_val.ensure(lpos.size()));
     HIPCHK(hipMemcpy(A.vt_pos.p, lpos.data(), lpos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
+  {
+    // blocks that read a ghost column (tile source >= the owned nodes) last
+    std::vector<int> inner, outer;
+    for (size_t j = 0; j < desc.size(); ++j) {
+      const int tn = A.vt_lm ? (desc[j].w >> 9) & 0x7ff : desc[j].w >> 8;
+      // (tile sources ascend: the last one tells)
+      const bool bnd = tn > 0 && tsrc[(size_t)desc[j].z + tn - 1] >= nloc;
+      (bnd ? outer : inner).push_back((int)j);
+    }
+    A.vt_nint = (int)inner.size(); A.vt_nbnd = (int)outer.size();
+    if (A.vt_nbnd) {
+      inner.insert(inner.end(), outer.begin(), outer.end());
+      CHK(A.vt_list.ensure(inner.size()));
+      HIPCHK(hipMemcpy(A.vt_list.p, inner.data(), inner.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+  }
   CHK(A.vt_desc.ensure(desc.size())); CHK(A.vt_rowoff.ensure(rowoff.size()));
   CHK(A.vt_tsrc.ensure(tsrc.size())); CHK(A.vt_loc.ensure(loc.size() + 8));
   HIPCHK(hipMemcpy(A.vt_desc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -1789,6 +1942,63 @@ static int detect_kron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   return 0;
 }
 
+// ROW-blocked structure: the `nc` rows of every node (nc = velocity components)
+// carry the same columns - the discrete gradient A01 and nothing else on this
+// path.  PCD_NO_ROWKRON=1: A/B switch.
+static int detect_rowkron(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
+                          const int32_t* rowptr, const int32_t* col, bool have_vals) {
+  static const bool off = [] { const char* e = getenv("PCD_NO_ROWKRON"); return e && e[0] == '1'; }();
+  A.rk = 0; A.rk_rb = 0; A.rk_nnz = 0;
+  const int nc = h->vel_block == 3 ? 3 : 2;
+  // (rectangular operators from a few thousand rows; long rows / dense / F (x) I
+  // operators have kernels of their own)
+  if (off || A.kron || A.kron_pat || A.dense || A.long_rows || A.wave_rows || nrows == ncols ||
+      nrows < 3 * 1024 || nrows % nc || rowptr[nrows] % nc)
+    return 0;
+  const int64_t nn = nrows / nc;
+  std::atomic<bool> ok{true};
+  parallel_chunks(nn, [&](int64_t s0, int64_t s1) {
+    for (int64_t s = s0; s < s1 && ok.load(std::memory_order_relaxed); ++s) {
+      const int32_t a = rowptr[nc * s], len = rowptr[nc * s + 1] - a;
+      bool good = true;
+      for (int c = 1; c < nc && good; ++c)
+        good = rowptr[nc * s + c + 1] - rowptr[nc * s + c] == len &&
+               !memcmp(col + a, col + rowptr[nc * s + c], (size_t)len * sizeof(int32_t));
+      if (!good) ok.store(false, std::memory_order_relaxed);
+    }
+  });
+  if (!ok.load()) return 0;
+  std::vector<int32_t> rpc(nn + 1, 0);
+  for (int64_t s = 0; s < nn; ++s) rpc[s + 1] = rpc[s] + (rowptr[nc * s + 1] - rowptr[nc * s]);
+  const int rb = rb_for(nn, rpc.data(), nc == 3 ? tile_c<3>() : tile_c<2>());
+  if (!rb) return 0;
+  std::vector<int32_t> cc(rpc[nn]), pos((size_t)rpc[nn] * nc);
+  parallel_chunks(nn, [&](int64_t s0, int64_t s1) {
+    for (int64_t s = s0; s < s1; ++s) {
+      const int32_t len = rpc[s + 1] - rpc[s], o = rpc[s];
+      for (int32_t k = 0; k < len; ++k) {
+        cc[o + k] = col[rowptr[nc * s] + k];
+        for (int c = 0; c < nc; ++c) pos[(size_t)(o + k) * nc + c] = rowptr[nc * s + c] + k;
+      }
+    }
+  });
+  A.rk_nnz = rpc[nn];
+  CHK(A.rk_rowptr.ensure(nn + 1)); CHK(A.rk_col.ensure(A.rk_nnz)); CHK(A.rk_pos.ensure(pos.size()));
+  CHK(A.rk_val.ensure(pos.size() + 2));
+  HIPCHK(hipMemcpy(A.rk_rowptr.p, rpc.data(), (nn + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(A.rk_col.p, cc.data(), cc.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(A.rk_pos.p, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice));
+  A.rk = nc; A.rk_rb = rb;
+  // bytes one launch moves: (4 + 8 nc) per node-entry + the vectors
+  A.rk_nt = g_nt_bytes >= 0 &&
+            (4.0 + 8.0 * nc) * (double)A.rk_nnz + 16.0 * (double)nrows > (double)g_nt_bytes;
+  if (have_vals)
+    hipLaunchKernelGGL(k_lm_values, dim3(grid1d(A.rk_nnz * nc, 4)), dim3(kBlock), 0, h->stream,
+                       A.rk_nnz * nc, A.rk_pos.p, A.val.p, A.rk_val.p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
                       const int32_t* rowptr, const int32_t* col,
                       const double* val, const int64_t* src) {
@@ -1833,6 +2043,7 @@ static int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
   A.wave_rows = g_want_wave && !A.long_rows && nrows > 0 && nnz / nrows >= 96 &&
                 (nrows <= 3 * 8192 || nnz / nrows >= 300);
   CHK(detect_kron(h, A, nrows, ncols, rowptr, col, val != nullptr));
+  CHK(detect_rowkron(h, A, nrows, ncols, rowptr, col, val != nullptr));
   return 0;
 }
 
@@ -1900,6 +2111,10 @@ static int upload_owned(Engine* h, DCsr& A, const Space* rs, const Space* cs,
     HIPCHK(hipMemcpy(A.send_idx.p, plan.send_idx.data(), plan.send_idx.size() * sizeof(int),
                      hipMemcpyHostToDevice));
   if (A.ph.dev.seq) { (void)hipFree(A.ph.dev.seq); }
+  if (A.ph.owner) {
+    std::lock_guard<std::mutex> lk(peer_live_mu());
+    if (peer_live().count(A.ph.owner)) A.ph.owner->give_back(A.ph);
+  }
   A.ph = PeerHalo();
   if (h->comm->peer()) {
     // collective: landing buffers and flags of this halo in the peers' arenas
@@ -2239,6 +2454,9 @@ static int gather_block_values(Engine* h, DCsr& A, const double* dvals) {
   if (!A.nnz) return 0;
   hipLaunchKernelGGL(k_gather_vals, dim3(grid1d(A.nnz, 4)), dim3(kBlock), 0,
                      h->stream, A.nnz, A.src.p, dvals, A.val.p);
+  if (A.rk && A.rk_nnz)
+    hipLaunchKernelGGL(k_lm_values, dim3(grid1d(A.rk_nnz * A.rk, 4)), dim3(kBlock), 0, h->stream,
+                       A.rk_nnz * A.rk, A.rk_pos.p, A.val.p, A.rk_val.p);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -3152,6 +3370,36 @@ int pcd_fieldsplit_apply(pcd_handle h, const double* x, double* y, int mem) {
   return io_end(io);
 }
 
+// The dominant kernel where it runs: `reps` EAGER fieldsplit applies (device
+// vectors) with an event pair around every fused Chebyshev step on the finest
+// velocity operator - the caches in the state the multigrid cycle leaves them
+// in, where a back-to-back loop on one operator keeps them warm.  An event
+// pair adds about a microsecond of its own.
+int pcd_probe_a00_step(pcd_handle h, const double* x, double* y, int reps, double* us, int* launches) {
+  if (!h) return fail(PCD_ERR_ARG, "null handle");
+  if (!us || !launches || reps < 1) return fail(PCD_ERR_ARG, "probe_a00_step: bad arguments");
+  const bool graph = h->graph_on;
+  h->graph_on = false;
+  int rc = pcd_fieldsplit_apply(h, x, y, PCD_MEM_DEVICE);        // warm
+  h->probe_ev.clear();
+  h->probe_on = true;
+  for (int r = 0; r < reps && !rc; ++r) rc = pcd_fieldsplit_apply(h, x, y, PCD_MEM_DEVICE);
+  h->probe_on = false;
+  h->graph_on = graph;
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(PCD_ERR_HIP, "probe_a00_step: synchronize");
+  double sum = 0.0;
+  int cnt = 0;
+  for (size_t i = 0; i + 1 < h->probe_ev.size() && !rc; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->probe_ev[i], h->probe_ev[i + 1]) == hipSuccess) { sum += 1e3 * ms; ++cnt; }
+  }
+  for (hipEvent_t e : h->probe_ev) (void)hipEventDestroy(e);
+  h->probe_ev.clear();
+  *us = cnt ? sum / cnt : 0.0;
+  *launches = cnt;
+  return rc;
+}
+
 // sqrt(v.v) over all ranks; synchronises
 static int dev_norm(Engine* h, int64_t n, const double* v, double* out) {
   const int G = grid1d(n, 4, 512);
@@ -3421,6 +3669,9 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     }
     case PCD_INFO_PEER_CALLS:
       *out = (h->comm && h->comm->peer()) ? (double)static_cast<PeerBackend*>(h->comm)->peer_calls : 0.0;
+      return 0;
+    case PCD_INFO_PEER_DECLINED:
+      *out = (h->comm && h->comm->peer()) ? (double)static_cast<PeerBackend*>(h->comm)->declined : 0.0;
       return 0;
     case PCD_INFO_BOOT_CALLS:
       *out = (double)h->boot_exchanges +

@@ -512,6 +512,47 @@ __global__ __launch_bounds__(kBlock) void k_fe_robin_edges(
   loc[e] = m00; loc[(int64_t)nb + e] = m01; loc[(int64_t)2 * nb + e] = m01; loc[(int64_t)3 * nb + e] = m11;
 }
 
+// The same term in space: one thread per boundary FACE, the P2 wind from its
+// six nodes (three vertices, then the midpoints of the edges 01, 02, 12),
+// 6-point rule of degree 4 on the triangle (the integrand has degree 4), local
+// 3 x 3 matrix loc[(i*3+j)][f] = |f| sum_q w_q (w.n)(q) lam_i(q) lam_j(q).
+__global__ __launch_bounds__(kBlock) void k_fe_robin_faces(
+    int nb, const int* __restrict__ nodes, const double* __restrict__ normal,
+    const double* __restrict__ area, const double* __restrict__ U, double* loc) {
+  const int f = blockIdx.x * kBlock + threadIdx.x;
+  if (f >= nb) return;
+  const double qa[2] = {0.445948490915965, 0.091576213509771};
+  const double qw[2] = {0.223381589678011, 0.109951743655322};
+  double un[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int64_t node = nodes[(int64_t)k * nb + f];
+    un[k] = U[3 * node] * normal[f] + U[3 * node + 1] * normal[nb + f] + U[3 * node + 2] * normal[2 * (int64_t)nb + f];
+  }
+  double m[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m[i] = 0.0;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double L[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) L[i] = i == k ? 1.0 - 2.0 * qa[g] : qa[g];
+      const double wn = L[0] * (2 * L[0] - 1) * un[0] + L[1] * (2 * L[1] - 1) * un[1] +
+                        L[2] * (2 * L[2] - 1) * un[2] + 4 * L[0] * L[1] * un[3] +
+                        4 * L[0] * L[2] * un[4] + 4 * L[1] * L[2] * un[5];
+      const double w = qw[g] * wn * area[f];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m[i * 3 + j] += w * L[i] * L[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) loc[(int64_t)i * nb + f] = m[i];
+}
+
 // out[pos[i]] += vals[i]   (positions distinct)
 __global__ __launch_bounds__(kBlock) void k_fe_add_at(
     int n, const int* __restrict__ pos, const double* __restrict__ vals, double* out) {

@@ -574,8 +574,10 @@ int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const) {
   return 0;
 }
 
-// BRM2 boundary term of Kp on the device (2-D): per inflow edge the P2 nodes
-// [3][nb] (start, end, midpoint), outward normals [2][nb], lengths; the
+// BRM2 boundary term of Kp on the device: per inflow edge (2-D) the P2 nodes
+// [3][nb] (start, end, midpoint), outward normals [2][nb], lengths - per inflow
+// face (3-D) [6][nb] nodes (vertices, then midpoints of the edges 01, 02, 12),
+// [3][nb] normals, areas; the
 // affected entries of Kp: aff_pos[n_aff] (distinct positions), each the sum of
 // aff_w[t] * loc[aff_src[t]] over aff_ptr (loc = local 2 x 2 matrices stored
 // [(i*2+j)][edge]; the weights carry the factor -1/nu).
@@ -585,21 +587,23 @@ int pcd_fe_bind_robin(pcd_handle h, int64_t nb, const int32_t* nodes,
                       const int32_t* aff_src, const double* aff_w) {
   if (!h || !h->fe || !h->fe->kp_bound) return fail(PCD_ERR_STATE, "fe_bind_robin: bind Kp first");
   FeState& fe = *h->fe;
-  if (fe.dim != 2) return fail(PCD_ERR_ARG, "fe_bind_robin: the boundary term is implemented in 2-D");
   if (nb < 0 || n_aff < 0 || (nb && (!nodes || !normals || !lengths || !aff_pos || !aff_ptr || !aff_src || !aff_w)))
     return fail(PCD_ERR_ARG, "fe_bind_robin: bad arguments");
   for (int64_t i = 0; i < n_aff; ++i)
     if (aff_pos[i] < 0 || aff_pos[i] >= fe.nnz_kp) return fail(PCD_ERR_ARG, "fe_bind_robin: position outside Kp");
   HIPCHK(hipSetDevice(h->device));
   fe.rb_nb = nb; fe.rb_naff = n_aff;
-  CHK(fe_upload(fe.rb_nodes, nodes, (size_t)3 * nb));
-  CHK(fe_upload(fe.rb_normal, normals, (size_t)2 * nb));
+  // (3-D: six P2 nodes per boundary face, three normal components, `lengths`
+  // = areas, local 3 x 3 matrices)
+  const size_t nnode = fe.dim == 2 ? 3 : 6, nloc = fe.dim == 2 ? 4 : 9;
+  CHK(fe_upload(fe.rb_nodes, nodes, nnode * nb));
+  CHK(fe_upload(fe.rb_normal, normals, (size_t)fe.dim * nb));
   CHK(fe_upload(fe.rb_length, lengths, (size_t)nb));
   CHK(fe_upload(fe.rb_pos, aff_pos, (size_t)n_aff));
   CHK(fe_upload(fe.rb_ptr, aff_ptr, (size_t)n_aff + 1));
   CHK(fe_upload(fe.rb_src, aff_src, (size_t)(n_aff ? aff_ptr[n_aff] : 0)));
   CHK(fe_upload(fe.rb_w, aff_w, (size_t)(n_aff ? aff_ptr[n_aff] : 0)));
-  CHK(fe.rb_loc.ensure((size_t)4 * nb)); CHK(fe.rb_tmp.ensure((size_t)n_aff));
+  CHK(fe.rb_loc.ensure(nloc * nb)); CHK(fe.rb_tmp.ensure((size_t)n_aff));
   fe.robin_bound = true;
   return 0;
 }
@@ -752,8 +756,12 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
                        (const unsigned char*)nullptr, (double*)nullptr, fe.kp_vals.p,
                        (const double*)nullptr, (double*)nullptr);
     if (fe.robin_bound && fe.rb_nb) {
-      hipLaunchKernelGGL(k_fe_robin_edges, dim3(grid1d(fe.rb_nb)), dim3(kBlock), 0, h->stream, (int)fe.rb_nb,
-                         fe.rb_nodes.p, fe.rb_normal.p, fe.rb_length.p, Lt.U.p, fe.rb_loc.p);
+      if (fe.dim == 2)
+        hipLaunchKernelGGL(k_fe_robin_edges, dim3(grid1d(fe.rb_nb)), dim3(kBlock), 0, h->stream, (int)fe.rb_nb,
+                           fe.rb_nodes.p, fe.rb_normal.p, fe.rb_length.p, Lt.U.p, fe.rb_loc.p);
+      else
+        hipLaunchKernelGGL(k_fe_robin_faces, dim3(grid1d(fe.rb_nb)), dim3(kBlock), 0, h->stream, (int)fe.rb_nb,
+                           fe.rb_nodes.p, fe.rb_normal.p, fe.rb_length.p, Lt.U.p, fe.rb_loc.p);
       hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(fe.rb_naff)), dim3(kBlock), 0, h->stream, fe.rb_naff,
                          fe.rb_ptr.p, fe.rb_src.p, fe.rb_w.p, fe.rb_loc.p, fe.rb_tmp.p);
       hipLaunchKernelGGL(k_fe_add_at, dim3(grid1d(fe.rb_naff)), dim3(kBlock), 0, h->stream, (int)fe.rb_naff,

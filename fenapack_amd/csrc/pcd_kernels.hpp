@@ -822,6 +822,105 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sc(
   }
 }
 
+// ---- ROW-blocked operators: the NC rows of a node share one column pattern
+// (the discrete gradient A01 = B^T: rows = velocity components of a node,
+// columns = pressure dofs; [ext PETSc] MatMult(A01) of the fieldsplit apply,
+// field_split.py:54-57).  A scalar CSR kernel reads the column index once per
+// component - 36 B per node-entry in space, 24 in the plane; here the set-up
+// keeps the pattern once per NODE and the values node-entry-major
+// (val[k][NC]): 4 + 8 NC B per node-entry (28 / 20), one scalar gather of x
+// per node-entry instead of NC.  Same three phases as the stream kernels.
+template <int RB, int NC, bool NT>
+__device__ __forceinline__ VecC<NC> stream_row_block_rk(
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, const XVec& xf, int r0, int nrows,
+    VecC<NC>* lds) {
+  const int r1 = min(r0 + RB, nrows);
+  const int k0 = rowptr[r0], k1 = rowptr[r1];
+  constexpr int TPR = kBlock / RB;
+  const int row = r0 + threadIdx.x / TPR;
+  const int sub = threadIdx.x % TPR;
+  const bool mine = row < r1;
+  const int ra = mine ? rowptr[row] - k0 : 0;
+  const int rb = mine ? rowptr[row + 1] - k0 : 0;
+  VecC<NC> s = vzero<NC>();
+  constexpr int kTileC = tile_c<NC>();
+  constexpr int U = kUnroll / 2;            // (NC values per entry in flight)
+  double* planes = reinterpret_cast<double*>(lds);
+  for (int c0 = 0; c0 < k1 - k0; c0 += kTileC) {
+    const int c1 = min(c0 + kTileC, k1 - k0);
+    if (c0) __syncthreads();
+    for (int base = k0 + c0; base < k0 + c1; base += U * kBlock) {
+      int c[U];
+      double v[U][NC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = base + u * kBlock + threadIdx.x;
+        const bool in = k < k0 + c1;
+        c[u] = in ? stream_load<NT>(col + k) : -1;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          v[u][i] = in ? stream_load<NT>(val + (size_t)NC * k + i) : 0.0;
+      }
+      double xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = base + u * kBlock + threadIdx.x;
+        if (k < k0 + c1) {
+#pragma unroll
+          for (int i = 0; i < NC; ++i)
+            planes[i * kTileC + (k - k0 - c0)] = v[u][i] * xv[u];
+        }
+      }
+    }
+    __syncthreads();
+    const int lo = max(ra, c0), hi = min(rb, c1);
+    int j = ra + sub;
+    if (j < lo) j += (lo - j + TPR - 1) / TPR * TPR;
+    for (; j < hi; j += TPR) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) s.c[i] += planes[i * kTileC + (j - c0)];
+    }
+  }
+#pragma unroll
+  for (int m = TPR / 2; m > 0; m >>= 1) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s.c[i] += __shfl_xor(s.c[i], m);
+  }
+  return s;
+}
+
+template <int RB, int MODE, int NC, bool NT = false>
+__global__ __launch_bounds__(kBlock) void k_spmv_rk(
+    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const double* __restrict__ val, XVec xf, const double* add_, double* y_) {
+  __shared__ VecC<NC> lds[tile_c<NC>()];
+  const VecC<NC>* add = vc<NC>(add_);
+  VecC<NC>* y = vc<NC>(y_);
+  const int nrb = (nrows + RB - 1) / RB;
+  int rb0, rb1;
+  row_block_range(nrb, RB, rb0, rb1, xcd_remap_always<NC, NT>(nrows));
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int r0 = rb * RB;
+    const int row = r0 + threadIdx.x / (kBlock / RB);
+    const bool mine = threadIdx.x % (kBlock / RB) == 0 && row < nrows;
+    VecC<NC> a = vzero<NC>();
+    if ((MODE == 1 || MODE == 2) && mine) a = add[row];
+    const VecC<NC> s = stream_row_block_rk<RB, NC, NT>(rowptr, col, val, xf, r0, nrows, lds);
+    if (mine) {
+      VecC<NC> o;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        o.c[i] = MODE == 0 ? s.c[i] : (MODE == 1 ? a.c[i] + s.c[i]
+                                        : (MODE == 2 ? a.c[i] - s.c[i] : -s.c[i]));
+      y[row] = o;
+    }
+    __syncthreads();
+  }
+}
+
 template <int RB, int NC, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_cheb_step_sc(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -1163,8 +1262,12 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   __shared__ __attribute__((aligned(16))) double ev[NT ? vt_entries(NC) + 2 * PCD_VT_WIDE : 1]; \
   __shared__ __attribute__((aligned(16))) unsigned short el[NT ? vt_entries(NC) + 4 * PCD_VT_WIDE : 1]
 
+// (`blist`: the blocks to run, or null = all of them - several ranks with
+// PCD_OVERLAP=1 run the blocks that read no ghost column while the halo is
+// on its way and the others after it has landed)
 #define PCD_VT_ARGS                                                                   \
-  int nblocks, const int4* __restrict__ desc, const unsigned short* __restrict__ rowoff, \
+  int nblocks, const int* __restrict__ blist, const int4* __restrict__ desc,          \
+  const unsigned short* __restrict__ rowoff,                                          \
   const int* __restrict__ tsrc, const double* __restrict__ val,                        \
   const unsigned short* __restrict__ loc
 
@@ -1177,7 +1280,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tc(
   VecC<NC>* y = vc<NC>(y_);
   int b0, b1;
   row_block_range(nblocks, ROWS, b0, b1, true);
-  for (int blk = b0; blk < b1; ++blk) {
+  for (int bq = b0; bq < b1; ++bq) {
+    const int blk = blist ? blist[bq] : bq;
     const int4 d = desc[blk];
     const int lr = threadIdx.x / (kBlock / ROWS);
     const int row = d.x + lr;
@@ -1208,7 +1312,8 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
   VecC<NC>* pn = vc<NC>(pn_);
   int b0, b1;
   row_block_range(nblocks, ROWS, b0, b1, true);
-  for (int blk = b0; blk < b1; ++blk) {
+  for (int bq = b0; bq < b1; ++bq) {
+    const int blk = blist ? blist[bq] : bq;
     const int4 d4 = desc[blk];
     const int lr = threadIdx.x / (kBlock / ROWS);
     const int row = d4.x + lr;
@@ -1240,7 +1345,8 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   int b0, b1;
   row_block_range(nblocks, ROWS, b0, b1, true);
-  for (int blk = b0; blk < b1; ++blk) {
+  for (int bq = b0; bq < b1; ++bq) {
+    const int blk = blist ? blist[bq] : bq;
     const int4 d4 = desc[blk];
     const int lr = threadIdx.x / (kBlock / ROWS);
     const int row = d4.x + lr;
@@ -1290,7 +1396,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
 // Two barriers per block, LDS per entry 8 NC B read.
 // ==========================================================================
 #ifndef PCD_LM_NODES3
-#define PCD_LM_NODES3 768
+#define PCD_LM_NODES3 512
 #endif
 #ifndef PCD_LM_NODES2
 #define PCD_LM_NODES2 768
@@ -1299,13 +1405,13 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
 #define PCD_LM_ROWS3 64
 #endif
 #ifndef PCD_LM_ROWS2
-#define PCD_LM_ROWS2 128
+#define PCD_LM_ROWS2 160
 #endif
 constexpr int kLmE = 8;                              // entries per lane
 constexpr int kLmEntries = kLmE * kBlock;            // entries per block
 constexpr int lm_nodes(int nc) { return nc == 3 ? PCD_LM_NODES3 : PCD_LM_NODES2; }
 constexpr int lm_rows(int nc) { return nc == 3 ? PCD_LM_ROWS3 : PCD_LM_ROWS2; }
-static_assert(lm_nodes(2) % kBlock == 0 && lm_nodes(3) % kBlock == 0, "one lane per tile node, whole passes");
+static_assert(lm_nodes(2) % 64 == 0 && lm_nodes(3) % 64 == 0, "tile nodes: whole waves");
 static_assert(lm_nodes(2) <= 2048 && lm_nodes(3) <= 2048, "11-bit tile slots");
 static_assert(lm_rows(2) <= 256 && lm_rows(3) <= 256, "one lane per row, 8-bit first rows");
 // descriptor: x = first row, y = lanes of all blocks before this one (its
@@ -1317,39 +1423,82 @@ static_assert(lm_rows(2) <= 256 && lm_rows(3) <= 256, "one lane per row, 8-bit f
   __shared__ double lmR[NC * lm_rows(NC)];                  \
   __shared__ double lmT[NC * kBlock]
 
+// The epilogue's vector operands (b, D^-1, p_{k-1}; the result) are read /
+// written once per launch as well.  While the five vectors of a step fit the
+// Infinity Cache next to the gathered tile they are better kept (cube N = 48,
+// 22 MB each: 76.7 us with default-policy accesses, 81.4 non-temporal; cavity
+// level 7 53.1 / 58.9); beyond it (cube N = 73, 76 MB each) they only push the
+// tile's lines out: 313.5 -> 285.6 us non-temporal (profiles/r05_d_*).  The
+// host decides per operator (`epi_nt`).  Index streams (tile sources, row
+// offsets) non-temporal: no gain at any size (PCD_LM_NT_IDX, A/B).
+#ifndef PCD_LM_NT_IDX
+#define PCD_LM_NT_IDX 0
+#endif
+template <class T>
+__device__ __forceinline__ T lm_idx_load(const T* p) {
+  if (PCD_LM_NT_IDX) return __builtin_nontemporal_load(p);
+  return *p;
+}
 template <int NC>
-__device__ __forceinline__ VecC<NC> lm_row_block(
-    const int4 d, const unsigned short* __restrict__ rowoff, int blk,
-    const int* __restrict__ tsrc, const double* __restrict__ val,
-    const unsigned short* __restrict__ loc, const double* x,
-    const double* ghost, int nloc, double* tile, double* lmR, double* lmT,
-    const double* xscale = nullptr, const double* gscale = nullptr) {
-  constexpr int TN = lm_nodes(NC), RM = lm_rows(NC), RO = vt_rowoff(RM);
+__device__ __forceinline__ VecC<NC> lm_epi_load(const VecC<NC>* p, bool nt) {
+  if (!nt) return *p;
+  VecC<NC> r;
+  const double* q = reinterpret_cast<const double*>(p);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) r.c[i] = __builtin_nontemporal_load(q + i);
+  return r;
+}
+template <int NC>
+__device__ __forceinline__ void lm_epi_store(VecC<NC>* p, const VecC<NC>& v, bool nt) {
+  if (!nt) { *p = v; return; }
+  double* q = reinterpret_cast<double*>(p);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) __builtin_nontemporal_store(v.c[i], q + i);
+}
+
+template <int NC>
+struct LmRegs {
   typedef double dv2 __attribute__((ext_vector_type(2)));
   typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+  dv2 ve[kLmE / 2];
+  uv4 le;
+  int ra, rb;
+  bool act;
+};
+
+// entries -> registers, vector tile -> LDS, barrier
+template <int NC>
+__device__ __forceinline__ void lm_stage(
+    LmRegs<NC>& g, const int4 d, const unsigned short* __restrict__ rowoff, int blk,
+    const int* __restrict__ tsrc, const double* __restrict__ val,
+    const unsigned short* __restrict__ loc, const double* x,
+    const double* ghost, int nloc, double* tile,
+    const double* xscale = nullptr, const double* gscale = nullptr) {
+  constexpr int TN = lm_nodes(NC), RO = vt_rowoff(lm_rows(NC));
+  typedef typename LmRegs<NC>::dv2 dv2;
+  typedef typename LmRegs<NC>::uv4 uv4;
   const int t = threadIdx.x;
   const int nr = d.w & 0x1ff, tn = (d.w >> 9) & 0x7ff, L = (d.w >> 20) & 0x1ff;
   // the matrix stream: addresses known with the descriptor
-  const bool act = t < L;
+  g.act = t < L;
   const dv2* vb = reinterpret_cast<const dv2*>(val) + (size_t)d.y * (kLmE / 2);
-  dv2 ve[kLmE / 2];
 #pragma unroll
   for (int k = 0; k < kLmE / 2; ++k)
-    ve[k] = act ? __builtin_nontemporal_load(vb + k * L + t) : dv2(0.0);
-  uv4 le = uv4(0u);
-  if (act) le = __builtin_nontemporal_load(reinterpret_cast<const uv4*>(loc) + d.y + t);
+    g.ve[k] = g.act ? __builtin_nontemporal_load(vb + k * L + t) : dv2(0.0);
+  g.le = uv4(0u);
+  if (g.act) g.le = __builtin_nontemporal_load(reinterpret_cast<const uv4*>(loc) + d.y + t);
   // entries [ra, rb) of the row whose sum this lane completes
-  const bool mine = t < nr;
-  const int ra = mine ? rowoff[blk * RO + t] : 0;
-  const int rb = mine ? rowoff[blk * RO + t + 1] : 0;
-  int node[TN / kBlock];
+  g.ra = t < nr ? lm_idx_load(rowoff + blk * RO + t) : 0;
+  g.rb = t < nr ? lm_idx_load(rowoff + blk * RO + t + 1) : 0;
+  constexpr int NP = (TN + kBlock - 1) / kBlock;      // passes over the tile
+  int node[NP];
 #pragma unroll
-  for (int u = 0; u < TN / kBlock; ++u) {
+  for (int u = 0; u < NP; ++u) {
     const int q = t + u * kBlock;
-    node[u] = q < tn ? tsrc[d.z + q] : -1;
+    node[u] = q < tn ? lm_idx_load(tsrc + d.z + q) : -1;
   }
 #pragma unroll
-  for (int u = 0; u < TN / kBlock; ++u) {
+  for (int u = 0; u < NP; ++u) {
     if (node[u] < 0) continue;
     const bool own = node[u] < nloc;
     const double* src = own ? x + (size_t)NC * node[u] : ghost + (size_t)NC * (node[u] - nloc);
@@ -1363,13 +1512,21 @@ __device__ __forceinline__ VecC<NC> lm_row_block(
     for (int i = 0; i < NC; ++i) tile[i * TN + t + u * kBlock] = v.c[i];
   }
   __syncthreads();
-  if (act) {
-    int cur = ((le.x >> 11) & 0xf) | (((le.x >> 27) & 0xf) << 4);
+}
+
+// lane sums, barrier, row sums (valid on the lanes t < rows of the block)
+template <int NC>
+__device__ __forceinline__ VecC<NC> lm_sum(const LmRegs<NC>& g, const double* tile,
+                                           double* lmR, double* lmT) {
+  constexpr int TN = lm_nodes(NC), RM = lm_rows(NC);
+  const int t = threadIdx.x;
+  if (g.act) {
+    int cur = ((g.le.x >> 11) & 0xf) | (((g.le.x >> 27) & 0xf) << 4);
     VecC<NC> s = vzero<NC>();
 #pragma unroll
     for (int u = 0; u < kLmE; ++u) {
-      const unsigned w = u & 1 ? le[u >> 1] >> 16 : le[u >> 1] & 0xffffu;
-      const double vv = u & 1 ? ve[u >> 1].y : ve[u >> 1].x;
+      const unsigned w = u & 1 ? g.le[u >> 1] >> 16 : g.le[u >> 1] & 0xffffu;
+      const double vv = u & 1 ? g.ve[u >> 1].y : g.ve[u >> 1].x;
       const int oo = w & 0x7ff;
 #pragma unroll
       for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * TN + oo];
@@ -1384,8 +1541,8 @@ __device__ __forceinline__ VecC<NC> lm_row_block(
   }
   __syncthreads();
   VecC<NC> sum = vzero<NC>();
-  if (mine && rb > ra) {
-    const int la = ra / kLmE, lb = (rb - 1) / kLmE;
+  if (g.rb > g.ra) {
+    const int la = g.ra / kLmE, lb = (g.rb - 1) / kLmE;
     for (int q = la; q < lb; ++q) {
 #pragma unroll
       for (int i = 0; i < NC; ++i) sum.c[i] += lmT[i * kBlock + q];
@@ -1396,8 +1553,23 @@ __device__ __forceinline__ VecC<NC> lm_row_block(
   return sum;
 }
 
+// epilogue operands requested with the block's first loads (0) or after its
+// first barrier, when the tile's registers are free again (1)
+#ifndef PCD_LM_LATE_EPI
+#define PCD_LM_LATE_EPI 1
+#endif
+// waves per SIMD the register allocation aims at (0: the compiler's choice)
+#ifndef PCD_LM_WAVES
+#define PCD_LM_WAVES 0
+#endif
+#if PCD_LM_WAVES
+#define PCD_LM_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PCD_LM_WAVES, PCD_LM_WAVES)))
+#else
+#define PCD_LM_BOUNDS __launch_bounds__(kBlock)
+#endif
+
 template <int MODE, int NC>
-__global__ __launch_bounds__(kBlock) void k_spmv_lm(
+__global__ PCD_LM_BOUNDS void k_spmv_lm(
     PCD_VT_ARGS, const double* x, const double* ghost, int nloc, const double* add_,
     double* y_) {
   PCD_LM_SHARED(NC);
@@ -1405,13 +1577,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv_lm(
   VecC<NC>* y = vc<NC>(y_);
   int b0, b1;
   row_block_range(nblocks, lm_rows(NC), b0, b1, true);
-  for (int blk = b0; blk < b1; ++blk) {
+  for (int bq = b0; bq < b1; ++bq) {
+    const int blk = blist ? blist[bq] : bq;
     const int4 d = desc[blk];
     const int row = d.x + threadIdx.x;
     const bool mine = (int)threadIdx.x < (d.w & 0x1ff);
     VecC<NC> a = vzero<NC>();
-    if ((MODE == 1 || MODE == 2) && mine) a = add[row];
-    const VecC<NC> s = lm_row_block<NC>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile, lmR, lmT);
+    LmRegs<NC> g;
+    if (!PCD_LM_LATE_EPI && (MODE == 1 || MODE == 2) && mine) a = add[row];
+    lm_stage<NC>(g, d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile);
+    if (PCD_LM_LATE_EPI && (MODE == 1 || MODE == 2) && mine) a = add[row];
+    const VecC<NC> s = lm_sum<NC>(g, tile, lmR, lmT);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -1424,38 +1600,46 @@ __global__ __launch_bounds__(kBlock) void k_spmv_lm(
 }
 
 template <int NC>
-__global__ __launch_bounds__(kBlock) void k_cheb_step_lm(
+__global__ PCD_LM_BOUNDS void k_cheb_step_lm(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, const double* pm_,
     const double* pk_, double* pn_, double c0, double c1, double c2,
-    const double* ghost, int nloc) {
+    const double* ghost, int nloc, int epi_nt) {
   PCD_LM_SHARED(NC);
+  const bool nt = epi_nt != 0;
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_), *pm = vc<NC>(pm_),
                *pk = vc<NC>(pk_);
   VecC<NC>* pn = vc<NC>(pn_);
   int b0, b1;
   row_block_range(nblocks, lm_rows(NC), b0, b1, true);
-  for (int blk = b0; blk < b1; ++blk) {
+  for (int bq = b0; bq < b1; ++bq) {
+    const int blk = blist ? blist[bq] : bq;
     const int4 d4 = desc[blk];
     const int row = d4.x + threadIdx.x;
     const bool mine = (int)threadIdx.x < (d4.w & 0x1ff);
     VecC<NC> bi = vzero<NC>(), d = bi, xk = bi, xm = bi;
-    if (mine) {
-      bi = b[row]; d = dinv[row]; xk = pk[row];
-      if (c0 != 0.0) xm = pm[row];
+    LmRegs<NC> g;
+    if (!PCD_LM_LATE_EPI && mine) {
+      bi = lm_epi_load<NC>(b + row, nt); d = lm_epi_load<NC>(dinv + row, nt); xk = pk[row];
+      if (c0 != 0.0) xm = lm_epi_load<NC>(pm + row, nt);
     }
-    const VecC<NC> s = lm_row_block<NC>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile, lmR, lmT);
+    lm_stage<NC>(g, d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile);
+    if (PCD_LM_LATE_EPI && mine) {
+      bi = lm_epi_load<NC>(b + row, nt); d = lm_epi_load<NC>(dinv + row, nt); xk = pk[row];
+      if (c0 != 0.0) xm = lm_epi_load<NC>(pm + row, nt);
+    }
+    const VecC<NC> s = lm_sum<NC>(g, tile, lmR, lmT);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
       for (int i = 0; i < NC; ++i)
         o.c[i] = c0 * xm.c[i] + c1 * xk.c[i] + c2 * d.c[i] * (bi.c[i] - s.c[i]);
-      pn[row] = o;
+      lm_epi_store<NC>(pn + row, o, nt);
     }
   }
 }
 
 template <int NC>
-__global__ __launch_bounds__(kBlock) void k_cheb_first_lm(
+__global__ PCD_LM_BOUNDS void k_cheb_first_lm(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, double* p0_,
     double* pn_, double s, double c1, double c2, const double* ghost, int nloc,
     const double* __restrict__ dghost) {
@@ -1464,14 +1648,19 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_lm(
   VecC<NC>*p0 = vc<NC>(p0_), *pn = vc<NC>(pn_);
   int b0, b1;
   row_block_range(nblocks, lm_rows(NC), b0, b1, true);
-  for (int blk = b0; blk < b1; ++blk) {
+  for (int bq = b0; bq < b1; ++bq) {
+    const int blk = blist ? blist[bq] : bq;
     const int4 d4 = desc[blk];
     const int row = d4.x + threadIdx.x;
     const bool mine = (int)threadIdx.x < (d4.w & 0x1ff);
     VecC<NC> d = vzero<NC>(), bi = d;
-    if (mine) { d = dinv[row]; bi = b[row]; }
-    const VecC<NC> sum = lm_row_block<NC>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, lmR, lmT,
-                                          dinv_, dghost);
+    LmRegs<NC> g;
+    if (!PCD_LM_LATE_EPI && mine) { d = dinv[row]; bi = b[row]; }
+    // (the tile holds D^-1 b - b with its halo when there are several ranks,
+    // the reciprocal diagonal of the ghost columns kept from its own exchange)
+    lm_stage<NC>(g, d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, dinv_, dghost);
+    if (PCD_LM_LATE_EPI && mine) { d = dinv[row]; bi = b[row]; }
+    const VecC<NC> sum = lm_sum<NC>(g, tile, lmR, lmT);
     if (mine) {
       VecC<NC> x0, o;
 #pragma unroll

@@ -42,6 +42,9 @@
 #pragma once
 #include "pcd_dist.hpp"
 
+#include <set>
+#include <utility>
+
 namespace pcd {
 
 constexpr int kPeerMaxPeers = 16;
@@ -89,6 +92,60 @@ __global__ __launch_bounds__(kBlock) void k_halo_xchg(PeerHaloDev d, const doubl
     // bounded by the wall clock (s_memrealtime, 100 MHz); sticky: once a wait
     // gave up, later ones do not spin - one time-out per failure, not one per
     // exchange
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(d.lflag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq_now) {
+      if (*(volatile int*)d.err) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > spin_limit) { *d.err = 1; break; }
+    }
+  }
+  __syncthreads();
+  for (int e = blockIdx.x * kBlock + threadIdx.x; e < d.nrecv; e += gridDim.x * kBlock) {
+    int q = 0;
+    while (e >= d.recv_off[q + 1]) ++q;
+    const int cnt = d.recv_off[q + 1] - d.recv_off[q];
+    d.ghost[e] = __hip_atomic_load(&d.land[q][p * cnt + (e - d.recv_off[q])], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&d.ctr[1], 1u) == gridDim.x - 1) {
+    d.ctr[1] = 0;
+    *d.seq = seq_now;
+  }
+}
+
+// The same exchange in two kernels, for consumers that compute the rows
+// needing no ghost column in between (PCD_OVERLAP=1): k_halo_send packs,
+// stores into the neighbours' landing buffers and signals; k_halo_wait waits
+// for the neighbours' signals, lands the data in the ghost segment and
+// advances the sequence number.  Both read *d.seq before anyone advances it
+// (same stream, in order), so they agree on the exchange's number.
+__global__ __launch_bounds__(kBlock) void k_halo_send(PeerHaloDev d, const double* x) {
+  __shared__ int s_last;
+  const unsigned long long seq_now = *d.seq + 1;
+  const size_t p = (size_t)(seq_now & 1);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.nsend; i += gridDim.x * kBlock) {
+    int q = 0;
+    while (i >= d.send_off[q + 1]) ++q;
+    const int cnt = d.send_off[q + 1] - d.send_off[q];
+    d.dst[q][p * cnt + (i - d.send_off[q])] = x[d.send_idx[i]];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&d.ctr[0], 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (s_last) {                                        // every workgroup's data is out
+    __threadfence_system();
+    if ((int)threadIdx.x < d.nsp)
+      __hip_atomic_store(d.rflag[threadIdx.x], seq_now, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) d.ctr[0] = 0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_halo_wait(PeerHaloDev d, long long spin_limit) {
+  const unsigned long long seq_now = *d.seq + 1;
+  const size_t p = (size_t)(seq_now & 1);
+  if ((int)threadIdx.x < d.nrp) {
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(d.lflag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq_now) {
       if (*(volatile int*)d.err) break;
@@ -167,11 +224,20 @@ __global__ __launch_bounds__(kBlock) void k_peer_allreduce(PeerReduceDev d, doub
 }
 
 // host side of one halo channel
+struct PeerBackend;
 struct PeerHalo {
   bool ready = false;
   PeerHaloDev dev;
   int grid = 1;
+  // what the channel holds of its rank's arena (offset, bytes): handed back
+  // when the operator is released (peer_give_back)
+  PeerBackend* owner = nullptr;
+  std::vector<std::pair<size_t, size_t>> takes;
 };
+// backends alive in this process: an operator may outlive the communicator it
+// registered its halo with (pcd_comm_init on an engine that holds operators)
+inline std::mutex& peer_live_mu() { static std::mutex m; return m; }
+inline std::set<PeerBackend*>& peer_live() { static std::set<PeerBackend*> s; return s; }
 
 struct PeerBackend : CommBackend {
   CommBackend* boot = nullptr;              // RCCL / thread group: set-up and bulk
@@ -186,8 +252,19 @@ struct PeerBackend : CommBackend {
   bool process_mode = false;
   long boot_calls = 0;                      // hot-path calls that went to the bootstrap backend
   long peer_calls = 0;                      // exchanges / reductions issued as kernels of the stream
+  long declined = 0;                        // halo channels that did not fit an arena (bootstrap path instead)
+  std::vector<std::pair<size_t, size_t>> freed;   // (offset, bytes) handed back by released operators
+  std::vector<std::pair<size_t, size_t>> taking;  // ... taken by the registration in progress
 
+  PeerBackend() {
+    std::lock_guard<std::mutex> lk(peer_live_mu());
+    peer_live().insert(this);
+  }
   ~PeerBackend() override {
+    {
+      std::lock_guard<std::mutex> lk(peer_live_mu());
+      peer_live().erase(this);
+    }
     for (void* p : opened) (void)hipIpcCloseMemHandle(p);
     if (arena) (void)hipFree(arena);
     if (dseq) (void)hipFree(dseq);
@@ -201,12 +278,30 @@ struct PeerBackend : CommBackend {
     return 1;
   }
   // sub-allocation (256-byte granules); 0 when the arena is full
+  // A region handed back by a released operator is used again for a request
+  // of the same size (a hierarchy pushed again after a pattern change asks
+  // for the sizes it asked for before); its flags start from zero like fresh
+  // arena memory - zeroed here, before the registration's collective steps
+  // tell any peer where the region is.
   char* take(size_t bytes) {
     const size_t b = (bytes + 255) / 256 * 256;
+    for (size_t i = 0; i < freed.size(); ++i)
+      if (freed[i].second == b && b) {
+        char* p = arena + freed[i].first;
+        if (hipMemset(p, 0, b) != hipSuccess) return nullptr;
+        taking.push_back(freed[i]);
+        freed.erase(freed.begin() + (long)i);
+        return p;
+      }
     if (used + b > cap) return nullptr;
     char* p = arena + used;
     used += b;
+    if (b) taking.push_back({(size_t)(p - arena), b});
     return p;
+  }
+  void give_back(PeerHalo& ph) {
+    for (auto& t : ph.takes) freed.push_back(t);
+    ph.takes.clear(); ph.owner = nullptr;
   }
   char* remote(int r, const char* mine_off_base, size_t off) const {
     (void)mine_off_base;
@@ -330,7 +425,7 @@ struct PeerBackend : CommBackend {
     const int nsp = (int)pl.peers_send.size(), nrp = (int)pl.peers_recv.size();
     bool fits = nsp <= kPeerMaxPeers && nrp <= kPeerMaxPeers;
     std::vector<size_t> land_off(nrp, 0), flag_off(nrp, 0);
-    const size_t used0 = used;
+    taking.clear();
     for (int j = 0; j < nrp && fits; ++j) {
       const size_t cnt = (size_t)(pl.recv_off[j + 1] - pl.recv_off[j]);
       char* l = take(2 * cnt * sizeof(double));
@@ -352,7 +447,19 @@ struct PeerBackend : CommBackend {
     if (!bad) bad = fail(hipStreamSynchronize(s), "sync");
     (void)hipFree(dok);
     if (bad) return 1;
-    if (ok != 0.0) { used = used0; if (seq) (void)hipFree(seq); return 0; }   // nobody registers
+    if (ok != 0.0) {                                   // nobody registers
+      for (auto& t : taking) freed.push_back(t);
+      taking.clear();
+      if (seq) (void)hipFree(seq);
+      ++declined;
+      if (getenv("PCD_COMM_VERBOSE"))
+        fprintf(stderr, "[pcd comm] rank %d: a halo channel does not fit the peer arena (%zu of %zu bytes "
+                        "in use, PCD_PEER_ARENA_MB): its exchanges take the bootstrap path\n",
+                rank, used, cap);
+      return 0;
+    }
+    ph.owner = this;
+    ph.takes.swap(taking);
     std::vector<double> out(2 * (size_t)std::max(nrp, 1)), in(2 * (size_t)std::max(nsp, 1));
     for (int j = 0; j < nrp; ++j) { out[2 * j] = (double)land_off[j]; out[2 * j + 1] = (double)flag_off[j]; }
     double *dout = nullptr, *din = nullptr;
@@ -399,6 +506,15 @@ struct PeerBackend : CommBackend {
     ++peer_calls;
     hipLaunchKernelGGL(k_halo_xchg, dim3(ph.grid), dim3(kBlock), 0, s, ph.dev, x, spin_limit);
     return fail(hipGetLastError(), "k_halo_xchg");
+  }
+  int halo_send(const PeerHalo& ph, const double* x, hipStream_t s) {
+    ++peer_calls;
+    hipLaunchKernelGGL(k_halo_send, dim3(ph.grid), dim3(kBlock), 0, s, ph.dev, x);
+    return fail(hipGetLastError(), "k_halo_send");
+  }
+  int halo_wait(const PeerHalo& ph, hipStream_t s) {
+    hipLaunchKernelGGL(k_halo_wait, dim3(ph.grid), dim3(kBlock), 0, s, ph.dev, spin_limit);
+    return fail(hipGetLastError(), "k_halo_wait");
   }
   // a wait gave up since the last call?  (host synchronisation points)
   int take_error(hipStream_t s) {

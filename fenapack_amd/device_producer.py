@@ -129,7 +129,8 @@ def coupled_pattern(indptr_f, indices_f, n, d):
 
 #: refuse Galerkin plans beyond this many (entry, weight) pairs: the lists are
 #: built with numpy temporaries several times their size
-MAX_GALERKIN_PAIRS = 400_000_000
+MAX_GALERKIN_PAIRS = int(os.environ.get("FENAPACK_AMD_MAX_GALERKIN_PAIRS",
+                                        "1000000000"))
 
 
 def galerkin_plan(rows_f, cols_f, P):
@@ -190,12 +191,26 @@ class DeviceProducer(object):
             raise ValueError("device producer: the velocity solve must be "
                              "-fieldsplit_u_pc_type mg (its smoother bounds "
                              "are re-estimated on the device)")
-        if ksp0.pc.mg_algebraic:
-            raise ValueError("device producer: needs the nested-mesh "
-                             "hierarchy (-fieldsplit_u_pc_type mg); an "
-                             "algebraic hierarchy (gamg) is refreshed by the "
-                             "host path")
-        self.galerkin = bool(ksp0.pc.mg_galerkin)
+        # -pc_type gamg: the aggregation - hence every prolongator and every
+        # coarse PATTERN - is fixed across the nonlinear iterations (built
+        # once from the first operator, fenapack_amd/amg.py); only the values
+        # of the Galerkin products change.  The finest level is assembled from
+        # the mesh like any other, the levels below it are the weighted-gather
+        # products of pcd_fe_set_level_galerkin with the smoothed-aggregation
+        # prolongators in place of the nested meshes' ones: what the reference
+        # re-does through hypre's set-up every outer iteration
+        # (demo_navier-stokes-pcd.py:153-160) happens in HBM.
+        self.algebraic = bool(ksp0.pc.mg_algebraic)
+        if self.algebraic and self.newton:
+            raise ValueError("device producer: the algebraic hierarchy "
+                             "aggregates the scalar stencil F of the Picard "
+                             "block F (x) I_d; --nls newton needs the "
+                             "nested-mesh hierarchy")
+        if self.algebraic and self.ranks:
+            raise ValueError("device producer: an algebraic hierarchy on "
+                             "several ranks is refreshed by the partitioned "
+                             "host producer (amg.PartitionedSA)")
+        self.galerkin = bool(ksp0.pc.mg_galerkin) or self.algebraic
         self.supg = bool(pb.stabilize)
         if self.supg and self.galerkin:
             raise ValueError("device producer: the SUPG preconditioner "
@@ -208,7 +223,7 @@ class DeviceProducer(object):
         self.levels = []                       # host problems, coarsest first
         for l in range(nlev):
             lh = top_h - (nlev - 1) + l
-            if lh == top_h:
+            if l == nlev - 1:
                 self.levels.append(pb)
             elif self.galerkin:
                 self.levels.append(None)       # no mesh data on these levels
@@ -221,13 +236,18 @@ class DeviceProducer(object):
         dphi = self._dphi(V)
         qw = V.wq[0] / V.area[0]
         eng.fe_begin(d, nlev, qw, V.phi, dphi, V.psi)
-        chain = pb.interpolations().velocity if nlev > 1 else None
+        chain = pb.interpolations().velocity \
+            if nlev > 1 and not self.algebraic else None
         self._pat = [None] * nlev       # (indptr, indices, n) of scalar F_l
         for l in range(nlev - 1, -1, -1):
             pl = self.levels[l]
             lh = top_h - (nlev - 1) + l
             if l == nlev - 1:
                 self._set_level(l, pl, None)
+            elif self.algebraic:
+                # (mg_data["chain"][l + 1]: level l -> l + 1 of the hierarchy
+                # the engine holds, after the choice of the coarsest level)
+                self._set_level_galerkin(l, ksp0.pc.mg_data["chain"][l + 1])
             elif self.galerkin:
                 self._set_level_galerkin(l, chain[lh + 1])
             else:
@@ -399,10 +419,11 @@ class DeviceProducer(object):
             pl = V.robin_plan(pb.robin_edges)
             nb = pl["length"].size
             pd = pl["pdofs"]
-            rows = np.repeat(pd[:, :, None], 2, axis=2).ravel()
-            cols = np.repeat(pd[:, None, :], 2, axis=1).ravel()
+            k = pd.shape[1]             # pressure dofs per facet: 2 (edge), 3 (face)
+            rows = np.repeat(pd[:, :, None], k, axis=2).ravel()
+            cols = np.repeat(pd[:, None, :], k, axis=1).ravel()
             where = pat.locate(rows, cols)           # (e, i, j) -> Kp entry
-            e_idx, ij = np.divmod(np.arange(where.size), 4)
+            e_idx, ij = np.divmod(np.arange(where.size), k * k)
             aff_pos, _, aff_ptr, order = _group(
                 where, np.zeros_like(where), pat.nnz, 1)
             self.eng.fe_bind_robin(pl["nodes"].T, pl["normal"].T,

@@ -207,7 +207,14 @@ class TetMesh(object):
             fkey = (faces[:, 0] * nv + faces[:, 1]) * nv + faces[:, 2]
             uf, first, cnt = np.unique(fkey, return_index=True,
                                        return_counts=True)
-        bfaces = faces[first[cnt == 1]]
+        bfirst = np.sort(first[cnt == 1])
+        bfaces = faces[bfirst]
+        # boundary facets (sorted vertex triples), the cell each belongs to and
+        # that cell's vertex opposite the facet (it lies inside: outward
+        # normals of the boundary integrals, TaylorHood.robin_plan)
+        self.boundary_faces = bfaces
+        self.boundary_face_cells = bfirst // 4
+        self.boundary_face_opposite = cells[bfirst // 4, bfirst % 4]
         self.boundary_vertices = np.unique(bfaces)
         bpairs = np.sort(np.concatenate([bfaces[:, [0, 1]], bfaces[:, [0, 2]],
                                          bfaces[:, [1, 2]]]), axis=1)
@@ -229,6 +236,19 @@ class TetMesh(object):
     def edge_midpoints(self):
         return 0.5 * (self.vertices[self.edges[:, 0]]
                       + self.vertices[self.edges[:, 1]])
+
+    def edge_index(self, a, b):
+        """Index in ``edges`` of the edges joining vertices ``a`` and ``b``
+        (arrays; ``edges`` is sorted by (first, second) vertex)."""
+        nv = self.num_vertices
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        key = self.edges[:, 0] * nv + self.edges[:, 1]
+        idx = np.searchsorted(key, lo * nv + hi)
+        assert np.array_equal(key[idx], lo * nv + hi), "not edges of this mesh"
+        return idx
+
+    def boundary_face_centroids(self):
+        return self.vertices[self.boundary_faces].mean(axis=1)
 
 
 def unit_cube_mesh(n):

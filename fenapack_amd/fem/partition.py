@@ -255,6 +255,27 @@ class SubSpace(object):
     def local_edges(self, gedges):
         return self._find(self.edges_g, gedges)
 
+    def local_facets(self, gfacets):
+        """Boundary facets of the global mesh (2-D: edge numbers; 3-D: rows of
+        ``boundary_faces``) that belong to cells of this sub-mesh, as facets of
+        the sub-mesh."""
+        m, sub = self.Vg.mesh, self.V.mesh
+        if m.dim != 3:
+            return self.local_edges(gfacets)
+        tri = m.boundary_faces[np.asarray(gfacets, dtype=np.int64)]
+        pos = np.searchsorted(self.vg, tri)
+        pos[pos == self.vg.size] = 0
+        lt = pos[(self.vg[pos] == tri).all(axis=1)]      # (monotone map: still sorted triples)
+        nv = sub.num_vertices
+        key = (lt[:, 0] * nv + lt[:, 1]) * nv + lt[:, 2]
+        bf = sub.boundary_faces
+        bkey = (bf[:, 0] * nv + bf[:, 1]) * nv + bf[:, 2]
+        order = np.argsort(bkey)
+        idx = np.searchsorted(bkey[order], key)
+        idx[idx == bkey.size] = 0
+        ok = bkey[order][idx] == key if bkey.size else np.zeros(key.size, bool)
+        return order[idx[ok]]
+
 
 class _RowLift(object):
     """Owned rows of local matrices -> global-shaped, row-sparse CSR.  The

@@ -153,7 +153,7 @@ class FlowProblem(object):
         self.bc_p_val = np.asarray(G.bc_p_val)[keep]
         for name in ("robin_edges", "inlet_edges", "outlet_edges"):
             if hasattr(G, name):
-                setattr(self, name, sub.local_edges(getattr(G, name)))
+                setattr(self, name, sub.local_facets(getattr(G, name)))
 
     def interpolations(self):
         """Prolongation chains for the multigrid inner solves (lazy)."""
@@ -388,4 +388,68 @@ class Cavity3D(FlowProblem):
             & (xyz[:, 0] > eps) & (xyz[:, 0] < 1 - eps) \
             & (xyz[:, 1] > eps) & (xyz[:, 1] < 1 - eps)
         val[lid, 0] = 1.0
+        return val.ravel()
+
+
+class Channel3D(FlowProblem):
+    """Square duct on the unit cube: inflow through ``x = 0`` (marker 1),
+    do-nothing outflow through ``x = 1`` (marker 2), no-slip walls - the
+    reference demo's in/outflow set-up (demo_navier-stokes-pcd.py:56-87) in
+    three dimensions, where its forms are dimension-free: BRM1 pins the
+    pressure operators on the inlet, BRM2 on the outlet and adds the Robin
+    term ``-(1/nu) (u.n) p q ds(1)`` to ``kp`` (:131-135).  Kuhn triangulation
+    of ``n0 * 2**level`` cubes per side."""
+
+    def __init__(self, level, nu=0.02, n0=2, **kw):
+        self.level, self.n0 = level, n0
+        FlowProblem.__init__(self, CubeHierarchy(n0, level), nu, **kw)
+
+    def _same_problem_on_level(self, level):
+        kw = dict(nu=self.nu, variant=self.variant, nls=self.nls,
+                  pcdr=self.pcdr, n0=self.n0,
+                  stabilize=self.stabilize or self.coarse_stabilize)
+        if self.idt:
+            kw["dt"] = 1.0 / self.idt
+        return Channel3D(level, **kw)
+
+    def _face_nodes_u(self, faces):
+        """P2 nodes (vertices and edge midpoints) of the given boundary faces."""
+        V, m = self.space, self.space.mesh
+        fv = m.boundary_faces[faces]
+        e = np.concatenate([m.edge_index(fv[:, 0], fv[:, 1]),
+                            m.edge_index(fv[:, 0], fv[:, 2]),
+                            m.edge_index(fv[:, 1], fv[:, 2])])
+        return np.unique(np.concatenate([V._rank[fv.ravel()],
+                                         V._rank[V.nv + e]]))
+
+    def _classify_boundary(self):
+        V, m = self.space, self.space.mesh
+        cx = m.boundary_face_centroids()[:, 0]
+        allf = np.arange(m.boundary_faces.shape[0])
+        inlet, outlet = allf[np.abs(cx) < 1e-12], allf[np.abs(cx - 1.0) < 1e-12]
+        walls = np.setdiff1d(allf, np.concatenate([inlet, outlet]))
+        self.inlet_edges, self.outlet_edges = inlet, outlet      # (boundary FACES in 3-D)
+        self.robin_edges = inlet                                 # ds(1)
+        # (bc0 on the walls first, bc1 on the inlet last: demo :68-71)
+        wall_nodes, inlet_nodes = self._face_nodes_u(walls), self._face_nodes_u(inlet)
+        nodes = np.union1d(wall_nodes, inlet_nodes)
+        self._bc_nodes = nodes
+        self._inlet_nodes = np.setdiff1d(inlet_nodes, wall_nodes)   # (the rim is wall: no-slip)
+        self.bc_u_idx = self._velocity_dofs(nodes)
+        pe = inlet if self.variant == "BRM1" else outlet
+        self.bc_p_idx = np.unique(V._pnum[m.boundary_faces[pe].ravel()])
+        self.bc_p_val = np.zeros(self.bc_p_idx.size)
+
+    def inflow_scale(self, t):
+        if self.idt:
+            return 1.0 - np.exp(-5.0 * t)
+        return 1.0
+
+    def bc_u_values(self, t):
+        V = self.space
+        nodes = self._bc_nodes
+        val = np.zeros((nodes.size, 3))
+        is_in = np.isin(nodes, self._inlet_nodes)
+        y, z = V.node_coords[nodes[is_in], 1], V.node_coords[nodes[is_in], 2]
+        val[is_in, 0] = self.inflow_scale(t) * 16.0 * y * (1 - y) * z * (1 - z)
         return val.ravel()

@@ -41,6 +41,13 @@ _QW2 = np.array([0.225] + [0.132394152788506] * 3 + [0.125939180544827] * 3)
 # 3-point Gauss rule on [0, 1] (degree 5) for boundary integrals
 _G3X = 0.5 + 0.5 * np.array([-np.sqrt(0.6), 0.0, np.sqrt(0.6)])
 _G3W = 0.5 * np.array([5 / 9., 8 / 9., 5 / 9.])
+# triangle, degree 4 (6 points; weights sum to 1): the facet integrand
+# (P2 wind) x (P1) x (P1) of the 3-D Robin term has degree 4
+_T6A = (0.445948490915965, 0.091576213509771)
+_T6W = (0.223381589678011, 0.109951743655322)
+_T6L = np.array([[1 - 2 * a if i == k else a for i in range(3)]
+                 for a in _T6A for k in range(3)])               # (6, 3) barycentric
+_T6Wq = np.repeat(np.array(_T6W), 3)                            # (6,)
 
 
 def _tet_rule(n=3):
@@ -794,15 +801,38 @@ class TaylorHood(object):
         return K
 
     def robin_plan(self, edges):
-        """Geometry of the boundary integral over ``edges`` (2D): P2 nodes
-        (start, end, midpoint), outward unit normals, lengths, pressure dofs
-        of the end points."""
-        if self.dim != 2:
-            raise NotImplementedError("Robin boundary term: 2D only")
+        """Geometry of the boundary integral over ``edges``: P2 nodes (2D:
+        start, end, midpoint of each boundary edge), outward unit normals,
+        lengths, pressure dofs of the end points; 3D: boundary faces, below."""
         key = ("_robin", tuple(np.asarray(edges).tolist()))
         if getattr(self, "_robin_cache", (None,))[0] == key:
             return self._robin_cache[1]
         m = self.mesh
+        if self.dim == 3:
+            # ``edges`` index the mesh's boundary FACES: P2 nodes (three
+            # vertices, then the midpoints of the edges 01, 02, 12), outward
+            # unit normals, areas ("length"), pressure dofs of the vertices.
+            # The form is the reference's, dimension-free:
+            # demo_navier-stokes-pcd.py:131-135
+            faces = np.asarray(edges)
+            fv = m.boundary_faces[faces]                            # (nb,3)
+            a, b, c = (m.vertices[fv[:, k]] for k in range(3))
+            cr = np.cross(b - a, c - a)
+            twice = np.linalg.norm(cr, axis=1)
+            n = cr / twice[:, None]
+            inward = m.vertices[m.boundary_face_opposite[faces]] - a
+            n = n * np.where((inward * n).sum(axis=1) > 0, -1.0, 1.0)[:, None]
+            r = self._rank
+            e01 = m.edge_index(fv[:, 0], fv[:, 1])
+            e02 = m.edge_index(fv[:, 0], fv[:, 2])
+            e12 = m.edge_index(fv[:, 1], fv[:, 2])
+            nodes = np.stack([r[fv[:, 0]], r[fv[:, 1]], r[fv[:, 2]],
+                              r[self.nv + e01], r[self.nv + e02],
+                              r[self.nv + e12]], axis=1)
+            plan = {"nodes": nodes, "normal": n, "length": 0.5 * twice,
+                    "pdofs": self._pnum[fv]}
+            self._robin_cache = (key, plan)
+            return plan
         edges = np.asarray(edges)
         ev = m.edges[edges]                                     # (nb,2)
         a, b = m.vertices[ev[:, 0]], m.vertices[ev[:, 1]]
@@ -832,6 +862,25 @@ class TaylorHood(object):
         pl = self.robin_plan(edges)
         pat = self._patterns(False)["PP"]
         n, length, nodes = pl["normal"], pl["length"], pl["nodes"]
+        if self.dim == 3:
+            # facets are triangles: P2 wind from its six facet nodes, P1 test
+            # and trial functions = the barycentric coordinates
+            L = _T6L                                             # (q, 3)
+            phi = np.concatenate([L * (2 * L - 1),
+                                  4 * np.stack([L[:, 0] * L[:, 1],
+                                                L[:, 0] * L[:, 2],
+                                                L[:, 1] * L[:, 2]], axis=1)],
+                                 axis=1)                         # (q, 6)
+            un = (U[nodes] * n[:, None, :]).sum(axis=2)          # (nb, 6)
+            wn = un @ phi.T                                      # (nb, q)
+            loc = np.einsum('q,eq,qi,qj->eij', _T6Wq, wn, L, L) \
+                * length[:, None, None]
+            pd = pl["pdofs"]                                     # (nb,3)
+            rows = np.repeat(pd[:, :, None], 3, axis=2).ravel()
+            cols = np.repeat(pd[:, None, :], 3, axis=1).ravel()
+            data = np.bincount(pat.locate(rows, cols), weights=loc.ravel(),
+                               minlength=pat.nnz)
+            return pat.matrix(data)
         # P2 wind along the edge: endpoints + midpoint dofs
         Ua, Ub, Um = U[nodes[:, 0]], U[nodes[:, 1]], U[nodes[:, 2]]
         s = _G3X

@@ -99,6 +99,9 @@ enum pcd_info {
   PCD_INFO_PEER_CALLS = 65,  /* halo exchanges / all-reduces issued as kernels of the
                               * stream (peer protocol), so far */
   PCD_INFO_BOOT_CALLS = 66,  /* ... and those that went through RCCL / the host transport */
+  PCD_INFO_PEER_DECLINED = 68, /* halo channels that did not fit the peer arena
+                              * (PCD_PEER_ARENA_MB): their exchanges take the bootstrap
+                              * path and a PCApply that holds one is not graph-captured */
   PCD_INFO_A00_MODEL_BYTES = 67  /* bytes one launch of the fused Chebyshev step on the velocity
                                   * block moves BY CONSTRUCTION with the kernel in force (matrix
                                   * stream + tile sources / row pointers + five vector streams);
@@ -335,6 +338,15 @@ int pcd_synchronize(pcd_handle h);
 /* capture the fixed-iteration fieldsplit apply into a hipGraph and replay it
  * (launch-bound at the 2D sizes: SURVEY 7, hard part 3); 0 = eager launches */
 int pcd_graph_enable(pcd_handle h, int on);
+/* Measurement aid of bench.py: the dominant kernel - the fused
+ * Chebyshev-Jacobi step on the finest velocity operator, [ext PETSc]
+ * KSPCHEBYSHEV + PCJACOBI inside the A00 solve of field_split.py:96-100 - timed
+ * WHERE IT RUNS: `reps` eager fieldsplit applies on device vectors x, y with an
+ * event pair around every such launch; *us = mean microseconds per launch,
+ * *launches = launches timed.  (A back-to-back loop on one operator keeps the
+ * caches warm; inside the multigrid cycle the coarser levels have used them.) */
+int pcd_probe_a00_step(pcd_handle h, const double* x, double* y, int reps,
+                       double* us, int* launches);
 /* Streaming bandwidth of this GPU measured by a kernel of this library
  * (16 B per lane, unit stride): kind 0 copy, 1 triad, 2 read-only sweep,
  * 3 read-mostly (6 % writes: the mix of the dominant kernel), 4 read-only
@@ -504,7 +516,11 @@ int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const);
  * normals[2][nb], lengths[nb]; aff_pos[n_aff] = the distinct entries of Kp
  * it touches, entry i += sum_t aff_w[t] * loc[aff_src[t]], t in
  * aff_ptr[i]..aff_ptr[i+1], loc = the local 2 x 2 edge matrices stored
- * [(i*2+j)][edge]; aff_w carries -1/nu.                                      */
+ * [(i*2+j)][edge]; aff_w carries -1/nu.  In space (three velocity components)
+ * the facets are the inflow FACES: nodes[6][nb] (three vertices, then the
+ * midpoints of the edges 01, 02, 12), normals[3][nb], lengths = areas, loc =
+ * local 3 x 3 matrices [(i*3+j)][face] - the reference's form is
+ * dimension-free.                                                            */
 int pcd_fe_bind_robin(pcd_handle h, int64_t nb, const int32_t* nodes,
                       const double* normals, const double* lengths,
                       int64_t n_aff, const int32_t* aff_pos,

@@ -8,12 +8,9 @@ import pytest
 # BLAS calls, and OpenBLAS's default pool (one thread per core of a 256-thread
 # host) costs each of them ~100 x its work (fenapack_amd.limit_blas_threads)
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
-# Thread ranks that use the peer-write protocol (tests/test_peer_gpu.py) run
-# kernels that wait for another rank's kernel: both must be in flight at once.
-# The streams of one process are multiplexed onto GPU_MAX_HW_QUEUES hardware
-# queues (default 4), and two rank streams in one queue serialise.  Read by
-# the HIP runtime when it initialises, i.e. after this line.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES is NOT set here: the suite runs with the queue count the
+# product runs with; the one opt-in test that needs eight hardware queues
+# starts a process of its own, tests/test_peer_gpu.py)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -106,6 +103,12 @@ def _suite_budgets(request):
     if node.get_closest_marker("heavy") is not None:
         limit = float(os.environ.get("FENAPACK_AMD_SUITE_BUDGET_S", "1000"))
         used = time.time() - _SESSION_T0
+        if used > limit and os.environ.get("FENAPACK_AMD_SUITE_STRICT", "1") == "0":
+            # (FENAPACK_AMD_SUITE_STRICT=0: a visible skip instead - for a
+            # session under `-x` on a slow host that should still report the
+            # tests that did run)
+            pytest.skip("suite time budget: %.0f s of %.0f s used before this "
+                        "full-size test could start" % (used, limit))
         if used > limit:
             pytest.fail("suite time budget: %.0f s of %.0f s used before this "
                         "full-size test could start (the suite must fit the "

@@ -108,3 +108,12 @@ def push_multigrid(e, slot, A, chain, nu=2, ratio=0.1, cycles=1):
                        chain[l], *bounds[l])
     e.set_inner(slot, "richardson", "mg", cycles, 0.0)
     return ops, bounds, C
+
+
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the multi-process
+    tests: a fixed number can be taken on a shared host)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

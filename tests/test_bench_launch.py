@@ -14,6 +14,8 @@ import sys
 
 import pytest
 
+from helpers import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -46,7 +48,7 @@ def test_bench_under_an_external_launcher():
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
          "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", "29637", BENCH, "--gpus", "2", "--steps", "2",
+         "--master-port", str(free_port()), BENCH, "--gpus", "2", "--steps", "2",
          "--warmup", "0", "--stub-step"], env=_env(), capture_output=True,
         text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]

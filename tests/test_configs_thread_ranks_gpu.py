@@ -4,7 +4,7 @@ a ``torch.distributed.run --nproc-per-node R`` start minus RCCL itself, which
 refuses two ranks on one device; real ranks: test_two_gpus.py).
 
 * config 4: unsteady demo, L-shape level 4, dt 0.2, 100 time steps, device
-  producer - on 1, 2 and 4 ranks: identical Picard counts, Krylov totals that
+  producer - on 1, 2 and 4 ranks (all three in this suite): identical Picard counts, Krylov totals that
   agree to a handful of iterations (round-off of the partitioned reductions),
   replicas identical.  Round 2's one-off run (tools/unsteady_thread_ranks.py,
   profiles/r02_ae_*): 13339 / 13340 / 13340 Krylov iterations, 421 Picard
@@ -62,16 +62,15 @@ def replicate_below(monkeypatch):
 
 @pytest.mark.heavy(4)
 @pytest.mark.timeout(900)
-def test_config4_unsteady_100_steps_on_1_and_2_ranks(hip_lib, replicate_below):
+def test_config4_unsteady_100_steps_on_1_2_and_4_ranks(hip_lib, replicate_below):
     """BASELINE config 4 as it is stated: the unsteady demo, 100 time steps,
-    row-partitioned - the FULL 100 steps on one rank and on two thread ranks
-    (R thread ranks share ONE GPU: a run costs R times the replicated device
-    work).  Identical Picard counts, Krylov totals that agree to a handful of
-    iterations (round-off of the partitioned reductions), replicas identical.
-    Four ranks (the other half of config 4) run the same code path with more
-    neighbours: tools/unsteady_thread_ranks.py, repeated every round
-    (profiles/r03_i_unsteady_level4_100steps_thread_ranks.jsonl: 13339 /
-    13340 / 13340 Krylov iterations on 1 / 2 / 4 ranks)."""
+    row-partitioned over 2 and 4 ranks - the FULL 100 steps on one rank, on
+    two and on four thread ranks (R thread ranks share ONE GPU: a run costs R
+    times the replicated device work).  Identical Picard counts, Krylov totals
+    that agree to a handful of iterations (round-off of the partitioned
+    reductions), replicas identical.  (Round 3's one-off run,
+    profiles/r03_i_unsteady_level4_100steps_thread_ranks.jsonl: 13339 / 13340 /
+    13340 Krylov iterations on 1 / 2 / 4 ranks.)"""
     # partitioned finest levels, replicated coarse ones - as on real ranks; the
     # default limit (60000 rows) would replicate everything at this size
     replicate_below(2000)
@@ -98,13 +97,17 @@ def test_config4_unsteady_100_steps_on_1_and_2_ranks(hip_lib, replicate_below):
     # round 2's totals (13339 Krylov / 421 Picard iterations); the producer's
     # element matrices changed by round-off since: a small band
     assert abs(one["krylov"] - 13339) <= 70 and abs(one["picard"] - 421) <= 2
-    runs = _on_ranks(2, solver(100))
-    for r in runs:                              # every replica
-        assert r["steps"] == 100 and r["picard"] == one["picard"]
-        assert abs(r["krylov"] - one["krylov"]) <= 20, (r["krylov"],
-                                                        one["krylov"])
-    assert len({r["krylov"] for r in runs}) == 1
-    assert len({round(r["checksum"], 6) for r in runs}) == 1
+    for R in (2, 4):
+        runs = _on_ranks(R, solver(100))
+        for r in runs:                              # every replica
+            assert r["steps"] == 100 and r["picard"] == one["picard"], R
+            assert abs(r["krylov"] - one["krylov"]) <= 20, (R, r["krylov"],
+                                                            one["krylov"])
+        assert len({r["krylov"] for r in runs}) == 1
+        assert len({round(r["checksum"], 6) for r in runs}) == 1
+        print("config 4, %d ranks: %d Krylov / %d Picard iterations (one rank: "
+              "%d / %d)" % (R, runs[0]["krylov"], runs[0]["picard"],
+                            one["krylov"], one["picard"]))
     PETScOptions.clear()
 
 

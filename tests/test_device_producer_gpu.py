@@ -88,6 +88,74 @@ def test_operators_and_residual_match_the_host_producer(hip_lib, kind,
         assert 0.0 < emin < emax < 1e3
 
 
+def _gamg_options(dim, coarse_limit=None):
+    PETScOptions.clear()
+    multigrid_inner_options(dim=dim, algebraic=True)
+    if coarse_limit is not None:
+        PETScOptions.set("fieldsplit_u_pc_mg_coarse_eq_limit", coarse_limit)
+
+
+@pytest.mark.parametrize("kind,limit", [("cavity", 100), ("cube", 60)])
+def test_algebraic_hierarchy_is_refreshed_on_the_device(hip_lib, kind, limit):
+    """-pc_type gamg: the aggregation is fixed across the nonlinear
+    iterations, so every coarse pattern is; the device producer assembles the
+    finest level from the mesh and takes the coarse operators as Galerkin
+    products with the smoothed-aggregation prolongators (gather plans) - what
+    the host refresh computes (amg / galerkin_chain) and the reference leaves
+    to hypre's set-up per outer iteration (demo_navier-stokes-pcd.py:153-160;
+    assembling.py:98-106).  Operators of every level against the host's
+    products at 1e-12."""
+    import scipy.sparse.linalg as spla
+    from fenapack_amd.fem.multigrid import galerkin_chain
+    pb = Cavity(4, nu=0.01) if kind == "cavity" else Cavity3D(1, nu=0.02, n0=6)
+    V = pb.space
+    _gamg_options(V.dim, coarse_limit=limit)
+    out = solve_steady_device(pb, max_newton=1)
+    prod = out["producer"]
+    assert prod.algebraic and prod.device_loop and prod.nlev >= 3, prod.nlev
+    rng = np.random.default_rng(7)
+    xu, xp = rng.standard_normal(V.n_u), rng.standard_normal(V.n_p)
+    b = prod.update(xu, xp)
+    lin = pb.linearise(xu, xp)
+    assert relerr(b, V.to_mixed(lin["bu"], lin["bp"])) < 1e-12
+    A00 = prod.level_matrix(prod.nlev - 1)
+    assert relerr(A00.data, lin["A00"].data) < 1e-13
+    ksp0 = out["solver"].linear_solver().ksp().pc.getFieldSplitSubKSP()[0]
+    assert ksp0.pc.mg_algebraic
+    coarse = galerkin_chain(lin["A00"], ksp0.pc.mg_data["chain"])[:-1]
+    assert len(coarse) == prod.nlev - 1
+    for l, ref in enumerate(coarse):
+        ref = ref.tocsr()
+        got = prod.level_matrix(l)
+        assert got.shape == ref.shape and got.nnz >= ref.nnz
+        assert spla.norm(got - ref) < 1e-12 * spla.norm(ref), l
+    for l in range(1, prod.nlev):
+        emin, emax = out["solver"].linear_solver().ksp().engine.fe_bounds(l)
+        assert 0.0 < emin < emax < 1e3
+
+
+@pytest.mark.parametrize("kind", ["cavity", "cube"])
+def test_picard_solve_with_algebraic_hierarchy_on_the_device(hip_lib, kind):
+    """... and the whole Picard loop: the same nonlinear history and Krylov
+    counts as the host-driven solve that refreshes the hierarchy on the host."""
+    mk = (lambda: Cavity(4, nu=0.01)) if kind == "cavity" \
+        else (lambda: Cavity3D(1, nu=0.02, n0=6))
+    outs = []
+    for fn in (solve_steady, solve_steady_device):
+        pb = mk()
+        _gamg_options(pb.space.dim, coarse_limit=100)
+        outs.append(fn(pb, max_newton=8))
+    ref, out = outs
+    assert out["producer"].algebraic
+    assert out["converged"] and ref["converged"]
+    assert out["newton_its"] == ref["newton_its"]
+    for a, b in zip(out["krylov_per_step"], ref["krylov_per_step"]):
+        assert abs(a - b) <= max(1, 0.05 * b), \
+            (out["krylov_per_step"], ref["krylov_per_step"])
+    assert relerr(out["w"].vector(), ref["w"].vector()) < 1e-5
+    PETScOptions.clear()
+
+
 @pytest.mark.parametrize("galerkin", [False, True])
 @pytest.mark.parametrize("kind,kw", [("cavity", {}), ("lshape", {}),
                                       ("cube", {})])
@@ -450,6 +518,37 @@ def test_brm2_boundary_term_of_kp_on_the_device(hip_lib):
     for fn in (solve_steady, solve_steady_device):
         pb2 = BackwardStep(3, nu=0.02, variant="BRM2")
         _options(2, galerkin=True)
+        outs.append(fn(pb2, max_newton=6))
+    ref, dev = outs
+    assert dev["newton_its"] == ref["newton_its"]
+    for i, j in zip(dev["krylov_per_step"], ref["krylov_per_step"]):
+        assert abs(i - j) <= max(1, 0.1 * j)       # (smoother bounds differ)
+    assert relerr(dev["w"].vector(), ref["w"].vector()) < 1e-5
+
+
+def test_brm2_boundary_term_in_space_on_the_device(hip_lib):
+    """The same term on a 3-D duct (inflow through a face of the cube): the
+    reference's form is dimension-free; k_fe_robin_faces assembles it from the
+    six P2 nodes of every inflow face, the Picard loop stays on the device."""
+    from fenapack_amd.fem import Channel3D
+    pb = Channel3D(1, nu=0.02, n0=4, variant="BRM2")
+    assert len(pb.robin_edges) == 2 * 8 * 8
+    V = pb.space
+    _options(3, galerkin=True)
+    out = solve_steady_device(pb, max_newton=1)
+    prod = out["producer"]
+    assert prod.device_loop
+    rng = np.random.default_rng(13)
+    xu, xp = rng.standard_normal(V.n_u), rng.standard_normal(V.n_p)
+    prod.update(xu, xp)
+    ref = pb.Kp(xu)
+    plain = V.assemble_Kp(pb.nu, pb.nodal_velocity(xu))
+    assert relerr(ref.data, plain.data) > 1e-3          # the term is there
+    assert relerr(prod.kp_matrix().data, ref.data) < 1e-13
+    outs = []
+    for fn in (solve_steady, solve_steady_device):
+        pb2 = Channel3D(1, nu=0.02, n0=4, variant="BRM2")
+        _options(3, galerkin=True)
         outs.append(fn(pb2, max_newton=6))
     ref, dev = outs
     assert dev["newton_its"] == ref["newton_its"]

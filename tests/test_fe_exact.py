@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle.fe_exact import element_matrices
-from fenapack_amd.fem import Cavity, Cavity3D, BackwardStep
+from fenapack_amd.fem import Cavity, Cavity3D, BackwardStep, Channel3D
 
 
 @pytest.mark.parametrize("make", [lambda: Cavity(1), lambda: BackwardStep(1),
@@ -87,3 +87,60 @@ def test_pattern_of_distinct_entries_matches_the_general_constructor():
     with pytest.raises(ValueError):
         FixedPattern.from_unique(np.r_[rows, rows[:1]], np.r_[cols, cols[:1]],
                                  (n, m))
+
+
+def test_robin_term_in_space_is_exact():
+    """BRM2's boundary term of Kp, ``int_inflow (w.n) p q ds``
+    (demo_navier-stokes-pcd.py:131-135), over the inflow FACES of a 3-D duct:
+    with a wind in P2 and hat functions p, q the integrand has degree 4 and
+    the 6-point facet rule integrates it exactly - checked against integrals
+    over the unit square taken by hand."""
+    pb = Channel3D(1, nu=0.02, n0=2, variant="BRM2")
+    V, m = pb.space, pb.space.mesh
+    assert V.dim == 3 and len(pb.robin_edges) == 2 * 4 * 4
+    pl = V.robin_plan(pb.robin_edges)
+    assert np.allclose(pl["normal"], [-1.0, 0.0, 0.0])           # outward at x = 0
+    assert abs(pl["length"].sum() - 1.0) < 1e-14                  # the inflow face
+    xyz, pc = V.node_coords, V.p_coords
+    one = np.ones(V.n_p)
+    # constant wind
+    U = np.tile(np.array([2.0, 0.5, -0.3]), (V.nn, 1))
+    R = V._boundary_flux_mass(U, pb.robin_edges)
+    assert abs(one @ (R @ one) + 2.0) < 1e-13
+    # quadratic wind w_x = y^2 + y z + 1 (in P2), tangential part ignored
+    U = np.zeros((V.nn, 3))
+    U[:, 0] = xyz[:, 1] ** 2 + xyz[:, 1] * xyz[:, 2] + 1.0
+    U[:, 1] = 3.0
+    R = V._boundary_flux_mass(U, pb.robin_edges)
+    assert abs(one @ (R @ one) + 19.0 / 12.0) < 1e-13
+    # p = y, q = z:  -int (y^2 + y z + 1) y z  over the unit square
+    assert abs(pc[:, 2] @ (R @ pc[:, 1]) + (1 / 8. + 1 / 9. + 1 / 4.)) < 1e-13
+    assert abs((R - R.T)).max() < 1e-15
+    # rows of dofs off the inflow face are empty
+    off = np.abs(pc[:, 0]) > 1e-12
+    assert np.abs(R[off]).sum() == 0.0
+    # ... and Kp carries it with the factor -1/nu
+    K0 = V.assemble_Kp(pb.nu, U)
+    K1 = V.assemble_Kp(pb.nu, U, robin_edges=pb.robin_edges)
+    assert np.abs((K0 - K1) - R / pb.nu).max() < 1e-12
+
+
+def test_channel_in_space_boundary_sets():
+    """Inflow face ds(1), outflow face ds(2), walls no-slip; BRM1 pins the
+    pressure operators on the inlet, BRM2 on the outlet
+    (demo_navier-stokes-pcd.py:56-87, 138-141)."""
+    for variant, x0 in (("BRM1", 0.0), ("BRM2", 1.0)):
+        pb = Channel3D(1, nu=0.02, n0=2, variant=variant)
+        V = pb.space
+        assert np.allclose(V.p_coords[pb.bc_p_idx, 0], x0)
+        assert pb.bc_p_idx.size == 25
+        g = pb.bc_u_values(0.0).reshape(-1, 3)
+        xyz = V.node_coords[pb._bc_nodes]
+        assert np.all(g[:, 1:] == 0.0)
+        inflow = g[:, 0] > 0
+        assert inflow.any() and np.allclose(xyz[inflow, 0], 0.0)
+        # the outflow face's interior carries no Dirichlet value
+        out_int = (np.abs(V.node_coords[:, 0] - 1) < 1e-12) \
+            & (np.abs(V.node_coords[:, 1] - 0.5) < 0.49) \
+            & (np.abs(V.node_coords[:, 2] - 0.5) < 0.49)
+        assert not np.isin(np.nonzero(out_int)[0], pb._bc_nodes).any()

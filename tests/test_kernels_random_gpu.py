@@ -52,8 +52,8 @@ def test_spmv_random_shapes(hip_lib, n, m, avg, long_rows):
 def _tile_form(monkeypatch, form):
     """``0``: stream kernels; ``2``: the LDS-staged vector-tile kernels
     (k_*_tc) on every F (x) I operator, whatever its size, direct form;
-    ``2staged``: their staged form (what operators beyond the Infinity Cache
-    get: matrix entries through LDS with non-temporal loads)."""
+    ``2staged``: the form operators beyond the Infinity Cache get - matrix
+    entries lane-major, straight to registers (k_*_lm)."""
     monkeypatch.setenv("PCD_VEC_TILE", form[0])
     if form == "2staged":
         monkeypatch.setenv("PCD_NT_BYTES", "0")
@@ -87,6 +87,43 @@ def test_multi_component_operators_and_near_misses(hip_lib, monkeypatch, nodes,
     for M in variants:
         e = c.Engine(hip_lib, "BRM1", 0)
         e.set_csr(c.MAT_A01, M)
+        assert relerr(e.spmv_np(c.MAT_A01, x, M.shape[0]), M @ x) < 1e-13
+
+
+@pytest.mark.parametrize("nc", [2, 3])
+@pytest.mark.parametrize("nodes,m,avg,nt", [(1100, 400, 5, False),
+                                            (4000, 1500, 14, False),
+                                            (4000, 1500, 14, True),
+                                            (1700, 9000, 300, False)])
+def test_row_blocked_operators_and_near_misses(hip_lib, monkeypatch, nc, nodes,
+                                               m, avg, nt):
+    """The discrete gradient's structure: the nc rows of a node share their
+    column pattern, the values differ (k_spmv_rk: one column index per
+    node-entry).  Near misses - one entry removed, one row longer - must fall
+    back to the general kernels; a value update must reach the row-blocked
+    copy."""
+    if nt:
+        monkeypatch.setenv("PCD_NT_BYTES", "0")
+    rng = np.random.default_rng(nodes + nc)
+    F = _random_csr(rng, nodes, m, avg, empty_frac=0.05)
+    K = sp.kron(F, np.ones((nc, 1)), format="csr")
+    K.sort_indices()
+    K.data[:] = rng.standard_normal(K.nnz)
+    x = rng.standard_normal(m)
+    add = rng.standard_normal(nc * nodes)
+    K2 = K.tolil()
+    r, cidx = int(K.nonzero()[0][5]), int(K.nonzero()[1][5])
+    K2[r, cidx] = 0.0
+    K2 = K2.tocsr()
+    K2.eliminate_zeros()
+    K2.sort_indices()
+    for M in (K, K2):
+        e = c.Engine(hip_lib, "BRM1", 0)
+        e.set_velocity_block(nc)
+        e.set_csr(c.MAT_A01, M)
+        assert relerr(e.spmv_np(c.MAT_A01, x, M.shape[0]), M @ x) < 1e-13
+        M.data[:] = rng.standard_normal(M.nnz)           # new values, same pattern
+        e.update_values(c.MAT_A01, M.data)
         assert relerr(e.spmv_np(c.MAT_A01, x, M.shape[0]), M @ x) < 1e-13
 
 

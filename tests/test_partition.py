@@ -9,13 +9,15 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D
+from fenapack_amd.fem import BackwardStep, Cavity, Cavity3D, Channel3D
 from fenapack_amd.fem import partition as pt
 
 CASES = {
     "cube16": (Cavity3D, dict(level=2, nu=0.01, n0=4)),
     "cavity4": (Cavity, dict(level=4, nu=0.01)),
     "lshape3_brm2": (BackwardStep, dict(level=3, nu=0.02, variant="BRM2")),
+    # 3-D inflow / outflow: the Robin term of Kp over the inflow FACES
+    "duct16_brm2": (Channel3D, dict(level=2, nu=0.02, n0=4, variant="BRM2")),
 }
 _GLOBAL = {}
 
@@ -61,7 +63,8 @@ def test_cut_is_the_engine_s_rule():
 @pytest.mark.parametrize("name,R", [("cube16", 2), ("cube16", 3),
                                     ("cube16", 8), ("cavity4", 2),
                                     ("cavity4", 3), ("cavity4", 8),
-                                    ("lshape3_brm2", 3)])
+                                    ("lshape3_brm2", 3),
+                                    ("duct16_brm2", 2), ("duct16_brm2", 3)])
 def test_owned_rows_are_bitwise_the_global_build(name, R):
     g = global_build(name)
     pb, lin = g["pb"], g["lin"]

@@ -23,6 +23,7 @@ from fenapack_amd.driver import multigrid_inner_options, solve_steady
 from fenapack_amd.fem import Cavity, Cavity3D
 from fenapack_amd.fem import partition as pt
 from fenapack_amd.parallel import Comm
+from helpers import free_port
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,7 +79,18 @@ def on_thread_ranks(R, body, own_streams):
 @pytest.mark.parametrize("cls,kw,dim,R", [
     (Cavity, dict(level=4, nu=0.01), 2, 2),
     (Cavity3D, dict(level=2, nu=0.01, n0=4), 3, 2)])
-def test_peer_protocol_on_thread_ranks(hip_lib, monkeypatch, cls, kw, dim, R):
+def test_peer_protocol_on_thread_ranks(hip_lib, monkeypatch, request, cls, kw, dim, R):
+    if os.environ.get("GPU_MAX_HW_QUEUES") != "8":
+        # the HIP runtime reads the queue count when it initialises: this test
+        # alone runs with eight hardware queues, in a process of its own - the
+        # rest of the suite keeps the default the product runs with
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+        run = subprocess.run(
+            [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
+             "-p", "no:cacheprovider", request.node.nodeid],
+            cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stdout[-4000:] + run.stderr[-2000:]
+        return
     monkeypatch.setenv("PCD_REPLICATE_BELOW", "1500")
     monkeypatch.setenv("PCD_PEER_TIMEOUT_S", "10")
     monkeypatch.setenv("PCD_THREAD_BARRIER_TIMEOUT_S", "30")
@@ -135,7 +147,7 @@ def _launch(args, port, timeout, nproc=2, extra_env=None):
 @pytest.mark.timeout(400)
 def test_two_processes_on_one_gpu_over_hip_ipc(hip_lib, tmp_path):
     out = str(tmp_path / "two.npz")
-    run = _launch([WORKER, "--out", out], 29671, 300,
+    run = _launch([WORKER, "--out", out], free_port(), 300,
                   extra_env={"PCD_COMM_PEER": "1", "PCD_PEER_TIMEOUT_S": "15",
                              "PCD_COMM_VERBOSE": "1"})
     assert run.returncode == 0, run.stderr[-4000:]
@@ -186,13 +198,54 @@ def test_two_processes_on_one_gpu_over_hip_ipc(hip_lib, tmp_path):
     assert two["exchanges_per_pcapply"] >= 4
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_interior_boundary_overlap_is_bitwise_the_fused_exchange(hip_lib, tmp_path,
+                                                                nproc):
+    """PCD_OVERLAP=1 ("SpMV overlaps the offd halo transfer with
+    the diag compute"): the tile kernels' blocks that read no ghost column run
+    between a send kernel and a wait-and-land kernel, the boundary blocks after
+    it - every block is computed as without the split, so solve and PCApply
+    are BITWISE the fused exchange's; two launches more per overlapped SpMV.
+    (PCD_VEC_TILE=2: tile kernels on every F (x) I operator, also at this
+    size.)  What it buys can only be priced with real peers; the switch is
+    there for the first multi-GPU run to A/B."""
+    res = {}
+    for ov in ("0", "1"):
+        out = str(tmp_path / ("ov%s.npz" % ov))
+        run = _launch([WORKER, "--out", out], free_port(), 300, nproc=nproc,
+                      extra_env={"PCD_COMM_PEER": "1", "PCD_PEER_TIMEOUT_S": "15",
+                                 "PCD_COMM_VERBOSE": "1", "PCD_VEC_TILE": "2",
+                                 "PCD_OVERLAP": ov})
+        assert run.returncode == 0, run.stderr[-4000:]
+        assert "peer protocol unavailable" not in run.stderr, run.stderr[-2000:]
+        res[ov] = np.load(out)
+    a, b = res["0"], res["1"]
+    assert a["ranks"] == nproc and b["ranks"] == nproc
+    assert list(a["its"]) == list(b["its"])
+    assert np.array_equal(a["x"], b["x"])
+    for k in ("y0", "y1", "y2", "y3"):            # eager / captured / replayed
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(b[k], b["y0"]), k
+    assert b["boot_calls_per_pcapply"] == 0.0
+    # the split costs launches: a send and a wait instead of one exchange, two
+    # consumer launches instead of one
+    assert b["launches_per_pcapply"] > a["launches_per_pcapply"]
+    assert b["launches_per_pcapply_graph"] <= 2.0
+    print("%d processes on one GPU: %.0f launches per PCApply fused, %.0f with "
+          "the interior / boundary split; %.3f / %.3f ms eager, %.3f / %.3f ms "
+          "replayed" % (nproc, a["launches_per_pcapply"], b["launches_per_pcapply"],
+                        1e3 * a["td_eager"], 1e3 * b["td_eager"],
+                        1e3 * a["td_graph"], 1e3 * b["td_graph"]))
+
+
 @pytest.mark.timeout(300)
 def test_a_process_that_leaves_does_not_hang_the_other(hip_lib, tmp_path):
     """Rank 1 exits after set-up: rank 0's exchange kernels give up after
     PCD_PEER_TIMEOUT_S, the engine reports PCD_ERR_COMM, the launcher ends
     with a non-zero status - nothing hangs, the GPU stays usable."""
     out = str(tmp_path / "gone.npz")
-    run = _launch([WORKER, "--out", out, "--fail-rank", "1"], 29673, 240,
+    run = _launch([WORKER, "--out", out, "--fail-rank", "1"], free_port(), 240,
                   extra_env={"PCD_COMM_PEER": "1", "PCD_PEER_TIMEOUT_S": "3"})
     assert run.returncode != 0
     assert not os.path.exists(out)
@@ -202,9 +255,9 @@ def test_a_process_that_leaves_does_not_hang_the_other(hip_lib, tmp_path):
 
 
 @pytest.mark.timeout(400)
-def test_bench_with_two_ranks_sharing_the_gpu(hip_lib):
-    """bench.py --gpus 2 through its own launcher, the ranks as two processes
-    on GPU 0 (--share-gpu: gloo bootstraps the peer protocol over HIP IPC):
+def test_bench_with_two_and_four_ranks_sharing_the_gpu(hip_lib):
+    """bench.py --gpus 2 (and 4) through its own launcher, the ranks as
+    processes on GPU 0 (--share-gpu: gloo bootstraps the peer protocol over HIP IPC):
     the contract's multi-rank path - launcher, barrier-bracketed timed region,
     max over ranks, ONE JSON line, hipGraph replay with ranks - on a box with
     one GPU.  (Real GPUs: test_two_gpus.py.)"""
@@ -213,9 +266,9 @@ def test_bench_with_two_ranks_sharing_the_gpu(hip_lib):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    for extra in ([], ["--partitioned-producer"]):
+    for n, extra in ((2, []), (2, ["--partitioned-producer"]), (4, [])):
         run = subprocess.run(
-            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n),
              "--share-gpu", "--level", "4", "--steps", "10", "--warmup", "3",
              "--no-cpu-baseline"] + extra,
             env=env, capture_output=True, text=True, timeout=360)
@@ -223,8 +276,8 @@ def test_bench_with_two_ranks_sharing_the_gpu(hip_lib):
         lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, run.stdout[-2000:]
         d = json.loads(lines[0])
-        assert d["n_gpus"] == 2 and d["steps"] == 10 and d["value"] > 0
-        assert d["config"]["parallelism"] == "row partition x2"
+        assert d["n_gpus"] == n and d["steps"] == 10 and d["value"] > 0
+        assert d["config"]["parallelism"] == "row partition x%d" % n
         assert d["config"]["launch"] == "hipGraph replay"
         assert ("partitioned" in d["config"]["producer"]) == bool(extra)
         assert len(d["gmres_its_per_newton_step"]) == 2

@@ -13,7 +13,7 @@ import pytest
 
 import oracle
 from fenapack_amd import _cabi as c
-from helpers import flow_state, configure_engine, relerr, set_iter_cfg
+from helpers import flow_state, configure_engine, relerr, set_iter_cfg, free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
@@ -61,7 +61,7 @@ def test_worker_on_one_rank_over_a_real_rccl_communicator(hip_lib, tmp_path,
     out = str(tmp_path / "one.npz")
     run = _launch([WORKER, "--out", out]
                   + (["--handover=rows"] if local else []),
-                  29639 + int(local), 420, nproc=1,
+                  free_port(), 420, nproc=1,
                   extra_env={"PCD_FORCE_COMM": "1"})
     assert run.returncode == 0, run.stderr[-3000:]
     one = np.load(out)
@@ -117,7 +117,7 @@ def test_two_processes_match_one_gpu(hip_lib, tmp_path, local):
     out = str(tmp_path / "two.npz")
     run = _launch([WORKER, "--out", out]
                   + (["--handover=rows"] if local else []),
-                  29641 + 6 * int(local), 600)
+                  free_port(), 600)
     assert run.returncode == 0, run.stderr[-3000:]
     two = np.load(out)
     assert two["ranks"] == 2 and 0 < two["nu_loc"] < 2 * 10 ** 9
@@ -150,6 +150,6 @@ def test_failing_rank_does_not_hang_the_job(tmp_path):
     """One rank dies after set-up while the other waits inside an RCCL
     collective: the launcher must end the job with a non-zero code."""
     run = _launch([WORKER, "--out", str(tmp_path / "x.npz"), "--fail-rank",
-                   "1"], 29643, 420)
+                   "1"], free_port(), 420)
     assert run.returncode != 0
     assert not os.path.exists(str(tmp_path / "x.npz"))

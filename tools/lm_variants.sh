@@ -1,0 +1,29 @@
+#!/bin/bash
+# compile-time variants of the lane-major tile kernels, us per launch of the
+# Chebyshev step on the finest A00 (first line per workload: the entries-in-LDS
+# form, PCD_VT_LM=0; second: the tree's default build).
+#   tools/lm_variants.sh "<flags>;<flags>;..." "<workload>" ...
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+SRC=fenapack_amd/csrc/pcd_engine.hip
+mkdir -p /tmp/pcdlibs
+IFS=';' read -ra VARS <<< "$1"
+shift
+i=0
+for V in "${VARS[@]}"; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC $V -o /tmp/pcdlibs/v$i.so $SRC &
+  i=$((i+1))
+done
+wait
+for WL in "$@"; do
+  PCD_VT_LM=0 python3 tools/time_a00_kernel.py $WL
+  python3 tools/time_a00_kernel.py $WL
+  i=0
+  for V in "${VARS[@]}"; do
+    echo -n "[$V] "
+    FENAPACK_AMD_HIP_LIB=/tmp/pcdlibs/v$i.so python3 tools/time_a00_kernel.py $WL
+    echo -n "[$V] "
+    FENAPACK_AMD_HIP_LIB=/tmp/pcdlibs/v$i.so python3 tools/time_a00_kernel.py $WL
+    i=$((i+1))
+  done
+done
