@@ -413,8 +413,9 @@ def main():
     ncomp = int(eng.info(c.INFO_A00_COMPONENTS))
     rows_wg = int(eng.info(c.INFO_A00_ROWS_PER_WG))
     if ncomp and rows_wg < 0:              # LDS-staged vector tiles
-        kernel_name = "pcd::k_cheb_step_tc<%d> (%d-row blocks)" % (ncomp,
-                                                                   -rows_wg)
+        lm = int(eng.info(c.INFO_A00_KERNEL)) == 4
+        kernel_name = "pcd::k_cheb_step_%s<%d> (blocks of <= %d rows)" % (
+            "lm" if lm else "tc", ncomp, -rows_wg)
     else:
         kernel_name = ("pcd::k_cheb_step_sc<%d, %d>" % (rows_wg, ncomp)) \
             if ncomp else ("pcd::k_cheb_step_s<%d>" % rows_wg if rows_wg

@@ -25,6 +25,7 @@ INFO_N_U, INFO_N_P, INFO_ITS_AP, INFO_ITS_MP, INFO_ITS_RP, INFO_ITS_A00, \
 INFO_REORDERED = 15          # HIP engine only: +1 velocity, +2 pressure renumbered
 INFO_LAUNCHES = 64           # HIP engine only: kernel launches of this host thread
 INFO_PEER_CALLS, INFO_BOOT_CALLS = 65, 66   # exchanges / reductions: peer kernels, bootstrap
+INFO_A00_KERNEL = 69         # 0 csr, 1 stream, 2 multi-component stream, 3 tiles, 4 lane-major tiles
 INFO_PEER_DECLINED = 68      # halo channels that did not fit the peer arena (bootstrap path)
 INFO_A00_MODEL_BYTES = 67    # bytes one Chebyshev step on A00 moves by construction
 INFO_NNZ_BASE = 16

@@ -142,7 +142,6 @@ struct DCsr {
   bool vt = false;
   int vt_blocks = 0, vt_rows = 0;     // rows per block (template parameter of the kernels)
   int64_t vt_nsrc = 0;                // tile slots of all blocks
-  bool vt_staged = false;             // staged (non-temporal) form of the tile kernels
   // lane-major form (operators streamed from HBM; pcd_kernels.hpp k_*_lm):
   // values in lane-major order (refreshed from val2 through vt_pos), 8 per lane
   bool vt_lm = false;
@@ -421,9 +420,9 @@ static bool g_no_small_tile = false;  // PCD_NO_SMALL_TILE=1: A/B switch
 // operators whose launches move more than this stream their matrix arrays with
 // non-temporal loads (PCD_NT_BYTES; -1: never): beyond the 256 MiB Infinity Cache
 static long long g_nt_bytes = 256ll << 20;
-// the tile kernels of operators streamed from HBM (nt2) take the STAGED form:
-// the block's (value, offset) pairs pass through LDS with coalesced
-// non-temporal loads; PCD_VT_NT=0 keeps the direct, default-policy form
+// the tile kernels of operators streamed from HBM (nt2) take the LANE-MAJOR
+// form (k_*_lm: entries straight to registers with coalesced non-temporal
+// loads); PCD_VT_NT=0 keeps the direct, default-policy form at every size
 static int g_vt_nt = 1;
 static int g_num_cus = 256;
 static int ensure_pinned(Engine* h, size_t n) {
@@ -640,14 +639,9 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
   }
   if (A.vt) {
     const int gt = grid_stream(vb.n, 1);
-#define PCD_SPMV_TC_(NT, ROWS)                                                                 \
-    hipLaunchKernelGGL((k_spmv_tc<MODE, NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream, \
-                       vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,       \
-                       A.vt_loc.p, x, ghost, nloc, add, y)
-#define PCD_SPMV_TC(NT) do { if (A.vt_rows == 128) PCD_SPMV_TC_(NT, 128); else PCD_SPMV_TC_(NT, 64); } while (0)
-    if (A.vt_staged) PCD_SPMV_TC(true); else PCD_SPMV_TC(false);
-#undef PCD_SPMV_TC
-#undef PCD_SPMV_TC_
+    hipLaunchKernelGGL((k_spmv_tc<MODE, NC, 64>), dim3(gt), dim3(kBlock), 0, h->stream,
+                       vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,
+                       A.vt_loc.p, x, ghost, nloc, add, y);
     return;
   }
   const int g = grid_stream(nn, A.rb2);
@@ -936,15 +930,12 @@ static int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
     if (!vb.n) return;
     const int gt = grid_stream(vb.n, 1);
     const int nloc = (int)(A.ncols / A.kron);
-#define PCD_CHEB_TC_(NC, NT, ROWS)                                                             \
-    hipLaunchKernelGGL((k_cheb_step_tc<NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream,  \
+#define PCD_CHEB_TC(NC)                                                                        \
+    hipLaunchKernelGGL((k_cheb_step_tc<NC, 64>), dim3(gt), dim3(kBlock), 0, h->stream,        \
                        vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,       \
                        A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
-#define PCD_CHEB_TC(NC, NT) do { if (A.vt_rows == 128) PCD_CHEB_TC_(NC, NT, 128); else PCD_CHEB_TC_(NC, NT, 64); } while (0)
-    if (A.kron == 2) { if (A.vt_staged) PCD_CHEB_TC(2, true); else PCD_CHEB_TC(2, false); }
-    else { if (A.vt_staged) PCD_CHEB_TC(3, true); else PCD_CHEB_TC(3, false); }
+    if (A.kron == 2) PCD_CHEB_TC(2); else PCD_CHEB_TC(3);
 #undef PCD_CHEB_TC
-#undef PCD_CHEB_TC_
   } else if (dinv && A.rb2 && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_step_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
@@ -1002,16 +993,13 @@ static int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
     const VtBlocks vb = vt_blocks_now(h, A);
     if (!vb.n) return;
     const int gt = grid_stream(vb.n, 1);
-#define PCD_FIRST_TC_(NC, NT, ROWS)                                                            \
-    hipLaunchKernelGGL((k_cheb_first_tc<NC, NT, ROWS>), dim3(gt), dim3(kBlock), 0, h->stream, \
+#define PCD_FIRST_TC(NC)                                                                       \
+    hipLaunchKernelGGL((k_cheb_first_tc<NC, 64>), dim3(gt), dim3(kBlock), 0, h->stream,       \
                        vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,       \
                        A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron), \
                        A.dghost.p ? A.dghost.p : dinv)
-#define PCD_FIRST_TC(NC, NT) do { if (A.vt_rows == 128) PCD_FIRST_TC_(NC, NT, 128); else PCD_FIRST_TC_(NC, NT, 64); } while (0)
-    if (A.kron == 2) { if (A.vt_staged) PCD_FIRST_TC(2, true); else PCD_FIRST_TC(2, false); }
-    else { if (A.vt_staged) PCD_FIRST_TC(3, true); else PCD_FIRST_TC(3, false); }
+    if (A.kron == 2) PCD_FIRST_TC(2); else PCD_FIRST_TC(3);
 #undef PCD_FIRST_TC
-#undef PCD_FIRST_TC_
   } else if (A.rb2 && kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;
     LAUNCH_RBC(A, k_cheb_first_sc, grid_stream(nn, A.rb2), nn, A.rowptr2.p, A.col2.p,
@@ -1671,34 +1659,26 @@ static bool kron_pattern(int nc, int64_t nrows, int64_t ncols, const int32_t* ro
 
 // LDS-staged vector tiles (pcd_kernels.hpp): row blocks of the scalar stencil
 // F chosen greedily - rows are added while the block's distinct columns fit
-// the tile (kVtNodes), its entries the entry buffer (kVtEntries) and its rows
-// the workgroup (kVtRows) -, per block its distinct columns in ascending order
+// the tile, its entries the lanes' registers (lane-major form) and its rows
+// the workgroup -, per block its distinct columns in ascending order
 // (the tile's sources) and per entry the offset of its column in the tile.  PCD_VEC_TILE: 0 off, 1 three-component operators
 // of at least PCD_VEC_TILE_ROWS node rows (default), 2 every F (x) I operator.
 static int g_vec_tile = 1;
 static long long g_vec_tile_rows = 80000;
-// rows per block: three components 64 (29 entries per row); two components
-// (11.5 entries per row) 64 in the direct form, 128 in the staged one -
-// measured on the finest A00 of the cavity (profiles/r04_r_vt_sweep_2d.txt):
-// level 6 (cache-resident) gather kernel 18.9 us, tile 15.5 (64 rows) / 17.7
-// (128); level 7 (HBM) 67.6 against 62.7 (128 rows, staged) / 91.8 (64)
-static int g_vt_rows2 = 0, g_vt_rows3 = 64;
-static int g_vt_lm = 1;
+// rows per block of the direct form: 64 (cavity level 6, cache-resident:
+// gather kernel 18.9 us, tile 15.5 with 64 rows, 17.7 with 128 -
+// profiles/r04_r_vt_sweep_2d.txt); the lane-major form: lm_rows()
 static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
                           const std::vector<int32_t>& rpc, const std::vector<int32_t>& cc) {
   A.vt = false; A.vt_blocks = 0;
   // (read per operator, defaults restored when a variable is gone: the A/B
   // tests of one process must not leak their switches into later engines)
-  { const char* e = getenv("PCD_VT_ROWS2"); g_vt_rows2 = (e && (atoi(e) == 64 || atoi(e) == 128)) ? atoi(e) : 0; }
   { const char* e = getenv("PCD_VT_NT"); g_vt_nt = e ? atoi(e) : 1; }
-  A.vt_staged = A.nt2 && g_vt_nt;      // the form is fixed with the layout
   // operators streamed from HBM: lane-major entries, straight to registers
-  // (k_*_lm; PCD_VT_LM=0 keeps the form that stages the entries in LDS)
-  { const char* e = getenv("PCD_VT_LM"); g_vt_lm = e ? atoi(e) : 1; }
-  A.vt_lm = A.vt_staged && g_vt_lm;
-  const int kVtRows = A.vt_lm ? lm_rows(nc)
-                      : nc == 2 ? (g_vt_rows2 ? g_vt_rows2 : (A.vt_staged ? 128 : 64)) : g_vt_rows3;
-  const int kEntries = A.vt_lm ? kLmEntries : vt_entries(nc);
+  // (the form is fixed with the layout)
+  A.vt_lm = A.nt2 && g_vt_nt;
+  const int kVtRows = A.vt_lm ? lm_rows(nc) : 64;
+  const int kEntries = A.vt_lm ? kLmEntries : INT32_MAX;       // (direct form: no entry buffer)
   const int kNodes = A.vt_lm ? lm_nodes(nc) : kVtNodes;
   const int kVtRowOff = vt_rowoff(kVtRows);
   A.vt_rows = kVtRows;
@@ -1747,7 +1727,7 @@ static int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
         int32_t nuniq = 0;
         uniq.clear();
         while (r1 < rz && r1 - r < kVtRows) {
-          if (rpc[r1 + 1] - rpc[r] > kEntries) break;                 // (staged form: LDS slots)
+          if (rpc[r1 + 1] - rpc[r] > kEntries) break;                 // (lane-major form: 8 per lane)
           int32_t add = 0;
           const size_t before = uniq.size();
           for (int32_t k = rpc[r1]; k < rpc[r1 + 1]; ++k)
@@ -3670,6 +3650,11 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
     case PCD_INFO_PEER_CALLS:
       *out = (h->comm && h->comm->peer()) ? (double)static_cast<PeerBackend*>(h->comm)->peer_calls : 0.0;
       return 0;
+    case PCD_INFO_A00_KERNEL: {
+      const DCsr& A = h->mat[PCD_MAT_A00];
+      *out = (A.kron && A.vt) ? (A.vt_lm ? 4.0 : 3.0) : (A.kron && A.rb2) ? 2.0 : A.rb ? 1.0 : 0.0;
+      return 0;
+    }
     case PCD_INFO_PEER_DECLINED:
       *out = (h->comm && h->comm->peer()) ? (double)static_cast<PeerBackend*>(h->comm)->declined : 0.0;
       return 0;

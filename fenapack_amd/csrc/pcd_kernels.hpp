@@ -1019,31 +1019,13 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
 #ifndef PCD_VT_U
 #define PCD_VT_U 8
 #endif
-#ifndef PCD_VT_WIDE
-#define PCD_VT_WIDE 1
-#endif
-#ifndef PCD_VT_PAIR
-#define PCD_VT_PAIR 1
-#endif
 #ifndef PCD_VT_U2
 #define PCD_VT_U2 (PCD_VT_U / 2)
 #endif
 // rows per block = template parameter ROWS of the kernels (256 / ROWS lanes
-// share a row): 64 for three components (29 entries per row), 64 or 128 for
-// two (11.5 entries per row), chosen on the host per operator
+// share a row): 64, chosen on the host per operator
 constexpr int kVtNodes = PCD_VT_NODES;      // tile nodes (x NC doubles)
 constexpr int vt_rowoff(int rows) { return rows + 2; }   // row offsets per block (rows + 1, padded)
-// entries per block (staged form: LDS slots).  LDS bounds the occupancy of the
-// staged form and its launch time follows T = a + b / W in the workgroups W
-// per CU (measured with LDS padding, cube N = 48: 142.6 / 108.1 / 91.2 us at
-// W = 2 / 3 / 4): two components fit FIVE workgroups per CU with 1792 slots
-// (12 KB tile + 17.5 KB entries; the 128-row blocks of a 2-D P2 stencil hold
-// ~1470 entries and stay full) - cavity level 7: 62.9 -> 56.8 us per launch;
-// three components would need a 512-node tile for that, and the blocks it
-// leaves (42 rows instead of 56) cost more than the occupancy brings
-// (N = 73: 363 -> 376 us; profiles/r04_j_*)
-constexpr int vt_entries(int nc) { return nc == 2 ? 1792 : 2048; }
-constexpr int kVtEntries = 2048;            // (largest)
 static_assert(kVtNodes % kBlock == 0, "one lane per tile node, whole passes");
 // per block: x = first row, y = first entry, z = first slot in `tsrc`,
 // w = rows | tile nodes << 8.  tsrc[z + t] = vector node of tile slot t (the
@@ -1055,12 +1037,17 @@ static_assert(kVtNodes % kBlock == 0, "one lane per tile node, whole passes");
 // launch at cube N = 32 against 35 for the gather kernel); a binary search of
 // the segments in LDS per tile slot (35 us: the LDS waits took the place of
 // the texture-addresser stalls, profiles/r04_f_*).
-template <int NC, bool NT, int ROWS>
+// This DIRECT form serves operators that stay in the caches between launches;
+// operators streamed from HBM take the lane-major form below (k_*_lm).  (A
+// third form that staged the block's entries in LDS with non-temporal loads
+// was the HBM form of round 4: 85.2 against 76.7 us at cube N = 48, 341.8
+// against 285.6 at N = 73 - profiles/r05_d_*; removed.)
+template <int NC, int ROWS>
 __device__ __forceinline__ VecC<NC> tile_row_block(
     const int4 d, const unsigned short* __restrict__ rowoff, int blk,
     const int* __restrict__ tsrc, const double* __restrict__ val,
     const unsigned short* __restrict__ loc, const double* x,
-    const double* ghost, int nloc, double* tile, double* ev, unsigned short* el,
+    const double* ghost, int nloc, double* tile,
     const double* xscale = nullptr, const double* gscale = nullptr) {
   // (xscale / gscale: the tile holds x .* xscale - one factor per NODE, its
   // first component's, as the diagonal of F (x) I repeats: the zero-guess
@@ -1103,151 +1090,50 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
     for (int i = 0; i < NC; ++i) tv[u][i] = t.c[i];
   }
   VecC<NC> s = vzero<NC>();
-  if (NT) {
-    // operators streamed from HBM: the block's (value, tile offset) pairs go
-    // through LDS with fully coalesced NON-TEMPORAL loads (lane t takes
-    // entries t, t + 256, ...) - read by rows they would touch every cache
-    // line from up to four load instructions, and a non-temporal line is
-    // fetched again each time (N = 48: 128 -> 157 us)
-    const int ne = rowoff[blk * kVtRowOff + nr];
-#if PCD_VT_WIDE
-    // 16-byte loads of the values (pairs) and 8-byte loads of the 16-bit
-    // offsets (quads) from bases aligned DOWN to the pair / quad the block's
-    // first entry sits in: 6-8 load and 6-8 LDS-write instructions per lane
-    // instead of 16 + 16; the LDS copies keep the shift (shv, shl)
-    typedef double dv2 __attribute__((ext_vector_type(2)));
-    typedef unsigned uv2 __attribute__((ext_vector_type(2)));
-    constexpr int E = vt_entries(NC);
-    constexpr int UV = (E / 2 + 1 + kBlock - 1) / kBlock, UL = (E / 4 + 1 + kBlock - 1) / kBlock;
-    const int shv = k0 & 1, shl = k0 & 3;
-    const dv2* vb = reinterpret_cast<const dv2*>(val + (k0 - shv));
-    const uv2* lb = reinterpret_cast<const uv2*>(loc + (k0 - shl));
-    dv2 ve[UV];
-    uv2 le[UL];
+  // the first entries of my row straight from the stream (the lanes of a row
+  // read contiguous bytes per step)
+  // (entries in flight per lane; two components: 4 - with 4 lanes per row
+  // that covers the 2-D P2 rows, and 58 instead of 70 VGPRs are an eighth
+  // wave per SIMD: cavity level 6 15.54 -> 15.20 us; three components:
+  // 8 - N = 32 29.6, 30.9 with 4)
+  constexpr int U = NC == 2 ? PCD_VT_U2 : PCD_VT_U;
+  double v[U];
+  int o[U];
+  // a lane takes PAIRS of consecutive entries: one 16-byte load of the
+  // values and one 4-byte load of the offsets per pair (8- and 2-byte
+  // aligned: the hardware's unaligned mode), half the load instructions
+  typedef double dv2u __attribute__((ext_vector_type(2), aligned(8)));
+  typedef unsigned short us2u __attribute__((ext_vector_type(2), aligned(2)));
 #pragma unroll
-    for (int u = 0; u < UV; ++u) {
-      const int p = threadIdx.x + u * kBlock;
-      ve[u] = 2 * p < ne + shv ? __builtin_nontemporal_load(vb + p) : dv2(0.0);
+  for (int u = 0; u < U / 2; ++u) {
+    const int jj = ra + 2 * sub + u * 2 * TPR;
+    const bool in = jj < rb, in2 = jj + 1 < rb;
+    dv2u vv = dv2u(0.0);
+    us2u ll = us2u((unsigned short)0);
+    if (in) {
+      vv = *reinterpret_cast<const dv2u*>(val + k0 + jj);
+      ll = *reinterpret_cast<const us2u*>(loc + k0 + jj);
     }
+    v[2 * u] = vv.x; o[2 * u] = ll.x;
+    v[2 * u + 1] = in2 ? vv.y : 0.0; o[2 * u + 1] = in2 ? (int)ll.y : 0;
+  }
 #pragma unroll
-    for (int u = 0; u < UL; ++u) {
-      const int q = threadIdx.x + u * kBlock;
-      le[u] = 4 * q < ne + shl ? __builtin_nontemporal_load(lb + q) : uv2(0u);
+  for (int u = 0; u < kVtNodes / kBlock; ++u)
+    if (src[u]) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
     }
+  __syncthreads();
 #pragma unroll
-    for (int u = 0; u < kVtNodes / kBlock; ++u)
-      if (src[u]) {
+  for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
-      }
+    for (int i = 0; i < NC; ++i) s.c[i] += v[u] * tile[i * kVtNodes + o[u]];
+  }
+  for (int jj = ra + sub + U * TPR; jj < rb; jj += TPR) {     // long rows
+    const double vv = val[k0 + jj];
+    const int oo = loc[k0 + jj];
 #pragma unroll
-    for (int u = 0; u < UV; ++u) {
-      const int p = threadIdx.x + u * kBlock;
-      if (2 * p < ne + shv) reinterpret_cast<dv2*>(ev)[p] = ve[u];
-    }
-#pragma unroll
-    for (int u = 0; u < UL; ++u) {
-      const int q = threadIdx.x + u * kBlock;
-      if (4 * q < ne + shl) reinterpret_cast<uv2*>(el)[q] = le[u];
-    }
-    __syncthreads();
-    // (one entry per trip: four per trip with the reads hoisted - to break the
-    // chain of two dependent LDS latencies per entry - is 9 % SLOWER, level 7
-    // 53.5 -> 58.8 us, cube N = 48 85.8 -> 93.7: the extra clamped reads of
-    // the last trip cost what they add in LDS operations, i.e. this phase is
-    // bound by LDS throughput, not by its latency)
-    for (int jj = ra + sub; jj < rb; jj += TPR) {
-      const double vv = ev[jj + shv];
-      const int oo = el[jj + shl];
-#pragma unroll
-      for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
-    }
-#else
-    constexpr int UE = vt_entries(NC) / kBlock;
-    double ve[UE];
-    unsigned short le[UE];
-#pragma unroll
-    for (int u = 0; u < UE; ++u) {
-      const int j = threadIdx.x + u * kBlock;
-      const bool in = j < ne;
-      ve[u] = in ? stream_load<true>(val + k0 + j) : 0.0;
-      le[u] = in ? stream_load<true>(loc + k0 + j) : (unsigned short)0;
-    }
-#pragma unroll
-    for (int u = 0; u < kVtNodes / kBlock; ++u)
-      if (src[u]) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
-      }
-#pragma unroll
-    for (int u = 0; u < UE; ++u) {
-      const int j = threadIdx.x + u * kBlock;
-      if (j < ne) { ev[j] = ve[u]; el[j] = le[u]; }
-    }
-    __syncthreads();
-    for (int jj = ra + sub; jj < rb; jj += TPR) {
-      const double vv = ev[jj];
-      const int oo = el[jj];
-#pragma unroll
-      for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
-    }
-#endif
-  } else {
-    // cache-resident operators: the first entries of my row straight from
-    // the stream (the lanes of a row read contiguous bytes per step)
-    // (entries in flight per lane; two components: 4 - with 4 lanes per row
-    // that covers the 2-D P2 rows, and 58 instead of 70 VGPRs are an eighth
-    // wave per SIMD: cavity level 6 15.54 -> 15.20 us; three components:
-    // 8 - N = 32 29.6, 30.9 with 4)
-    constexpr int U = NC == 2 ? PCD_VT_U2 : PCD_VT_U;
-    double v[U];
-    int o[U];
-#if PCD_VT_PAIR
-    // a lane takes PAIRS of consecutive entries: one 16-byte load of the
-    // values and one 4-byte load of the offsets per pair (8- and 2-byte
-    // aligned: the hardware's unaligned mode), half the load instructions
-    typedef double dv2u __attribute__((ext_vector_type(2), aligned(8)));
-    typedef unsigned short us2u __attribute__((ext_vector_type(2), aligned(2)));
-#pragma unroll
-    for (int u = 0; u < U / 2; ++u) {
-      const int jj = ra + 2 * sub + u * 2 * TPR;
-      const bool in = jj < rb, in2 = jj + 1 < rb;
-      dv2u vv = dv2u(0.0);
-      us2u ll = us2u((unsigned short)0);
-      if (in) {
-        vv = *reinterpret_cast<const dv2u*>(val + k0 + jj);
-        ll = *reinterpret_cast<const us2u*>(loc + k0 + jj);
-      }
-      v[2 * u] = vv.x; o[2 * u] = ll.x;
-      v[2 * u + 1] = in2 ? vv.y : 0.0; o[2 * u + 1] = in2 ? (int)ll.y : 0;
-    }
-#else
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int jj = ra + sub + u * TPR;
-      const bool in = jj < rb;
-      v[u] = in ? val[k0 + jj] : 0.0;
-      o[u] = in ? (int)loc[k0 + jj] : 0;
-    }
-#endif
-#pragma unroll
-    for (int u = 0; u < kVtNodes / kBlock; ++u)
-      if (src[u]) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) tile[i * kVtNodes + threadIdx.x + u * kBlock] = tv[u][i];
-      }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int i = 0; i < NC; ++i) s.c[i] += v[u] * tile[i * kVtNodes + o[u]];
-    }
-    for (int jj = ra + sub + U * TPR; jj < rb; jj += TPR) {     // long rows
-      const double vv = val[k0 + jj];
-      const int oo = loc[k0 + jj];
-#pragma unroll
-      for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
-    }
+    for (int i = 0; i < NC; ++i) s.c[i] += vv * tile[i * kVtNodes + oo];
   }
 #pragma unroll
   for (int m = TPR / 2; m > 0; m >>= 1) {
@@ -1257,10 +1143,7 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   return s;
 }
 
-#define PCD_VT_SHARED(NC)                                         \
-  __shared__ double tile[NC * kVtNodes];                          \
-  __shared__ __attribute__((aligned(16))) double ev[NT ? vt_entries(NC) + 2 * PCD_VT_WIDE : 1]; \
-  __shared__ __attribute__((aligned(16))) unsigned short el[NT ? vt_entries(NC) + 4 * PCD_VT_WIDE : 1]
+#define PCD_VT_SHARED(NC) __shared__ double tile[NC * kVtNodes]
 
 // (`blist`: the blocks to run, or null = all of them - several ranks with
 // PCD_OVERLAP=1 run the blocks that read no ghost column while the halo is
@@ -1271,7 +1154,7 @@ __device__ __forceinline__ VecC<NC> tile_row_block(
   const int* __restrict__ tsrc, const double* __restrict__ val,                        \
   const unsigned short* __restrict__ loc
 
-template <int MODE, int NC, bool NT, int ROWS>
+template <int MODE, int NC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_spmv_tc(
     PCD_VT_ARGS, const double* x, const double* ghost, int nloc, const double* add_,
     double* y_) {
@@ -1288,7 +1171,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tc(
     const bool mine = threadIdx.x % (kBlock / ROWS) == 0 && lr < (d.w & 0xff);
     VecC<NC> a = vzero<NC>();
     if ((MODE == 1 || MODE == 2) && mine) a = add[row];
-    const VecC<NC> s = tile_row_block<NC, NT, ROWS>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile, ev, el);
+    const VecC<NC> s = tile_row_block<NC, ROWS>(d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -1301,7 +1184,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tc(
   }
 }
 
-template <int NC, bool NT, int ROWS>
+template <int NC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, const double* pm_,
     const double* pk_, double* pn_, double c0, double c1, double c2,
@@ -1323,7 +1206,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
       bi = b[row]; d = dinv[row]; xk = pk[row];
       if (c0 != 0.0) xm = pm[row];
     }
-    const VecC<NC> s = tile_row_block<NC, NT, ROWS>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile, ev, el);
+    const VecC<NC> s = tile_row_block<NC, ROWS>(d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile);
     if (mine) {
       VecC<NC> o;
 #pragma unroll
@@ -1335,7 +1218,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step_tc(
   }
 }
 
-template <int NC, bool NT, int ROWS>
+template <int NC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, double* p0_,
     double* pn_, double s, double c1, double c2, const double* ghost, int nloc,
@@ -1355,8 +1238,8 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
     if (mine) { d = dinv[row]; bi = b[row]; }
     // (the tile holds D^-1 b - b with its halo when there are several ranks,
     // the reciprocal diagonal of the ghost columns kept from its own exchange)
-    const VecC<NC> sum = tile_row_block<NC, NT, ROWS>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, ev, el,
-                                                      dinv_, dghost);
+    const VecC<NC> sum = tile_row_block<NC, ROWS>(d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile,
+                                                  dinv_, dghost);
     if (mine) {
       VecC<NC> x0, o;
 #pragma unroll

@@ -99,6 +99,11 @@ enum pcd_info {
   PCD_INFO_PEER_CALLS = 65,  /* halo exchanges / all-reduces issued as kernels of the
                               * stream (peer protocol), so far */
   PCD_INFO_BOOT_CALLS = 66,  /* ... and those that went through RCCL / the host transport */
+  PCD_INFO_A00_KERNEL = 69,  /* kernel family the fused Chebyshev step on the velocity block
+                              * takes: 0 row-wise CSR, 1 CSR stream (k_cheb_step_s), 2 multi-
+                              * component stream (_sc), 3 vector tiles, direct form (_tc),
+                              * 4 vector tiles, lane-major form (_lm: operators beyond the
+                              * Infinity Cache) */
   PCD_INFO_PEER_DECLINED = 68, /* halo channels that did not fit the peer arena
                               * (PCD_PEER_ARENA_MB): their exchanges take the bootstrap
                               * path and a PCApply that holds one is not graph-captured */

@@ -1,7 +1,6 @@
 #!/bin/bash
 # compile-time variants of the lane-major tile kernels, us per launch of the
-# Chebyshev step on the finest A00 (first line per workload: the entries-in-LDS
-# form, PCD_VT_LM=0; second: the tree's default build).
+# Chebyshev step on the finest A00 (first line per workload: the tree's default build).
 #   tools/lm_variants.sh "<flags>;<flags>;..." "<workload>" ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
@@ -16,7 +15,6 @@ for V in "${VARS[@]}"; do
 done
 wait
 for WL in "$@"; do
-  PCD_VT_LM=0 python3 tools/time_a00_kernel.py $WL
   python3 tools/time_a00_kernel.py $WL
   i=0
   for V in "${VARS[@]}"; do
