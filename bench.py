@@ -290,6 +290,10 @@ def main():
     elif args.geometry == "cube":                                # 3D, Re = 100
         cls, kw = Cavity3D, dict(level=args.level, nu=0.01, n0=args.n0,
                                  variant=args.variant)
+        # (config 5's own mesh, N = 73: 2.33 M tetrahedra - above the host
+        # assembler's default limit; the memory estimate and the resident-set
+        # watchdog still apply)
+        os.environ.setdefault("FENAPACK_AMD_MAX_CELLS", "4000000")
     else:
         cls, kw = BackwardStep, dict(level=args.level, nu=0.02,
                                      variant=args.variant)
@@ -680,7 +684,7 @@ def kernels_sha16():
     """Hash of the kernel sources a PMC measurement is valid for."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("pcd_kernels.hpp", "pcd_engine.hip"):
+    for f in ("pcd_kernels.hpp", "pcd_apply.hip", "pcd_setup.hip"):
         h.update(open(os.path.join(ROOT, "fenapack_amd", "csrc", f),
                       "rb").read())
     return h.hexdigest()[:16]
@@ -691,7 +695,7 @@ def pmc_measurement(n_u, world):
     profiles/*pmc_roofline*.json) for THIS workload and THESE kernels, or
     None: PMC counters cannot be collected inside this process, and a
     measurement taken on other kernel sources is not quoted (the file carries
-    the hash of csrc/pcd_kernels.hpp + pcd_engine.hip it was taken on)."""
+    the hash of csrc/pcd_kernels.hpp + pcd_apply.hip + pcd_setup.hip it was taken on)."""
     import glob
     if world != 1:
         return None

@@ -19,7 +19,7 @@ multiplied out once on the host and applied as ONE sparse product:
 
 The matrices are built by running the engine's own recurrences (same
 coefficients, same order: ``mg_smooth`` / ``solve_cheb`` in
-``csrc/pcd_engine.hip``) on sparse matrices instead of vectors, so the
+``csrc/pcd_apply.hip``) on sparse matrices instead of vectors, so the
 composed operator equals the step-by-step one in exact arithmetic; in floating
 point they differ by reassociation only (tests compare both engine paths and
 the oracle at 1e-11).  More bytes per launch, far fewer launches: worth it

@@ -16,7 +16,7 @@
 //     element contributions from a precomputed list, in a fixed order - no
 //     atomics, bitwise reproducible, and the Dirichlet treatment
 //     (`keep` mask + diagonal values) rides on the same pass.
-// Included by pcd_engine.hip after the engine types.
+// Included through pcd_internal.hpp by every translation unit of the engine.
 #pragma once
 
 namespace pcd {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_newton_p2(
 // the ncomp = d*d scalar matrices of the Newton term gathered on the pattern of
 // F: out[m*nnz + k] = sum of the element contributions of plane m (list order),
 // Dirichlet rows/columns removed (keep); `unc` (optional) without the mask
-__global__ __launch_bounds__(kBlock) void k_fe_gather_blocks(
+static __global__ __launch_bounds__(kBlock) void k_fe_gather_blocks(
     int64_t nnz, int ncomp, int64_t plane, const int* __restrict__ ptr,
     const int* __restrict__ src, const double* __restrict__ cells,
     const unsigned char* __restrict__ keep, double* unc, double* out) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_convection_p1(
 // rows/columns removed (keep[k] == 0)
 // `cells_s` / `out_s` (optional): the same entry with the stabilisation
 // contributions added (the preconditioner's operator); `out` may then be null
-__global__ __launch_bounds__(kBlock) void k_fe_gather(
+static __global__ __launch_bounds__(kBlock) void k_fe_gather(
     int64_t nnz, const int* __restrict__ ptr, const int* __restrict__ src,
     const double* __restrict__ cells, const double* __restrict__ cst,
     const unsigned char* __restrict__ keep, double* unc, double* out,
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_gather(
 // out[k] = sum_t w[t] * in[src[t]]: one stage of the numeric Galerkin triple
 // product P^T F P on fixed patterns (B = F P, then F_c = P^T B); the lists
 // carry the prolongation weights, so the product is two weighted gathers
-__global__ __launch_bounds__(kBlock) void k_fe_wgather(
+static __global__ __launch_bounds__(kBlock) void k_fe_wgather(
     int64_t nnz, const int64_t* __restrict__ ptr, const int* __restrict__ src,
     const double* __restrict__ w, const double* __restrict__ in, double* out) {
   for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_wgather(
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_fe_set(
+static __global__ __launch_bounds__(kBlock) void k_fe_set(
     int n, const int* __restrict__ pos, const double* __restrict__ val,
     double* out) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_scatter(
 }
 
 // wind of the next coarser level by injection (P2 spaces are nested)
-__global__ __launch_bounds__(kBlock) void k_fe_inject(
+static __global__ __launch_bounds__(kBlock) void k_fe_inject(
     int64_t nn, int dim, const int* __restrict__ inject,
     const double* __restrict__ Uf, double* Uc) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nn;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_inject(
 }
 
 // power iteration helper: y *= dinv (if given); parts[block] = sum y^2
-__global__ __launch_bounds__(kBlock) void k_fe_scale_sqnorm(
+static __global__ __launch_bounds__(kBlock) void k_fe_scale_sqnorm(
     int64_t n, const double* __restrict__ dinv, double* y, double* parts) {
   __shared__ double sm[4];
   double s = 0.0;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_scale_sqnorm(
 // step, -1 for rows already used), so there is no separate pivot kernel and no
 // grid-wide synchronisation.  n ~ 10^3: n short launches (~2 ms) replace a
 // device->host->device round trip around LAPACK that cost 20x more.
-__global__ __launch_bounds__(kBlock) void k_gj_init(
+static __global__ __launch_bounds__(kBlock) void k_gj_init(
     int n, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, double* W, double* colcur) {
   const int i = blockIdx.x;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_init(
   if (threadIdx.x == 0) colcur[i] = fabs(W[(int64_t)i * ld]);
 }
 
-__global__ __launch_bounds__(kBlock) void k_gj_step(
+static __global__ __launch_bounds__(kBlock) void k_gj_step(
     int n, int k, double* W, const double* __restrict__ colcur, double* colnext,
     int* pivrow, int* singular) {
   __shared__ double sv[kBlock];
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_step(
 
 // dense (d n)^2 row-major out = inv(F) x I_d: row k of inv(F) is the right half
 // of the row that served as pivot of column k, divided by that pivot
-__global__ __launch_bounds__(kBlock) void k_gj_store(int n, int d, const double* __restrict__ W,
+static __global__ __launch_bounds__(kBlock) void k_gj_store(int n, int d, const double* __restrict__ W,
                                                       const int* __restrict__ pivrow, double* out) {
   const int64_t N = (int64_t)n * d, total = N * N;
   for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_store(int n, int d, const double*
 // the P2 wind along the edge from its end points and midpoint, 3-point Gauss
 // rule (degree 5; the integrand has degree 4), local 2 x 2 matrix
 // loc[(i*2+j)][e] = L_e sum_q w_q (w.n)(q) psi_i(q) psi_j(q).
-__global__ __launch_bounds__(kBlock) void k_fe_robin_edges(
+static __global__ __launch_bounds__(kBlock) void k_fe_robin_edges(
     int nb, const int* __restrict__ nodes, const double* __restrict__ normal,
     const double* __restrict__ length, const double* __restrict__ U, double* loc) {
   const int e = blockIdx.x * kBlock + threadIdx.x;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_robin_edges(
 // six nodes (three vertices, then the midpoints of the edges 01, 02, 12),
 // 6-point rule of degree 4 on the triangle (the integrand has degree 4), local
 // 3 x 3 matrix loc[(i*3+j)][f] = |f| sum_q w_q (w.n)(q) lam_i(q) lam_j(q).
-__global__ __launch_bounds__(kBlock) void k_fe_robin_faces(
+static __global__ __launch_bounds__(kBlock) void k_fe_robin_faces(
     int nb, const int* __restrict__ nodes, const double* __restrict__ normal,
     const double* __restrict__ area, const double* __restrict__ U, double* loc) {
   const int f = blockIdx.x * kBlock + threadIdx.x;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_robin_faces(
 }
 
 // out[pos[i]] += vals[i]   (positions distinct)
-__global__ __launch_bounds__(kBlock) void k_fe_add_at(
+static __global__ __launch_bounds__(kBlock) void k_fe_add_at(
     int n, const int* __restrict__ pos, const double* __restrict__ vals, double* out) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     out[pos[i]] += vals[i];
@@ -563,13 +563,13 @@ __global__ __launch_bounds__(kBlock) void k_fe_add_at(
 // ---- nonlinear residual on the device ---------------------------------------
 // v = x_u with the Dirichlet entries replaced by their boundary values g
 // (v = x_u - d, d = the boundary defect of the iterate)
-__global__ __launch_bounds__(kBlock) void k_fe_bc_replace(
+static __global__ __launch_bounds__(kBlock) void k_fe_bc_replace(
     int n, const int* __restrict__ idx, const double* __restrict__ g, double* v) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     v[idx[i]] = g[i];
 }
 // Dirichlet rows of the residual: F_u[idx] = mult * (x_u[idx] - g)
-__global__ __launch_bounds__(kBlock) void k_fe_bc_rows(
+static __global__ __launch_bounds__(kBlock) void k_fe_bc_rows(
     int n, const int* __restrict__ idx, const double* __restrict__ g,
     const double* __restrict__ mult, const double* __restrict__ xu, double* Fu) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_fe_bc_rows(
 }
 
 // deterministic start vector of the power iteration
-__global__ __launch_bounds__(kBlock) void k_fe_seed(int64_t n, double* v) {
+static __global__ __launch_bounds__(kBlock) void k_fe_seed(int64_t n, double* v) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * kBlock) {
     uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;

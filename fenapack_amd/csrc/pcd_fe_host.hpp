@@ -1,5 +1,5 @@
-// Host side of the device operator producer (kernels: pcd_fe.hpp); included at
-// the end of pcd_engine.hip.  One FE level per multigrid level of the velocity
+// Host side of the device operator producer (kernels: pcd_fe.hpp); included by
+// pcd_producer.hip (its own translation unit).  One FE level per multigrid level of the velocity
 // block (coarsest first); the finest level writes the caller's system values,
 // the intermediate ones the multigrid operators, the coarsest one is handed
 // back to the host (its explicit inverse is a host computation).
@@ -101,7 +101,7 @@ struct FeState {
   }
 };
 
-static void fe_release(Engine* h) {
+void fe_release(Engine* h) {
   if (!h->fe) return;
   h->fe->release();
   delete h->fe;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_step(
 }
 
 // x = s * dinv .* b   (Chebyshev / Richardson / preonly start, zero guess)
-__global__ __launch_bounds__(kBlock) void k_scale_dinv(
+static __global__ __launch_bounds__(kBlock) void k_scale_dinv(
     int n, const double* __restrict__ dinv, const double* b, double s,
     double* x) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
@@ -130,7 +130,7 @@ struct CgState {
 };
 
 // x = 0, r = b, z = dinv r, p = z; parts_rz[blk] = sum r.z
-__global__ __launch_bounds__(kBlock) void k_cg_init(
+static __global__ __launch_bounds__(kBlock) void k_cg_init(
     int n, const double* __restrict__ dinv, const double* b, double* x,
     double* r, double* z, double* p, double* parts_rz, CgState* st) {
   __shared__ double sm[4];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_init(
 
 // p = z + (rz_new / rz_old) p; detects convergence (every workgroup takes the
 // same decision from the same partials; workgroup 0 publishes it)
-__global__ __launch_bounds__(kBlock) void k_cg_pupdate(
+static __global__ __launch_bounds__(kBlock) void k_cg_pupdate(
     int n, const double* z, double* p, const double* parts_new,
     const double* parts_old, int nparts, double rtol, CgState* st) {
   __shared__ double sm[4];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_spmv_dot(
 }
 
 // alpha = rz / pq; x += alpha p; r -= alpha q; z = dinv r; parts_out = r.z
-__global__ __launch_bounds__(kBlock) void k_cg_update(
+static __global__ __launch_bounds__(kBlock) void k_cg_update(
     int n, const double* __restrict__ dinv, const double* p, const double* q,
     double* x, double* r, double* z, const double* parts_rz, int nparts_rz,
     const double* parts_pq, int nparts_pq, double* parts_out, int it,
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(
 // all-reduce of two numbers per iteration instead of two of one; p.Ap follows
 // from dpi = delta - beta^2 dpi_old / beta_old^2.  State ping-pongs between
 // st_in / st_out so that every workgroup reads the same snapshot.
-__global__ __launch_bounds__(kBlock) void k_cgsr_init(
+static __global__ __launch_bounds__(kBlock) void k_cgsr_init(
     int n, const double* __restrict__ dinv, const double* b, double* x,
     double* r, double* z, CgState* st) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_cgsr_spmv_dots(
 
 // the iteration's scalars from the (reduced) dots, then all vector updates:
 // p = z + b p, w = s + b w, x += a p, r -= a w, z = dinv r
-__global__ __launch_bounds__(kBlock) void k_cgsr_update(
+static __global__ __launch_bounds__(kBlock) void k_cgsr_update(
     int n, const double* __restrict__ dinv, double* z, const double* sv,
     double* p, double* w, double* x, double* r, const double* pb, int nb,
     const double* pd, int nd, double rtol, int it, const CgState* st_in,
@@ -353,7 +353,7 @@ struct XCg {
 // matrix + vectors stay cache-resident between launches; larger operators
 // stream from HBM and do better with all XCDs walking one front (DESIGN.md
 // section 4 has the A/B).  PCD_NO_XCD_REMAP=1 sets it to 0.
-__constant__ int g_xcd_remap_max_rows = 1 << 20;
+static __constant__ int g_xcd_remap_max_rows = 1 << 20;
 // ... and at EVERY size by the two-component kernels that stream the matrix
 // non-temporally (bit 0: two-component kernels, bit 1: three-component ones;
 // PCD_XCD_REMAP_NT).  Measured: cavity level 7 70.6 -> 68.8 us and the counted
@@ -361,12 +361,12 @@ __constant__ int g_xcd_remap_max_rows = 1 << 20;
 // the same way (1.21 -> 1.02 x) but the launch gets 2 % SLOWER (262 -> 267 us:
 // the 3-D kernel is bound by its gather instructions, not by bytes), so bit 1
 // stays off (profiles/r03_x_xcd_nt_*.txt) ...
-__constant__ int g_xcd_remap_nt = 1;
+static __constant__ int g_xcd_remap_nt = 1;
 // ... below this many node rows.  Cube N = 73 (3.18 M node rows; config 5's own
 // mesh): counted traffic 1.32 x the kernel-model bytes, and the mapping wins:
 // 395.1 -> 376.5 us per launch, 2.913 -> 2.848 ms per PCApply
 // (profiles/r03_x_xcd_nt_cube73.txt; PCD_XCD_REMAP_NT3_ROWS).
-__constant__ int g_xcd_remap_nt3_rows = 2600000;
+static __constant__ int g_xcd_remap_nt3_rows = 2600000;
 
 template <int NC, bool NT>
 __device__ __forceinline__ bool xcd_remap_always(int nrows) {
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_s(
 // when `val` holds the scalar stencil F of an F (x) I operator)
 // (`ghost` / `nloc`: several ranks - the reciprocal diagonal of the ghost
 // columns, exchanged like any halo; one GPU: nloc = every column)
-__global__ __launch_bounds__(kBlock) void k_scale_cols(
+static __global__ __launch_bounds__(kBlock) void k_scale_cols(
     int64_t nnz, const int* __restrict__ col, const double* __restrict__ val,
     const double* __restrict__ dinv, int stride, double* vals,
     const double* __restrict__ ghost, int nloc) {
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_sc(
 // ~30 cache lines for 1.5 KB of payload, and the texture-addresser, not HBM,
 // bounds the kernel (profiles/r02_s_*: TA busy 61 %).  Here the set-up gives
 // every row block the list of CONTIGUOUS column segments it touches
-// (pcd_engine.hip build_vec_tile): the workgroup loads those segments into
+// (pcd_setup.hip build_vec_tile): the workgroup loads those segments into
 // LDS with coalesced loads - every line once per block - and the row sums
 // gather from the tile with 16-bit offsets instead of from L1 / L2
 // LDS; (value, offset) pairs come straight from the matrix stream.  No product
@@ -1558,7 +1558,7 @@ __global__ PCD_LM_BOUNDS void k_cheb_first_lm(
 }
 
 // lane-major values from F's row-major ones: out[s] = pos[s] < 0 ? 0 : valc[pos[s]]
-__global__ __launch_bounds__(kBlock) void k_lm_values(
+static __global__ __launch_bounds__(kBlock) void k_lm_values(
     int64_t nslots, const int* __restrict__ pos, const double* valc, double* out) {
   for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots;
        s += (int64_t)gridDim.x * kBlock) {
@@ -1570,7 +1570,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_values(
 // valc[k] = val[pos[k]]; *mismatch |= (val[pos[c*nnzc + k]] differs, c >= 1):
 // pos holds, component-major, where the entry k of F sits in each component's
 // rows of the full matrix
-__global__ __launch_bounds__(kBlock) void k_kron_gather(
+static __global__ __launch_bounds__(kBlock) void k_kron_gather(
     int nnzc, int nc, const int* __restrict__ pos, const double* val,
     double* valc, int* mismatch) {
   for (int k = blockIdx.x * kBlock + threadIdx.x; k < nnzc;
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(kBlock) void k_kron_gather(
 }
 
 // ---- BLAS-1 glue of the apply bodies --------------------------------------
-__global__ __launch_bounds__(kBlock) void k_copy(int n, const double* x,
+static __global__ __launch_bounds__(kBlock) void k_copy(int n, const double* x,
                                                   double* y) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
        i += gridDim.x * kBlock)
@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(kBlock) void k_copy(int n, const double* x,
 }
 
 // y = a*x + b*y  (b == 0 never reads y)
-__global__ __launch_bounds__(kBlock) void k_axpby(int n, double a,
+static __global__ __launch_bounds__(kBlock) void k_axpby(int n, double a,
                                                    const double* x, double b,
                                                    double* y) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(kBlock) void k_axpby(int n, double a,
 }
 
 // halo pack: out[i] = x[idx[i]]
-__global__ __launch_bounds__(kBlock) void k_pack(
+static __global__ __launch_bounds__(kBlock) void k_pack(
     int n, const int* __restrict__ idx, const double* x, double* out) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
        i += gridDim.x * kBlock)
@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(
 
 // slot[j] = sum parts[j*stride .. j*stride + n)   (one workgroup per j): the
 // rank-local value that then goes through ncclAllReduce
-__global__ __launch_bounds__(kBlock) void k_sum_parts(const double* parts,
+static __global__ __launch_bounds__(kBlock) void k_sum_parts(const double* parts,
                                                        int n, int stride,
                                                        double* slot) {
   __shared__ double sm[4];
@@ -1620,7 +1620,7 @@ __global__ __launch_bounds__(kBlock) void k_sum_parts(const double* parts,
 // in-process test backend (ranks = threads on one GPU): out = sum over ranks
 // of their operands, added in rank order on every rank (identical results)
 struct RankBufs { const double* p[16]; int n; };
-__global__ __launch_bounds__(kBlock) void k_sum_ranks(RankBufs bufs, int64_t count,
+static __global__ __launch_bounds__(kBlock) void k_sum_ranks(RankBufs bufs, int64_t count,
                                                        double* out) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count;
        i += (int64_t)gridDim.x * kBlock) {
@@ -1632,7 +1632,7 @@ __global__ __launch_bounds__(kBlock) void k_sum_ranks(RankBufs bufs, int64_t cou
 
 // z = x with the subfield BC values inserted (copy + VecSetValues fused):
 // slot[i] = position in val[] of row i's BC value, or -1
-__global__ __launch_bounds__(kBlock) void k_copy_bc(
+static __global__ __launch_bounds__(kBlock) void k_copy_bc(
     int n, const double* x, const int* __restrict__ slot,
     const double* __restrict__ val, double* z) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(kBlock) void k_copy_bc(
 }
 
 // SubfieldBC::apply: x[idx[i]] = val[i]  (VecSetValues INSERT)
-__global__ __launch_bounds__(kBlock) void k_bc_set(
+static __global__ __launch_bounds__(kBlock) void k_bc_set(
     int n_bc, const int* __restrict__ idx, const double* __restrict__ val,
     double* x) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1652,7 +1652,7 @@ __global__ __launch_bounds__(kBlock) void k_bc_set(
 
 // fieldsplit scatter: out[i] = in[perm[i]]  /  out[perm[i]] = in[i]
 // (four independent index -> value chains per thread in flight)
-__global__ __launch_bounds__(kBlock) void k_gather(
+static __global__ __launch_bounds__(kBlock) void k_gather(
     int n, const int* __restrict__ perm, const double* in, double* out) {
   const int stride = gridDim.x * kBlock;
   int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1664,7 +1664,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(
   }
   for (; i < n; i += stride) out[i] = in[perm[i]];
 }
-__global__ __launch_bounds__(kBlock) void k_scatter(
+static __global__ __launch_bounds__(kBlock) void k_scatter(
     int n, const int* __restrict__ perm, const double* in, double* out) {
   const int stride = gridDim.x * kBlock;
   int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1679,7 +1679,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(
 }
 
 // block values from the caller's monolithic value array
-__global__ __launch_bounds__(kBlock) void k_gather_vals(
+static __global__ __launch_bounds__(kBlock) void k_gather_vals(
     int64_t nnz, const int64_t* __restrict__ src, const double* vals,
     double* out) {
   for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz;
@@ -1688,7 +1688,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_vals(
 }
 
 // reciprocal diagonal (1 where the diagonal is zero or absent)
-__global__ __launch_bounds__(kBlock) void k_dinv(
+static __global__ __launch_bounds__(kBlock) void k_dinv(
     int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
     const double* __restrict__ val, double* dinv) {
   const int row = blockIdx.x * kBlock + threadIdx.x;
@@ -1702,7 +1702,7 @@ __global__ __launch_bounds__(kBlock) void k_dinv(
 // ---- GMRES: classical Gram-Schmidt as batched dots -------------------------
 // parts[(j0+jj)*G + blk] = sum_i V[(j0+jj)*ld + i] * w[i]
 constexpr int kDotTile = 8;
-__global__ __launch_bounds__(kBlock) void k_mdot(
+static __global__ __launch_bounds__(kBlock) void k_mdot(
     int64_t n, const double* V, int64_t ld, int nvec, const double* w,
     double* parts, int G) {
   __shared__ double sm[4];
@@ -1726,7 +1726,7 @@ __global__ __launch_bounds__(kBlock) void k_mdot(
 }
 
 // h[j] = sum_blk parts[j*G + blk]   (one workgroup per j)
-__global__ __launch_bounds__(kBlock) void k_mdot_reduce(const double* parts,
+static __global__ __launch_bounds__(kBlock) void k_mdot_reduce(const double* parts,
                                                          int G, double* h) {
   __shared__ double sm[4];
   const double s = reduce_parts(parts + (int64_t)blockIdx.x * G, G, sm);
@@ -1736,7 +1736,7 @@ __global__ __launch_bounds__(kBlock) void k_mdot_reduce(const double* parts,
 // w -= sum_j h[j] V_j ; parts[blk] = sum w^2.  The basis vectors are read
 // eight at a time into independent registers (the coefficients sit in LDS):
 // a dependent chain of nvec loads per element left most of the bandwidth idle.
-__global__ __launch_bounds__(kBlock) void k_maxpy_norm(
+static __global__ __launch_bounds__(kBlock) void k_maxpy_norm(
     int64_t n, const double* __restrict__ V, int64_t ld, int nvec,
     const double* __restrict__ h, double* __restrict__ w, double sign,
     double* __restrict__ parts) {
@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(kBlock) void k_maxpy_norm(
 }
 
 // nrm = sqrt(sum parts); w /= nrm; *out_nrm = nrm
-__global__ __launch_bounds__(kBlock) void k_normalize(
+static __global__ __launch_bounds__(kBlock) void k_normalize(
     int64_t n, double* w, const double* parts, int nparts, double* out_nrm) {
   __shared__ double sm[4];
   const double nrm = sqrt(reduce_parts(parts, nparts, sm));
@@ -1985,7 +1985,7 @@ __global__ __launch_bounds__(kBlock) void k_bw_read(int64_t n2, const double2* _
 }
 
 // copy (kind 0) / triad (kind 1), grid-stride
-__global__ __launch_bounds__(kBlock) void k_bw_probe(
+static __global__ __launch_bounds__(kBlock) void k_bw_probe(
     int kind, int64_t n2, const double2* __restrict__ b,
     const double2* __restrict__ c, double s, double2* __restrict__ a) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
@@ -2013,13 +2013,13 @@ struct GmresStatus {
   int pad;
 };
 
-__global__ void k_gmres_reset(double beta, int m, double* g, GmresStatus* st) {
+static __global__ void k_gmres_reset(double beta, int m, double* g, GmresStatus* st) {
   for (int i = threadIdx.x; i <= m; i += blockDim.x) g[i] = (i == 0) ? beta : 0.0;
   if (threadIdx.x == 0) { st->res = beta; st->done = 0; st->kconv = 0; st->code = 0; }
 }
 
 // H: column-major, leading dimension m + 1
-__global__ void k_gmres_column(int k, int m, const double* hcol, double* H,
+static __global__ void k_gmres_column(int k, int m, const double* hcol, double* H,
                                double* cs, double* sn, double* g, double tol,
                                GmresStatus* st) {
   if (threadIdx.x != 0 || st->done) return;
@@ -2044,7 +2044,7 @@ __global__ void k_gmres_column(int k, int m, const double* hcol, double* H,
 }
 
 // y = H(0:k,0:k)^-1 g(0:k) by back substitution (one wave; k <= 255)
-__global__ void k_gmres_ysolve(int k, int m, const double* H, const double* g,
+static __global__ void k_gmres_ysolve(int k, int m, const double* H, const double* g,
                                double* y) {
   __shared__ double ys[256];
   const int lane = threadIdx.x;
@@ -2059,7 +2059,7 @@ __global__ void k_gmres_ysolve(int k, int m, const double* H, const double* g,
 }
 
 // out = sum_j y[j] V_j
-__global__ __launch_bounds__(kBlock) void k_combine(
+static __global__ __launch_bounds__(kBlock) void k_combine(
     int64_t n, const double* V, int64_t ld, int nvec, const double* y,
     double* out) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;

@@ -67,7 +67,7 @@ struct PeerHaloDev {
   int* err = nullptr;                       // set when a wait gave up
 };
 
-__global__ __launch_bounds__(kBlock) void k_halo_xchg(PeerHaloDev d, const double* x,
+static __global__ __launch_bounds__(kBlock) void k_halo_xchg(PeerHaloDev d, const double* x,
                                                        long long spin_limit) {
   __shared__ int s_last;
   const unsigned long long seq_now = *d.seq + 1;      // (advanced by the last finisher)
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_halo_xchg(PeerHaloDev d, const doubl
 // for the neighbours' signals, lands the data in the ghost segment and
 // advances the sequence number.  Both read *d.seq before anyone advances it
 // (same stream, in order), so they agree on the exchange's number.
-__global__ __launch_bounds__(kBlock) void k_halo_send(PeerHaloDev d, const double* x) {
+static __global__ __launch_bounds__(kBlock) void k_halo_send(PeerHaloDev d, const double* x) {
   __shared__ int s_last;
   const unsigned long long seq_now = *d.seq + 1;
   const size_t p = (size_t)(seq_now & 1);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_halo_send(PeerHaloDev d, const doubl
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_halo_wait(PeerHaloDev d, long long spin_limit) {
+static __global__ __launch_bounds__(kBlock) void k_halo_wait(PeerHaloDev d, long long spin_limit) {
   const unsigned long long seq_now = *d.seq + 1;
   const size_t p = (size_t)(seq_now & 1);
   if ((int)threadIdx.x < d.nrp) {
@@ -178,7 +178,7 @@ struct PeerReduceDev {
   int* err = nullptr;
 };
 
-__global__ __launch_bounds__(kBlock) void k_peer_allreduce(PeerReduceDev d, double* buf, int count,
+static __global__ __launch_bounds__(kBlock) void k_peer_allreduce(PeerReduceDev d, double* buf, int count,
                                                             long long spin_limit) {
   __shared__ int s_last;
   const unsigned long long seq_now = *d.seq + 1;       // (advanced by the last finisher)

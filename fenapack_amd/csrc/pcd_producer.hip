@@ -1,0 +1,5 @@
+// pcd_producer.hip - device operator producer (pcd_fe_*)
+// (one of the engine's translation units; shared declarations: pcd_internal.hpp)
+#include "pcd_internal.hpp"
+
+#include "pcd_fe_host.hpp"

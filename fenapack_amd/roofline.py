@@ -61,7 +61,7 @@ def b_fieldsplit(n_u, n_p, nnz_a00, nnz_a01, pcd_bytes, k_f,
 
 
 def b_vcycle(mg_data, n_fine, nnz_fine):
-    """One V(nu, nu) cycle (pcd_engine.hip: mg_vcycle / mg_smooth): per level
+    """One V(nu, nu) cycle (pcd_apply.hip: mg_vcycle / mg_smooth): per level
     l >= 1 a Jacobi start (24 n), nu-1 + nu fused Chebyshev steps, the
     residual SpMV, restriction and prolongation-add SpMVs; level 0 is one
     dense SpMV; one final copy on the finest level."""

@@ -1,6 +1,6 @@
 """CPU suite: the host composition of inner solves (fenapack_amd/compose.py)
 against plain numpy restatements of the engine's recurrences (mg_smooth /
-solve_cheb / mg_vcycle in csrc/pcd_engine.hip).  The GPU suite
+solve_cheb / mg_vcycle in csrc/pcd_apply.hip).  The GPU suite
 (test_precomposed_gpu.py) then checks the engine's use of these operators
 against its own step-by-step path and the oracle."""
 import numpy as np

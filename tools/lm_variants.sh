@@ -4,13 +4,12 @@
 #   tools/lm_variants.sh "<flags>;<flags>;..." "<workload>" ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-SRC=fenapack_amd/csrc/pcd_engine.hip
 mkdir -p /tmp/pcdlibs
 IFS=';' read -ra VARS <<< "$1"
 shift
 i=0
 for V in "${VARS[@]}"; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC $V -o /tmp/pcdlibs/v$i.so $SRC &
+  tools/build_hip.sh /tmp/pcdlibs/v$i.so $V &
   i=$((i+1))
 done
 wait

@@ -43,7 +43,7 @@ def dispatches(root, counter):
 
 def kernels_sha16():
     h = hashlib.sha256()
-    for f in ("pcd_kernels.hpp", "pcd_engine.hip"):
+    for f in ("pcd_kernels.hpp", "pcd_apply.hip", "pcd_setup.hip"):
         h.update(open(os.path.join(ROOT, "fenapack_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

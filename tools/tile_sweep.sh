@@ -4,9 +4,8 @@
 # 3-D cube N = 32.  Builds the variants on the box (hipcc, ~15 s each).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-SRC=fenapack_amd/csrc/pcd_engine.hip
 mkdir -p /tmp/pcdlibs
-build() { /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC $1 -o /tmp/pcdlibs/$2.so $SRC; }
+build() { tools/build_hip.sh /tmp/pcdlibs/$2.so $1; }
 python3 tools/time_a00_kernel.py 6
 python3 tools/time_a00_kernel.py 3 cube
 for T2 in 1024 1536 3072; do
