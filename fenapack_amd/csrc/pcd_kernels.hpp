@@ -1307,15 +1307,19 @@ static_assert(lm_rows(2) <= 256 && lm_rows(3) <= 256, "one lane per row, 8-bit f
   __shared__ double lmT[NC * kBlock]
 
 // The epilogue's vector operands (b, D^-1, p_{k-1}; the result) are read /
-// written once per launch as well.  While the five vectors of a step fit the
-// Infinity Cache next to the gathered tile they are better kept (cube N = 48,
-// 22 MB each: 76.7 us with default-policy accesses, 81.4 non-temporal; cavity
-// level 7 53.1 / 58.9); beyond it (cube N = 73, 76 MB each) they only push the
-// tile's lines out: 313.5 -> 285.6 us non-temporal (profiles/r05_d_*).  The
-// host decides per operator (`epi_nt`).  Index streams (tile sources, row
-// offsets) non-temporal: no gain at any size (PCD_LM_NT_IDX, A/B).
+// written once per launch as well; non-temporal accesses to them (`epi_nt`,
+// PCD_LM_EPI_NT=1) bring nothing at any size on a same-box A/B - cube N = 73
+// 310.9 / 310.6 us, N = 48 75.3 / 75.2, cavity level 7 52.7 -> 55.6
+// (profiles/r05_g_*) - and stay off.  Index streams (tile sources, row
+// offsets) non-temporal: no gain either (PCD_LM_NT_IDX).
 #ifndef PCD_LM_NT_IDX
 #define PCD_LM_NT_IDX 0
+#endif
+#ifndef PCD_LM_TSRC_FIRST
+#define PCD_LM_TSRC_FIRST 1
+#endif
+#ifndef PCD_LM_TSRC_FIXED
+#define PCD_LM_TSRC_FIXED 1
 #endif
 template <class T>
 __device__ __forceinline__ T lm_idx_load(const T* p) {
@@ -1362,6 +1366,24 @@ __device__ __forceinline__ void lm_stage(
   typedef typename LmRegs<NC>::uv4 uv4;
   const int t = threadIdx.x;
   const int nr = d.w & 0x1ff, tn = (d.w >> 9) & 0x7ff, L = (d.w >> 20) & 0x1ff;
+  constexpr int NP = (TN + kBlock - 1) / kBlock;      // passes over the tile
+  int node[NP];
+  // Loads return in the order they were issued: the tile sources head the
+  // block's only chain of two dependent round trips (sources -> vector
+  // nodes), so they go first (PCD_LM_TSRC_FIRST) - with PCD_LM_TSRC_FIXED from
+  // an address that depends on the block index alone (stride TN, padded with
+  // -1), i.e. together with the descriptor
+#if PCD_LM_TSRC_FIRST
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int q = t + u * kBlock;
+#if PCD_LM_TSRC_FIXED
+    node[u] = q < TN ? lm_idx_load(tsrc + (size_t)blk * TN + q) : -1;
+#else
+    node[u] = q < tn ? lm_idx_load(tsrc + d.z + q) : -1;
+#endif
+  }
+#endif
   // the matrix stream: addresses known with the descriptor
   g.act = t < L;
   const dv2* vb = reinterpret_cast<const dv2*>(val) + (size_t)d.y * (kLmE / 2);
@@ -1373,13 +1395,18 @@ __device__ __forceinline__ void lm_stage(
   // entries [ra, rb) of the row whose sum this lane completes
   g.ra = t < nr ? lm_idx_load(rowoff + blk * RO + t) : 0;
   g.rb = t < nr ? lm_idx_load(rowoff + blk * RO + t + 1) : 0;
-  constexpr int NP = (TN + kBlock - 1) / kBlock;      // passes over the tile
-  int node[NP];
+#if !PCD_LM_TSRC_FIRST
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     const int q = t + u * kBlock;
+#if PCD_LM_TSRC_FIXED
+    node[u] = q < TN ? lm_idx_load(tsrc + (size_t)blk * TN + q) : -1;
+#else
     node[u] = q < tn ? lm_idx_load(tsrc + d.z + q) : -1;
+#endif
   }
+#endif
+  (void)tn;
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     if (node[u] < 0) continue;

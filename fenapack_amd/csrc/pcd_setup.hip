@@ -205,6 +205,21 @@ int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
       at += b_src[sb].size();
     }
   }
+#if PCD_LM_TSRC_FIXED
+  if (A.vt_lm) {
+    // tile sources at a fixed stride per block (padded with -1): their address
+    // depends on the block index alone
+    const int TN = lm_nodes(nc);
+    std::vector<int32_t> fixed(desc.size() * (size_t)TN, -1);
+    for (size_t j = 0; j < desc.size(); ++j) {
+      const int tn = (desc[j].w >> 9) & 0x7ff;
+      std::copy(tsrc.begin() + desc[j].z, tsrc.begin() + desc[j].z + tn, fixed.begin() + j * (size_t)TN);
+      desc[j].z = (int)(j * (size_t)TN);
+    }
+    if (fixed.size() > (size_t)INT32_MAX) return 0;
+    tsrc.swap(fixed);
+  }
+#endif
   // rows of hundreds of entries leave a handful of rows per block: most lanes
   // of the row-sum phase idle and the tile is loaded for nothing
   if ((double)nn < 8.0 * (double)desc.size()) return 0;
@@ -802,7 +817,7 @@ int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const int32_t
                              int64_t n_u, const int32_t* is_u, int64_t n_p, const int32_t* is_p,
                              std::vector<int32_t>& isu_r, std::vector<int32_t>& isp_r) {
   { const char* e = getenv("PCD_REORDER");
-    if (e) h->reorder_mode = !strcmp(e, "none") ? 0 : !strcmp(e, "always") ? 2 : 1; }
+    if (e) h->reorder_mode = !strcmp(e, "none") ? 0 : !strcmp(e, "always") ? 2 : !strcmp(e, "cluster") ? 3 : 1; }
   for (int64_t i = 0; i < n_u; ++i)
     if (is_u[i] < 0 || is_u[i] >= n) return fail(PCD_ERR_ARG, "set_system: index sets do not partition 0..n-1");
   for (int64_t i = 0; i < n_p; ++i)
@@ -835,8 +850,12 @@ int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const int32_t
         gp = grp.data(); gc = gcc.data();
       }
       const double m = locality_metric(nn, gp, gc);
-      if (h->reorder_mode == 2 || m > 0.1) {
-        std::vector<int32_t> nodes = rcm_order(nn, gp, gc);
+      if (h->reorder_mode >= 2 || m > 0.1) {
+        // ("cluster": graph balls of PCD_CLUSTER_NODES nodes in the caller's
+        // order instead of reverse Cuthill-McKee - for the vector-tile kernels)
+        static const int kc = [] { const char* e = getenv("PCD_CLUSTER_NODES"); return e && atoi(e) > 0 ? atoi(e) : 56; }();
+        std::vector<int32_t> nodes = h->reorder_mode == 3 && m <= 0.1 ? cluster_order(nn, gp, gc, kc)
+                                                                      : rcm_order(nn, gp, gc);
         h->ru.n2o = nc > 1 ? expand_nodes(nodes, nc) : nodes;
         h->ru.o2n = invert_perm(h->ru.n2o);
         // pressure: by the first (renumbered) velocity dof it couples to - only
@@ -867,7 +886,7 @@ int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const int32_t
 
 int pcd_set_reorder(pcd_handle h, int mode) {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
-  if (mode < 0 || mode > 2) return fail(PCD_ERR_ARG, "set_reorder: mode 0 (never), 1 (auto) or 2 (always)");
+  if (mode < 0 || mode > 3) return fail(PCD_ERR_ARG, "set_reorder: mode 0 (never), 1 (auto), 2 (always) or 3 (cluster)");
   h->reorder_mode = mode;
   return 0;
 }

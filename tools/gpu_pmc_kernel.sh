@@ -25,13 +25,13 @@ acc = {}
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "k_cheb_step_sc" not in n and "k_cheb_step_tc" not in n:
+        if "k_cheb_step_sc" not in n and "k_cheb_step_tc" not in n and "k_cheb_step_lm" not in n:
             continue
         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 if not acc:
     print("set [%s]: no data (counter names not accepted?)" % sets)
 for k, v in sorted(acc.items()):
-    print("%-40s mean %.6g over %d launches of k_cheb_step_[st]c" % (k, sum(v) / len(v), len(v)))
+    print("%-40s mean %.6g over %d launches of k_cheb_step_[st]c|lm" % (k, sum(v) / len(v), len(v)))
 PY
   rm -rf $OUT/${TAG}_pk_$i
 done
