@@ -482,6 +482,20 @@ static __global__ __launch_bounds__(kBlock) void k_gj_store(int n, int d, const 
   }
 }
 
+// the same without the entries that couple no components: row (k, c) of
+// inv(F) x I_d keeps its n entries (j, c), j ascending - the CSR order
+static __global__ __launch_bounds__(kBlock) void k_gj_store_compact(int n, int d, const double* __restrict__ W,
+                                                              const int* __restrict__ pivrow, double* out) {
+  const int64_t total = (int64_t)n * d * n;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = t / n;
+    const int j = (int)(t % n), k = (int)(r / d);
+    const int64_t p = pivrow[k];
+    out[t] = W[p * 2 * n + n + j] / W[p * 2 * n + k];
+  }
+}
+
 // ---- BRM2 boundary term of Kp: - (1/nu) int_{inflow} (w.n) p q ds ------------
 // (demo_navier-stokes-pcd.py:131-135).  One thread per boundary edge (2-D):
 // the P2 wind along the edge from its end points and midpoint, 3-point Gauss

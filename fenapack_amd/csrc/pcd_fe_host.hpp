@@ -242,7 +242,10 @@ static int fe_invert_coarsest(Engine* h, FeState& fe, MgLevel& M0) {
   // Newton: the coarsest operator is a coupled (d n0)^2 matrix, inverted whole
   const int n = (int)fe.inv_n, d = fe.newton ? 1 : fe.dim;
   const int64_t N = (int64_t)n * d;
-  if (!M0.A.set || M0.A.nrows != N || M0.A.nnz != N * N)
+  // (stored whole, or - Picard, d > 1 - as inv(F) (x) I_d without the entries
+  // that couple no components: n per row)
+  const bool compact = d > 1 && M0.A.nnz == N * n;
+  if (!M0.A.set || M0.A.nrows != N || (M0.A.nnz != N * N && !compact))
     return fail(PCD_ERR_STATE, "fe: multigrid level 0 is not the dense %lld x %lld inverse",
                 (long long)N, (long long)N);
   HIPCHK(hipMemsetAsync(fe.inv_flag.p, 0, sizeof(int), h->stream));
@@ -259,8 +262,12 @@ static int fe_invert_coarsest(Engine* h, FeState& fe, MgLevel& M0) {
   for (int k = 0; k < n; ++k)
     hipLaunchKernelGGL(k_gj_step, dim3(n), dim3(kBlock), 0, h->stream, n, k, fe.inv_W.p,
                        cc[k & 1], cc[(k + 1) & 1], fe.inv_piv.p, fe.inv_flag.p);
-  hipLaunchKernelGGL(k_gj_store, dim3(grid1d(N * N, 4, 1 << 16)), dim3(kBlock), 0, h->stream, n, d,
-                     fe.inv_W.p, fe.inv_piv.p, M0.A.val.p);
+  if (compact)
+    hipLaunchKernelGGL(k_gj_store_compact, dim3(grid1d(N * n, 4, 1 << 16)), dim3(kBlock), 0, h->stream, n, d,
+                       fe.inv_W.p, fe.inv_piv.p, M0.A.val.p);
+  else
+    hipLaunchKernelGGL(k_gj_store, dim3(grid1d(N * N, 4, 1 << 16)), dim3(kBlock), 0, h->stream, n, d,
+                       fe.inv_W.p, fe.inv_piv.p, M0.A.val.p);
   HIPCHK(hipGetLastError());
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, fe.inv_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));

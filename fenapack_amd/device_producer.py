@@ -378,6 +378,12 @@ class DeviceProducer(object):
                                      *mg["bounds"][l])
             if l == 0:
                 self._K0 = K     # (a one-level hierarchy: the same pattern)
+                # the coupled coarsest operator is inverted WHOLE on the
+                # device: level 0 holds the full (d n0)^2 inverse (the host's
+                # first hierarchy, built at w = 0 where the block is still
+                # F (x) I_d, handed over inv(F) once: re-create it)
+                N0 = n * d
+                eng.mg_set_level(c.KSP_A00, 0, dense_csr(np.zeros((N0, N0))))
             eng.fe_set_newton(l, block_positions(K, indptr, indices, d))
 
     def _bind_system(self):
@@ -483,7 +489,10 @@ class DeviceProducer(object):
         d = self.V.dim
         F0 = self._scalar(0).toarray()
         Finv = np.linalg.inv(F0)
-        C = dense_csr(np.kron(Finv, np.eye(d)))
+        # (the layout fem.multigrid.coarse_inverse hands over: inv(F) (x) I_d
+        # without the entries that couple no components)
+        from . import _host
+        C = _host.kron_expand(dense_csr(Finv), d)
         self.eng.mg_update_values(c.KSP_A00, 0, C.data)
 
     def _scalar(self, l):

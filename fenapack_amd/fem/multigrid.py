@@ -266,12 +266,11 @@ def coarse_inverse(A0, block=1):
     scalar factor is inverted (``inv(F (x) I) = inv(F) (x) I``)."""
     F = _kron_factor(A0, block)
     if F is not None:
-        Ci = coarse_inverse(F, 1).toarray()
-        n = Ci.shape[0]
-        C = np.zeros((n, block, n, block))
-        for k in range(block):
-            C[:, k, :, k] = Ci
-        return dense_csr(C.reshape(n * block, n * block))
+        # inv(F) (x) I with the entries that couple no components NOT stored:
+        # n entries per row instead of n * block - the engine recognises the
+        # structure and reads inv(F) once for all components (k_dense_c<NC>;
+        # cube N = 48, 6591 coarse dofs: 347 MB -> 39 MB per cycle)
+        return _host.kron_expand(coarse_inverse(F, 1), block)
     D = A0.toarray()
     try:
         C = np.linalg.inv(D)

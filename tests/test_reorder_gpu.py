@@ -224,6 +224,21 @@ def test_permuted_numbering_same_result_same_speed(hip_lib, monkeypatch, kind,
     # input taken as it comes costs only 7-10 % more, so this is a sanity bound,
     # loose enough for a busy box - the numbers printed above are the record)
     assert t1 <= 1.6 * t0, (t0, t1)
+    # PCD_REORDER=cluster: graph balls of nodes numbered consecutively, so
+    # that a row block of the vector-tile kernels touches fewer distinct
+    # columns (pcd_reorder.hpp cluster_order) - on the LEXICOGRAPHIC input;
+    # the same operator in another numbering: same result
+    monkeypatch.setenv("PCD_REORDER", "cluster")
+    monkeypatch.setenv("PCD_VEC_TILE", "2")
+    e3 = _engine(hip_lib, st, base, mg0)
+    assert int(e3.info(c.INFO_REORDERED)) == 3
+    assert relerr(e3.fieldsplit_apply_np(x), y0) < 1e-11
+    assert relerr(e3.spmv_np(c.MAT_A00, xu, V.n_u), L["A00"] @ xu) < 1e-13
+    assert relerr(e3.spmv_np(c.MAT_A01, xp, V.n_u), L["A01"] @ xp) < 1e-13
+    x3, its3, _ = e3.gmres_np(b, rtol=1e-6, restart=150, max_it=300)
+    assert abs(its3 - its0) <= max(2, its0 // 4), (its0, its3)
+    monkeypatch.delenv("PCD_VEC_TILE")
+    monkeypatch.setenv("PCD_REORDER", "none")
     # the device producer addresses entries in its caller's numbering
     with pytest.raises(c.EngineError, match="renumbered"):
         qw = np.ones(3) / 3
