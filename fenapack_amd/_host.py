@@ -68,6 +68,13 @@ def library():
     L.pcdh_spgemm_count.argtypes = [ctypes.c_int64, ctypes.c_int64,
                                     ctypes.c_int64, _I32P, _I32P, _I32P,
                                     _I32P, _I64P]
+    L.pcdh_product_plan_count.argtypes = [ctypes.c_int64, ctypes.c_int64,
+                                          _I32P, _I32P, _I32P, _I32P, _I64P,
+                                          _I64P]
+    L.pcdh_product_plan_fill.argtypes = [ctypes.c_int64, ctypes.c_int64,
+                                         _I32P, _I32P, _F64P, _I32P, _I32P,
+                                         _F64P, ctypes.c_int, _I64P, _I64P,
+                                         _I32P, _I64P, _I32P, _F64P]
     L.pcdh_spgemm_fill.argtypes = [ctypes.c_int64, ctypes.c_int64,
                                    ctypes.c_int64, _I32P, _I32P, _F64P, _I32P,
                                    _I32P, _F64P, _I64P, _I32P, _F64P]
@@ -233,6 +240,44 @@ def spgemm(A, B, row0=0, row1=None):
     C = sp.csr_matrix((cv, cc, idx), shape=(row1 - row0, B.shape[1]))
     C.has_sorted_indices = True
     return C
+
+
+def product_plan(A, B, mode):
+    """Gather plan of ``C = A @ B`` on its structural pattern
+    (``pcdh_product_plan_*``): returns ``(c_indptr, c_indices, ptr, src, w)`` -
+    entry ``e`` of ``C`` (CSR order) is ``sum(w[t] * X[src[t]])`` over
+    ``t in ptr[e]:ptr[e+1]`` with ``X`` = the values of ``A`` (``mode`` 0, the
+    weights are ``B``'s) or of ``B`` (``mode`` 1, the weights are ``A``'s)."""
+    import scipy.sparse as sp
+    A, B = sp.csr_matrix(A), sp.csr_matrix(B)
+    assert A.shape[1] == B.shape[0]
+    for M in (A, B):
+        if not M.has_sorted_indices:
+            M.sort_indices()
+    arp, ac, av = _i32(A.indptr), _i32(A.indices), \
+        np.ascontiguousarray(A.data, dtype=np.float64)
+    brp, bc, bv = _i32(B.indptr), _i32(B.indices), \
+        np.ascontiguousarray(B.data, dtype=np.float64)
+    L = library()
+    n = A.shape[0]
+    crp = np.empty(n + 1, dtype=np.int64)
+    trp = np.empty(n + 1, dtype=np.int64)
+    _chk(L.pcdh_product_plan_count(n, B.shape[1], _p(arp, _I32P), _p(ac, _I32P),
+                                   _p(brp, _I32P), _p(bc, _I32P),
+                                   _p(crp, _I64P), _p(trp, _I64P)))
+    nnz, nt = int(crp[-1]), int(trp[-1])
+    if max(nnz, nt, A.nnz, B.nnz) >= 2 ** 31:
+        raise ValueError("product_plan: more than 2^31 entries / terms")
+    cc = np.empty(nnz, dtype=np.int32)
+    ptr = np.empty(nnz + 1, dtype=np.int64)
+    src = np.empty(nt, dtype=np.int32)
+    w = np.empty(nt, dtype=np.float64)
+    _chk(L.pcdh_product_plan_fill(n, B.shape[1], _p(arp, _I32P), _p(ac, _I32P),
+                                  _p(av, _F64P), _p(brp, _I32P), _p(bc, _I32P),
+                                  _p(bv, _F64P), int(mode), _p(crp, _I64P),
+                                  _p(trp, _I64P), _p(cc, _I32P), _p(ptr, _I64P),
+                                  _p(src, _I32P), _p(w, _F64P)))
+    return crp, cc, ptr, src, w
 
 
 def transpose(A):

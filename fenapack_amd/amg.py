@@ -93,10 +93,24 @@ def aggregate(S, seed=0, distance=2):
     n = S.shape[0]
     pat = sp.csr_matrix((np.ones(S.nnz), S.indices, S.indptr), shape=S.shape)
     if distance >= 2:
-        G2 = (pat @ pat + pat).tocsr()
-        G2.setdiag(0)
-        G2.eliminate_zeros()
-        G2.sort_indices()
+        # vertices within two edges: the off-diagonal pattern of (pat + I)^2
+        # (= pat^2 + pat off the diagonal); one product - the threaded native
+        # SpGEMM from a few 10^5 entries - and the diagonal dropped on the
+        # arrays (scipy's setdiag goes through COO: 2 s of 6 at cube N = 28)
+        pI = (pat + sp.identity(n, format="csr")).tocsr()
+        if pI.nnz > 400000 and not _host.use_numpy():
+            pI.sort_indices()
+            G2 = _host.spgemm(pI, pI)
+        else:
+            G2 = (pI @ pI).tocsr()
+            G2.sort_indices()
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(G2.indptr))
+        keep = rows != G2.indices
+        indptr = np.zeros(n + 1, dtype=G2.indptr.dtype)
+        np.cumsum(np.bincount(rows[keep], minlength=n), out=indptr[1:])
+        G2 = sp.csr_matrix((np.ones(int(keep.sum())), G2.indices[keep], indptr),
+                           shape=(n, n))
+        G2.has_sorted_indices = True
     else:
         G2 = pat          # MIS-1: roots two edges apart, aggregates = stars
     isolated = np.diff(S.indptr) == 0

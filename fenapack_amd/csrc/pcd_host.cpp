@@ -385,6 +385,73 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols, const int32_t* 
   return 0;
 }
 
+// ---------------------------------------------------- plan of a sparse product
+// C = A B on a fixed pattern, as a GATHER PLAN: for every entry of C the list
+// of products that sum to it, so that later numeric products are one weighted
+// gather on the device (pcd_fe_set_level_galerkin).  Entry (i, J) of C lists
+// its terms in the order of A's row i (then B's row): the order the numpy
+// builder's stable grouping yields.  mode 0: term = (index of the A entry,
+// weight = the B value) - B = F P with F changing, P fixed; mode 1: term =
+// (index of the B entry, weight = the A value) - F_c = P^T B with B changing.
+int pcdh_product_plan_count(int64_t nrows, int64_t b_cols, const int32_t* arp,
+                            const int32_t* ac, const int32_t* brp, const int32_t* bc,
+                            int64_t* crp, int64_t* trp) {
+  if (nrows < 0 || b_cols < 0 || !arp || !brp || !crp || !trp)
+    return fail(PCDH_ERR_ARG, "product_plan_count: bad arguments");
+  const int T = nthreads(nrows * 64);
+  crp[0] = 0; trp[0] = 0;
+#pragma omp parallel num_threads(T)
+  {
+    std::vector<int64_t> mark(b_cols, -1);
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = 0; i < nrows; ++i) {
+      int64_t cnt = 0, terms = 0;
+      for (int32_t k = arp[i]; k < arp[i + 1]; ++k) {
+        const int32_t j = ac[k];
+        terms += brp[j + 1] - brp[j];
+        for (int32_t q = brp[j]; q < brp[j + 1]; ++q)
+          if (mark[bc[q]] != i) { mark[bc[q]] = i; ++cnt; }
+      }
+      crp[i + 1] = cnt; trp[i + 1] = terms;
+    }
+  }
+  for (int64_t i = 0; i < nrows; ++i) { crp[i + 1] += crp[i]; trp[i + 1] += trp[i]; }
+  return 0;
+}
+
+int pcdh_product_plan_fill(int64_t nrows, int64_t b_cols, const int32_t* arp, const int32_t* ac,
+                           const double* av, const int32_t* brp, const int32_t* bc,
+                           const double* bv, int mode, const int64_t* crp, const int64_t* trp,
+                           int32_t* cc, int64_t* ptr, int32_t* src, double* w) {
+  if (nrows < 0 || !arp || !brp || !crp || !trp || !ptr || (mode != 0 && mode != 1) ||
+      (mode == 0 ? !bv : !av) || (crp[nrows] && !cc) || (trp[nrows] && (!src || !w)))
+    return fail(PCDH_ERR_ARG, "product_plan_fill: bad arguments");
+  const int T = nthreads(nrows * 64);
+  (void)b_cols;
+#pragma omp parallel num_threads(T)
+  {
+    struct Term { int32_t col, src; double w; };
+    std::vector<Term> buf;
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = 0; i < nrows; ++i) {
+      buf.clear();
+      for (int32_t k = arp[i]; k < arp[i + 1]; ++k) {
+        const int32_t j = ac[k];
+        for (int32_t q = brp[j]; q < brp[j + 1]; ++q)
+          buf.push_back(Term{bc[q], mode == 0 ? k : q, mode == 0 ? bv[q] : av[k]});
+      }
+      std::stable_sort(buf.begin(), buf.end(), [](const Term& x, const Term& y) { return x.col < y.col; });
+      int64_t e = crp[i], t = trp[i];
+      for (size_t p = 0; p < buf.size(); ++p) {
+        if (p == 0 || buf[p].col != buf[p - 1].col) { cc[e] = buf[p].col; ptr[e] = t; ++e; }
+        src[t] = buf[p].src; w[t] = buf[p].w; ++t;
+      }
+    }
+  }
+  ptr[crp[nrows]] = trp[nrows];
+  return 0;
+}
+
 // ----------------------------------------------------------------------- SpMV
 int pcdh_spmv(int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
               const double* x, const double* scale, double* y) {

@@ -116,6 +116,28 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols,
                      const int32_t* b_col, const double* b_val,
                      const int64_t* c_rowptr, int32_t* c_col, double* c_val);
 
+/* ---- gather plan of a sparse product ------------------------------------------
+ * C = A B on a fixed pattern as a plan: for every entry of C (rows of A in
+ * order, columns ascending; c_rowptr / c_col) the terms that sum to it
+ * (ptr[e] .. ptr[e + 1] in src / w), in the order of A's row.  mode 0: src =
+ * index of the A entry, w = the B value (B = F P: F changes, P is fixed);
+ * mode 1: src = index of the B entry, w = the A value (F_c = P^T B).  The
+ * device-side Galerkin refresh of the multigrid hierarchies
+ * (pcd_fe_set_level_galerkin; what hypre's set-up redoes per outer iteration in
+ * demo_navier-stokes-pcd.py:153-160).  Two calls: counts (entries and terms per
+ * row, as row pointers), then fill.
+ */
+int pcdh_product_plan_count(int64_t nrows, int64_t b_cols, const int32_t* a_rowptr,
+                            const int32_t* a_col, const int32_t* b_rowptr,
+                            const int32_t* b_col, int64_t* c_rowptr /* nrows + 1 */,
+                            int64_t* t_rowptr /* nrows + 1 */);
+int pcdh_product_plan_fill(int64_t nrows, int64_t b_cols, const int32_t* a_rowptr,
+                           const int32_t* a_col, const double* a_val,
+                           const int32_t* b_rowptr, const int32_t* b_col,
+                           const double* b_val, int mode, const int64_t* c_rowptr,
+                           const int64_t* t_rowptr, int32_t* c_col,
+                           int64_t* ptr /* nnz(C) + 1 */, int32_t* src, double* w);
+
 /* ---- y = scale .* (A x) ------------------------------------------------------
  * Threaded CSR SpMV (row sums in ascending entry order: bitwise what scipy's
  * csr_matvec gives).  The host-side power iterations behind

@@ -142,3 +142,43 @@ def test_kron_layout_of_a_level_matches_scipy():
     # scipy keeps the structural zeros of kron(F, I)? it does not store them:
     assert K.nnz == d * pat.nnz
     assert np.array_equal(got, K.data)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_native_galerkin_plan_is_the_numpy_plan_term_for_term(dim, monkeypatch):
+    """``libpcd_host``'s product-plan builder (threads over the rows) against
+    the numpy builder: the same entries, the same terms in the same order -
+    so the device's weighted gathers add in the same order whichever built
+    the plan.  Smoothed-aggregation prolongator (several entries per row)."""
+    import scipy.sparse as sp
+    from fenapack_amd import _host
+    from fenapack_amd import device_producer as dp
+    from fenapack_amd.amg import smoothed_aggregation_chain
+    from fenapack_amd.fem import Cavity, Cavity3D
+    if _host.use_numpy():
+        pytest.skip("libpcd_host is not in use (FENAPACK_AMD_HOST=numpy)")
+    pb = Cavity(3, nu=0.01) if dim == 2 else Cavity3D(0, nu=0.01, n0=8)
+    V = pb.space
+    A00 = sp.csr_matrix(pb.linearise(np.zeros(V.n_u), np.zeros(V.n_p))["A00"])
+    chain = smoothed_aggregation_chain(A00, block=dim, coarse_rows=200,
+                                       theta=0.02)
+    F = _host.kron_factor(A00, dim)
+    Ps = sp.csr_matrix(chain[-1])[::dim, ::dim]
+    rows_f = np.repeat(np.arange(F.shape[0]), np.diff(F.indptr))
+    nat = dp.galerkin_plan(rows_f, F.indices, Ps)
+    monkeypatch.setattr(_host, "use_numpy", lambda: True)
+    ref = dp.galerkin_plan(rows_f, F.indices, Ps)
+    assert len(nat) == len(ref) == 8
+    for a, b in zip(nat, ref):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    # ... and the plan computes the product
+    Fv = np.random.default_rng(0).standard_normal(F.nnz)
+    Fm = sp.csr_matrix((Fv, F.indices, F.indptr), shape=F.shape)
+    b_ptr, b_src, b_w, c_ptr, c_src, c_w, ip, ix = nat
+    B = np.add.reduceat(np.append(b_w * Fv[b_src], 0.0), b_ptr[:-1])
+    B[np.diff(b_ptr) == 0] = 0.0
+    C = np.add.reduceat(np.append(c_w * B[c_src], 0.0), c_ptr[:-1])
+    C[np.diff(c_ptr) == 0] = 0.0
+    got = sp.csr_matrix((C, ix, ip), shape=(Ps.shape[1],) * 2)
+    ref_m = (Ps.T @ Fm @ Ps).tocsr()
+    assert abs(got - ref_m).max() < 1e-12 * abs(ref_m).max()
