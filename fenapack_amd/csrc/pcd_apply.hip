@@ -464,11 +464,7 @@ int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
 #define PCD_CHEB_LM(NC)                                                                        \
     hipLaunchKernelGGL((k_cheb_step_lm<NC>), dim3(gt), dim3(kBlock), 0, h->stream,            \
                        vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.vt_val.p,     \
-                       A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc, epi_nt)
-    // (non-temporal accesses to the step's vectors: measured neutral or worse)
-    // (PCD_LM_EPI_NT = 0 / 1: A/B switch)
-    static const int epi_force = [] { const char* e = getenv("PCD_LM_EPI_NT"); return e ? atoi(e) : -1; }();
-    const int epi_nt = epi_force > 0;
+                       A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
     if (A.kron == 2) PCD_CHEB_LM(2); else PCD_CHEB_LM(3);
 #undef PCD_CHEB_LM
   } else if (tile) {

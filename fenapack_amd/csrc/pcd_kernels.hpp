@@ -1256,10 +1256,11 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_tc(
 
 // ==========================================================================
 // LANE-MAJOR form of the vector-tile kernels (operators streamed from HBM).
-// The staged form above passes every (value, offset) pair through LDS: 10 B
-// written + 10 B + 8 NC B read per entry, and the entry buffers are half of
-// the workgroup's LDS, i.e. they decide how many workgroups a CU holds - which
-// is what the launch time follows (profiles/r04_j_*: T = a + b / W).  Here the
+// Round 4's form for such operators passed every (value, offset) pair through
+// LDS: 10 B written + 10 B + 8 NC B read per entry, and the entry buffers were
+// half of the workgroup's LDS, i.e. they decided how many workgroups a CU
+// holds - which is what its launch time followed (profiles/r04_j_*: T = a +
+// b / W).  Here the
 // set-up stores each block's entries LANE-MAJOR: lane t owns the kLmE = 8
 // CONSECUTIVE entries 8 t .. 8 t + 7 of the block's row-major stream (blocks
 // are padded to whole lanes with zero entries: < 0.4 % of the stream); the
@@ -1299,50 +1300,22 @@ static_assert(lm_nodes(2) <= 2048 && lm_nodes(3) <= 2048, "11-bit tile slots");
 static_assert(lm_rows(2) <= 256 && lm_rows(3) <= 256, "one lane per row, 8-bit first rows");
 // descriptor: x = first row, y = lanes of all blocks before this one (its
 // values start at 8 y doubles, its offsets at 8 y shorts), z = first slot in
-// `tsrc`, w = rows | tile nodes << 9 | active lanes << 20
+// `tsrc` (= block x lm_nodes: a fixed stride, padded with -1), w = rows |
+// tile nodes << 9 | active lanes << 20
 
 #define PCD_LM_SHARED(NC)                                   \
   __shared__ double tile[NC * lm_nodes(NC)];                \
   __shared__ double lmR[NC * lm_rows(NC)];                  \
   __shared__ double lmT[NC * kBlock]
 
-// The epilogue's vector operands (b, D^-1, p_{k-1}; the result) are read /
-// written once per launch as well; non-temporal accesses to them (`epi_nt`,
-// PCD_LM_EPI_NT=1) bring nothing at any size on a same-box A/B - cube N = 73
-// 310.9 / 310.6 us, N = 48 75.3 / 75.2, cavity level 7 52.7 -> 55.6
-// (profiles/r05_g_*) - and stay off.  Index streams (tile sources, row
-// offsets) non-temporal: no gain either (PCD_LM_NT_IDX).
-#ifndef PCD_LM_NT_IDX
-#define PCD_LM_NT_IDX 0
-#endif
-#ifndef PCD_LM_TSRC_FIRST
-#define PCD_LM_TSRC_FIRST 1
-#endif
-#ifndef PCD_LM_TSRC_FIXED
-#define PCD_LM_TSRC_FIXED 1
-#endif
-template <class T>
-__device__ __forceinline__ T lm_idx_load(const T* p) {
-  if (PCD_LM_NT_IDX) return __builtin_nontemporal_load(p);
-  return *p;
-}
-template <int NC>
-__device__ __forceinline__ VecC<NC> lm_epi_load(const VecC<NC>* p, bool nt) {
-  if (!nt) return *p;
-  VecC<NC> r;
-  const double* q = reinterpret_cast<const double*>(p);
-#pragma unroll
-  for (int i = 0; i < NC; ++i) r.c[i] = __builtin_nontemporal_load(q + i);
-  return r;
-}
-template <int NC>
-__device__ __forceinline__ void lm_epi_store(VecC<NC>* p, const VecC<NC>& v, bool nt) {
-  if (!nt) { *p = v; return; }
-  double* q = reinterpret_cast<double*>(p);
-#pragma unroll
-  for (int i = 0; i < NC; ++i) __builtin_nontemporal_store(v.c[i], q + i);
-}
-
+// Measured and not kept (profiles/r05_b_* ... r05_i_*; the switches are gone):
+// non-temporal accesses to the epilogue's vectors (same-box A/B: cube N = 73
+// 310.9 / 310.6 us, N = 48 75.3 / 75.2, cavity level 7 52.7 -> 55.6), non-
+// temporal index streams (+ 6 %), the tile sources after the entries (cube
+// N = 48: 75.0 against 69.7 us) or at their compact positions (69.7 against
+// 68.5), the epilogue's operands with the block's first loads (N = 73: 312 ->
+// 309, level 7 55.5 -> 53.7 with them late), a register allocation forced to
+// eight waves per SIMD (spills: 81.3 against 74.0 at N = 48).
 template <int NC>
 struct LmRegs {
   typedef double dv2 __attribute__((ext_vector_type(2)));
@@ -1365,25 +1338,18 @@ __device__ __forceinline__ void lm_stage(
   typedef typename LmRegs<NC>::dv2 dv2;
   typedef typename LmRegs<NC>::uv4 uv4;
   const int t = threadIdx.x;
-  const int nr = d.w & 0x1ff, tn = (d.w >> 9) & 0x7ff, L = (d.w >> 20) & 0x1ff;
+  const int nr = d.w & 0x1ff, L = (d.w >> 20) & 0x1ff;
   constexpr int NP = (TN + kBlock - 1) / kBlock;      // passes over the tile
   int node[NP];
   // Loads return in the order they were issued: the tile sources head the
   // block's only chain of two dependent round trips (sources -> vector
-  // nodes), so they go first (PCD_LM_TSRC_FIRST) - with PCD_LM_TSRC_FIXED from
-  // an address that depends on the block index alone (stride TN, padded with
-  // -1), i.e. together with the descriptor
-#if PCD_LM_TSRC_FIRST
+  // nodes), so they go first - from an address that depends on the block
+  // index alone (stride TN, padded with -1), i.e. together with the descriptor
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     const int q = t + u * kBlock;
-#if PCD_LM_TSRC_FIXED
-    node[u] = q < TN ? lm_idx_load(tsrc + (size_t)blk * TN + q) : -1;
-#else
-    node[u] = q < tn ? lm_idx_load(tsrc + d.z + q) : -1;
-#endif
+    node[u] = q < TN ? tsrc[(size_t)blk * TN + q] : -1;
   }
-#endif
   // the matrix stream: addresses known with the descriptor
   g.act = t < L;
   const dv2* vb = reinterpret_cast<const dv2*>(val) + (size_t)d.y * (kLmE / 2);
@@ -1393,20 +1359,8 @@ __device__ __forceinline__ void lm_stage(
   g.le = uv4(0u);
   if (g.act) g.le = __builtin_nontemporal_load(reinterpret_cast<const uv4*>(loc) + d.y + t);
   // entries [ra, rb) of the row whose sum this lane completes
-  g.ra = t < nr ? lm_idx_load(rowoff + blk * RO + t) : 0;
-  g.rb = t < nr ? lm_idx_load(rowoff + blk * RO + t + 1) : 0;
-#if !PCD_LM_TSRC_FIRST
-#pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    const int q = t + u * kBlock;
-#if PCD_LM_TSRC_FIXED
-    node[u] = q < TN ? lm_idx_load(tsrc + (size_t)blk * TN + q) : -1;
-#else
-    node[u] = q < tn ? lm_idx_load(tsrc + d.z + q) : -1;
-#endif
-  }
-#endif
-  (void)tn;
+  g.ra = t < nr ? rowoff[blk * RO + t] : 0;
+  g.rb = t < nr ? rowoff[blk * RO + t + 1] : 0;
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     if (node[u] < 0) continue;
@@ -1463,23 +1417,10 @@ __device__ __forceinline__ VecC<NC> lm_sum(const LmRegs<NC>& g, const double* ti
   return sum;
 }
 
-// epilogue operands requested with the block's first loads (0) or after its
-// first barrier, when the tile's registers are free again (1)
-#ifndef PCD_LM_LATE_EPI
-#define PCD_LM_LATE_EPI 1
-#endif
-// waves per SIMD the register allocation aims at (0: the compiler's choice)
-#ifndef PCD_LM_WAVES
-#define PCD_LM_WAVES 0
-#endif
-#if PCD_LM_WAVES
-#define PCD_LM_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PCD_LM_WAVES, PCD_LM_WAVES)))
-#else
-#define PCD_LM_BOUNDS __launch_bounds__(kBlock)
-#endif
-
+// (the epilogue's operands are requested after the block's first barrier,
+// when the tile's registers are free again)
 template <int MODE, int NC>
-__global__ PCD_LM_BOUNDS void k_spmv_lm(
+__global__ __launch_bounds__(kBlock) void k_spmv_lm(
     PCD_VT_ARGS, const double* x, const double* ghost, int nloc, const double* add_,
     double* y_) {
   PCD_LM_SHARED(NC);
@@ -1494,9 +1435,8 @@ __global__ PCD_LM_BOUNDS void k_spmv_lm(
     const bool mine = (int)threadIdx.x < (d.w & 0x1ff);
     VecC<NC> a = vzero<NC>();
     LmRegs<NC> g;
-    if (!PCD_LM_LATE_EPI && (MODE == 1 || MODE == 2) && mine) a = add[row];
     lm_stage<NC>(g, d, rowoff, blk, tsrc, val, loc, x, ghost, nloc, tile);
-    if (PCD_LM_LATE_EPI && (MODE == 1 || MODE == 2) && mine) a = add[row];
+    if ((MODE == 1 || MODE == 2) && mine) a = add[row];
     const VecC<NC> s = lm_sum<NC>(g, tile, lmR, lmT);
     if (mine) {
       VecC<NC> o;
@@ -1510,12 +1450,11 @@ __global__ PCD_LM_BOUNDS void k_spmv_lm(
 }
 
 template <int NC>
-__global__ PCD_LM_BOUNDS void k_cheb_step_lm(
+__global__ __launch_bounds__(kBlock) void k_cheb_step_lm(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, const double* pm_,
     const double* pk_, double* pn_, double c0, double c1, double c2,
-    const double* ghost, int nloc, int epi_nt) {
+    const double* ghost, int nloc) {
   PCD_LM_SHARED(NC);
-  const bool nt = epi_nt != 0;
   const VecC<NC>*dinv = vc<NC>(dinv_), *b = vc<NC>(b_), *pm = vc<NC>(pm_),
                *pk = vc<NC>(pk_);
   VecC<NC>* pn = vc<NC>(pn_);
@@ -1528,14 +1467,10 @@ __global__ PCD_LM_BOUNDS void k_cheb_step_lm(
     const bool mine = (int)threadIdx.x < (d4.w & 0x1ff);
     VecC<NC> bi = vzero<NC>(), d = bi, xk = bi, xm = bi;
     LmRegs<NC> g;
-    if (!PCD_LM_LATE_EPI && mine) {
-      bi = lm_epi_load<NC>(b + row, nt); d = lm_epi_load<NC>(dinv + row, nt); xk = pk[row];
-      if (c0 != 0.0) xm = lm_epi_load<NC>(pm + row, nt);
-    }
     lm_stage<NC>(g, d4, rowoff, blk, tsrc, val, loc, pk_, ghost, nloc, tile);
-    if (PCD_LM_LATE_EPI && mine) {
-      bi = lm_epi_load<NC>(b + row, nt); d = lm_epi_load<NC>(dinv + row, nt); xk = pk[row];
-      if (c0 != 0.0) xm = lm_epi_load<NC>(pm + row, nt);
+    if (mine) {
+      bi = b[row]; d = dinv[row]; xk = pk[row];
+      if (c0 != 0.0) xm = pm[row];
     }
     const VecC<NC> s = lm_sum<NC>(g, tile, lmR, lmT);
     if (mine) {
@@ -1543,13 +1478,13 @@ __global__ PCD_LM_BOUNDS void k_cheb_step_lm(
 #pragma unroll
       for (int i = 0; i < NC; ++i)
         o.c[i] = c0 * xm.c[i] + c1 * xk.c[i] + c2 * d.c[i] * (bi.c[i] - s.c[i]);
-      lm_epi_store<NC>(pn + row, o, nt);
+      pn[row] = o;
     }
   }
 }
 
 template <int NC>
-__global__ PCD_LM_BOUNDS void k_cheb_first_lm(
+__global__ __launch_bounds__(kBlock) void k_cheb_first_lm(
     PCD_VT_ARGS, const double* __restrict__ dinv_, const double* b_, double* p0_,
     double* pn_, double s, double c1, double c2, const double* ghost, int nloc,
     const double* __restrict__ dghost) {
@@ -1565,11 +1500,10 @@ __global__ PCD_LM_BOUNDS void k_cheb_first_lm(
     const bool mine = (int)threadIdx.x < (d4.w & 0x1ff);
     VecC<NC> d = vzero<NC>(), bi = d;
     LmRegs<NC> g;
-    if (!PCD_LM_LATE_EPI && mine) { d = dinv[row]; bi = b[row]; }
     // (the tile holds D^-1 b - b with its halo when there are several ranks,
     // the reciprocal diagonal of the ghost columns kept from its own exchange)
     lm_stage<NC>(g, d4, rowoff, blk, tsrc, val, loc, b_, ghost, nloc, tile, dinv_, dghost);
-    if (PCD_LM_LATE_EPI && mine) { d = dinv[row]; bi = b[row]; }
+    if (mine) { d = dinv[row]; bi = b[row]; }
     const VecC<NC> sum = lm_sum<NC>(g, tile, lmR, lmT);
     if (mine) {
       VecC<NC> x0, o;

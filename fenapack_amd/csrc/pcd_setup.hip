@@ -114,11 +114,11 @@ int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   // count: level-6 PCApply 0.3093 -> 0.2989 ms with tiles on level 5 as well,
   // 0.3014 with level 4 (26 k node rows) too (profiles/r04_k_*).
   // Measured, k_cheb_step on the finest A00 of the unit cube, us per launch
-  // (profiles/r04_q_vt_sweep*.txt, r04_e_*, r04_f_*): N = 32 (90 MB per
-  // launch, cache-resident) gather kernel 34.9, tile kernel 27.1-29.6;
-  // N = 48 (428 MB per launch, HBM-bound) 110.8 against 91.3 in the staged
-  // non-temporal form (123.9 with default-policy loads, 157 with
-  // non-temporal loads read by rows).
+  // (profiles/r04_q_vt_sweep*.txt, r04_e_*, r05_a_* ... r05_i_*): N = 32 (90 MB
+  // per launch, cache-resident) gather kernel 34.9, tile kernel (direct form)
+  // 27.3; N = 48 (428 MB per launch, HBM-bound) 110.8 against 68.5 in the
+  // lane-major form (85.4 with the entries staged in LDS, round 4; 123.9 in the
+  // direct form).
   if (!g_vec_tile || (g_vec_tile == 1 && nn < g_vec_tile_rows)) return 0;
   if (nn < 1 || A.dense2 || A.long_rows || A.wave_rows) return 0;
   // independent super-blocks of rows: block boundaries restart at multiples of
@@ -205,7 +205,6 @@ int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
       at += b_src[sb].size();
     }
   }
-#if PCD_LM_TSRC_FIXED
   if (A.vt_lm) {
     // tile sources at a fixed stride per block (padded with -1): their address
     // depends on the block index alone
@@ -219,7 +218,6 @@ int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
     if (fixed.size() > (size_t)INT32_MAX) return 0;
     tsrc.swap(fixed);
   }
-#endif
   // rows of hundreds of entries leave a handful of rows per block: most lanes
   // of the row-sum phase idle and the tile is loaded for nothing
   if ((double)nn < 8.0 * (double)desc.size()) return 0;

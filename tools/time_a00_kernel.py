@@ -64,5 +64,5 @@ print("level %d n_u %d nnz %d: %.2f us per launch, %.0f GB/s algorithmic (%s)"
                   ("PCD_NO_XCD_REMAP", "PCD_NO_KRON2", "PCD_FORCE_CSR_VECTOR",
                    "PCD_MAX_RB", "PCD_MAX_CHUNKS", "PCD_MIN_WGS", "PCD_NO_COL16",
                    "PCD_XCD_REMAP_MAX_ROWS", "PCD_NT_BYTES", "PCD_XCD_REMAP_NT",
-                   "PCD_VEC_TILE", "PCD_VT_NT", "PCD_NO_ROWKRON", "PCD_OVERLAP", "PCD_LM_EPI_NT",
+                   "PCD_VEC_TILE", "PCD_VT_NT", "PCD_NO_ROWKRON", "PCD_OVERLAP",
                    "FENAPACK_AMD_HIP_LIB") if k in os.environ) or "default"))
