@@ -30,6 +30,12 @@ struct FeLevel {
   // of the level (pcd_fe_bind_pattern), and the values expanded that way
   DBuf<int> kpos;
   DBuf<double> gvals;
+  // ... with the plan CUT BY ROWS (pcd_fe_set_rows): cells, contribution lists
+  // and F cover the node rows [row0, row0 + nrows) this rank owns of the level
+  // only - the element work and the plan memory of a rank are 1 / R of the
+  // level's; the winds stay whole (vectors are replicated, operators are not)
+  bool rows = false;
+  int64_t row0 = 0, nrows = 0;
   void release() {
     b_ptr.release(); c_ptr.release(); b_src.release(); c_src.release();
     b_w.release(); c_w.release(); B.release();
@@ -57,6 +63,7 @@ struct FeState {
   DCsr Ku;                           // global F x I_d of the finest level
   DCsr Ju;                           // ... and the global coupled block (Newton)
   DBuf<int> gperm;                   // split position -> caller's index, all rows
+  DBuf<double> sys_tmp;              // row-cut plans: scratch system values (residual)
   DBuf<double> bloc, dxloc;          // this rank's slices for GMRES
   DBuf<int64_t> sys_pos; bool sys_bound = false; int sys_blocks = 0;
   int64_t nnz_kp = 0; double kp_scale = 1.0; bool kp_bound = false;
@@ -87,6 +94,7 @@ struct FeState {
     qw.release(); phi.release(); dphi.release(); psi.release(); Func.release();
     Nunc.release(); Jv.release(); inv_vals.release(); dvec.release(); y2.release();
     Ku.release(); Ju.release(); gperm.release(); bloc.release(); dxloc.release();
+    sys_tmp.release();
     phic.release(); qw_s.release(); phi_s.release(); dphi_s.release();
     sys_pos.release(); kp_ptr.release(); kp_src.release(); kp_const.release();
     kp_cells.release(); kp_vals.release(); xu.release(); v.release();
@@ -372,6 +380,29 @@ int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
   return 0;
 }
 
+// Several ranks: the plan of `level` handed to pcd_fe_set_level covers the node
+// rows [node_row0, node_row0 + n_node_rows) of the level's scalar operator only
+// (this rank's rows, pcd_row_range: the cells that touch them, the contribution
+// lists and constants of their entries; dofs2 and the injection map keep GLOBAL
+// node numbers, nn2 stays the global node count).  A rank then assembles and
+// stores 1 / R of a partitioned level; vectors - the iterate, the winds, the
+// residual - stay replicated.  Picard block, re-discretised levels
+// (-pc_mg_galerkin none).  Afterwards pcd_fe_bind_pattern / pcd_fe_bind_system /
+// the mass values of pcd_fe_bind_residual take these rows' entries.
+int pcd_fe_set_rows(pcd_handle h, int level, int64_t node_row0, int64_t n_node_rows) {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_rows: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 1 || level >= fe.nlev || !fe.lev[level].set || fe.lev[level].galerkin)
+    return fail(PCD_ERR_ARG, "fe_set_rows: level %d is not a re-discretised level above the coarsest one", level);
+  if (!h->comm) return fail(PCD_ERR_STATE, "fe_set_rows: no communicator attached (pcd_comm_init first)");
+  FeLevel& L = fe.lev[level];
+  if (node_row0 < 0 || n_node_rows < 0 || node_row0 + n_node_rows > L.nn2)
+    return fail(PCD_ERR_ARG, "fe_set_rows: rows [%lld, %lld) outside the level's %lld nodes",
+                (long long)node_row0, (long long)(node_row0 + n_node_rows), (long long)L.nn2);
+  L.rows = true; L.row0 = node_row0; L.nrows = n_node_rows;
+  return 0;
+}
+
 // A coarse level whose operator is the Galerkin product of the next finer one
 // (-pc_mg_galerkin both): B = F_finer P (nnz_b entries, entry e = sum
 // b_w[t] * F_finer[b_src[t]]), F = P^T B (nnz_f entries, entry k = sum
@@ -447,6 +478,27 @@ int pcd_fe_bind_pattern(pcd_handle h, int level, int64_t nn2, const int32_t* row
   if (level < 0 || level >= fe.nlev || !fe.lev[level].set || !rowptr || !colidx || nn2 < 1)
     return fail(PCD_ERR_ARG, "fe_bind_pattern: level %d is not set / bad arguments", level);
   FeLevel& L = fe.lev[level];
+  if (L.rows) {
+    // rows [row0, row0 + nrows) only: rowptr holds the GLOBAL entry offsets of
+    // these rows (rowptr[0] = entries of the rows before them), colidx their
+    // column indices
+    const int d = fe.dim;
+    if (nn2 != L.nrows || rowptr[nn2] - rowptr[0] != L.nnzf)
+      return fail(PCD_ERR_ARG, "fe_bind_pattern: row-cut level %d holds %lld rows / %lld entries, got %lld / %lld",
+                  level, (long long)L.nrows, (long long)L.nnzf, (long long)nn2, (long long)(rowptr[nn2] - rowptr[0]));
+    if (fe.newton) return fail(PCD_ERR_STATE, "fe_bind_pattern: row-cut plans go with the Picard block");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<int32_t> kpos((size_t)d * L.nnzf);
+    for (int64_t a = 0; a < nn2; ++a) {
+      const int64_t b0 = rowptr[a], len = rowptr[a + 1] - b0;
+      if ((b0 + len) * d >= INT32_MAX) return fail(PCD_ERR_ARG, "fe_bind_pattern: values exceed int32 indexing");
+      for (int64_t k = b0; k < b0 + len; ++k)
+        for (int c = 0; c < d; ++c)
+          kpos[(size_t)c * L.nnzf + (k - rowptr[0])] = (int32_t)(d * b0 + c * len + (k - b0));
+    }
+    CHK(fe_upload(L.kpos, kpos.data(), kpos.size()));
+    return 0;                            // (gvals is sized with the level's operator, fe_refresh)
+  }
   if (rowptr[nn2] != L.nnzf) return fail(PCD_ERR_ARG, "fe_bind_pattern: %lld entries, the level has %lld",
                                         (long long)rowptr[nn2], (long long)L.nnzf);
   const int d = fe.dim;
@@ -718,9 +770,11 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
           // global CSR order and let the ordinary value refresh cut it
           if (!L.kpos.p) return fail(PCD_ERR_STATE, "fe_update: several ranks need pcd_fe_bind_pattern on every level");
           const int nb = fe.newton ? d2 : fe.dim;
-          if (!M.A.set || M.A.gnnz != (int64_t)nb * L.nnzf)
+          if (!M.A.set || (!L.rows && M.A.gnnz != (int64_t)nb * L.nnzf) || (L.rows && M.A.replicated))
             return fail(PCD_ERR_STATE, "fe_update: multigrid level %d does not have the FE pattern", l);
-          CHK(L.gvals.ensure((size_t)nb * L.nnzf));
+          // (row-cut plan: only this rank's rows of the global value array are
+          // written - the only ones its operator gathers)
+          CHK(L.gvals.ensure((size_t)(L.rows ? M.A.gnnz : nb * L.nnzf)));
           if (fe.newton)        // npos = positions in the global coupled CSR
             hipLaunchKernelGGL(k_fe_scatter_blocks<int>, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
                                h->stream, L.nnzf, fe.dim, L.npos.p, L.F.p, L.N.p, L.gvals.p);
@@ -822,9 +876,38 @@ static int fe_subtract_newton_defect(Engine* h, FeState& fe, const double* dxu, 
   return 0;
 }
 
+// several ranks, row-cut plans: y = (S x I_d) v by rows.  S holds this rank's
+// rows of the scalar operator; they take the place of A00's values for one
+// SpMV (scattered into a scratch copy of the system values at A00's positions,
+// gathered through the operator's provenance like any value refresh), the
+// engine's partitioned A00 - halo exchange and all - applies them to this
+// rank's slice of the replicated vector, the slices are summed into a replica,
+// and A00 gets its own values back.
+static int fe_apply_rows(Engine* h, FeState& fe, const double* S, const double* dv, double* dy) {
+  FeLevel& Lt = fe.lev[fe.nlev - 1];
+  DCsr& A = h->mat[PCD_MAT_A00];
+  if (!fe.sys_bound || !A.set || !A.has_src)
+    return fail(PCD_ERR_STATE, "fe: row-cut plans need the system bound (pcd_fe_bind_system)");
+  const int64_t nu = fe.dim * Lt.nn2, r0 = h->sp_u.bounds[0][h->rank];
+  CHK(fe.sys_tmp.ensure(h->sys_nnz));
+  hipLaunchKernelGGL(k_fe_scatter<int64_t>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,
+                     h->stream, Lt.nnzf, fe.dim, fe.sys_pos.p, S, fe.sys_tmp.p);
+  CHK(gather_block_values(h, A, fe.sys_tmp.p));
+  CHK(refresh_kron(h, A));
+  HIPCHK(hipMemsetAsync(dy, 0, nu * sizeof(double), h->stream));
+  int rc = spmv(h, A, dv + r0, dy + r0);
+  if (!rc && h->comm->allreduce(dy, nu, h->stream)) rc = fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+  // A00's own values back (the preconditioner's: P may differ from A)
+  const double* own = (h->p_is_a || !h->psysvals.p) ? h->sysvals.p : h->psysvals.p;
+  CHK(gather_block_values(h, A, own));
+  CHK(refresh_kron(h, A));
+  return rc;
+}
+
 // several ranks: y = (S x I_d) v with the replicated global operator Ku
 static int fe_apply_global(Engine* h, FeState& fe, const double* S, const double* dv, double* dy) {
   FeLevel& Lt = fe.lev[fe.nlev - 1];
+  if (Lt.rows) return fe_apply_rows(h, fe, S, dv, dy);
   if (!fe.Ku.set || !Lt.kpos.p)
     return fail(PCD_ERR_STATE, "fe: several ranks need pcd_fe_bind_pattern on the finest level");
   hipLaunchKernelGGL(k_fe_scatter<int>, dim3(grid1d(Lt.nnzf, 1, 1 << 20)), dim3(kBlock), 0,

@@ -241,6 +241,16 @@ class DeviceProducer(object):
                              "stabilisation parameter)")
         nlev = len(ksp0.pc.mg_data["ops"]) if self.mg else 1
         self.nlev = nlev
+        # Several ranks: plans CUT BY ROWS (pcd_fe_set_rows) - every rank hands
+        # the engine the cells, contribution lists and constants of the node
+        # rows it owns of each partitioned level only, so that the element
+        # work and the plan memory on a GPU are 1 / R of the level's (vectors
+        # stay replicated).  Picard block, re-discretised coarse levels;
+        # FENAPACK_AMD_FE_ROWS=0 keeps the replicated plans.
+        self.rows = bool(self.ranks) and not self.newton and not self.galerkin \
+            and os.environ.get("FENAPACK_AMD_FE_ROWS", "1") != "0"
+        self._cut = [None] * nlev      # per level: (a0, a1, e0, e1) or None
+        self.plan_entries = [0] * nlev  # what this rank holds (cells, entries)
         top_h = len(pb.hierarchy.meshes) - 1
         self.levels = []                       # host problems, coarsest first
         for l in range(nlev):
@@ -280,7 +290,13 @@ class DeviceProducer(object):
             # replicated producer, partitioned solve: the engine needs the
             # layout of every level's global F x I_d (pcd_fe_bind_pattern)
             for l in range(nlev):
-                eng.fe_bind_pattern(l, self._pat[l][0], self._pat[l][1])
+                indptr, indices, _ = self._pat[l]
+                if self._cut[l] is not None:
+                    a0, a1, e0, e1 = self._cut[l]
+                    # (GLOBAL entry offsets of the owned rows, their columns)
+                    eng.fe_bind_pattern(l, indptr[a0:a1 + 1], indices[e0:e1])
+                else:
+                    eng.fe_bind_pattern(l, indptr, indices)
         self._bind_system()
         self._bind_kp(ksp1)
         a, b, cc, dd = ksp0.pc.mg_esteig
@@ -312,6 +328,9 @@ class DeviceProducer(object):
             if pb.idt:
                 pat = V._patterns(False)["SS"]
                 mass = pat.sum_entries(V.p2_mass_cells())
+                cut = self._cut[nlev - 1]
+                if cut is not None:
+                    mass = mass[cut[2]:cut[3]]
             eng.fe_bind_residual(sp.csr_matrix(pb._A01_raw),
                                  sp.csr_matrix(pb._A10_raw), pb.bc_u_idx,
                                  pb._bc_mult[pb.bc_u_idx], mass, pb.idt)
@@ -345,16 +364,59 @@ class DeviceProducer(object):
         diag_pos = np.nonzero((rows == cols) & flag[rows])[0]
         diag_val = pl._bc_mult[d * rows[diag_pos]]
         g = V.gradlam                                  # (nc, d+1, d)
+        dofs2, gl, area, cell_h = V.cell_dofs2, g.reshape(nc, -1), V.area, \
+            (V.cell_h if self.supg else None)
+        cut = self._rows_of_level(l, V)
+        if cut is not None:
+            # this rank's node rows [a0, a1): their entries [e0, e1) of the
+            # pattern, the cells that touch them (renumbered 0 .. in the
+            # element storage), everything else of the level left out
+            a0, a1 = cut
+            e0, e1 = int(pat.indptr[a0]), int(pat.indptr[a1])
+            own = np.zeros(V.nn, dtype=bool)
+            own[a0:a1] = True
+            cells = np.nonzero(own[dofs2].any(axis=1))[0]
+            newid = np.full(nc, -1, dtype=np.int64)
+            newid[cells] = np.arange(cells.size)
+            p0, p1 = int(ptr[e0]), int(ptr[e1])
+            ab, cell = np.divmod(src[p0:p1].astype(np.int64), nc)
+            assert newid[cell].min(initial=0) >= 0
+            src = (ab * cells.size + newid[cell]).astype(np.int32)
+            ptr = (ptr[e0:e1 + 1] - ptr[e0]).astype(np.int32)
+            f_const, keep = f_const[e0:e1], keep[e0:e1]
+            sel = (diag_pos >= e0) & (diag_pos < e1)
+            diag_pos, diag_val = diag_pos[sel] - e0, diag_val[sel]
+            dofs2, gl, area = dofs2[cells], gl[cells], area[cells]
+            if cell_h is not None:
+                cell_h = cell_h[cells]
+            self._cut[l] = (a0, a1, e0, e1)
+        self.plan_entries[l] = (int(dofs2.shape[0]), int(ptr.size - 1))
         self.eng.fe_set_level(
-            l, V.cell_dofs2.T, g.reshape(nc, -1).T, V.area, ptr, src, f_const,
+            l, dofs2.T, gl.T, area, ptr, src, f_const,
             keep, diag_pos, diag_val, inject, V.nn)
+        if cut is not None:
+            self.eng.fe_set_rows(l, a0, a1 - a0)
         self._pat[l] = (pat.indptr, pat.indices, V.nn)
         if self.supg:
             from .fem.taylor_hood import _p2_basis
             lam = np.full((1, V.nvl), 1.0 / V.nvl)
             phi_mid, _ = _p2_basis(lam, V.local_edges)
-            self.eng.fe_set_supg(l, V.cell_h, pl.nu, phi_mid[0], V.qw_s,
+            self.eng.fe_set_supg(l, cell_h, pl.nu, phi_mid[0], V.qw_s,
                                  V.phi_s, V.dphi_s)
+
+    def _rows_of_level(self, l, V):
+        """Node rows ``(a0, a1)`` of level ``l`` this rank's plan is cut to, or
+        ``None`` (one rank, replicated plans, or a level the engine replicates:
+        at most PCD_REPLICATE_BELOW rows, and the coarsest one)."""
+        if not self.rows or l == 0:
+            return None
+        limit = int(os.environ.get("PCD_REPLICATE_BELOW", "60000"))
+        if l < self.nlev - 1 and V.n_u <= limit:
+            return None
+        r0, r1 = self.eng.row_range(V.n_u, velocity=True)
+        d = V.dim
+        assert r0 % d == 0 and r1 % d == 0
+        return r0 // d, r1 // d
 
     def _set_level_galerkin(self, l, P):
         """Level ``l`` = P^T (level l+1) P with the scalar part of the
@@ -426,6 +488,9 @@ class DeviceProducer(object):
             pos = np.empty((d, patS.nnz), dtype=np.int64)
             for k in range(d):
                 pos[k] = mono.inv[patA.locate(d * rows + k, d * cols + k)]
+        cut = self._cut[self.nlev - 1]
+        if cut is not None:
+            pos = np.ascontiguousarray(pos[:, cut[2]:cut[3]])
         self.eng.fe_bind_system(pos)
 
     def _bind_kp(self, ksp1):
@@ -519,6 +584,14 @@ class DeviceProducer(object):
 
     def _scalar(self, l):
         indptr, indices, n = self._pat[l]
+        if self._cut[l] is not None:
+            # this rank's rows only (global shape, the other rows empty)
+            a0, a1, e0, e1 = self._cut[l]
+            vals = self.eng.fe_level_values(l, e1 - e0)
+            ip = np.zeros(n + 1, dtype=np.int64)
+            ip[a0 + 1:a1 + 1] = np.asarray(indptr[a0 + 1:a1 + 1]) - e0
+            ip[a1 + 1:] = e1 - e0
+            return sp.csr_matrix((vals, indices[e0:e1], ip), shape=(n, n))
         vals = self.eng.fe_level_values(l, indices.size)
         return sp.csr_matrix((vals, indices, indptr), shape=(n, n))
 

@@ -458,6 +458,18 @@ int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
                      const unsigned char* f_keep, int64_t n_diag,
                      const int32_t* diag_pos, const double* diag_val,
                      const int32_t* inject);
+/* Several ranks: the plan handed to pcd_fe_set_level for `level` covers the node
+ * rows [node_row0, node_row0 + n_node_rows) of the level's scalar operator only -
+ * this rank's rows (pcd_row_range): the cells that touch them, the contribution
+ * lists / constants / masks of their entries; dofs2 and inject keep GLOBAL node
+ * numbers, nn2 the global node count.  A rank then assembles and stores 1 / R
+ * of a partitioned level (the reference's ranks assemble their own cells:
+ * assembling.py:151-155 on DOLFIN's partitioned mesh); vectors stay replicated.
+ * Picard block, re-discretised levels.  pcd_fe_bind_pattern then takes the
+ * GLOBAL entry offsets of these rows (rowptr[0] = entries before them) and
+ * their column indices; pcd_fe_bind_system / the mass values of
+ * pcd_fe_bind_residual these rows' entries.                                    */
+int pcd_fe_set_rows(pcd_handle h, int level, int64_t node_row0, int64_t n_node_rows);
 /* A coarse level as the Galerkin product of the next finer one
  * (-pc_mg_galerkin both, [ext PETSc] MatPtAP) instead of a re-discretisation:
  * B = F_finer P has nnz_b entries, entry e = sum_t b_w[t] * F_finer[b_src[t]],

@@ -213,6 +213,89 @@ def test_tile_kernels_read_their_ghost_columns(hip_lib, monkeypatch, form,
         assert its == ir and relerr(x, xr) < 1e-7
 
 
+@pytest.mark.parametrize("R", [2, 3])
+@pytest.mark.parametrize("dt", [None, 0.2])
+def test_device_producer_plans_cut_by_rows(hip_lib, monkeypatch, R, dt):
+    """Several ranks, Picard, re-discretised coarse levels: every rank hands
+    the engine the cells and contribution lists of ITS node rows of each
+    partitioned level only (pcd_fe_set_rows) - element work and plan memory
+    of a rank are 1 / R of the level's; the nonlinear side's VECTORS stay
+    replicated, the unconstrained operator of the residual is applied by rows
+    through the engine's own partitioned A00.  Against the replicated plans
+    (FENAPACK_AMD_FE_ROWS=0) on the same ranks: the same nonlinear history, the
+    same Krylov counts, the same solution; operators of the owned rows equal."""
+    from fenapack_amd import PETScOptions
+    from fenapack_amd.device_producer import (solve_steady_device,
+                                              solve_unsteady_device)
+    from fenapack_amd.driver import multigrid_inner_options
+    from fenapack_amd.fem import BackwardStep, Cavity
+    from fenapack_amd.parallel import Comm
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "300")
+
+    def run(rows):
+        monkeypatch.setenv("FENAPACK_AMD_FE_ROWS", "1" if rows else "0")
+        PETScOptions.clear()
+        multigrid_inner_options(dim=2, galerkin_u=False)
+        PETScOptions.set("fieldsplit_u_pc_mg_coarse_eq_limit", 300)
+        group = ctypes.c_void_p()
+        comms = [Comm(r, R, thread_group=group) for r in range(R)]
+        out, errs = [None] * R, []
+
+        def body(r):
+            try:
+                if dt:
+                    pb = BackwardStep(3, nu=0.02, dt=dt)
+                    o = solve_unsteady_device(pb, dt=dt, t_end=3 * dt,
+                                              newton_rtol=1e-5, comm=comms[r])
+                    hist = o["krylov_per_newton"]
+                else:
+                    pb = Cavity(5, nu=0.01)
+                    o = solve_steady_device(pb, max_newton=8, comm=comms[r])
+                    hist = [o["krylov_per_step"]]
+                prod = o["producer"]
+                top = prod.nlev - 1
+                out[r] = {"its": o["newton_its"], "hist": hist,
+                          "x": o["w"].vector().copy(), "rows": prod.rows,
+                          "plan": list(prod.plan_entries),
+                          "F": prod._scalar(top), "cut": prod._cut[top],
+                          "cells": pb.space.mesh.num_cells}
+            except Exception as ex:            # pragma: no cover
+                import traceback
+                errs.append((r, repr(ex), traceback.format_exc()))
+
+        th = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        assert not any(t.is_alive() for t in th), "ranks deadlocked"
+        assert not errs, errs
+        return out
+
+    rep, cut = run(False), run(True)
+    PETScOptions.clear()
+    assert all(not o["rows"] for o in rep) and all(o["rows"] for o in cut)
+    for a, b in zip(cut, rep):
+        assert a["its"] == b["its"] and a["hist"] == b["hist"]
+        assert relerr(a["x"], b["x"]) < 1e-10
+        # this rank's rows of the finest operator: what the replicated plan
+        # assembled for the same rows, bitwise (the same sums in the same order)
+        a0, a1 = a["cut"][0], a["cut"][1]
+        Fa, Fb = a["F"][a0:a1], b["F"][a0:a1]
+        assert np.array_equal(Fa.indices, Fb.indices)
+        assert np.array_equal(Fa.data, Fb.data)
+        assert a["F"].nnz == Fa.nnz                      # nothing outside its rows
+    # plan memory: cells and entries of the finest level per rank ~ 1 / R
+    ncell = cut[0]["cells"]
+    tot_cells = sum(o["plan"][-1][0] for o in cut)
+    tot_ent = sum(o["plan"][-1][1] for o in cut)
+    assert tot_ent == rep[0]["plan"][-1][1]               # the rows partition the operator
+    assert ncell <= tot_cells <= 1.35 * ncell             # (+ one layer of cells per cut)
+    assert max(o["plan"][-1][0] for o in cut) <= 1.4 * ncell / R
+    print("\nfinest level: %d cells / %d entries replicated; per rank %s"
+          % (ncell, rep[0]["plan"][-1][1], [o["plan"][-1] for o in cut]))
+
+
 @pytest.mark.parametrize("R,galerkin,dt,nls", [
     (2, True, None, "picard"), (3, False, None, "picard"),
     (2, True, 0.2, "picard"), (2, True, None, "newton"),
