@@ -116,6 +116,7 @@ _HIP_ONLY = {
     "fe_bind_kp": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
     "fe_set_kp_const": [C.c_void_p],
     "fe_set_rows": [C.c_int, C.c_int64, C.c_int64],
+    "fe_set_kp_rows": [C.c_int64, C.c_int64],
     "fe_bind_robin": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_void_p],
@@ -562,6 +563,9 @@ class Engine(object):
         self._call("fe_set_level_galerkin", int(level), int(c_ptr.size - 1),
                    int(b_ptr.size - 1), _ptr(b_ptr), _ptr(b_src), _ptr(b_w),
                    _ptr(c_ptr), _ptr(c_src), _ptr(c_w))
+
+    def fe_set_kp_rows(self, entry_offset, nnz_global):
+        self._call("fe_set_kp_rows", int(entry_offset), int(nnz_global))
 
     def fe_set_rows(self, level, node_row0, n_node_rows):
         self._call("fe_set_rows", int(level), int(node_row0), int(n_node_rows))

@@ -67,6 +67,9 @@ struct FeState {
   DBuf<double> bloc, dxloc;          // this rank's slices for GMRES
   DBuf<int64_t> sys_pos; bool sys_bound = false; int sys_blocks = 0;
   int64_t nnz_kp = 0; double kp_scale = 1.0; bool kp_bound = false;
+  // row-cut plan of Kp (pcd_fe_set_kp_rows): the bound entries are this rank's
+  // pressure rows, `kp_off` entries into the operator's `kp_glob` values
+  int64_t kp_off = 0, kp_glob = 0;
   DBuf<int> kp_ptr, kp_src;
   DBuf<double> kp_const, kp_cells, kp_vals;
   // coarsest level inverted on the device (pattern of its scalar operator)
@@ -616,7 +619,26 @@ int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
   else fe.kp_const.release();
   CHK(fe.kp_cells.ensure((size_t)nv * nv * L.nc));
   CHK(fe.kp_vals.ensure(nnz_kp));
+  fe.kp_off = 0; fe.kp_glob = nnz_kp;
   fe.kp_bound = true;
+  return 0;
+}
+
+// Several ranks, plans cut by rows: the entries bound by pcd_fe_bind_kp are this
+// rank's pressure rows - `entry_offset` entries into the operator's
+// `nnz_global` values (the cells of the finest level's plan must then cover the
+// cells that touch these rows as well).
+int pcd_fe_set_kp_rows(pcd_handle h, int64_t entry_offset, int64_t nnz_global) {
+  if (!h || !h->fe || !h->fe->kp_bound) return fail(PCD_ERR_STATE, "fe_set_kp_rows: bind Kp first");
+  FeState& fe = *h->fe;
+  if (!h->comm) return fail(PCD_ERR_STATE, "fe_set_kp_rows: no communicator attached");
+  if (entry_offset < 0 || entry_offset + fe.nnz_kp > nnz_global)
+    return fail(PCD_ERR_ARG, "fe_set_kp_rows: entries [%lld, %lld) outside the operator's %lld",
+                (long long)entry_offset, (long long)(entry_offset + fe.nnz_kp), (long long)nnz_global);
+  HIPCHK(hipSetDevice(h->device));
+  fe.kp_off = entry_offset; fe.kp_glob = nnz_global;
+  CHK(fe.kp_vals.ensure(nnz_global));
+  HIPCHK(hipMemset(fe.kp_vals.p, 0, nnz_global * sizeof(double)));
   return 0;
 }
 
@@ -649,7 +671,7 @@ int pcd_fe_bind_robin(pcd_handle h, int64_t nb, const int32_t* nodes,
   if (nb < 0 || n_aff < 0 || (nb && (!nodes || !normals || !lengths || !aff_pos || !aff_ptr || !aff_src || !aff_w)))
     return fail(PCD_ERR_ARG, "fe_bind_robin: bad arguments");
   for (int64_t i = 0; i < n_aff; ++i)
-    if (aff_pos[i] < 0 || aff_pos[i] >= fe.nnz_kp) return fail(PCD_ERR_ARG, "fe_bind_robin: position outside Kp");
+    if (aff_pos[i] < 0 || aff_pos[i] >= fe.kp_glob) return fail(PCD_ERR_ARG, "fe_bind_robin: position outside Kp");
   HIPCHK(hipSetDevice(h->device));
   fe.rb_nb = nb; fe.rb_naff = n_aff;
   // (3-D: six P2 nodes per boundary face, three normal components, `lengths`
@@ -814,7 +836,7 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
                          Lt.dofs2.p, Lt.gradlam.p, Lt.measure.p, fe_tables(fe), Lt.U.p, fe.kp_scale, fe.kp_cells.p);
     hipLaunchKernelGGL(k_fe_gather, dim3(grid1d(fe.nnz_kp, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
                        fe.nnz_kp, fe.kp_ptr.p, fe.kp_src.p, fe.kp_cells.p, fe.kp_const.p,
-                       (const unsigned char*)nullptr, (double*)nullptr, fe.kp_vals.p,
+                       (const unsigned char*)nullptr, (double*)nullptr, fe.kp_vals.p + fe.kp_off,
                        (const double*)nullptr, (double*)nullptr);
     if (fe.robin_bound && fe.rb_nb) {
       if (fe.dim == 2)
@@ -830,7 +852,7 @@ static int fe_refresh(Engine* h, FeState& fe, const double* dxu, bool want_unc) 
     }
     HIPCHK(hipGetLastError());
     if (h->mat[PCD_MAT_KP].set) {
-      if ((h->comm ? h->mat[PCD_MAT_KP].gnnz : h->mat[PCD_MAT_KP].nnz) != fe.nnz_kp)
+      if ((h->comm ? h->mat[PCD_MAT_KP].gnnz : h->mat[PCD_MAT_KP].nnz) != fe.kp_glob)
         return fail(PCD_ERR_STATE, "fe_update: Kp pattern differs from the FE pattern");
       CHK(pcd_update_values(h, PCD_MAT_KP, fe.kp_vals.p, PCD_MEM_DEVICE));
     }
@@ -1201,7 +1223,7 @@ int pcd_fe_get_kp_values(pcd_handle h, double* out) {
   if (!h || !h->fe || !h->fe->kp_bound || !out)
     return fail(PCD_ERR_STATE, "fe_get_kp_values: Kp is not bound");
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpyAsync(out, h->fe->kp_vals.p, h->fe->nnz_kp * sizeof(double),
+  HIPCHK(hipMemcpyAsync(out, h->fe->kp_vals.p + h->fe->kp_off, h->fe->nnz_kp * sizeof(double),
                         hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;

@@ -375,9 +375,21 @@ class DeviceProducer(object):
             e0, e1 = int(pat.indptr[a0]), int(pat.indptr[a1])
             own = np.zeros(V.nn, dtype=bool)
             own[a0:a1] = True
-            cells = np.nonzero(own[dofs2].any(axis=1))[0]
+            sel_c = own[dofs2].any(axis=1)
+            if l == self.nlev - 1:
+                # the finest level's cells also serve Kp: the cells that touch
+                # this rank's PRESSURE rows as well (the pressure cut falls
+                # elsewhere than the velocity cut)
+                q0, q1 = self.eng.row_range(V.n_p, velocity=False)
+                ownp = np.zeros(V.n_p, dtype=bool)
+                ownp[q0:q1] = True
+                sel_c |= ownp[V.cell_dofs1].any(axis=1)
+                self._p_rows = (q0, q1)
+            cells = np.nonzero(sel_c)[0]
             newid = np.full(nc, -1, dtype=np.int64)
             newid[cells] = np.arange(cells.size)
+            if l == self.nlev - 1:
+                self._top_cells, self._top_newid = cells, newid
             p0, p1 = int(ptr[e0]), int(ptr[e1])
             ab, cell = np.divmod(src[p0:p1].astype(np.int64), nc)
             assert newid[cell].min(initial=0) >= 0
@@ -503,7 +515,25 @@ class DeviceProducer(object):
         if idt:
             M = V.area[:, None, None] * V._ref()["P"][None] * (idt / pb.nu)
             cst = pat.sum_entries(M)
+        cutp = None
+        if self._cut[self.nlev - 1] is not None:
+            # this rank's pressure rows of Kp, sources renumbered to the
+            # finest level's local cells
+            q0, q1 = self._p_rows
+            e0, e1 = int(pat.indptr[q0]), int(pat.indptr[q1])
+            p0, p1 = int(ptr[e0]), int(ptr[e1])
+            ab, cell = np.divmod(src[p0:p1].astype(np.int64), nc)
+            assert self._top_newid[cell].min(initial=0) >= 0
+            src = (ab * self._top_cells.size
+                   + self._top_newid[cell]).astype(np.int32)
+            ptr = (ptr[e0:e1 + 1] - ptr[e0]).astype(np.int32)
+            if cst is not None:
+                cst = cst[e0:e1]
+            cutp = (e0, e1)
         self.eng.fe_bind_kp(ptr, src, cst, 1.0 / pb.nu)
+        if cutp is not None:
+            self.eng.fe_set_kp_rows(cutp[0], pat.nnz)
+        self._kp_cut = cutp
         self.nnz_kp = pat.nnz
         # BRM2: - (1/nu) int_inflow (w.n) p q ds depends on the iterate too:
         # a few boundary edges, local 2 x 2 matrices, gathered into the
@@ -517,6 +547,10 @@ class DeviceProducer(object):
             cols = np.repeat(pd[:, None, :], k, axis=1).ravel()
             where = pat.locate(rows, cols)           # (e, i, j) -> Kp entry
             e_idx, ij = np.divmod(np.arange(where.size), k * k)
+            if cutp is not None:
+                # (rows of other ranks: their owners add the term)
+                mine = (where >= cutp[0]) & (where < cutp[1])
+                where, e_idx, ij = where[mine], e_idx[mine], ij[mine]
             aff_pos, _, aff_ptr, order = _group(
                 where, np.zeros_like(where), pat.nnz, 1)
             self.eng.fe_bind_robin(pl["nodes"].T, pl["normal"].T,
@@ -617,6 +651,11 @@ class DeviceProducer(object):
 
     def kp_matrix(self):
         pat = self.V._patterns(False)["PP"]
+        cut = getattr(self, "_kp_cut", None)
+        if cut is not None:                  # this rank's pressure rows only
+            vals = np.zeros(pat.nnz)
+            vals[cut[0]:cut[1]] = self.eng.fe_kp_values(cut[1] - cut[0])
+            return pat.matrix(vals)
         return pat.matrix(self.eng.fe_kp_values(pat.nnz))
 
 
@@ -767,5 +806,6 @@ def solve_unsteady_device(problem, dt, t_end, **kw):
             "krylov_per_newton": newton_per_step, "residuals": residuals,
             "time": time.time() - t0, "ndof": V.ndof,
             "producer_timing": dict(s.producer.timing),
+            "producer": s.producer,
             "time_gmres": s.time_gmres,
             "time_device_loop": s.time_device_loop}

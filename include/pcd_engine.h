@@ -524,6 +524,11 @@ int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos);
  * (same plan layout with nv x nv element matrices; kp_const may be NULL)     */
 int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
                    const int32_t* kp_src, const double* kp_const, double scale);
+/* Several ranks, plans cut by rows (pcd_fe_set_rows): the entries bound by
+ * pcd_fe_bind_kp are this rank's pressure rows, `entry_offset` entries into the
+ * operator's `nnz_global` values; the cells of the finest level's plan then
+ * cover the cells that touch these rows as well.                               */
+int pcd_fe_set_kp_rows(pcd_handle h, int64_t entry_offset, int64_t nnz_global);
 /* replace kp_const (terms the host keeps assembling every iteration, e.g. the
  * BRM2 boundary integral of demo_navier-stokes-pcd.py:131-135); NULL = none  */
 int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const);

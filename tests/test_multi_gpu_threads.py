@@ -213,8 +213,8 @@ def test_tile_kernels_read_their_ghost_columns(hip_lib, monkeypatch, form,
         assert its == ir and relerr(x, xr) < 1e-7
 
 
-@pytest.mark.parametrize("R", [2, 3])
-@pytest.mark.parametrize("dt", [None, 0.2])
+@pytest.mark.parametrize("R,dt", [(2, None), (3, None), (8, None),
+                                  (2, 0.2), (3, 0.2)])
 def test_device_producer_plans_cut_by_rows(hip_lib, monkeypatch, R, dt):
     """Several ranks, Picard, re-discretised coarse levels: every rank hands
     the engine the cells and contribution lists of ITS node rows of each
@@ -279,11 +279,12 @@ def test_device_producer_plans_cut_by_rows(hip_lib, monkeypatch, R, dt):
         assert a["its"] == b["its"] and a["hist"] == b["hist"]
         assert relerr(a["x"], b["x"]) < 1e-10
         # this rank's rows of the finest operator: what the replicated plan
-        # assembled for the same rows, bitwise (the same sums in the same order)
+        # assembled for the same rows (at iterates that agree to round-off: the
+        # residual's slices are summed across the ranks in another order)
         a0, a1 = a["cut"][0], a["cut"][1]
         Fa, Fb = a["F"][a0:a1], b["F"][a0:a1]
         assert np.array_equal(Fa.indices, Fb.indices)
-        assert np.array_equal(Fa.data, Fb.data)
+        assert relerr(Fa.data, Fb.data) < 1e-9
         assert a["F"].nnz == Fa.nnz                      # nothing outside its rows
     # plan memory: cells and entries of the finest level per rank ~ 1 / R
     ncell = cut[0]["cells"]
