@@ -300,6 +300,10 @@ struct PeerBackend : CommBackend {
     return p;
   }
   void give_back(PeerHalo& ph) {
+    // (the regions may be handed out again at once: nothing of this rank's
+    // may still be in flight on them - its last exchange on the channel has
+    // then completed, and with it every peer's store into these buffers)
+    (void)hipDeviceSynchronize();
     for (auto& t : ph.takes) freed.push_back(t);
     ph.takes.clear(); ph.owner = nullptr;
   }
