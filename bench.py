@@ -608,6 +608,44 @@ def main():
         "setup_seconds": t_setup,
     }
 
+    if world > 1:
+        # what the ranks exchange per PCApply (outside the timed region): one
+        # EAGER apply counted through the engine's own counters - halo
+        # exchanges and all-reduces issued as one-shot peer-write kernels of
+        # the stream (csrc/pcd_peer.hpp) against those that went through
+        # RCCL / the host transport, and the launches around them.  The timed
+        # steps above replay the captured graph of the same sequence.
+        try:
+            eng.graph_enable(False)
+            step()
+            torch.cuda.synchronize()
+            k0 = [eng.info(k) for k in (c.INFO_LAUNCHES, c.INFO_PEER_CALLS,
+                                        c.INFO_BOOT_CALLS)]
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            t_eager = (time.perf_counter() - t1) / 10
+            k1 = [eng.info(k) for k in (c.INFO_LAUNCHES, c.INFO_PEER_CALLS,
+                                        c.INFO_BOOT_CALLS)]
+            eng.graph_enable(not args.no_graph)
+            out["comm"] = {
+                "launches_per_pcapply": (k1[0] - k0[0]) / 10,
+                "peer_write_exchanges_and_reductions_per_pcapply":
+                    (k1[1] - k0[1]) / 10,
+                "rccl_or_host_transport_calls_per_pcapply":
+                    (k1[2] - k0[2]) / 10,
+                "halo_channels_declined_by_the_peer_arena":
+                    int(eng.info(c.INFO_PEER_DECLINED)),
+                "transport": "shared GPU: HIP IPC between processes on one "
+                             "device" if args.share_gpu else
+                             "one process per GPU: HIP IPC peer mappings "
+                             "(xGMI), RCCL for set-up and bulk",
+                "ms_per_pcapply_eager": 1e3 * t_eager,
+                "rows_u_of_rank0": nu_loc, "rows_p_of_rank0": np_loc,
+            }
+        except Exception as exc:                   # never lose the bench line
+            out["comm"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, pb, ksp, eng, c, x,
                                            bytes_pc)

@@ -180,6 +180,60 @@ def test_config5_shape_cube_n32_on_8_ranks(hip_lib, replicate_below):
     PETScOptions.clear()
 
 
+@pytest.mark.heavy(9)
+@pytest.mark.timeout(1200)
+def test_config5_own_mesh_cube_n73_on_8_ranks():
+    """BASELINE config 5 at its OWN size and rank count - the unit cube with
+    N = 73 per side, 9 934 793 DOF, 8 ranks - as far as one GPU allows: the
+    ranks are threads on this GPU (tools/steady_thread_ranks.py), every one
+    assembles its slab only (fem/partition.py), hands over its own rows
+    (FENAPACK_AMD_LOCAL_HANDOVER=1), and the algebraic hierarchy (-pc_type
+    gamg) is aggregated and smoothed across the ranks.  Two Picard steps: the
+    GMRES history of the one-GPU run of the same mesh (test_full_size_gpu.py::
+    test_cube_n73_config5_own_mesh: 10 / 69), identical replicas, row counts
+    balanced to a node, a rank's share of the host memory below a fifth of the
+    one-rank producer's.  Parity of the partitioned path at the stated shape -
+    not a timing (8 engines time-share one GPU).
+
+    A process of its own, like the one-GPU test: the eight slabs together hold
+    more host memory than this session's watchdog allows."""
+    import json
+    import subprocess
+    import sys
+    from fenapack_amd import _guard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = _guard.host_memory_available()
+    need = 110e9          # (measured peak: 75 GB, profiles/r04_z5_config5_own_mesh_8_thread_ranks_*)
+    assert have is None or have >= need, (
+        "config 5's own mesh on 8 thread ranks needs a host with %.0f GB "
+        "available to this control group, %.0f GB here" % (need / 1e9,
+                                                         (have or 0) / 1e9))
+    env = dict(os.environ)
+    for k in ("FENAPACK_AMD_NO_WATCHDOG", "PCD_REPLICATE_BELOW"):
+        env.pop(k, None)
+    env["FENAPACK_AMD_WATCHDOG"] = "1"
+    env["FENAPACK_AMD_LOCAL_HANDOVER"] = "1"
+    run = subprocess.run(
+        [sys.executable, os.path.join(root, "tools", "steady_thread_ranks.py"),
+         "--partitioned", "--algebraic", "--n0=73", "cube", "0", "8"],
+        cwd=root, env=env, capture_output=True, text=True, timeout=1100)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    rec = json.loads(run.stdout.strip().splitlines()[-1])
+    print("cube N = 73 on 8 thread ranks:", rec)
+    assert rec["ndof"] == 9934793 and rec["ranks"] == 8
+    assert rec["producer"] == "partitioned" and rec["local_handover"]
+    hist = rec["krylov_per_step"]
+    assert len(hist) == 2 and abs(hist[0] - 10) <= 1 and abs(hist[1] - 69) <= 2, hist
+    assert rec["replicas_agree"]
+    rows = rec["rows_u_per_rank"]
+    assert sum(rows) == 9529569 and max(rows) - min(rows) <= 3
+    assert rec["peak_rss_gb_per_rank"] < 12.0
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_own_mesh_8_thread_ranks.json"), "w") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
 @pytest.mark.parametrize("R", [2, 3])
 def test_host_driven_solve_with_rank_local_handover(hip_lib, replicate_below,
                                                     monkeypatch, R):

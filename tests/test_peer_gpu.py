@@ -281,3 +281,12 @@ def test_bench_with_two_and_four_ranks_sharing_the_gpu(hip_lib):
         assert d["config"]["launch"] == "hipGraph replay"
         assert ("partitioned" in d["config"]["producer"]) == bool(extra)
         assert len(d["gmres_its_per_newton_step"]) == 2
+        # what the ranks exchange per PCApply: every halo exchange / reduction
+        # a one-shot peer-write kernel, none through RCCL / the host transport
+        cm = d["comm"]
+        assert "error" not in cm, cm
+        assert cm["peer_write_exchanges_and_reductions_per_pcapply"] >= 4
+        assert cm["rccl_or_host_transport_calls_per_pcapply"] == 0.0
+        assert cm["halo_channels_declined_by_the_peer_arena"] == 0
+        assert cm["launches_per_pcapply"] > \
+            cm["peer_write_exchanges_and_reductions_per_pcapply"]
