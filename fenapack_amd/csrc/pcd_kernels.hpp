@@ -851,27 +851,37 @@ __device__ __forceinline__ VecC<NC> stream_row_block_rk(
     const int c1 = min(c0 + kTileC, k1 - k0);
     if (c0) __syncthreads();
     for (int base = k0 + c0; base < k0 + c1; base += U * kBlock) {
+      // The NC values of an entry sit side by side (val[k][NC]): a lane that
+      // loads "its" entry's values reads NC doubles at a stride of 8 NC bytes,
+      // and every one of the NC load instructions of a wave touches all the
+      // cache lines of the wave's 64 entries.  Instead the wave loads its 64 NC
+      // doubles CONTIGUOUSLY - double l + 64 j of the wave's stretch on lane l -
+      // and fetches the gathered x of the entry that double belongs to,
+      // (l + 64 j) / NC, from the lane that gathered it (a wave shuffle).  Same
+      // products, same places in LDS.
+      const int lane = threadIdx.x & 63, wv0 = threadIdx.x & ~63;
       int c[U];
       double v[U][NC];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = base + u * kBlock + threadIdx.x;
-        const bool in = k < k0 + c1;
-        c[u] = in ? stream_load<NT>(col + k) : -1;
+        c[u] = k < k0 + c1 ? stream_load<NT>(col + k) : -1;
+        const size_t f0 = (size_t)NC * (base + u * kBlock + wv0) + lane;
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
-          v[u][i] = in ? stream_load<NT>(val + (size_t)NC * k + i) : 0.0;
+        for (int j = 0; j < NC; ++j)
+          v[u][j] = f0 + 64 * j < (size_t)NC * (k0 + c1) ? stream_load<NT>(val + f0 + 64 * j) : 0.0;
       }
       double xv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : 0.0;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = base + u * kBlock + threadIdx.x;
-        if (k < k0 + c1) {
 #pragma unroll
-          for (int i = 0; i < NC; ++i)
-            planes[i * kTileC + (k - k0 - c0)] = v[u][i] * xv[u];
+        for (int j = 0; j < NC; ++j) {
+          const int fl = lane + 64 * j, e = fl / NC, i = fl - e * NC;
+          const double xe = __shfl(xv[u], e);
+          const int k = base + u * kBlock + wv0 + e;
+          if (k < k0 + c1) planes[i * kTileC + (k - k0 - c0)] = v[u][j] * xe;
         }
       }
     }
