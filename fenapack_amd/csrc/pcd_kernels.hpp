@@ -851,37 +851,63 @@ __device__ __forceinline__ VecC<NC> stream_row_block_rk(
     const int c1 = min(c0 + kTileC, k1 - k0);
     if (c0) __syncthreads();
     for (int base = k0 + c0; base < k0 + c1; base += U * kBlock) {
-      // The NC values of an entry sit side by side (val[k][NC]): a lane that
-      // loads "its" entry's values reads NC doubles at a stride of 8 NC bytes,
-      // and every one of the NC load instructions of a wave touches all the
-      // cache lines of the wave's 64 entries.  Instead the wave loads its 64 NC
-      // doubles CONTIGUOUSLY - double l + 64 j of the wave's stretch on lane l -
-      // and fetches the gathered x of the entry that double belongs to,
-      // (l + 64 j) / NC, from the lane that gathered it (a wave shuffle).  Same
-      // products, same places in LDS.
-      const int lane = threadIdx.x & 63, wv0 = threadIdx.x & ~63;
       int c[U];
       double v[U][NC];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = base + u * kBlock + threadIdx.x;
-        c[u] = k < k0 + c1 ? stream_load<NT>(col + k) : -1;
-        const size_t f0 = (size_t)NC * (base + u * kBlock + wv0) + lane;
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-          v[u][j] = f0 + 64 * j < (size_t)NC * (k0 + c1) ? stream_load<NT>(val + f0 + 64 * j) : 0.0;
-      }
       double xv[U];
+      if constexpr (NT) {
+        // The NC values of an entry sit side by side (val[k][NC]): a lane that
+        // loads "its" entry's values reads NC doubles at a stride of 8 NC bytes,
+        // and every one of the NC load instructions of a wave touches all the
+        // cache lines of the wave's 64 entries.  Here the wave loads its 64 NC
+        // doubles CONTIGUOUSLY - double l + 64 j of the wave's stretch on lane
+        // l - and fetches the gathered x of the entry that double belongs to,
+        // (l + 64 j) / NC, from the lane that gathered it (a wave shuffle).  Same
+        // products, same places in LDS.  Operators streamed from HBM (NT) only:
+        // same-box A/B on the discrete gradient, cube N = 73: 230.7 -> 198.6 us;
+        // cube N = 48 (resident in the Infinity Cache, NT off) 59.8 -> 63.5 us
+        // (profiles/r05_o_*).
+        const int lane = threadIdx.x & 63, wv0 = threadIdx.x & ~63;
 #pragma unroll
-      for (int u = 0; u < U; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : 0.0;
+        for (int u = 0; u < U; ++u) {
+          const int k = base + u * kBlock + threadIdx.x;
+          c[u] = k < k0 + c1 ? stream_load<NT>(col + k) : -1;
+          const size_t f0 = (size_t)NC * (base + u * kBlock + wv0) + lane;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+          for (int j = 0; j < NC; ++j)
+            v[u][j] = f0 + 64 * j < (size_t)NC * (k0 + c1) ? stream_load<NT>(val + f0 + 64 * j) : 0.0;
+        }
 #pragma unroll
-        for (int j = 0; j < NC; ++j) {
-          const int fl = lane + 64 * j, e = fl / NC, i = fl - e * NC;
-          const double xe = __shfl(xv[u], e);
-          const int k = base + u * kBlock + wv0 + e;
-          if (k < k0 + c1) planes[i * kTileC + (k - k0 - c0)] = v[u][j] * xe;
+        for (int u = 0; u < U; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            const int fl = lane + 64 * j, e = fl / NC, i = fl - e * NC;
+            const double xe = __shfl(xv[u], e);
+            const int k = base + u * kBlock + wv0 + e;
+            if (k < k0 + c1) planes[i * kTileC + (k - k0 - c0)] = v[u][j] * xe;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = base + u * kBlock + threadIdx.x;
+          const bool in = k < k0 + c1;
+          c[u] = in ? stream_load<NT>(col + k) : -1;
+#pragma unroll
+          for (int i = 0; i < NC; ++i)
+            v[u][i] = in ? stream_load<NT>(val + (size_t)NC * k + i) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = c[u] >= 0 ? xf(c[u]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = base + u * kBlock + threadIdx.x;
+          if (k < k0 + c1) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+              planes[i * kTileC + (k - k0 - c0)] = v[u][i] * xv[u];
+          }
         }
       }
     }
@@ -1325,7 +1351,11 @@ static_assert(lm_rows(2) <= 256 && lm_rows(3) <= 256, "one lane per row, 8-bit f
 // N = 48: 75.0 against 69.7 us) or at their compact positions (69.7 against
 // 68.5), the epilogue's operands with the block's first loads (N = 73: 312 ->
 // 309, level 7 55.5 -> 53.7 with them late), a register allocation forced to
-// eight waves per SIMD (spills: 81.3 against 74.0 at N = 48).
+// eight waves per SIMD (spills: 81.3 against 74.0 at N = 48), the tile of a
+// three-component operator gathered per DOUBLE instead of per node (lane t the
+// doubles t + 256 j of the tile's 3 TN, so that a wave's load covers 512
+// contiguous bytes where the nodes are consecutive: N = 48 69.2 -> 103.5 us,
+// N = 73 301 -> 412, profiles/r05_p_*).
 template <int NC>
 struct LmRegs {
   typedef double dv2 __attribute__((ext_vector_type(2)));
