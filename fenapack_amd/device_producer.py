@@ -228,10 +228,18 @@ class DeviceProducer(object):
                              "aggregates the scalar stencil F of the Picard "
                              "block F (x) I_d; --nls newton needs the "
                              "nested-mesh hierarchy")
-        if self.algebraic and self.ranks:
-            raise ValueError("device producer: an algebraic hierarchy on "
-                             "several ranks is refreshed by the partitioned "
-                             "host producer (amg.PartitionedSA)")
+        # (several ranks with the GLOBAL hand-over: the aggregation runs on
+        # every rank alike - amg.smoothed_aggregation_chain is deterministic -
+        # so the prolongators and the coarse patterns are replicated like the
+        # nested meshes' ones and the Galerkin plans below stay replicated;
+        # the engine takes its rows of every level.  The PARTITIONED host
+        # producer's hierarchy (amg.PartitionedSA: aggregates per rank, levels
+        # cut where they fall) has no device producer yet.)
+        if self.algebraic and self.ranks and \
+                getattr(ksp0.pc, "_mg_psa", None) is not None:
+            raise ValueError("device producer: the algebraic hierarchy of "
+                             "the partitioned host producer "
+                             "(amg.PartitionedSA) is refreshed on the host")
         self.galerkin = bool(ksp0.pc.mg_galerkin) or self.algebraic
         self.supg = bool(pb.stabilize)
         if self.supg and self.galerkin:

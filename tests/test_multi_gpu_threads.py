@@ -381,6 +381,77 @@ def test_device_producer_on_several_ranks(hip_lib, R, galerkin, dt, nls):
         assert relerr(x, out[0][2]) < 1e-12
 
 
+@pytest.mark.parametrize("R,kind", [(2, "cavity"), (3, "cube")])
+def test_device_producer_with_an_algebraic_hierarchy_on_several_ranks(hip_lib, R,
+                                                                      kind):
+    """-pc_type gamg with ranks and the global hand-over: the aggregation is
+    the same on every rank, so prolongators and coarse patterns are replicated
+    and the device producer refreshes the Galerkin products of every level in
+    HBM as on one GPU (the reference re-runs hypre's set-up per outer
+    iteration: demo_navier-stokes-pcd.py:153-160); the solve is partitioned.
+    Same nonlinear history, Krylov counts and solution as the one-GPU device
+    solve; the ranks own row blocks."""
+    import os
+    from fenapack_amd import PETScOptions
+    from fenapack_amd.device_producer import solve_steady_device
+    from fenapack_amd.driver import multigrid_inner_options
+    from fenapack_amd.fem import Cavity, Cavity3D
+    from fenapack_amd.parallel import Comm
+
+    def problem():
+        return Cavity(4, nu=0.01) if kind == "cavity" \
+            else Cavity3D(1, nu=0.02, n0=6)
+
+    rows = []
+
+    def solve(comm):
+        out = solve_steady_device(problem(), max_newton=8, comm=comm)
+        assert out["converged"] and out["producer"].algebraic
+        assert out["producer"].device_loop
+        eng = out["solver"].linear_solver().ksp().engine
+        rows.append((eng.info(c.INFO_N_U_LOCAL), out["producer"].ranks))
+        return out["newton_its"], out["krylov_per_step"], \
+            out["w"].vector().copy()
+
+    PETScOptions.clear()
+    multigrid_inner_options(dim=2 if kind == "cavity" else 3, algebraic=True)
+    PETScOptions.set("fieldsplit_u_pc_mg_coarse_eq_limit", 100)
+    os.environ["PCD_REPLICATE_BELOW"] = "300"
+    try:
+        ref = solve(None)
+        group = ctypes.c_void_p()
+        comms = [Comm(r, R, thread_group=group) for r in range(R)]
+        out, errs = [None] * R, []
+
+        def body(r):
+            try:
+                out[r] = solve(comms[r])
+            except Exception as ex:            # pragma: no cover
+                import traceback
+                errs.append((r, repr(ex), traceback.format_exc()))
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(R)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not any(t.is_alive() for t in threads), "ranks deadlocked"
+        assert not errs, errs
+    finally:
+        del os.environ["PCD_REPLICATE_BELOW"]
+        PETScOptions.clear()
+    for its, krylov, x in out:
+        assert its == ref[0]
+        assert len(krylov) == len(ref[1])
+        for i, j in zip(krylov, ref[1]):
+            assert abs(i - j) <= max(1, 0.05 * j), (krylov, ref[1])
+        assert relerr(x, ref[2]) < 1e-5
+        assert relerr(x, out[0][2]) < 1e-12
+    n_u = rows[0][0]
+    assert rows[0][1] == 0 and sum(r[0] for r in rows[1:]) == n_u
+    assert all(0 < r[0] < n_u and r[1] == R for r in rows[1:])
+
+
 def test_device_producer_over_rccl_single_rank(hip_lib, monkeypatch):
     """The same replicated-producer path over the RCCL backend itself, with
     the one-rank communicator this box allows (all-reduces of whole vectors,

@@ -266,11 +266,18 @@ def test_bench_with_two_and_four_ranks_sharing_the_gpu(hip_lib):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    for n, extra in ((2, []), (2, ["--partitioned-producer"]), (4, [])):
+    # (the last form is config 5's start-up in small: the cube through
+    # -pc_type gamg with every rank assembling its slab and the hierarchy
+    # aggregated rank by rank - amg.PartitionedSA over torch.distributed)
+    cube = ["--geometry", "cube", "--level", "1", "--n0", "6", "--algebraic",
+            "--partitioned-producer"]
+    for n, extra in ((2, []), (2, ["--partitioned-producer"]), (4, []),
+                     (2, cube)):
         run = subprocess.run(
             [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n),
-             "--share-gpu", "--level", "4", "--steps", "10", "--warmup", "3",
-             "--no-cpu-baseline"] + extra,
+             "--share-gpu", "--steps", "10", "--warmup", "3",
+             "--no-cpu-baseline"]
+            + (["--level", "4"] if "--geometry" not in extra else []) + extra,
             env=env, capture_output=True, text=True, timeout=360)
         assert run.returncode == 0, run.stderr[-3000:]
         lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
@@ -280,6 +287,8 @@ def test_bench_with_two_and_four_ranks_sharing_the_gpu(hip_lib):
         assert d["config"]["parallelism"] == "row partition x%d" % n
         assert d["config"]["launch"] == "hipGraph replay"
         assert ("partitioned" in d["config"]["producer"]) == bool(extra)
+        if "--algebraic" in extra:
+            assert "cube N=12" in d["config"]["workload"], d["config"]
         assert len(d["gmres_its_per_newton_step"]) == 2
         # what the ranks exchange per PCApply: every halo exchange / reduction
         # a one-shot peer-write kernel, none through RCCL / the host transport
