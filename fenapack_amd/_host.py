@@ -96,6 +96,10 @@ def library():
                                    PP32, _I64P]
     L.pcdh_union_fill.argtypes = [ctypes.c_int64, ctypes.c_int, _I64P, PP32,
                                   PP32, PP32, PP32, _I64P, _I64P, _I32P, _I64P]
+    L.pcdh_mis2_degrees.argtypes = [ctypes.c_int64, _I32P, _I32P, _I64P]
+    L.pcdh_mis2.argtypes = [ctypes.c_int64, _I32P, _I32P, _F64P,
+                            ctypes.POINTER(ctypes.c_int8),
+                            ctypes.POINTER(ctypes.c_int64)]
     _lib = L
     nt = os.environ.get("FENAPACK_AMD_HOST_THREADS")
     if nt:
@@ -450,3 +454,32 @@ def gather_sum(ptr, members, vals, out=None):
     _chk(library().pcdh_gather_sum(ng, _p(ptr, _I64P), _p(members, _I64P),
                                    _p(vals, _F64P), _p(out, _F64P)))
     return out
+
+
+def mis2_degrees(S):
+    """Number of vertices within two edges of every vertex of the graph ``S``
+    (CSR pattern, symmetric, no diagonal) - the row lengths of the
+    off-diagonal pattern of ``(S + I)^2`` without forming it."""
+    import scipy.sparse as sp
+    S = sp.csr_matrix(S)
+    n = S.shape[0]
+    deg = np.zeros(n, dtype=np.int64)
+    ip, ix = _i32(S.indptr), _i32(S.indices)
+    _chk(library().pcdh_mis2_degrees(n, _p(ip, _I32P), _p(ix, _I32P),
+                                     _p(deg, _I64P)))
+    return deg
+
+
+def mis2(S, w):
+    """Maximal independent set of the DISTANCE-2 graph of ``S`` by Luby's
+    rounds with the priorities ``w`` (``pcdh_mis2``): boolean mask."""
+    import scipy.sparse as sp
+    S = sp.csr_matrix(S)
+    n = S.shape[0]
+    out = np.zeros(n, dtype=np.int8)
+    ip, ix = _i32(S.indptr), _i32(S.indices)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    _chk(library().pcdh_mis2(n, _p(ip, _I32P), _p(ix, _I32P), _p(w, _F64P),
+                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)),
+                             None))
+    return out.astype(bool)

@@ -92,7 +92,19 @@ def aggregate(S, seed=0, distance=2):
     Returns ``agg`` (n,) with values in ``[-1, nagg)``."""
     n = S.shape[0]
     pat = sp.csr_matrix((np.ones(S.nnz), S.indices, S.indptr), shape=S.shape)
-    if distance >= 2:
+    isolated = np.diff(S.indptr) == 0
+    G2 = None
+    if distance >= 2 and not _host.use_numpy() and n < 2 ** 31 \
+            and os.environ.get("FENAPACK_AMD_MIS2_EXPLICIT", "0") != "1":
+        # the distance-2 graph is never formed: its row lengths (the degree
+        # term of Luby's priorities) and the rounds themselves walk two hops
+        # of `pat` (libpcd_host pcdh_mis2*: cube N = 73's 5.4e8-entry square -
+        # half a minute and tens of GB - is gone; the same set as _mis on the
+        # explicit graph, tests/test_host_native.py)
+        rng = np.random.default_rng(seed)
+        w = rng.random(n) + 1.0 / (1.0 + _host.mis2_degrees(pat))
+        roots = _host.mis2(pat, w) & ~isolated
+    elif distance >= 2:
         # vertices within two edges: the off-diagonal pattern of (pat + I)^2
         # (= pat^2 + pat off the diagonal); one product - the threaded native
         # SpGEMM from a few 10^5 entries - and the diagonal dropped on the
@@ -113,8 +125,8 @@ def aggregate(S, seed=0, distance=2):
         G2.has_sorted_indices = True
     else:
         G2 = pat          # MIS-1: roots two edges apart, aggregates = stars
-    isolated = np.diff(S.indptr) == 0
-    roots = _mis(G2, seed) & ~isolated
+    if G2 is not None:
+        roots = _mis(G2, seed) & ~isolated
     agg = np.full(n, -1, dtype=np.int64)
     ridx = np.nonzero(roots)[0]
     agg[ridx] = np.arange(ridx.size)

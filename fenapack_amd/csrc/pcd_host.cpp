@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <utility>
+#include <limits>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -639,6 +640,113 @@ int pcdh_union_fill(int64_t n, int nb, const int64_t* nr, const int32_t* const* 
     }
   }
   if (dup) return fail(PCDH_ERR_ARG, "union_fill: the blocks overlap");
+  return 0;
+}
+
+// ------------------------------------------------- distance-2 independent set
+int pcdh_mis2_degrees(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t* deg) {
+  if (n < 0 || !rowptr || (rowptr[n] && !col) || (n && !deg))
+    return fail(PCDH_ERR_ARG, "mis2_degrees: bad arguments");
+  if (n > INT32_MAX) return fail(PCDH_ERR_ARG, "mis2_degrees: more than 2^31 vertices");
+  const int T = nthreads((int64_t)rowptr[n] * 8);
+#pragma omp parallel num_threads(T)
+  {
+    // stamp[k] == i: vertex k already counted for vertex i
+    std::vector<int32_t> stamp((size_t)n, -1);
+#pragma omp for schedule(dynamic, 1024)
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t cnt = 0;
+      auto visit = [&](int32_t j) {
+        for (int32_t q = rowptr[j]; q < rowptr[j + 1]; ++q) {
+          const int32_t k = col[q];
+          if (k != i && stamp[k] != (int32_t)i) { stamp[k] = (int32_t)i; ++cnt; }
+        }
+      };
+      visit((int32_t)i);
+      for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+        const int32_t j = col[p];
+        if (j == i) continue;
+        // (j itself is within one edge: counted by visit(i) above)
+        visit(j);
+      }
+      deg[i] = cnt;
+    }
+  }
+  return 0;
+}
+
+int pcdh_mis2(int64_t n, const int32_t* rowptr, const int32_t* col, const double* w,
+              int8_t* in_set, int64_t* rounds) {
+  if (n < 0 || !rowptr || (rowptr[n] && !col) || (n && (!w || !in_set)))
+    return fail(PCDH_ERR_ARG, "mis2: bad arguments");
+  if (n > INT32_MAX) return fail(PCDH_ERR_ARG, "mis2: more than 2^31 vertices");
+  const double ninf = -std::numeric_limits<double>::infinity();
+  const int T = nthreads((int64_t)rowptr[n] * 4);
+  std::vector<int8_t> state((size_t)n, 0);          // 0 undecided, 1 in, -1 out
+  // the two largest priorities of DISTINCT undecided vertices in the closed
+  // one-hop neighbourhood of every vertex (v1 >= v2; i1 / i2 = -1: none)
+  std::vector<double> v1((size_t)n), v2((size_t)n);
+  std::vector<int32_t> i1((size_t)n), i2((size_t)n);
+  std::vector<int8_t> win((size_t)n), near((size_t)n);
+  int64_t nround = 0;
+  for (;;) {
+    int64_t nund = 0;
+#pragma omp parallel for schedule(static, 4096) num_threads(T) reduction(+ : nund)
+    for (int64_t i = 0; i < n; ++i) nund += state[i] == 0;
+    if (!nund) break;
+    ++nround;
+#pragma omp parallel for schedule(static, 2048) num_threads(T)
+    for (int64_t j = 0; j < n; ++j) {
+      double a1 = ninf, a2 = ninf;
+      int32_t b1 = -1, b2 = -1;
+      auto offer = [&](int32_t k) {
+        const double x = state[k] == 0 ? w[k] : ninf;
+        // (ties keep the first comer: which of two equal candidates is "the
+        // largest" does not matter, both block each other below)
+        if (b1 < 0 || x > a1) { a2 = a1; b2 = b1; a1 = x; b1 = k; }
+        else if (b2 < 0 || x > a2) { a2 = x; b2 = k; }
+      };
+      offer((int32_t)j);
+      for (int32_t q = rowptr[j]; q < rowptr[j + 1]; ++q)
+        if (col[q] != j) offer(col[q]);
+      v1[j] = a1; i1[j] = b1; v2[j] = b2 < 0 ? ninf : a2; i2[j] = b2;
+    }
+    int64_t nwin = 0;
+#pragma omp parallel for schedule(static, 2048) num_threads(T) reduction(+ : nwin)
+    for (int64_t i = 0; i < n; ++i) {
+      win[i] = 0;
+      if (state[i] != 0) continue;
+      // max over the two-hop neighbourhood, the vertex itself left out
+      auto other = [&](int32_t j) { return i1[j] != (int32_t)i ? v1[j] : v2[j]; };
+      double nb = other((int32_t)i);
+      for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p)
+        if (col[p] != i) nb = std::max(nb, other(col[p]));
+      if (w[i] > nb) { win[i] = 1; ++nwin; }
+    }
+    if (!nwin) {                               // tied priorities: break by index
+      int64_t best = -1;
+      for (int64_t i = 0; i < n; ++i)
+        if (state[i] == 0 && (best < 0 || w[i] > w[best])) best = i;
+      win[best] = 1;
+    }
+    // vertices within two edges of a new member drop out
+#pragma omp parallel for schedule(static, 2048) num_threads(T)
+    for (int64_t j = 0; j < n; ++j) {
+      int8_t any = win[j];
+      for (int32_t q = rowptr[j]; q < rowptr[j + 1] && !any; ++q) any = win[col[q]];
+      near[j] = any;
+    }
+#pragma omp parallel for schedule(static, 2048) num_threads(T)
+    for (int64_t i = 0; i < n; ++i) {
+      if (win[i]) { state[i] = 1; continue; }
+      if (state[i] != 0) continue;
+      int8_t any = near[i];
+      for (int32_t p = rowptr[i]; p < rowptr[i + 1] && !any; ++p) any = near[col[p]];
+      if (any) state[i] = -1;
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) in_set[i] = state[i] == 1;
+  if (rounds) *rounds = nround;
   return 0;
 }
 

@@ -206,6 +206,33 @@ int pcdh_union_fill(int64_t n, int nb, const int64_t* nr,
                     const int64_t* data_off, const int64_t* out_indptr,
                     int32_t* out_indices, int64_t* out_order);
 
+/* ---- distance-2 maximal independent set without the squared graph ------------
+ * The roots of the smoothed-aggregation hierarchy behind -pc_type gamg
+ * (fenapack_amd/amg.py; the reference leaves its algebraic hierarchy to hypre:
+ * demo_navier-stokes-pcd.py:153-160) are a maximal independent set of the
+ * DISTANCE-2 graph G2 = off-diagonal pattern of (S + I)^2 of the strength graph
+ * S.  For a 3-D P2 stencil G2 has ~170 entries per row (cube N = 73: 5.4e8
+ * entries, tens of GB and half a minute of SpGEMM before the first Luby round);
+ * both functions below walk two hops of S instead and never store G2.
+ * `rowptr` / `col`: pattern of S - symmetric, no diagonal entries.
+ * pcdh_mis2_degrees: deg[i] = number of vertices other than i within two edges
+ *   of i (= the row lengths of G2: the degree term of Luby's priorities).
+ * pcdh_mis2: Luby's rounds on G2 with the priorities `w` - an undecided vertex
+ *   joins the set when its priority is STRICTLY greater than that of every
+ *   undecided vertex within two edges (the maximum over the two-hop
+ *   neighbourhood excluding the vertex itself comes from the two largest
+ *   DISTINCT candidates of every closed one-hop neighbourhood), vertices
+ *   within two edges of a new member drop out; a round without a winner
+ *   (tied priorities) admits the undecided vertex of largest priority, lowest
+ *   index first.  in_set[i] = 1 / 0.  Every round is a pure function of the
+ *   state before it: the result does not depend on the thread count, and it
+ *   is the set the numpy restatement over the explicit G2 finds (amg._mis).
+ */
+int pcdh_mis2_degrees(int64_t n, const int32_t* rowptr, const int32_t* col,
+                      int64_t* deg);
+int pcdh_mis2(int64_t n, const int32_t* rowptr, const int32_t* col,
+              const double* w, int8_t* in_set, int64_t* rounds /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

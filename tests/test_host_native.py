@@ -288,3 +288,102 @@ def test_group_pairs_with_a_smaller_team_than_asked_for():
     out = subprocess.run([sys.executable, "-c", code], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def _explicit_distance2(S):
+    n = S.shape[0]
+    pI = (S + sp.identity(n, format="csr")).tocsr()
+    G2 = (pI @ pI).tocsr()
+    G2.setdiag(0)
+    G2.eliminate_zeros()
+    G2.sort_indices()
+    G2.data[:] = 1.0
+    return G2
+
+
+def _luby_on(G, w):
+    """amg._mis with given priorities (the explicit-graph restatement)."""
+    from fenapack_amd import amg
+    n = G.shape[0]
+    state = np.zeros(n, np.int8)
+    while True:
+        und = state == 0
+        if not und.any():
+            break
+        wm = np.where(und, w, -np.inf)
+        win = und & (wm > amg._row_max(G, wm))
+        if not win.any():
+            idx = np.nonzero(und)[0]
+            win = np.zeros(n, bool)
+            win[idx[np.argmax(w[idx])]] = True
+        state[win] = 1
+        hit = amg._row_max(G, np.where(win, 1.0, -np.inf)) > 0
+        state[hit & (state == 0)] = -1
+    return state == 1
+
+
+@pytest.mark.parametrize("n,dens", [(1, 0.0), (60, 0.05), (500, 0.01),
+                                    (4000, 0.0015), (4000, 0.0002)])
+def test_distance2_independent_set_without_the_squared_graph(n, dens):
+    """pcdh_mis2_degrees / pcdh_mis2 walk two hops of the strength graph
+    instead of forming its square (cube N = 73: 5.4e8 entries): the row
+    lengths of the explicit distance-2 graph and the set Luby's rounds find on
+    it (amg._mis) - random priorities, TIED priorities (strict comparison, a
+    round without a winner admits the lowest index), isolated vertices, one
+    thread and many."""
+    from fenapack_amd import amg
+    rng = np.random.default_rng(n)
+    A = sp.random(n, n, density=dens, random_state=int(rng.integers(1 << 30)),
+                  format="csr")
+    S = (A + A.T).tocsr()
+    S.setdiag(0)
+    S.eliminate_zeros()
+    S.sort_indices()
+    S.data[:] = 1.0
+    G2 = _explicit_distance2(S)
+    assert np.array_equal(H.mis2_degrees(S), np.diff(G2.indptr))
+    for seed in range(3):
+        w = np.random.default_rng(seed).random(n) + 1.0 / (1.0 + np.diff(G2.indptr))
+        ref = amg._mis(G2, seed)
+        assert np.array_equal(H.mis2(S, w), ref), seed
+        # maximal and independent at distance 2
+        if n > 1:
+            assert not (G2[ref][:, ref]).nnz
+            assert np.all(ref | (np.asarray(G2[:, ref].sum(axis=1)).ravel() > 0))
+    for levels in (1, 3):                       # all tied / heavily tied
+        w = np.floor(np.random.default_rng(5).random(n) * levels) / levels
+        assert np.array_equal(H.mis2(S, w), _luby_on(G2, w)), levels
+    L = H.library()
+    before = L.pcdh_get_threads()
+    try:
+        w = np.random.default_rng(9).random(n)
+        L.pcdh_set_threads(1)
+        one = H.mis2(S, w)
+        L.pcdh_set_threads(7)
+        assert np.array_equal(H.mis2(S, w), one)
+    finally:
+        L.pcdh_set_threads(before)
+
+
+@pytest.mark.parametrize("make", [lambda: Cavity(3, nu=0.01),
+                                  lambda: Cavity3D(0, nu=0.01, n0=7)])
+def test_aggregation_equals_the_explicit_graph_route(make, monkeypatch):
+    """amg.aggregate on a P2 stencil: the aggregates of the native distance-2
+    rounds are those of the explicit (S + I)^2 route, vertex by vertex - the
+    hierarchies behind -pc_type gamg (and every GMRES count asserted on them)
+    do not move."""
+    from fenapack_amd import amg
+    pb = make()
+    V = pb.space
+    A00 = sp.csr_matrix(pb.linearise(np.zeros(V.n_u), np.zeros(V.n_p))["A00"])
+    F = H.kron_factor(A00, V.dim)
+    for theta in (0.0, 0.02):
+        S = amg._strength(F, theta)
+        monkeypatch.setenv("FENAPACK_AMD_MIS2_EXPLICIT", "1")
+        ref = amg.aggregate(S, 0, 2)
+        monkeypatch.setenv("FENAPACK_AMD_MIS2_EXPLICIT", "0")
+        got = amg.aggregate(S, 0, 2)
+        assert got[1] == ref[1] and np.array_equal(got[0], ref[0])
+    with pytest.raises(H.HostError):
+        H.library()  # (loaded) - bad arguments are refused, not read
+        H._chk(H.library().pcdh_mis2(3, None, None, None, None, None))

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--top", type=int, default=45)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--algebraic", action="store_true",
+                    help="-pc_type gamg (meshes without a nested hierarchy)")
     args = ap.parse_args()
 
     import oracle
@@ -43,7 +45,7 @@ def main():
             pb = Cavity3D(args.level, nu=0.01, n0=args.n0, variant="BRM1")
         t1 = time.time()
         PETScOptions.clear()
-        multigrid_inner_options(dim=pb.space.dim)
+        multigrid_inner_options(dim=pb.space.dim, algebraic=args.algebraic)
         w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150,
                                   newton_rtol=0.0, max_newton=args.steps,
                                   device=0)
