@@ -475,8 +475,19 @@ class PartitionedSA(object):
         of OTHER ranks (smoothing across the cut put entries there) travel to
         their owners (``HostComm.sum_rows``)."""
         r0, r1 = lev["own"]
-        AP = sp.csr_matrix(A[r0:r1] @ lev["Pext"])       # nloc x nc
-        C = sp.csr_matrix(lev["Pg"].T @ AP)              # nc x nc, my terms
+        if A.nnz > 400000 and not _host.use_numpy():
+            # the threaded native SpGEMM on the STRUCTURAL pattern: the
+            # refresh of every nonlinear step is these two products, and a
+            # pattern that does not depend on the values (scipy drops entries
+            # that cancel to an exact zero) is a level the engine keeps
+            # instead of taking it again
+            AP = _host.spgemm(A, lev["Pext"], r0, r1)    # nloc x nc
+            if "PgT" not in lev:
+                lev["PgT"] = _host.transpose(lev["Pg"])
+            C = _host.spgemm(lev["PgT"], AP)             # nc x nc, my terms
+        else:
+            AP = sp.csr_matrix(A[r0:r1] @ lev["Pext"])
+            C = sp.csr_matrix(lev["Pg"].T @ AP)
         if self.smooth == "global":
             C = self.host.sum_rows(C, lev["cuts"])
         C.sort_indices()
