@@ -646,6 +646,19 @@ def main():
             }
         except Exception as exc:                   # never lose the bench line
             out["comm"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if world > 1 and not partitioned and not args.no_cpu_baseline:
+        # parity of THIS partitioned run at full size, on the line: one
+        # PCApply of the global vector through the ranks (host-pointer call:
+        # collective, every rank gets the whole result) against the oracle's
+        # one-thread apply of the same workload on rank 0 - the checker sees
+        # what the product was handed (oracle.mirror).  Not a timing; the
+        # partitioned producer holds no global operators to mirror.
+        try:
+            out["parity_with_ranks"] = ranks_parity(pb, ksp, eng, xg, rank)
+        except Exception as exc:                   # never lose the bench line
+            out["parity_with_ranks"] = {"error": "%s: %s"
+                                        % (type(exc).__name__, exc)}
+        dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, pb, ksp, eng, c, x,
                                            bytes_pc)
@@ -839,6 +852,26 @@ def physical_cores():
         return len(seen) or None
     except Exception:
         return None
+
+
+def ranks_parity(pb, ksp, eng, xg, rank):
+    """One fieldsplit PCApply of the global vector ``xg`` through the
+    partitioned engine (collective host-pointer call) against the oracle's
+    apply of the same workload and inner settings, on rank 0."""
+    yg = np.empty_like(xg)
+    eng.fieldsplit_apply(xg, yg)                     # all ranks
+    if rank != 0:
+        return None
+    import oracle
+    serial = oracle.Engine(pb.variant)
+    oracle.mirror(serial, pb, ksp)
+    yh = np.empty_like(xg)
+    serial.fieldsplit_apply(xg, yh)
+    return {"hip_ranks_vs_oracle_rel_err":
+            float(np.abs(yg - yh).max() / np.abs(yh).max()),
+            "what": "one fieldsplit PCApply of the global vector through all "
+                    "ranks against oracle/pcd_oracle.c (one thread) on the "
+                    "same operators, hierarchy and inner settings"}
 
 
 def cpu_baseline(args, pb, ksp, eng, c, x, algorithmic_bytes=None):

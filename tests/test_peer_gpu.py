@@ -273,10 +273,13 @@ def test_bench_with_two_and_four_ranks_sharing_the_gpu(hip_lib):
             "--partitioned-producer"]
     for n, extra in ((2, []), (2, ["--partitioned-producer"]), (4, []),
                      (2, cube)):
+        # (the plain two-rank form also runs the line's own parity check:
+        # one PCApply through the ranks against the oracle on rank 0)
+        check = n == 2 and not extra
         run = subprocess.run(
             [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n),
-             "--share-gpu", "--steps", "10", "--warmup", "3",
-             "--no-cpu-baseline"]
+             "--share-gpu", "--steps", "10", "--warmup", "3"]
+            + ([] if check else ["--no-cpu-baseline"])
             + (["--level", "4"] if "--geometry" not in extra else []) + extra,
             env=env, capture_output=True, text=True, timeout=360)
         assert run.returncode == 0, run.stderr[-3000:]
@@ -287,6 +290,11 @@ def test_bench_with_two_and_four_ranks_sharing_the_gpu(hip_lib):
         assert d["config"]["parallelism"] == "row partition x%d" % n
         assert d["config"]["launch"] == "hipGraph replay"
         assert ("partitioned" in d["config"]["producer"]) == bool(extra)
+        if check:
+            assert d["parity_with_ranks"]["hip_ranks_vs_oracle_rel_err"] < 1e-11, \
+                d["parity_with_ranks"]
+        else:
+            assert "parity_with_ranks" not in d
         if "--algebraic" in extra:
             assert "cube N=12" in d["config"]["workload"], d["config"]
         assert len(d["gmres_its_per_newton_step"]) == 2
