@@ -41,6 +41,14 @@ def parse():
                    choices=["cavity", "lshape", "cube"])
     p.add_argument("--n0", type=int, default=4)
     p.add_argument("--variant", default="BRM1", choices=["BRM1", "BRM2"])
+    p.add_argument("--re", type=float, default=100.0,
+                   help="Reynolds number of the cavity / cube (lid speed 1, "
+                        "side 1: nu = 1 / Re); BASELINE configs[2] is 1000")
+    p.add_argument("--supg", action="store_true",
+                   help="SUPG-stabilised preconditioner matrix "
+                        "(fenapack/stabilization.py; BASELINE configs[2]): "
+                        "goes with --rediscretise-u (every level its own "
+                        "stabilisation parameter)")
     p.add_argument("--inner", default="mg", choices=["mg", "jacobi"])
     p.add_argument("--cycles-u", type=int, default=1)
     p.add_argument("--cycles-p", type=int, default=1)
@@ -285,11 +293,20 @@ def main():
     if args.share_gpu and world > 1:
         from fenapack_amd.parallel import TorchHostTransport
         comm = Comm(rank, world, host_transport=TorchHostTransport())
+    if args.supg and not args.rediscretise_u:
+        raise SystemExit("--supg goes with --rediscretise-u (a Galerkin "
+                         "product of a stabilised operator is not the "
+                         "stabilised operator of the coarse mesh)")
     if args.geometry == "cavity":
-        cls, kw = Cavity, dict(level=args.level, nu=0.01, variant=args.variant)
-    elif args.geometry == "cube":                                # 3D, Re = 100
-        cls, kw = Cavity3D, dict(level=args.level, nu=0.01, n0=args.n0,
-                                 variant=args.variant)
+        cls, kw = Cavity, dict(level=args.level, nu=1.0 / args.re,
+                               variant=args.variant)
+        if args.supg:
+            kw["stabilize"] = True
+    elif args.geometry == "cube":
+        cls, kw = Cavity3D, dict(level=args.level, nu=1.0 / args.re,
+                                 n0=args.n0, variant=args.variant)
+        if args.supg:
+            kw["stabilize"] = True
         # (config 5's own mesh, N = 73: 2.33 M tetrahedra - above the host
         # assembler's default limit; the memory estimate and the resident-set
         # watchdog still apply)
@@ -537,6 +554,25 @@ def main():
         pmc["roofline_kernel"]["traffic_bytes_per_launch"]
     pc_traffic = None if pmc is None or args.inner != "mg" else \
         pmc["pcapply"]["traffic_bytes_per_apply"]
+    # (the committed counter passes ran ONE inner configuration per size: the
+    # dominant kernel's traffic goes with the operator's pattern and holds for
+    # other settings on the same mesh, the whole apply's does not - quoted
+    # only when this workload issues the launches the counters saw)
+    launches_now = None
+    if world == 1:
+        eng.graph_enable(False)
+        step()
+        torch.cuda.synchronize()
+        l0 = eng.info(c.INFO_LAUNCHES)
+        step()
+        torch.cuda.synchronize()
+        launches_now = int(eng.info(c.INFO_LAUNCHES) - l0)
+        eng.graph_enable(not args.no_graph)
+    if pc_traffic is not None and \
+            launches_now != pmc["pcapply"]["launches_per_apply"]:
+        pc_traffic = None
+        pmc = dict(pmc, pcapply=dict(pmc["pcapply"],
+                                     launches_per_apply=launches_now))
     # the practical roof, measured by a kernel of this library on this box
     # (the dominant kernel is 93 % reads: the copy / triad probes, 33-50 %
     # writes, under-state what a read stream reaches - round 2's level-7 run
@@ -560,8 +596,9 @@ def main():
     # 10 B per entry + their tile sources, the gather kernels 12 B + row pointers)
     b_model = float(eng.info(c.INFO_A00_MODEL_BYTES))
     out = {
-        "metric": "fieldsplit PCApply calls/sec (%s Re=100, P2/P1)"
-                  % ("3D cavity" if args.geometry == "cube" else "2D cavity"),
+        "metric": "fieldsplit PCApply calls/sec (%s Re=%g, P2/P1)"
+                  % ("3D cavity" if args.geometry == "cube" else "2D cavity",
+                     args.re if args.geometry != "lshape" else 100.0),
         "value": args.steps / dt,
         "unit": "PCApply/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -573,12 +610,15 @@ def main():
         "data": "synthetic (own P2/P1 assembly; matrices frozen at Picard "
                 "iterate %d computed on the GPU)" % args.picard_steps,
         "config": {
-            "workload": ("cube N=%d (n0 %d, %d refinements), Re=100, P2/P1, "
-                         "PCD %s" % (args.n0 * 2 ** args.level, args.n0,
-                                     args.level, args.variant))
+            "workload": ("cube N=%d (n0 %d, %d refinements), Re=%g, P2/P1, "
+                         "PCD %s%s" % (args.n0 * 2 ** args.level, args.n0,
+                                       args.level, args.re, args.variant,
+                                       " + SUPG" if args.supg else ""))
             if args.geometry == "cube" else
-            "%s level %d, Re=100, P2/P1, PCD %s"
-            % (args.geometry, args.level, args.variant),
+            "%s level %d, Re=%g, P2/P1, PCD %s%s"
+            % (args.geometry, args.level,
+               args.re if args.geometry != "lshape" else 100.0, args.variant,
+               " + SUPG" if args.supg else ""),
             "ndof": int(n), "n_u": int(V.n_u), "n_p": int(V.n_p),
             "inner": inner_desc,
             "gmres": "restart 150, rtol 1e-6, right PC",
@@ -790,8 +830,9 @@ def roofline_block(kernel, b_alg, t, traffic, b_model, probes,
         "frac_traffic": None if traffic is None else gbs(traffic) / peak,
         "traffic": traffic,
         "traffic_gbs": gbs(traffic),
-        "traffic_source": None if pmc is None else pmc["file"],
-        "traffic_stale": pmc is None,
+        "traffic_source": None if pmc is None or traffic is None
+        else pmc["file"],
+        "traffic_stale": pmc is None or traffic is None,
         "us_per_launch": 1e6 * t,
         "measured_probes_gbs": probes,
         "measured_torch_copy_gbs": torch_copy_gbs,
