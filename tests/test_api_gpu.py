@@ -222,3 +222,37 @@ def test_algebraic_hierarchy_in_three_dimensions(monkeypatch):
     ops = ksp0.pc.mg_data["ops"]
     assert ksp0.pc.mg_algebraic and len(ops) >= 2
     assert ops[0].shape[0] <= ksp0.pc.mg_coarse_eq_limit
+
+
+def test_bench_line_of_the_re1000_supg_configuration():
+    """``bench.py --re 1000 --supg --rediscretise-u`` - BASELINE configs[2]'s
+    flow (Re = 1000, SUPG-stabilised preconditioner matrix,
+    fenapack/stabilization.py:66-67) through the bench contract, in small
+    (level 4): one JSON line that names the workload, carries the oracle's
+    parity of this very state, and withholds the whole-apply PMC traffic
+    (no counter pass exists for this inner configuration).  --supg without
+    --rediscretise-u is refused."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--level", "4",
+           "--re", "1000", "--supg", "--steps", "5", "--warmup", "2",
+           "--cycles-u", "2", "--cycles-p", "2", "--smooth", "3",
+           "--no-producer", "--cpu-seconds", "1"]
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "--rediscretise-u" in bad.stderr
+    run = subprocess.run(cmd + ["--rediscretise-u"], capture_output=True,
+                         text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "fieldsplit PCApply calls/sec (2D cavity Re=1000, P2/P1)"
+    assert d["config"]["workload"] == \
+        "cavity level 4, Re=1000, P2/P1, PCD BRM1 + SUPG"
+    assert d["value"] > 0 and len(d["gmres_its_per_newton_step"]) == 2
+    assert d["cpu_baseline"]["gpu_vs_oracle_rel_err"] < 1e-11
+    assert d["pcapply_roofline"]["traffic"] is None
+    assert d["pcapply_roofline"]["traffic_stale"]
