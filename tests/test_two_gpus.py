@@ -95,9 +95,9 @@ def test_bench_on_two_gpus_over_rccl():
     for n in (1, 2):
         out = subprocess.run(
             [sys.executable, BENCH, "--gpus", str(n), "--level", "4",
-             "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-             "--no-producer"], env=_env(), capture_output=True, text=True,
-            timeout=420)
+             "--steps", "3", "--warmup", "1", "--no-producer"]
+            + (["--no-cpu-baseline"] if n == 1 else []),
+            env=_env(), capture_output=True, text=True, timeout=420)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, out.stdout
@@ -106,6 +106,14 @@ def test_bench_on_two_gpus_over_rccl():
     assert recs[2]["config"]["parallelism"] == "row partition x2"
     assert recs[2]["gmres_its_per_newton_step"] == \
         recs[1]["gmres_its_per_newton_step"]
+    # the line's own parity check (one PCApply through both GPUs against the
+    # oracle on rank 0) and what the ranks exchanged per PCApply
+    assert recs[2]["parity_with_ranks"]["hip_ranks_vs_oracle_rel_err"] < 1e-11, \
+        recs[2]["parity_with_ranks"]
+    cm = recs[2]["comm"]
+    assert "error" not in cm, cm
+    assert cm["peer_write_exchanges_and_reductions_per_pcapply"] \
+        + cm["rccl_or_host_transport_calls_per_pcapply"] >= 4
 
 
 @needs2
