@@ -351,6 +351,147 @@ int spmv_other_values(Engine* h, DCsr& A, double*& other, const double* x, doubl
   return rc;
 }
 
+// ---- ChebPatch: m Chebyshev-Jacobi steps of a small scalar operator in ONE
+// launch (pcd_internal.hpp, k_cheb_patch).  PCD_CHEB_PATCH=0 switches it off;
+// PCD_CHEB_PATCH_ROWS (default 2 000 000) is the largest operator it is built
+// for; PCD_CHEB_PATCH_CLUSTER (512) rows per cluster.  Measured on the
+// pressure mass matrix of the cavity (5 steps, same-box A/B, profiles/r05_u_*):
+// level 6 (103 041 rows: 206 clusters, 2.0 x the rows in patches) 27 us in
+// five launches -> 9.6 us, one PCApply 0.288 -> 0.273 ms; level 7 (410 881
+// rows) 64 -> 26 us, 0.744 -> 0.702 ms - the matrix is read once (twice, with
+// the redundancy) instead of five times.  In space the patches of five edges
+// outgrow the workgroup and the step-by-step path stays.
+// One rank only (a ghost column changes with every step).  Clusters: greedy
+// breadth-first balls in the operator's own row order (pcd_reorder.hpp's
+// cluster rule); the patch = the cluster and everything within m edges,
+// ordered by distance.  Not built (the step-by-step path stays) when a patch
+// exceeds the workgroup's LDS or the patches together exceed 3 x the rows.
+int build_cheb_patch(Engine* h, DCsr& A, int m) {
+  A.cp.release();
+  // (read per build: the A/B tests of one process switch it between engines)
+  const char* eo = getenv("PCD_CHEB_PATCH");
+  const int on = eo ? atoi(eo) : 1;
+  const char* er = getenv("PCD_CHEB_PATCH_ROWS");
+  const int64_t max_rows = er ? atoll(er) : 2000000;
+  const char* ec = getenv("PCD_CHEB_PATCH_CLUSTER");
+  const int csize = std::max(32, ec ? atoi(ec) : 512);
+  if (!on || h->comm || m < 2 || m > kChebPatchMaxM || !A.set || A.kron || A.dense || A.nrows != A.ncols ||
+      A.nrows < 1 || A.nrows > max_rows || A.nnz < 1 || A.plan.nghost)
+    return 0;
+  const int64_t n = A.nrows;
+  std::vector<int32_t> rp(n + 1), cc(A.nnz);
+  HIPCHK(hipMemcpy(rp.data(), A.rowptr.p, (n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cc.data(), A.col.p, (size_t)A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  // symmetric adjacency (the operator's pattern may be one-sided at BC rows)
+  std::vector<int64_t> ap(n + 1, 0);
+  for (int64_t i = 0; i < n; ++i)
+    for (int32_t q = rp[i]; q < rp[i + 1]; ++q)
+      if (cc[q] != i) { ++ap[i + 1]; ++ap[cc[q] + 1]; }
+  for (int64_t i = 0; i < n; ++i) ap[i + 1] += ap[i];
+  std::vector<int32_t> adj(ap[n]);
+  {
+    std::vector<int64_t> fill(ap.begin(), ap.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+      for (int32_t q = rp[i]; q < rp[i + 1]; ++q)
+        if (cc[q] != i) { adj[fill[i]++] = cc[q]; adj[fill[cc[q]]++] = (int32_t)i; }
+  }
+  // clusters
+  std::vector<int32_t> order; order.reserve(n);
+  std::vector<int64_t> cstart;
+  {
+    std::vector<char> seen(n, 0);
+    for (int64_t s0 = 0; s0 < n; ++s0) {
+      if (seen[s0]) continue;
+      const size_t first = order.size();
+      cstart.push_back((int64_t)first);
+      order.push_back((int32_t)s0); seen[s0] = 1;
+      for (size_t q = first; q < order.size() && order.size() - first < (size_t)csize; ++q) {
+        const int32_t v = order[q];
+        for (int64_t e = ap[v]; e < ap[v + 1] && order.size() - first < (size_t)csize; ++e)
+          if (!seen[adj[e]]) { seen[adj[e]] = 1; order.push_back(adj[e]); }
+      }
+      std::sort(order.begin() + first, order.end());
+    }
+    cstart.push_back((int64_t)order.size());
+  }
+  const int nb = (int)cstart.size() - 1;
+  // patches: breadth-first layers around every cluster
+  std::vector<int32_t> node;
+  std::vector<int4> desc(nb);
+  std::vector<int> cnt((size_t)nb * (kChebPatchMaxM + 1), 0);
+  std::vector<unsigned short> ecol;
+  std::vector<int> epos;
+  std::vector<int32_t> stamp(n, -1), local(n, 0);
+  int64_t total = 0;
+  int wmax = 0;
+  for (int b = 0; b < nb; ++b) {
+    const size_t off = node.size();
+    for (int64_t q = cstart[b]; q < cstart[b + 1]; ++q) {
+      stamp[order[q]] = b; local[order[q]] = (int32_t)(node.size() - off); node.push_back(order[q]);
+    }
+    int* c = &cnt[(size_t)b * (kChebPatchMaxM + 1)];
+    c[0] = (int)(node.size() - off);
+    size_t lo = off;
+    for (int k = 1; k <= m; ++k) {
+      const size_t hi = node.size();
+      for (size_t q = lo; q < hi; ++q) {
+        const int32_t v = node[q];
+        for (int64_t e = ap[v]; e < ap[v + 1]; ++e) {
+          const int32_t w = adj[e];
+          if (stamp[w] != b) { stamp[w] = b; local[w] = (int32_t)(node.size() - off); node.push_back(w); }
+        }
+      }
+      std::sort(node.begin() + hi, node.end());
+      for (size_t q = hi; q < node.size(); ++q) local[node[q]] = (int32_t)(q - off);
+      lo = hi;
+      c[k] = (int)(node.size() - off);
+    }
+    for (int k = m + 1; k <= kChebPatchMaxM; ++k) c[k] = c[m];
+    const int P = c[m];
+    if (P > kChebPatchNodes) return 0;                        // does not fit the workgroup's LDS
+    total += P;
+    if (total > 3 * n + 4096) return 0;                       // too much redundant work
+    // ELL rows of the nodes within m - 1 edges (their columns lie within m)
+    const int R = c[m - 1], Rpad = (R + 63) / 64 * 64;
+    int W = 0;
+    for (int r = 0; r < R; ++r) { const int32_t g = node[off + r]; W = std::max(W, rp[g + 1] - rp[g]); }
+    if (W > 16 || Rpad > 0xffff) return 0;                   // (the kernel keeps the rows in registers)
+    wmax = std::max(wmax, W);
+    const size_t ell = ecol.size();
+    if (ell + (size_t)W * Rpad > (size_t)INT32_MAX) return 0;
+    ecol.resize(ell + (size_t)W * Rpad, 0);
+    epos.resize(ell + (size_t)W * Rpad, -1);
+    for (int r = 0; r < R; ++r) {
+      const int32_t g = node[off + r];
+      int e = 0;
+      for (int32_t q = rp[g]; q < rp[g + 1]; ++q, ++e) {
+        if (stamp[cc[q]] != b) return fail(PCD_ERR_STATE, "cheb patch: column outside the patch");
+        ecol[ell + (size_t)e * Rpad + r] = (unsigned short)local[cc[q]];
+        epos[ell + (size_t)e * Rpad + r] = q;
+      }
+    }
+    desc[b] = int4{(int)off, (int)ell, P, Rpad | (W << 16)};
+  }
+  if (node.size() > (size_t)INT32_MAX) return 0;
+  ChebPatch& cp = A.cp;
+  CHK(cp.node.ensure(node.size())); CHK(cp.desc.ensure(nb)); CHK(cp.cnt.ensure(cnt.size()));
+  CHK(cp.col.ensure(ecol.size())); CHK(cp.val.ensure(ecol.size())); CHK(cp.pos.ensure(epos.size()));
+  HIPCHK(hipMemcpy(cp.node.p, node.data(), node.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cp.desc.p, desc.data(), (size_t)nb * sizeof(int4), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cp.cnt.p, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cp.col.p, ecol.data(), ecol.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cp.pos.p, epos.data(), epos.size() * sizeof(int), hipMemcpyHostToDevice));
+  cp.nslots = (int64_t)ecol.size(); cp.nblocks = nb; cp.m = m; cp.wmax = wmax;
+  hipLaunchKernelGGL(k_lm_values, dim3(grid1d(cp.nslots, 4)), dim3(kBlock), 0, h->stream,
+                     cp.nslots, cp.pos.p, A.val.p, cp.val.p);
+  HIPCHK(hipGetLastError());
+  cp.ready = true;
+  if (const char* e = getenv("PCD_CHEB_PATCH_STATS")) if (e[0] == '1')
+    fprintf(stderr, "[pcd cheb patch] %lld rows, m = %d: %d clusters, %.2f x the rows in patches, %lld ELL slots\n",
+            (long long)n, m, nb, (double)total / (double)n, (long long)cp.nslots);
+  return 0;
+}
+
 int refresh_dinv(Engine* h, DCsr& A) {
   CHK(refresh_kron(h, A));
   if (A.nrows != A.ncols) return 0;
@@ -389,6 +530,9 @@ int refresh_dinv(Engine* h, DCsr& A) {
                          A.nnz, A.col.p, A.val.p, A.dinv.p, 1, A.vals.p, A.ghost.p, (int)A.ncols);
     }
   }
+  if (A.cp.ready)                       // the patch copies follow the values in force
+    hipLaunchKernelGGL(k_lm_values, dim3(grid1d(A.cp.nslots, 4)), dim3(kBlock), 0, h->stream,
+                       A.cp.nslots, A.cp.pos.p, A.val.p, A.cp.val.p);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -431,6 +575,9 @@ int inner_prepare(Engine* h, int slot) {
       break;
     case PCD_KSP_CHEBYSHEV:
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n));
+      // (all its steps in one launch where the operator is small enough)
+      if (s.pc == PCD_PC_JACOBI && (!h->mat[kSlotMat[slot]].cp.ready || h->mat[kSlotMat[slot]].cp.m != s.max_it))
+        CHK(build_cheb_patch(h, h->mat[kSlotMat[slot]], s.max_it));
       break;
     case PCD_KSP_RICHARDSON:
       CHK(s.t0.ensure(n));
@@ -712,6 +859,27 @@ int solve_cheb(Engine* h, const DCsr& A, Inner& s, const double* b,
   double* ring[3];
   const int m = s.max_it;
   ring[m % 3] = x; ring[(m + 1) % 3] = s.t0.p; ring[(m + 2) % 3] = s.t1.p;
+  if (A.cp.ready && A.cp.m == m && s.pc == PCD_PC_JACOBI && dinv && !h->comm) {
+    ChebPatchCoef cf;
+    cf.scale = scale; cf.m = m;
+    for (int it = 0; it < m; ++it) {
+      const double c_kp1 = 2.0 * mu * c_k - c_km1;
+      const double omega = omegaprod * c_k / c_kp1;
+      const double f = (it == m - 1) ? out_scale : 1.0;
+      cf.c0[it] = it == 0 ? 0.0 : f * (1.0 - omega);
+      cf.c1[it] = f * omega; cf.c2[it] = f * omega * scale;
+      c_km1 = c_k; c_k = c_kp1;
+    }
+    if (A.cp.wmax <= 8)
+      hipLaunchKernelGGL(k_cheb_patch<8>, dim3(A.cp.nblocks), dim3(kPatchThreads), 0, h->stream, A.cp.desc.p,
+                         A.cp.cnt.p, A.cp.node.p, A.cp.col.p, A.cp.val.p, dinv, b, x, cf);
+    else
+      hipLaunchKernelGGL(k_cheb_patch<16>, dim3(A.cp.nblocks), dim3(kPatchThreads), 0, h->stream, A.cp.desc.p,
+                         A.cp.cnt.p, A.cp.node.p, A.cp.col.p, A.cp.val.p, dinv, b, x, cf);
+    HIPCHK(hipGetLastError());
+    s.last_its = m; s.its_on_device = false;
+    return 0;
+  }
   const int g1 = grid1d(n, 1);
   const bool fuse = m >= 1 && can_fuse_first(h, A, dinv);
   if (!fuse)

@@ -104,8 +104,34 @@ struct DBuf {
   }
 };
 
+// Chebyshev-Jacobi solves of m steps in ONE launch (k_cheb_patch): the rows
+// are cut into graph clusters, every cluster carries the nodes within m edges
+// (its PATCH, ordered by distance) and the matrix rows of the nodes within
+// m - 1 edges in ELL form with 16-bit patch-local columns; a workgroup runs the
+// m steps of its patch in LDS - step k on the nodes within m - k edges - and
+// writes its own rows.  For operators at the launch-latency floor (a dependent
+// launch on <= 10^5 rows costs 4-6 us whatever it computes).
+constexpr int kChebPatchMaxM = 8;
+constexpr int kChebPatchNodes = 1536;        // patch nodes a workgroup holds (5 x 8 B each in LDS)
+struct ChebPatch {
+  bool ready = false;
+  int m = 0, nblocks = 0, wmax = 0;      // wmax: the widest ELL row of all patches
+  int64_t nslots = 0;
+  DBuf<int> node;                 // patch node lists, block after block
+  DBuf<int4> desc;                // x node offset, y ELL offset, z patch nodes, w padded rows | width << 16
+  DBuf<int> cnt;                  // per block kChebPatchMaxM + 1: nodes within k edges
+  DBuf<unsigned short> col;       // ELL columns (patch-local)
+  DBuf<double> val;               // ELL values
+  DBuf<int> pos;                  // ... their positions in the operator's values (-1: padding)
+  void release() {
+    ready = false; m = 0; nblocks = 0; wmax = 0; nslots = 0;
+    node.release(); desc.release(); cnt.release(); col.release(); val.release(); pos.release();
+  }
+};
+
 struct DCsr {
   int64_t nrows = 0, ncols = 0, nnz = 0;
+  ChebPatch cp;
   DBuf<int> rowptr, col;
   DBuf<double> val, dinv;
   DBuf<double> vals, val2s;   // column-scaled copies val .* dinv[col] (zero-guess first step)
@@ -177,6 +203,7 @@ struct DCsr {
     vt = false; vt_blocks = 0; vt_desc.release(); vt_rowoff.release(); vt_tsrc.release(); vt_loc.release();
     vt_lm = false; vt_slots = 0; vt_val.release(); vt_pos.release();
     vt_list.release(); vt_nint = vt_nbnd = 0;
+    cp.release();
     rk = 0; rk_rb = 0; rk_nnz = 0; rk_rowptr.release(); rk_col.release(); rk_pos.release(); rk_val.release();
     plan = HaloPlan(); replicated = false;
     if (ph.dev.seq) (void)hipFree(ph.dev.seq);
@@ -513,6 +540,7 @@ int spmv(Engine* h, const DCsr& A, const double* x, double* y,
                 bool halo_done = false);
 int spmv_other_values(Engine* h, DCsr& A, double*& other, const double* x, double* y);
 int refresh_dinv(Engine* h, DCsr& A);
+int build_cheb_patch(Engine* h, DCsr& A, int m);
 int inner_prepare(Engine* h, int slot);
 int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                             const double* b, const double* pm, const double* pk,

@@ -1558,6 +1558,85 @@ __global__ __launch_bounds__(kBlock) void k_cheb_first_lm(
   }
 }
 
+// ==========================================================================
+// m Chebyshev-Jacobi steps in ONE launch (ChebPatch, pcd_internal.hpp): a
+// workgroup holds the patch of its cluster in LDS - b, D^-1 and a ring of three
+// iterates - and runs step k on the nodes within m - k edges of the cluster
+// (they are the first cnt[m - k] nodes of the patch: the list is ordered by
+// distance); the matrix rows come as ELL slices (entry e of all rows side by
+// side: coalesced) with patch-local 16-bit columns (WMAX: the widest row the
+// instantiation holds).  Zero initial guess:
+// p0 = scale D^-1 b, then p_{k+1} = c0 p_{k-1} + c1 p_k + c2 D^-1 (b - A p_k)
+// with the host's coefficients (solve_cheb).  What a cluster computes for the
+// nodes around it other clusters compute as well: redundant arithmetic instead
+// of m - 1 dependent launches.
+// ==========================================================================
+struct ChebPatchCoef {
+  double c0[8], c1[8], c2[8];
+  double scale;
+  int m;
+};
+constexpr int kPatchThreads = 512;
+constexpr int kPatchRows = 3;                 // matrix rows per thread: 3 x 512 = the 1536 patch nodes
+// The matrix rows a thread works on are the same in every step: they are read
+// ONCE, into registers (kPatchRows x WMAX values and patch-local columns per
+// thread, every loop unrolled) - the steps themselves touch LDS only.
+template <int WMAX>
+static __global__ __launch_bounds__(kPatchThreads) void k_cheb_patch(
+    const int4* __restrict__ desc, const int* __restrict__ cnt_, const int* __restrict__ node,
+    const unsigned short* __restrict__ col, const double* __restrict__ val,
+    const double* __restrict__ dinv, const double* b, double* x, ChebPatchCoef cf) {
+  constexpr int PM = 1536, NT = kPatchThreads, RT = kPatchRows;
+  static_assert(NT * RT >= PM, "every patch row has a thread");
+  __shared__ double lds[5 * PM];
+  double *bl = lds, *dl = lds + PM, *p0 = lds + 2 * PM, *p1 = lds + 3 * PM, *p2 = lds + 4 * PM;
+  const int4 d = desc[blockIdx.x];
+  const int* cnt = cnt_ + (size_t)blockIdx.x * 9;
+  const int P = d.z, Rpad = d.w & 0xffff, W = d.w >> 16;
+  const int t = threadIdx.x;
+  const int R0 = cnt[cf.m - 1];                       // rows that are ever updated
+  double av[RT][WMAX];
+  unsigned short ac[RT][WMAX];
+  const unsigned short* cb = col + d.y;
+  const double* vb = val + d.y;
+#pragma unroll
+  for (int j = 0; j < RT; ++j) {
+    const int r = t + j * NT;
+#pragma unroll
+    for (int e = 0; e < WMAX; ++e) {
+      const bool in = r < R0 && e < W;
+      av[j][e] = in ? vb[(size_t)e * Rpad + r] : 0.0;
+      ac[j][e] = in ? cb[(size_t)e * Rpad + r] : (unsigned short)0;
+    }
+  }
+  for (int q = t; q < P; q += NT) {
+    const int nd = node[d.x + q];
+    const double bq = b[nd], dq = dinv[nd];
+    bl[q] = bq; dl[q] = dq; p0[q] = cf.scale * dq * bq;
+  }
+  __syncthreads();
+  double *pm = p2, *pk = p0, *pn = p1;
+  for (int it = 0; it < cf.m; ++it) {
+    const int Rk = cnt[cf.m - 1 - it];
+    const double c0 = cf.c0[it], c1 = cf.c1[it], c2 = cf.c2[it];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const int r = t + j * NT;
+      if (r < Rk) {
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < WMAX; ++e) s += av[j][e] * pk[ac[j][e]];
+        const double keep = c0 != 0.0 ? c0 * pm[r] : 0.0;
+        pn[r] = keep + c1 * pk[r] + c2 * dl[r] * (bl[r] - s);
+      }
+    }
+    __syncthreads();
+    double* o = pm; pm = pk; pk = pn; pn = o;
+  }
+  const int own = cnt[0];
+  for (int r = t; r < own; r += NT) x[node[d.x + r]] = pk[r];
+}
+
 // lane-major values from F's row-major ones: out[s] = pos[s] < 0 ? 0 : valc[pos[s]]
 static __global__ __launch_bounds__(kBlock) void k_lm_values(
     int64_t nslots, const int* __restrict__ pos, const double* valc, double* out) {

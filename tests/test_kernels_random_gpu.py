@@ -242,3 +242,90 @@ def test_smoother_on_a_fully_dense_multi_component_level(hip_lib, nc):
         o.set_inner(c.KSP_AP, *cfg)
         assert relerr(e.inner_solve_np(c.KSP_AP, b),
                       o.inner_solve_np(c.KSP_AP, b)) < 1e-11, cfg
+
+
+def _grid_operator(rng, shape, diag_links):
+    """SPD-ish operator on a structured grid: nearest neighbours (and the
+    diagonal ones of a P1 triangulation where asked), random positive
+    weights, diagonally dominant."""
+    n = int(np.prod(shape))
+    idx = np.arange(n).reshape(shape)
+    rows, cols = [], []
+    dirs = []
+    for ax in range(len(shape)):
+        d = [0] * len(shape)
+        d[ax] = 1
+        dirs.append(tuple(d))
+    if diag_links:
+        dirs.append(tuple([1] * len(shape)))
+    for d in dirs:
+        sl_a = tuple(slice(0, s - dd) for s, dd in zip(shape, d))
+        sl_b = tuple(slice(dd, s) for s, dd in zip(shape, d))
+        rows.append(idx[sl_a].ravel())
+        cols.append(idx[sl_b].ravel())
+    r, cc = np.concatenate(rows), np.concatenate(cols)
+    w = rng.random(r.size) + 0.1
+    A = sp.coo_matrix((np.r_[-w, -w], (np.r_[r, cc], np.r_[cc, r])), shape=(n, n)).tocsr()
+    A = A + sp.diags(-np.asarray(A.sum(axis=1)).ravel() + rng.random(n) + 0.5)
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("shape,diag", [((150, 150), True), ((97, 61), False),
+                                        ((14, 14, 14), False)])
+def test_chebyshev_steps_in_one_launch(hip_lib, monkeypatch, shape, diag):
+    """ChebPatch (k_cheb_patch): the m Chebyshev-Jacobi steps of a small scalar
+    operator in ONE launch - graph clusters with their m-edge patches, the
+    steps run in LDS - against the step-by-step path (PCD_CHEB_PATCH=0) and
+    the oracle, m = 2 .. 8; a value update reaches the patch copies; an
+    operator whose patches would not fit stays on the step-by-step path."""
+    rng = np.random.default_rng(sum(shape))
+    A = _grid_operator(rng, shape, diag)
+    n = A.shape[0]
+    b = rng.standard_normal(n)
+    o = oracle.Engine("BRM1")
+    o.set_csr(c.MAT_MP, A)
+    engines = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("PCD_CHEB_PATCH", sw)
+        e = c.Engine(hip_lib, "BRM1", 0)
+        e.set_csr(c.MAT_MP, A)
+        engines[sw] = e
+    used = 0
+    for m in (2, 3, 5, 8):
+        cfg = ("chebyshev", "jacobi", m, 0.0, 0.4, 2.1)
+        o.set_inner(c.KSP_MP, *cfg)
+        ref = o.inner_solve_np(c.KSP_MP, b)
+        out = {}
+        for sw, e in engines.items():
+            monkeypatch.setenv("PCD_CHEB_PATCH", sw)
+            e.set_inner(c.KSP_MP, *cfg)
+            e.inner_solve_np(c.KSP_MP, b)                       # (set-up on first use)
+            l0 = e.info(c.INFO_LAUNCHES)
+            out[sw] = e.inner_solve_np(c.KSP_MP, b)
+            out[sw + "launches"] = e.info(c.INFO_LAUNCHES) - l0
+        assert relerr(out["0"], ref) < 1e-11, m
+        assert relerr(out["1"], ref) < 1e-11, m
+        assert relerr(out["1"], out["0"]) < 1e-13, m
+        if out["1launches"] < out["0launches"]:
+            used += 1
+            assert out["0launches"] - out["1launches"] == m - 1, (m, out)
+    # the plane fits for every m here; in space the patches of many edges
+    # outgrow the workgroup and the step-by-step path stays
+    assert used >= (4 if len(shape) == 2 else 1), used
+    # new values, same pattern
+    A2 = A.copy()
+    A2.data[:] = A.data * (1.0 + 0.1 * rng.random(A.nnz))
+    A2 = sp.csr_matrix((A2 + A2.T) * 0.5)
+    A2.sort_indices()
+    assert np.array_equal(A2.indices, A.indices)
+    cfg = ("chebyshev", "jacobi", 5, 0.0, 0.4, 2.1)
+    o.set_csr(c.MAT_MP, A2)
+    o.set_inner(c.KSP_MP, *cfg)
+    ref = o.inner_solve_np(c.KSP_MP, b)
+    for sw, e in engines.items():
+        monkeypatch.setenv("PCD_CHEB_PATCH", sw)
+        e.set_inner(c.KSP_MP, *cfg)
+        e.update_values(c.MAT_MP, A2.data)
+        assert relerr(e.inner_solve_np(c.KSP_MP, b), ref) < 1e-11, sw
