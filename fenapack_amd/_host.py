@@ -14,7 +14,10 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIBRARY_PATH = os.path.join(HERE, "lib", "libpcd_host.so")
+# (FENAPACK_AMD_HOST_LIBRARY: another build of the SAME sources - the ASan +
+# UBSan one of csrc/Makefile, which the CPU suite runs its native tests on)
+HOST_LIBRARY_PATH = os.environ.get(
+    "FENAPACK_AMD_HOST_LIBRARY", os.path.join(HERE, "lib", "libpcd_host.so"))
 
 _I64P = ctypes.POINTER(ctypes.c_int64)
 _I32P = ctypes.POINTER(ctypes.c_int32)

@@ -5,7 +5,7 @@
 
 const char* pcd_last_error(void) { return g_err; }
 
-int pcd_create(pcd_handle* out, int variant, int device) {
+int pcd_create(pcd_handle* out, int variant, int device) try {
   if (!out) return fail(PCD_ERR_ARG, "create: null out");
   if (variant < PCD_BRM1 || variant > PCDR_BRM2)
     return fail(PCD_ERR_ARG, "create: bad variant %d", variant);
@@ -30,9 +30,9 @@ int pcd_create(pcd_handle* out, int variant, int device) {
   h->variant = variant; h->device = device;
   *out = h;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_create)
 
-int pcd_destroy(pcd_handle h) {
+int pcd_destroy(pcd_handle h) try {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
@@ -55,15 +55,15 @@ int pcd_destroy(pcd_handle h) {
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   delete h;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_destroy)
 
-int pcd_set_stream(pcd_handle h, void* hip_stream) {
+int pcd_set_stream(pcd_handle h, void* hip_stream) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   HIPCHK(hipStreamSynchronize(h->stream));
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   ++h->gen;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_set_stream)
 
 
 // Field vectors cross the ABI in the CALLER's numbering (global vectors); the
@@ -122,7 +122,7 @@ int fio_end(FieldIo& f) {
   return io_end(f.io);
 }
 
-int pcd_apply(pcd_handle h, const double* x, double* y, int mem) {
+int pcd_apply(pcd_handle h, const double* x, double* y, int mem) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!h->ready) return fail(PCD_ERR_STATE, "apply: call pcd_setup first");
   if (!x || !y || x == y) return fail(PCD_ERR_ARG, "apply: x and y must be distinct non-null vectors");
@@ -131,9 +131,9 @@ int pcd_apply(pcd_handle h, const double* x, double* y, int mem) {
                 &h->rp, &h->rp));
   CHK(pcd_apply_dev(h, f.lx, f.ly));
   return fio_end(f);
-}
+} PCD_ABI_CATCH(pcd_apply)
 
-int pcd_fieldsplit_apply(pcd_handle h, const double* x, double* y, int mem) {
+int pcd_fieldsplit_apply(pcd_handle h, const double* x, double* y, int mem) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!h->ready || !h->mat[PCD_MAT_A00].set)
     return fail(PCD_ERR_STATE, "fieldsplit_apply: pcd_set_system + pcd_setup first");
@@ -152,14 +152,14 @@ int pcd_fieldsplit_apply(pcd_handle h, const double* x, double* y, int mem) {
   if (h->comm && h->comm->allreduce(io.dy, n, h->stream))
     return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
   return io_end(io);
-}
+} PCD_ABI_CATCH(pcd_fieldsplit_apply)
 
 // The dominant kernel where it runs: `reps` EAGER fieldsplit applies (device
 // vectors) with an event pair around every fused Chebyshev step on the finest
 // velocity operator - the caches in the state the multigrid cycle leaves them
 // in, where a back-to-back loop on one operator keeps them warm.  An event
 // pair adds about a microsecond of its own.
-int pcd_probe_a00_step(pcd_handle h, const double* x, double* y, int reps, double* us, int* launches) {
+int pcd_probe_a00_step(pcd_handle h, const double* x, double* y, int reps, double* us, int* launches) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!us || !launches || reps < 1) return fail(PCD_ERR_ARG, "probe_a00_step: bad arguments");
   const bool graph = h->graph_on;
@@ -182,7 +182,7 @@ int pcd_probe_a00_step(pcd_handle h, const double* x, double* y, int reps, doubl
   *us = cnt ? sum / cnt : 0.0;
   *launches = cnt;
   return rc;
-}
+} PCD_ABI_CATCH(pcd_probe_a00_step)
 
 // which -> (row space, column space) of a stored operator
 void mat_spaces(Engine* h, int which, const Space** rs, const Space** cs) {
@@ -194,7 +194,7 @@ void mat_spaces(Engine* h, int which, const Space** rs, const Space** cs) {
   }
 }
 
-int pcd_spmv(pcd_handle h, int which, const double* x, double* y, int mem) {
+int pcd_spmv(pcd_handle h, int which, const double* x, double* y, int mem) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (which < 0 || which >= PCD_MAT_COUNT || !h->mat[which].set)
     return fail(PCD_ERR_STATE, "spmv: operator %d not set", which);
@@ -210,9 +210,9 @@ int pcd_spmv(pcd_handle h, int which, const double* x, double* y, int mem) {
                 rs, h->comm ? rs->total() : A.nrows, A.nrows, x, y, mem, false, rx, ry));
   CHK(spmv(h, A, f.lx, f.ly));
   return fio_end(f);
-}
+} PCD_ABI_CATCH(pcd_spmv)
 
-int pcd_inner_solve(pcd_handle h, int slot, const double* b, double* x, int mem) {
+int pcd_inner_solve(pcd_handle h, int slot, const double* b, double* x, int mem) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "inner_solve: bad slot %d", slot);
   const DCsr& A = h->mat[kSlotMat[slot]];
@@ -227,9 +227,9 @@ int pcd_inner_solve(pcd_handle h, int slot, const double* b, double* x, int mem)
   CHK(fio_begin(f, h, rs, ng, A.nrows, rs, ng, A.nrows, b, x, mem, false, rr, rr));
   CHK(inner_solve(h, slot, f.lx, f.ly));
   return fio_end(f);
-}
+} PCD_ABI_CATCH(pcd_inner_solve)
 
-int pcd_apply_bc(pcd_handle h, double* x, int mem) {
+int pcd_apply_bc(pcd_handle h, double* x, int mem) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!x) return fail(PCD_ERR_ARG, "apply_bc: null vector");
   if (!h->ready) return fail(PCD_ERR_STATE, "apply_bc: call pcd_setup first");
@@ -238,9 +238,9 @@ int pcd_apply_bc(pcd_handle h, double* x, int mem) {
                 nullptr, &h->rp));
   CHK(apply_bc_dev(h, f.ly));
   return fio_end(f);
-}
+} PCD_ABI_CATCH(pcd_apply_bc)
 
-int pcd_get_info(pcd_handle h, int key, double* out) {
+int pcd_get_info(pcd_handle h, int key, double* out) try {
   if (!h || !out) return fail(PCD_ERR_ARG, "get_info: null argument");
   switch (key) {
     case PCD_INFO_N_U: *out = (double)h->n_u; return 0;
@@ -314,15 +314,15 @@ int pcd_get_info(pcd_handle h, int key, double* out) {
       }
   }
   return fail(PCD_ERR_ARG, "get_info: unknown key %d", key);
-}
+} PCD_ABI_CATCH(pcd_get_info)
 
-int pcd_set_velocity_block(pcd_handle h, int ncomp) {
+int pcd_set_velocity_block(pcd_handle h, int ncomp) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (ncomp < 1 || ncomp > 3) return fail(PCD_ERR_ARG, "set_velocity_block: 1..3 components");
   for (auto& m : h->mat) if (m.set) return fail(PCD_ERR_STATE, "set_velocity_block: call before any operator is handed over");
   h->vel_block = ncomp;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_set_velocity_block)
 
 // Streaming bandwidth of this GPU as a kernel of this library sees it:
 // kind 0 copy, 1 triad, 2 read-only, 3 read-mostly (6 % writes), 4 read-only
@@ -330,7 +330,7 @@ int pcd_set_velocity_block(pcd_handle h, int ncomp) {
 // `bytes` each (>= 256 MiB: beyond the
 // Infinity Cache), best of `reps` launches, timed with events on the engine's
 // stream.  *gbs = bytes moved (reads + writes) per second / 1e9.
-int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double* gbs) {
+int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double* gbs) try {
   if (!h || !gbs) return fail(PCD_ERR_ARG, "bandwidth_probe: null argument");
   if (kind < 0 || kind > 4 || bytes < 4096 || reps < 1) return fail(PCD_ERR_ARG, "bandwidth_probe: bad arguments");
   HIPCHK(hipSetDevice(h->device));
@@ -372,16 +372,16 @@ int pcd_bandwidth_probe(pcd_handle h, int kind, int64_t bytes, int reps, double*
   a.release(); b.release(); c.release();
   *gbs = best;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_bandwidth_probe)
 
-int pcd_graph_enable(pcd_handle h, int on) {
+int pcd_graph_enable(pcd_handle h, int on) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   h->graph_on = on != 0;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_graph_enable)
 
 // ---- multi-GPU bootstrap ---------------------------------------------------
-int pcd_comm_unique_id(void* out128) {
+int pcd_comm_unique_id(void* out128) try {
   if (!out128) return fail(PCD_ERR_ARG, "comm_unique_id: null buffer");
   std::string err;
   if (!rccl_api().load(err)) return fail(PCD_ERR_COMM, "%s", err.c_str());
@@ -391,7 +391,7 @@ int pcd_comm_unique_id(void* out128) {
   static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
   memcpy(out128, &id, sizeof id);
   return 0;
-}
+} PCD_ABI_CATCH(pcd_comm_unique_id)
 
 int comm_attach(Engine* h, CommBackend* c, int rank, int nranks) {
   for (auto& m : h->mat) if (m.set) { delete c; return fail(PCD_ERR_STATE, "comm_init: call before any operator is handed over"); }
@@ -474,7 +474,7 @@ CommBackend* wrap_peer(Engine* h, CommBackend* boot, int rank, int nranks, Threa
   return pb;
 }
 
-int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) {
+int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(PCD_ERR_ARG, "comm_init: bad rank/size/id");
   // one rank: nothing to partition - unless PCD_FORCE_COMM=1 asks for the
@@ -491,10 +491,10 @@ int pcd_comm_init(pcd_handle h, int rank, int nranks, const void* id) {
   if (r != ncclSuccess) { delete b; return fail(PCD_ERR_COMM, "ncclCommInitRank: %s", rccl_api().GetErrorString(r)); }
   for (auto& m : h->mat) if (m.set) { delete b; return fail(PCD_ERR_STATE, "comm_init: call before any operator is handed over"); }
   return comm_attach(h, wrap_peer(h, b, rank, nranks, nullptr, true), rank, nranks);
-}
+} PCD_ABI_CATCH(pcd_comm_init)
 
 int pcd_comm_init_host(pcd_handle h, int rank, int nranks, pcd_host_allreduce_fn allreduce,
-                       pcd_host_exchange_fn exchange, void* ctx) {
+                       pcd_host_exchange_fn exchange, void* ctx) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (nranks < 2 || rank < 0 || rank >= nranks || !allreduce || !exchange)
     return fail(PCD_ERR_ARG, "comm_init_host: bad rank / size / callbacks");
@@ -503,11 +503,11 @@ int pcd_comm_init_host(pcd_handle h, int rank, int nranks, pcd_host_allreduce_fn
   HostBackend* b = new HostBackend();
   b->ar = allreduce; b->ex = exchange; b->ctx = ctx;
   return comm_attach(h, wrap_peer(h, b, rank, nranks, nullptr, true), rank, nranks);
-}
+} PCD_ABI_CATCH(pcd_comm_init_host)
 
 // test-only backend: `nranks` engines of ONE process (one thread each) on one
 // GPU exchange through device copies; *group is created by the first caller
-int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group) {
+int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group) try {
   if (!h || !group) return fail(PCD_ERR_ARG, "comm_init_threads: null argument");
   if (nranks < 2 || rank < 0 || rank >= nranks) return fail(PCD_ERR_ARG, "comm_init_threads: bad rank/size");
   {
@@ -520,7 +520,7 @@ int pcd_comm_init_threads(pcd_handle h, int rank, int nranks, void** group) {
   for (auto& m : h->mat) if (m.set) { delete b; return fail(PCD_ERR_STATE, "comm_init: call before any operator is handed over"); }
   HIPCHK(hipSetDevice(h->device));
   return comm_attach(h, wrap_peer(h, b, rank, nranks, b->g, false), rank, nranks);
-}
+} PCD_ABI_CATCH(pcd_comm_init_threads)
 
 // Host-only view of the partitioning (no device call): the row block, the
 // localised columns and the halo plan rank `rank` of `nranks` derives from a
@@ -531,7 +531,7 @@ int pcd_dist_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
                    int nranks, int even_rows, int even_cols, int64_t* counts,
                    int32_t* out_rowptr, int32_t* out_col, double* out_val,
                    int32_t* send_peers, int32_t* send_off, int32_t* send_idx,
-                   int32_t* recv_peers, int32_t* recv_off) {
+                   int32_t* recv_peers, int32_t* recv_off) try {
   if (!rowptr || !colidx || !vals || !counts || nranks < 1 || rank < 0 || rank >= nranks)
     return fail(PCD_ERR_ARG, "dist_probe: bad arguments");
   const Space rs = Space::field(nrows, nranks, even_rows ? (even_rows > 1 ? even_rows : 2) : 1);
@@ -551,5 +551,5 @@ int pcd_dist_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
   std::copy(plan.peers_recv.begin(), plan.peers_recv.end(), recv_peers);
   std::copy(plan.recv_off.begin(), plan.recv_off.end(), recv_off);
   return 0;
-}
+} PCD_ABI_CATCH(pcd_dist_probe)
 

@@ -368,6 +368,9 @@ int spmv_other_values(Engine* h, DCsr& A, double*& other, const double* x, doubl
 // exceeds the workgroup's LDS or the patches together exceed 3 x the rows.
 int build_cheb_patch(Engine* h, DCsr& A, int m) {
   A.cp.release();
+  // declined builds are remembered until the pattern or m changes (pcd_inner_solve
+  // prepares on every call: the clustering of up to 2 M rows is not redone)
+  A.cp.tried_m = m;
   // (read per build: the A/B tests of one process switch it between engines)
   const char* eo = getenv("PCD_CHEB_PATCH");
   const int on = eo ? atoi(eo) : 1;
@@ -576,8 +579,12 @@ int inner_prepare(Engine* h, int slot) {
     case PCD_KSP_CHEBYSHEV:
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n));
       // (all its steps in one launch where the operator is small enough)
-      if (s.pc == PCD_PC_JACOBI && (!h->mat[kSlotMat[slot]].cp.ready || h->mat[kSlotMat[slot]].cp.m != s.max_it))
-        CHK(build_cheb_patch(h, h->mat[kSlotMat[slot]], s.max_it));
+      if (s.pc == PCD_PC_JACOBI) {
+        const ChebPatch& cp = h->mat[kSlotMat[slot]].cp;
+        const bool have = cp.ready && cp.m == s.max_it;
+        const bool declined = !cp.ready && cp.tried_m == s.max_it;
+        if (!have && !declined) CHK(build_cheb_patch(h, h->mat[kSlotMat[slot]], s.max_it));
+      }
       break;
     case PCD_KSP_RICHARDSON:
       CHK(s.t0.ensure(n));

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <utility>
 #include <limits>
@@ -26,6 +27,36 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+
+// Nothing throws across the ABI (include/pcd_host.h; SURVEY 8(b) "Errors").
+// Every export is a function-try-block closed by PCDH_ABI_CATCH: bad_alloc ->
+// PCDH_ERR_NOMEM, anything else -> PCDH_ERR_STATE, message in pcdh_last_error().
+#define PCDH_ABI_CATCH(name)                                                         \
+  catch (const std::bad_alloc&) { return fail(PCDH_ERR_NOMEM, #name ": out of host memory"); } \
+  catch (const std::exception& e_) { return fail(PCDH_ERR_STATE, #name ": %s", e_.what()); }   \
+  catch (...) { return fail(PCDH_ERR_STATE, #name ": unknown exception"); }
+
+// An exception must not leave an OpenMP structured block either (that is
+// std::terminate, not a status code): what allocates inside a parallel region
+// - the threads' scratch, the rows' buffers - sits between OMP_TRY and
+// OMP_CATCH, which record the failure in a flag of the team; the loops skip
+// their remaining iterations (every thread still meets every worksharing
+// construct) and the export returns PCDH_ERR_NOMEM after the region.
+struct OmpFail {
+  int v = 0;
+  void set() {
+#pragma omp atomic write
+    v = 1;
+  }
+  bool on() const {
+    int r;
+#pragma omp atomic read
+    r = v;
+    return r != 0;
+  }
+};
+#define OMP_TRY try {
+#define OMP_CATCH(f) } catch (...) { (f).set(); }
 
 // Threads for a job of `work` items: one per 32 k items, at most 32 (or what
 // pcdh_set_threads asked for).  Small set-ups - the test suite builds
@@ -110,6 +141,7 @@ static int group_impl(int64_t n, RowF row, ColF col, int64_t nrows, int64_t row0
   // pass 2: per chunk, counting sort by row, then sort each row by column
   std::vector<int64_t> rowlen(nk, 0);            // groups per row
   std::vector<std::vector<int64_t>> c_ucols(B), c_gsize(B);
+  OmpFail oom;
 #pragma omp parallel num_threads(T)
   {
     std::vector<int64_t> cnt;
@@ -117,7 +149,8 @@ static int group_impl(int64_t n, RowF row, ColF col, int64_t nrows, int64_t row0
 #pragma omp for schedule(dynamic, 1)
     for (int64_t b = 0; b < B; ++b) {
       const int64_t r_lo = b * W, r_hi = std::min<int64_t>(nk, r_lo + W);
-      if (r_lo >= r_hi) continue;
+      if (r_lo >= r_hi || oom.on()) continue;
+      OMP_TRY
       const int64_t p0 = chunk_off[b], p1 = chunk_off[b + 1];
       cnt.assign(r_hi - r_lo + 1, 0);
       for (int64_t p = p0; p < p1; ++p) ++cnt[row(part[p]) - row0 - r_lo + 1];
@@ -148,8 +181,10 @@ static int group_impl(int64_t n, RowF row, ColF col, int64_t nrows, int64_t row0
         }
         rowlen[r_lo + r] = groups;
       }
+      OMP_CATCH(oom)
     }
   }
+  if (oom.on()) return fail(PCDH_ERR_NOMEM, "group: out of host memory");
   for (int64_t r = 0; r < nk; ++r) g->indptr[r + 1] = g->indptr[r] + rowlen[r];
   const int64_t nnz = g->indptr[nk];
   g->nnz = nnz;
@@ -176,15 +211,15 @@ extern "C" {
 const char* pcdh_last_error(void) { return g_err; }
 
 
-int pcdh_set_threads(int n) {
+int pcdh_set_threads(int n) try {
   if (n < 0) return fail(PCDH_ERR_ARG, "set_threads: negative count");
   g_threads = n;
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_set_threads)
 int pcdh_get_threads(void) { return nthreads(); }
 
 int pcdh_group_pairs(int64_t n, const int64_t* rows, const int64_t* cols,
-                     int64_t nrows, int64_t row0, int64_t row1, pcdh_group* out) {
+                     int64_t nrows, int64_t row0, int64_t row1, pcdh_group* out) try {
   if (!out || n < 0 || (n && !rows) || nrows < 0 || row0 < 0 || row1 > nrows || row0 > row1)
     return fail(PCDH_ERR_ARG, "group_pairs: bad arguments");
   pcdh_group_s* g = new (std::nothrow) pcdh_group_s();
@@ -203,11 +238,11 @@ int pcdh_group_pairs(int64_t n, const int64_t* rows, const int64_t* cols,
   if (rc) { delete g; return rc; }
   *out = g;
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_group_pairs)
 
 int pcdh_pattern_cells(int64_t ncell, int nr, const int64_t* rdofs, int nc,
                        const int64_t* cdofs, int64_t nrows, int64_t row0,
-                       int64_t row1, pcdh_group* out) {
+                       int64_t row1, pcdh_group* out) try {
   if (!out || ncell < 0 || nr < 1 || nc < 1 || (ncell && (!rdofs || !cdofs)) ||
       nrows < 0 || row0 < 0 || row1 > nrows || row0 > row1)
     return fail(PCDH_ERR_ARG, "pattern_cells: bad arguments");
@@ -227,13 +262,13 @@ int pcdh_pattern_cells(int64_t ncell, int nr, const int64_t* rdofs, int nc,
   if (rc) { delete g; return rc; }
   *out = g;
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_pattern_cells)
 
 int64_t pcdh_group_nnz(pcdh_group g) { return g ? g->nnz : -1; }
 int64_t pcdh_group_kept(pcdh_group g) { return g ? g->kept : -1; }
 
 int pcdh_group_export(pcdh_group g, int64_t* indptr, int64_t* ucols, int64_t* inv,
-                      int64_t* ptr, int64_t* order) {
+                      int64_t* ptr, int64_t* order) try {
   if (!g) return fail(PCDH_ERR_ARG, "group_export: null group");
   const int T = nthreads(g->n);
   if (indptr) std::copy(g->indptr.begin(), g->indptr.end(), indptr);
@@ -248,13 +283,13 @@ int pcdh_group_export(pcdh_group g, int64_t* indptr, int64_t* ucols, int64_t* in
       for (int64_t p = g->ptr[k]; p < g->ptr[k + 1]; ++p) inv[g->order[p]] = k;
   }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_group_export)
 
 void pcdh_group_free(pcdh_group g) { delete g; }
 
 // ------------------------------------------------------ sub-matrix extraction
 int pcdh_extract_count(int64_t nr, const int32_t* rows, const int32_t* rowptr,
-                       const int32_t* col, const int32_t* colmap, int32_t* orp) {
+                       const int32_t* col, const int32_t* colmap, int32_t* orp) try {
   if (nr < 0 || !rows || !rowptr || !col || !colmap || !orp)
     return fail(PCDH_ERR_ARG, "extract_count: bad arguments");
   const int T = nthreads(nr * 8);
@@ -272,19 +307,22 @@ int pcdh_extract_count(int64_t nr, const int32_t* rows, const int32_t* rowptr,
     orp[i + 1] = (int32_t)run;
   }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_extract_count)
 
 int pcdh_extract_fill(int64_t nr, const int32_t* rows, const int32_t* rowptr,
                       const int32_t* col, const int32_t* colmap, const int32_t* orp,
-                      int32_t* oc, int64_t* osrc) {
+                      int32_t* oc, int64_t* osrc) try {
   if (nr < 0 || !rows || !rowptr || !col || !colmap || !orp || (orp[nr] && (!oc || !osrc)))
     return fail(PCDH_ERR_ARG, "extract_fill: bad arguments");
   const int T = nthreads(nr * 8);
+  OmpFail oom;
 #pragma omp parallel num_threads(T)
   {
     std::vector<std::pair<int32_t, int64_t>> tmp;
 #pragma omp for schedule(static, 4096)
     for (int64_t i = 0; i < nr; ++i) {
+      if (oom.on()) continue;
+      OMP_TRY
       tmp.clear();
       bool sorted = true;
       for (int32_t k = rowptr[rows[i]]; k < rowptr[rows[i] + 1]; ++k) {
@@ -296,14 +334,16 @@ int pcdh_extract_fill(int64_t nr, const int32_t* rows, const int32_t* rowptr,
       if (!sorted) std::sort(tmp.begin(), tmp.end());
       int64_t q = orp[i];
       for (auto& t : tmp) { oc[q] = t.first; osrc[q] = t.second; ++q; }
+      OMP_CATCH(oom)
     }
   }
+  if (oom.on()) return fail(PCDH_ERR_NOMEM, "extract_fill: out of host memory");
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_extract_fill)
 
 // -------------------------------------------------------------------- transpose
 int pcdh_transpose(int64_t nr, int64_t nc, const int32_t* rp, const int32_t* ci,
-                   const double* va, int32_t* trp, int32_t* tc, double* tv) {
+                   const double* va, int32_t* trp, int32_t* tc, double* tv) try {
   if (nr < 0 || nc < 0 || !rp || !trp || (rp[nr] && (!ci || !tc)))
     return fail(PCDH_ERR_ARG, "transpose: bad arguments");
   const int64_t nnz = rp[nr];
@@ -321,21 +361,24 @@ int pcdh_transpose(int64_t nr, int64_t nc, const int32_t* rp, const int32_t* ci,
       if (va && tv) tv[q] = va[k];
     }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_transpose)
 
 // ----------------------------------------------------------------------- SpGEMM
 int pcdh_spgemm_count(int64_t row0, int64_t row1, int64_t b_cols,
                       const int32_t* arp, const int32_t* ac, const int32_t* brp,
-                      const int32_t* bc, int64_t* crp) {
+                      const int32_t* bc, int64_t* crp) try {
   if (row0 < 0 || row1 < row0 || b_cols < 0 || !arp || !brp || !crp)
     return fail(PCDH_ERR_ARG, "spgemm_count: bad arguments");
   const int T = nthreads((row1 - row0) * 64);
   crp[0] = 0;
+  OmpFail oom;
 #pragma omp parallel num_threads(T)
   {
-    std::vector<int32_t> mark(b_cols, -1);
+    std::vector<int32_t> mark;
+    OMP_TRY mark.assign(b_cols, -1); OMP_CATCH(oom)
 #pragma omp for schedule(dynamic, 256)
     for (int64_t i = row0; i < row1; ++i) {
+      if (oom.on()) continue;
       int64_t cnt = 0;
       for (int32_t k = arp[i]; k < arp[i + 1]; ++k) {
         const int32_t j = ac[k];
@@ -345,23 +388,28 @@ int pcdh_spgemm_count(int64_t row0, int64_t row1, int64_t b_cols,
       crp[i - row0 + 1] = cnt;
     }
   }
+  if (oom.on()) return fail(PCDH_ERR_NOMEM, "spgemm_count: out of host memory");
   for (int64_t i = 0; i < row1 - row0; ++i) crp[i + 1] += crp[i];
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_spgemm_count)
 
 int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols, const int32_t* arp,
                      const int32_t* ac, const double* av, const int32_t* brp,
                      const int32_t* bc, const double* bv, const int64_t* crp,
-                     int32_t* cc, double* cv) {
+                     int32_t* cc, double* cv) try {
   if (row0 < 0 || row1 < row0 || !arp || !brp || !crp || (crp[row1 - row0] && (!cc || !cv)))
     return fail(PCDH_ERR_ARG, "spgemm_fill: bad arguments");
   const int T = nthreads((row1 - row0) * 64);
+  OmpFail oom;
 #pragma omp parallel num_threads(T)
   {
-    std::vector<int64_t> where(b_cols, -1);     // column -> slot of the current row
+    std::vector<int64_t> where;                 // column -> slot of the current row
     std::vector<std::pair<int32_t, double>> rowbuf;
+    OMP_TRY where.assign(b_cols, -1); OMP_CATCH(oom)
 #pragma omp for schedule(dynamic, 256)
     for (int64_t i = row0; i < row1; ++i) {
+      if (oom.on()) continue;
+      OMP_TRY
       const int64_t base = crp[i - row0];
       int64_t fillp = base;
       for (int32_t k = arp[i]; k < arp[i + 1]; ++k) {
@@ -381,10 +429,12 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols, const int32_t* 
       std::sort(rowbuf.begin(), rowbuf.end(),
                 [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) { return x.first < y.first; });
       for (int64_t p = 0; p < len; ++p) { cc[base + p] = rowbuf[p].first; cv[base + p] = rowbuf[p].second; where[rowbuf[p].first] = -1; }
+      OMP_CATCH(oom)
     }
   }
+  if (oom.on()) return fail(PCDH_ERR_NOMEM, "spgemm_fill: out of host memory");
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_spgemm_fill)
 
 // ---------------------------------------------------- plan of a sparse product
 // C = A B on a fixed pattern, as a GATHER PLAN: for every entry of C the list
@@ -396,16 +446,19 @@ int pcdh_spgemm_fill(int64_t row0, int64_t row1, int64_t b_cols, const int32_t* 
 // (index of the B entry, weight = the A value) - F_c = P^T B with B changing.
 int pcdh_product_plan_count(int64_t nrows, int64_t b_cols, const int32_t* arp,
                             const int32_t* ac, const int32_t* brp, const int32_t* bc,
-                            int64_t* crp, int64_t* trp) {
+                            int64_t* crp, int64_t* trp) try {
   if (nrows < 0 || b_cols < 0 || !arp || !brp || !crp || !trp)
     return fail(PCDH_ERR_ARG, "product_plan_count: bad arguments");
   const int T = nthreads(nrows * 64);
   crp[0] = 0; trp[0] = 0;
+  OmpFail oom;
 #pragma omp parallel num_threads(T)
   {
-    std::vector<int64_t> mark(b_cols, -1);
+    std::vector<int64_t> mark;
+    OMP_TRY mark.assign(b_cols, -1); OMP_CATCH(oom)
 #pragma omp for schedule(dynamic, 256)
     for (int64_t i = 0; i < nrows; ++i) {
+      if (oom.on()) continue;
       int64_t cnt = 0, terms = 0;
       for (int32_t k = arp[i]; k < arp[i + 1]; ++k) {
         const int32_t j = ac[k];
@@ -416,25 +469,29 @@ int pcdh_product_plan_count(int64_t nrows, int64_t b_cols, const int32_t* arp,
       crp[i + 1] = cnt; trp[i + 1] = terms;
     }
   }
+  if (oom.on()) return fail(PCDH_ERR_NOMEM, "product_plan_count: out of host memory");
   for (int64_t i = 0; i < nrows; ++i) { crp[i + 1] += crp[i]; trp[i + 1] += trp[i]; }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_product_plan_count)
 
 int pcdh_product_plan_fill(int64_t nrows, int64_t b_cols, const int32_t* arp, const int32_t* ac,
                            const double* av, const int32_t* brp, const int32_t* bc,
                            const double* bv, int mode, const int64_t* crp, const int64_t* trp,
-                           int32_t* cc, int64_t* ptr, int32_t* src, double* w) {
+                           int32_t* cc, int64_t* ptr, int32_t* src, double* w) try {
   if (nrows < 0 || !arp || !brp || !crp || !trp || !ptr || (mode != 0 && mode != 1) ||
       (mode == 0 ? !bv : !av) || (crp[nrows] && !cc) || (trp[nrows] && (!src || !w)))
     return fail(PCDH_ERR_ARG, "product_plan_fill: bad arguments");
   const int T = nthreads(nrows * 64);
   (void)b_cols;
+  OmpFail oom;
 #pragma omp parallel num_threads(T)
   {
     struct Term { int32_t col, src; double w; };
     std::vector<Term> buf;
 #pragma omp for schedule(dynamic, 256)
     for (int64_t i = 0; i < nrows; ++i) {
+      if (oom.on()) continue;
+      OMP_TRY
       buf.clear();
       for (int32_t k = arp[i]; k < arp[i + 1]; ++k) {
         const int32_t j = ac[k];
@@ -447,15 +504,17 @@ int pcdh_product_plan_fill(int64_t nrows, int64_t b_cols, const int32_t* arp, co
         if (p == 0 || buf[p].col != buf[p - 1].col) { cc[e] = buf[p].col; ptr[e] = t; ++e; }
         src[t] = buf[p].src; w[t] = buf[p].w; ++t;
       }
+      OMP_CATCH(oom)
     }
   }
+  if (oom.on()) return fail(PCDH_ERR_NOMEM, "product_plan_fill: out of host memory");
   ptr[crp[nrows]] = trp[nrows];
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_product_plan_fill)
 
 // ----------------------------------------------------------------------- SpMV
 int pcdh_spmv(int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
-              const double* x, const double* scale, double* y) {
+              const double* x, const double* scale, double* y) try {
   if (nrows < 0 || !rowptr || (rowptr[nrows] && (!col || !val)) || !x || !y)
     return fail(PCDH_ERR_ARG, "spmv: bad arguments");
   const int T = nthreads((int64_t)rowptr[nrows]);
@@ -466,13 +525,13 @@ int pcdh_spmv(int64_t nrows, const int32_t* rowptr, const int32_t* col, const do
     y[i] = scale ? scale[i] * s : s;
   }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_spmv)
 
 // y = scale .* (A X) for nvec interleaved vectors (X, Y: nrows x nvec row-major):
 // the power iteration of F (x) I_nvec without the expanded matrix; each of the
 // nvec row sums runs in ascending entry order (= the expanded operator's sums)
 int pcdh_spmm(int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
-              int nvec, const double* x, const double* scale, double* y) {
+              int nvec, const double* x, const double* scale, double* y) try {
   if (nrows < 0 || nvec < 1 || nvec > 8 || !rowptr || (rowptr[nrows] && (!col || !val)) || !x || !y)
     return fail(PCDH_ERR_ARG, "spmm: bad arguments");
   const int T = nthreads((int64_t)rowptr[nrows] * nvec);
@@ -487,11 +546,11 @@ int pcdh_spmm(int64_t nrows, const int32_t* rowptr, const int32_t* col, const do
     for (int c = 0; c < nvec; ++c) y[i * nvec + c] = scale ? scale[i * nvec + c] * s[c] : s[c];
   }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_spmm)
 
 // ------------------------------------------------------- F (x) I_nc, both ways
 int pcdh_kron_factor(int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
-                     int nc, int32_t* f_rowptr, int32_t* f_col, double* f_val) {
+                     int nc, int32_t* f_rowptr, int32_t* f_col, double* f_val) try {
   if (nrows < 0 || nc < 2 || !rowptr || !f_rowptr) return fail(PCDH_ERR_ARG, "kron_factor: bad arguments");
   if (nrows % nc || rowptr[nrows] % nc) return PCDH_NOT_KRON;
   const int64_t ns = nrows / nc;
@@ -519,10 +578,10 @@ int pcdh_kron_factor(int64_t nrows, const int32_t* rowptr, const int32_t* col, c
     for (int32_t k = 0; k < len; ++k) { f_col[o + k] = col[a + k] / nc; f_val[o + k] = val[a + k]; }
   }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_kron_factor)
 
 int pcdh_kron_expand(int64_t ns, const int32_t* f_rowptr, const int32_t* f_col, const double* f_val,
-                     int nc, int32_t* rowptr, int32_t* col, double* val) {
+                     int nc, int32_t* rowptr, int32_t* col, double* val) try {
   if (ns < 0 || nc < 1 || !f_rowptr || !rowptr || (f_rowptr[ns] && (!f_col || !f_val || !col || !val)))
     return fail(PCDH_ERR_ARG, "kron_expand: bad arguments");
   if ((int64_t)f_rowptr[ns] * nc > INT32_MAX) return fail(PCDH_ERR_ARG, "kron_expand: more than 2^31 entries");
@@ -538,13 +597,13 @@ int pcdh_kron_expand(int64_t ns, const int32_t* f_rowptr, const int32_t* f_col, 
   }
   rowptr[nc * ns] = nc * f_rowptr[ns];
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_kron_expand)
 
 // ------------------------------------------------- sums of grouped contributions
 // out[g] = sum of vals[members[k]], k in [ptr[g], ptr[g+1]), added in ascending k
 // (members ascend within a group: numpy.bincount's order of additions)
 int pcdh_gather_sum(int64_t ngroups, const int64_t* ptr, const int64_t* members,
-                    const double* vals, double* out) {
+                    const double* vals, double* out) try {
   if (ngroups < 0 || !ptr || (ptr[ngroups] && (!members || !vals)) || !out)
     return fail(PCDH_ERR_ARG, "gather_sum: bad arguments");
   const int T = nthreads(ptr[ngroups]);
@@ -555,7 +614,7 @@ int pcdh_gather_sum(int64_t ngroups, const int64_t* ptr, const int64_t* members,
     out[g] = s;
   }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_gather_sum)
 
 // ------------------------------------------ wind x barycentric gradients per cell
 // out[c, m, k] = |T_c| * sum_d U[dofs[c, m], d] * gradlam[c, k, d], the sum in
@@ -564,7 +623,7 @@ int pcdh_gather_sum(int64_t ngroups, const int64_t* ptr, const int64_t* members,
 // matrices (taylor_hood.py p2_convection_nodal), one pass instead of eight
 int pcdh_wind_gradlam(int64_t ncell, int na, int nvl, int dim, const int64_t* dofs,
                       const double* U, const double* gradlam, const double* area,
-                      double* out) {
+                      double* out) try {
   if (ncell < 0 || na < 1 || nvl < 1 || dim < 1 || dim > 3 ||
       (ncell && (!dofs || !U || !gradlam || !area || !out)))
     return fail(PCDH_ERR_ARG, "wind_gradlam: bad arguments");
@@ -588,11 +647,11 @@ int pcdh_wind_gradlam(int64_t ncell, int na, int nvl, int dim, const int64_t* do
     }
   }
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_wind_gradlam)
 
 // ------------------------------------------------------- union of mapped blocks
 int pcdh_union_count(int64_t n, int nb, const int64_t* nr, const int32_t* const* rowmap,
-                     const int32_t* const* indptr, int64_t* out) {
+                     const int32_t* const* indptr, int64_t* out) try {
   if (n < 0 || nb < 1 || !nr || !rowmap || !indptr || !out)
     return fail(PCDH_ERR_ARG, "union_count: bad arguments");
   for (int64_t i = 0; i <= n; ++i) out[i] = 0;
@@ -604,12 +663,12 @@ int pcdh_union_count(int64_t n, int nb, const int64_t* nr, const int32_t* const*
     }
   for (int64_t i = 0; i < n; ++i) out[i + 1] += out[i];
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_union_count)
 
 int pcdh_union_fill(int64_t n, int nb, const int64_t* nr, const int32_t* const* rowmap,
                     const int32_t* const* colmap, const int32_t* const* indptr,
                     const int32_t* const* indices, const int64_t* data_off,
-                    const int64_t* out_indptr, int32_t* out_indices, int64_t* out_order) {
+                    const int64_t* out_indptr, int32_t* out_indices, int64_t* out_order) try {
   if (n < 0 || nb < 1 || !nr || !rowmap || !colmap || !indptr || !indices || !data_off ||
       !out_indptr || !out_indices || !out_order)
     return fail(PCDH_ERR_ARG, "union_fill: bad arguments");
@@ -619,11 +678,14 @@ int pcdh_union_fill(int64_t n, int nb, const int64_t* nr, const int32_t* const* 
   for (int b = 0; b < nb; ++b)
     for (int64_t i = 0; i < nr[b]; ++i) inv[(size_t)b * n + rowmap[b][i]] = (int32_t)i;
   int dup = 0;
+  OmpFail oom;
 #pragma omp parallel num_threads(T)
   {
     std::vector<std::pair<int32_t, int64_t>> tmp;
 #pragma omp for schedule(static, 2048)
     for (int64_t g = 0; g < n; ++g) {
+      if (oom.on()) continue;
+      OMP_TRY
       tmp.clear();
       for (int b = 0; b < nb; ++b) {
         const int32_t i = inv[(size_t)b * n + g];
@@ -637,24 +699,29 @@ int pcdh_union_fill(int64_t n, int nb, const int64_t* nr, const int32_t* const* 
         if (t && tmp[t].first == tmp[t - 1].first) dup = 1;
         out_indices[q] = tmp[t].first; out_order[q] = tmp[t].second; ++q;
       }
+      OMP_CATCH(oom)
     }
   }
+  if (oom.on()) return fail(PCDH_ERR_NOMEM, "union_fill: out of host memory");
   if (dup) return fail(PCDH_ERR_ARG, "union_fill: the blocks overlap");
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_union_fill)
 
 // ------------------------------------------------- distance-2 independent set
-int pcdh_mis2_degrees(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t* deg) {
+int pcdh_mis2_degrees(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t* deg) try {
   if (n < 0 || !rowptr || (rowptr[n] && !col) || (n && !deg))
     return fail(PCDH_ERR_ARG, "mis2_degrees: bad arguments");
   if (n > INT32_MAX) return fail(PCDH_ERR_ARG, "mis2_degrees: more than 2^31 vertices");
   const int T = nthreads((int64_t)rowptr[n] * 8);
+  OmpFail oom;
 #pragma omp parallel num_threads(T)
   {
     // stamp[k] == i: vertex k already counted for vertex i
-    std::vector<int32_t> stamp((size_t)n, -1);
+    std::vector<int32_t> stamp;
+    OMP_TRY stamp.assign((size_t)n, -1); OMP_CATCH(oom)
 #pragma omp for schedule(dynamic, 1024)
     for (int64_t i = 0; i < n; ++i) {
+      if (oom.on()) continue;
       int64_t cnt = 0;
       auto visit = [&](int32_t j) {
         for (int32_t q = rowptr[j]; q < rowptr[j + 1]; ++q) {
@@ -672,11 +739,12 @@ int pcdh_mis2_degrees(int64_t n, const int32_t* rowptr, const int32_t* col, int6
       deg[i] = cnt;
     }
   }
+  if (oom.on()) return fail(PCDH_ERR_NOMEM, "mis2_degrees: out of host memory");
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_mis2_degrees)
 
 int pcdh_mis2(int64_t n, const int32_t* rowptr, const int32_t* col, const double* w,
-              int8_t* in_set, int64_t* rounds) {
+              int8_t* in_set, int64_t* rounds) try {
   if (n < 0 || !rowptr || (rowptr[n] && !col) || (n && (!w || !in_set)))
     return fail(PCDH_ERR_ARG, "mis2: bad arguments");
   if (n > INT32_MAX) return fail(PCDH_ERR_ARG, "mis2: more than 2^31 vertices");
@@ -748,6 +816,6 @@ int pcdh_mis2(int64_t n, const int32_t* rowptr, const int32_t* col, const double
   for (int64_t i = 0; i < n; ++i) in_set[i] = state[i] == 1;
   if (rounds) *rounds = nround;
   return 0;
-}
+} PCDH_ABI_CATCH(pcdh_mis2)
 
 }  // extern "C"

@@ -31,6 +31,8 @@ using namespace pcd;
 // Host-side set-up loops (sub-matrix extraction, structure detection) run on
 // a few threads: chunks [begin, end) of 0..n, one std::thread each.
 #include <atomic>
+#include <exception>
+#include <new>
 #include <thread>
 template <class F>
 inline void parallel_chunks(int64_t n, F f) {
@@ -38,9 +40,24 @@ inline void parallel_chunks(int64_t n, F f) {
   if (const char* e = getenv("PCD_SETUP_THREADS")) T = std::max(1, atoi(e));
   T = (int)std::min<int64_t>(T, std::max<int64_t>(1, n / 4096));
   if (T <= 1) { f((int64_t)0, n); return; }
+  // an exception of a worker (bad_alloc of its scratch) must not end the
+  // process: it is kept, the others finish, and it is thrown again on the
+  // caller's thread - where the export's PCD_ABI_CATCH turns it into a status
+  std::vector<std::exception_ptr> ex((size_t)T);
   std::vector<std::thread> th;
-  for (int t = 0; t < T; ++t) th.emplace_back(f, n * t / T, n * (t + 1) / T);
-  for (auto& x : th) x.join();
+  th.reserve((size_t)T);
+  auto guarded = [&f, &ex](int t, int64_t b, int64_t e) {
+    try { f(b, e); } catch (...) { ex[(size_t)t] = std::current_exception(); }
+  };
+  struct Joiner {                        // (a failed thread start joins those already running)
+    std::vector<std::thread>& th;
+    ~Joiner() { for (auto& x : th) if (x.joinable()) x.join(); }
+  };
+  {
+    Joiner j{th};
+    for (int t = 0; t < T; ++t) th.emplace_back(guarded, t, n * t / T, n * (t + 1) / T);
+  }
+  for (auto& e : ex) if (e) std::rethrow_exception(e);
 }
 
 // PCD_SETUP_TIMING=1: wall time of the set-up phases on stderr (diagnostics)
@@ -82,6 +99,18 @@ inline int fail(int code, const char* fmt, ...) {
     if (rc_) return rc_;       \
   } while (0)
 
+// Nothing throws across the ABI (SURVEY 8(b) "Errors": "never throws across
+// the ABI, never aborts"; the reference turns every Python exception of its
+// PCPYTHON context into a PETSc error code: fenapack/field_split.py:135-140).
+// Every extern "C" entry point is a function-try-block closed by this macro:
+// std::bad_alloc of the host-side set-up containers -> PCD_ERR_NOMEM, anything
+// else -> PCD_ERR_INTERNAL; the message is in pcd_last_error(), the handle
+// stays destroyable (pcd_destroy only releases what is there).
+#define PCD_ABI_CATCH(name)                                                                  \
+  catch (const std::bad_alloc&) { return fail(PCD_ERR_NOMEM, #name ": out of host memory"); } \
+  catch (const std::exception& e_) { return fail(PCD_ERR_INTERNAL, #name ": %s", e_.what()); } \
+  catch (...) { return fail(PCD_ERR_INTERNAL, #name ": unknown exception"); }
+
 // ------------------------------------------------------------ device data
 template <class T>
 struct DBuf {
@@ -115,6 +144,7 @@ constexpr int kChebPatchMaxM = 8;
 constexpr int kChebPatchNodes = 1536;        // patch nodes a workgroup holds (5 x 8 B each in LDS)
 struct ChebPatch {
   bool ready = false;
+  int tried_m = 0;                       // a build for this m was declined on the pattern in force: not retried
   int m = 0, nblocks = 0, wmax = 0;      // wmax: the widest ELL row of all patches
   int64_t nslots = 0;
   DBuf<int> node;                 // patch node lists, block after block
@@ -124,7 +154,7 @@ struct ChebPatch {
   DBuf<double> val;               // ELL values
   DBuf<int> pos;                  // ... their positions in the operator's values (-1: padding)
   void release() {
-    ready = false; m = 0; nblocks = 0; wmax = 0; nslots = 0;
+    ready = false; tried_m = 0; m = 0; nblocks = 0; wmax = 0; nslots = 0;
     node.release(); desc.release(); cnt.release(); col.release(); val.release(); pos.release();
   }
 };
@@ -207,13 +237,10 @@ struct DCsr {
     rk = 0; rk_rb = 0; rk_nnz = 0; rk_rowptr.release(); rk_col.release(); rk_pos.release(); rk_val.release();
     plan = HaloPlan(); replicated = false;
     if (ph.dev.seq) (void)hipFree(ph.dev.seq);
-    if (ph.owner) {
-      // the channel's landing buffers and flags go back to the arena's free
-      // list (a gamg hierarchy pushed again every Picard step would otherwise
-      // fill the arena and fall back to the bootstrap path without a word)
-      std::lock_guard<std::mutex> lk(peer_live_mu());
-      if (peer_live().count(ph.owner)) ph.owner->give_back(ph);
-    }
+    // the channel's landing buffers and flags go back to the arena's free
+    // list (a gamg hierarchy pushed again every Picard step would otherwise
+    // fill the arena and fall back to the bootstrap path without a word)
+    peer_give_back(ph);
     ph = PeerHalo();
     set = false; nrows = ncols = nnz = 0; has_src = false; val_src = false;
   }
@@ -291,7 +318,7 @@ struct Inner {
   }
 };
 
-struct FeState;                        // device operator producer (pcd_fe_host.hpp)
+struct FeState;                        // device operator producer (pcd_producer_abi.hpp)
 
 struct pcd_engine_s {
   FeState* fe = nullptr;

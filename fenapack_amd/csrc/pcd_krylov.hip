@@ -39,7 +39,7 @@ int apply_system(Engine* h, const double* z, double* w) {
 
 int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
                     double rtol, double atol, int m, int max_it, int* its,
-                    double* rnorm) {
+                    double* rnorm) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!h->ready || !h->mat[PCD_MAT_A].set)
     return fail(PCD_ERR_STATE, "gmres_solve: pcd_set_system + pcd_setup first");
@@ -164,5 +164,5 @@ int pcd_gmres_solve(pcd_handle h, const double* b, double* x, int mem,
   if (its) *its = it;
   if (rnorm) *rnorm = res;
   return peer_check(h);
-}
+} PCD_ABI_CATCH(pcd_gmres_solve)
 

@@ -239,6 +239,8 @@ struct PeerHalo {
 inline std::mutex& peer_live_mu() { static std::mutex m; return m; }
 inline std::set<PeerBackend*>& peer_live() { static std::set<PeerBackend*> s; return s; }
 
+inline void peer_give_back(PeerHalo& ph);  // (defined below PeerBackend)
+
 struct PeerBackend : CommBackend {
   CommBackend* boot = nullptr;              // RCCL / thread group: set-up and bulk
   char* arena = nullptr;                    // this rank's arena (uncached)
@@ -250,6 +252,7 @@ struct PeerBackend : CommBackend {
   int* derr = nullptr;                      // error word read by the host at synchronisation points
   long long spin_limit = 3000000000ll;      // 30 s of the 100 MHz wall clock
   bool process_mode = false;
+  int device = 0;                           // the device the arena lives on (init)
   long boot_calls = 0;                      // hot-path calls that went to the bootstrap backend
   long peer_calls = 0;                      // exchanges / reductions issued as kernels of the stream
   long declined = 0;                        // halo channels that did not fit an arena (bootstrap path instead)
@@ -299,11 +302,11 @@ struct PeerBackend : CommBackend {
     if (b) taking.push_back({(size_t)(p - arena), b});
     return p;
   }
+  // (the caller has drained the OWNER's device first - peer_give_back below:
+  // the regions may be handed out again at once, so nothing of this rank's
+  // may still be in flight on them; its last exchange on the channel has then
+  // completed, and with it every peer's store into these buffers)
   void give_back(PeerHalo& ph) {
-    // (the regions may be handed out again at once: nothing of this rank's
-    // may still be in flight on them - its last exchange on the channel has
-    // then completed, and with it every peer's store into these buffers)
-    (void)hipDeviceSynchronize();
     for (auto& t : ph.takes) freed.push_back(t);
     ph.takes.clear(); ph.owner = nullptr;
   }
@@ -317,6 +320,7 @@ struct PeerBackend : CommBackend {
   int init(size_t capacity, char** arenas_of_group, void (*group_barrier)(void*), void* group,
            hipStream_t s) {
     cap = capacity;
+    (void)hipGetDevice(&device);
     void* p = nullptr;
     hipError_t e = hipExtMallocWithFlags(&p, cap, hipDeviceMallocUncached);
     if (e != hipSuccess) e = hipExtMallocWithFlags(&p, cap, hipDeviceMallocFinegrained);
@@ -531,5 +535,30 @@ struct PeerBackend : CommBackend {
     return e;
   }
 };
+
+// Hand a released operator's channel back to its backend's free list.  The
+// drain runs on the OWNER's device (a pcd_destroy / GC thread, or thread ranks
+// on several GPUs, may call with another one current) and OUTSIDE the
+// process-wide lock: a device-wide wait under it would serialise all thread
+// ranks, and one waiting on a kernel that spins for a rank waiting on the lock
+// could only leave through the spin time-out.
+inline void peer_give_back(PeerHalo& ph) {
+  if (!ph.owner) return;
+  int dev = -1;
+  {
+    std::lock_guard<std::mutex> lk(peer_live_mu());
+    if (peer_live().count(ph.owner)) dev = ph.owner->device;
+  }
+  if (dev >= 0) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+    std::lock_guard<std::mutex> lk(peer_live_mu());
+    if (peer_live().count(ph.owner)) ph.owner->give_back(ph);
+  }
+  ph.owner = nullptr;
+}
 
 }  // namespace pcd

@@ -2,4 +2,4 @@
 // (one of the engine's translation units; shared declarations: pcd_internal.hpp)
 #include "pcd_internal.hpp"
 
-#include "pcd_fe_host.hpp"
+#include "pcd_producer_abi.hpp"

@@ -1,4 +1,4 @@
-// Host side of the device operator producer (kernels: pcd_fe.hpp); included by
+// The C ABI and host side of the device operator producer (pcd_fe_*; kernels: pcd_fe.hpp); included by
 // pcd_producer.hip (its own translation unit).  One FE level per multigrid level of the velocity
 // block (coarsest first); the finest level writes the caller's system values,
 // the intermediate ones the multigrid operators, the coarsest one is handed
@@ -294,7 +294,7 @@ extern "C" {
 // CSR pattern of its scalar operator (n0 rows, the order of
 // pcd_fe_get_level_values(h, 0, .)); needs pcd_fe_bind_mg
 int pcd_fe_bind_coarse_inverse(pcd_handle h, int64_t n0, const int32_t* rowptr,
-                               const int32_t* colidx) {
+                               const int32_t* colidx) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_coarse_inverse: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   const int64_t want = fe.newton ? (int64_t)fe.dim * fe.dim * fe.lev[0].nnzf : fe.lev[0].nnzf;
@@ -313,10 +313,10 @@ int pcd_fe_bind_coarse_inverse(pcd_handle h, int64_t n0, const int32_t* rowptr,
   CHK(fe.inv_col0.ensure(n0)); CHK(fe.inv_col1.ensure(n0));
   fe.inv_bound = true;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_bind_coarse_inverse)
 
 int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
-                 const double* phi, const double* dphi, const double* psi) {
+                 const double* phi, const double* dphi, const double* psi) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (dim != 2 && dim != 3) return fail(PCD_ERR_ARG, "fe_begin: dim must be 2 or 3");
   // the producer's plans address operator entries in the numbering its caller
@@ -342,7 +342,7 @@ int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
   CHK(fe_upload(fe.psi, psi, (size_t)nq * nv));
   fe.lev.resize(nlevels);
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_begin)
 
 int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
                      const int32_t* dofs2, const double* gradlam,
@@ -350,7 +350,7 @@ int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
                      const int32_t* f_src, const double* f_const,
                      const unsigned char* f_keep, int64_t n_diag,
                      const int32_t* diag_pos, const double* diag_val,
-                     const int32_t* inject) {
+                     const int32_t* inject) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_level: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (level < 0 || level >= fe.nlev) return fail(PCD_ERR_ARG, "fe_set_level: bad level %d", level);
@@ -381,7 +381,7 @@ int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
   CHK(L.U.ensure((size_t)fe.dim * nn2));
   L.set = true; L.ev_init = false;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_level)
 
 // Several ranks: the plan of `level` handed to pcd_fe_set_level covers the node
 // rows [node_row0, node_row0 + n_node_rows) of the level's scalar operator only
@@ -392,7 +392,7 @@ int pcd_fe_set_level(pcd_handle h, int level, int64_t ncells, int64_t nn2,
 // residual - stay replicated.  Picard block, re-discretised levels
 // (-pc_mg_galerkin none).  Afterwards pcd_fe_bind_pattern / pcd_fe_bind_system /
 // the mass values of pcd_fe_bind_residual take these rows' entries.
-int pcd_fe_set_rows(pcd_handle h, int level, int64_t node_row0, int64_t n_node_rows) {
+int pcd_fe_set_rows(pcd_handle h, int level, int64_t node_row0, int64_t n_node_rows) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_rows: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (level < 1 || level >= fe.nlev || !fe.lev[level].set || fe.lev[level].galerkin)
@@ -404,7 +404,7 @@ int pcd_fe_set_rows(pcd_handle h, int level, int64_t node_row0, int64_t n_node_r
                 (long long)node_row0, (long long)(node_row0 + n_node_rows), (long long)L.nn2);
   L.rows = true; L.row0 = node_row0; L.nrows = n_node_rows;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_rows)
 
 // A coarse level whose operator is the Galerkin product of the next finer one
 // (-pc_mg_galerkin both): B = F_finer P (nnz_b entries, entry e = sum
@@ -413,7 +413,7 @@ int pcd_fe_set_rows(pcd_handle h, int level, int64_t node_row0, int64_t n_node_r
 int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f, int64_t nnz_b,
                               const int64_t* b_ptr, const int32_t* b_src,
                               const double* b_w, const int64_t* c_ptr,
-                              const int32_t* c_src, const double* c_w) {
+                              const int32_t* c_src, const double* c_w) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_level_galerkin: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (level < 0 || level >= fe.nlev - 1)
@@ -434,7 +434,7 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f, int64_t nn
   CHK(L.F.ensure(nnz_f));
   L.set = true; L.ev_init = false;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_level_galerkin)
 
 // SUPG-stabilised preconditioner matrix (fenapack/stabilization.py:39-68 and
 // its use at demo_navier-stokes-pcd.py:122-127): per re-discretised level the
@@ -444,7 +444,7 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f, int64_t nn
 // stabilised operator, the system matrix from the unstabilised one.
 int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
                     const double* phi_mid, int nq_s, const double* qw_s,
-                    const double* phi_s, const double* dphi_s) {
+                    const double* phi_s, const double* dphi_s) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_supg: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (level < 0 || level >= fe.nlev || !fe.lev[level].set || fe.lev[level].galerkin)
@@ -464,7 +464,7 @@ int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
   fe.nq_s = nq_s;
   fe.nu = nu; fe.supg = true;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_supg)
 
 // Several ranks (pcd_comm_init before pcd_fe_begin): the scalar CSR pattern of
 // a level (nn2 + 1 row pointers, nnz_f sorted column indices - the order of
@@ -475,7 +475,7 @@ int pcd_fe_set_supg(pcd_handle h, int level, const double* cell_h, double nu,
 // the finest level it also creates the replicated operator the residual
 // applies.  Not needed on one GPU.
 int pcd_fe_bind_pattern(pcd_handle h, int level, int64_t nn2, const int32_t* rowptr,
-                        const int32_t* colidx) {
+                        const int32_t* colidx) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_pattern: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (level < 0 || level >= fe.nlev || !fe.lev[level].set || !rowptr || !colidx || nn2 < 1)
@@ -550,7 +550,7 @@ int pcd_fe_bind_pattern(pcd_handle h, int level, int64_t nn2, const int32_t* row
     }
   }
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_bind_pattern)
 
 // Newton linearisation (`--nls newton`, demo_navier-stokes-pcd.py:42,113-116):
 // the velocity block becomes F x I_d + N(w), N_ij = (phi_b d_j w_i, phi_a), on
@@ -560,7 +560,7 @@ int pcd_fe_bind_pattern(pcd_handle h, int level, int64_t nn2, const int32_t* row
 // (i, j) of scalar entry k sits in the values of that level's operator - the
 // multigrid level's CSR (0 < level < finest), the engine's A00 (finest), the
 // CSR handed to pcd_fe_bind_coarse_inverse (level 0, then (d n0) rows).
-int pcd_fe_set_newton(pcd_handle h, int level, const int32_t* pos) {
+int pcd_fe_set_newton(pcd_handle h, int level, const int32_t* pos) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_newton: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (level < 0 || level >= fe.nlev || !fe.lev[level].set || !pos)
@@ -582,12 +582,12 @@ int pcd_fe_set_newton(pcd_handle h, int level, const int32_t* pos) {
   fe.newton = true;
   fe.sys_bound = false;                  // positions of d blocks are not enough any more
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_newton)
 
 // sys_pos[c * nnz_f + k]: where entry k of the finest scalar operator sits, for
 // component c, in the caller's system values (pcd_set_system's array).  After
 // pcd_fe_set_newton: sys_pos[(i * d + j) * nnz_f + k] for every block (i, j).
-int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos) {
+int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_system: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   FeLevel& L = fe.lev[fe.nlev - 1];
@@ -601,10 +601,10 @@ int pcd_fe_bind_system(pcd_handle h, const int64_t* sys_pos) {
   CHK(fe_upload(fe.sys_pos, sys_pos, (size_t)nb * L.nnzf));
   fe.sys_bound = true; fe.sys_blocks = nb;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_bind_system)
 
 int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
-                   const int32_t* kp_src, const double* kp_const, double scale) {
+                   const int32_t* kp_src, const double* kp_const, double scale) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_kp: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   FeLevel& L = fe.lev[fe.nlev - 1];
@@ -622,13 +622,13 @@ int pcd_fe_bind_kp(pcd_handle h, int64_t nnz_kp, const int32_t* kp_ptr,
   fe.kp_off = 0; fe.kp_glob = nnz_kp;
   fe.kp_bound = true;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_bind_kp)
 
 // Several ranks, plans cut by rows: the entries bound by pcd_fe_bind_kp are this
 // rank's pressure rows - `entry_offset` entries into the operator's
 // `nnz_global` values (the cells of the finest level's plan must then cover the
 // cells that touch these rows as well).
-int pcd_fe_set_kp_rows(pcd_handle h, int64_t entry_offset, int64_t nnz_global) {
+int pcd_fe_set_kp_rows(pcd_handle h, int64_t entry_offset, int64_t nnz_global) try {
   if (!h || !h->fe || !h->fe->kp_bound) return fail(PCD_ERR_STATE, "fe_set_kp_rows: bind Kp first");
   FeState& fe = *h->fe;
   if (!h->comm) return fail(PCD_ERR_STATE, "fe_set_kp_rows: no communicator attached");
@@ -640,11 +640,11 @@ int pcd_fe_set_kp_rows(pcd_handle h, int64_t entry_offset, int64_t nnz_global) {
   CHK(fe.kp_vals.ensure(nnz_global));
   HIPCHK(hipMemset(fe.kp_vals.p, 0, nnz_global * sizeof(double)));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_kp_rows)
 
 // new constant part of Kp (terms the host keeps assembling, e.g. the BRM2
 // boundary integral); NULL = none
-int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const) {
+int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const) try {
   if (!h || !h->fe || !h->fe->kp_bound) return fail(PCD_ERR_STATE, "fe_set_kp_const: Kp is not bound");
   HIPCHK(hipSetDevice(h->device));
   FeState& fe = *h->fe;
@@ -653,7 +653,7 @@ int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const) {
   HIPCHK(hipMemcpyAsync(fe.kp_const.p, kp_const, fe.nnz_kp * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_kp_const)
 
 // BRM2 boundary term of Kp on the device: per inflow edge (2-D) the P2 nodes
 // [3][nb] (start, end, midpoint), outward normals [2][nb], lengths - per inflow
@@ -665,7 +665,7 @@ int pcd_fe_set_kp_const(pcd_handle h, const double* kp_const) {
 int pcd_fe_bind_robin(pcd_handle h, int64_t nb, const int32_t* nodes,
                       const double* normals, const double* lengths, int64_t n_aff,
                       const int32_t* aff_pos, const int64_t* aff_ptr,
-                      const int32_t* aff_src, const double* aff_w) {
+                      const int32_t* aff_src, const double* aff_w) try {
   if (!h || !h->fe || !h->fe->kp_bound) return fail(PCD_ERR_STATE, "fe_bind_robin: bind Kp first");
   FeState& fe = *h->fe;
   if (nb < 0 || n_aff < 0 || (nb && (!nodes || !normals || !lengths || !aff_pos || !aff_ptr || !aff_src || !aff_w)))
@@ -687,12 +687,12 @@ int pcd_fe_bind_robin(pcd_handle h, int64_t nb, const int32_t* nodes,
   CHK(fe.rb_loc.ensure(nloc * nb)); CHK(fe.rb_tmp.ensure((size_t)n_aff));
   fe.robin_bound = true;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_bind_robin)
 
 // multigrid hierarchy of inner solve `slot` follows the FE levels; smoother
 // bounds after every update: [emin_factor, emax_factor] * lambda_max(D^-1 A)
 int pcd_fe_bind_mg(pcd_handle h, int slot, double emin_factor,
-                   double emax_factor, int iters) {
+                   double emax_factor, int iters) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_mg: call pcd_fe_begin first");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "fe_bind_mg: bad slot %d", slot);
   FeState& fe = *h->fe;
@@ -703,7 +703,7 @@ int pcd_fe_bind_mg(pcd_handle h, int slot, double emin_factor,
     return fail(PCD_ERR_ARG, "fe_bind_mg: bad smoother factors");
   fe.mg_slot = slot; fe.emin_f = emin_factor; fe.emax_f = emax_factor; fe.est_iters = iters;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_bind_mg)
 
 // Re-assemble everything that depends on the iterate `xu` (velocity dofs,
 // fieldsplit-local numbering) and refresh the engine's operators in place.
@@ -953,7 +953,7 @@ static int fe_apply_unconstrained(Engine* h, FeState& fe, const double* dv, doub
 extern "C" {
 
 int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
-                  int mem) {
+                  int mem) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_update: call pcd_fe_begin first");
   if (!xu || ((v == nullptr) != (ru == nullptr))) return fail(PCD_ERR_ARG, "fe_update: bad vectors");
   FeState& fe = *h->fe;
@@ -980,7 +980,7 @@ int pcd_fe_update(pcd_handle h, const double* xu, const double* v, double* ru,
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_update)
 
 }  // extern "C"
 
@@ -1039,7 +1039,7 @@ int pcd_fe_bind_residual(pcd_handle h, const int32_t* bt_rowptr, const int32_t* 
                          const double* bt_val, const int32_t* b_rowptr,
                          const int32_t* b_col, const double* b_val, int64_t n_bc,
                          const int32_t* bc_idx, const double* bc_mult,
-                         const double* mass_vals, double idt) {
+                         const double* mass_vals, double idt) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_bind_residual: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (!fe.sys_bound) return fail(PCD_ERR_STATE, "fe_bind_residual: bind the system first");
@@ -1066,10 +1066,10 @@ int pcd_fe_bind_residual(pcd_handle h, const int32_t* bt_rowptr, const int32_t* 
   fe.have_mu0 = false;
   fe.res_bound = true;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_bind_residual)
 
 // boundary values of the Dirichlet dofs (order of bc_idx); time dependent
-int pcd_fe_set_bc_values(pcd_handle h, const double* g) {
+int pcd_fe_set_bc_values(pcd_handle h, const double* g) try {
   if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_set_bc_values: bind the residual first");
   if (!g && h->fe->n_bc) return fail(PCD_ERR_ARG, "fe_set_bc_values: null values");
   HIPCHK(hipSetDevice(h->device));
@@ -1077,11 +1077,11 @@ int pcd_fe_set_bc_values(pcd_handle h, const double* g) {
     HIPCHK(hipMemcpyAsync(h->fe->bc_g.p, g, h->fe->n_bc * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_bc_values)
 
 // previous time level u0 (velocity dofs): the residual subtracts idt M u0
 // (demo_unsteady-navier-stokes-pcd.py:104-120); NULL drops the term
-int pcd_fe_set_previous(pcd_handle h, const double* u0, int mem) {
+int pcd_fe_set_previous(pcd_handle h, const double* u0, int mem) try {
   if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_set_previous: bind the residual first");
   FeState& fe = *h->fe;
   if (!u0) { fe.have_mu0 = false; return 0; }
@@ -1105,11 +1105,11 @@ int pcd_fe_set_previous(pcd_handle h, const double* u0, int mem) {
   HIPCHK(hipStreamSynchronize(h->stream));
   fe.have_mu0 = true;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_set_previous)
 
 // Refresh the operators at the iterate x (caller's mixed numbering) and
 // return the nonlinear residual b (same numbering) and its 2-norm.
-int pcd_fe_residual(pcd_handle h, const double* x, double* b, int mem, double* norm) {
+int pcd_fe_residual(pcd_handle h, const double* x, double* b, int mem, double* norm) try {
   if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_residual: bind the residual first");
   if (!x || !b || !norm) return fail(PCD_ERR_ARG, "fe_residual: null argument");
   FeState& fe = *h->fe;
@@ -1127,7 +1127,7 @@ int pcd_fe_residual(pcd_handle h, const double* x, double* b, int mem, double* n
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_residual)
 
 // The whole Picard iteration on the device (the loop of
 // fenapack/nonlinear_solvers.py:28-82 around dolfin::NewtonSolver [ext]):
@@ -1139,7 +1139,7 @@ int pcd_fe_residual(pcd_handle h, const double* x, double* b, int mem, double* n
 int pcd_fe_picard_solve(pcd_handle h, double* x, int mem, double r0, double rtol,
                         double atol, int max_it, double relax, double lin_rtol,
                         double lin_atol, int restart, int lin_max_it, int* n_it,
-                        int* lin_its, double* res_hist, int* converged) {
+                        int* lin_its, double* res_hist, int* converged) try {
   if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_picard_solve: bind the residual first");
   if (!x || !n_it || !converged || max_it < 0 || (max_it && (!lin_its || !res_hist)))
     return fail(PCD_ERR_ARG, "fe_picard_solve: bad arguments");
@@ -1190,10 +1190,10 @@ int pcd_fe_picard_solve(pcd_handle h, double* x, int mem, double r0, double rtol
   HIPCHK(hipStreamSynchronize(h->stream));
   *n_it = it; *converged = conv ? 1 : 0;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_picard_solve)
 
 // scalar operator of one level as last assembled (host array of nnz_f values)
-int pcd_fe_get_level_values(pcd_handle h, int level, double* out) {
+int pcd_fe_get_level_values(pcd_handle h, int level, double* out) try {
   if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_get_level_values: call pcd_fe_begin first");
   FeState& fe = *h->fe;
   if (level < 0 || level >= fe.nlev || !fe.lev[level].set || !out)
@@ -1203,11 +1203,11 @@ int pcd_fe_get_level_values(pcd_handle h, int level, double* out) {
                         hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_get_level_values)
 
 // the d*d scalar matrices of the Newton term on one level as last assembled
 // (host array of d*d*nnz_f values, [(i*d+j)][k]; Dirichlet rows/columns zero)
-int pcd_fe_get_newton_values(pcd_handle h, int level, double* out) {
+int pcd_fe_get_newton_values(pcd_handle h, int level, double* out) try {
   if (!h || !h->fe || !h->fe->newton) return fail(PCD_ERR_STATE, "fe_get_newton_values: pcd_fe_set_newton was not called");
   FeState& fe = *h->fe;
   if (level < 0 || level >= fe.nlev || !fe.lev[level].N.p || !out)
@@ -1217,9 +1217,9 @@ int pcd_fe_get_newton_values(pcd_handle h, int level, double* out) {
                         hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_get_newton_values)
 
-int pcd_fe_get_kp_values(pcd_handle h, double* out) {
+int pcd_fe_get_kp_values(pcd_handle h, double* out) try {
   if (!h || !h->fe || !h->fe->kp_bound || !out)
     return fail(PCD_ERR_STATE, "fe_get_kp_values: Kp is not bound");
   HIPCHK(hipSetDevice(h->device));
@@ -1227,16 +1227,16 @@ int pcd_fe_get_kp_values(pcd_handle h, double* out) {
                         hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_get_kp_values)
 
 // smoother bounds the producer installed on a multigrid level (diagnostics)
-int pcd_fe_get_bounds(pcd_handle h, int level, double* emin, double* emax) {
+int pcd_fe_get_bounds(pcd_handle h, int level, double* emin, double* emax) try {
   if (!h || !h->fe || h->fe->mg_slot < 0) return fail(PCD_ERR_STATE, "fe_get_bounds: no multigrid bound");
   Inner& s = h->inner[h->fe->mg_slot];
   if (level < 1 || level >= (int)s.mg.size() || !emin || !emax)
     return fail(PCD_ERR_ARG, "fe_get_bounds: bad level");
   *emin = s.mg[level].emin; *emax = s.mg[level].emax;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_fe_get_bounds)
 
 }  // extern "C"

@@ -418,6 +418,9 @@ int upload_csr(Engine* h, DCsr& A, int64_t nrows, int64_t ncols,
                       const int32_t* rowptr, const int32_t* col,
                       const double* val, const int64_t* src) {
   const int64_t nnz = rowptr[nrows];
+  // a one-launch Chebyshev patch belongs to the PATTERN it was cut from: a
+  // second hand-over on the slot drops it (inner_prepare builds the new one)
+  A.cp.release();
   A.nrows = nrows; A.ncols = ncols; A.nnz = nnz;
   CHK(A.rowptr.ensure(nrows + 1)); CHK(A.col.ensure(nnz)); CHK(A.val.ensure(nnz));
   HIPCHK(hipMemcpyAsync(A.rowptr.p, rowptr, (nrows + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -644,15 +647,15 @@ int peer_check(Engine* h) {
   return 0;
 }
 
-int pcd_synchronize(pcd_handle h) {
+int pcd_synchronize(pcd_handle h) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   HIPCHK(hipStreamSynchronize(h->stream));
   return peer_check(h);
-}
+} PCD_ABI_CATCH(pcd_synchronize)
 
 int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
                 const int32_t* rowptr, const int32_t* colidx,
-                const double* vals) {
+                const double* vals) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (which < 0 || which >= PCD_MAT_A)
     return fail(PCD_ERR_ARG, "set_csr: operator %d cannot be set directly", which);
@@ -685,9 +688,9 @@ int pcd_set_csr(pcd_handle h, int which, int64_t nrows, int64_t ncols,
   values_changed(h, which);
   h->ready = false; ++h->gen;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_set_csr)
 
-int pcd_row_range(pcd_handle h, int velocity, int64_t n_global, int64_t* r0, int64_t* r1) {
+int pcd_row_range(pcd_handle h, int velocity, int64_t n_global, int64_t* r0, int64_t* r1) try {
   if (!h || !r0 || !r1 || n_global < 0) return fail(PCD_ERR_ARG, "row_range: bad arguments");
   if (!h->comm) { *r0 = 0; *r1 = n_global; return 0; }
   // the same rule for every space of the engine - the fields and the levels of
@@ -695,11 +698,11 @@ int pcd_row_range(pcd_handle h, int velocity, int64_t n_global, int64_t* r0, int
   const std::vector<int64_t> b = Space::cut(n_global, h->nranks, velocity ? h->vel_block : 1);
   *r0 = b[h->rank]; *r1 = b[h->rank + 1];
   return 0;
-}
+} PCD_ABI_CATCH(pcd_row_range)
 
 int pcd_set_csr_local(pcd_handle h, int which, int64_t nrows_global, int64_t ncols_global,
                       int64_t nrows_local, const int32_t* rowptr, const int32_t* colidx,
-                      const double* vals) {
+                      const double* vals) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (which < 0 || which >= PCD_MAT_A)
     return fail(PCD_ERR_ARG, "set_csr_local: operator %d cannot be set directly", which);
@@ -744,9 +747,9 @@ int pcd_set_csr_local(pcd_handle h, int which, int64_t nrows_global, int64_t nco
   values_changed(h, which);
   h->ready = false; ++h->gen;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_set_csr_local)
 
-int pcd_update_values(pcd_handle h, int which, const double* vals, int mem) {
+int pcd_update_values(pcd_handle h, int which, const double* vals, int mem) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (which < 0 || which >= PCD_MAT_A || !h->mat[which].set)
     return fail(PCD_ERR_STATE, "update_values: operator %d not set", which);
@@ -758,7 +761,7 @@ int pcd_update_values(pcd_handle h, int which, const double* vals, int mem) {
   values_changed(h, which);
   if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_update_values)
 
 // host-side MatCreateSubMatrix with value provenance
 void extract_block(int64_t nr, const int32_t* rows, const int32_t* rowptr,
@@ -882,15 +885,15 @@ int decide_reordering(Engine* h, int64_t n, const int32_t* rowptr, const int32_t
   return 0;
 }
 
-int pcd_set_reorder(pcd_handle h, int mode) {
+int pcd_set_reorder(pcd_handle h, int mode) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (mode < 0 || mode > 3) return fail(PCD_ERR_ARG, "set_reorder: mode 0 (never), 1 (auto), 2 (always) or 3 (cluster)");
   h->reorder_mode = mode;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_set_reorder)
 
 int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
-                      int mem) {
+                      int mem) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!h->mat[PCD_MAT_A].set) return fail(PCD_ERR_STATE, "update_system: no system set");
   if (!vals) return fail(PCD_ERR_ARG, "update_system: null vals");
@@ -935,12 +938,12 @@ int pcd_update_system(pcd_handle h, const double* vals, const double* pvals,
   values_changed(h, PCD_MAT_A00);
   if (mem == PCD_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_update_system)
 
 int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
                    const int32_t* colidx, const double* vals,
                    const double* pvals, int64_t n_u, const int32_t* is_u,
-                   int64_t n_p, const int32_t* is_p) {
+                   int64_t n_p, const int32_t* is_p) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (!rowptr || !colidx || !vals || !is_u || !is_p)
     return fail(PCD_ERR_ARG, "set_system: null argument");
@@ -1006,7 +1009,7 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
   const int rc = pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
   pt.lap("set_system: values");
   return rc;
-}
+} PCD_ABI_CATCH(pcd_set_system)
 
 // Rank-local form of pcd_set_system: this rank's rows of the monolithic matrix
 // only.  `rows[i]` is the caller's (global) index of local row i: the rank's
@@ -1021,7 +1024,7 @@ int pcd_set_system(pcd_handle h, int64_t n, const int32_t* rowptr,
 int pcd_set_system_local(pcd_handle h, int64_t n, int64_t n_u, const int32_t* is_u,
                          int64_t n_p, const int32_t* is_p, int64_t nrows_local,
                          const int32_t* rows, const int32_t* rowptr, const int32_t* colidx,
-                         const double* vals, const double* pvals) {
+                         const double* vals, const double* pvals) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (nrows_local < 0 || nrows_local > n)
     return fail(PCD_ERR_ARG, "set_system_local: nrows_local outside [0, n]");
@@ -1092,19 +1095,19 @@ int pcd_set_system_local(pcd_handle h, int64_t n, int64_t n_u, const int32_t* is
   CHK(hand_over(h->mat[PCD_MAT_A], &h->sp_sys, &h->sp_sys, nrows_local, la, ma, n));
   h->ready = false; ++h->gen;
   return pcd_update_system(h, vals, pvals, PCD_MEM_HOST);
-}
+} PCD_ABI_CATCH(pcd_set_system_local)
 
-int pcd_set_bc(pcd_handle h, int64_t n_bc, const int32_t* idx, const double* vals) {
+int pcd_set_bc(pcd_handle h, int64_t n_bc, const int32_t* idx, const double* vals) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (n_bc < 0 || (n_bc && (!idx || !vals))) return fail(PCD_ERR_ARG, "set_bc: bad arrays");
   h->bc_host.assign(idx, idx + n_bc);
   h->bc_val_host.assign(vals, vals + n_bc);
   h->ready = false; ++h->gen;             // filtered / uploaded by pcd_setup
   return 0;
-}
+} PCD_ABI_CATCH(pcd_set_bc)
 
 // ---- multigrid hierarchy ------------------------------------------------
-int pcd_mg_begin(pcd_handle h, int slot, int nlevels, int nu_pre, int nu_post) {
+int pcd_mg_begin(pcd_handle h, int slot, int nlevels, int nu_pre, int nu_post) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_begin: bad slot %d", slot);
   if (nlevels < 1 || nlevels > 32 || nu_pre < 0 || nu_post < 0)
@@ -1121,9 +1124,9 @@ int pcd_mg_begin(pcd_handle h, int slot, int nlevels, int nu_pre, int nu_post) {
   s.nu_pre = nu_pre; s.nu_post = nu_post;
   ++h->gen;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_mg_begin)
 
-int pcd_mg_set_level_cuts(pcd_handle h, int slot, int level, int64_t n, const int64_t* bounds) {
+int pcd_mg_set_level_cuts(pcd_handle h, int slot, int level, int64_t n, const int64_t* bounds) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_set_level_cuts: bad slot %d", slot);
   Inner& s = h->inner[slot];
@@ -1145,13 +1148,13 @@ int pcd_mg_set_level_cuts(pcd_handle h, int slot, int level, int64_t n, const in
   Space sp; sp.nf = 1; sp.bounds[0].assign(bounds, bounds + h->nranks + 1);
   s.mg_space[level] = sp;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_mg_set_level_cuts)
 
 int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
                      const int32_t* rowptr, const int32_t* colidx,
                      const double* vals, int64_t p_rows, int64_t p_cols,
                      const int32_t* prowptr, const int32_t* pcolidx,
-                     const double* pvals, double emin, double emax) {
+                     const double* pvals, double emin, double emax) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_set_level: bad slot %d", slot);
   Inner& s = h->inner[slot];
@@ -1294,7 +1297,7 @@ int pcd_mg_set_level(pcd_handle h, int slot, int level, int64_t n,
   ++h->gen;
   if (h->ready) CHK(inner_prepare(h, slot));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_mg_set_level)
 
 // Rank-local form of pcd_mg_set_level for a PARTITIONED level (more rows than
 // PCD_REPLICATE_BELOW; replicated levels are small by definition and keep the
@@ -1308,7 +1311,7 @@ int pcd_mg_set_level_local(pcd_handle h, int slot, int level, int64_t n, int64_t
                            const int32_t* rowptr, const int32_t* colidx, const double* vals,
                            int64_t p_cols, const int32_t* prowptr, const int32_t* pcolidx,
                            const double* pvals, int64_t r_rows_local, const int32_t* rrowptr,
-                           const int32_t* rcolidx, const double* rvals, double emin, double emax) {
+                           const int32_t* rcolidx, const double* rvals, double emin, double emax) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_set_level_local: bad slot %d", slot);
   Inner& s = h->inner[slot];
@@ -1402,7 +1405,7 @@ int pcd_mg_set_level_local(pcd_handle h, int slot, int level, int64_t n, int64_t
   ++h->gen;
   if (h->ready) CHK(inner_prepare(h, slot));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_mg_set_level_local)
 
 // Pre-composed form of one level (see MgLevel): Wd is n_c x n, Wu is
 // n x (2 n + 2 n_c) over [x1 | r_c | e_c | b].  wd_rowptr == NULL drops it.
@@ -1412,7 +1415,7 @@ int pcd_mg_set_fused(pcd_handle h, int slot, int level,
                      int64_t wd_rows, int64_t wd_cols, const int32_t* wd_rowptr,
                      const int32_t* wd_col, const double* wd_val,
                      int64_t wu_rows, int64_t wu_cols, const int32_t* wu_rowptr,
-                     const int32_t* wu_col, const double* wu_val) {
+                     const int32_t* wu_col, const double* wu_val) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_set_fused: bad slot %d", slot);
   Inner& s = h->inner[slot];
@@ -1470,14 +1473,14 @@ int pcd_mg_set_fused(pcd_handle h, int slot, int level,
   M.fused = true;
   if (h->ready) CHK(inner_prepare(h, slot));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_mg_set_fused)
 
 // Factor k of nfactors of an explicitly composed inner solve
 // (pc_type = PCD_PC_EXPLICIT): x = W_{nfactors-1} ... W_0 b.  Factors are
 // square operators on the slot's space; k == 0 starts a new chain.
 int pcd_set_inner_factor(pcd_handle h, int slot, int k, int nfactors, int64_t n,
                          const int32_t* rowptr, const int32_t* colidx,
-                         const double* vals) {
+                         const double* vals) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "set_inner_factor: bad slot %d", slot);
   if (nfactors < 1 || nfactors > 8 || k < 0 || k >= nfactors)
@@ -1509,10 +1512,10 @@ int pcd_set_inner_factor(pcd_handle h, int slot, int k, int nfactors, int64_t n,
                 (long long)s.chain[k].nrows, (long long)A.nrows);
   ++h->gen;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_set_inner_factor)
 
 int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
-                         double emin, double emax, int mem) {
+                         double emin, double emax, int mem) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "mg_update_values: bad slot %d", slot);
   Inner& s = h->inner[slot];
@@ -1532,10 +1535,10 @@ int pcd_mg_update_values(pcd_handle h, int slot, int level, const double* vals,
     ++h->gen;                        // Chebyshev coefficients are baked in
   }
   return 0;
-}
+} PCD_ABI_CATCH(pcd_mg_update_values)
 
 int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type, int max_it,
-                  double rtol, double emin, double emax) {
+                  double rtol, double emin, double emax) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   if (slot < 0 || slot >= PCD_KSP_COUNT) return fail(PCD_ERR_ARG, "set_inner: bad slot %d", slot);
   if (ksp_type < PCD_KSP_PREONLY || ksp_type > PCD_KSP_CG_SR)
@@ -1561,9 +1564,9 @@ int pcd_set_inner(pcd_handle h, int slot, int ksp_type, int pc_type, int max_it,
   s.emin = emin; s.emax = emax;
   if (h->ready) CHK(inner_prepare(h, slot));
   return 0;
-}
+} PCD_ABI_CATCH(pcd_set_inner)
 
-int pcd_setup(pcd_handle h) {
+int pcd_setup(pcd_handle h) try {
   if (!h) return fail(PCD_ERR_ARG, "null handle");
   HIPCHK(hipSetDevice(h->device));
   if (!h->mat[PCD_MAT_AP].set || !h->mat[PCD_MAT_MP].set || !h->mat[PCD_MAT_KP].set)
@@ -1615,5 +1618,5 @@ int pcd_setup(pcd_handle h) {
   for (int s = 0; s < PCD_KSP_COUNT; ++s) CHK(inner_prepare(h, s));
   h->ready = true; ++h->gen;
   return 0;
-}
+} PCD_ABI_CATCH(pcd_setup)
 

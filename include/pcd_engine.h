@@ -37,7 +37,8 @@ enum pcd_status {
   PCD_ERR_NOMEM = 3,
   PCD_ERR_STATE = 4,     /* operator or solver missing at setup/apply        */
   PCD_ERR_COMM = 5,      /* RCCL failure                                     */
-  PCD_ERR_BREAKDOWN = 6  /* numerical breakdown (zero pivot / NaN)           */
+  PCD_ERR_BREAKDOWN = 6, /* numerical breakdown (zero pivot / NaN)           */
+  PCD_ERR_INTERNAL = 7   /* an exception of the host side was caught at the ABI */
 };
 
 /* fenapack/preconditioners.py:89,139,211,256 - the four python contexts */

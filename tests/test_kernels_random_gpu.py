@@ -329,3 +329,41 @@ def test_chebyshev_steps_in_one_launch(hip_lib, monkeypatch, shape, diag):
         e.set_inner(c.KSP_MP, *cfg)
         e.update_values(c.MAT_MP, A2.data)
         assert relerr(e.inner_solve_np(c.KSP_MP, b), ref) < 1e-11, sw
+
+
+def test_chebyshev_patch_follows_a_pattern_change(hip_lib, monkeypatch):
+    """A second pcd_set_csr on the slot with ANOTHER pattern (fewer rows, fewer
+    entries) drops the one-launch patch of the first (upload_csr releases it;
+    round-5 advisor finding): the solve on the new operator equals the
+    step-by-step path and the oracle, and is again one launch."""
+    rng = np.random.default_rng(7)
+    A1 = _grid_operator(rng, (120, 120), True)
+    A2 = _grid_operator(rng, (61, 47), False)
+    assert A2.nnz < A1.nnz and A2.shape[0] < A1.shape[0]
+    cfg = ("chebyshev", "jacobi", 5, 0.0, 0.4, 2.1)
+    engines = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("PCD_CHEB_PATCH", sw)
+        e = c.Engine(hip_lib, "BRM1", 0)
+        e.set_csr(c.MAT_MP, A1)
+        e.set_inner(c.KSP_MP, *cfg)
+        e.inner_solve_np(c.KSP_MP, rng.standard_normal(A1.shape[0]))   # builds the patch of A1
+        engines[sw] = e
+    b = rng.standard_normal(A2.shape[0])
+    o = oracle.Engine("BRM1")
+    o.set_csr(c.MAT_MP, A2)
+    o.set_inner(c.KSP_MP, *cfg)
+    ref = o.inner_solve_np(c.KSP_MP, b)
+    out = {}
+    for sw, e in engines.items():
+        monkeypatch.setenv("PCD_CHEB_PATCH", sw)
+        e.set_csr(c.MAT_MP, A2)
+        e.set_inner(c.KSP_MP, *cfg)
+        e.inner_solve_np(c.KSP_MP, b)
+        l0 = e.info(c.INFO_LAUNCHES)
+        out[sw] = e.inner_solve_np(c.KSP_MP, b)
+        out[sw + "launches"] = e.info(c.INFO_LAUNCHES) - l0
+    assert relerr(out["0"], ref) < 1e-11
+    assert relerr(out["1"], ref) < 1e-11
+    assert relerr(out["1"], out["0"]) < 1e-13
+    assert out["0launches"] - out["1launches"] == 4, out
