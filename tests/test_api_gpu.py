@@ -256,3 +256,37 @@ def test_bench_line_of_the_re1000_supg_configuration():
     assert d["cpu_baseline"]["gpu_vs_oracle_rel_err"] < 1e-11
     assert d["pcapply_roofline"]["traffic"] is None
     assert d["pcapply_roofline"]["traffic_stale"]
+
+
+def test_bench_line_of_the_north_stars_literal_solvers():
+    """``bench.py --inner jacobi`` - the solvers `north_star` names: a
+    Jacobi-preconditioned CG (wave64 reductions) for the pressure Laplacian
+    (fenapack/preconditioners.py:42-49, 130: `ksp_Ap.solve`), Chebyshev-Jacobi
+    for the mass matrix (:133) and a Chebyshev / Jacobi sweep for the velocity
+    block - through the bench contract in small (level 4): the line carries
+    the `cg` block (two launches per iteration on one rank, B_cg of SURVEY
+    8(d) over the measured time), the executed k_A, and the oracle's parity of
+    this very apply (a tolerance-driven CG: 1e-7, not the fixed-count 1e-11)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--level", "4",
+           "--inner", "jacobi", "--steps", "5", "--warmup", "2",
+           "--a00-its", "60", "--a00-ratio", "0.01", "--cpu-seconds", "1"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and len(d["gmres_its_per_newton_step"]) == 2
+    assert d["config"]["inner"]["Ap"].startswith("cg+jacobi")
+    cg = d["cg"]
+    assert "error" not in cg, cg
+    assert cg["launches_per_iteration"] == 2.0, cg
+    assert cg["executed_k_A_last_apply"] > 10
+    n_p, = [d["config"]["n_p"]]
+    assert cg["algorithmic_bytes_per_iteration"] > 148 * n_p
+    assert 0.0 < cg["frac"] < 1.0 and cg["us_per_iteration"] > 1.0
+    assert d["cpu_baseline"]["gpu_vs_oracle_rel_err"] < 1e-7

@@ -34,6 +34,13 @@ p.add_argument("--geometry", default="cavity")
 p.add_argument("--variant", default="BRM1")
 p.add_argument("--n0", type=int, default=4)
 p.add_argument("--algebraic", action="store_true")
+p.add_argument("--inner", default="mg", choices=["mg", "jacobi"],
+               help="jacobi: the north star's literal solvers (bench.py "
+                    "--inner jacobi) + stage 4, fixed-count Jacobi-PCG on Ap")
+p.add_argument("--a00-its", type=int, default=240)
+p.add_argument("--a00-ratio", type=float, default=0.002)
+p.add_argument("--cycles-p", type=int, default=1)
+p.add_argument("--supg", action="store_true")
 a = p.parse_args()
 if a.geometry == "cavity":
     pb = Cavity(a.level, nu=0.01, variant=a.variant)
@@ -43,7 +50,12 @@ else:
     pb = BackwardStep(a.level, nu=0.02, variant=a.variant)
 V = pb.space
 PETScOptions.clear()
-multigrid_inner_options(dim=V.dim, algebraic=a.algebraic)
+if a.inner == "mg":
+    multigrid_inner_options(dim=V.dim, algebraic=a.algebraic,
+                            cycles_p=a.cycles_p)
+else:
+    from fenapack_amd.driver import default_inner_options              # noqa
+    default_inner_options(a00_its=a.a00_its, a00_ratio=a.a00_ratio, dim=V.dim)
 w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150, newton_rtol=1e-5,
                           max_newton=2)
 nls.parameters["error_on_nonconvergence"] = False
@@ -62,10 +74,20 @@ for _ in range(20):                      # (1) k_scale_dinv only
 eng.set_inner(c.KSP_A00, "chebyshev", "jacobi", 9, 0.0, 0.1 * emax, emax)
 for _ in range(10):                      # (2) the roofline kernel
     eng.inner_solve(c.KSP_A00, bu, xu)
-eng.set_inner(c.KSP_A00, "richardson", "mg", 1, 0.0)
+if a.inner == "mg":
+    eng.set_inner(c.KSP_A00, "richardson", "mg", 1, 0.0)
+else:
+    ksp0.push_settings()
+    # (4) the Jacobi-PCG iteration on Ap: 10 solves of 40 iterations, rtol 0
+    pcd = ksp.pc.getFieldSplitSubKSP()[1].pc.getPythonContext()
+    bp, xp = rng.standard_normal(V.n_p), np.empty(V.n_p)
+    eng.set_inner(c.KSP_AP, "cg", "jacobi", 40, 0.0)
+    for _ in range(10):
+        eng.inner_solve(c.KSP_AP, bp, xp)
+    pcd.ksp_Ap.push_settings()
 x, y = rng.standard_normal(V.ndof), np.empty(V.ndof)
 eng.graph_enable(False)
-for _ in range(10):                      # (3) whole PCApplies
+for _ in range(10 if a.inner == "mg" else 3):     # (3) whole PCApplies
     eng.fieldsplit_apply(x, y)
 print("n_u", V.n_u, "n_p", V.n_p, "nnz_A00", int(eng.info(c.INFO_NNZ_BASE + c.MAT_A00)),
       "components", int(eng.info(c.INFO_A00_COMPONENTS)),

@@ -73,6 +73,7 @@ def main():
     kus = sum(F[i][4] for i in ks) / len(ks) / 1e3
     # (3) whole PCApplies: k_gather ... k_scatter windows, the last ten
     ends = [i for i, r in enumerate(F) if r[1] == "k_scatter"][-10:]
+    PEAK = 8.0e12
     starts = [max(j for j, r in enumerate(F[:e]) if r[1] == "k_gather")
               for e in ends]
     per = []
@@ -80,6 +81,49 @@ def main():
         rd = corr * sum(F[i][3] for i in range(s, e + 1))
         wr = sum(W[i][3] for i in range(s, e + 1))
         per.append((rd, wr, e - s + 1))
+    # (4) every launch of the LAST apply (bytes, time under the counter pass,
+    # fraction of 8 TB/s), and the same summed by kernel over the applies
+    s, e = starts[-1], ends[-1]
+    launches = []
+    for i in range(s, e + 1):
+        rd, wr, ns = corr * F[i][3], W[i][3], 0.5 * (F[i][4] + W[i][4])
+        launches.append({"kernel": F[i][1], "grid": F[i][2],
+                         "read_bytes": rd, "write_bytes": wr,
+                         "us": ns / 1e3,
+                         "gbs": (rd + wr) / max(ns, 1.0),
+                         "frac": (rd + wr) / max(ns, 1.0) * 1e9 / PEAK})
+    by = {}
+    for s_, e_ in zip(starts, ends):
+        for i in range(s_, e_ + 1):
+            k = by.setdefault(F[i][1], [0, 0.0, 0.0])
+            k[0] += 1
+            k[1] += corr * F[i][3] + W[i][3]
+            k[2] += 0.5 * (F[i][4] + W[i][4])
+    by_kernel = [{"kernel": k, "launches_per_apply": v[0] / len(ends),
+                  "traffic_bytes_per_apply": v[1] / len(ends),
+                  "us_per_apply": v[2] / len(ends) / 1e3,
+                  "frac": v[1] / max(v[2], 1.0) * 1e9 / PEAK}
+                 for k, v in sorted(by.items(), key=lambda kv: -kv[1][2])]
+    # (5) the Jacobi-PCG iteration (pmc_pcapply.py --inner jacobi, stage 4):
+    # k_cg_spmv_s + k_cg_update of the fixed-count solves on Ap
+    cg = None
+    upd = [i for i, r in enumerate(F) if r[1] == "k_cg_update"]
+    if upd:
+        big_u = max(F[i][2] for i in upd)
+        # the standalone solves ran 40 iterations each: take their launches
+        # (largest run of consecutive spmv / update pairs)
+        sp_ = [i for i, r in enumerate(F) if r[1].startswith("k_cg_spmv")]
+        pair = [i for i in sp_ if i + 1 < len(F) and F[i + 1][1] == "k_cg_update"]
+        n_it = len(pair)
+        tr = sum(corr * (F[i][3] + F[i + 1][3]) + W[i][3] + W[i + 1][3]
+                 for i in pair)
+        ns = sum(0.5 * (F[i][4] + W[i][4] + F[i + 1][4] + W[i + 1][4])
+                 for i in pair)
+        cg = {"kernels": sorted({F[i][1] for i in pair} | {"k_cg_update"}),
+              "iterations_counted": n_it, "grid_update": big_u,
+              "launches_per_iteration": 2,
+              "traffic_bytes_per_iteration": tr / n_it,
+              "us_per_iteration_under_the_counter_pass": ns / n_it / 1e3}
     out = {
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace "
                    "--output-format csv -- python3 tools/pmc_pcapply.py "
@@ -102,6 +146,9 @@ def main():
             "read_bytes_per_apply": sum(p[0] for p in per) / len(per),
             "write_bytes_per_apply": sum(p[1] for p in per) / len(per),
             "traffic_bytes_per_apply": sum(p[0] + p[1] for p in per) / len(per)},
+        "cg_iteration": cg,
+        "pcapply_by_kernel": by_kernel,
+        "pcapply_launches": launches,
     }
     print(json.dumps(out, indent=1))
 
