@@ -221,6 +221,21 @@ def stub_main(args, json_out, rank, world):
         dist.destroy_process_group()
 
 
+def rss_trace(what):
+    """FENAPACK_AMD_RSS_TRACE=1: resident set of this process at the phases of
+    the run, on stderr (which phase a host-memory peak belongs to)."""
+    if os.environ.get("FENAPACK_AMD_RSS_TRACE") != "1":
+        return
+    with open("/proc/self/statm") as f:
+        rss = int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+    sys.stderr.write("[rss] %-34s %7.2f GB  t=%.1f s\n"
+                     % (what, rss / 1e9, time.time() - _T0))
+    sys.stderr.flush()
+
+
+_T0 = time.time()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -332,6 +347,7 @@ def main():
         kw = dict(kw)
         pb = cls(kw.pop("level"), **kw)
     V = pb.space
+    rss_trace("problem built")
     PETScOptions.clear()
     if args.inner == "mg":
         multigrid_inner_options(cycles_u=args.cycles_u, cycles_p=args.cycles_p,
@@ -376,6 +392,7 @@ def main():
     HOST_STEP_SECONDS["value"] = (time.time() - t_nls) / max(
         len(nls.krylov_history), 1)
     gmres_per_step = list(nls.krylov_history)
+    rss_trace("nonlinear steps done")
     ksp = nls.linear_solver().ksp()
     eng = ksp.engine
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -449,7 +466,9 @@ def main():
     def step():
         eng.fieldsplit_apply(x.t, y.t, c.MEM_DEVICE)
 
+    rss_trace("dominant kernel timed")
     dt = timed_steps(step, torch.cuda.synchronize, args, dist, world, "cuda")
+    rss_trace("timed region done")
     try:
         us_c, n_c = eng.probe_a00_step(x.t, y.t, 3)
         in_cycle = {"us_per_launch": us_c, "launches_timed": n_c}
@@ -711,6 +730,7 @@ def main():
                                         % (type(exc).__name__, exc)}
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rss_trace("before the cpu baseline")
         out["cpu_baseline"] = cpu_baseline(args, pb, ksp, eng, c, x,
                                            bytes_pc)
     if world == 1 and args.inner == "mg" and not args.no_producer:
@@ -721,6 +741,7 @@ def main():
             out["picard_step"] = picard_step_times(pb, w, nls, ksp, c)
         except Exception as exc:                  # never lose the bench line
             out["picard_step"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    rss_trace("end")
     out["host_peak_rss_gb"] = round(_guard.peak_rss_bytes() / 1e9, 2)
     out["host_rss_watchdog_limit_gb"] = None if not _guard._WATCHDOG["limit"] \
         else round(_guard._WATCHDOG["limit"] / 1e9, 1)
@@ -1024,6 +1045,10 @@ def cpu_baseline(args, pb, ksp, eng, c, x, algorithmic_bytes=None):
                      "settings (%.1f s), oracle/pcd_oracle.c; CPU "
                      "restatement, not PETSc" % (n1, t1),
            "single_thread": r1, "gpu_vs_oracle_rel_err": err,
+           # executed inner iterations of that apply, engine next to oracle (a
+           # tolerance-driven CG: the counts agree, the results to cond * rtol)
+           "k_A_engine_and_oracle": [int(eng.info(c.INFO_ITS_AP)),
+                                     int(serial.info(c.INFO_ITS_AP))],
            "host_cpus": os.cpu_count()}
     try:
         # the TEAM port: one parallel region per PCApply, first-touch

@@ -108,6 +108,7 @@ _HIP_ONLY = {
     "fe_set_level_galerkin": [C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p],
+    "fe_set_level_product": [C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 12,
     "fe_set_supg": [C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                     C.c_void_p, C.c_void_p, C.c_void_p],
     "fe_bind_pattern": [C.c_int, C.c_int64, C.c_void_p, C.c_void_p],
@@ -563,6 +564,19 @@ class Engine(object):
         self._call("fe_set_level_galerkin", int(level), int(c_ptr.size - 1),
                    int(b_ptr.size - 1), _ptr(b_ptr), _ptr(b_src), _ptr(b_w),
                    _ptr(c_ptr), _ptr(c_src), _ptr(c_w))
+
+    def fe_set_level_product(self, level, P, PT, f_indptr, f_indices,
+                             b_indptr, b_indices, c_indptr, c_indices):
+        """Galerkin level by the numeric sparse product on fixed patterns:
+        scalar ``P`` (fine x coarse) and its transpose ``PT`` (scipy CSR,
+        sorted), the pattern of the finer level's ``F`` and the structural
+        patterns of ``B = F P`` and ``F_c = P^T B``."""
+        keep = [_i32(P.indptr), _i32(P.indices), _f64(P.data),
+                _i32(PT.indptr), _i32(PT.indices), _f64(PT.data),
+                _i32(f_indptr), _i32(f_indices), _i32(b_indptr),
+                _i32(b_indices), _i32(c_indptr), _i32(c_indices)]
+        self._call("fe_set_level_product", int(level), int(P.shape[0]),
+                   int(P.shape[1]), *[_ptr(a) for a in keep])
 
     def fe_set_kp_rows(self, entry_offset, nnz_global):
         self._call("fe_set_kp_rows", int(entry_offset), int(nnz_global))

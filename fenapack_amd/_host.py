@@ -249,6 +249,28 @@ def spgemm(A, B, row0=0, row1=None):
     return C
 
 
+def product_pattern(a_indptr, a_indices, b_indptr, b_indices, b_cols):
+    """STRUCTURAL pattern of ``A @ B`` from the two patterns alone (the
+    symbolic phase of the device's numeric product, ``pcd_fe_set_level_product``):
+    ``(indptr, indices)`` as int32, columns sorted in every row."""
+    arp, ac = _i32(a_indptr), _i32(a_indices)
+    brp, bc = _i32(b_indptr), _i32(b_indices)
+    n = arp.size - 1
+    L = library()
+    crp = np.empty(n + 1, dtype=np.int64)
+    _chk(L.pcdh_spgemm_count(0, n, int(b_cols), _p(arp, _I32P), _p(ac, _I32P),
+                             _p(brp, _I32P), _p(bc, _I32P), _p(crp, _I64P)))
+    nnz = int(crp[-1])
+    if nnz >= 2 ** 31:
+        raise ValueError("product_pattern: more than 2^31 entries")
+    cc = np.empty(nnz, dtype=np.int32)
+    cv = np.empty(nnz, dtype=np.float64)          # (values of ones: dropped)
+    _chk(L.pcdh_spgemm_fill(0, n, int(b_cols), _p(arp, _I32P), _p(ac, _I32P),
+                            None, _p(brp, _I32P), _p(bc, _I32P), None,
+                            _p(crp, _I64P), _p(cc, _I32P), _p(cv, _F64P)))
+    return crp.astype(np.int32), cc
+
+
 def product_plan(A, B, mode):
     """Gather plan of ``C = A @ B`` on its structural pattern
     (``pcdh_product_plan_*``): returns ``(c_indptr, c_indices, ptr, src, w)`` -

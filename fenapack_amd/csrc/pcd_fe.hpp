@@ -351,6 +351,72 @@ static __global__ __launch_bounds__(kBlock) void k_fe_wgather(
   }
 }
 
+// C = A B on FIXED patterns - the numeric phase of a sparse product whose
+// symbolic phase ran once on the host (libpcd_host pcdh_spgemm_*): what PETSc's
+// MatMatMult / transposeMatMult(..., result=) do when the reference refreshes
+// R_p (fenapack/field_split_backend.py:160-166) and hypre / GAMG when they
+// re-form the coarse operators of a hierarchy whose aggregation is kept.  The
+// two Galerkin stages B = F P and F_c = P^T B of the device operator producer.
+//
+// A GROUP of G lanes owns a row i of C: its sorted column list and one
+// accumulator per entry live in LDS (CAP entries per pass; a longer row takes
+// several passes over A's row, each restricted to its column window).  The
+// entries k of A's row are taken IN ORDER; for each one the group's lanes run
+// along B's row j = col_A[k] - the columns of one row are distinct, so the
+// lanes of a step never meet in an accumulator (no atomics) - find the
+// column in the LDS list by bisection and add a_ik * b_jJ there.  Every entry
+// of C is thus summed in the order of A's row: reproducible, the same bits on
+// every rank that computes it, and the order of the gather plans this kernel
+// replaced (pcdh_product_plan_*: ~12 B per TERM resident in HBM, hundreds of
+// millions of terms for a 3-D hierarchy; here: nothing but the patterns).
+// LDS traffic of one wave is ordered (DS operations execute in issue order),
+// which is what lets step k + 1 read what step k wrote without a barrier.
+constexpr int kSpgemmSlots = 4096;       // C entries a workgroup holds (16 KB of columns + 32 KB of sums)
+template <int G>
+static __global__ __launch_bounds__(kBlock) void k_spgemm_fixed(
+    int nrows, const int* __restrict__ arp, const int* __restrict__ ac, const double* __restrict__ av,
+    const int* __restrict__ brp, const int* __restrict__ bc, const double* __restrict__ bv,
+    const int* __restrict__ crp, const int* __restrict__ cc, double* __restrict__ cv) {
+  constexpr int NG = kBlock / G;                 // groups per workgroup
+  constexpr int CAP = kSpgemmSlots / NG;         // C entries of a row per pass
+  static_assert(G >= 8 && G <= 64 && (G & (G - 1)) == 0, "a group is a power-of-two part of a wave");
+  __shared__ int s_col[kSpgemmSlots];
+  __shared__ double s_acc[kSpgemmSlots];
+  const int g = threadIdx.x / G, lane = threadIdx.x % G;
+  int* col = s_col + g * CAP;
+  double* acc = s_acc + g * CAP;
+  for (int i = blockIdx.x * NG + g; i < nrows; i += gridDim.x * NG) {
+    const int c0 = crp[i], nC = crp[i + 1] - c0;
+    const int a0 = arp[i], a1 = arp[i + 1];
+    for (int p0 = 0; p0 < nC; p0 += CAP) {
+      const int np = min(CAP, nC - p0);
+      for (int t = lane; t < np; t += G) { col[t] = cc[c0 + p0 + t]; acc[t] = 0.0; }
+      __builtin_amdgcn_wave_barrier();
+      const int lo = col[0], hi = col[np - 1];
+      for (int k = a0; k < a1; ++k) {
+        const int j = ac[k];
+        const double a = av[k];
+        const int q1 = brp[j + 1];
+        for (int q = brp[j] + lane; q < q1; q += G) {
+          const int J = bc[q];
+          if (J < lo || J > hi) continue;          // (another pass' window)
+          int l = 0, r = np - 1;
+          while (l < r) {
+            const int m = (l + r) >> 1;
+            if (col[m] < J) l = m + 1; else r = m;
+          }
+          // (a structural pattern holds every J; the test keeps a foreign
+          // pattern from corrupting a neighbour's sum)
+          if (col[l] == J) acc[l] += a * bv[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      for (int t = lane; t < np; t += G) cv[c0 + p0 + t] = acc[t];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 static __global__ __launch_bounds__(kBlock) void k_fe_set(
     int n, const int* __restrict__ pos, const double* __restrict__ val,
     double* out) {

@@ -21,6 +21,14 @@ struct FeLevel {
   DBuf<int64_t> b_ptr, c_ptr;
   DBuf<int> b_src, c_src;
   DBuf<double> b_w, c_w, B;
+  // ... or by the numeric sparse product on fixed patterns (k_spgemm_fixed,
+  // pcd_fe_set_level_product): P and P^T with their values, the patterns of
+  // the finer level's F, of B = F P and of this level's F = P^T B
+  bool product = false;
+  int64_t pr_nf = 0, pr_nc = 0;       // fine / coarse scalar rows
+  int pr_g1 = 8, pr_g2 = 32;          // lanes per row of the two stages
+  DBuf<int> p_rp, p_col, pt_rp, pt_col, ff_rp, ff_col, bb_rp, bb_col, cc_rp, cc_col;
+  DBuf<double> p_val, pt_val;
   // Newton linearisation: the d*d scalar matrices N_ij (masked), their element
   // storage, the Galerkin intermediate, and where block entry (i, j, k) sits in
   // the values of this level's operator
@@ -39,6 +47,9 @@ struct FeLevel {
   void release() {
     b_ptr.release(); c_ptr.release(); b_src.release(); c_src.release();
     b_w.release(); c_w.release(); B.release();
+    product = false;
+    p_rp.release(); p_col.release(); pt_rp.release(); pt_col.release(); ff_rp.release(); ff_col.release();
+    bb_rp.release(); bb_col.release(); cc_rp.release(); cc_col.release(); p_val.release(); pt_val.release();
     N.release(); cellsN.release(); BN.release(); npos.release();
     kpos.release(); gvals.release();
     cell_h.release(); cells_s.release(); Fa.release();
@@ -131,8 +142,48 @@ static FeTables fe_tables(const FeState& fe) {
                   fe.nq_s, fe.qw_s.p, fe.phi_s.p, fe.dphi_s.p};
 }
 
+// one numeric product on fixed patterns, G lanes per row of C
+static int fe_spgemm(Engine* h, int G, int64_t nrows, const int* arp, const int* ac, const double* av,
+                     const int* brp, const int* bc, const double* bv, const int* crp, const int* cc,
+                     double* cv) {
+  if (nrows < 1) return 0;
+  const int ng = kBlock / G;
+  const int grid = (int)std::min<int64_t>((nrows + ng - 1) / ng, (int64_t)g_num_cus * 16);
+#define PCD_SPGEMM(GG)                                                                                     \
+  hipLaunchKernelGGL(k_spgemm_fixed<GG>, dim3(grid), dim3(kBlock), 0, h->stream, (int)nrows, arp, ac, av, \
+                     brp, bc, bv, crp, cc, cv)
+  switch (G) {
+    case 8: PCD_SPGEMM(8); break;
+    case 16: PCD_SPGEMM(16); break;
+    case 32: PCD_SPGEMM(32); break;
+    default: PCD_SPGEMM(64); break;
+  }
+#undef PCD_SPGEMM
+  return 0;
+}
+
+// lanes per row of C for a product whose B rows hold `avg` entries on average
+static int fe_spgemm_group(double avg) { return avg <= 8.0 ? 8 : avg <= 16.0 ? 16 : avg <= 40.0 ? 32 : 64; }
+
 // coarse operator as the Galerkin product of the next finer level's one
 static int fe_galerkin_level(Engine* h, FeLevel& L, const FeLevel& finer, bool newton, int d2) {
+  if (L.product) {
+    // B = F_finer P, F = P^T B: two numeric products on the patterns bound by
+    // pcd_fe_set_level_product (Newton: the same for each of the d*d blocks)
+    CHK(fe_spgemm(h, L.pr_g1, L.pr_nf, L.ff_rp.p, L.ff_col.p, finer.F.p, L.p_rp.p, L.p_col.p, L.p_val.p,
+                  L.bb_rp.p, L.bb_col.p, L.B.p));
+    CHK(fe_spgemm(h, L.pr_g2, L.pr_nc, L.pt_rp.p, L.pt_col.p, L.pt_val.p, L.bb_rp.p, L.bb_col.p, L.B.p,
+                  L.cc_rp.p, L.cc_col.p, L.F.p));
+    if (newton)
+      for (int m = 0; m < d2; ++m) {
+        CHK(fe_spgemm(h, L.pr_g1, L.pr_nf, L.ff_rp.p, L.ff_col.p, finer.N.p + (int64_t)m * finer.nnzf,
+                      L.p_rp.p, L.p_col.p, L.p_val.p, L.bb_rp.p, L.bb_col.p, L.BN.p + (int64_t)m * L.nnzb));
+        CHK(fe_spgemm(h, L.pr_g2, L.pr_nc, L.pt_rp.p, L.pt_col.p, L.pt_val.p, L.bb_rp.p, L.bb_col.p,
+                      L.BN.p + (int64_t)m * L.nnzb, L.cc_rp.p, L.cc_col.p, L.N.p + (int64_t)m * L.nnzf));
+      }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(L.nnzb, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
                      L.nnzb, L.b_ptr.p, L.b_src.p, L.b_w.p, finer.F.p, L.B.p);
   hipLaunchKernelGGL(k_fe_wgather, dim3(grid1d(L.nnzf, 1, 1 << 20)), dim3(kBlock), 0, h->stream,
@@ -435,6 +486,64 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f, int64_t nn
   L.set = true; L.ev_init = false;
   return 0;
 } PCD_ABI_CATCH(pcd_fe_set_level_galerkin)
+
+// The same level by a NUMERIC SPARSE PRODUCT on fixed patterns (k_spgemm_fixed):
+// the symbolic phase ran on the host once (the aggregation, hence every
+// pattern, is kept across the nonlinear iterations), the device keeps P, P^T
+// and the three patterns and recomputes values - what the reference's
+// transposeMatMult(..., result=) does (fenapack/field_split_backend.py:160-166)
+// and what hypre's / GAMG's set-up re-does every outer iteration
+// (demo_navier-stokes-pcd.py:153-160).  No per-term lists: the memory held
+// for the refresh is the patterns (12 B per entry of P, 4 B per entry of the
+// three patterns) instead of ~12 B per TERM of both products.
+int pcd_fe_set_level_product(pcd_handle h, int level, int64_t n_fine, int64_t n_coarse,
+                             const int32_t* p_rowptr, const int32_t* p_col, const double* p_val,
+                             const int32_t* pt_rowptr, const int32_t* pt_col, const double* pt_val,
+                             const int32_t* f_rowptr, const int32_t* f_col,
+                             const int32_t* b_rowptr, const int32_t* b_col,
+                             const int32_t* c_rowptr, const int32_t* c_col) try {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_level_product: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev - 1)
+    return fail(PCD_ERR_ARG, "fe_set_level_product: level %d is not a coarse level", level);
+  if (n_fine < 1 || n_coarse < 1 || n_fine > INT32_MAX || !p_rowptr || !p_col || !p_val || !pt_rowptr ||
+      !pt_col || !pt_val || !f_rowptr || !f_col || !b_rowptr || !b_col || !c_rowptr || !c_col)
+    return fail(PCD_ERR_ARG, "fe_set_level_product: bad arguments");
+  const int64_t nnz_p = p_rowptr[n_fine], nnz_f = f_rowptr[n_fine], nnz_b = b_rowptr[n_fine],
+                nnz_c = c_rowptr[n_coarse];
+  if (pt_rowptr[n_coarse] != nnz_p || nnz_f < 1 || nnz_b < 1 || nnz_c < 1)
+    return fail(PCD_ERR_ARG, "fe_set_level_product: P^T does not have P's entries, or an empty pattern");
+  HIPCHK(hipSetDevice(h->device));
+  FeLevel& L = fe.lev[level];
+  L.release();
+  L.galerkin = true; L.product = true; L.nnzf = nnz_c; L.nnzb = nnz_b;
+  L.pr_nf = n_fine; L.pr_nc = n_coarse;
+  CHK(fe_upload(L.p_rp, p_rowptr, (size_t)n_fine + 1));
+  CHK(fe_upload(L.p_col, p_col, (size_t)nnz_p));
+  CHK(fe_upload(L.p_val, p_val, (size_t)nnz_p));
+  CHK(fe_upload(L.pt_rp, pt_rowptr, (size_t)n_coarse + 1));
+  CHK(fe_upload(L.pt_col, pt_col, (size_t)nnz_p));
+  CHK(fe_upload(L.pt_val, pt_val, (size_t)nnz_p));
+  CHK(fe_upload(L.ff_rp, f_rowptr, (size_t)n_fine + 1));
+  CHK(fe_upload(L.ff_col, f_col, (size_t)nnz_f));
+  CHK(fe_upload(L.bb_rp, b_rowptr, (size_t)n_fine + 1));
+  CHK(fe_upload(L.bb_col, b_col, (size_t)nnz_b));
+  CHK(fe_upload(L.cc_rp, c_rowptr, (size_t)n_coarse + 1));
+  CHK(fe_upload(L.cc_col, c_col, (size_t)nnz_c));
+  CHK(L.B.ensure(nnz_b));
+  CHK(L.F.ensure(nnz_c));
+  // lanes per row of C: along the rows of the product's SECOND factor
+  L.pr_g1 = fe_spgemm_group((double)nnz_p / (double)n_fine);
+  L.pr_g2 = fe_spgemm_group((double)nnz_b / (double)n_fine);
+  // (PCD_SPGEMM_GROUP=8|16|32|64 forces the group size of both stages - the
+  // tests use it to send ordinary rows through the several-pass path)
+  if (const char* e = getenv("PCD_SPGEMM_GROUP")) {
+    const int g = atoi(e);
+    if (g == 8 || g == 16 || g == 32 || g == 64) L.pr_g1 = L.pr_g2 = g;
+  }
+  L.set = true; L.ev_init = false;
+  return 0;
+} PCD_ABI_CATCH(pcd_fe_set_level_product)
 
 // SUPG-stabilised preconditioner matrix (fenapack/stabilization.py:39-68 and
 // its use at demo_navier-stokes-pcd.py:122-127): per re-discretised level the

@@ -133,6 +133,9 @@ MAX_GALERKIN_PAIRS = int(os.environ.get("FENAPACK_AMD_MAX_GALERKIN_PAIRS",
                                         "1000000000"))
 
 
+MAX_GALERKIN_PAIRS_NUMPY = 400000000
+
+
 def galerkin_plan(rows_f, cols_f, P):
     """Fixed-pattern numeric ``P^T F P``: two weighted-gather stages.
 
@@ -167,7 +170,9 @@ def galerkin_plan(rows_f, cols_f, P):
                              "use -pc_mg_galerkin none" % c_src.size)
         return (b_ptr, b_src, b_w, c_ptr, c_src, c_w, crp.astype(np.int32),
                 ccol)
-    if est > MAX_GALERKIN_PAIRS:
+    # (the numpy builder makes temporaries several times the list size: its
+    # cap stays at 4e8 pairs whatever the native builder is allowed)
+    if est > min(MAX_GALERKIN_PAIRS, MAX_GALERKIN_PAIRS_NUMPY):
         raise ValueError("Galerkin plan of ~%.3g pairs exceeds the limit; use "
                          "-pc_mg_galerkin none" % est)
     # B = F P: entry (i, J) collects F[i, j] * P[j, J]
@@ -178,7 +183,7 @@ def galerkin_plan(rows_f, cols_f, P):
     del k_rep, pidx, order
     # F_c = P^T B: entry (I, J) collects P[i, I] * B[i, J]
     e_rep, pidx = _expand_by_rows(P, rows_b)
-    if e_rep.size > MAX_GALERKIN_PAIRS:
+    if e_rep.size > min(MAX_GALERKIN_PAIRS, MAX_GALERKIN_PAIRS_NUMPY):
         raise ValueError("Galerkin plan of %d pairs exceeds the limit; use "
                          "-pc_mg_galerkin none" % e_rep.size)
     rows_c, cols_c, c_ptr, order = _group(
@@ -259,6 +264,8 @@ class DeviceProducer(object):
             and os.environ.get("FENAPACK_AMD_FE_ROWS", "1") != "0"
         self._cut = [None] * nlev      # per level: (a0, a1, e0, e1) or None
         self.plan_entries = [0] * nlev  # what this rank holds (cells, entries)
+        self.plan_terms = [0] * nlev    # per-term lists of a Galerkin level ("plans" mode)
+        self.refresh_bytes = [0] * nlev  # HBM a Galerkin level's refresh holds
         top_h = len(pb.hierarchy.meshes) - 1
         self.levels = []                       # host problems, coarsest first
         for l in range(nlev):
@@ -441,12 +448,29 @@ class DeviceProducer(object):
     def _set_level_galerkin(self, l, P):
         """Level ``l`` = P^T (level l+1) P with the scalar part of the
         velocity prolongation ``P`` (= P_s x I_d)."""
+        from . import _host
         d = self.V.dim
         Ps = sp.csr_matrix(P)[::d, ::d]
+        Ps.sort_indices()
         indptr_f, indices_f, n_f = self._pat[l + 1]
-        rows_f = np.repeat(np.arange(n_f), np.diff(indptr_f))
-        plan = galerkin_plan(rows_f, indices_f, Ps)
-        indptr_c, indices_c = plan[6], plan[7]
+        # The product itself: a numeric sparse product on fixed patterns
+        # (k_spgemm_fixed; the symbolic phase here, once) - or, on request
+        # (FENAPACK_AMD_GALERKIN=plans: the route of rounds 3-5, kept as the
+        # cross-check of the kernel), two weighted gathers over per-TERM lists
+        self.galerkin_mode = os.environ.get("FENAPACK_AMD_GALERKIN", "product")
+        if self.galerkin_mode not in ("product", "plans"):
+            raise ValueError("FENAPACK_AMD_GALERKIN = product | plans")
+        if self.galerkin_mode == "plans" or _host.use_numpy():
+            rows_f = np.repeat(np.arange(n_f), np.diff(indptr_f))
+            plan = galerkin_plan(rows_f, indices_f, Ps)
+            indptr_c, indices_c = plan[6], plan[7]
+        else:
+            plan = None
+            PT = _host.transpose(Ps)
+            b_ip, b_ix = _host.product_pattern(indptr_f, indices_f, Ps.indptr,
+                                               Ps.indices, Ps.shape[1])
+            indptr_c, indices_c = _host.product_pattern(
+                PT.indptr, PT.indices, b_ip, b_ix, Ps.shape[1])
         # scipy's SpGEMM drops entries that cancel to an exact zero, so the
         # host's Galerkin pattern depends on the values it was built from;
         # the device product needs the structural pattern: re-create the
@@ -459,7 +483,19 @@ class DeviceProducer(object):
             mg = self.ksp0.pc.mg_data
             self.eng.mg_set_level(c.KSP_A00, l, K, mg["chain"][l],
                                   *mg["bounds"][l])
-        self.eng.fe_set_level_galerkin(l, *plan[:6])
+        if plan is not None:
+            self.eng.fe_set_level_galerkin(l, *plan[:6])
+            self.plan_terms[l] = int(plan[1].size + plan[4].size)
+        else:
+            self.eng.fe_set_level_product(l, Ps, PT, indptr_f, indices_f,
+                                          b_ip, b_ix, indptr_c, indices_c)
+        # bytes held in HBM for this level's refresh
+        self.refresh_bytes[l] = (
+            8 * (plan[0].size + plan[3].size) + 12 * self.plan_terms[l]
+            if plan is not None else
+            2 * (12 * Ps.nnz + 4 * (sum(Ps.shape) + 2))
+            + 4 * (len(indices_f) + b_ix.size + indices_c.size)
+            + 4 * (2 * n_f + Ps.shape[1] + 3))
         self._pat[l] = (indptr_c, indices_c, Ps.shape[1])
 
     def _set_newton(self, ksp0):

@@ -481,6 +481,23 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f,
                               const int32_t* b_src, const double* b_w,
                               const int64_t* c_ptr, const int32_t* c_src,
                               const double* c_w);
+/* The same coarse level by a NUMERIC SPARSE PRODUCT on fixed patterns - the
+ * reference's transposeMatMult(..., result=) (fenapack/field_split_backend.py:
+ * 160-166: pattern reused, values recomputed) and the per-iteration AMG set-up
+ * of demo_navier-stokes-pcd.py:153-160 on a kept aggregation.  P (n_fine x
+ * n_coarse, scalar) and P^T with their values; the pattern of the finer
+ * level's scalar F; the STRUCTURAL patterns of B = F P (n_fine rows) and of
+ * this level's F = P^T B (n_coarse rows) from a symbolic product run once on
+ * the host (pcd_host.h pcdh_spgemm_*).  Columns sorted in every row.  Every
+ * entry is summed in the order of the first factor's row: reproducible.     */
+int pcd_fe_set_level_product(pcd_handle h, int level, int64_t n_fine,
+                             int64_t n_coarse, const int32_t* p_rowptr,
+                             const int32_t* p_col, const double* p_val,
+                             const int32_t* pt_rowptr, const int32_t* pt_col,
+                             const double* pt_val, const int32_t* f_rowptr,
+                             const int32_t* f_col, const int32_t* b_rowptr,
+                             const int32_t* b_col, const int32_t* c_rowptr,
+                             const int32_t* c_col);
 /* SUPG-stabilised preconditioner matrix (fenapack/stabilization.py:39-68, used
  * at demo_navier-stokes-pcd.py:122-127): cell sizes h of one re-discretised
  * level (ncells values), viscosity, P2 basis at the cell midpoint (na values),

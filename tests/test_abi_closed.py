@@ -157,12 +157,13 @@ rp = A.indptr.astype(np.int32); ci = A.indices.astype(np.int32); va = A.data
 i32 = ctypes.POINTER(ctypes.c_int32); f64 = ctypes.POINTER(ctypes.c_double)
 rcs = []
 for which in (c.MAT_AP, c.MAT_KP, c.MAT_MP):
-    rc = lib.pcd_set_csr(e.h, which, ctypes.c_int64(n), ctypes.c_int64(n),
-                         rp.ctypes.data_as(i32), ci.ctypes.data_as(i32),
-                         va.ctypes.data_as(f64))
-    rcs.append((rc, lib.pcd_last_error().decode()))
+    # (the raw export, not the wrapper that raises: the STATUS is the subject)
+    rc = lib.lib.pcd_set_csr(e._h, which, ctypes.c_int64(n), ctypes.c_int64(n),
+                             rp.ctypes.data_as(i32), ci.ctypes.data_as(i32),
+                             va.ctypes.data_as(f64))
+    rcs.append((rc, lib.last_error().decode()))
 print("CODES", rcs)
-rc = lib.pcd_destroy(e.h); e.h = None
+rc = lib.lib.pcd_destroy(e._h); e._h = ctypes.c_void_p()
 print("DESTROYED", rc)
 """
 

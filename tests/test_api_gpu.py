@@ -266,7 +266,8 @@ def test_bench_line_of_the_north_stars_literal_solvers():
     block - through the bench contract in small (level 4): the line carries
     the `cg` block (two launches per iteration on one rank, B_cg of SURVEY
     8(d) over the measured time), the executed k_A, and the oracle's parity of
-    this very apply (a tolerance-driven CG: 1e-7, not the fixed-count 1e-11)."""
+    this very apply (a tolerance-driven CG: the iteration counts agree, the
+    results to cond(Ap) * rtol - not the fixed-count paths' 1e-11)."""
     import json
     import os
     import subprocess
@@ -289,4 +290,9 @@ def test_bench_line_of_the_north_stars_literal_solvers():
     n_p, = [d["config"]["n_p"]]
     assert cg["algorithmic_bytes_per_iteration"] > 148 * n_p
     assert 0.0 < cg["frac"] < 1.0 and cg["us_per_iteration"] > 1.0
-    assert d["cpu_baseline"]["gpu_vs_oracle_rel_err"] < 1e-7
+    # the CG stops by its tolerance: engine and oracle execute the same number
+    # of iterations, and their results agree to cond(Ap) * rtol, not to
+    # rounding (level 6: 1931 iterations either side, 1.8e-4)
+    ke, ko = d["cpu_baseline"]["k_A_engine_and_oracle"]
+    assert abs(ke - ko) <= 1 and ke == cg["executed_k_A_last_apply"], (ke, ko)
+    assert d["cpu_baseline"]["gpu_vs_oracle_rel_err"] < 1e-4

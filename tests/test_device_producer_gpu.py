@@ -602,3 +602,58 @@ def test_tiny_hierarchies(hip_lib, level):
     for i, j in zip(dev["krylov_per_step"], ref["krylov_per_step"]):
         assert abs(i - j) <= max(1, 0.05 * j)
     assert relerr(dev["w"].vector(), ref["w"].vector()) < 1e-6
+
+
+@pytest.mark.parametrize("kind,group", [("cavity", None), ("cube", None),
+                                        ("cube", "8"), ("newton", None)])
+def test_galerkin_levels_by_the_numeric_sparse_product(hip_lib, kind, group,
+                                                       monkeypatch):
+    """The coarse operators of a Galerkin hierarchy as NUMERIC SPARSE PRODUCTS
+    on fixed patterns (k_spgemm_fixed, pcd_fe_set_level_product: the
+    reference's transposeMatMult(..., result=), field_split_backend.py:160-166)
+    against the per-term gather plans they replaced
+    (FENAPACK_AMD_GALERKIN=plans) and the host's products: every level at
+    1e-12, the same structural patterns, and a fraction of the memory held
+    for the refresh.  PCD_SPGEMM_GROUP=8 sends the 3-D coarse rows (more
+    entries than a group's LDS window) through the several-pass path."""
+    import scipy.sparse.linalg as spla
+    from fenapack_amd.fem.multigrid import galerkin_chain
+    rng = np.random.default_rng(11)
+    got = {}
+    for mode in ("product", "plans"):
+        monkeypatch.setenv("FENAPACK_AMD_GALERKIN", mode)
+        if group and mode == "product":
+            monkeypatch.setenv("PCD_SPGEMM_GROUP", group)
+        else:
+            monkeypatch.delenv("PCD_SPGEMM_GROUP", raising=False)
+        if kind == "cavity":
+            pb = Cavity(4, nu=0.01)
+            _gamg_options(2, coarse_limit=100)
+        elif kind == "cube":
+            pb = Cavity3D(1, nu=0.02, n0=6)
+            _gamg_options(3, coarse_limit=60)
+        else:
+            pb = Cavity(3, nu=0.01, nls="newton")
+            _options(2, coarse_limit=300, galerkin=True)
+        V = pb.space
+        out = solve_steady_device(pb, max_newton=1)
+        prod = out["producer"]
+        assert prod.galerkin_mode == mode and prod.nlev >= 3
+        if mode == "product":
+            xu, xp = rng.standard_normal(V.n_u), rng.standard_normal(V.n_p)
+        prod.update(xu, xp)
+        # (level_matrix: F x I_d, with the Newton blocks N where they exist)
+        mats = [prod.level_matrix(l) for l in range(prod.nlev - 1)]
+        got[mode] = (mats, sum(prod.refresh_bytes), sum(prod.plan_terms))
+        if mode == "product" and kind != "newton":
+            lin = pb.linearise(xu, xp)
+            ksp0 = out["solver"].linear_solver().ksp().pc.getFieldSplitSubKSP()[0]
+            ref = galerkin_chain(lin["A00"], ksp0.pc.mg_data["chain"])[:-1]
+            for l, R in enumerate(ref):
+                assert spla.norm(mats[l] - R.tocsr()) < 1e-12 * spla.norm(R), l
+    for l, (a, b) in enumerate(zip(got["product"][0], got["plans"][0])):
+        assert a.nnz == b.nnz and np.array_equal(a.indices, b.indices), l
+        assert relerr(a.data, b.data) < 1e-13, l
+    assert got["product"][2] == 0 and got["plans"][2] > 0
+    # patterns and P instead of 12 B per term of both products
+    assert got["product"][1] < 0.5 * got["plans"][1], got

@@ -12,4 +12,7 @@ done
 cd $ROOT
 NU=$(grep -o "n_u [0-9]*" $OUT/${TAG}_pmc_FETCH_SIZE.log | tail -1 | cut -d" " -f2)
 python3 tools/pmc_roofline.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $NU > $OUT/${TAG}_pmc_roofline.json 2> $OUT/${TAG}_pmc_roofline.err
-rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
+# (kept when the summary failed: what was collected says why)
+if [ -s $OUT/${TAG}_pmc_roofline.json ]; then rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE; else
+  for C in FETCH_SIZE WRITE_SIZE; do find $OUT/${TAG}_pmc_$C -name "*kernel_trace.csv" -delete; find $OUT/${TAG}_pmc_$C -name "*counter_collection.csv" -exec sh -c 'cut -d, -f1-12 "$1" | head -400 > "$1.head"; rm "$1"' _ {} \; ; done
+fi

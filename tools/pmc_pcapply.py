@@ -45,6 +45,8 @@ a = p.parse_args()
 if a.geometry == "cavity":
     pb = Cavity(a.level, nu=0.01, variant=a.variant)
 elif a.geometry == "cube":
+    # (config 5's own mesh is above the host assembler's default limit)
+    os.environ.setdefault("FENAPACK_AMD_MAX_CELLS", "4000000")
     pb = Cavity3D(a.level, nu=0.01, n0=a.n0, variant=a.variant)
 else:
     pb = BackwardStep(a.level, nu=0.02, variant=a.variant)

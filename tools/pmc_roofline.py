@@ -54,6 +54,12 @@ def main():
     assert [r[1] for r in F] == [r[1] for r in W], "passes ran different kernels"
     # (1) calibration on the 20 standalone k_scale_dinv of the finest level
     sd = [i for i, r in enumerate(F) if r[1] == "k_scale_dinv"]
+    if not sd:
+        names = {}
+        for r in F:
+            names[r[1]] = names.get(r[1], 0) + 1
+        sys.exit("no k_scale_dinv dispatch in %s (%d dispatches: %s)"
+                 % (sys.argv[1], len(F), sorted(names.items())[:40]))
     big = max(F[i][2] for i in sd)
     sd = [i for i in sd if F[i][2] == big][-20:]
     n_u = int(sys.argv[3]) if len(sys.argv) > 3 else None
