@@ -733,7 +733,8 @@ def main():
         rss_trace("before the cpu baseline")
         out["cpu_baseline"] = cpu_baseline(args, pb, ksp, eng, c, x,
                                            bytes_pc)
-    if world == 1 and args.inner == "mg" and not args.no_producer:
+    if args.inner == "mg" and not args.no_producer and (
+            world == 1 or (partitioned and args.algebraic)):
         # end-to-end context, after everything that is reported above: two
         # more Picard steps with the device operator producer
         # against the host producer's time for the steps done during setup
@@ -756,10 +757,10 @@ def main():
 def picard_step_times(pb, w, nls, ksp, c):
     """Seconds per nonlinear step: host (numpy) producer as timed by the
     set-up solve vs. the engine's device producer for two further steps."""
-    from fenapack_amd.device_producer import DeviceProducer
+    from fenapack_amd.device_producer_rows import make_device_producer
     V = pb.space
     t0 = time.perf_counter()
-    prod = DeviceProducer(pb, ksp)
+    prod = make_device_producer(pb, ksp)
     t_plan = time.perf_counter() - t0
     x = w.vector()
     solver = nls.linear_solver()
@@ -792,8 +793,18 @@ def picard_step_times(pb, w, nls, ksp, c):
             x -= dx
             b = prod.update(x[V.is_u], x[V.is_p])
         dt = (time.perf_counter() - t0) / steps
+    extra = {}
+    if getattr(pb, "partitioned", False):
+        # the rank-local producer: what this rank holds for the refresh and
+        # what one refresh puts on the wire (all-reduced buffers of the
+        # by-rows products), per level, coarsest first
+        extra = {"producer": "rank-local (fem/partition.py slab, "
+                             "amg.PartitionedSA refreshed on the device)",
+                 "refresh_bytes_held_by_level_rank0": prod.refresh_bytes,
+                 "wire_doubles_by_level": prod.wire_doubles,
+                 "plan_cells_and_entries_rank0": prod.plan_entries[-1]}
     return {"device_producer_seconds": dt, "gmres_its": its_hist,
-            "plan_seconds": t_plan,
+            "plan_seconds": t_plan, **extra,
             "host_producer_seconds_incl_setup": HOST_STEP_SECONDS.get("value"),
             "device_resident_loop": bool(prod.device_loop),
             "what": "assemble operators of all multigrid levels + Kp + "
@@ -908,6 +919,20 @@ def roofline_block(kernel, b_alg, t, traffic, b_model, probes,
     contract's `achieved` / `frac` (SURVEY 8d algorithmic bytes: the unfused
     textbook count, which a fused kernel may beat, so it can exceed 1 and is
     then NOT a fraction of anything physical)."""
+    # Which time the fractions use.  An operator that fits the Infinity Cache
+    # (< 200 MB per launch) is timed back to back: its own previous launch
+    # left it where the cycle's previous level would.  Beyond the cache the
+    # back-to-back loop is generous - the tail of the operator is still cached
+    # from the launch before (level 7: 53 against 60 us) - so there the time
+    # INSIDE THE CYCLE is the one every fraction is taken on (the review of
+    # round 5, item 9); the back-to-back time stays on the line beside it.
+    t_back_to_back = t
+    basis = "back_to_back"
+    if (not whole_apply and resident_bytes is not None
+            and resident_bytes >= 200e6 and in_cycle
+            and in_cycle.get("us_per_launch")):
+        t = in_cycle["us_per_launch"] * 1e-6
+        basis = "in_cycle"
     gbs = lambda nbytes: None if nbytes is None else nbytes / t / 1e9
     achieved = gbs(b_alg)
     # a working set below ~200 MB stays in the 256 MiB Infinity Cache between
@@ -928,6 +953,8 @@ def roofline_block(kernel, b_alg, t, traffic, b_model, probes,
         else pmc["file"],
         "traffic_stale": pmc is None or traffic is None,
         "us_per_launch": 1e6 * t,
+        "us_per_launch_basis": basis,
+        "us_per_launch_back_to_back": 1e6 * t_back_to_back,
         "measured_probes_gbs": probes,
         "measured_torch_copy_gbs": torch_copy_gbs,
         "measured_roof_gbs": roof, "measured_roof_probe": roof_key,
@@ -958,6 +985,9 @@ def roofline_block(kernel, b_alg, t, traffic, b_model, probes,
         # the cycle have used the caches in between (an event pair per launch
         # adds about a microsecond)
         out["us_per_launch_cache_state"] = (
+            "inside eager PCApplies, after the coarser levels used the caches "
+            "(%.0f MB per launch: beyond the 256 MiB Infinity Cache)"
+            % ((b_model or b_alg) / 1e6)) if basis == "in_cycle" else (
             "back-to-back loop on one operator (cache-warm as far as %.0f MB "
             "fit L2 / the 256 MiB Infinity Cache)" % ((b_model or b_alg) / 1e6))
         out["in_cycle"] = in_cycle
@@ -1077,6 +1107,26 @@ def cpu_baseline(args, pb, ksp, eng, c, x, algorithmic_bytes=None):
             if r > rN:
                 rN, nN, tN, nthreads = r, n_done, el, t
                 errN = float(np.abs(yh2 - yh).max() / np.abs(yh).max())
+        # A/B of the team's barrier at the thread counts where it matters: the
+        # NUMA-aware two-level barrier (groups of 16 consecutive - i.e. socket- /
+        # L3-local - threads; oracle/pcd_oracle.c t_full_barrier) is what the
+        # sweep above ran; the runtime's own centralised barrier next to it
+        sweep_rt = {}
+        os.environ["PCDO_TEAM_GROUP"] = "0"
+        try:
+            for t in [t for t in counts if t > 16]:
+                par.team_prepare(t)
+                par.team_fieldsplit_apply(xh, yh2)
+                n_done, t0 = 0, time.perf_counter()
+                while True:
+                    par.team_fieldsplit_apply(xh, yh2)
+                    n_done += 1
+                    el = time.perf_counter() - t0
+                    if el > 0.5 * budget or n_done >= 200:
+                        break
+                sweep_rt[t] = round(n_done / el, 2)
+        finally:
+            os.environ.pop("PCDO_TEAM_GROUP", None)
         # the reported figure: the best thread count of the sweep measured
         # again over a longer sample (a third of the CPU budget: ~5 s)
         par.team_prepare(nthreads)
@@ -1099,6 +1149,9 @@ def cpu_baseline(args, pb, ksp, eng, c, x, algorithmic_bytes=None):
         out["all_cores"] = {
             "value": rN, "threads": nthreads, "threads_available": navail,
             "physical_cores": phys, "sweep": sweep,
+            "sweep_with_the_runtimes_own_barrier": sweep_rt,
+            "team_barrier": "two-level, groups of 16 consecutive threads "
+                            "(socket / L3 local); PCDO_TEAM_GROUP",
             "sweep_value_at_best": round(sweep_best, 2),
             "team_vs_serial_oracle_rel_err": errN,
             "host_stream_triad_gbs_by_threads": triad,

@@ -109,6 +109,11 @@ _HIP_ONLY = {
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p],
     "fe_set_level_product": [C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 12,
+    "fe_set_level_product_rows": [C.c_int, C.c_int64, C.c_int64, C.c_int64]
+    + [C.c_void_p] * 12 + [C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int,
+                           C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                           C.c_int64, C.c_int64],
+    "fe_set_residual_rows": [C.c_int],
     "fe_set_supg": [C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                     C.c_void_p, C.c_void_p, C.c_void_p],
     "fe_bind_pattern": [C.c_int, C.c_int64, C.c_void_p, C.c_void_p],
@@ -577,6 +582,32 @@ class Engine(object):
                 _i32(b_indices), _i32(c_indptr), _i32(c_indices)]
         self._call("fe_set_level_product", int(level), int(P.shape[0]),
                    int(P.shape[1]), *[_ptr(a) for a in keep])
+
+    def fe_set_level_product_rows(self, level, Pext, PT, f_indptr, f_indices,
+                                  b_indptr, b_indices, t_indptr, t_indices,
+                                  n_out, wire_len, sends, adds, pos,
+                                  gather_off=0, gather_total=0, node_row0=0,
+                                  n_node_rows=0):
+        """Galerkin level BY ROWS (``pcd_fe_set_level_product_rows``):
+        ``Pext`` (global shape: own + halo rows), ``PT`` = transpose of the
+        own rows, the patterns, and the exchange lists."""
+        keep = [_i32(Pext.indptr), _i32(Pext.indices), _f64(Pext.data),
+                _i32(PT.indptr), _i32(PT.indices), _f64(PT.data),
+                _i32(f_indptr), _i32(f_indices), _i32(b_indptr),
+                _i32(b_indices), _i32(t_indptr), _i32(t_indices)]
+        sends = np.ascontiguousarray(sends, dtype=np.int64).reshape(-1, 3)
+        adds = np.ascontiguousarray(adds, dtype=np.int64).reshape(-1, 4)
+        pos = _i32(pos)
+        self._call("fe_set_level_product_rows", int(level),
+                   int(len(f_indptr) - 1), int(Pext.shape[0]),
+                   int(Pext.shape[1]), *([_ptr(a) for a in keep] + [
+                       int(n_out), int(wire_len), int(sends.shape[0]),
+                       _ptr(sends), int(adds.shape[0]), _ptr(adds), _ptr(pos),
+                       int(gather_off), int(gather_total), int(node_row0),
+                       int(n_node_rows)]))
+
+    def fe_set_residual_rows(self, on=True):
+        self._call("fe_set_residual_rows", int(bool(on)))
 
     def fe_set_kp_rows(self, entry_offset, nnz_global):
         self._call("fe_set_kp_rows", int(entry_offset), int(nnz_global))

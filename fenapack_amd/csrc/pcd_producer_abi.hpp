@@ -29,6 +29,17 @@ struct FeLevel {
   int pr_g1 = 8, pr_g2 = 32;          // lanes per row of the two stages
   DBuf<int> p_rp, p_col, pt_rp, pt_col, ff_rp, ff_col, bb_rp, bb_col, cc_rp, cc_col;
   DBuf<double> p_val, pt_val;
+  // ... BY ROWS (pcd_fe_set_level_product_rows: the hierarchy of a partitioned
+  // producer): this rank multiplies ITS rows of the finer operator, its TERMS
+  // of the coarse rows of other ranks travel to their owners over one
+  // all-reduced wire buffer, the terms of its own coarse rows are added in
+  // rank order, and (a level the engine replicates) the rows are gathered
+  bool prows = false;
+  int64_t pr_nown = 0, pr_nterm = 0, pr_nout = 0, pr_wire = 0, pr_goff = 0, pr_gtot = 0;
+  std::vector<int64_t> pr_sends;      // (first term, count, wire offset) per destination
+  std::vector<int64_t> pr_adds;       // (source 0 terms / 1 wire, source offset, count, offset into pr_pos)
+  DBuf<int> pr_pos;                   // where a source's entries land in this rank's rows
+  DBuf<double> T, wire, Fown;
   // Newton linearisation: the d*d scalar matrices N_ij (masked), their element
   // storage, the Galerkin intermediate, and where block entry (i, j, k) sits in
   // the values of this level's operator
@@ -47,7 +58,8 @@ struct FeLevel {
   void release() {
     b_ptr.release(); c_ptr.release(); b_src.release(); c_src.release();
     b_w.release(); c_w.release(); B.release();
-    product = false;
+    product = false; prows = false; pr_sends.clear(); pr_adds.clear();
+    pr_pos.release(); T.release(); wire.release(); Fown.release();
     p_rp.release(); p_col.release(); pt_rp.release(); pt_col.release(); ff_rp.release(); ff_col.release();
     bb_rp.release(); bb_col.release(); cc_rp.release(); cc_col.release(); p_val.release(); pt_val.release();
     N.release(); cellsN.release(); BN.release(); npos.release();
@@ -95,6 +107,8 @@ struct FeState {
   // nonlinear residual on the device (pcd_fe_bind_residual)
   bool res_bound = false, have_mu0 = false;
   DCsr A01raw, A10raw;                 // unconstrained constant blocks
+  bool res_rows = false;               // ... of which this rank holds ITS ROWS only (pcd_fe_set_residual_rows)
+  DBuf<double> rtmp;
   int64_t n_bc = 0; double idt = 0.0;
   DBuf<int> bc_idx;
   DBuf<double> bc_mult, bc_g, mass, mu0, u0;
@@ -117,7 +131,7 @@ struct FeState {
     inv_piv.release(); inv_col0.release(); inv_col1.release();
     rb_nodes.release(); rb_pos.release(); rb_src.release(); rb_ptr.release();
     rb_normal.release(); rb_length.release(); rb_w.release(); rb_loc.release(); rb_tmp.release();
-    A01raw.release(); A10raw.release(); bc_idx.release(); bc_mult.release();
+    A01raw.release(); A10raw.release(); rtmp.release(); bc_idx.release(); bc_mult.release();
     bc_g.release(); mass.release(); mu0.release(); u0.release(); xd.release();
     bd.release(); dxd.release(); xs.release(); bs.release(); vv.release();
   }
@@ -167,6 +181,52 @@ static int fe_spgemm_group(double avg) { return avg <= 8.0 ? 8 : avg <= 16.0 ? 1
 
 // coarse operator as the Galerkin product of the next finer level's one
 static int fe_galerkin_level(Engine* h, FeLevel& L, const FeLevel& finer, bool newton, int d2) {
+  if (L.prows) {
+    // by rows: B = (my rows of F_finer) P_ext, T = (my rows of P)^T B - my
+    // TERMS of every coarse row my fine rows reach (MatPtAP on an MPI matrix;
+    // amg.PartitionedSA._galerkin on the host)
+    if (newton) return fail(PCD_ERR_STATE, "fe: the by-rows product goes with the Picard block");
+    CHK(fe_spgemm(h, L.pr_g1, L.pr_nown, L.ff_rp.p, L.ff_col.p, finer.F.p, L.p_rp.p, L.p_col.p, L.p_val.p,
+                  L.bb_rp.p, L.bb_col.p, L.B.p));
+    CHK(fe_spgemm(h, L.pr_g2, L.pr_nc, L.pt_rp.p, L.pt_col.p, L.pt_val.p, L.bb_rp.p, L.bb_col.p, L.B.p,
+                  L.cc_rp.p, L.cc_col.p, L.T.p));
+    // the terms of other ranks' coarse rows: contiguous slices of T (rows of a
+    // rank are consecutive), each at its place of a wire buffer every rank
+    // holds alike - one all-reduce delivers all of them (sums with zeros)
+    if (L.pr_wire) {
+      HIPCHK(hipMemsetAsync(L.wire.p, 0, (size_t)L.pr_wire * sizeof(double), h->stream));
+      for (size_t q = 0; q + 2 < L.pr_sends.size(); q += 3)
+        if (L.pr_sends[q + 1])
+          HIPCHK(hipMemcpyAsync(L.wire.p + L.pr_sends[q + 2], L.T.p + L.pr_sends[q],
+                                (size_t)L.pr_sends[q + 1] * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      if (!h->comm) return fail(PCD_ERR_STATE, "fe: the by-rows product needs the communicator");
+      if (h->comm->allreduce(L.wire.p, (size_t)L.pr_wire, h->stream))
+        return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+    }
+    // my coarse rows: the sources' entries in RANK order (HostComm.sum_rows),
+    // each a pattern of its own - positions distinct within one source
+    double* own = L.pr_gtot ? L.Fown.p : L.F.p;
+    if (L.pr_nout) HIPCHK(hipMemsetAsync(own, 0, (size_t)L.pr_nout * sizeof(double), h->stream));
+    for (size_t q = 0; q + 3 < L.pr_adds.size(); q += 4) {
+      const int64_t cnt = L.pr_adds[q + 2];
+      if (!cnt) continue;
+      const double* src = (L.pr_adds[q] ? L.wire.p : L.T.p) + L.pr_adds[q + 1];
+      hipLaunchKernelGGL(k_fe_add_at, dim3(grid1d(cnt)), dim3(kBlock), 0, h->stream, (int)cnt,
+                         L.pr_pos.p + L.pr_adds[q + 3], src, own);
+    }
+    if (L.pr_gtot) {
+      // a level the engine replicates: every rank's rows, in rank order, are
+      // the whole operator (coarse rows are numbered rank by rank)
+      HIPCHK(hipMemsetAsync(L.F.p, 0, (size_t)L.pr_gtot * sizeof(double), h->stream));
+      if (L.pr_nout)
+        HIPCHK(hipMemcpyAsync(L.F.p + L.pr_goff, own, (size_t)L.pr_nout * sizeof(double),
+                              hipMemcpyDeviceToDevice, h->stream));
+      if (h->comm->allreduce(L.F.p, (size_t)L.pr_gtot, h->stream))
+        return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (L.product) {
     // B = F_finer P, F = P^T B: two numeric products on the patterns bound by
     // pcd_fe_set_level_product (Newton: the same for each of the d*d blocks)
@@ -544,6 +604,99 @@ int pcd_fe_set_level_product(pcd_handle h, int level, int64_t n_fine, int64_t n_
   L.set = true; L.ev_init = false;
   return 0;
 } PCD_ABI_CATCH(pcd_fe_set_level_product)
+
+// The product BY ROWS - a hierarchy whose levels are partitioned (what every
+// rank of the reference does for its rows of fp / kp each outer iteration:
+// fenapack/assembling.py:98-106, field_split_backend.py:79-83, 285-291; the
+// owned-rows-only rule of SubfieldBC.h:136-155; hypre / GAMG re-forming the
+// coarse operators, demo_navier-stokes-pcd.py:153-160).  This rank holds
+// n_own node rows of the finer level's scalar F (global columns: f_*), the
+// prolongation rows of its own AND its halo nodes (P_ext: n_fine rows, global
+// shape, the others empty), the transpose of its own rows (n_coarse x n_own),
+// the patterns of B = F_rows P_ext (n_own rows) and of its TERMS T = P_own^T B
+// (n_coarse rows).  sends: (first term, count, wire offset) per destination -
+// the terms of another rank's coarse rows are consecutive; wire_len doubles
+// every rank holds alike, delivered by ONE all-reduce.  adds: (source 0 = T /
+// 1 = wire, source offset, count, offset into pos), applied in order, land in
+// this rank's n_out entries (pos).  gather_total > 0: the level is replicated -
+// the rows of all ranks, this rank's at gather_off, are the level's F.
+int pcd_fe_set_level_product_rows(pcd_handle h, int level, int64_t n_own, int64_t n_fine, int64_t n_coarse,
+                                  const int32_t* pe_rowptr, const int32_t* pe_col, const double* pe_val,
+                                  const int32_t* pt_rowptr, const int32_t* pt_col, const double* pt_val,
+                                  const int32_t* f_rowptr, const int32_t* f_col,
+                                  const int32_t* b_rowptr, const int32_t* b_col,
+                                  const int32_t* t_rowptr, const int32_t* t_col,
+                                  int64_t n_out, int64_t wire_len, int n_sends, const int64_t* sends,
+                                  int n_adds, const int64_t* adds, const int32_t* pos,
+                                  int64_t gather_off, int64_t gather_total,
+                                  int64_t node_row0, int64_t n_node_rows) try {
+  if (!h || !h->fe) return fail(PCD_ERR_STATE, "fe_set_level_product_rows: call pcd_fe_begin first");
+  FeState& fe = *h->fe;
+  if (level < 0 || level >= fe.nlev - 1)
+    return fail(PCD_ERR_ARG, "fe_set_level_product_rows: level %d is not a coarse level", level);
+  if (!h->comm) return fail(PCD_ERR_STATE, "fe_set_level_product_rows: no communicator attached");
+  if (n_own < 0 || n_fine < 1 || n_coarse < 1 || n_fine > INT32_MAX || !pe_rowptr || !pt_rowptr || !f_rowptr ||
+      !b_rowptr || !t_rowptr || n_out < 0 || wire_len < 0 || n_sends < 0 || n_adds < 0 ||
+      (n_sends && !sends) || (n_adds && (!adds || !pos)) || gather_off < 0 || gather_total < 0 ||
+      (gather_total && gather_off + n_out > gather_total))
+    return fail(PCD_ERR_ARG, "fe_set_level_product_rows: bad arguments");
+  const int64_t nnz_pe = pe_rowptr[n_fine], nnz_pt = pt_rowptr[n_coarse], nnz_f = f_rowptr[n_own],
+                nnz_b = b_rowptr[n_own], nnz_t = t_rowptr[n_coarse];
+  if ((nnz_pe && (!pe_col || !pe_val)) || (nnz_pt && (!pt_col || !pt_val)) || (nnz_f && !f_col) ||
+      (nnz_b && !b_col) || (nnz_t && !t_col))
+    return fail(PCD_ERR_ARG, "fe_set_level_product_rows: null index / value arrays");
+  int64_t npos = 0;
+  for (int q = 0; q < n_sends; ++q)
+    if (sends[3 * q] < 0 || sends[3 * q + 1] < 0 || sends[3 * q] + sends[3 * q + 1] > nnz_t ||
+        sends[3 * q + 2] < 0 || sends[3 * q + 2] + sends[3 * q + 1] > wire_len)
+      return fail(PCD_ERR_ARG, "fe_set_level_product_rows: send %d outside the terms / the wire", q);
+  for (int q = 0; q < n_adds; ++q) {
+    const int64_t src = adds[4 * q], off = adds[4 * q + 1], cnt = adds[4 * q + 2], po = adds[4 * q + 3];
+    if ((src != 0 && src != 1) || off < 0 || cnt < 0 || po < 0 || off + cnt > (src ? wire_len : nnz_t))
+      return fail(PCD_ERR_ARG, "fe_set_level_product_rows: add %d outside its source", q);
+    npos = std::max(npos, po + cnt);
+  }
+  for (int64_t k = 0; k < npos; ++k)
+    if (pos[k] < 0 || pos[k] >= n_out) return fail(PCD_ERR_ARG, "fe_set_level_product_rows: a position outside the rows");
+  HIPCHK(hipSetDevice(h->device));
+  FeLevel& L = fe.lev[level];
+  L.release();
+  L.galerkin = true; L.prows = true;
+  L.nnzb = nnz_b; L.pr_nown = n_own; L.pr_nf = n_fine; L.pr_nc = n_coarse; L.pr_nterm = nnz_t;
+  L.pr_nout = n_out; L.pr_wire = wire_len; L.pr_goff = gather_off; L.pr_gtot = gather_total;
+  L.nnzf = gather_total ? gather_total : n_out;
+  L.pr_sends.assign(sends, sends + 3 * (size_t)n_sends);
+  L.pr_adds.assign(adds, adds + 4 * (size_t)n_adds);
+  CHK(fe_upload(L.p_rp, pe_rowptr, (size_t)n_fine + 1));
+  CHK(fe_upload(L.p_col, pe_col, (size_t)nnz_pe));
+  CHK(fe_upload(L.p_val, pe_val, (size_t)nnz_pe));
+  CHK(fe_upload(L.pt_rp, pt_rowptr, (size_t)n_coarse + 1));
+  CHK(fe_upload(L.pt_col, pt_col, (size_t)nnz_pt));
+  CHK(fe_upload(L.pt_val, pt_val, (size_t)nnz_pt));
+  CHK(fe_upload(L.ff_rp, f_rowptr, (size_t)n_own + 1));
+  CHK(fe_upload(L.ff_col, f_col, (size_t)nnz_f));
+  CHK(fe_upload(L.bb_rp, b_rowptr, (size_t)n_own + 1));
+  CHK(fe_upload(L.bb_col, b_col, (size_t)nnz_b));
+  CHK(fe_upload(L.cc_rp, t_rowptr, (size_t)n_coarse + 1));
+  CHK(fe_upload(L.cc_col, t_col, (size_t)nnz_t));
+  CHK(fe_upload(L.pr_pos, pos, (size_t)npos));
+  CHK(L.B.ensure(std::max<int64_t>(nnz_b, 1)));
+  CHK(L.T.ensure(std::max<int64_t>(nnz_t, 1)));
+  CHK(L.F.ensure(std::max<int64_t>(L.nnzf, 1)));
+  if (wire_len) CHK(L.wire.ensure(wire_len));
+  if (gather_total) CHK(L.Fown.ensure(std::max<int64_t>(n_out, 1)));
+  L.pr_g1 = fe_spgemm_group(n_own ? (double)nnz_pe / (double)std::max<int64_t>(1, n_own) : 8.0);
+  L.pr_g2 = fe_spgemm_group(n_own ? (double)nnz_b / (double)n_own : 8.0);
+  if (const char* e = getenv("PCD_SPGEMM_GROUP")) {
+    const int g = atoi(e);
+    if (g == 8 || g == 16 || g == 32 || g == 64) L.pr_g1 = L.pr_g2 = g;
+  }
+  // a partitioned level keeps this rank's node rows only (like a row-cut plan)
+  if (!gather_total) { L.rows = true; L.row0 = node_row0; L.nrows = n_node_rows; }
+  L.nn2 = n_coarse;
+  L.set = true; L.ev_init = false;
+  return 0;
+} PCD_ABI_CATCH(pcd_fe_set_level_product_rows)
 
 // SUPG-stabilised preconditioner matrix (fenapack/stabilization.py:39-68 and
 // its use at demo_navier-stokes-pcd.py:122-127): per re-discretised level the
@@ -1119,10 +1272,22 @@ static int fe_residual_dev(Engine* h, FeState& fe, const double* xd, double* bd,
                        (int)fe.n_bc, fe.bc_idx.p, fe.bc_g.p, fe.vv.p);
   CHK(fe_apply_unconstrained(h, fe, fe.vv.p, Fu));
   if (fe.newton) CHK(fe_subtract_newton_defect(h, fe, xu, fe.vv.p, Fu));
-  CHK(spmv(h, fe.A01raw, xp, Fu, 1, Fu));
+  if (fe.res_rows) {
+    // B^T by rows: this rank's rows of B^T x_p (the others are zero), summed
+    // into every replica - like F_unc v above (fe_apply_rows)
+    CHK(fe.rtmp.ensure(nu));
+    CHK(spmv(h, fe.A01raw, xp, fe.rtmp.p));
+    if (h->comm->allreduce(fe.rtmp.p, (size_t)nu, h->stream))
+      return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
+    hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, 1.0, fe.rtmp.p, 1.0, Fu);
+  } else {
+    CHK(spmv(h, fe.A01raw, xp, Fu, 1, Fu));
+  }
   if (fe.have_mu0)
     hipLaunchKernelGGL(k_axpby, dim3(grid1d(nu, 4)), dim3(kBlock), 0, h->stream, (int)nu, -1.0, fe.mu0.p, 1.0, Fu);
   CHK(spmv(h, fe.A10raw, fe.vv.p, Fp));
+  if (fe.res_rows && h->comm->allreduce(Fp, (size_t)np, h->stream))
+    return fail(PCD_ERR_COMM, "allreduce: %s", h->comm->err.c_str());
   if (fe.n_bc)
     hipLaunchKernelGGL(k_fe_bc_rows, dim3(grid1d(fe.n_bc)), dim3(kBlock), 0, h->stream,
                        (int)fe.n_bc, fe.bc_idx.p, fe.bc_g.p, fe.bc_mult.p, xu, Fu);
@@ -1176,6 +1341,17 @@ int pcd_fe_bind_residual(pcd_handle h, const int32_t* bt_rowptr, const int32_t* 
   fe.res_bound = true;
   return 0;
 } PCD_ABI_CATCH(pcd_fe_bind_residual)
+
+// The constant blocks handed to pcd_fe_bind_residual hold THIS RANK'S ROWS
+// only (global shape, the other rows empty - what a partitioned assembly
+// holds: fenapack/SubfieldBC.h:136-155, _field_split_utils.py:39-50): B^T x_p
+// and B v of the residual are then completed by one all-reduce each.
+int pcd_fe_set_residual_rows(pcd_handle h, int on) try {
+  if (!h || !h->fe || !h->fe->res_bound) return fail(PCD_ERR_STATE, "fe_set_residual_rows: bind the residual first");
+  if (on && !h->comm) return fail(PCD_ERR_STATE, "fe_set_residual_rows: no communicator attached");
+  h->fe->res_rows = on != 0;
+  return 0;
+} PCD_ABI_CATCH(pcd_fe_set_residual_rows)
 
 // boundary values of the Dirichlet dofs (order of bc_idx); time dependent
 int pcd_fe_set_bc_values(pcd_handle h, const double* g) try {

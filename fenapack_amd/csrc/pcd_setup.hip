@@ -99,6 +99,19 @@ int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   // operators streamed from HBM: lane-major entries, straight to registers
   // (the form is fixed with the layout)
   A.vt_lm = A.nt2 && g_vt_nt;
+  // ... and operators with LONG rows (the coarse levels of an algebraic
+  // hierarchy: ~180 entries per node row on config 5's first level).  The
+  // direct form gives a row 256 / 64 = 4 lanes whatever the block holds, and a
+  // block of such rows is cut by its tile nodes after 8-16 rows: 32-64 of the
+  // 256 lanes work (N = 73, first coarse level, counter pass of round 6: 112 MB
+  // in 58-78 us = 0.18-0.25 of the HBM peak); the lane-major form deals a
+  // block's entries out evenly, 8 per lane.  PCD_LM_ROW_ENTRIES: mean entries
+  // per node row from which the form is lane-major (default 64; 0: never).
+  {
+    const char* e = getenv("PCD_LM_ROW_ENTRIES");
+    const long long thr = e ? atoll(e) : 64;
+    if (g_vt_nt && thr > 0 && nn > 0 && (long long)(rpc[nn] / nn) >= thr) A.vt_lm = true;
+  }
   const int kVtRows = A.vt_lm ? lm_rows(nc) : 64;
   const int kEntries = A.vt_lm ? kLmEntries : INT32_MAX;       // (direct form: no entry buffer)
   const int kNodes = A.vt_lm ? lm_nodes(nc) : kVtNodes;

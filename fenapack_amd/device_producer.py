@@ -742,7 +742,10 @@ class DevicePicardSolver(object):
             if len(self.residual_history) == it:       # final one skipped
                 self.residual_history.append(float("nan"))
             t0 = time.time()
-            self.producer = DeviceProducer(pb, nls.linear_solver().ksp())
+            # (a partitioned problem gets the rank-local producer)
+            from .device_producer_rows import make_device_producer
+            self.producer = make_device_producer(pb,
+                                                 nls.linear_solver().ksp())
             self.time_plan = time.time() - t0
             # (no hipGraph replay here: every update changes the smoother
             # bounds baked into the captured launches, and re-capturing costs

@@ -861,6 +861,10 @@ class KSP(object):
         rtol = self.rtol
         if self.type == "chebyshev":
             lo, hi = self._chebyshev_bounds()
+            # what the engine holds from here on (an estimate re-run later -
+            # a warm power iteration goes on from where it stopped - is a
+            # slightly different interval, i.e. another polynomial)
+            self.cheb_bounds_pushed = (lo, hi)
         if self.type != "cg" or self.norm_type == "none":
             rtol = 0.0                      # fixed iteration count
         max_it = 1 if self.type == "preonly" else self.max_it

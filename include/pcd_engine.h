@@ -498,6 +498,34 @@ int pcd_fe_set_level_product(pcd_handle h, int level, int64_t n_fine,
                              const int32_t* f_col, const int32_t* b_rowptr,
                              const int32_t* b_col, const int32_t* c_rowptr,
                              const int32_t* c_col);
+/* The product BY ROWS: the coarse levels of a hierarchy whose operators are
+ * partitioned (fenapack/assembling.py:98-106 and field_split_backend.py:79-83,
+ * 285-291: every rank re-assembles fp / kp for ITS rows each outer iteration;
+ * SubfieldBC.h:136-155: owned rows only; the AMG set-up re-run on them,
+ * demo_navier-stokes-pcd.py:153-160).  This rank holds n_own node rows of the
+ * finer level's scalar F (f_*: global columns), P_ext = the prolongation rows
+ * of its own and its halo nodes (n_fine rows, global shape), the transpose of
+ * its own rows (pt_*: n_coarse x n_own), the structural patterns of
+ * B = F_rows P_ext (n_own rows) and of its TERMS T = P_own^T B (n_coarse rows).
+ * Terms of other ranks' coarse rows are consecutive in T: sends[3q..] = (first
+ * term, count, wire offset); wire_len doubles, alike on every rank, are
+ * delivered by ONE all-reduce.  adds[4q..] = (source: 0 T / 1 wire, source
+ * offset, count, offset into pos): applied in order (rank order), they land in
+ * this rank's n_out entries.  gather_total > 0: the level is replicated - all
+ * ranks' rows, this rank's at gather_off, form its F.  Otherwise the level
+ * keeps node rows [node_row0, node_row0 + n_node_rows) (like pcd_fe_set_rows). */
+int pcd_fe_set_level_product_rows(
+    pcd_handle h, int level, int64_t n_own, int64_t n_fine, int64_t n_coarse,
+    const int32_t* pe_rowptr, const int32_t* pe_col, const double* pe_val,
+    const int32_t* pt_rowptr, const int32_t* pt_col, const double* pt_val,
+    const int32_t* f_rowptr, const int32_t* f_col, const int32_t* b_rowptr,
+    const int32_t* b_col, const int32_t* t_rowptr, const int32_t* t_col,
+    int64_t n_out, int64_t wire_len, int n_sends, const int64_t* sends,
+    int n_adds, const int64_t* adds, const int32_t* pos, int64_t gather_off,
+    int64_t gather_total, int64_t node_row0, int64_t n_node_rows);
+/* The blocks of pcd_fe_bind_residual hold this rank's rows only (global shape;
+ * SubfieldBC.h:136-155): their products are completed by all-reduces.       */
+int pcd_fe_set_residual_rows(pcd_handle h, int on);
 /* SUPG-stabilised preconditioner matrix (fenapack/stabilization.py:39-68, used
  * at demo_navier-stokes-pcd.py:122-127): cell sizes h of one re-discretised
  * level (ncells values), viscosity, P2 basis at the cell midpoint (na values),

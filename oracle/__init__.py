@@ -137,8 +137,14 @@ def mirror(o, pb, ksp):
                                d["chain"][l], *d["bounds"][l])
             o.set_inner(slot, k.type, "mg", k.max_it, 0.0)
         else:
-            lo, hi = (k._chebyshev_bounds() if k.type == "chebyshev"
-                      else (0.5, 2.0))
+            # the interval the PRODUCT was handed (petsc.KSP.push_settings),
+            # not a fresh estimate: the power iteration is warm-started, a
+            # second run ends elsewhere and 240 Chebyshev steps on another
+            # interval are another operator (round 6: 0.5 relative at cube
+            # N = 48 between the engine and a checker mirrored that way)
+            lo, hi = (getattr(k, "cheb_bounds_pushed", None)
+                      or k._chebyshev_bounds()) if k.type == "chebyshev" \
+                else (0.5, 2.0)
             o.set_inner(slot, k.engine_type, "jacobi", k.max_it,
                         k.rtol if k.type == "cg" else 0.0, lo, hi)
     o.setup()

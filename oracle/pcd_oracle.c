@@ -910,6 +910,45 @@ static __thread int t_dirty = 0;            /* short loops since the last full b
 static __thread int t_sense = 0;
 static volatile int t_sb_count = 0, t_sb_sense = 0;
 
+/* The whole team's barrier, NUMA-aware (round 6): a two-level sense-reversing
+ * barrier in place of libgomp's centralised one.  Threads are pinned to cores
+ * in order (OMP_PLACES=cores, bench.py), so t_grp consecutive thread ids share
+ * a socket / an L3: they meet on a counter of their own cache line, the last
+ * one of each group meets the other groups' last ones on the top counter, and
+ * the release travels back the same way - per barrier every thread touches
+ * one line that lives in its own L3, and only n_groups threads touch the line
+ * that crosses the sockets (the centralised barrier: all of them, 150 times
+ * per PCApply).  PCDO_TEAM_GROUP sets the group size (default 16; 0 = the
+ * runtime's own barrier, kept for A/B). */
+#define T_MAX_GROUPS 64
+typedef struct { volatile int count, sense; char pad[56]; } t_node_t;
+static t_node_t t_grp_node[T_MAX_GROUPS] __attribute__((aligned(64)));
+static t_node_t t_top_node __attribute__((aligned(64)));
+static int t_grp = 16;
+static __thread int t_hsense = 0;
+static inline void t_full_barrier(void) {
+  const int nth = omp_get_num_threads();
+  if (t_grp <= 0 || nth <= t_grp || (nth + t_grp - 1) / t_grp > T_MAX_GROUPS) {
+    _Pragma("omp barrier")
+    return;
+  }
+  const int tid = omp_get_thread_num(), g = tid / t_grp, ng = (nth + t_grp - 1) / t_grp;
+  const int gsize = (g + 1) * t_grp <= nth ? t_grp : nth - g * t_grp;
+  t_hsense = !t_hsense;
+  if (__atomic_add_fetch(&t_grp_node[g].count, 1, __ATOMIC_ACQ_REL) == gsize) {
+    __atomic_store_n(&t_grp_node[g].count, 0, __ATOMIC_RELAXED);
+    if (__atomic_add_fetch(&t_top_node.count, 1, __ATOMIC_ACQ_REL) == ng) {
+      __atomic_store_n(&t_top_node.count, 0, __ATOMIC_RELAXED);
+      __atomic_store_n(&t_top_node.sense, t_hsense, __ATOMIC_RELEASE);
+    } else {
+      while (__atomic_load_n(&t_top_node.sense, __ATOMIC_ACQUIRE) != t_hsense) __builtin_ia32_pause();
+    }
+    __atomic_store_n(&t_grp_node[g].sense, t_hsense, __ATOMIC_RELEASE);
+  } else {
+    while (__atomic_load_n(&t_grp_node[g].sense, __ATOMIC_ACQUIRE) != t_hsense) __builtin_ia32_pause();
+  }
+}
+
 /* Every parallel region starts from a known barrier state: t_dirty / t_sense
  * live in the pool threads and would otherwise survive a region that ended on
  * a short loop (the next, larger team would then take t_sync()'s barrier with
@@ -918,12 +957,18 @@ static volatile int t_sb_count = 0, t_sb_sense = 0;
 static inline void t_region(void) {
   __atomic_store_n(&t_sb_count, 0, __ATOMIC_RELAXED);
   __atomic_store_n(&t_sb_sense, 0, __ATOMIC_RELEASE);
+  for (int g = 0; g < T_MAX_GROUPS; ++g) {
+    __atomic_store_n(&t_grp_node[g].count, 0, __ATOMIC_RELAXED);
+    __atomic_store_n(&t_grp_node[g].sense, 0, __ATOMIC_RELAXED);
+  }
+  __atomic_store_n(&t_top_node.count, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&t_top_node.sense, 0, __ATOMIC_RELEASE);
 }
-static inline void t_begin(void) { t_dirty = 0; t_sense = 0; }
+static inline void t_begin(void) { t_dirty = 0; t_sense = 0; t_hsense = 0; }
 
 static inline void t_sync(void) {
   if (t_dirty) {
-    _Pragma("omp barrier")
+    t_full_barrier();
     t_dirty = 0;
   }
 }
@@ -952,7 +997,7 @@ static inline int64_t t_hi(int64_t n) {
 static inline void t_end(int64_t n) {
   const int nth = omp_get_num_threads(), k = t_width(n);
   if (k == nth) {
-    _Pragma("omp barrier")
+    t_full_barrier();
   } else {
     if (omp_get_thread_num() < k) t_sub_barrier(k);
     t_dirty = 1;
@@ -1227,16 +1272,37 @@ static int team_slot(pcdo_t *h) {
 }
 
 /* first-touch copies of everything the apply streams; freezes the threads */
+static void t_free_csr(csr_t *m) {
+  free(m->rowptr); free(m->col); free(m->val); free(m->dinv);
+  memset(m, 0, sizeof *m);
+}
+static void t_free_team(team_t *T) {
+  for (int m = 0; m < MAT_COUNT; ++m) t_free_csr(&T->mat[m]);
+  for (int s = 0; s < SLOT_COUNT; ++s) {
+    for (int k = 0; k < 3; ++k) free(T->cw[s][k]);
+    team_mg_t *g = &T->mg[s];
+    for (int l = 0; l < MG_MAX_LEVELS; ++l) {
+      t_free_csr(&g->A[l]); t_free_csr(&g->P[l]); t_free_csr(&g->R[l]);
+      free(g->x[l]); free(g->t0[l]); free(g->t1[l]); free(g->r[l]); free(g->b[l]);
+    }
+  }
+  free(T->w0); free(T->w1); free(T->wu); free(T->xs); free(T->ys); free(T->perm);
+  free(T);
+}
+
 int pcdo_team_prepare(pcdo_t *h, int threads) {
   if (!h->ready || !h->mat[MAT_A00].set)
     return fail(4, "team_prepare: system/setup missing");
   if (threads < 1) threads = omp_get_max_threads();
   { const char *e = getenv("PCDO_TEAM_BIG"); if (e) t_big = atoi(e);
-    e = getenv("PCDO_TEAM_SUB"); if (e && atoi(e) > 0) t_sub = atoi(e); }
+    e = getenv("PCDO_TEAM_SUB"); if (e && atoi(e) > 0) t_sub = atoi(e);
+    e = getenv("PCDO_TEAM_GROUP"); if (e) t_grp = atoi(e); }
   int slot = team_slot(h);
   if (slot < 0) for (int i = 0; i < 64 && slot < 0; ++i) if (!g_team_owner[i]) slot = i;
   if (slot < 0) return fail(3, "team_prepare: too many engines");
-  /* (a re-prepare leaks the previous copies: timing tool, few calls) */
+  /* a re-prepare frees the previous team's copies (bench.py sweeps ten thread
+   * counts: at config 5's size every leaked team was ~12 GB - round 6) */
+  if (g_team_owner[slot] == h && g_team[slot]) { t_free_team(g_team[slot]); g_team[slot] = NULL; }
   team_t *T = (team_t *)calloc(1, sizeof *T);
   T->threads = threads;
   for (int m = 0; m < MAT_COUNT; ++m) t_copy_csr(&T->mat[m], &h->mat[m], threads);

@@ -265,14 +265,17 @@ def test_three_dimensional_producer_and_solver_chain():
     assert relerr(st["A"] @ x, st["b"]) < 1e-6
 
 
-@pytest.mark.parametrize("variant,mg,sub", [("BRM1", True, None),
-                                            ("BRM2", True, None),
-                                            ("RBRM1", False, None),
-                                            ("BRM1", False, None),
-                                            # short loops on a sub-team of two
-                                            ("BRM1", True, 2),
-                                            ("RBRM1", False, 2)])
-def test_team_timing_port_equals_the_serial_oracle(variant, mg, sub,
+@pytest.mark.parametrize("variant,mg,sub,group", [
+    ("BRM1", True, None, None), ("BRM2", True, None, None),
+    ("RBRM1", False, None, None), ("BRM1", False, None, None),
+    # short loops on a sub-team of two
+    ("BRM1", True, 2, None), ("RBRM1", False, 2, None),
+    # the NUMA-aware two-level barrier: groups of two threads (3 threads: a
+    # ragged last group; 4: two full ones), with and without a sub-team
+    ("BRM1", True, None, 2), ("BRM1", True, 2, 2), ("RBRM1", False, 2, 2),
+    # ... and the runtime's own barrier (group 0: the A/B switch)
+    ("BRM1", True, 2, 0)])
+def test_team_timing_port_equals_the_serial_oracle(variant, mg, sub, group,
                                                    monkeypatch):
     """bench.py's cpu_baseline times the OpenMP TEAM port (one parallel region
     per PCApply, first-touch placement, fused loops, short loops on a
@@ -288,6 +291,10 @@ def test_team_timing_port_equals_the_serial_oracle(variant, mg, sub,
     else:
         monkeypatch.setenv("PCDO_TEAM_SUB", "8")
         monkeypatch.setenv("PCDO_TEAM_BIG", "40000")
+    if group is None:
+        monkeypatch.delenv("PCDO_TEAM_GROUP", raising=False)
+    else:
+        monkeypatch.setenv("PCDO_TEAM_GROUP", str(group))
     st = flow_state("lshape", 3, dt=0.2 if variant.startswith("R") else None)
     pb, V, L = st["pb"], st["V"], st["L"]
     par, _ = oracle.omp_engine(variant)
@@ -307,7 +314,7 @@ def test_team_timing_port_equals_the_serial_oracle(variant, mg, sub,
         eng.setup()
     x = np.random.default_rng(3).standard_normal(V.ndof)
     ref = ser.fieldsplit_apply_np(x)
-    for threads in (1, 3, 4):
+    for threads in (1, 3, 4) + ((6, 8, 5) if group else ()):
         par.team_prepare(threads)
         y = np.empty_like(x)
         par.team_fieldsplit_apply(x, y)
@@ -326,6 +333,7 @@ def test_team_barrier_state_does_not_survive_a_region(monkeypatch):
     from helpers import push_multigrid
     monkeypatch.setenv("PCDO_TEAM_SUB", "2")
     monkeypatch.setenv("PCDO_TEAM_BIG", str(10 ** 9))
+    monkeypatch.setenv("PCDO_TEAM_GROUP", "2")       # (two-level full barrier)
     st = flow_state("lshape", 2)
     pb, V, L = st["pb"], st["V"], st["L"]
     par, _ = oracle.omp_engine("BRM1")
