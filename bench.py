@@ -803,6 +803,10 @@ def picard_step_times(pb, w, nls, ksp, c):
                  "refresh_bytes_held_by_level_rank0": prod.refresh_bytes,
                  "wire_doubles_by_level": prod.wire_doubles,
                  "plan_cells_and_entries_rank0": prod.plan_entries[-1]}
+    extra["plan_seconds_by_phase"] = {
+        k: round(v, 2) for k, v in getattr(prod, "init_timing", {}).items()}
+    extra["refresh_bytes_held"] = int(sum(prod.refresh_bytes))
+    extra["galerkin"] = getattr(prod, "galerkin_mode", None)
     return {"device_producer_seconds": dt, "gmres_its": its_hist,
             "plan_seconds": t_plan, **extra,
             "host_producer_seconds_incl_setup": HOST_STEP_SECONDS.get("value"),

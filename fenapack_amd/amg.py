@@ -228,17 +228,53 @@ def block_graph_operator(A, block):
     return G
 
 
+def diagonal_block_mean(A, block):
+    """Scalar operator on the nodes of a COUPLED block matrix: the mean of its
+    ``block`` diagonal blocks ``A[i::block, i::block]``.  For the Newton
+    velocity block ``F (x) I_d + N(w)`` that is ``F + (1/d) sum_i N_ii`` - the
+    Picard stencil plus ``(div w / d)`` times a mass-like term."""
+    A = sp.csr_matrix(A)
+    F = None
+    for i in range(block):
+        B = sp.csr_matrix(A[i::block, i::block])
+        F = B if F is None else F + B
+    F = sp.csr_matrix(F * (1.0 / block))
+    F.sort_indices()
+    return F
+
+
 def smoothed_aggregation_chain(A, block=1, coarse_rows=2000, max_levels=12,
-                               theta=0.02, min_ratio=1.5, distance=2):
+                               theta=0.02, min_ratio=1.5, distance=2,
+                               coupled="scalar"):
     """Prolongation chain ``[None, P_1, ..., P_L]`` for the finest operator
     ``A`` (``P_l`` maps level ``l-1`` to ``l``; the format
     ``PC.setMGInterpolations`` takes).  Coarsening stops at ``coarse_rows``
-    rows (explicit inverse there) or when it stalls."""
+    rows (explicit inverse there) or when it stalls.
+
+    ``coupled`` - what a COUPLED block operator (the Newton velocity block)
+    is coarsened with: ``"scalar"`` (default) aggregates and smooths on the
+    mean of its diagonal blocks - the scalar stencil, as for the Picard block -
+    and prolongates every component alike, ``P = P_s (x) I_d``: the form the
+    device producer refreshes (``P^T (F (x) I + N) P`` block by block with the
+    one scalar ``P_s``); ``"block"`` aggregates on the block-norm graph and
+    smooths with the coupled operator itself (a general ``P``; host refresh
+    only)."""
     A = sp.csr_matrix(A)
     Ps = []
     cur = A
     curF = scalar_stencil(cur, block) if block > 1 else None
+    if coupled not in ("scalar", "block"):
+        raise ValueError("smoothed_aggregation_chain: coupled = %r" % (coupled,))
     while cur.shape[0] > coarse_rows and len(Ps) < max_levels - 1:
+        if block > 1 and curF is None and coupled == "scalar":
+            Fd = diagonal_block_mean(cur, block)
+            Pf = sa_prolongator(Fd, theta, seed=len(Ps), distance=distance)
+            if Pf.shape[1] * min_ratio > Pf.shape[0]:
+                break                              # coarsening stalled
+            P = _host.kron_expand(Pf, block)
+            Ps.append(P)
+            cur = _galerkin(cur, P)
+            continue
         if block == 1 or curF is not None:
             # scalar operator, or F (x) I_d: everything on the scalar factor,
             # expanded (with its factor attached) for the hand-over

@@ -184,6 +184,12 @@ static void launch_spmv_kron_nc(Engine* h, const DCsr& A, const double* x,
   }
   if (A.vt) {
     const int gt = grid_stream(vb.n, 1);
+    // (ROWS = 16: operators with long rows, 16 lanes per row - build_vec_tile)
+    if (A.vt_rows == 16)
+      hipLaunchKernelGGL((k_spmv_tc<MODE, NC, 16>), dim3(gt), dim3(kBlock), 0, h->stream,
+                         vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,
+                         A.vt_loc.p, x, ghost, nloc, add, y);
+    else
     hipLaunchKernelGGL((k_spmv_tc<MODE, NC, 64>), dim3(gt), dim3(kBlock), 0, h->stream,
                        vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,
                        A.vt_loc.p, x, ghost, nloc, add, y);
@@ -626,11 +632,12 @@ int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
     if (!vb.n) return;
     const int gt = grid_stream(vb.n, 1);
     const int nloc = (int)(A.ncols / A.kron);
-#define PCD_CHEB_TC(NC)                                                                        \
-    hipLaunchKernelGGL((k_cheb_step_tc<NC, 64>), dim3(gt), dim3(kBlock), 0, h->stream,        \
+#define PCD_CHEB_TC(NC, RW)                                                                    \
+    hipLaunchKernelGGL((k_cheb_step_tc<NC, RW>), dim3(gt), dim3(kBlock), 0, h->stream,        \
                        vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,       \
                        A.vt_loc.p, dinv, b, pm, pk, pn, c0, c1, c2, A.ghost.p, nloc)
-    if (A.kron == 2) PCD_CHEB_TC(2); else PCD_CHEB_TC(3);
+    if (A.vt_rows == 16) { if (A.kron == 2) PCD_CHEB_TC(2, 16); else PCD_CHEB_TC(3, 16); }
+    else if (A.kron == 2) PCD_CHEB_TC(2, 64); else PCD_CHEB_TC(3, 64);
 #undef PCD_CHEB_TC
   } else if (dinv && A.rb2 && kron_ok(A, b, pm, pk, pn, true)) {
     const int nn = n / A.kron;
@@ -689,12 +696,13 @@ int launch_cheb_first(Engine* h, const DCsr& A, const double* dinv,
     const VtBlocks vb = vt_blocks_now(h, A);
     if (!vb.n) return;
     const int gt = grid_stream(vb.n, 1);
-#define PCD_FIRST_TC(NC)                                                                       \
-    hipLaunchKernelGGL((k_cheb_first_tc<NC, 64>), dim3(gt), dim3(kBlock), 0, h->stream,       \
+#define PCD_FIRST_TC(NC, RW)                                                                   \
+    hipLaunchKernelGGL((k_cheb_first_tc<NC, RW>), dim3(gt), dim3(kBlock), 0, h->stream,       \
                        vb.n, vb.list, A.vt_desc.p, A.vt_rowoff.p, A.vt_tsrc.p, A.val2.p,       \
                        A.vt_loc.p, dinv, b, p0, pn, s, c1, c2, ghost, (int)(A.ncols / A.kron), \
                        A.dghost.p ? A.dghost.p : dinv)
-    if (A.kron == 2) PCD_FIRST_TC(2); else PCD_FIRST_TC(3);
+    if (A.vt_rows == 16) { if (A.kron == 2) PCD_FIRST_TC(2, 16); else PCD_FIRST_TC(3, 16); }
+    else if (A.kron == 2) PCD_FIRST_TC(2, 64); else PCD_FIRST_TC(3, 64);
 #undef PCD_FIRST_TC
   } else if (A.rb2 && kron_ok(A, b, p0, pn, nullptr, true)) {
     const int nn = n / A.kron;

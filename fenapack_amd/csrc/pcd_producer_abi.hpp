@@ -432,9 +432,9 @@ int pcd_fe_begin(pcd_handle h, int dim, int nlevels, int nq, const double* qw,
   if (dim != 2 && dim != 3) return fail(PCD_ERR_ARG, "fe_begin: dim must be 2 or 3");
   // the producer's plans address operator entries in the numbering its caller
   // handed over: it works on engines that kept that numbering
-  if (h->sys_local)
-    return fail(PCD_ERR_STATE, "fe_begin: the system was handed over rank-locally (pcd_set_system_local); the "
-                               "device producer addresses entries of the global value array");
+  // (a rank-local hand-over - pcd_set_system_local - goes with plans whose
+  // positions address THIS RANK'S value arrays: pcd_fe_bind_system checks every
+  // position against the values the engine holds; device_producer_rows.py)
   if (h->ru.active() || h->rp.active())
     return fail(PCD_ERR_STATE, "fe_begin: the engine renumbered the dofs at pcd_set_system (the "
                                "caller's numbering was not local); the device producer needs "

@@ -99,20 +99,25 @@ int build_vec_tile(Engine* h, DCsr& A, int nc, int64_t nn, int64_t nloc,
   // operators streamed from HBM: lane-major entries, straight to registers
   // (the form is fixed with the layout)
   A.vt_lm = A.nt2 && g_vt_nt;
-  // ... and operators with LONG rows (the coarse levels of an algebraic
-  // hierarchy: ~180 entries per node row on config 5's first level).  The
-  // direct form gives a row 256 / 64 = 4 lanes whatever the block holds, and a
-  // block of such rows is cut by its tile nodes after 8-16 rows: 32-64 of the
-  // 256 lanes work (N = 73, first coarse level, counter pass of round 6: 112 MB
-  // in 58-78 us = 0.18-0.25 of the HBM peak); the lane-major form deals a
-  // block's entries out evenly, 8 per lane.  PCD_LM_ROW_ENTRIES: mean entries
-  // per node row from which the form is lane-major (default 64; 0: never).
-  {
-    const char* e = getenv("PCD_LM_ROW_ENTRIES");
+  // Operators with LONG rows (the coarse levels of an algebraic hierarchy: ~180
+  // entries per node row on config 5's first level).  The direct form gives a
+  // row 256 / ROWS lanes whatever the block holds, and a block of such rows is
+  // cut by its tile nodes after 8-16 rows: with ROWS = 64 only 32-64 of the
+  // 256 lanes work (N = 73, first coarse level, counter pass of round 6:
+  // 112 MB in 58-78 us = 0.18-0.25 of the HBM peak).  Such operators take
+  // blocks of <= 16 rows, 16 lanes each (the ROWS = 16 instantiation of the
+  // same kernels).  PCD_VT_LONG_ROW: mean entries per node row from which
+  // (default 64; 0: never).  (The lane-major form was tried for them first:
+  // its 512 tile nodes do not hold every single row of such a level, and an
+  // operator whose tiles cannot be built falls to the scalar kernels - 3 x
+  // the bytes: 2.24 -> 2.40 ms per PCApply, profiles/r06_c_*.)
+  int long_rows16 = 0;
+  if (!A.vt_lm) {
+    const char* e = getenv("PCD_VT_LONG_ROW");
     const long long thr = e ? atoll(e) : 64;
-    if (g_vt_nt && thr > 0 && nn > 0 && (long long)(rpc[nn] / nn) >= thr) A.vt_lm = true;
+    if (thr > 0 && nn > 0 && (long long)(rpc[nn] / nn) >= thr) long_rows16 = 1;
   }
-  const int kVtRows = A.vt_lm ? lm_rows(nc) : 64;
+  const int kVtRows = A.vt_lm ? lm_rows(nc) : (long_rows16 ? 16 : 64);
   const int kEntries = A.vt_lm ? kLmEntries : INT32_MAX;       // (direct form: no entry buffer)
   const int kNodes = A.vt_lm ? lm_nodes(nc) : kVtNodes;
   const int kVtRowOff = vt_rowoff(kVtRows);

@@ -229,10 +229,20 @@ class DeviceProducer(object):
         # (demo_navier-stokes-pcd.py:153-160) happens in HBM.
         self.algebraic = bool(ksp0.pc.mg_algebraic)
         if self.algebraic and self.newton:
-            raise ValueError("device producer: the algebraic hierarchy "
-                             "aggregates the scalar stencil F of the Picard "
-                             "block F (x) I_d; --nls newton needs the "
-                             "nested-mesh hierarchy")
+            # --nls newton on an algebraic hierarchy (the reference's bench
+            # sweeps nls x ls: test/bench/test_pcd_scaling.py:194-223): the
+            # chain must prolongate every component alike, P = P_s (x) I_d
+            # (amg.smoothed_aggregation_chain coupled="scalar": aggregates of
+            # the mean diagonal block) - then P^T (F (x) I + N) P is the scalar
+            # triple product of every block, as on nested meshes
+            from .petsc import _scalar_of
+            for P in ksp0.pc.mg_data["chain"][1:]:
+                f = _scalar_of(P)
+                if f is None or f[1] != V.dim:
+                    raise ValueError(
+                        "device producer: --nls newton on an algebraic "
+                        "hierarchy needs -fieldsplit_u_pc_gamg_coupled scalar "
+                        "(P = P_s (x) I_d)")
         # (several ranks with the GLOBAL hand-over: the aggregation runs on
         # every rank alike - amg.smoothed_aggregation_chain is deterministic -
         # so the prolongators and the coarse patterns are replicated like the
@@ -282,6 +292,14 @@ class DeviceProducer(object):
                 self.levels.append(pb._coarse_problems[lh])
         dphi = self._dphi(V)
         qw = V.wq[0] / V.area[0]
+        # seconds of this set-up by phase (bench.py's picard_step reports it)
+        self.init_timing = {}
+        _t = [time.perf_counter()]
+
+        def lap(what):
+            now = time.perf_counter()
+            self.init_timing[what] = self.init_timing.get(what, 0.0) + now - _t[0]
+            _t[0] = now
         eng.fe_begin(d, nlev, qw, V.phi, dphi, V.psi)
         chain = pb.interpolations().velocity \
             if nlev > 1 and not self.algebraic else None
@@ -291,14 +309,18 @@ class DeviceProducer(object):
             lh = top_h - (nlev - 1) + l
             if l == nlev - 1:
                 self._set_level(l, pl, None)
+                lap("finest level: contribution lists, constants")
             elif self.algebraic:
                 # (mg_data["chain"][l + 1]: level l -> l + 1 of the hierarchy
                 # the engine holds, after the choice of the coarsest level)
                 self._set_level_galerkin(l, ksp0.pc.mg_data["chain"][l + 1])
+                lap("Galerkin levels: symbolic products, hand-over")
             elif self.galerkin:
                 self._set_level_galerkin(l, chain[lh + 1])
+                lap("Galerkin levels: symbolic products, hand-over")
             else:
                 self._set_level(l, pl, injection_map(chain[lh + 1], d))
+                lap("re-discretised coarse levels")
         if self.newton:
             self._set_newton(ksp0)
         if self.ranks:
@@ -312,8 +334,11 @@ class DeviceProducer(object):
                     eng.fe_bind_pattern(l, indptr[a0:a1 + 1], indices[e0:e1])
                 else:
                     eng.fe_bind_pattern(l, indptr, indices)
+        lap("newton positions / patterns of the ranks")
         self._bind_system()
+        lap("positions in the system values")
         self._bind_kp(ksp1)
+        lap("Kp plan")
         a, b, cc, dd = ksp0.pc.mg_esteig
         eng.fe_bind_mg(c.KSP_A00, b, dd, 12)
         # the coarsest level's dense inverse: on the device as well, unless
@@ -349,6 +374,7 @@ class DeviceProducer(object):
             eng.fe_bind_residual(sp.csr_matrix(pb._A01_raw),
                                  sp.csr_matrix(pb._A10_raw), pb.bc_u_idx,
                                  pb._bc_mult[pb.bc_u_idx], mass, pb.idt)
+        lap("coarse inverse, residual blocks")
         # constant host pieces of the residual
         self._bc_idx = pb.bc_u_idx
         self.timing = {"update": 0.0, "coarse_inverse": 0.0, "host": 0.0}

@@ -334,6 +334,10 @@ class PC(object):
         # per pattern and kept while values change
         self.mg_algebraic = False
         self.mg_gamg_threshold = 0.02
+        # a coupled (Newton) velocity block: "scalar" = aggregate the mean of
+        # its diagonal blocks, P = P_s (x) I_d (what the device producer
+        # refreshes); "block" = block-norm graph, general P (amg.py)
+        self.mg_gamg_coupled = "scalar"
 
     def setMGOperators(self, callback):
         """``callback(nlev)`` -> operators of the ``nlev - 1`` coarse levels,
@@ -500,6 +504,8 @@ class KSP(object):
         th = o.getReal("pc_gamg_threshold")
         if th is not None:
             self.pc.mg_gamg_threshold = th
+        self.pc.mg_gamg_coupled = o.getString("pc_gamg_coupled",
+                                              self.pc.mg_gamg_coupled)
         self.pc.mg_levels = o.getInt("pc_mg_levels", self.pc.mg_levels)
         self.pc.mg_coarse_eq_limit = o.getInt("pc_mg_coarse_eq_limit",
                                               self.pc.mg_coarse_eq_limit)
@@ -598,7 +604,8 @@ class KSP(object):
                 pc.setMGInterpolations(smoothed_aggregation_chain(
                     self._ops[1].A, block=blk,
                     coarse_rows=pc.mg_coarse_eq_limit,
-                    theta=pc.mg_gamg_threshold))
+                    theta=pc.mg_gamg_threshold,
+                    coupled=pc.mg_gamg_coupled))
         if pc._mg_chain is None:
             raise RuntimeError("%spc_type mg needs interpolations "
                                "(pc.setMGInterpolations)" % self._prefix)

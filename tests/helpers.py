@@ -117,3 +117,63 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+# ---- config 5's own mesh: the two child processes of the suite ----------------
+_N73 = {}
+
+
+def n73_children():
+    """The suite's two runs on config 5's own mesh (cube N = 73, 9 934 793 DOF)
+    - the one-GPU parity run (tools/parity_large.py) and the 8-thread-rank run
+    (tools/steady_thread_ranks.py) - are processes of their own (tens of GB of
+    host memory each, under the scripts' own watchdog).  They are started
+    TOGETHER by whichever test asks first and run side by side: 54 s + 66 s one
+    after the other (round 5), about the longer one's time together.  Returns
+    ``{"one_gpu": rec, "ranks8": rec}`` with ``rec = {"proc", "out", "err",
+    "t0"}``; :func:`n73_result` waits for one of them."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import time
+    if _N73:
+        return _N73
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("FENAPACK_AMD_NO_WATCHDOG", "PCD_REPLICATE_BELOW"):
+        env.pop(k, None)
+    env["FENAPACK_AMD_WATCHDOG"] = "1"
+    # (both builds thread their host work: share the cores)
+    half = str(max(4, (os.cpu_count() or 8) // 2))
+    env.setdefault("FENAPACK_AMD_HOST_THREADS", half)
+    cmds = {
+        "one_gpu": ([sys.executable, os.path.join(root, "tools", "parity_large.py"),
+                     "--geometry", "cube", "--level", "0", "--n0", "73",
+                     "--algebraic"], {}),
+        "ranks8": ([sys.executable,
+                    os.path.join(root, "tools", "steady_thread_ranks.py"),
+                    "--partitioned", "--algebraic", "--n0=73", "cube", "0", "8"],
+                   {"FENAPACK_AMD_LOCAL_HANDOVER": "1"}),
+    }
+    for name, (cmd, extra) in cmds.items():
+        out = tempfile.TemporaryFile(mode="w+")
+        err = tempfile.TemporaryFile(mode="w+")
+        proc = subprocess.Popen(cmd, cwd=root, env=dict(env, **extra),
+                                stdout=out, stderr=err, text=True)
+        _N73[name] = {"proc": proc, "out": out, "err": err, "t0": time.time()}
+    return _N73
+
+
+def n73_result(name, timeout=1100):
+    """(returncode, stdout, stderr) of one of :func:`n73_children`."""
+    import subprocess
+    rec = n73_children()[name]
+    try:
+        rc = rec["proc"].wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        rec["proc"].kill()
+        rc = -9
+    rec["out"].seek(0)
+    rec["err"].seek(0)
+    return rc, rec["out"].read(), rec["err"].read()

@@ -26,7 +26,12 @@ import torch                                                  # noqa: E402
 import torch.distributed as dist                              # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)                                      # the ONE GPU
+# the ONE GPU - or, from tools/first_contact.py on a box with several
+# (PCD_KIT_ONE_GPU_PER_RANK=1), a device per rank: the same arenas, mapped
+# across devices
+DEV = int(os.environ.get("LOCAL_RANK", "0")) \
+    if os.environ.get("PCD_KIT_ONE_GPU_PER_RANK") == "1" else 0
+torch.cuda.set_device(DEV)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 dist.init_process_group("gloo")
 
@@ -43,7 +48,7 @@ comm.host = pt.TorchHostComm()
 PETScOptions.clear()
 multigrid_inner_options(dim=2, galerkin_u=False)
 pp = pt.partitioned(Cavity, rank, world, host=comm.host, level=a.level, nu=0.01)
-out = solve_steady(pp, max_newton=3, newton_rtol=0.0, comm=comm)
+out = solve_steady(pp, max_newton=3, newton_rtol=0.0, comm=comm, device=DEV)
 ksp = out["solver"].linear_solver().ksp()
 eng = ksp.engine
 res = {"its": np.array(out["krylov_per_step"]), "x": out["w"].vector().copy(),
@@ -73,7 +78,7 @@ t_eager = (time.perf_counter() - t0) / 50
 # [u_loc; p_loc]): what bench.py times; kernel launches per PCApply
 from fenapack_amd.petsc import Vec                            # noqa: E402
 nl = int(eng.info(c.INFO_N_U_LOCAL)) + int(eng.info(c.INFO_N_P_LOCAL))
-xd = Vec(xg[:nl].copy(), device="cuda:0")
+xd = Vec(xg[:nl].copy(), device="cuda:%d" % DEV)
 yd = xd.duplicate()
 
 

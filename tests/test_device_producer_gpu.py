@@ -657,3 +657,44 @@ def test_galerkin_levels_by_the_numeric_sparse_product(hip_lib, kind, group,
     assert got["product"][2] == 0 and got["plans"][2] > 0
     # patterns and P instead of 12 B per term of both products
     assert got["product"][1] < 0.5 * got["plans"][1], got
+
+
+def test_newton_on_an_algebraic_hierarchy(hip_lib):
+    """--nls newton through -pc_type gamg with the refresh on the device (the
+    reference's bench sweeps nls in {picard, newton} x ls in {direct,
+    iterative}: test/bench/test_pcd_scaling.py:194-223).  The chain prolongates
+    every component alike (P = P_s (x) I_d, aggregates of the scalar stencil),
+    so the coupled block's coarse operators P^T (F (x) I + N) P are the scalar
+    products of every block (k_spgemm_fixed, d*d + 1 of them per level):
+    operators of every level against the host's products at 1e-12, the Newton
+    loop against the host-driven one."""
+    import scipy.sparse.linalg as spla
+    from fenapack_amd.driver import solve_steady
+    from fenapack_amd.fem.multigrid import galerkin_chain
+    pb = Cavity3D(1, nu=0.02, n0=6, nls="newton")            # cube N = 12
+    V = pb.space
+    _gamg_options(3, coarse_limit=60)
+    out = solve_steady_device(pb, max_newton=4)
+    prod = out["producer"]
+    assert prod.algebraic and prod.newton and prod.device_loop
+    assert prod.nlev >= 3 and prod.galerkin_mode == "product"
+    rng = np.random.default_rng(3)
+    xu, xp = rng.standard_normal(V.n_u), rng.standard_normal(V.n_p)
+    b = prod.update(xu, xp)
+    lin = pb.linearise(xu, xp)
+    assert relerr(b, V.to_mixed(lin["bu"], lin["bp"])) < 1e-12
+    ksp0 = out["solver"].linear_solver().ksp().pc.getFieldSplitSubKSP()[0]
+    coarse = galerkin_chain(lin["A00"], ksp0.pc.mg_data["chain"])[:-1]
+    assert len(coarse) == prod.nlev - 1
+    for l, ref in enumerate(coarse):
+        got = prod.level_matrix(l)
+        assert spla.norm(got - ref.tocsr()) < 1e-12 * spla.norm(ref), l
+    _gamg_options(3, coarse_limit=60)
+    host = solve_steady(Cavity3D(1, nu=0.02, n0=6, nls="newton"), max_newton=4)
+    PETScOptions.clear()
+    assert out["converged"] == host["converged"]
+    assert len(out["krylov_per_step"]) == len(host["krylov_per_step"])
+    assert all(abs(a - b) <= 1 for a, b in zip(out["krylov_per_step"],
+                                               host["krylov_per_step"])), (
+        out["krylov_per_step"], host["krylov_per_step"])
+    assert relerr(out["w"].vector(), host["w"].vector()) < 1e-6
