@@ -249,6 +249,36 @@ def spgemm(A, B, row0=0, row1=None):
     return C
 
 
+def locate(M, rows, cols):
+    """Positions (in ``M.data`` order) of the entries ``(rows[q], cols[q])``
+    of the scipy CSR matrix ``M`` (columns sorted in every row)."""
+    import scipy.sparse as sp
+    M = sp.csr_matrix(M)
+    if not M.has_sorted_indices:
+        raise ValueError("locate: the matrix's indices must be sorted")
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    if use_numpy():
+        ip = M.indptr.astype(np.int64)
+        key = np.repeat(np.arange(M.shape[0], dtype=np.int64),
+                        np.diff(ip)) * M.shape[1] + M.indices
+        q = rows * M.shape[1] + cols
+        pos = np.searchsorted(key, q)
+        if pos.max(initial=0) >= key.size or np.any(key[pos] != q):
+            raise HostError("locate: an entry is not in the pattern")
+        return pos
+    rp = np.ascontiguousarray(M.indptr, dtype=np.int64)
+    ci = _i32(M.indices)
+    pos = np.empty(rows.size, dtype=np.int64)
+    L = library()
+    L.pcdh_locate.argtypes = [ctypes.c_int64, _I64P, _I64P, ctypes.c_int64,
+                              _I64P, _I32P, _I64P]
+    _chk(L.pcdh_locate(rows.size, _p(rows, _I64P), _p(cols, _I64P),
+                       M.shape[0], _p(rp, _I64P), _p(ci, _I32P),
+                       _p(pos, _I64P)))
+    return pos
+
+
 def product_pattern(a_indptr, a_indices, b_indptr, b_indices, b_cols):
     """STRUCTURAL pattern of ``A @ B`` from the two patterns alone (the
     symbolic phase of the device's numeric product, ``pcd_fe_set_level_product``):

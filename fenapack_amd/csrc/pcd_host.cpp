@@ -707,6 +707,29 @@ int pcdh_union_fill(int64_t n, int nb, const int64_t* nr, const int32_t* const* 
   return 0;
 } PCDH_ABI_CATCH(pcdh_union_fill)
 
+// ------------------------------------------------------- positions of entries
+// pos[q] = position of entry (qrow[q], qcol[q]) in the CSR (rowptr, col) whose
+// columns are sorted in every row; PCDH_ERR_ARG when one is missing.
+int pcdh_locate(int64_t nq, const int64_t* qrow, const int64_t* qcol, int64_t nrows,
+                const int64_t* rowptr, const int32_t* col, int64_t* pos) try {
+  if (nq < 0 || nrows < 0 || !rowptr || (nq && (!qrow || !qcol || !pos)) || (rowptr[nrows] && !col))
+    return fail(PCDH_ERR_ARG, "locate: bad arguments");
+  const int T = nthreads(nq * 4);
+  int bad = 0;
+#pragma omp parallel for schedule(static, 8192) num_threads(T) reduction(| : bad)
+  for (int64_t q = 0; q < nq; ++q) {
+    const int64_t r = qrow[q];
+    if (r < 0 || r >= nrows) { bad |= 1; pos[q] = -1; continue; }
+    const int32_t* b = col + rowptr[r];
+    const int32_t* e = col + rowptr[r + 1];
+    const int32_t* p = std::lower_bound(b, e, (int32_t)qcol[q]);
+    if (p == e || *p != qcol[q] || qcol[q] > INT32_MAX) { bad |= 1; pos[q] = -1; continue; }
+    pos[q] = (int64_t)(p - col);
+  }
+  if (bad) return fail(PCDH_ERR_ARG, "locate: an entry is not in the pattern");
+  return 0;
+} PCDH_ABI_CATCH(pcdh_locate)
+
 // ------------------------------------------------- distance-2 independent set
 int pcdh_mis2_degrees(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t* deg) try {
   if (n < 0 || !rowptr || (rowptr[n] && !col) || (n && !deg))

@@ -553,26 +553,32 @@ class DeviceProducer(object):
             eng.fe_set_newton(l, block_positions(K, indptr, indices, d))
 
     def _bind_system(self):
+        # Where entry (k, component[s]) of the finest scalar F sits in the
+        # values of the monolithic matrix the engine was handed: a bisection
+        # per entry in that matrix's own rows (libpcd_host pcdh_locate).
+        # (Rounds 3-5 went through the inverse of the assembly permutation -
+        # an argsort of config 5's 1.1e9 entries: 10.6 of the 14.3 s of this
+        # set-up, and 9 GB of host memory per index array.)
+        from . import _host
         V, d = self.V, self.V.dim
         patS = V._patterns(False)["SS"]
-        patA = V._patterns(self.newton)["A00"]
-        lin_nnz = (patA.nnz, V._patterns(False)["A01"].nnz,
-                   V._patterns(False)["A10"].nnz)
-        mono = getattr(V, "_mono_%d_%d_%d" % lin_nnz)
-        rows, cols = patS.rows.astype(np.int64), patS.indices.astype(np.int64)
+        M = self.ksp.getOperators()[0].A
+        cut = self._cut[self.nlev - 1]
+        e0, e1 = (cut[2], cut[3]) if cut is not None else (0, patS.nnz)
+        rows = patS.rows[e0:e1].astype(np.int64)
+        cols = patS.indices[e0:e1].astype(np.int64)
+        is_u = np.asarray(V.is_u, dtype=np.int64)
         if self.newton:
-            pos = np.empty((d * d, patS.nnz), dtype=np.int64)
+            pos = np.empty((d * d, e1 - e0), dtype=np.int64)
             for i in range(d):
                 for j in range(d):
-                    pos[i * d + j] = mono.inv[patA.locate(d * rows + i,
-                                                          d * cols + j)]
+                    pos[i * d + j] = _host.locate(M, is_u[d * rows + i],
+                                                  is_u[d * cols + j])
         else:
-            pos = np.empty((d, patS.nnz), dtype=np.int64)
+            pos = np.empty((d, e1 - e0), dtype=np.int64)
             for k in range(d):
-                pos[k] = mono.inv[patA.locate(d * rows + k, d * cols + k)]
-        cut = self._cut[self.nlev - 1]
-        if cut is not None:
-            pos = np.ascontiguousarray(pos[:, cut[2]:cut[3]])
+                pos[k] = _host.locate(M, is_u[d * rows + k],
+                                      is_u[d * cols + k])
         self.eng.fe_bind_system(pos)
 
     def _bind_kp(self, ksp1):

@@ -377,8 +377,7 @@ class PartitionedDeviceProducer(DeviceProducer):
             target = is_u[d * g_cols + k]
             # per row: its (sorted) columns in the monolithic matrix
             lo = ip[rows[lrow]]
-            hi = ip[rows[lrow] + 1]
-            p = _search_rows(M.indices, lo, hi, target)
+            p = _host.locate(M, rows[lrow], target)
             pos[k] = start[lrow] + (p - lo)
         self.eng.fe_bind_system(pos)
 
@@ -442,25 +441,3 @@ class PartitionedDeviceProducer(DeviceProducer):
         raise NotImplementedError(
             "partitioned device producer: the residual is evaluated on the "
             "device (residual() / pcd_fe_picard_solve)")
-
-
-def _search_rows(indices, lo, hi, target):
-    """For every query ``i``: the position ``p`` in ``[lo[i], hi[i])`` with
-    ``indices[p] == target[i]`` (the rows' columns are sorted) - a bisection
-    carried for all queries at once."""
-    lo = lo.astype(np.int64).copy()
-    hi = hi.astype(np.int64).copy()
-    left, right = lo.copy(), hi - 1
-    while True:
-        act = left < right
-        if not act.any():
-            break
-        mid = (left + right) >> 1
-        less = indices[np.where(act, mid, left)] < target
-        go = act & less
-        left = np.where(go, mid + 1, left)
-        right = np.where(act & ~less, mid, right)
-    if not np.array_equal(indices[left], target):
-        raise ValueError("partitioned device producer: an entry of the plan "
-                         "is not in the system matrix")
-    return left

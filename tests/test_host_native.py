@@ -387,3 +387,31 @@ def test_aggregation_equals_the_explicit_graph_route(make, monkeypatch):
     with pytest.raises(H.HostError):
         H.library()  # (loaded) - bad arguments are refused, not read
         H._chk(H.library().pcdh_mis2(3, None, None, None, None, None))
+
+
+def test_locate_entries_in_a_sorted_csr(monkeypatch):
+    """pcdh_locate: positions of (row, col) queries in a CSR with sorted
+    columns - the device producer's "where does entry k of the velocity block
+    sit in the system values" - against the numpy route (searchsorted on
+    global keys); a missing entry is refused, not guessed."""
+    rng = np.random.default_rng(3)
+    M = sp.random(5000, 4000, density=0.004, format="csr", random_state=1)
+    M.sort_indices()
+    coo = M.tocoo()                                  # (CSR order kept)
+    pick = rng.permutation(M.nnz)[:20000]
+    pos = H.locate(M, coo.row[pick], coo.col[pick])
+    assert np.array_equal(pos, pick)
+    monkeypatch.setenv("FENAPACK_AMD_NUMPY_PRODUCER", "1")
+    assert np.array_equal(H.locate(M, coo.row[pick], coo.col[pick]), pick)
+    monkeypatch.delenv("FENAPACK_AMD_NUMPY_PRODUCER")
+    empty_row = int(np.nonzero(np.diff(M.indptr) == 0)[0][0]) \
+        if (np.diff(M.indptr) == 0).any() else None
+    with pytest.raises(H.HostError):
+        H.locate(M, [0], [int(M[0].indices[-1]) + 1 if M[0].nnz and
+                          M[0].indices[-1] + 1 < 4000 and
+                          M[0, M[0].indices[-1] + 1] == 0 else 3999])
+    if empty_row is not None:
+        with pytest.raises(H.HostError):
+            H.locate(M, [empty_row], [0])
+    with pytest.raises(H.HostError):
+        H.locate(M, [5000], [0])                     # row outside the matrix

@@ -89,7 +89,8 @@ def test_operators_of_the_rank_local_producer_equal_the_host_refresh(
     runs = on_thread_ranks(R, body)
     PETScOptions.clear()
     r0 = runs[0]
-    assert r0["levels"] >= 3
+    # (limit 60000 at this size: the one coarse level is the gathered one)
+    assert r0["levels"] >= (3 if limit == 1500 else 2)
     assert r0["npart"] == (2 if limit == 1500 else 1), r0
     if limit == 1500:
         # a partitioned coarse level exists, and something crosses the wire
