@@ -716,7 +716,10 @@ def main():
             }
         except Exception as exc:                   # never lose the bench line
             out["comm"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-    if world > 1 and not partitioned and not args.no_cpu_baseline:
+    # (a partitioned producer: the rows are gathered on rank 0 for the checker
+    # - at sizes where one host holds the whole problem next to the slabs)
+    if world > 1 and not args.no_cpu_baseline and (
+            not partitioned or V.ndof <= 4000000):
         # parity of THIS partitioned run at full size, on the line: one
         # PCApply of the global vector through the ranks (host-pointer call:
         # collective, every rank gets the whole result) against the oracle's
@@ -1029,11 +1032,19 @@ def ranks_parity(pb, ksp, eng, xg, rank):
     apply of the same workload and inner settings, on rank 0."""
     yg = np.empty_like(xg)
     eng.fieldsplit_apply(xg, yg)                     # all ranks
-    if rank != 0:
-        return None
     import oracle
-    serial = oracle.Engine(pb.variant)
-    oracle.mirror(serial, pb, ksp)
+    if getattr(pb, "partitioned", False):
+        # every rank holds its rows only: put them back together on rank 0
+        # (collective; oracle.mirror_partitioned)
+        serial = oracle.Engine(pb.variant) if rank == 0 else None
+        oracle.mirror_partitioned(serial, pb, ksp)
+        if rank != 0:
+            return None
+    else:
+        if rank != 0:
+            return None
+        serial = oracle.Engine(pb.variant)
+        oracle.mirror(serial, pb, ksp)
     yh = np.empty_like(xg)
     serial.fieldsplit_apply(xg, yh)
     return {"hip_ranks_vs_oracle_rel_err":

@@ -773,6 +773,9 @@ class KSP(object):
                     if cuts[l] is not None else
                     eng.row_range(ops[l].shape[0], velocity=vel)
                     for l in range(L)]
+        # (what a checker needs to put this rank's rows back together:
+        # oracle.mirror_partitioned)
+        pc.mg_data["rows"] = rng_ if local else None
         if pc._mg_pushed != sig:
             eng.mg_begin(slot, L, nu_pre, nu_post)
             if local:

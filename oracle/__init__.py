@@ -149,3 +149,94 @@ def mirror(o, pb, ksp):
                         k.rtol if k.type == "cg" else 0.0, lo, hi)
     o.setup()
     return o
+
+
+def mirror_partitioned(o, pp, ksp, root=0):
+    """:func:`mirror` for a PARTITIONED run (``fem.partition.PartitionedProblem``
+    with the rank-local hand-over): every rank holds its rows of every
+    partitioned operator; their rows are put back together on rank ``root``
+    (``pp.host.allgather``: references between thread ranks, pickles between
+    processes) and the oracle engine ``o`` of that rank is configured with the
+    whole operators, the whole hierarchy (prolongation rows of the owners - a
+    partitioned algebraic chain carries halo rows too), the same smoother
+    bounds and coarse inverses.  COLLECTIVE: every rank calls it (``o`` may be
+    ``None`` off the root); returns ``o`` on the root, ``None`` elsewhere.
+    The checker then sees one global problem - what the ranks together were
+    handed - at sizes where that fits one host."""
+    import numpy as np
+    import scipy.sparse as sp
+    from fenapack_amd import _cabi as c
+    host, me = pp.host, pp.rank
+    V = pp.space
+
+    def whole(M, rows=None):
+        """Sum over ranks of row-sparse, global-shaped ``M`` (``rows``: keep
+        only my rows ``[r0, r1)`` first - matrices that carry halo rows)."""
+        M = sp.csr_matrix(M)
+        if rows is not None:
+            r0, r1 = rows
+            ip = np.zeros(M.shape[0] + 1, dtype=np.int64)
+            lo, hi = int(M.indptr[r0]), int(M.indptr[r1])
+            ip[r0 + 1:r1 + 1] = M.indptr[r0 + 1:r1 + 1] - lo
+            ip[r1 + 1:] = hi - lo
+            M = sp.csr_matrix((M.data[lo:hi], M.indices[lo:hi], ip),
+                              shape=M.shape)
+        parts = host.allgather(M)
+        if me != root:
+            return None
+        out = parts[0]
+        for q in parts[1:]:
+            out = out + q
+        out = sp.csr_matrix(out)
+        out.sort_indices()
+        return out
+
+    ksp0, ksp1 = ksp.pc.getFieldSplitSubKSP()
+    pcd = ksp1.pc.getPythonContext()
+    A, P = ksp.getOperators()
+    Ap = whole(pcd.ksp_Ap.getOperators()[0].A)
+    Mp = whole(pcd.ksp_Mp.getOperators()[0].A)
+    Kp = whole(pcd.mat_Kp.A)
+    Aw = whole(A.A)
+    pmat = None if (P is None or P is A or not P.isAssembled()) else whole(P.A)
+    if me == root:
+        o.set_velocity_block(V.dim)
+        o.set_csr(c.MAT_AP, Ap)
+        o.set_csr(c.MAT_MP, Mp)
+        o.set_csr(c.MAT_KP, Kp)
+        o.set_bc(pp.bc_p_idx, pp.bc_p_val)
+        o.set_system(Aw, V.is_u, V.is_p, pmat)
+    for k, slot in ((ksp0, c.KSP_A00), (pcd.ksp_Ap, c.KSP_AP),
+                    (pcd.ksp_Mp, c.KSP_MP)):
+        if k.pc.type == "mg":
+            d = k.pc.mg_data
+            L = len(d["ops"])
+            rows = d.get("rows") or [None] * L
+            ops, chain = [], [None]
+            for l in range(1, L):
+                part = rows[l] is not None
+                ops.append(None if l == L - 1 else
+                           (whole(d["ops"][l]) if part else d["ops"][l]))
+                # prolongation rows live with the level's rows
+                chain.append(whole(d["chain"][l], rows[l]) if part
+                             else d["chain"][l])
+            if me == root:
+                o.mg_begin(slot, L, d["nu"], d.get("nu_post", d["nu"]))
+                o.mg_set_level(slot, 0, d["C"])
+                for l in range(1, L):
+                    o.mg_set_level(slot, l, ops[l - 1], chain[l],
+                                   *d["bounds"][l])
+                o.set_inner(slot, k.type, "mg", k.max_it, 0.0)
+        elif me == root:
+            lo, hi = (getattr(k, "cheb_bounds_pushed", None)
+                      or k._chebyshev_bounds()) if k.type == "chebyshev" \
+                else (0.5, 2.0)
+            o.set_inner(slot, k.engine_type, "jacobi", k.max_it,
+                        k.rtol if k.type == "cg" else 0.0, lo, hi)
+        elif k.type == "chebyshev" and \
+                getattr(k, "cheb_bounds_pushed", None) is None:
+            k._chebyshev_bounds()              # (collective: reduces over ranks)
+    if me != root:
+        return None
+    o.setup()
+    return o

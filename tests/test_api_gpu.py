@@ -263,7 +263,7 @@ def test_bench_line_of_the_north_stars_literal_solvers():
     Jacobi-preconditioned CG (wave64 reductions) for the pressure Laplacian
     (fenapack/preconditioners.py:42-49, 130: `ksp_Ap.solve`), Chebyshev-Jacobi
     for the mass matrix (:133) and a Chebyshev / Jacobi sweep for the velocity
-    block - through the bench contract in small (level 4): the line carries
+    block - through the bench contract in small (level 3): the line carries
     the `cg` block (two launches per iteration on one rank, B_cg of SURVEY
     8(d) over the measured time), the executed k_A, and the oracle's parity of
     this very apply (a tolerance-driven CG: the iteration counts agree, the
@@ -273,7 +273,7 @@ def test_bench_line_of_the_north_stars_literal_solvers():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--level", "4",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--level", "3",
            "--inner", "jacobi", "--steps", "5", "--warmup", "2",
            "--a00-its", "60", "--a00-ratio", "0.01", "--cpu-seconds", "1"]
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
