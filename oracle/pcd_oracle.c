@@ -918,8 +918,15 @@ static volatile int t_sb_count = 0, t_sb_sense = 0;
  * the release travels back the same way - per barrier every thread touches
  * one line that lives in its own L3, and only n_groups threads touch the line
  * that crosses the sockets (the centralised barrier: all of them, 150 times
- * per PCApply).  PCDO_TEAM_GROUP sets the group size (default 16; 0 = the
- * runtime's own barrier, kept for A/B). */
+ * per PCApply).  PCDO_TEAM_GROUP sets the group size; 0 (the default) = the
+ * runtime's own barrier.  MEASURED on this pool's 2 x 64-core hosts
+ * (bench.py cpu_baseline, "sweep_with_the_two_level_barrier", round 6): the
+ * two-level form LOSES at every thread count where it differs - level 6, 32
+ * threads: 196-212 PCApply/s against 243-273 with libgomp's barrier (whose
+ * waiters spin on a generation word of its own cache line and fall back to a
+ * futex) - also with count and release word on separate lines.  Kept as the
+ * A/B switch; the collapse of the sweep past 32 threads is not the barrier's
+ * centralisation. */
 #define T_MAX_GROUPS 64
 /* (arrivals and the release word on cache lines of their own: an arrival
  * must not invalidate the line the group's waiters spin on - the first form
@@ -931,7 +938,7 @@ typedef struct {
 } t_node_t;
 static t_node_t t_grp_node[T_MAX_GROUPS] __attribute__((aligned(128)));
 static t_node_t t_top_node __attribute__((aligned(128)));
-static int t_grp = 16;
+static int t_grp = 0;          /* measured (round 6): the runtime's barrier wins - see below */
 static __thread int t_hsense = 0;
 static inline void t_full_barrier(void) {
   const int nth = omp_get_num_threads();
@@ -1303,7 +1310,7 @@ int pcdo_team_prepare(pcdo_t *h, int threads) {
   if (threads < 1) threads = omp_get_max_threads();
   { const char *e = getenv("PCDO_TEAM_BIG"); if (e) t_big = atoi(e);
     e = getenv("PCDO_TEAM_SUB"); if (e && atoi(e) > 0) t_sub = atoi(e);
-    e = getenv("PCDO_TEAM_GROUP"); if (e) t_grp = atoi(e); }
+    e = getenv("PCDO_TEAM_GROUP"); t_grp = e ? atoi(e) : 0; }
   int slot = team_slot(h);
   if (slot < 0) for (int i = 0; i < 64 && slot < 0; ++i) if (!g_team_owner[i]) slot = i;
   if (slot < 0) return fail(3, "team_prepare: too many engines");

@@ -273,7 +273,7 @@ def test_three_dimensional_producer_and_solver_chain():
     # the NUMA-aware two-level barrier: groups of two threads (3 threads: a
     # ragged last group; 4: two full ones), with and without a sub-team
     ("BRM1", True, None, 2), ("BRM1", True, 2, 2), ("RBRM1", False, 2, 2),
-    # ... and the runtime's own barrier (group 0: the A/B switch)
+    # ... and the runtime's own barrier spelled out (group 0 = the default)
     ("BRM1", True, 2, 0)])
 def test_team_timing_port_equals_the_serial_oracle(variant, mg, sub, group,
                                                    monkeypatch):
