@@ -40,6 +40,11 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# (the resident-set watchdog of this repository's scripts; the kit itself only
+# starts child processes and never touches the GPU)
+from fenapack_amd import _guard                                      # noqa: E402
+_guard.start_rss_watchdog()
 
 
 def free_port():
