@@ -76,9 +76,6 @@ class PartitionedDeviceProducer(DeviceProducer):
         if pp.stabilize or pp.coarse_stabilize:
             raise ValueError("partitioned device producer: no SUPG (its "
                              "hierarchy is re-discretised, not Galerkin)")
-        if pp.variant == "BRM2" and len(pp.robin_edges) > 0:
-            raise ValueError("partitioned device producer: the BRM2 inflow "
-                             "term of Kp is assembled on the host")
         self.newton, self.supg = False, False
         self.pb, self.V, self.ksp = pp, V, ksp
         self.eng = eng = ksp.engine
@@ -405,6 +402,30 @@ class PartitionedDeviceProducer(DeviceProducer):
         self._kp_cut = (e0, e1)
         self._kp_rows = (q0, q1)
         self.nnz_kp = e1 - e0
+        # BRM2: - (1/nu) int_inflow (w.n) p q ds (demo_navier-stokes-pcd.py:
+        # 131-135) over the inflow facets of the SLAB - every facet that
+        # touches an owned pressure row lies in it (its cell touches that row);
+        # entries of other ranks' rows are left to their owners, the plan's
+        # node numbers index the replicated wind (global)
+        if pp.variant == "BRM2" and len(loc.robin_edges) > 0:
+            from .device_producer import _group
+            pl = Vl.robin_plan(loc.robin_edges)
+            nb = pl["length"].size
+            pd = pl["pdofs"]
+            k = pd.shape[1]
+            rows = np.repeat(pd[:, :, None], k, axis=2).ravel()
+            cols = np.repeat(pd[:, None, :], k, axis=1).ravel()
+            where = pat.locate(rows, cols)
+            e_idx, ij = np.divmod(np.arange(where.size), k * k)
+            mine = (where >= e0) & (where < e1)
+            where, e_idx, ij = where[mine] - e0, e_idx[mine], ij[mine]
+            if where.size:
+                aff_pos, _, aff_ptr, order = _group(
+                    where, np.zeros_like(where), e1 - e0, 1)
+                self.eng.fe_bind_robin(
+                    sub.nodes_g[pl["nodes"]].T, pl["normal"].T, pl["length"],
+                    aff_pos, aff_ptr, (ij * nb + e_idx)[order],
+                    np.full(where.size, -1.0 / loc.nu))
 
     # ------------------------------------------------------------ diagnostics
     def _scalar(self, l):

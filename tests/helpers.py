@@ -144,10 +144,15 @@ def n73_children():
     for k in ("FENAPACK_AMD_NO_WATCHDOG", "PCD_REPLICATE_BELOW"):
         env.pop(k, None)
     env["FENAPACK_AMD_WATCHDOG"] = "1"
-    # (both builds thread their host work: share the cores)
-    half = str(max(4, (os.cpu_count() or 8) // 2))
+    # (the builds thread their host work: share the cores)
+    half = str(max(4, (os.cpu_count() or 8) // 3))
     env.setdefault("FENAPACK_AMD_HOST_THREADS", half)
     cmds = {
+        # (the partitioned path against the oracle, cube N = 48 on 8 thread
+        # ranks: 35 GB of host memory - a child as well, beside the other two)
+        "n48_ranks8": ([sys.executable,
+                        os.path.join(root, "tools", "parity_partitioned.py"),
+                        "--n0", "48", "--ranks", "8"], {}),
         "one_gpu": ([sys.executable, os.path.join(root, "tools", "parity_large.py"),
                      "--geometry", "cube", "--level", "0", "--n0", "73",
                      "--algebraic"], {}),

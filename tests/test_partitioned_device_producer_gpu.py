@@ -23,7 +23,7 @@ import scipy.sparse.linalg as spla
 from fenapack_amd import PETScOptions, _host
 from fenapack_amd.device_producer import DevicePicardSolver
 from fenapack_amd.driver import multigrid_inner_options, solve_steady
-from fenapack_amd.fem import Cavity3D
+from fenapack_amd.fem import Cavity3D, Channel3D
 from fenapack_amd.fem import partition as pt
 
 from test_partitioned_gpu import on_thread_ranks
@@ -36,7 +36,11 @@ def _relerr(a, b):
 
 
 @pytest.mark.parametrize("N,R,limit", [(16, 2, 1500), (16, 3, 1500),
-                                       (16, 8, 1500), (16, 2, 60000)])
+                                       (16, 8, 1500), (16, 2, 60000),
+                                       # a duct with inflow / outflow, BRM2: the
+                                       # Robin term of K_p over the inflow
+                                       # faces of every rank's slab
+                                       ("duct", 3, 1500)])
 def test_operators_of_the_rank_local_producer_equal_the_host_refresh(
         hip_lib, monkeypatch, N, R, limit):
     """cube N = 16 on 2, 3 and 8 thread ranks.  PCD_REPLICATE_BELOW = 1500: two
@@ -46,10 +50,13 @@ def test_operators_of_the_rank_local_producer_equal_the_host_refresh(
     monkeypatch.setenv("PCD_REPLICATE_BELOW", str(limit))
     PETScOptions.clear()
     multigrid_inner_options(dim=3, algebraic=True)
-    kw = dict(level=0, nu=0.01, n0=N)
+    duct = N == "duct"
+    cls = Channel3D if duct else Cavity3D
+    kw = dict(level=0, nu=0.02, n0=16, variant="BRM2") if duct \
+        else dict(level=0, nu=0.01, n0=N)
 
     def body(r, comm, host):
-        pp = pt.partitioned(Cavity3D, r, R, host=host, **kw)
+        pp = pt.partitioned(cls, r, R, host=host, **kw)
         V, d = pp.space, pp.space.dim
         s = DevicePicardSolver(pp, max_newton=2, newton_rtol=0.0, comm=comm)
         s.solve()                           # host step, then one device step
@@ -137,3 +144,50 @@ def test_picard_solve_of_the_rank_local_producer_equals_the_host_driven_one(
         assert all(abs(a - b) <= 1 for a, b in zip(r["its"], ref[0]["its"])), (
             r["its"], ref[0]["its"])
         assert np.abs(r["x"] - x1).max() <= 1e-6 * np.abs(x1).max()
+
+
+def test_unsteady_loop_of_the_rank_local_producer(hip_lib, monkeypatch):
+    """The unsteady demo's loop (demo_unsteady-navier-stokes-pcd.py:188-208:
+    backward Euler, the mass term in F and K_p, the previous velocity in the
+    residual) over the rank-local device producer: L-shape level 3, dt 0.2,
+    three time steps on 2 thread ranks through -pc_type gamg, against the
+    host-driven loop of the same partitioned producer."""
+    from fenapack_amd.device_producer import solve_unsteady_device
+    from fenapack_amd.driver import solve_unsteady
+    from fenapack_amd.fem import BackwardStep
+    monkeypatch.setenv("PCD_REPLICATE_BELOW", "400")
+    R, dt = 2, 0.2
+    kw = dict(level=3, nu=0.02, dt=dt)
+
+    def options():
+        PETScOptions.clear()
+        multigrid_inner_options(dim=2, algebraic=True, cycles_u=2, cycles_p=2)
+
+    def host_driven(r, comm, host):
+        pp = pt.partitioned(BackwardStep, r, R, host=host, **kw)
+        out = solve_unsteady(pp, dt=dt, t_end=3 * dt, newton_rtol=1e-5,
+                             comm=comm)
+        return {"its": out["krylov_per_newton"], "x": out["w"].vector().copy()}
+
+    def on_device(r, comm, host):
+        pp = pt.partitioned(BackwardStep, r, R, host=host, **kw)
+        out = solve_unsteady_device(pp, dt=dt, t_end=3 * dt, newton_rtol=1e-5,
+                                    comm=comm)
+        assert out["producer"].device_loop
+        return {"its": out["krylov_per_newton"], "x": out["w"].vector().copy()}
+
+    options()
+    ref = on_thread_ranks(R, host_driven)
+    options()
+    dev = on_thread_ranks(R, on_device)
+    PETScOptions.clear()
+    x1 = ref[0]["x"]
+    flat = lambda h: [k for step in h for k in step]
+    for r in dev:
+        assert np.array_equal(r["x"], dev[0]["x"])
+        assert len(flat(r["its"])) == len(flat(ref[0]["its"])), (
+            r["its"], ref[0]["its"])
+        assert all(abs(a - b) <= 2 for a, b in
+                   zip(flat(r["its"]), flat(ref[0]["its"]))), (
+            r["its"], ref[0]["its"])
+        assert np.abs(r["x"] - x1).max() <= 1e-5 * np.abs(x1).max()
