@@ -93,8 +93,8 @@ def test_config4_unsteady_100_steps_on_1_2_and_4_ranks(hip_lib, replicate_below)
         return solve
 
     # (one after the other: side by side - 1 + 2 + 4 engines on the one GPU,
-    # a thread each - the three runs took 104 s where they take 89 s in turn:
-    # the host threads contend for the interpreter and the launch queue)
+    # a thread each - the three runs were no faster: the host threads contend
+    # for the interpreter and the launch queue)
     both = {R: _on_ranks(R, solver(100)) for R in (1, 2, 4)}
     one = both[1][0]
     assert one["ndof"] == 25987 and one["steps"] == 100
