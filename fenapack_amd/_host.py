@@ -68,6 +68,8 @@ def library():
                                     _I32P, _I32P, _I32P, _I64P]
     L.pcdh_transpose.argtypes = [ctypes.c_int64, ctypes.c_int64, _I32P, _I32P,
                                  _F64P, _I32P, _I32P, _F64P]
+    L.pcdh_locate.argtypes = [ctypes.c_int64, _I64P, _I64P, ctypes.c_int64,
+                              _I64P, _I32P, _I64P]
     L.pcdh_spgemm_count.argtypes = [ctypes.c_int64, ctypes.c_int64,
                                     ctypes.c_int64, _I32P, _I32P, _I32P,
                                     _I32P, _I64P]
@@ -271,8 +273,6 @@ def locate(M, rows, cols):
     ci = _i32(M.indices)
     pos = np.empty(rows.size, dtype=np.int64)
     L = library()
-    L.pcdh_locate.argtypes = [ctypes.c_int64, _I64P, _I64P, ctypes.c_int64,
-                              _I64P, _I32P, _I64P]
     _chk(L.pcdh_locate(rows.size, _p(rows, _I64P), _p(cols, _I64P),
                        M.shape[0], _p(rp, _I64P), _p(ci, _I32P),
                        _p(pos, _I64P)))

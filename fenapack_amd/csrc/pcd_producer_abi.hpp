@@ -535,6 +535,7 @@ int pcd_fe_set_level_galerkin(pcd_handle h, int level, int64_t nnz_f, int64_t nn
   FeLevel& L = fe.lev[level];
   L.release();
   L.galerkin = true; L.nnzf = nnz_f; L.nnzb = nnz_b;
+  L.rows = false; L.row0 = 0; L.nrows = 0;
   CHK(fe_upload(L.b_ptr, b_ptr, (size_t)nnz_b + 1));
   CHK(fe_upload(L.b_src, b_src, (size_t)b_ptr[nnz_b]));
   CHK(fe_upload(L.b_w, b_w, (size_t)b_ptr[nnz_b]));
@@ -577,6 +578,7 @@ int pcd_fe_set_level_product(pcd_handle h, int level, int64_t n_fine, int64_t n_
   FeLevel& L = fe.lev[level];
   L.release();
   L.galerkin = true; L.product = true; L.nnzf = nnz_c; L.nnzb = nnz_b;
+  L.rows = false; L.row0 = 0; L.nrows = 0;      // (a whole level: a re-bound one may have been a row block)
   L.pr_nf = n_fine; L.pr_nc = n_coarse;
   CHK(fe_upload(L.p_rp, p_rowptr, (size_t)n_fine + 1));
   CHK(fe_upload(L.p_col, p_col, (size_t)nnz_p));
@@ -692,6 +694,7 @@ int pcd_fe_set_level_product_rows(pcd_handle h, int level, int64_t n_own, int64_
     if (g == 8 || g == 16 || g == 32 || g == 64) L.pr_g1 = L.pr_g2 = g;
   }
   // a partitioned level keeps this rank's node rows only (like a row-cut plan)
+  L.rows = false; L.row0 = 0; L.nrows = 0;
   if (!gather_total) { L.rows = true; L.row0 = node_row0; L.nrows = n_node_rows; }
   L.nn2 = n_coarse;
   L.set = true; L.ev_init = false;
@@ -1338,6 +1341,7 @@ int pcd_fe_bind_residual(pcd_handle h, const int32_t* bt_rowptr, const int32_t* 
   if (n_bc) HIPCHK(hipMemset(fe.bc_g.p, 0, n_bc * sizeof(double)));
   if (mass_vals) CHK(fe_upload(fe.mass, mass_vals, (size_t)fe.lev[fe.nlev - 1].nnzf));
   fe.have_mu0 = false;
+  fe.res_rows = false;                   // (whole blocks unless pcd_fe_set_residual_rows says otherwise)
   fe.res_bound = true;
   return 0;
 } PCD_ABI_CATCH(pcd_fe_bind_residual)

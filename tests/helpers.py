@@ -161,6 +161,15 @@ def n73_children():
                     "--partitioned", "--algebraic", "--n0=73", "cube", "0", "8"],
                    {"FENAPACK_AMD_LOCAL_HANDOVER": "1"}),
     }
+    # (a session that ends before it collected them - a selection, `-x` after
+    # a failure - does not leave GPU processes behind for whatever runs next)
+    import atexit
+
+    def _reap():
+        for rec in _N73.values():
+            if rec["proc"].poll() is None:
+                rec["proc"].kill()
+    atexit.register(_reap)
     for name, (cmd, extra) in cmds.items():
         out = tempfile.TemporaryFile(mode="w+")
         err = tempfile.TemporaryFile(mode="w+")
