@@ -68,6 +68,8 @@ def library():
                                     _I32P, _I32P, _I32P, _I64P]
     L.pcdh_transpose.argtypes = [ctypes.c_int64, ctypes.c_int64, _I32P, _I32P,
                                  _F64P, _I32P, _I32P, _F64P]
+    L.pcdh_take_segments.argtypes = [ctypes.c_int64, _I64P, ctypes.c_int,
+                                     ctypes.c_void_p, _I64P, _F64P]
     L.pcdh_locate.argtypes = [ctypes.c_int64, _I64P, _I64P, ctypes.c_int64,
                               _I64P, _I32P, _I64P]
     L.pcdh_spgemm_count.argtypes = [ctypes.c_int64, ctypes.c_int64,
@@ -249,6 +251,23 @@ def spgemm(A, B, row0=0, row1=None):
     C = sp.csr_matrix((cv, cc, idx), shape=(row1 - row0, B.shape[1]))
     C.has_sorted_indices = True
     return C
+
+
+def take_segments(idx, arrays):
+    """``numpy.concatenate(arrays)[idx]`` without the concatenation, on
+    threads (``pcdh_take_segments``)."""
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
+    if use_numpy() or idx.size < 200000:
+        return np.concatenate(arrs)[idx]
+    off = np.zeros(len(arrs) + 1, dtype=np.int64)
+    np.cumsum([a.size for a in arrs], out=off[1:])
+    ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    out = np.empty(idx.size, dtype=np.float64)
+    L = library()
+    _chk(L.pcdh_take_segments(idx.size, _p(idx, _I64P), len(arrs), ptrs,
+                              _p(off, _I64P), _p(out, _F64P)))
+    return out
 
 
 def locate(M, rows, cols):

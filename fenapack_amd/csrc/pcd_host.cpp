@@ -707,6 +707,35 @@ int pcdh_union_fill(int64_t n, int nb, const int64_t* nr, const int32_t* const* 
   return 0;
 } PCDH_ABI_CATCH(pcdh_union_fill)
 
+// ------------------------------------------------------------ gathers of values
+// out[i] = concat(seg[0], seg[1], ...)[idx[i]] without forming the
+// concatenation: seg_off[s] = first index of segment s (nseg + 1 entries).
+// The monolithic system's values from its blocks (an assembly that is a pure
+// permutation) and a sub-matrix's values from its parent's, on threads: what
+// numpy does with concatenate + fancy indexing on ONE thread (at config 5's
+// size 1.1e9 entries per call, twice per nonlinear step).
+int pcdh_take_segments(int64_t n, const int64_t* idx, int nseg, const double* const* seg,
+                       const int64_t* seg_off, double* out) try {
+  if (n < 0 || nseg < 1 || nseg > 16 || !seg || !seg_off || (n && (!idx || !out)))
+    return fail(PCDH_ERR_ARG, "take_segments: bad arguments");
+  for (int s_ = 0; s_ < nseg; ++s_)
+    if (seg_off[s_ + 1] < seg_off[s_] || (seg_off[s_ + 1] > seg_off[s_] && !seg[s_]))
+      return fail(PCDH_ERR_ARG, "take_segments: bad segment %d", s_);
+  const int64_t total = seg_off[nseg];
+  const int T = nthreads(n);
+  int bad = 0;
+#pragma omp parallel for schedule(static, 1 << 16) num_threads(T) reduction(| : bad)
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t k = idx[i];
+    if (k < seg_off[0] || k >= total) { bad |= 1; out[i] = 0.0; continue; }
+    int s_ = 0;
+    while (k >= seg_off[s_ + 1]) ++s_;
+    out[i] = seg[s_][k - seg_off[s_]];
+  }
+  if (bad) return fail(PCDH_ERR_ARG, "take_segments: an index outside the segments");
+  return 0;
+} PCDH_ABI_CATCH(pcdh_take_segments)
+
 // ------------------------------------------------------- positions of entries
 // pos[q] = position of entry (qrow[q], qcol[q]) in the CSR (rowptr, col) whose
 // columns are sorted in every row; PCDH_ERR_ARG when one is missing.

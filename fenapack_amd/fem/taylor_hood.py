@@ -953,6 +953,7 @@ class TaylorHood(object):
                 pat.order = order            # (inv follows on demand)
             setattr(self, key, pat)
         pat = getattr(self, key)
-        vals = np.concatenate([A00.data, A01.data, A10.data,
-                               np.zeros(self.n_p)])
-        return pat.matrix(vals[pat.order])
+        # (an assembly that is a pure permutation: the blocks' values gathered
+        # into the matrix's order on threads, no concatenated copy)
+        return pat.matrix(_host.take_segments(
+            pat.order, [A00.data, A01.data, A10.data, np.zeros(self.n_p)]))

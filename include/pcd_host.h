@@ -233,6 +233,16 @@ int pcdh_mis2_degrees(int64_t n, const int32_t* rowptr, const int32_t* col,
 int pcdh_mis2(int64_t n, const int32_t* rowptr, const int32_t* col,
               const double* w, int8_t* in_set, int64_t* rounds /* may be NULL */);
 
+/* ---- gathers of values ------------------------------------------------------
+ * out[i] = concat(seg[0 .. nseg-1])[idx[i]], the concatenation never formed:
+ * seg_off[s] = first index of segment s (nseg + 1 entries, at most 16
+ * segments).  The values of the monolithic system from its blocks, of a
+ * sub-matrix from its parent (what createSubMatrix(..., submat=) refreshes:
+ * fenapack/field_split_backend.py:331-334), on threads.                      */
+int pcdh_take_segments(int64_t n, const int64_t* idx, int nseg,
+                       const double* const* seg, const int64_t* seg_off,
+                       double* out);
+
 /* ---- positions of entries ---------------------------------------------------
  * pos[q] = position of entry (qrow[q], qcol[q]) in a CSR pattern with sorted
  * columns (threads over the queries, a bisection per query).  The device

@@ -415,3 +415,52 @@ def test_locate_entries_in_a_sorted_csr(monkeypatch):
             H.locate(M, [empty_row], [0])
     with pytest.raises(H.HostError):
         H.locate(M, [5000], [0])                     # row outside the matrix
+
+
+def test_take_segments_is_concatenate_and_index():
+    """pcdh_take_segments: ``numpy.concatenate(arrays)[idx]`` without the
+    concatenation (the monolithic system's values from its blocks, a
+    sub-matrix's from its parent's); an index outside the segments is
+    refused."""
+    rng = np.random.default_rng(8)
+    arrays = [rng.standard_normal(n) for n in (300000, 1, 0, 250000)]
+    total = sum(a.size for a in arrays)
+    idx = rng.integers(0, total, 600000)
+    ref = np.concatenate(arrays)[idx]
+    assert np.array_equal(H.take_segments(idx, arrays), ref)
+    with pytest.raises(H.HostError):
+        H.take_segments(np.full(300000, total), arrays)
+
+
+def test_velocity_block_extraction_is_cached_per_pattern():
+    """PCDKSP._A00_host: the (0, 0) block of the system on the host (PETSc's
+    createSubMatrix(..., submat=): field_split_backend.py:331-334) - index
+    structure once per pattern, a threaded gather per refresh - equals scipy's
+    fancy indexing, also after the values changed."""
+    from fenapack_amd.field_split import PCDKSP
+    pb = Cavity3D(0, nu=0.01, n0=12)
+    V = pb.space
+    rng = np.random.default_rng(1)
+
+    class _M(object):
+        def __init__(self, A):
+            self.A = A
+
+        def isAssembled(self):
+            return True
+
+    class _IS(object):
+        indices = V.is_u
+
+    k = PCDKSP.__new__(PCDKSP)
+    for _ in range(2):
+        lin = pb.linearise(rng.standard_normal(V.n_u), np.zeros(V.n_p))
+        A = V.monolithic(lin["A00"], lin["A01"], lin["A10"])
+        assert A.nnz > 200000
+        got = k._A00_host(_M(A), None, _IS())
+        ref = sp.csr_matrix(A[V.is_u][:, V.is_u])
+        ref.sort_indices()
+        assert np.array_equal(got.indptr, ref.indptr)
+        assert np.array_equal(got.indices, ref.indices)
+        assert np.array_equal(got.data, ref.data)
+    assert k._a00_extract is not None
