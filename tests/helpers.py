@@ -119,37 +119,20 @@ def free_port():
         return s.getsockname()[1]
 
 
-# ---- config 5's own mesh: the two child processes of the suite ----------------
+# ---- config 5's own mesh: the child processes of the suite --------------------
 _N73 = {}
+#: measured host peaks of the three children (GB) - what running them side by
+#: side needs of the control group
+_N73_PEAK_GB = {"n48_ranks8": 30.0, "one_gpu": 57.0, "ranks8": 75.0}
 
 
-def n73_children():
-    """The suite's two runs on config 5's own mesh (cube N = 73, 9 934 793 DOF)
-    - the one-GPU parity run (tools/parity_large.py) and the 8-thread-rank run
-    (tools/steady_thread_ranks.py) - are processes of their own (tens of GB of
-    host memory each, under the scripts' own watchdog).  They are started
-    TOGETHER by whichever test asks first and run side by side: 54 s + 66 s one
-    after the other (round 5), about the longer one's time together.  Returns
-    ``{"one_gpu": rec, "ranks8": rec}`` with ``rec = {"proc", "out", "err",
-    "t0"}``; :func:`n73_result` waits for one of them."""
+def _n73_commands():
     import os
-    import subprocess
     import sys
-    import tempfile
-    import time
-    if _N73:
-        return _N73
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
-    for k in ("FENAPACK_AMD_NO_WATCHDOG", "PCD_REPLICATE_BELOW"):
-        env.pop(k, None)
-    env["FENAPACK_AMD_WATCHDOG"] = "1"
-    # (the builds thread their host work: share the cores)
-    half = str(max(4, (os.cpu_count() or 8) // 3))
-    env.setdefault("FENAPACK_AMD_HOST_THREADS", half)
-    cmds = {
+    return root, {
         # (the partitioned path against the oracle, cube N = 48 on 8 thread
-        # ranks: 35 GB of host memory - a child as well, beside the other two)
+        # ranks - a child as well, beside the other two)
         "n48_ranks8": ([sys.executable,
                         os.path.join(root, "tools", "parity_partitioned.py"),
                         "--n0", "48", "--ranks", "8"], {}),
@@ -161,16 +144,50 @@ def n73_children():
                     "--partitioned", "--algebraic", "--n0=73", "cube", "0", "8"],
                    {"FENAPACK_AMD_LOCAL_HANDOVER": "1"}),
     }
-    # (a session that ends before it collected them - a selection, `-x` after
-    # a failure - does not leave GPU processes behind for whatever runs next)
-    import atexit
 
-    def _reap():
-        for rec in _N73.values():
-            if rec["proc"].poll() is None:
-                rec["proc"].kill()
-    atexit.register(_reap)
-    for name, (cmd, extra) in cmds.items():
+
+def n73_children(only=None):
+    """The suite's runs on config 5's own mesh (cube N = 73, 9 934 793 DOF) -
+    the one-GPU parity run (tools/parity_large.py) and the 8-thread-rank run
+    (tools/steady_thread_ranks.py) - and the partitioned parity run at cube
+    N = 48 (tools/parity_partitioned.py) are processes of their own (tens of GB
+    of host memory each, under the scripts' own watchdog).  Where the control
+    group has the memory for all of them (their measured peaks add up to
+    162 GB: 200 GB available or more) they are started TOGETHER by whichever
+    test asks first and run side by side - 58 s instead of 54 + 66 + 27 s one
+    after the other; on a smaller host every test starts its own child when
+    it asks (``only``).  Returns ``{name: {"proc", "out", "err", "t0"}}``;
+    :func:`n73_result` waits for one of them."""
+    import atexit
+    import os
+    import subprocess
+    import tempfile
+    import time
+    from fenapack_amd import _guard
+    root, cmds = _n73_commands()
+    have = _guard.host_memory_available()
+    together = have is None or have >= 200e9
+    want = list(cmds) if together else [only]
+    env = dict(os.environ)
+    for k in ("FENAPACK_AMD_NO_WATCHDOG", "PCD_REPLICATE_BELOW"):
+        env.pop(k, None)
+    env["FENAPACK_AMD_WATCHDOG"] = "1"
+    if together:
+        # (the builds thread their host work: share the cores)
+        env.setdefault("FENAPACK_AMD_HOST_THREADS",
+                       str(max(4, (os.cpu_count() or 8) // 3)))
+    if not _N73:
+        # (a session that ends before it collected them - a selection, `-x`
+        # after a failure - does not leave GPU processes behind)
+        def _reap():
+            for rec in _N73.values():
+                if rec["proc"].poll() is None:
+                    rec["proc"].kill()
+        atexit.register(_reap)
+    for name in want:
+        if name is None or name in _N73:
+            continue
+        cmd, extra = cmds[name]
         out = tempfile.TemporaryFile(mode="w+")
         err = tempfile.TemporaryFile(mode="w+")
         proc = subprocess.Popen(cmd, cwd=root, env=dict(env, **extra),
@@ -182,7 +199,7 @@ def n73_children():
 def n73_result(name, timeout=1100):
     """(returncode, stdout, stderr) of one of :func:`n73_children`."""
     import subprocess
-    rec = n73_children()[name]
+    rec = n73_children(only=name)[name]
     try:
         rc = rec["proc"].wait(timeout=timeout)
     except subprocess.TimeoutExpired:

@@ -207,7 +207,8 @@ def test_config5_own_mesh_cube_n73_on_8_ranks():
     from fenapack_amd import _guard
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     have = _guard.host_memory_available()
-    need = 200e9          # (measured peaks: 75 GB here + 57 GB of the one-GPU run beside it)
+    need = 110e9          # (measured peak: 75 GB; side by side with the other children
+    #                       only where the host holds all of them: helpers.n73_children)
     assert have is None or have >= need, (
         "config 5's own mesh on 8 thread ranks needs a host with %.0f GB "
         "available to this control group, %.0f GB here" % (need / 1e9,

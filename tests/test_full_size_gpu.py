@@ -166,7 +166,8 @@ def test_cube_n73_config5_own_mesh():
     from fenapack_amd import _guard
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     have = _guard.host_memory_available()
-    need = 200e9       # (measured peaks: 57 GB here + 75 GB of the 8-rank run beside it)
+    need = 90e9        # (measured peak: 57 GB; the children run side by side only
+    #                    where the host holds all of them: helpers.n73_children)
     assert have is None or have >= need, (
         "config 5's own mesh needs a host with %.0f GB available to this "
         "control group, %.0f GB here" % (need / 1e9, (have or 0) / 1e9))
