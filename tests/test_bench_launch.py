@@ -72,3 +72,26 @@ def test_world_size_mismatch_and_child_failure_exit_nonzero():
     if torch.cuda.device_count() < 2:
         assert out.returncode != 0
         assert out.stdout.strip() == ""
+
+
+def test_first_contact_kit_runs_a_stage_and_writes_its_records(tmp_path):
+    """tools/first_contact.py (the one command for the first box with several
+    GPUs): every stage is a child process with a JSON of its own and a summary
+    at the end - here the stage that needs no GPU (the device inventory)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "kit"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools",
+                                                     "first_contact.py"),
+                        "--out", str(out), "--stages", "00_devices"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(out / "00_devices.json"))
+    assert rec["status"] == "ok" and "gpus" in rec["result"]
+    assert "peer_access" in rec["result"]
+    summary = json.load(open(out / "summary.json"))
+    assert [s["stage"] for s in summary["stages"]] == ["00_devices"]
+    assert "00_devices" in r.stdout

@@ -356,6 +356,27 @@ def test_c_abi_error_behaviour(hip_lib):
                                 np.zeros(2, dtype=np.int64), [0], [1.0])
     with pytest.raises(c.EngineError, match="Kp is not bound"):
         e.fe_kp_values(3)
+    # the product forms of a Galerkin level (round 6)
+    import scipy.sparse as sp
+    P = sp.csr_matrix(np.array([[1.0, 0.0], [0.5, 0.5], [0.0, 1.0]]))
+    PT = sp.csr_matrix(P.T)
+    F = sp.csr_matrix(np.ones((3, 3)))
+    B = sp.csr_matrix(np.ones((3, 2)))
+    C = sp.csr_matrix(np.ones((2, 2)))
+    with pytest.raises(c.EngineError, match="not a coarse level"):
+        e.fe_set_level_product(1, P, PT, F.indptr, F.indices, B.indptr,
+                               B.indices, C.indptr, C.indices)
+    bad_PT = sp.csr_matrix(np.array([[1.0, 0.5, 0.0], [0.0, 0.0, 1.0]]))
+    with pytest.raises(c.EngineError, match="does not have P's entries"):
+        e.fe_set_level_product(0, P, bad_PT, F.indptr, F.indices, B.indptr,
+                               B.indices, C.indptr, C.indices)
+    # by rows: a communicator is needed; the residual's row blocks likewise
+    with pytest.raises(c.EngineError, match="no communicator"):
+        e.fe_set_level_product_rows(0, P, PT, F.indptr, F.indices, B.indptr,
+                                    B.indices, C.indptr, C.indices, 4, 0,
+                                    np.zeros((0, 3)), np.zeros((0, 4)), [])
+    with pytest.raises(c.EngineError, match="bind the residual first"):
+        e.fe_set_residual_rows(True)
 
 
 @pytest.mark.parametrize("kind", ["cavity", "cube"])
