@@ -68,6 +68,11 @@ def library():
                                     _I32P, _I32P, _I32P, _I64P]
     L.pcdh_transpose.argtypes = [ctypes.c_int64, ctypes.c_int64, _I32P, _I32P,
                                  _F64P, _I32P, _I32P, _F64P]
+    L.pcdh_locate_blocks.argtypes = [ctypes.c_int64, _I32P, _I32P, ctypes.c_int,
+                                     ctypes.c_int, _I32P, _I32P, ctypes.c_int64,
+                                     _I64P, ctypes.c_int64, _I64P, _I32P, _I64P]
+    L.pcdh_contribution_src.argtypes = [ctypes.c_int64, _I64P, ctypes.c_int64,
+                                        ctypes.c_int64, _I32P]
     L.pcdh_take_segments.argtypes = [ctypes.c_int64, _I64P, ctypes.c_int,
                                      ctypes.c_void_p, _I64P, _F64P]
     L.pcdh_locate.argtypes = [ctypes.c_int64, _I64P, _I64P, ctypes.c_int64,
@@ -296,6 +301,49 @@ def locate(M, rows, cols):
                        M.shape[0], _p(rp, _I64P), _p(ci, _I32P),
                        _p(pos, _I64P)))
     return pos
+
+
+def locate_blocks(M, rows, cols, d, pairs, is_u):
+    """``pos[p, q]`` = position in ``M.data`` of the entry ``(is_u[d rows[q] +
+    i], is_u[d cols[q] + j])`` for every component pair ``(i, j) = pairs[p]``
+    (``pcdh_locate_blocks``; the numpy route: :func:`locate` per pair)."""
+    import scipy.sparse as sp
+    M = sp.csr_matrix(M)
+    is_u = np.ascontiguousarray(is_u, dtype=np.int64)
+    pairs = [(int(i), int(j)) for i, j in pairs]
+    if use_numpy():
+        r64 = np.asarray(rows, dtype=np.int64)
+        c64 = np.asarray(cols, dtype=np.int64)
+        return np.stack([locate(M, is_u[d * r64 + i], is_u[d * c64 + j])
+                         for i, j in pairs])
+    if not M.has_sorted_indices:
+        raise ValueError("locate_blocks: the matrix's indices must be sorted")
+    rows, cols = _i32(rows), _i32(cols)
+    ci = np.array([p[0] for p in pairs], dtype=np.int32)
+    cj = np.array([p[1] for p in pairs], dtype=np.int32)
+    rp = np.ascontiguousarray(M.indptr, dtype=np.int64)
+    col = _i32(M.indices)
+    pos = np.empty((len(pairs), rows.size), dtype=np.int64)
+    _chk(library().pcdh_locate_blocks(
+        rows.size, _p(rows, _I32P), _p(cols, _I32P), int(d), len(pairs),
+        _p(ci, _I32P), _p(cj, _I32P), is_u.size, _p(is_u, _I64P), M.shape[0],
+        _p(rp, _I64P), _p(col, _I32P), _p(pos, _I64P)))
+    return pos
+
+
+def contribution_src(order, nloc2, ncells):
+    """``(order % nloc2) * ncells + order // nloc2`` as int32, on threads."""
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    if use_numpy():
+        cell, ab = np.divmod(order, nloc2)
+        src = ab * ncells + cell
+        assert src.size == 0 or src.max() < 2 ** 31
+        return src.astype(np.int32)
+    src = np.empty(order.size, dtype=np.int32)
+    _chk(library().pcdh_contribution_src(order.size, _p(order, _I64P),
+                                         int(nloc2), int(ncells),
+                                         _p(src, _I32P)))
+    return src
 
 
 def product_pattern(a_indptr, a_indices, b_indptr, b_indices, b_cols):

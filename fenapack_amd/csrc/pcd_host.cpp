@@ -759,6 +759,61 @@ int pcdh_locate(int64_t nq, const int64_t* qrow, const int64_t* qcol, int64_t nr
   return 0;
 } PCDH_ABI_CATCH(pcdh_locate)
 
+// pos[p * nq + q] = position of the entry (is_u[d rows[q] + ci[p]],
+// is_u[d cols[q] + cj[p]]) in the CSR (rowptr, col): where the d (Picard:
+// ci = cj = 0 .. d-1) or d*d (Newton) component entries of the scalar pattern
+// entry q sit in the monolithic system's values - locate() for all components
+// at once, without the index arrays numpy would build for each of them.
+int pcdh_locate_blocks(int64_t nq, const int32_t* rows, const int32_t* cols, int d, int npairs,
+                       const int32_t* ci, const int32_t* cj, int64_t n_u, const int64_t* is_u,
+                       int64_t nrows, const int64_t* rowptr, const int32_t* col, int64_t* pos) try {
+  if (nq < 0 || d < 1 || npairs < 1 || !ci || !cj || !is_u || !rowptr || (nq && (!rows || !cols || !pos)) ||
+      (rowptr[nrows] && !col))
+    return fail(PCDH_ERR_ARG, "locate_blocks: bad arguments");
+  for (int p_ = 0; p_ < npairs; ++p_)
+    if (ci[p_] < 0 || ci[p_] >= d || cj[p_] < 0 || cj[p_] >= d)
+      return fail(PCDH_ERR_ARG, "locate_blocks: component outside [0, d)");
+  const int T = nthreads(nq * 4 * npairs);
+  int bad = 0;
+#pragma omp parallel for schedule(static, 8192) num_threads(T) reduction(| : bad)
+  for (int64_t q = 0; q < nq; ++q) {
+    for (int p_ = 0; p_ < npairs; ++p_) {
+      const int64_t ur = (int64_t)d * rows[q] + ci[p_], uc = (int64_t)d * cols[q] + cj[p_];
+      int64_t& out = pos[(int64_t)p_ * nq + q];
+      out = -1;
+      if (rows[q] < 0 || cols[q] < 0 || ur >= n_u || uc >= n_u) { bad |= 1; continue; }
+      const int64_t r = is_u[ur], c = is_u[uc];
+      if (r < 0 || r >= nrows || c > INT32_MAX) { bad |= 1; continue; }
+      const int32_t* b = col + rowptr[r];
+      const int32_t* e = col + rowptr[r + 1];
+      const int32_t* f = std::lower_bound(b, e, (int32_t)c);
+      if (f == e || *f != c) { bad |= 1; continue; }
+      out = (int64_t)(f - col);
+    }
+  }
+  if (bad) return fail(PCDH_ERR_ARG, "locate_blocks: an entry is not in the pattern");
+  return 0;
+} PCDH_ABI_CATCH(pcdh_locate_blocks)
+
+// src[t] = (order[t] % nloc2) * ncells + order[t] / nloc2: the element storage
+// position (component-major: ab * ncells + cell) of every member of a
+// contribution list whose members are element entries laid out (cell, ab).
+int pcdh_contribution_src(int64_t n, const int64_t* order, int64_t nloc2, int64_t ncells, int32_t* src) try {
+  if (n < 0 || nloc2 < 1 || ncells < 1 || (n && (!order || !src)))
+    return fail(PCDH_ERR_ARG, "contribution_src: bad arguments");
+  if (nloc2 * ncells > INT32_MAX) return fail(PCDH_ERR_ARG, "contribution_src: element storage exceeds int32 indexing");
+  const int T = nthreads(n);
+  int bad = 0;
+#pragma omp parallel for schedule(static, 1 << 16) num_threads(T) reduction(| : bad)
+  for (int64_t t = 0; t < n; ++t) {
+    const int64_t o = order[t];
+    if (o < 0 || o >= nloc2 * ncells) { bad |= 1; src[t] = 0; continue; }
+    src[t] = (int32_t)((o % nloc2) * ncells + o / nloc2);
+  }
+  if (bad) return fail(PCDH_ERR_ARG, "contribution_src: a member outside the element storage");
+  return 0;
+} PCDH_ABI_CATCH(pcdh_contribution_src)
+
 // ------------------------------------------------- distance-2 independent set
 int pcdh_mis2_degrees(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t* deg) try {
   if (n < 0 || !rowptr || (rowptr[n] && !col) || (n && !deg))

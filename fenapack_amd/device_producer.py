@@ -54,10 +54,8 @@ def _contribution_plan(inv, ncells, nloc2, nnz, pattern=None):
         gptr, order = g.members()
         ptr = gptr[g.indptr]                       # (slots without members: empty)
         g.release()
-    cell, ab = np.divmod(order, nloc2)
-    src = ab * ncells + cell
-    assert src.size < 2 ** 31
-    return ptr.astype(np.int32), src.astype(np.int32)
+    assert order.size < 2 ** 31
+    return ptr.astype(np.int32), _host.contribution_src(order, nloc2, ncells)
 
 
 def _expand_by_rows(P, row_of):
@@ -565,20 +563,10 @@ class DeviceProducer(object):
         M = self.ksp.getOperators()[0].A
         cut = self._cut[self.nlev - 1]
         e0, e1 = (cut[2], cut[3]) if cut is not None else (0, patS.nnz)
-        rows = patS.rows[e0:e1].astype(np.int64)
-        cols = patS.indices[e0:e1].astype(np.int64)
-        is_u = np.asarray(V.is_u, dtype=np.int64)
-        if self.newton:
-            pos = np.empty((d * d, e1 - e0), dtype=np.int64)
-            for i in range(d):
-                for j in range(d):
-                    pos[i * d + j] = _host.locate(M, is_u[d * rows + i],
-                                                  is_u[d * cols + j])
-        else:
-            pos = np.empty((d, e1 - e0), dtype=np.int64)
-            for k in range(d):
-                pos[k] = _host.locate(M, is_u[d * rows + k],
-                                      is_u[d * cols + k])
+        pairs = [(i, j) for i in range(d) for j in range(d)] if self.newton \
+            else [(k, k) for k in range(d)]
+        pos = _host.locate_blocks(M, patS.rows[e0:e1], patS.indices[e0:e1], d,
+                                  pairs, V.is_u)
         self.eng.fe_bind_system(pos)
 
     def _bind_kp(self, ksp1):

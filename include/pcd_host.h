@@ -255,6 +255,20 @@ int pcdh_locate(int64_t nq, const int64_t* qrow, const int64_t* qcol,
                 int64_t nrows, const int64_t* rowptr, const int32_t* col,
                 int64_t* pos);
 
+/* pcdh_locate for the d (ci = cj = 0 .. d-1: Picard) or d*d (Newton) component
+ * entries of every scalar pattern entry at once: pos[p * nq + q] = position of
+ * (is_u[d rows[q] + ci[p]], is_u[d cols[q] + cj[p]]) in the CSR - the device
+ * producer's map from the velocity block to the monolithic system's values. */
+int pcdh_locate_blocks(int64_t nq, const int32_t* rows, const int32_t* cols,
+                       int d, int npairs, const int32_t* ci, const int32_t* cj,
+                       int64_t n_u, const int64_t* is_u, int64_t nrows,
+                       const int64_t* rowptr, const int32_t* col, int64_t* pos);
+/* element storage position (component-major) of every member of a contribution
+ * list whose members are element entries laid out (cell, ab):
+ * src[t] = (order[t] % nloc2) * ncells + order[t] / nloc2                     */
+int pcdh_contribution_src(int64_t n, const int64_t* order, int64_t nloc2,
+                          int64_t ncells, int32_t* src);
+
 #ifdef __cplusplus
 }
 #endif

@@ -464,3 +464,37 @@ def test_velocity_block_extraction_is_cached_per_pattern():
         assert np.array_equal(got.indices, ref.indices)
         assert np.array_equal(got.data, ref.data)
     assert k._a00_extract is not None
+
+
+def test_locate_blocks_and_contribution_sources():
+    """pcdh_locate_blocks: the d (Picard) / d*d (Newton) component entries of
+    every scalar pattern entry in the monolithic system at once - equal to the
+    per-component route AND to the inverse of the assembly permutation the
+    device producer used through round 5; pcdh_contribution_src: the element
+    storage position of a contribution list's members."""
+    pb = Cavity3D(0, nu=0.01, n0=8)
+    V, d = pb.space, 3
+    lin = pb.linearise(np.random.default_rng(0).standard_normal(V.n_u),
+                       np.zeros(V.n_p))
+    A = V.monolithic(lin["A00"], lin["A01"], lin["A10"])
+    patS = V._patterns(False)["SS"]
+    patA = V._patterns(False)["A00"]
+    mono = getattr(V, "_mono_%d_%d_%d" % (lin["A00"].nnz, lin["A01"].nnz,
+                                          lin["A10"].nnz))
+    rows, cols = patS.rows.astype(np.int64), patS.indices.astype(np.int64)
+    pairs = [(k, k) for k in range(d)]
+    pos = H.locate_blocks(A, patS.rows, patS.indices, d, pairs, V.is_u)
+    old = np.stack([mono.inv[patA.locate(d * rows + k, d * cols + k)]
+                    for k in range(d)])
+    assert np.array_equal(pos, old)
+    # all d*d pairs on the coupled pattern (F x ones(d, d)): every queried
+    # entry must exist - the Picard system lacks the off-diagonal blocks
+    with pytest.raises(H.HostError):
+        H.locate_blocks(A, patS.rows, patS.indices, d,
+                        [(0, 1)], V.is_u)
+    order = np.random.default_rng(1).integers(0, 100 * 5000, 300000)
+    cell, ab = np.divmod(order, 100)
+    assert np.array_equal(H.contribution_src(order, 100, 5000),
+                          (ab * 5000 + cell).astype(np.int32))
+    with pytest.raises(H.HostError):
+        H.contribution_src(np.array([100 * 5000]), 100, 5000)
