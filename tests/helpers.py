@@ -167,6 +167,10 @@ def n73_children(only=None):
     root, cmds = _n73_commands()
     have = _guard.host_memory_available()
     together = have is None or have >= 200e9
+    # (FENAPACK_AMD_SUITE_CHILDREN=sequential | together: the A/B switch)
+    mode = os.environ.get("FENAPACK_AMD_SUITE_CHILDREN")
+    if mode in ("sequential", "together"):
+        together = mode == "together"
     want = list(cmds) if together else [only]
     env = dict(os.environ)
     for k in ("FENAPACK_AMD_NO_WATCHDOG", "PCD_REPLICATE_BELOW"):
