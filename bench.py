@@ -358,11 +358,8 @@ def main():
         default_inner_options(a00_its=args.a00_its, a00_ratio=args.a00_ratio,
                               ap_rtol=args.ap_rtol, ap_its=args.ap_its,
                               mp_its=args.mp_its, dim=V.dim)
-    if args.inner == "jacobi":
-        # CG with a single reduction per iteration (-ksp_cg_single_reduction):
-        # several ranks: one 2-double all-reduce per iteration; one rank: the
-        # whole iteration in ONE launch where the operator lives in L2
-        # (k_cgsr_fused), the two-launch form beyond
+    if args.inner == "jacobi" and args.gpus > 1:
+        # several ranks: CG with one 2-double all-reduce per iteration
         PETScOptions.set("fieldsplit_p_PCD_Ap_ksp_cg_single_reduction", "true")
     if args.smooth_p is not None:
         PETScOptions.set("fieldsplit_p_PCD_Ap_mg_levels_ksp_max_it",
@@ -836,10 +833,9 @@ def kernels_sha16():
 
 def cg_iteration_block(eng, pcd, V, nnz_ap, x, np_loc, nu_loc, world, k_a,
                        args):
-    """Per-iteration cost of the Jacobi-PCG on Ap as the engine runs it (the
-    single-reduction form; one rank: ONE launch per iteration where the
-    operator lives in L2 - k_cgsr_fused -, two beyond; wave64 shuffles +
-    fixed-order partials, no atomics; several ranks: ONE all-reduce of two
+    """Per-iteration cost of the Jacobi-PCG on Ap as the engine runs it (one
+    rank: k_cg_spmv_s + k_cg_update, wave64 shuffles + fixed-order partials,
+    no atomics; several ranks: the single-reduction form, ONE all-reduce of two
     doubles per iteration): launches, microseconds, SURVEY 8(d)'s B_cg over
     that time against 8 TB/s, and - when a counter pass on these kernel
     sources is committed - the PMC traffic of one iteration."""
@@ -883,8 +879,7 @@ def cg_iteration_block(eng, pcd, V, nnz_ap, x, np_loc, nu_loc, world, k_a,
         "note": "fixed iteration counts %d and %d, rtol 0 (no host check "
                 "inside); the tolerance-driven solve reads a 4-byte flag "
                 "every 32 iterations (16 with ranks) and is not captured "
-                "into the hipGraph; PCD_CGSR_FUSED_ROWS=0 is the two-launch "
-                "form" % (m_lo, m_hi),
+                "into the hipGraph" % (m_lo, m_hi),
     }
     if world > 1:
         out["allreduces_and_halos_per_iteration"] = \

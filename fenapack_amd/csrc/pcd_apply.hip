@@ -578,12 +578,9 @@ int inner_prepare(Engine* h, int slot) {
       break;
     case PCD_KSP_CG_SR:
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n)); CHK(s.t2.ensure(n));
-      CHK(s.t3.ensure(n)); CHK(s.t4.ensure(n)); CHK(s.parts.ensure(4 * kMaxParts));
+      CHK(s.t3.ensure(n)); CHK(s.t4.ensure(n)); CHK(s.parts.ensure(3 * kMaxParts));
       CHK(s.slots.ensure(4));
       CHK(s.state.ensure(2));
-      if (cgsr_fused_rows() >= n && !h->comm) {        // (the one-launch iteration: second set of r, w, s)
-        CHK(s.t5.ensure(n)); CHK(s.t6.ensure(n)); CHK(s.t7.ensure(n));
-      }
       break;
     case PCD_KSP_CHEBYSHEV:
       CHK(s.t0.ensure(n)); CHK(s.t1.ensure(n));
@@ -816,61 +813,11 @@ int solve_cg(Engine* h, const DCsr& A, Inner& s, const double* b,
   return 0;
 }
 
-// One rank, an operator that lives in L2: the whole iteration of the
-// single-reduction CG in ONE launch (k_cgsr_fused) - update of iteration k and
-// SpMV + dots of iteration k + 1, z recomputed where it is gathered.
-// PCD_CGSR_FUSED_ROWS: the largest operator it takes (default 300 000 rows; 0:
-// never).  Level 6 (n_p 103 041): 14.2 us (two launches, classic CG) -> one
-// launch per iteration.
-int64_t cgsr_fused_rows() {
-  const char* e = getenv("PCD_CGSR_FUSED_ROWS");
-  return e ? atoll(e) : 300000;
-}
-
-int solve_cg_sr_fused(Engine* h, const DCsr& A, Inner& s, const double* b, double* x) {
-  const int n = (int)A.nrows;
-  const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
-  double* R[2] = {s.t0.p, s.t5.p};
-  double* W[2] = {s.t4.p, s.t6.p};
-  double* S[2] = {s.t3.p, s.t7.p};
-  double *z = s.t1.p, *p = s.t2.p;
-  double* PB[2] = {s.parts.p, s.parts.p + 2 * kMaxParts};
-  double* PD[2] = {s.parts.p + kMaxParts, s.parts.p + 3 * kMaxParts};
-  CgState* st = s.state.p;
-  const int ge = grid1d(n, 4, kMaxParts);
-  const int gs = grid_rows(n, A.lpr, kMaxParts);
-  // x = 0, r = b, z = D^-1 r; s_0 = A z_0 and the first dots: the two-launch
-  // form's kernels (state record 0)
-  hipLaunchKernelGGL(k_cgsr_init, dim3(ge), dim3(kBlock), 0, h->stream, n, dinv, b, x, R[0], z, st);
-  LAUNCH_LPR(A, k_cgsr_spmv_dots, gs, n, A.rowptr.p, A.col.p, A.val.p, z, R[0], S[0], PB[0], PD[0], st,
-             (const double*)nullptr, n);
-  const int check = 32;
-  int it = 0;
-  for (; it < s.max_it; ++it) {
-    const int i0 = it & 1, i1 = (it + 1) & 1;
-    LAUNCH_LPR(A, k_cgsr_fused, gs, n, A.rowptr.p, A.col.p, A.val.p, dinv, R[i0], R[i1], W[i0], W[i1],
-               S[i0], S[i1], p, x, PB[i0], PD[i0], gs, PB[i1], PD[i1], s.rtol, it, st + i0, st + i1);
-    if (s.rtol > 0.0 && (it % check) == check - 1 && it + 1 < s.max_it) {
-      CHK(ensure_pinned(h, 8));
-      int* flag = reinterpret_cast<int*>(h->pinned);
-      HIPCHK(hipMemcpyAsync(flag, &(st + i1)->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      if (*flag) { ++it; break; }
-    }
-  }
-  HIPCHK(hipGetLastError());
-  s.its_on_device = true;
-  s.state_idx = it & 1;                  // the record the last launch wrote
-  return 0;
-}
-
 // [ext PETSc] KSPCG with -ksp_cg_single_reduction: per iteration one SpMV
 // fused with both dot products, (several ranks: ONE all-reduce of two
 // doubles,) one kernel with every vector update.
 int solve_cg_sr(Engine* h, const DCsr& A, Inner& s, const double* b,
                        double* x) {
-  if (!h->comm && s.t5.p && (int64_t)A.nrows <= cgsr_fused_rows() && s.t5.n >= (size_t)A.nrows)
-    return solve_cg_sr_fused(h, A, s, b, x);
   const int n = (int)A.nrows;
   const double* dinv = (s.pc == PCD_PC_JACOBI) ? A.dinv.p : nullptr;
   double *r = s.t0.p, *z = s.t1.p, *p = s.t2.p, *sv = s.t3.p, *w = s.t4.p;

@@ -299,8 +299,7 @@ struct Inner {
   bool chain_stale = false;          // the operator changed after composition
   // device scratch, sized at setup
   DBuf<double> t0, t1, t2, t3, t4;   // r,z,p,q,p'  or the Chebyshev ring
-  DBuf<double> t5, t6, t7;           // the second set of r, w, s of the one-launch CG iteration
-  DBuf<double> parts;                // 4 * kMaxParts
+  DBuf<double> parts;                // 3 * kMaxParts
   DBuf<double> slots;                // rank-reduced scalars (multi-GPU)
   DBuf<CgState> state;
   std::vector<Space> mg_space;       // multi-GPU: row space of every level
@@ -311,7 +310,6 @@ struct Inner {
   int state_idx = 0;                 // which of the two state records is final
   void release() {
     t0.release(); t1.release(); t2.release(); t3.release(); t4.release();
-    t5.release(); t6.release(); t7.release();
     parts.release(); slots.release(); state.release();
     for (auto& l : mg) l.release();
     mg.clear();
@@ -571,7 +569,6 @@ int spmv_other_values(Engine* h, DCsr& A, double*& other, const double* x, doubl
 int refresh_dinv(Engine* h, DCsr& A);
 int build_cheb_patch(Engine* h, DCsr& A, int m);
 int inner_prepare(Engine* h, int slot);
-int64_t cgsr_fused_rows();             // largest operator of the one-launch CG iteration (PCD_CGSR_FUSED_ROWS)
 int launch_cheb_step(Engine* h, const DCsr& A, const double* dinv,
                             const double* b, const double* pm, const double* pk,
                             double* pn, double c0, double c1, double c2);

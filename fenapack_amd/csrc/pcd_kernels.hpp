@@ -325,107 +325,6 @@ static __global__ __launch_bounds__(kBlock) void k_cgsr_update(
   }
 }
 
-// ---- ... and a single LAUNCH per iteration (round 6) ------------------------
-// The update of iteration k and the SpMV + dot products of iteration k + 1 in
-// ONE kernel.  The SpMV needs z_{k+1} at every gathered column, i.e. vectors
-// other workgroups are updating in the same launch; instead of waiting for
-// them, z_{k+1}[c] = D^-1[c] (r_k[c] - a (s_k[c] + b w_{k-1}[c])) is RECOMPUTED
-// on the fly from the vectors of iteration k, which this launch only reads:
-// r, w and s are double-buffered (read the `_in`, write the `_out` set), so are
-// the partial sums and the state record; p and x are touched by their own rows
-// only.  Same recurrences, same expressions per element (cgsr_znew is the one
-// place z is formed) as k_cgsr_spmv_dots + k_cgsr_update: the iterates agree to
-// rounding.  Four gathered vectors per entry instead of one - for operators
-// that live in L2 (the pressure Laplacian of the 2-D cavity: 8.6 MB), where an
-// iteration is bound by its dependent LAUNCHES (two of them: 14.2 us at level
-// 6), not by bytes; larger operators keep the two-launch forms.
-struct CgsrZ {
-  const double *r, *sv, *w, *dinv;
-  double a, bb;
-  int first;
-  __device__ __forceinline__ double operator()(int c) const {
-    const double wi = first ? sv[c] : sv[c] + bb * w[c];
-    const double ri = r[c] - a * wi;
-    return dinv ? dinv[c] * ri : ri;
-  }
-};
-
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void k_cgsr_fused(
-    int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const double* __restrict__ val, const double* __restrict__ dinv,
-    const double* r_in, double* r_out, const double* w_in, double* w_out,
-    const double* sv_in, double* sv_out, double* p, double* x,
-    const double* pb, const double* pd, int nparts, double* pb_out, double* pd_out,
-    double rtol, int it, const CgState* st_in, CgState* st_out) {
-  __shared__ double sm[4];
-  if (st_in->done) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *st_out = *st_in;
-    return;
-  }
-  const double beta = reduce_parts(pb, nparts, sm);
-  const double delta = reduce_parts(pd, nparts, sm);
-  const double beta0 = it == 0 ? beta : st_in->rz0;
-  const bool conv = (beta == 0.0) ||
-      (rtol > 0.0 && sqrt(fabs(beta)) <= rtol * sqrt(fabs(beta0)));
-  if (conv) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      *st_out = *st_in; st_out->rz0 = beta0; st_out->its = it; st_out->done = 1;
-    }
-    return;
-  }
-  double bb = 0.0, dpi = delta;
-  if (it > 0) {
-    const double bo = st_in->betaold;
-    bb = beta / bo;
-    dpi = delta - beta * beta * st_in->dpiold / (bo * bo);
-  }
-  if (!(dpi > 0.0) || !isfinite(dpi)) {          // (as k_cgsr_update: stop, its = -(it + 1))
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      *st_out = *st_in; st_out->rz0 = beta0; st_out->its = -(it + 1); st_out->done = 1;
-    }
-    return;
-  }
-  const double a = beta / dpi;
-  const CgsrZ zf{r_in, sv_in, w_in, dinv, a, bb, it == 0};
-  constexpr int RPB = kBlock / LPR;
-  const int lane = threadIdx.x % LPR;
-  const int nloop = (nrows + RPB - 1) / RPB * RPB;
-  double ab = 0.0, ad = 0.0;
-  for (int row = blockIdx.x * RPB + threadIdx.x / LPR; row < nloop; row += gridDim.x * RPB) {
-    // s_{k+1}[row] = (A z_{k+1})[row], z_{k+1} formed where it is gathered
-    double s = 0.0;
-    if (row < nrows) {
-      const int b = rowptr[row], e = rowptr[row + 1];
-      for (int k = b + lane; k < e; k += LPR) s += val[k] * zf(col[k]);
-    }
-#pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LPR);
-    if (lane == 0 && row < nrows) {
-      const double ro = r_in[row];
-      const double zo = dinv ? dinv[row] * ro : ro;          // z_k[row], as it was stored
-      const double pi = it > 0 ? zo + bb * p[row] : zo;
-      const double wi = it > 0 ? sv_in[row] + bb * w_in[row] : sv_in[row];
-      p[row] = pi; w_out[row] = wi;
-      x[row] += a * pi;
-      const double ri = ro - a * wi;
-      r_out[row] = ri;
-      const double zi = dinv ? dinv[row] * ri : ri;
-      sv_out[row] = s;
-      ab += zi * ri; ad += zi * s;
-    }
-  }
-  ab = block_sum(ab, sm);
-  ad = block_sum(ad, sm);
-  if (threadIdx.x == 0) {
-    pb_out[blockIdx.x] = ab; pd_out[blockIdx.x] = ad;
-    if (blockIdx.x == 0) {
-      st_out->rz0 = beta0; st_out->its = it + 1; st_out->done = 0;
-      st_out->betaold = beta; st_out->dpiold = dpi;
-    }
-  }
-}
-
 // ==========================================================================
 // CSR-stream kernels (the fast path).  One workgroup owns RB consecutive rows.
 // Phase 1 streams that row block's val/col arrays with unit-stride lanes

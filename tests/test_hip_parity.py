@@ -421,55 +421,3 @@ def test_single_reduction_cg_vs_oracle(hip_lib):
     e.set_inner(c.KSP_AP, "cg", "jacobi", 5000, 1e-10)
     e.set_inner(c.KSP_MP, "cg", "jacobi", 200, 1e-12)
     assert relerr(y1, e.apply_np(xp)) < 1e-7
-
-
-def test_single_reduction_cg_in_one_launch_per_iteration(hip_lib, monkeypatch):
-    """One rank, an operator that lives in L2: the whole iteration of the
-    single-reduction CG is ONE launch (k_cgsr_fused: the update of iteration k
-    and the SpMV + dots of iteration k + 1, z recomputed where it is gathered)
-    - against the two-launch form (PCD_CGSR_FUSED_ROWS=0) and the oracle's
-    restatement, fixed counts and tolerance-driven, and by launch count."""
-    st = flow_state("cavity", 4)
-    V = st["V"]
-    rng = np.random.default_rng(7)
-    b = rng.standard_normal(V.n_p)
-    o = oracle.Engine("BRM1")
-    configure_engine(o, st)
-    eng = {}
-    for mode, rows in (("fused", None), ("two", "0")):
-        if rows is None:
-            monkeypatch.delenv("PCD_CGSR_FUSED_ROWS", raising=False)
-        else:
-            monkeypatch.setenv("PCD_CGSR_FUSED_ROWS", rows)
-        e = hip_engine(hip_lib, "BRM1")
-        configure_engine(e, st)
-        e.set_inner(c.KSP_AP, "cgsr", "jacobi", 3, 0.0)
-        e.setup()                                   # (buffers are sized here)
-        eng[mode] = e
-    for its in (1, 2, 3, 10, 33, 64, 65):
-        out = {}
-        for mode, e in eng.items():
-            e.set_inner(c.KSP_AP, "cgsr", "jacobi", its, 0.0)
-            e.inner_solve_np(c.KSP_AP, b)
-            l0 = e.info(c.INFO_LAUNCHES)
-            out[mode] = e.inner_solve_np(c.KSP_AP, b)
-            out[mode + "_launches"] = e.info(c.INFO_LAUNCHES) - l0
-            assert int(e.info(c.INFO_ITS_AP)) == its, (mode, its)
-        o.set_inner(c.KSP_AP, "cgsr", "jacobi", its, 0.0)
-        o.setup()
-        ref = o.inner_solve_np(c.KSP_AP, b)
-        assert relerr(out["fused"], ref) < 1e-11, its
-        assert relerr(out["two"], ref) < 1e-11, its
-        assert relerr(out["fused"], out["two"]) < 1e-12, its
-        # init + first SpMV + one launch per iteration against init + two
-        assert out["fused_launches"] == 2 + its, (its, out)
-        assert out["two_launches"] >= 1 + 2 * its, (its, out)
-    got = {}
-    for mode, e in eng.items():
-        e.set_inner(c.KSP_AP, "cgsr", "jacobi", 5000, 1e-10)
-        got[mode] = (e.inner_solve_np(c.KSP_AP, b), int(e.info(c.INFO_ITS_AP)))
-    o.set_inner(c.KSP_AP, "cgsr", "jacobi", 5000, 1e-10)
-    o.setup()
-    ref, kref = o.inner_solve_np(c.KSP_AP, b), int(o.info(c.INFO_ITS_AP))
-    assert abs(got["fused"][1] - kref) <= 1 and abs(got["two"][1] - kref) <= 1
-    assert relerr(got["fused"][0], ref) < 1e-7

@@ -58,9 +58,6 @@ if a.inner == "mg":
 else:
     from fenapack_amd.driver import default_inner_options              # noqa
     default_inner_options(a00_its=a.a00_its, a00_ratio=a.a00_ratio, dim=V.dim)
-    # (bench.py --inner jacobi: the single-reduction CG, one launch per
-    # iteration on one rank where the operator lives in L2)
-    PETScOptions.set("fieldsplit_p_PCD_Ap_ksp_cg_single_reduction", "true")
 w, nls, nlp = make_solver(pb, gmres_rtol=1e-6, restart=150, newton_rtol=1e-5,
                           max_newton=2)
 nls.parameters["error_on_nonconvergence"] = False
@@ -86,7 +83,7 @@ else:
     # (4) the Jacobi-PCG iteration on Ap: 10 solves of 40 iterations, rtol 0
     pcd = ksp.pc.getFieldSplitSubKSP()[1].pc.getPythonContext()
     bp, xp = rng.standard_normal(V.n_p), np.empty(V.n_p)
-    eng.set_inner(c.KSP_AP, "cgsr", "jacobi", 40, 0.0)
+    eng.set_inner(c.KSP_AP, "cg", "jacobi", 40, 0.0)
     for _ in range(10):
         eng.inner_solve(c.KSP_AP, bp, xp)
     pcd.ksp_Ap.push_settings()

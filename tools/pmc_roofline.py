@@ -113,18 +113,11 @@ def main():
     # (5) the Jacobi-PCG iteration (pmc_pcapply.py --inner jacobi, stage 4):
     # k_cg_spmv_s + k_cg_update of the fixed-count solves on Ap
     cg = None
-    fused = [i for i, r in enumerate(F) if r[1].startswith("k_cgsr_fused")]
     upd = [i for i, r in enumerate(F) if r[1] == "k_cg_update"]
-    if fused:
-        # the one-launch iteration of the single-reduction CG
-        tr = sum(corr * F[i][3] + W[i][3] for i in fused)
-        ns = sum(0.5 * (F[i][4] + W[i][4]) for i in fused)
-        cg = {"kernels": sorted({F[i][1] for i in fused}),
-              "iterations_counted": len(fused), "launches_per_iteration": 1,
-              "traffic_bytes_per_iteration": tr / len(fused),
-              "us_per_iteration_under_the_counter_pass": ns / len(fused) / 1e3}
-    elif upd:
+    if upd:
         big_u = max(F[i][2] for i in upd)
+        # the standalone solves ran 40 iterations each: take their launches
+        # (largest run of consecutive spmv / update pairs)
         sp_ = [i for i, r in enumerate(F) if r[1].startswith("k_cg_spmv")]
         pair = [i for i in sp_ if i + 1 < len(F) and F[i + 1][1] == "k_cg_update"]
         n_it = len(pair)
